@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X separation hot path (BASELINE.json metric: spectrogram-frames/s,
+DSD100 4-source model, frameSize=2048 hop=512).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the whole hot path (STFT -> x0.3 -> tiles -> conv encoder/decoder ->
+soft mask -> cross-fade overlap-add -> /0.3 -> iSTFT -> truncate) over one batch of 32 tiles
+(BASELINE.json configs[1]: "DSD100 4-source separate_dsd.py, batch=32 tiles, fp32, 1xMI355X"),
+i.e. 2.14 s of synthetic 44.1 kHz audio already resident in HBM, producing 4 PCM signals in
+HBM.  With N GPUs every rank separates its own 32-tile batch (weak scaling, configs[2]) and
+the PCM of all ranks is all-gathered over RCCL inside the timed region.
+
+Rank 0 prints ONE JSON line.  `roofline` refers to the dominant kernel (transposed conv1 +
+bias + rectify + soft mask + cross-fade), timed with HIP events inside the timed region;
+`cpu_baseline` is the CPU oracle (reference-equivalent NumPy + torch-CPU float64 path) timed
+on this host; `saturating` repeats the measurement on a long clip (4096 tiles, 3 min 58 s) where
+the chip is full -- the 32-tile step is launch/latency-bound (DESIGN.md "measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HOP, TC, OV, SCALE, SR = 512, 30, 25, 0.3, 44100
+PEAK_F32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
+
+
+def samples_for_tiles(n_tiles):
+    """Shortest signal (whole hops) whose script tiling (separate_dsd.py:123) yields n_tiles."""
+    frames = TC + 1 + (n_tiles - 1) * (TC - OV)
+    return (frames - 2) * HOP
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--tiles", type=int, default=32, help="tiles per GPU per step (BASELINE configs[1]: 32)")
+    ap.add_argument("--frame-size", type=int, default=2048)
+    ap.add_argument("--sat-tiles", type=int, default=4096, help="tiles of the saturating extra run (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs; there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import deepconvsep_amd as dcs
+    from deepconvsep_amd import _lib
+    from deepconvsep_amd.arch import ARCHS, TILER_SCRIPT
+    from deepconvsep_amd.synth import synth_audio, synth_params
+
+    N = args.frame_size
+    F = N // 2 + 1
+    params = synth_params("dsd", TC, F, seed=2)
+    sep = dcs.Separator("dsd", params, SCALE, TC, OV, 32, F, N, HOP, np.hanning)
+    ctx, net, plan = sep.ctx, sep.net, sep.plan
+
+    L = samples_for_tiles(args.tiles)
+    audio_h = synth_audio(L, seed=100 + rank)
+    audio = ctx.to_device(audio_h, np.float32)
+    T = _lib.frame_count(L, HOP)
+    n_tiles = _lib.tile_count(T, TC, OV, TILER_SCRIPT)
+    assert n_tiles == args.tiles, (n_tiles, args.tiles)
+    frames_per_step = (n_tiles - 1) * (TC - OV) + TC        # unique frames fully separated
+    pcm = torch.empty((4, L), dtype=torch.float32, device=audio.device)
+    gathered = torch.empty((world * 4, L), dtype=torch.float32, device=audio.device) if world > 1 else None
+
+    def step():
+        net.separate(plan, audio, OV, TILER_SCRIPT, SCALE, out=pcm)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, pcm)      # RCCL over xGMI: the final gather
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timing(["final"])
+    ctx.timing_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    final_ms, final_launches = ctx.timing_query("final")
+    ctx.timing(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=audio.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    value = world * frames_per_step * args.steps / elapsed
+
+    # ---- per-kernel breakdown (separate instrumented pass, not part of `value`)
+    kernels_ms = {}
+    ctx.timing("all")
+    ctx.timing_reset()
+    for _ in range(min(args.steps, 20)):
+        net.separate(plan, audio, OV, TILER_SCRIPT, SCALE, out=pcm)
+    for tag in _lib.TAGS:
+        ms, cnt = ctx.timing_query(tag)
+        if cnt:
+            kernels_ms[tag] = round(ms, 5)
+    ctx.timing(None)
+
+    # algorithmic FLOPs of the dominant kernel: transposed conv1 of the 3 live branches
+    # (separate_dsd.py:212,218,224): per tile 3 * 2 * tc * 50 * F  (DESIGN.md "roofline")
+    final_flops_tile = 3 * 2 * TC * 50 * F
+    def roof(n, ms):
+        ach = n * final_flops_tile / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"bound": "mfma", "kernel": "final_kernel<fold> (deconv1+bias+relu+mask+crossfade)",
+                "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                "avg_kernel_ms": round(ms, 5), "launches": int(final_launches)}
+    roofline = roof(n_tiles, final_ms)
+
+    # ---- saturating regime (extra): same path, long clip
+    saturating = None
+    if args.sat_tiles and rank == 0:
+        Ls = samples_for_tiles(args.sat_tiles)
+        a2 = ctx.to_device(synth_audio(Ls, seed=7), np.float32)
+        out2 = torch.empty((4, Ls), dtype=torch.float32, device=a2.device)
+        for _ in range(2):
+            net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
+        ctx.timing("all")
+        ctx.timing_reset()
+        torch.cuda.synchronize()
+        k2 = 10
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t0
+        fr2 = (args.sat_tiles - 1) * (TC - OV) + TC
+        sat_k = {}
+        for tag in _lib.TAGS:
+            ms, cnt = ctx.timing_query(tag)
+            if cnt:
+                sat_k[tag] = round(ms, 5)
+        ctx.timing(None)
+        r2 = roof(args.sat_tiles, sat_k.get("final", 0.0))
+        r2["launches"] = k2
+        total_flops = args.sat_tiles * ARCHS["dsd"].flops_per_tile(TC, F)
+        saturating = {"tiles": args.sat_tiles, "audio_seconds": round(Ls / SR, 2), "value": round(fr2 * k2 / e2, 1),
+                      "unit": "frames/s", "x_realtime": round(fr2 * k2 / e2 * HOP / SR, 1),
+                      "ms_per_step": round(e2 / k2 * 1e3, 4), "roofline": r2, "kernels_ms": sat_k,
+                      "whole_path_algorithmic_tflops": round(total_flops * k2 / e2 / 1e12, 2)}
+        del a2, out2
+    if world > 1:
+        dist.barrier()
+
+    # ---- CPU baseline: the oracle on this host's cores, same 32-tile batch (rank 0, N=1 only)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pipeline
+        torch.set_num_threads(os.cpu_count() or 1)
+        pipeline.separate("dsd", params, audio_h, SCALE, TC, OV, 32, N, HOP, np.hanning)   # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            pipeline.separate("dsd", params, audio_h, SCALE, TC, OV, 32, N, HOP, np.hanning)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= 10.0 or reps >= 200:
+                break
+        cpu_baseline = {"value": round(frames_per_step * reps / el, 1), "unit": "frames/s",
+                        "cores": int(torch.get_num_threads()), "kind": "port",
+                        "sample": "%d x the same 32-tile / %.2f s batch through oracle.pipeline.separate "
+                                  "(reference NumPy STFT/tiling/overlap-add loops + torch-CPU float64 network; "
+                                  "Theano/Lasagne unavailable), %.1f s of CPU time, host cpu_count=%d"
+                                  % (reps, L / SR, el, os.cpu_count() or 0)}
+
+    if rank == 0:
+        line = {
+            "metric": "spectrogram-frames/s", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "x_realtime": round(value * HOP / SR, 1),
+            "config": {"workload": "DSD100 4-source separate_dsd path (BASELINE configs[1]): frameSize=%d hop=512 "
+                                   "hann, time_context=30 overlap=25 scale=0.3, one batch of %d tiles = %.2f s of "
+                                   "44.1 kHz audio per GPU per step, STFT->net->mask->overlap-add->iSTFT, "
+                                   "input and output resident in HBM%s"
+                                   % (N, n_tiles, L / SR, ", PCM all-gathered over RCCL" if world > 1 else ""),
+                       "tiles_per_gpu_per_step": n_tiles, "frames_per_gpu_per_step": frames_per_step,
+                       "frame_size": N, "bins": F, "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",
+                       "parallelism": "tiles sharded by rank (dp%d)" % world},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_ms": kernels_ms, "saturating": saturating,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""Static descriptions of the reference's ``build_ca`` graphs.
+
+Each entry states what the reference builds with Lasagne for one separation
+script; the HIP model (``csrc/``) is instantiated from it.
+
+  dsd / hiphop  examples/dsd100/separate_dsd.py:172-236  (hiphopss/separate_hhds.py:171-235)
+  ikala         examples/ikala/separate_ikala.py:172-192   (max-pool variant)
+  bach10        examples/bach10/separate_bach10.py:172-229
+  bach10_si     examples/bach10_scoreinformed/separate_bach10.py:388-447
+"""
+import numpy as np
+
+# enum values shared with include/dcs.h
+ARCH_DSD, ARCH_IKALA, ARCH_BACH10, ARCH_BACH10_SI = 0, 1, 2, 3
+EPS_A, EPS_B = 0, 1
+TIE_ALL, TIE_FIRST = 0, 1
+TILER_SCRIPT, TILER_LIBRARY = 0, 1
+
+
+class Arch(object):
+    def __init__(self, name, code, in_channels, conv1, pool_w, conv2, hidden, branch_fc,
+                 n_sources, eps_mode, source_names):
+        self.name = name
+        self.code = code
+        self.C = in_channels
+        self.conv1 = conv1            # (filters, kernel width or 'F', stride along frequency)
+        self.pool_w = pool_w          # 0 = no pooling layer
+        self.conv2 = conv2            # (filters, kernel height fn(tc), kernel width)
+        self.hidden = hidden
+        self.branch_fc = list(branch_fc)
+        self.n_fc = max(branch_fc) + 1
+        self.S = n_sources
+        self.eps_mode = eps_mode
+        self.source_names = source_names
+
+    def dims(self, tc, F):
+        nf1, kw1, sw1 = self.conv1
+        kw1 = F if kw1 == 'F' else kw1
+        w1 = (F - kw1) // sw1 + 1
+        wp = w1 // self.pool_w if self.pool_w else w1
+        nf2, kh2, kw2 = self.conv2
+        kh2 = kh2(tc)
+        h2, w2 = tc - kh2 + 1, wp - kw2 + 1
+        return dict(nf1=nf1, kw1=kw1, sw1=sw1, w1=w1, wp=wp, nf2=nf2, kh2=kh2, kw2=kw2,
+                    h2=h2, w2=w2, flat=nf2 * h2 * w2)
+
+    def param_shapes(self, tc, F):
+        """Shapes in ``lasagne.layers.get_all_params`` order = the ``.pkl`` order."""
+        d = self.dims(tc, F)
+        shapes = [(d['nf1'], self.C, 1, d['kw1']), (d['nf1'],), (d['nf1'],),
+                  (d['nf2'], d['nf1'], d['kh2'], d['kw2']), (d['nf2'],), (d['nf2'],),
+                  (d['flat'], self.hidden), (self.hidden,)]
+        for _ in range(self.n_fc):
+            shapes += [(self.hidden, d['flat']), (d['flat'],)]
+        shapes.append((len(self.branch_fc) * self.C,))
+        return shapes
+
+    def flops_per_tile(self, tc, F):
+        """Algorithmic multiply-add FLOPs of one tile through the reference graph
+        (every output branch computed, as Theano does for the aliased DSD branch only once)."""
+        d = self.dims(tc, F)
+        conv1 = 2 * d['nf1'] * self.C * d['kw1'] * tc * d['w1']
+        conv2 = 2 * d['nf2'] * d['nf1'] * d['kh2'] * d['kw2'] * d['h2'] * d['w2']
+        fc = 2 * d['flat'] * self.hidden
+        nb = self.n_fc
+        return conv1 + conv2 + fc + nb * (fc + conv2 + conv1)
+
+
+ARCHS = {
+    'dsd': Arch('dsd', ARCH_DSD, 1, (50, 'F', 1), 0, (50, lambda tc: int(tc / 2), 1), 128,
+                [0, 1, 2, 1], 4, EPS_A, ['vocals', 'bass', 'drums', 'other']),
+    'ikala': Arch('ikala', ARCH_IKALA, 1, (30, 30, 3), 4, (30, lambda tc: 10, 20), 256,
+                  [0, 1], 2, EPS_A, ['voice', 'music']),
+    'bach10': Arch('bach10', ARCH_BACH10, 1, (30, 30, 4), 0, (30, lambda tc: int(2 * tc / 3), 1), 256,
+                   [0, 1, 2, 3], 4, EPS_B, ['bassoon', 'clarinet', 'saxphone', 'violin']),
+    'bach10_si': Arch('bach10_si', ARCH_BACH10_SI, 4, (30, 30, 4), 0,
+                      (30, lambda tc: int(2 * tc / 3), 1), 256, [0, 1, 2, 3], 4, EPS_B,
+                      ['bassoon', 'clarinet', 'saxphone', 'violin']),
+}
+ARCHS['hiphop'] = ARCHS['dsd']
+
+
+def check_params(arch, params, tc, F):
+    """Same failure behaviour as ``lasagne.layers.set_all_param_values``
+    (separate_dsd.py:250): ValueError on a count or shape mismatch."""
+    shapes = arch.param_shapes(tc, F)
+    if len(params) != len(shapes):
+        raise ValueError("mismatch: got %d values to set %d parameters" % (len(params), len(shapes)))
+    for p, s in zip(params, shapes):
+        if tuple(np.shape(p)) != tuple(s):
+            raise ValueError("mismatch: parameter has shape %r but value to set has shape %r"
+                             % (tuple(s), tuple(np.shape(p))))

@@ -1,0 +1,298 @@
+// C-ABI entry points that are not tied to the network: context, framing integers, STFT plan,
+// tiling.  (Network + fused path: net.hip.)
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "dcs_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void dcs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* dcs_last_error(void) { return g_err; }
+extern "C" int dcs_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------- buffers / timing
+int DcsBuffer::ensure(size_t need) {
+    if (need <= bytes) return DCS_OK;
+    if (ptr) {
+        // other work on the stream may still read the old block
+        (void)hipDeviceSynchronize();
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    size_t want = need + need / 8;
+    DCS_HIP(hipMalloc(&ptr, want));
+    bytes = want;
+    return DCS_OK;
+}
+
+void DcsBuffer::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+DcsTimer::DcsTimer(dcs_ctx* c, int t) : ctx(c), tag(t), idx(0), on((c->timing_mask >> t) & 1u) {
+    if (!on) return;
+    DcsTimingSlot& s = ctx->slots[tag];
+    if (s.used == s.start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        s.start.push_back(a);
+        s.stop.push_back(b);
+    }
+    idx = s.used++;
+    (void)hipEventRecord(s.start[idx], ctx->stream);
+}
+
+void DcsTimer::done() {
+    if (on) (void)hipEventRecord(ctx->slots[tag].stop[idx], ctx->stream);
+}
+
+extern "C" int dcs_timing_enable(dcs_ctx* ctx, unsigned tag_mask) {
+    if (!ctx) DCS_FAIL(DCS_EINVAL, "dcs_timing_enable: null ctx");
+    ctx->timing_mask = tag_mask;
+    return DCS_OK;
+}
+
+extern "C" int dcs_timing_reset(dcs_ctx* ctx) {
+    if (!ctx) DCS_FAIL(DCS_EINVAL, "dcs_timing_reset: null ctx");
+    for (auto& s : ctx->slots) s.used = 0;
+    return DCS_OK;
+}
+
+extern "C" int dcs_timing_query(dcs_ctx* ctx, int which, double* avg_ms, int64_t* launches) {
+    if (!ctx || which < 0 || which >= DCS_TAG_COUNT) DCS_FAIL(DCS_EINVAL, "dcs_timing_query: bad argument");
+    DCS_HIP(hipStreamSynchronize(ctx->stream));
+    DcsTimingSlot& s = ctx->slots[which];
+    double total = 0.0;
+    for (size_t i = 0; i < s.used; ++i) {
+        float ms = 0.f;
+        DCS_HIP(hipEventElapsedTime(&ms, s.start[i], s.stop[i]));
+        total += ms;
+    }
+    if (avg_ms) *avg_ms = s.used ? total / (double)s.used : 0.0;
+    if (launches) *launches = (int64_t)s.used;
+    return DCS_OK;
+}
+
+// ------------------------------------------------------------------------------- context
+extern "C" int dcs_create(int device, void* hip_stream, dcs_ctx** out) {
+    if (!out) DCS_FAIL(DCS_EINVAL, "dcs_create: out is null");
+    int count = 0;
+    DCS_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) DCS_FAIL(DCS_EINVAL, "dcs_create: device %d of %d", device, count);
+    DCS_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    DCS_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        DCS_FAIL(DCS_EUNSUPPORTED, "dcs_create: device %d is %s; libdcs is built for gfx950 only", device,
+                 prop.gcnArchName);
+    dcs_ctx* c = new dcs_ctx();
+    c->device = device;
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return DCS_OK;
+}
+
+extern "C" int dcs_destroy(dcs_ctx* ctx) {
+    if (!ctx) return DCS_OK;
+    for (auto& s : ctx->slots) {
+        for (auto e : s.start) (void)hipEventDestroy(e);
+        for (auto e : s.stop) (void)hipEventDestroy(e);
+    }
+    delete ctx;
+    return DCS_OK;
+}
+
+extern "C" int dcs_synchronize(dcs_ctx* ctx) {
+    if (!ctx) DCS_FAIL(DCS_EINVAL, "dcs_synchronize: null ctx");
+    DCS_HIP(hipStreamSynchronize(ctx->stream));
+    return DCS_OK;
+}
+
+// ------------------------------------------------------------------------------- framing integers
+extern "C" int64_t dcs_frame_count(int64_t n_samples, int hop) {
+    if (hop <= 0 || n_samples < 0) return -1;
+    // int(np.ceil(lengthData / np.double(hopsize)) + 2)        transform.py:309
+    return (n_samples + hop - 1) / hop + 2;
+}
+
+extern "C" int64_t dcs_inverse_length(int64_t n_frames, int hop, int frame) {
+    if (n_frames <= 0 || hop <= 0 || frame <= 0) return -1;
+    // int(hopsize*(numberFrames-1) + lengthWindow) - int(lengthWindow/2.0)   transform.py:373,390
+    return (int64_t)hop * (n_frames - 1) + frame - frame / 2;
+}
+
+extern "C" int64_t dcs_tile_count(int64_t n_frames, int tc, int ov, int tiler) {
+    if (tc <= 0 || ov < 0 || ov >= tc) return -1;
+    const int64_t guard = (tiler == DCS_TILER_SCRIPT) ? tc : ov;
+    const int64_t stride = tc - ov;
+    // tiles while start + guard < T, start = i * stride
+    if (n_frames <= guard) return 0;
+    return (n_frames - guard - 1) / stride + 1;
+}
+
+// ------------------------------------------------------------------------------- STFT plan
+extern "C" int dcs_stft_plan(dcs_ctx* ctx, int frame, int hop, const double* window_h, dcs_stft** out) {
+    if (!ctx || !window_h || !out) DCS_FAIL(DCS_EINVAL, "dcs_stft_plan: null argument");
+    if (frame < 16 || frame > 8192 || (frame & (frame - 1)))
+        DCS_FAIL(DCS_EUNSUPPORTED, "dcs_stft_plan: frameSize %d is not a power of two in [16, 8192]", frame);
+    if (hop <= 0 || hop > frame) DCS_FAIL(DCS_EINVAL, "dcs_stft_plan: hopSize %d not in (0, %d]", hop, frame);
+    DCS_HIP(hipSetDevice(ctx->device));
+    dcs_stft* p = new dcs_stft();
+    p->ctx = ctx;
+    p->frame = frame;
+    p->hop = hop;
+    int M = frame / 2, lg = 0;
+    while ((1 << lg) < M) ++lg;
+    p->log2m = lg;
+
+    std::vector<float> wf(frame), wsqf(frame);
+    std::vector<double> wsqd(frame);
+    for (int i = 0; i < frame; ++i) {
+        wf[i] = (float)window_h[i];
+        wsqd[i] = window_h[i] * window_h[i];
+        wsqf[i] = (float)wsqd[i];
+    }
+    std::vector<double2> twd(M + 1);
+    std::vector<float2> twf(M + 1);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k <= M; ++k) {
+        double a = -2.0 * pi * (double)k / (double)frame;
+        twd[k].x = cos(a);
+        twd[k].y = sin(a);
+    }
+    // exact values on the axes (keeps DC / Nyquist bins exactly real like numpy's rfft)
+    twd[0].x = 1.0; twd[0].y = 0.0;
+    twd[M].x = -1.0; twd[M].y = 0.0;
+    if (M % 2 == 0) { twd[M / 2].x = 0.0; twd[M / 2].y = -1.0; }
+    for (int k = 0; k <= M; ++k) {
+        twf[k].x = (float)twd[k].x;
+        twf[k].y = (float)twd[k].y;
+    }
+    auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+        DCS_HIP(hipMalloc(dst, bytes));
+        DCS_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return DCS_OK;
+    };
+    int rc = DCS_OK;
+    if ((rc = up((void**)&p->win_f, wf.data(), frame * sizeof(float))) ||
+        (rc = up((void**)&p->win_d, window_h, frame * sizeof(double))) ||
+        (rc = up((void**)&p->wsq_f, wsqf.data(), frame * sizeof(float))) ||
+        (rc = up((void**)&p->wsq_d, wsqd.data(), frame * sizeof(double))) ||
+        (rc = up((void**)&p->tw_f, twf.data(), (M + 1) * sizeof(float2))) ||
+        (rc = up((void**)&p->tw_d, twd.data(), (M + 1) * sizeof(double2)))) {
+        dcs_stft_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return DCS_OK;
+}
+
+extern "C" int dcs_stft_plan_destroy(dcs_stft* p) {
+    if (!p) return DCS_OK;
+    (void)hipFree(p->win_f);
+    (void)hipFree(p->win_d);
+    (void)hipFree(p->wsq_f);
+    (void)hipFree(p->wsq_d);
+    (void)hipFree(p->tw_f);
+    (void)hipFree(p->tw_d);
+    p->frames.release();
+    delete p;
+    return DCS_OK;
+}
+
+template <typename R>
+static int forward_checked(dcs_stft* p, const R* audio, int64_t L, R* mag, R* phase, int64_t ld, int64_t rows_out,
+                           int (*launch)(dcs_stft*, const R*, int64_t, R*, R*, int64_t, int64_t, int64_t)) {
+    if (!p || !mag || (!audio && L > 0)) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: null argument");
+    if (L < 0) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: negative length");
+    const int64_t T = dcs_frame_count(L, p->hop);
+    if (ld < p->frame / 2 + 1) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: ld %lld < bins %d", (long long)ld, p->frame / 2 + 1);
+    if (rows_out < T) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: rows_out %lld < frames %lld", (long long)rows_out, (long long)T);
+    return launch(p, audio, L, mag, phase, ld, rows_out, T);
+}
+
+extern "C" int dcs_stft_forward_f32(dcs_stft* p, const float* audio_d, int64_t n, float* mag_d, float* phase_d,
+                                    int64_t ld, int64_t rows_out) {
+    return forward_checked<float>(p, audio_d, n, mag_d, phase_d, ld, rows_out, dcs_launch_stft_forward_f32);
+}
+extern "C" int dcs_stft_forward_f64(dcs_stft* p, const double* audio_d, int64_t n, double* mag_d, double* phase_d,
+                                    int64_t ld, int64_t rows_out) {
+    return forward_checked<double>(p, audio_d, n, mag_d, phase_d, ld, rows_out, dcs_launch_stft_forward_f64);
+}
+
+template <typename R>
+static int inverse_checked(dcs_stft* p, const R* mag, int64_t src_stride, const R* phase, int64_t ld, int64_t T,
+                           int n_src, R pre_div, R* audio, int64_t n_out,
+                           int (*launch)(dcs_stft*, const R*, int64_t, const R*, int64_t, int64_t, int, R, R*, int64_t)) {
+    if (!p || !mag || !phase || !audio) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: null argument");
+    if (T <= 0 || n_src <= 0) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: empty input");
+    if (ld < p->frame / 2 + 1) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: ld < bins");
+    if (n_out < 0 || n_out > dcs_inverse_length(T, p->hop, p->frame))
+        DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: n_out %lld exceeds %lld", (long long)n_out,
+                 (long long)dcs_inverse_length(T, p->hop, p->frame));
+    if (pre_div == R(0)) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: pre_div is zero");
+    return launch(p, mag, src_stride, phase, ld, T, n_src, pre_div, audio, n_out);
+}
+
+extern "C" int dcs_stft_inverse_f32(dcs_stft* p, const float* mag_d, int64_t src_stride, const float* phase_d,
+                                    int64_t ld, int64_t T, int n_src, float pre_div, float* audio_d, int64_t n_out) {
+    return inverse_checked<float>(p, mag_d, src_stride, phase_d, ld, T, n_src, pre_div, audio_d, n_out,
+                                  dcs_launch_stft_inverse_f32);
+}
+extern "C" int dcs_stft_inverse_f64(dcs_stft* p, const double* mag_d, int64_t src_stride, const double* phase_d,
+                                    int64_t ld, int64_t T, int n_src, double pre_div, double* audio_d,
+                                    int64_t n_out) {
+    return inverse_checked<double>(p, mag_d, src_stride, phase_d, ld, T, n_src, pre_div, audio_d, n_out,
+                                   dcs_launch_stft_inverse_f64);
+}
+
+// ------------------------------------------------------------------------------- tiling
+extern "C" int dcs_tile(dcs_ctx* ctx, const float* mag_d, int64_t ch_stride, int64_t ld, int C, int64_t T, int F,
+                        int tc, int ov, int tiler, float scale, float* tiles_d, int64_t n_tiles) {
+    if (!ctx || !mag_d || (!tiles_d && n_tiles > 0)) DCS_FAIL(DCS_EINVAL, "dcs_tile: null argument");
+    if (C < 1 || F < 1 || ld < F || tc < 1 || ov < 0 || ov >= tc) DCS_FAIL(DCS_EINVAL, "dcs_tile: bad shape");
+    if (tiler != DCS_TILER_SCRIPT && tiler != DCS_TILER_LIBRARY) DCS_FAIL(DCS_EINVAL, "dcs_tile: bad tiler");
+    if (tiler == DCS_TILER_SCRIPT && C != 1)
+        DCS_FAIL(DCS_EINVAL, "dcs_tile: the script tiler takes a [T,F] spectrogram (separate_dsd.py:119)");
+    if (n_tiles != dcs_tile_count(T, tc, ov, tiler))
+        DCS_FAIL(DCS_EINVAL, "dcs_tile: n_tiles %lld != %lld", (long long)n_tiles,
+                 (long long)dcs_tile_count(T, tc, ov, tiler));
+    if (n_tiles == 0) return DCS_OK;
+    return dcs_launch_tile(ctx, mag_d, ch_stride, ld, C, T, F, tc, ov, tiler, scale, tiles_d, n_tiles);
+}
+
+extern "C" int dcs_overlap_add(dcs_ctx* ctx, const float* out_d, int64_t n, int S, int tc, int ov, int F,
+                               const double* rise_h, float* sep_d, int64_t sep_stride, int64_t ld) {
+    if (!ctx || !out_d || !rise_h || !sep_d) DCS_FAIL(DCS_EINVAL, "dcs_overlap_add: null argument");
+    if (n < 0 || S < 1 || tc < 1 || ov < 1 || ov >= tc || F < 1 || ld < F)
+        DCS_FAIL(DCS_EINVAL, "dcs_overlap_add: bad shape");
+    if (ov > 256) DCS_FAIL(DCS_EUNSUPPORTED, "dcs_overlap_add: overlap > 256");
+    std::vector<float> rise(ov);
+    for (int i = 0; i < ov; ++i) rise[i] = (float)rise_h[i];
+    float* rise_d = nullptr;
+    DCS_HIP(hipMalloc((void**)&rise_d, ov * sizeof(float)));
+    DCS_HIP(hipMemcpyAsync(rise_d, rise.data(), ov * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    DCS_HIP(hipStreamSynchronize(ctx->stream));  // rise[] is a stack-lifetime host buffer
+    int rc = dcs_launch_overlap_add(ctx, out_d, n, S, tc, ov, F, rise_d, sep_d, sep_stride, ld);
+    DCS_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(rise_d);
+    return rc;
+}

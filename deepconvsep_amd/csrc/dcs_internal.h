@@ -1,0 +1,119 @@
+// Internal declarations shared by the libdcs translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dcs.h"
+
+void dcs_set_error(const char* fmt, ...);
+
+#define DCS_FAIL(code, ...)          \
+    do {                             \
+        dcs_set_error(__VA_ARGS__);  \
+        return (code);               \
+    } while (0)
+
+#define DCS_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            dcs_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,    \
+                          __LINE__);                                                           \
+            return e__ == hipErrorOutOfMemory ? DCS_ENOMEM : DCS_EHIP;                         \
+        }                                                                                      \
+    } while (0)
+
+#define DCS_CHECK(expr)                 \
+    do {                                \
+        int rc__ = (expr);              \
+        if (rc__ != DCS_OK) return rc__; \
+    } while (0)
+
+// A grow-only device scratch buffer.  Regions handed out keep their address until the
+// buffer has to grow (then `generation` changes and zero-initialised regions are re-zeroed).
+struct DcsBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);
+    void release();
+};
+
+struct DcsTimingSlot {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+};
+
+struct dcs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    unsigned timing_mask = 0;  // bit t set: kernels tagged t are bracketed by HIP events
+    DcsTimingSlot slots[DCS_TAG_COUNT];
+    int n_cu = 256;
+};
+
+// RAII-ish helper: records a start event on construction and a stop event in done().
+struct DcsTimer {
+    dcs_ctx* ctx;
+    int tag;
+    size_t idx;
+    bool on;
+    DcsTimer(dcs_ctx* c, int t);
+    void done();
+};
+
+static inline int64_t dcs_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int dcs_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------- FFT plan
+struct dcs_stft {
+    dcs_ctx* ctx = nullptr;
+    int frame = 0;   // N
+    int hop = 0;
+    int log2m = 0;   // log2(N/2)
+    // device tables
+    float* win_f = nullptr;     // [N]
+    double* win_d = nullptr;    // [N]
+    float2* tw_f = nullptr;     // [N/2+1]  exp(-2 pi i k / N), k = 0..N/2
+    double2* tw_d = nullptr;
+    float* wsq_f = nullptr;     // [N] window*window in float32 (normaliser terms)
+    double* wsq_d = nullptr;
+    DcsBuffer frames;           // iSTFT scratch: windowed time frames [n_src][T][N]
+};
+
+// launchers implemented in fft.hip
+int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase,
+                                int64_t ld, int64_t rows_out, int64_t T);
+int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, double* mag, double* phase,
+                                int64_t ld, int64_t rows_out, int64_t T);
+int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase,
+                                int64_t ld, int64_t T, int n_src, float pre_div, float* audio, int64_t n_out);
+int dcs_launch_stft_inverse_f64(dcs_stft* p, const double* mag, int64_t src_stride, const double* phase,
+                                int64_t ld, int64_t T, int n_src, double pre_div, double* audio, int64_t n_out);
+
+// ---------------------------------------------------------------------------------- GEMM on rows
+// C[row(r)][0..n_store) = act( a_scale * A[arow(r)][0..K) . B[K][ldb] + bias )
+//   arow(r) = ((r / a_gdiv) * a_gmul + r % a_gdiv) * lda      (elements)
+//   crow(r) = ((r / c_gdiv) * c_gmul + r % c_gdiv) * ldc
+// B is padded with zero rows to a multiple of 32 and ldb is a multiple of 64.
+struct DcsGemm {
+    const float* A; int64_t lda; int a_gdiv; int64_t a_gmul; float a_scale;
+    const float* B; int ldb;
+    const float* bias;
+    float* C; int64_t ldc; int c_gdiv; int64_t c_gmul;
+    int64_t M; int n_cols;   // n_cols: padded N (multiple of 64) to compute
+    int n_store;             // columns actually written (<= n_cols)
+    int K;                   // valid K (A columns); multiple of 4 when a_vec
+    int relu;
+    int a_vec;               // 1: A rows are 16-byte aligned and lda % 4 == 0 -> float4 loads
+};
+int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag);
+
+// ---------------------------------------------------------------------------------- tiling kernels
+int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F,
+                    int tc, int ov, int tiler, float scale, float* tiles, int64_t n);
+int dcs_launch_overlap_add(dcs_ctx* ctx, const float* out, int64_t n, int S, int tc, int ov, int F,
+                           const float* rise_d, float* sep, int64_t sep_stride, int64_t ld);

@@ -1,0 +1,27 @@
+// Launch interface of the DSD decoder kernels (dsd.hip).
+#pragma once
+#include "dcs_internal.h"
+
+struct DsdFinalArgs {
+    const float* G;       // [n][3][tc][CI] transposed-conv2 outputs
+    const float* Bw;      // [CI][ldb]  Bw[c][f] = W1[c,0,0,F-1-f]; ldb = F rounded up to 64, zero padded
+    int ldb;
+    const float* bias;    // [4] output BiasLayer
+    const float* mix;     // mixture magnitudes: FOLD mag[T][mix_ld]; else tiles[n*tc][F]
+    int64_t mix_ld;
+    float mix_scale;      // scale_factor (FOLD) or 1
+    float* out;           // FOLD sep[c][t][out_ld]; else out[c][n*tc][F]
+    int64_t out_src_stride;
+    int64_t out_ld;
+    const float* rise;    // [ov] = np.linspace(0, 1, ov)
+    int64_t n;            // tiles
+    int64_t rows;         // FOLD: frames to produce; else n*tc
+    int tc, ov, st;
+    int F, CI;
+    int mmax;             // FOLD: ceil(ov/st)+1 covering tiles per frame; else 1
+    int mask_mode;        // 0 = convention A, 1 = convention B, 2 = raw network output
+};
+
+int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float* G, int64_t n_ks, int H2, int CP,
+                           int CI, int kh, int tc, int ncp);
+int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold);

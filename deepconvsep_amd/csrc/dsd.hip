@@ -1,0 +1,261 @@
+// Decoder kernels of the DSD100 / hiphop graph (examples/dsd100/separate_dsd.py:208-234) and
+// its soft mask (:258-271), fp32 MFMA (v_mfma_f32_16x16x4_f32), gfx950.
+//
+//   deconv2_kernel : InverseLayer(l_reshape_i, l_conv2)  -- VJP of the (tc/2 x 1) convolution
+//   final_kernel   : InverseLayer(., l_conv1) -> ConcatLayer -> BiasLayer -> rectify -> soft mask
+//                    -> x mixture [-> cross-fade overlap-add of util.py:297-327 when FOLD]
+#include "dcs_internal.h"
+#include "dsd.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------------
+// Transposed conv2 as "GEMM + col2im".  For one (tile, branch):
+//   P[t', dt*CI + ci] = sum_co D[t', co] * W2c[co, ci, dt]          (MFMA, M = H2, K = CP, N = kh*CI)
+//   G[t, ci]          = sum_dt P[t - dt, dt*CI + ci],  0 <= t-dt < H2 (LDS reduction)
+// which spends kh*CI*CP*H2 MACs -- the exact count of the transposed convolution -- instead of the
+// (tc x kh*CP) x CI padded-GEMM form that multiplies mostly zeros.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void deconv2_kernel(const float* __restrict__ D, const float* __restrict__ Bw,
+                                                           float* __restrict__ G, int H2, int CP, int CI, int kh,
+                                                           int tc, int ncp /* padded kh*CI, multiple of 16 */) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nrb = (H2 + 15) >> 4;  // 1 or 2 row blocks
+    const int as = CP + 2;
+    float* As = smem;                 // [16*nrb][CP+2]
+    float* P = smem + 16 * nrb * as;  // [16*nrb][ncp]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t ks = blockIdx.x;
+    const float* Dp = D + ks * (int64_t)H2 * CP;
+
+    for (int idx = tid; idx < 16 * nrb * CP; idx += kThreads) {
+        const int row = idx / CP, c = idx - row * CP;
+        As[row * as + c] = (row < H2) ? Dp[row * CP + c] : 0.f;
+    }
+    __syncthreads();
+
+    const int ncb = ncp >> 4;
+    const int nq = CP >> 2;
+    for (int cb = wave; cb < ncb; cb += 4) {
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* bcol = Bw + cb * 16 + fi;
+        for (int q = 0; q < nq; ++q) {
+            const float b = bcol[(int64_t)(4 * q + kq) * ncp];
+            const float a0 = As[fi * as + 4 * q + kq];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
+            if (nrb > 1) {
+                const float a1 = As[(16 + fi) * as + 4 * q + kq];
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            P[(kq * 4 + e) * ncp + cb * 16 + fi] = acc0[e];
+            if (nrb > 1) P[(16 + kq * 4 + e) * ncp + cb * 16 + fi] = acc1[e];
+        }
+    }
+    __syncthreads();
+
+    float* Gp = G + ks * (int64_t)tc * CI;
+    for (int o = tid; o < tc * CI; o += kThreads) {
+        const int t = o / CI, ci = o - t * CI;
+        int lo = t - (H2 - 1);
+        if (lo < 0) lo = 0;
+        int hi = t < kh - 1 ? t : kh - 1;
+        float sum = 0.f;
+        for (int dt = lo; dt <= hi; ++dt) sum += P[(t - dt) * ncp + dt * CI + ci];
+        Gp[o] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Transposed conv1 (K = CI input channels, N = F bins) fused with everything after it.
+// Workgroup = 16 rows x 64 bins; wave w owns 16 bins; the three branch accumulators of one
+// (row, bin) live in the same lane, so bias + rectify + soft mask + x mixture happen in
+// registers.  FOLD: a row is an output frame t and the loop over m walks the tiles that cover it
+// in the order of the reference's sequential cross-fade (owner tile first, then the blends), so
+// the masked tiles never exist in HBM.  !FOLD: a row is one frame of one tile (predict_function2).
+// ------------------------------------------------------------------------------------------------
+template <bool FOLD>
+__global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
+    constexpr int NBR = 3;      // dense branches that reach the output (separate_dsd.py:228)
+    constexpr int NQ_MAX = 16;  // CI <= 64
+    __shared__ __attribute__((aligned(16))) float As[NBR * 16 * (64 + 2)];
+    __shared__ int meta_k0[16];
+    __shared__ int meta_j0[16];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int col = blockIdx.y * 64 + wave * 16 + fi;
+    const int CI = a.CI, as = a.CI + 2, nq = a.CI >> 2;
+    const int tc = a.tc, st = a.st, ov = a.ov;
+    const int64_t n = a.n;
+
+    if (tid < 16) {
+        const int64_t r = row0 + tid;
+        int k0 = 0, j0 = -1;
+        if (r < a.rows) {
+            if (FOLD) {
+                int64_t kk = (r < ov) ? 0 : (r - ov) / st;
+                if (kk > n - 1) kk = n - 1;
+                const int64_t jj = r - kk * st;
+                if (jj < tc) {
+                    k0 = (int)kk;
+                    j0 = (int)jj;
+                }
+            } else {
+                k0 = (int)(r / tc);
+                j0 = (int)(r - (int64_t)k0 * tc);
+            }
+        }
+        meta_k0[tid] = k0;
+        meta_j0[tid] = j0;
+    }
+
+    // B fragments: Bw[c][bin], this lane's bin, rows 4q+kq -- constant for the whole workgroup
+    float breg[NQ_MAX];
+#pragma unroll
+    for (int q = 0; q < NQ_MAX; ++q) breg[q] = (q < nq) ? a.Bw[(int64_t)(4 * q + kq) * a.ldb + col] : 0.f;
+
+    // mixture value of this lane's 4 (row, bin) cells
+    float mixv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t r = row0 + kq * 4 + e;
+        mixv[e] = (r < a.rows && col < a.F) ? a.mix_scale * a.mix[r * a.mix_ld + col] : 0.f;
+    }
+    const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
+    const float eps_r = 5e-19f;  // eps * rand_num with the unseeded draw replaced by 0.5 (separate_dsd.py:245,256)
+
+    float res[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) res[c][e] = 0.f;
+
+    __syncthreads();
+
+    const int slots = NBR * 16 * nq;  // float4 slots of one staged A set
+    for (int m = 0; m < a.mmax; ++m) {
+        // ---- stage the decoder rows G[k0+m][branch][j0 - m*st][:] of the 16 rows, 3 branches
+        for (int idx = tid; idx < slots; idx += kThreads) {
+            const int s = idx / (16 * nq);
+            const int rem = idx - s * 16 * nq;
+            const int i = rem / nq, c4 = rem - i * nq;
+            const int j0 = meta_j0[i];
+            const int64_t k = (int64_t)meta_k0[i] + m;
+            const int j = j0 - m * st;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j0 >= 0 && j >= 0 && k < n)
+                v = *reinterpret_cast<const f32x4*>(a.G + ((k * NBR + s) * tc + j) * (int64_t)CI + c4 * 4);
+            float* d = As + (s * 16 + i) * as + c4 * 4;
+            *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+        }
+        __syncthreads();
+
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NQ_MAX; ++q) {
+            if (q < nq) {
+                const float b = breg[q];
+                const int off = fi * as + 4 * q + kq;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(As[off], b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(As[16 * as + off], b, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(As[32 * as + off], b, acc2, 0, 0, 0);
+            }
+        }
+
+        // ---- bias + rectify (separate_dsd.py:234), soft mask (:258-271), cross-fade (util.py:321-325)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = kq * 4 + e;
+            const int j0 = meta_j0[i];
+            const int j = j0 - m * st;
+            const bool valid = (j0 >= 0) && (j >= 0) && ((int64_t)meta_k0[i] + m < n);
+            // output channels 0..3 use branches 0,1,2,1
+            const float p0 = fmaxf(acc0[e] + bias0, 0.f);
+            const float p1 = fmaxf(acc1[e] + bias1, 0.f);
+            const float p2 = fmaxf(acc2[e] + bias2, 0.f);
+            const float p3 = fmaxf(acc1[e] + bias3, 0.f);
+            float v0, v1, v2, v3;
+            if (a.mask_mode == 0) {  // convention A
+                const float s0 = p0 + eps_r, s1 = p1 + eps_r, s2 = p2 + eps_r, s3 = p3 + eps_r;
+                const float den = ((s0 + s1) + s2) + s3;
+                const float x = mixv[e];
+                v0 = (s0 / den) * x; v1 = (s1 / den) * x; v2 = (s2 / den) * x; v3 = (s3 / den) * x;
+            } else if (a.mask_mode == 1) {  // convention B
+                const float den = (((p0 + p1) + p2) + p3) + eps_r;
+                const float x = mixv[e];
+                v0 = (p0 / den) * x; v1 = (p1 / den) * x; v2 = (p2 / den) * x; v3 = (p3 / den) * x;
+            } else {  // raw network output (get_output)
+                v0 = p0; v1 = p1; v2 = p2; v3 = p3;
+            }
+            if (m == 0) {
+                if (valid) { res[0][e] = v0; res[1][e] = v1; res[2][e] = v2; res[3][e] = v3; }
+            } else if (valid) {
+                const float up = a.rise[j], down = a.rise[ov - 1 - j];
+                res[0][e] = down * res[0][e] + up * v0;
+                res[1][e] = down * res[1][e] + up * v1;
+                res[2][e] = down * res[2][e] + up * v2;
+                res[3][e] = down * res[3][e] + up * v3;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (col < a.F) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t r = row0 + kq * 4 + e;
+            if (r < a.rows) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a.out[c * a.out_src_stride + r * a.out_ld + col] = res[c][e];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float* G, int64_t n_ks, int H2, int CP,
+                           int CI, int kh, int tc, int ncp) {
+    if (n_ks <= 0) return DCS_OK;
+    const int nrb = (H2 + 15) / 16;
+    if (nrb > 2) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: conv2 output height %d > 32", H2);
+    const size_t lds = (size_t)16 * nrb * ((CP + 2) + ncp) * sizeof(float);
+    if (lds > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: LDS %zu too large", lds);
+    if (lds > 48 * 1024)
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deconv2_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DcsTimer tm(ctx, DCS_TAG_DECONV2);
+    hipLaunchKernelGGL(deconv2_kernel, dim3((unsigned)n_ks), dim3(kThreads), lds, ctx->stream, D, Bw, G, H2, CP, CI,
+                       kh, tc, ncp);
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
+    if (a.rows <= 0) return DCS_OK;
+    if (a.CI > 64 || (a.CI & 3)) DCS_FAIL(DCS_EUNSUPPORTED, "final: CI %d", a.CI);
+    dim3 grid((unsigned)dcs_cdiv(a.rows, 16), (unsigned)(a.ldb / 64));
+    DcsTimer tm(ctx, DCS_TAG_FINAL);
+    if (fold)
+        hipLaunchKernelGGL(final_kernel<true>, grid, dim3(kThreads), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(final_kernel<false>, grid, dim3(kThreads), 0, ctx->stream, a);
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}

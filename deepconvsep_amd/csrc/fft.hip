@@ -1,0 +1,328 @@
+// STFT / iSTFT kernels for gfx950.
+//
+// Replaces the per-frame Python loops of stft_norm / istft_norm
+// (reference transform.py:277-396; script copy examples/dsd100/separate_dsd.py:49-111).
+//
+// One workgroup (256 threads, 4 wavefronts) transforms one frame.  The N-point real transform is
+// done as an N/2-point complex Stockham FFT in LDS (radix-4 passes + one radix-2 pass when
+// log2(N/2) is odd; ping-pong between two LDS buffers, natural-order output) followed by the
+// usual even/odd split.  Twiddles exp(-2 pi i k / N), k = 0..N/2, are tabulated on the host in
+// float64; the kernels read them through the vector L1 (the table is <= 32 KiB and shared by
+// every workgroup).
+//
+// HBM traffic per frame (forward): hop new samples in (neighbouring frames hit L2), 2*(N/2+1)
+// values out -- the stage is HBM-bound.
+#include "dcs_internal.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <typename R> struct V2;
+template <> struct V2<float> { using type = float2; };
+template <> struct V2<double> { using type = double2; };
+
+template <typename R2, typename R>
+__device__ __forceinline__ R2 mk(R x, R y) {
+    R2 r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+
+// w(j) = exp(DIR * 2 pi i j / N) for 0 <= j < N from the half-circle table tw[0..N/2]
+// (tw holds the forward sign, exp(-2 pi i j / N)).
+template <typename R, typename R2, int DIR>
+__device__ __forceinline__ R2 twiddle(const R2* __restrict__ tw, int j, int M) {
+    R2 w;
+    if (j <= M) {
+        w = tw[j];
+    } else {
+        w = tw[j - M];
+        w.x = -w.x;
+        w.y = -w.y;
+    }
+    if (DIR > 0) w.y = -w.y;
+    return w;
+}
+
+template <typename R2>
+__device__ __forceinline__ R2 cmul(R2 a, R2 b) {
+    R2 r;
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+    return r;
+}
+
+// In-LDS complex FFT of length M = 2^log2m, DIR = -1 forward / +1 inverse (unscaled).
+// Input in `a`; returns the buffer that holds the natural-order result.  Every thread of the
+// workgroup must call it; it ends with a barrier.
+template <typename R, typename R2, int DIR>
+__device__ R2* fft_lds(R2* a, R2* b, const R2* __restrict__ tw, int M, int log2m) {
+    const int tid = threadIdx.x;
+    int Ns = 1;
+    int lg = 0;
+    // radix-4 passes
+    while (lg + 2 <= log2m) {
+        const int quarter = M >> 2;
+        const int step = (2 * M) / (4 * Ns);  // N / (4 Ns): table stride per unit of t*k
+        for (int j = tid; j < quarter; j += kThreads) {
+            const int k = j & (Ns - 1);
+            R2 v0 = a[j];
+            R2 v1 = a[j + quarter];
+            R2 v2 = a[j + 2 * quarter];
+            R2 v3 = a[j + 3 * quarter];
+            if (Ns > 1) {
+                v1 = cmul(v1, twiddle<R, R2, DIR>(tw, k * step, M));
+                v2 = cmul(v2, twiddle<R, R2, DIR>(tw, 2 * k * step, M));
+                v3 = cmul(v3, twiddle<R, R2, DIR>(tw, 3 * k * step, M));
+            }
+            R2 a02 = mk<R2, R>(v0.x + v2.x, v0.y + v2.y);
+            R2 s02 = mk<R2, R>(v0.x - v2.x, v0.y - v2.y);
+            R2 a13 = mk<R2, R>(v1.x + v3.x, v1.y + v3.y);
+            R2 s13 = mk<R2, R>(v1.x - v3.x, v1.y - v3.y);
+            // forward: y1 = s02 - i s13, y3 = s02 + i s13; inverse: swapped
+            R2 ym = mk<R2, R>(s02.x + s13.y, s02.y - s13.x);  // s02 - i*s13
+            R2 yp = mk<R2, R>(s02.x - s13.y, s02.y + s13.x);  // s02 + i*s13
+            const int d = ((j - k) << 2) + k;                 // (j / Ns) * 4 Ns + k
+            b[d] = mk<R2, R>(a02.x + a13.x, a02.y + a13.y);
+            b[d + Ns] = (DIR < 0) ? ym : yp;
+            b[d + 2 * Ns] = mk<R2, R>(a02.x - a13.x, a02.y - a13.y);
+            b[d + 3 * Ns] = (DIR < 0) ? yp : ym;
+        }
+        __syncthreads();
+        R2* t = a;
+        a = b;
+        b = t;
+        Ns <<= 2;
+        lg += 2;
+    }
+    if (lg < log2m) {  // one radix-2 pass
+        const int half = M >> 1;
+        const int step = (2 * M) / (2 * Ns);
+        for (int j = tid; j < half; j += kThreads) {
+            const int k = j & (Ns - 1);
+            R2 v0 = a[j];
+            R2 v1 = a[j + half];
+            if (Ns > 1) v1 = cmul(v1, twiddle<R, R2, DIR>(tw, k * step, M));
+            const int d = ((j - k) << 1) + k;
+            b[d] = mk<R2, R>(v0.x + v1.x, v0.y + v1.y);
+            b[d + Ns] = mk<R2, R>(v0.x - v1.x, v0.y - v1.y);
+        }
+        __syncthreads();
+        R2* t = a;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+__device__ __forceinline__ float dcs_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double dcs_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float dcs_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double dcs_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ void dcs_sincos(float a, float* s, float* c) { sincosf(a, s, c); }
+__device__ __forceinline__ void dcs_sincos(double a, double* s, double* c) { sincos(a, s, c); }
+
+// ------------------------------------------------------------------------------------------
+// forward: frame t = window * padded[t*hop : t*hop+N], padded = [N/2 zeros | audio | zeros]
+// (transform.py:309-333); mag = |X| / sqrt(N), phase = angle(X) (transform.py:244-247)
+// ------------------------------------------------------------------------------------------
+template <typename R, typename R2>
+__global__ __launch_bounds__(kThreads) void stft_forward_kernel(
+    const R* __restrict__ audio, int64_t L, const R* __restrict__ win, const R2* __restrict__ tw,
+    R* __restrict__ mag, R* __restrict__ phase, int64_t ld, int N, int hop, int log2m, int64_t T, R sqrt_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = N >> 1;
+    const int tid = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    R* mrow = mag + t * ld;
+    R* prow = phase ? phase + t * ld : nullptr;
+    if (t >= T) {  // rows past the last frame: zeros (zero-padding tiler, util.py:233)
+        for (int k = tid; k < ld; k += kThreads) {
+            mrow[k] = R(0);
+            if (prow) prow[k] = R(0);
+        }
+        return;
+    }
+    R2* buf0 = reinterpret_cast<R2*>(smem);
+    R2* buf1 = buf0 + M;
+    const int64_t base = t * (int64_t)hop - M;  // audio index of padded sample t*hop
+    for (int m = tid; m < M; m += kThreads) {
+        const int64_t p = base + 2 * m;
+        R x0 = R(0), x1 = R(0);
+        if (p >= 0 && p < L) x0 = audio[p] * win[2 * m];
+        if (p + 1 >= 0 && p + 1 < L) x1 = audio[p + 1] * win[2 * m + 1];
+        buf0[m] = mk<R2, R>(x0, x1);
+    }
+    __syncthreads();
+    const R2* Z = fft_lds<R, R2, -1>(buf0, buf1, tw, M, log2m);
+    for (int k = tid; k <= M; k += kThreads) {
+        const R2 zk = Z[k & (M - 1)];
+        const R2 zm = Z[(M - k) & (M - 1)];
+        // E = (zk + conj(zm))/2 ; O = -i (zk - conj(zm))/2 ; X = E + w^k O
+        const R er = R(0.5) * (zk.x + zm.x), ei = R(0.5) * (zk.y - zm.y);
+        const R orr = R(0.5) * (zk.y + zm.y), oi = R(-0.5) * (zk.x - zm.x);
+        const R2 w = tw[k];
+        const R xr = er + (w.x * orr - w.y * oi);
+        const R xi = ei + (w.x * oi + w.y * orr);
+        mrow[k] = dcs_sqrt(xr * xr + xi * xi) / sqrt_n;
+        if (prow) prow[k] = dcs_atan2(xi, xr);
+    }
+    for (int k = M + 1 + tid; k < ld; k += kThreads) {  // row padding
+        mrow[k] = R(0);
+        if (prow) prow[k] = R(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse, step 1: X = (mag / pre_div) * sqrt(N) * exp(j phase) (transform.py:271-272,
+// separate_dsd.py:304) -> irfft (imaginary parts of DC / Nyquist ignored, as numpy does)
+// -> window * frame written to the scratch [src][t][N]  (transform.py:382-388)
+// ------------------------------------------------------------------------------------------
+template <typename R, typename R2>
+__global__ __launch_bounds__(kThreads) void stft_inverse_kernel(
+    const R* __restrict__ mag, int64_t src_stride, const R* __restrict__ phase, int64_t ld,
+    const R* __restrict__ win, const R2* __restrict__ tw, R* __restrict__ frames, int N, int log2m, int64_t T,
+    R pre_div, R sqrt_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = N >> 1;
+    const int tid = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    const int s = blockIdx.y;
+    R2* buf0 = reinterpret_cast<R2*>(smem);
+    R2* buf1 = buf0 + M;  // M+1 entries: holds X first, then serves as the FFT ping-pong buffer
+    R2* X = buf1;
+    const R* mrow = mag + (int64_t)s * src_stride + t * ld;
+    const R* prow = phase + t * ld;
+    for (int k = tid; k <= M; k += kThreads) {
+        const R a = (mrow[k] / pre_div) * sqrt_n;
+        R sn, cs;
+        dcs_sincos(prow[k], &sn, &cs);
+        R2 x = mk<R2, R>(a * cs, a * sn);
+        if (k == 0 || k == M) x.y = R(0);
+        X[k] = x;
+    }
+    __syncthreads();
+    for (int k = tid; k < M; k += kThreads) {
+        const R2 xk = X[k];
+        const R2 xm = X[M - k];
+        // E = (xk + conj(xm))/2 ; D = (xk - conj(xm))/2 ; O = D * conj(w^k) ; Z = E + i O
+        const R er = R(0.5) * (xk.x + xm.x), ei = R(0.5) * (xk.y - xm.y);
+        const R dr = R(0.5) * (xk.x - xm.x), di = R(0.5) * (xk.y + xm.y);
+        const R2 w = tw[k];
+        const R orr = dr * w.x + di * w.y;
+        const R oi = di * w.x - dr * w.y;
+        buf0[k] = mk<R2, R>(er - oi, ei + orr);
+    }
+    __syncthreads();
+    const R2* z = fft_lds<R, R2, +1>(buf0, buf1, tw, M, log2m);
+    const R inv_m = R(1) / R(M);
+    R2* out = reinterpret_cast<R2*>(frames + ((int64_t)s * T + t) * N);
+    const R2* w2 = reinterpret_cast<const R2*>(win);
+    for (int m = tid; m < M; m += kThreads) {
+        const R2 v = z[m];
+        const R2 w = w2[m];
+        out[m] = mk<R2, R>((v.x * inv_m) * w.x, (v.y * inv_m) * w.y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse, step 2: gather overlap-add + normalisation (transform.py:384-394).  Output sample m
+// sits at padded position p = m + N/2 and receives frames n with n*hop <= p < n*hop + N, summed
+// in increasing n like the reference loop; the normaliser sums window*window over the same
+// frames, zeros -> 1.
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(kThreads) void istft_ola_kernel(const R* __restrict__ frames,
+                                                             const R* __restrict__ wsq, R* __restrict__ audio,
+                                                             int64_t n_out, int N, int hop, int64_t T) {
+    const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int s = blockIdx.y;
+    if (m >= n_out) return;
+    const int64_t p = m + (N >> 1);
+    int64_t n_hi = p / hop;
+    if (n_hi > T - 1) n_hi = T - 1;
+    const int64_t n_lo = (p < N) ? 0 : (p - N) / hop + 1;
+    R acc = R(0), norm = R(0);
+    const R* f = frames + (int64_t)s * T * N;
+    for (int64_t n = n_lo; n <= n_hi; ++n) {
+        const int64_t off = p - n * hop;
+        acc += f[n * N + off];
+        norm += wsq[off];
+    }
+    if (norm == R(0)) norm = R(1);
+    audio[(int64_t)s * n_out + m] = acc / norm;
+}
+
+template <typename R, typename R2>
+int launch_forward(dcs_stft* p, const R* win, const R2* tw, const R* audio, int64_t L, R* mag, R* phase,
+                   int64_t ld, int64_t rows_out, int64_t T) {
+    if (rows_out <= 0) return DCS_OK;
+    const int M = p->frame / 2;
+    const size_t lds = 2 * (size_t)M * sizeof(R2);
+    auto kern = stft_forward_kernel<R, R2>;
+    if (lds > 48 * 1024)
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    DcsTimer tm(p->ctx, DCS_TAG_STFT);
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows_out), dim3(kThreads), lds, p->ctx->stream, audio, L, win, tw,
+                       mag, phase, ld, p->frame, p->hop, p->log2m, T, (R)sqrt((double)p->frame));
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+template <typename R, typename R2>
+int launch_inverse(dcs_stft* p, const R* win, const R2* tw, const R* wsq, const R* mag, int64_t src_stride,
+                   const R* phase, int64_t ld, int64_t T, int n_src, R pre_div, R* audio, int64_t n_out) {
+    if (T <= 0 || n_src <= 0 || n_out <= 0) return DCS_OK;
+    const int N = p->frame;
+    const int M = N / 2;
+    DCS_CHECK(p->frames.ensure((size_t)n_src * T * N * sizeof(R)));
+    R* frames = reinterpret_cast<R*>(p->frames.ptr);
+    const size_t lds = (2 * (size_t)M + 1) * sizeof(R2);
+    auto kern = stft_inverse_kernel<R, R2>;
+    if (lds > 48 * 1024)
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    {
+        DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
+        hipLaunchKernelGGL(kern, dim3((unsigned)T, (unsigned)n_src), dim3(kThreads), lds, p->ctx->stream, mag,
+                           src_stride, phase, ld, win, tw, frames, N, p->log2m, T, pre_div,
+                           (R)sqrt((double)N));
+        tm.done();
+    }
+    DCS_HIP(hipGetLastError());
+    {
+        DcsTimer tm(p->ctx, DCS_TAG_OLA);
+        hipLaunchKernelGGL(istft_ola_kernel<R>, dim3((unsigned)dcs_cdiv(n_out, kThreads), (unsigned)n_src),
+                           dim3(kThreads), 0, p->ctx->stream, frames, wsq, audio, n_out, N, p->hop, T);
+        tm.done();
+    }
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+}  // namespace
+
+int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, int64_t ld,
+                                int64_t rows_out, int64_t T) {
+    return launch_forward<float, float2>(p, p->win_f, p->tw_f, audio, L, mag, phase, ld, rows_out, T);
+}
+int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, double* mag, double* phase,
+                                int64_t ld, int64_t rows_out, int64_t T) {
+    return launch_forward<double, double2>(p, p->win_d, p->tw_d, audio, L, mag, phase, ld, rows_out, T);
+}
+int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, int64_t ld,
+                                int64_t T, int n_src, float pre_div, float* audio, int64_t n_out) {
+    return launch_inverse<float, float2>(p, p->win_f, p->tw_f, p->wsq_f, mag, src_stride, phase, ld, T, n_src,
+                                         pre_div, audio, n_out);
+}
+int dcs_launch_stft_inverse_f64(dcs_stft* p, const double* mag, int64_t src_stride, const double* phase,
+                                int64_t ld, int64_t T, int n_src, double pre_div, double* audio, int64_t n_out) {
+    return launch_inverse<double, double2>(p, p->win_d, p->tw_d, p->wsq_d, mag, src_stride, phase, ld, T, n_src,
+                                           pre_div, audio, n_out);
+}

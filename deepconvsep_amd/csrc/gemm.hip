@@ -1,0 +1,181 @@
+// fp32 MFMA GEMM over gathered rows (gfx950, v_mfma_f32_16x16x4_f32).
+//
+// Every dense / convolution layer of the reference's build_ca graph whose receptive field is a
+// contiguous run of an activation matrix is this one kernel with a different row mapping:
+//   conv1 (1 x F filter,      separate_dsd.py:198)  rows = frames,      A row = spectrogram row
+//   conv2 (tc/2 x 1 filter,   separate_dsd.py:202)  rows = positions,   A row = kh consecutive H1 rows
+//   DenseLayer bottleneck     (separate_dsd.py:206)  rows = tiles,       A row = H2 consecutive C2 rows
+//   DenseLayer per source     (separate_dsd.py:209)  rows = tiles
+// Arithmetic is exact f32 (the f32-input MFMA is an fmaf chain), accumulation order = k ascending.
+//
+// Tiling: workgroup = 4 wavefronts; block tile (16*RB) x 64, K step 32; wave w owns output columns
+// [16w, 16w+16) of the block and RB row blocks (B fragment reused RB times).  A and B tiles are
+// staged through LDS with 16-byte global loads, prefetched one K tile ahead in registers.
+#include "dcs_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int BK = 32;
+constexpr int BN = 64;
+constexpr int AS = BK + 2;   // A tile row stride (floats): 2*i + kq distinct banks for the fragment read
+constexpr int BS = BN + 16;  // B tile row stride: rows kq, kq+1 land 16 banks apart
+
+template <int RB, bool VEC>
+__global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
+    constexpr int BM = 16 * RB;
+    constexpr int A_F4 = BM * (BK / 4);                        // float4 slots in an A tile
+    constexpr int A_PER = (A_F4 + kThreads - 1) / kThreads;    // per thread
+    constexpr int B_PER = (BK * BN / 4) / kThreads;            // = 2
+    __shared__ __attribute__((aligned(16))) float lds[BM * AS + BK * BS];
+    float* As = lds;
+    float* Bs = lds + BM * AS;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    // kernel arguments as scalars (taking the struct's address would spill it to scratch)
+    const int gK = g.K, gldb = g.ldb;
+    const int64_t gM = g.M;
+    const float gscale = g.a_scale;
+
+    // per-thread A source rows
+    const float* a_ptr[A_PER];
+    int a_c4[A_PER];
+    int a_row[A_PER];
+    bool a_ok[A_PER];
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        const int idx = tid + u * kThreads;
+        const int row = idx / (BK / 4);
+        a_row[u] = row;
+        a_c4[u] = idx % (BK / 4);
+        const int64_t r = m0 + row;
+        a_ok[u] = (idx < A_F4) && (r < gM);
+        const int64_t rr = a_ok[u] ? r : 0;
+        a_ptr[u] = g.A + ((rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda;
+    }
+    const float* b_ptr[B_PER];
+    int b_row[B_PER], b_c4[B_PER];
+#pragma unroll
+    for (int u = 0; u < B_PER; ++u) {
+        const int idx = tid + u * kThreads;
+        b_row[u] = idx / (BN / 4);
+        b_c4[u] = idx % (BN / 4);
+        b_ptr[u] = g.B + (int64_t)b_row[u] * gldb + n0 + b_c4[u] * 4;
+    }
+
+    f32x4 ra[A_PER];  // native vectors: HIP's float4 struct did not survive SROA here (scratch)
+    f32x4 rb[B_PER];
+    // (macros, not lambdas: by-reference captures of ra/rb pushed the prefetch registers to scratch)
+#define DCS_LOAD_TILES(kt_)                                                                   \
+    {                                                                                         \
+        const int k0_ = (kt_) * BK;                                                           \
+        _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                   \
+            const int k = k0_ + a_c4[u] * 4;                                                  \
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                              \
+            if (a_ok[u]) {                                                                    \
+                if (VEC) {                                                                    \
+                    if (k < gK) v = *reinterpret_cast<const f32x4*>(a_ptr[u] + k);            \
+                } else {                                                                      \
+                    if (k + 0 < gK) v[0] = a_ptr[u][k + 0];                                   \
+                    if (k + 1 < gK) v[1] = a_ptr[u][k + 1];                                   \
+                    if (k + 2 < gK) v[2] = a_ptr[u][k + 2];                                   \
+                    if (k + 3 < gK) v[3] = a_ptr[u][k + 3];                                   \
+                }                                                                             \
+            }                                                                                 \
+            ra[u] = v;                                                                        \
+        }                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < B_PER; ++u)                                     \
+            rb[u] = *reinterpret_cast<const f32x4*>(b_ptr[u] + (int64_t)k0_ * gldb);          \
+    }
+#define DCS_STORE_TILES()                                                                     \
+    {                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                   \
+            if (tid + u * kThreads < A_F4) {                                                  \
+                float* d = As + a_row[u] * AS + a_c4[u] * 4;                                  \
+                *reinterpret_cast<float2*>(d) = make_float2(gscale * ra[u][0], gscale * ra[u][1]);    \
+                *reinterpret_cast<float2*>(d + 2) = make_float2(gscale * ra[u][2], gscale * ra[u][3]); \
+            }                                                                                 \
+        }                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < B_PER; ++u)                                     \
+            *reinterpret_cast<f32x4*>(Bs + b_row[u] * BS + b_c4[u] * 4) = rb[u];              \
+    }
+
+    f32x4 acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (gK + BK - 1) / BK;
+    DCS_LOAD_TILES(0)
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        DCS_STORE_TILES()
+        __syncthreads();
+        if (kt + 1 < nkt) DCS_LOAD_TILES(kt + 1)
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const float b = Bs[(kk * 4 + kq) * BS + wave * 16 + fi];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float a = As[(r * 16 + fi) * AS + kk * 4 + kq];
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: C/D layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
+    const int col = n0 + wave * 16 + fi;
+    if (col < g.n_store) {
+        const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = m0 + r * 16 + kq * 4 + e;
+                if (row < g.M) {
+                    float v = acc[r][e] + bias;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+#undef DCS_LOAD_TILES
+#undef DCS_STORE_TILES
+
+template <int RB>
+void launch_rb(dcs_ctx* ctx, const DcsGemm& g) {
+    dim3 grid((unsigned)dcs_cdiv(g.M, 16 * RB), (unsigned)(g.n_cols / BN));
+    if (g.a_vec)
+        hipLaunchKernelGGL((gemm_rows_kernel<RB, true>), grid, dim3(kThreads), 0, ctx->stream, g);
+    else
+        hipLaunchKernelGGL((gemm_rows_kernel<RB, false>), grid, dim3(kThreads), 0, ctx->stream, g);
+}
+
+}  // namespace
+
+int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
+    if (g.M <= 0) return DCS_OK;
+    if (g.n_cols % BN) DCS_FAIL(DCS_EINVAL, "gemm_rows: n_cols %d not a multiple of %d", g.n_cols, BN);
+    if (g.a_vec && ((g.K & 3) || (g.lda & 3))) DCS_FAIL(DCS_EINVAL, "gemm_rows: vector path needs K, lda %% 4 == 0");
+    DcsTimer tm(ctx, tag);
+    // few rows: maximise the number of workgroups; many rows: reuse each B fragment 4 times
+    const int64_t groups16 = (g.M + 15) / 16;
+    const int64_t col_groups = g.n_cols / BN;
+    if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu)
+        launch_rb<1>(ctx, g);
+    else if (groups16 * col_groups <= 16 * (int64_t)ctx->n_cu)
+        launch_rb<2>(ctx, g);
+    else
+        launch_rb<4>(ctx, g);
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}

@@ -1,0 +1,22 @@
+// Generic build_ca path (strided conv1, optional max-pool, 2-D conv2, large dense layers):
+// iKala, Bach10 and score-informed graphs.  Implemented in generic.hip.
+#pragma once
+#include <vector>
+
+#include "dcs_internal.h"
+
+struct DcsGenericDims {
+    int nf1, kw1, sw1, w1, pool_w, wp, nf2, kh2, kw2, h2, w2, flat, hidden, n_fc, n_branch, S;
+    int branch_fc[4];
+};
+
+struct DcsGenericNet;
+
+int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int F,
+                       const std::vector<std::vector<float>>& params, DcsGenericNet** out);
+void dcs_generic_destroy(DcsGenericNet* g);
+// tiles [n, C, tc, F] -> mask_mode 0/1: out [S, n, tc, F] masked; mask_mode 2: p [n, n_branch*C, tc, F]
+int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mask_mode, int tie_mode, float* out);
+int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, int64_t L, int ov, int tiler, float scale,
+                         int eps_mode, int tie_mode, float* pcm, float* sep_out, float* mag_out, float* phase_out,
+                         int64_t ld_out, DcsBuffer* ws);

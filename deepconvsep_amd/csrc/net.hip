@@ -1,0 +1,447 @@
+// Network handle (build_ca + set_all_param_values), predict_function2 and the fused file-level
+// separation path.  Reference: examples/dsd100/separate_dsd.py:172-311.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "dcs_internal.h"
+#include "dsd.h"
+#include "generic.h"
+
+namespace {
+
+struct Dims {
+    int nf1, kw1, sw1, w1, pool_w, wp, nf2, kh2, kw2, h2, w2, flat, hidden, n_fc, n_branch, S;
+    int branch_fc[4];
+};
+
+int arch_dims(int arch, int C, int tc, int F, Dims* d) {
+    memset(d, 0, sizeof(*d));
+    switch (arch) {
+        case DCS_ARCH_DSD:  // separate_dsd.py:198-234
+            d->nf1 = 50; d->kw1 = F; d->sw1 = 1; d->pool_w = 0;
+            d->nf2 = 50; d->kh2 = tc / 2; d->kw2 = 1; d->hidden = 128;
+            d->n_fc = 3; d->n_branch = 4; d->S = 4;
+            d->branch_fc[0] = 0; d->branch_fc[1] = 1; d->branch_fc[2] = 2; d->branch_fc[3] = 1;
+            if (C != 1) DCS_FAIL(DCS_EINVAL, "dsd network takes 1 input channel");
+            break;
+        case DCS_ARCH_IKALA:  // separate_ikala.py:173-191
+            d->nf1 = 30; d->kw1 = 30; d->sw1 = 3; d->pool_w = 4;
+            d->nf2 = 30; d->kh2 = 10; d->kw2 = 20; d->hidden = 256;
+            d->n_fc = 2; d->n_branch = 2; d->S = 2;
+            d->branch_fc[0] = 0; d->branch_fc[1] = 1;
+            if (C != 1) DCS_FAIL(DCS_EINVAL, "ikala network takes 1 input channel");
+            break;
+        case DCS_ARCH_BACH10:     // separate_bach10.py:197-227
+        case DCS_ARCH_BACH10_SI:  // bach10_scoreinformed/separate_bach10.py:414-444
+            d->nf1 = 30; d->kw1 = 30; d->sw1 = 4; d->pool_w = 0;
+            d->nf2 = 30; d->kh2 = (2 * tc) / 3; d->kw2 = 1; d->hidden = 256;
+            d->n_fc = 4; d->n_branch = 4; d->S = 4;
+            for (int i = 0; i < 4; ++i) d->branch_fc[i] = i;
+            if (arch == DCS_ARCH_BACH10 && C != 1) DCS_FAIL(DCS_EINVAL, "bach10 network takes 1 input channel");
+            if (arch == DCS_ARCH_BACH10_SI && C != 4)
+                DCS_FAIL(DCS_EINVAL, "score-informed network takes 4 input channels");
+            break;
+        default:
+            DCS_FAIL(DCS_EINVAL, "unknown architecture %d", arch);
+    }
+    if (F < d->kw1) DCS_FAIL(DCS_EINVAL, "feature size %d smaller than the conv1 filter %d", F, d->kw1);
+    d->w1 = (F - d->kw1) / d->sw1 + 1;
+    d->wp = d->pool_w ? d->w1 / d->pool_w : d->w1;
+    d->h2 = tc - d->kh2 + 1;
+    d->w2 = d->wp - d->kw2 + 1;
+    if (d->h2 < 1 || d->w2 < 1 || d->kh2 < 1) DCS_FAIL(DCS_EINVAL, "time_context %d / feature size %d too small", tc, F);
+    d->flat = d->nf2 * d->h2 * d->w2;
+    return DCS_OK;
+}
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src) {
+    DCS_HIP(hipMalloc((void**)dst, src.size() * sizeof(T)));
+    DCS_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DCS_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+struct dcs_model {
+    dcs_ctx* ctx = nullptr;
+    int arch = 0, C = 1, tc = 30, F = 0;
+    Dims d;
+    // ---- DSD packed weights
+    int CI = 0, CP = 0, K1 = 0, F64 = 0, ncp = 0, hid64 = 0, nd = 0, nd64 = 0;
+    float *B1 = nullptr, *bias1 = nullptr, *B2 = nullptr, *bias2 = nullptr, *Bfc = nullptr, *biasfc = nullptr;
+    float *Bd = nullptr, *biasd = nullptr, *Bw2 = nullptr, *Bfin = nullptr, *bout = nullptr;
+    // ---- generic path (ikala / bach10 / score-informed)
+    DcsGenericNet* gen = nullptr;
+    // ---- scratch
+    DcsBuffer ws;
+    float* rise_d = nullptr;
+    int rise_ov = -1;
+};
+
+namespace {
+
+int ensure_rise(dcs_model* m, int ov) {
+    if (m->rise_ov == ov) return DCS_OK;
+    std::vector<float> r(ov > 0 ? ov : 1, 0.f);
+    // np.linspace(0., 1.0, num=overlap)  (util.py:306): arange * (1/(ov-1)), last element = 1.0
+    if (ov > 1) {
+        const double step = 1.0 / (double)(ov - 1);
+        for (int i = 0; i < ov; ++i) r[i] = (float)((double)i * step);
+        r[ov - 1] = 1.0f;
+    }
+    if (m->rise_d) {
+        DCS_HIP(hipStreamSynchronize(m->ctx->stream));
+        (void)hipFree(m->rise_d);
+        m->rise_d = nullptr;
+    }
+    DCS_HIP(hipMalloc((void**)&m->rise_d, r.size() * sizeof(float)));
+    DCS_HIP(hipMemcpy(m->rise_d, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
+    m->rise_ov = ov;
+    return DCS_OK;
+}
+
+// Re-layout of the DSD parameters into the GEMM operands (see DESIGN.md "weight packing").
+int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
+    const Dims& d = m->d;
+    const int F = m->F;
+    const int CI = (int)dcs_round_up(d.nf1, 4), CP = (int)dcs_round_up(d.nf2, 4);
+    m->CI = CI;
+    m->CP = CP;
+    m->K1 = (int)dcs_round_up(F, 4);
+    m->F64 = (int)dcs_round_up(F, 64);
+    m->ncp = (int)dcs_round_up(d.kh2 * CI, 16);
+    m->hid64 = (int)dcs_round_up(d.hidden, 64);
+    m->nd = d.n_fc * d.h2 * CP;
+    m->nd64 = (int)dcs_round_up(m->nd, 64);
+    if (CI > 64 || CP > 64) DCS_FAIL(DCS_EUNSUPPORTED, "dsd packing: more than 64 filters");
+    const float *W1 = P[0].data(), *b1 = P[1].data(), *b1b = P[2].data();
+    const float *W2 = P[3].data(), *b2 = P[4].data(), *b2b = P[5].data();
+    const float *Wfc = P[6].data(), *bfc = P[7].data();
+
+    // conv1 (true convolution = correlation with the flipped filter): B1[f][c] = W1[c,0,0,F-1-f]
+    std::vector<float> B1((size_t)dcs_round_up(m->K1, 32) * 64, 0.f), bias1(64, 0.f);
+    for (int c = 0; c < d.nf1; ++c) {
+        for (int f = 0; f < F; ++f) B1[(size_t)f * 64 + c] = W1[(size_t)c * F + (F - 1 - f)];
+        bias1[c] = b1[c] + b1b[c];
+    }
+    // conv2: B2[u*CI + ci][co] = W2[co,ci,kh-1-u,0]
+    const int kh = d.kh2;
+    std::vector<float> B2((size_t)dcs_round_up(kh * CI, 32) * 64, 0.f), bias2(64, 0.f);
+    for (int co = 0; co < d.nf2; ++co) {
+        for (int ci = 0; ci < d.nf1; ++ci)
+            for (int u = 0; u < kh; ++u)
+                B2[(size_t)(u * CI + ci) * 64 + co] = W2[((size_t)co * d.nf1 + ci) * kh + (kh - 1 - u)];
+        bias2[co] = b2[co] + b2b[co];
+    }
+    // bottleneck: input index of the flattened [nf2, h2, 1] map is co*h2 + t'; ours is t'*CP + co
+    std::vector<float> Bfc((size_t)dcs_round_up(d.h2 * CP, 32) * m->hid64, 0.f), biasfc(m->hid64, 0.f);
+    for (int co = 0; co < d.nf2; ++co)
+        for (int t = 0; t < d.h2; ++t)
+            for (int h = 0; h < d.hidden; ++h)
+                Bfc[(size_t)(t * CP + co) * m->hid64 + h] = Wfc[(size_t)(co * d.h2 + t) * d.hidden + h];
+    for (int h = 0; h < d.hidden; ++h) biasfc[h] = bfc[h];
+    // per-source dense layers, concatenated along N and permuted to [branch][t'][co]
+    std::vector<float> Bd((size_t)dcs_round_up(m->hid64, 32) * m->nd64, 0.f), biasd(m->nd64, 0.f);
+    for (int s = 0; s < d.n_fc; ++s) {
+        const float* Ws = P[8 + 2 * s].data();
+        const float* bs = P[9 + 2 * s].data();
+        for (int co = 0; co < d.nf2; ++co)
+            for (int t = 0; t < d.h2; ++t) {
+                const size_t col = (size_t)(s * d.h2 + t) * CP + co;
+                for (int h = 0; h < d.hidden; ++h) Bd[(size_t)h * m->nd64 + col] = Ws[(size_t)h * d.flat + co * d.h2 + t];
+                biasd[col] = bs[co * d.h2 + t];
+            }
+    }
+    // transposed conv2: Bw2[co][dt*CI + ci] = W2[co,ci,kh-1-dt,0]
+    std::vector<float> Bw2((size_t)CP * m->ncp, 0.f);
+    for (int co = 0; co < d.nf2; ++co)
+        for (int ci = 0; ci < d.nf1; ++ci)
+            for (int dt = 0; dt < kh; ++dt)
+                Bw2[(size_t)co * m->ncp + dt * CI + ci] = W2[((size_t)co * d.nf1 + ci) * kh + (kh - 1 - dt)];
+    // transposed conv1: Bfin[c][f] = W1[c,0,0,F-1-f]
+    std::vector<float> Bfin((size_t)CI * m->F64, 0.f);
+    for (int c = 0; c < d.nf1; ++c)
+        for (int f = 0; f < F; ++f) Bfin[(size_t)c * m->F64 + f] = W1[(size_t)c * F + (F - 1 - f)];
+    std::vector<float> bout(P[8 + 2 * d.n_fc].begin(), P[8 + 2 * d.n_fc].end());
+
+    DCS_CHECK(upload(&m->B1, B1));
+    DCS_CHECK(upload(&m->bias1, bias1));
+    DCS_CHECK(upload(&m->B2, B2));
+    DCS_CHECK(upload(&m->bias2, bias2));
+    DCS_CHECK(upload(&m->Bfc, Bfc));
+    DCS_CHECK(upload(&m->biasfc, biasfc));
+    DCS_CHECK(upload(&m->Bd, Bd));
+    DCS_CHECK(upload(&m->biasd, biasd));
+    DCS_CHECK(upload(&m->Bw2, Bw2));
+    DCS_CHECK(upload(&m->Bfin, Bfin));
+    DCS_CHECK(upload(&m->bout, bout));
+    return DCS_OK;
+}
+
+struct DsdScratch {
+    float *H1, *C2, *Z, *D, *G;
+};
+
+// Encoder + dense layers + transposed conv2 for n tiles whose frames are rows of `rows_src`.
+//   fused   : rows_src = scaled spectrogram rows (frame t), tile k starts at frame k*st
+//   per tile: rows_src = tile frames (k*tc + j)
+int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, float a_scale, int64_t n,
+               int64_t tile_row_stride /* st or tc */, bool shared_frames, const DsdScratch& w) {
+    const Dims& d = m->d;
+    const int tc = m->tc, CI = m->CI, CP = m->CP;
+    const int64_t BIG = (int64_t)1 << 40;
+    // conv1 + both biases  (separate_dsd.py:198-199)
+    const int64_t n_rows1 = shared_frames ? (n - 1) * tile_row_stride + tc : n * tc;
+    DcsGemm g1{};
+    g1.A = rows_src; g1.lda = lda; g1.a_gdiv = 1 << 30; g1.a_gmul = 0; g1.a_scale = a_scale;
+    g1.B = m->B1; g1.ldb = 64; g1.bias = m->bias1;
+    g1.C = w.H1; g1.ldc = CI; g1.c_gdiv = 1 << 30; g1.c_gmul = 0;
+    g1.M = n_rows1; g1.n_cols = 64; g1.n_store = CI; g1.K = a_vec ? m->K1 : m->F; g1.relu = 0; g1.a_vec = a_vec;
+    (void)BIG;
+    DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g1, DCS_TAG_CONV1));
+    // conv2 + both biases (separate_dsd.py:202-203): output row = position; its A row is kh consecutive H1 rows
+    DcsGemm g2{};
+    g2.A = w.H1; g2.lda = CI; g2.a_scale = 1.f;
+    if (shared_frames) { g2.a_gdiv = 1 << 30; g2.a_gmul = 0; g2.M = (n - 1) * tile_row_stride + d.h2; }
+    else { g2.a_gdiv = d.h2; g2.a_gmul = tc; g2.M = n * d.h2; }
+    g2.B = m->B2; g2.ldb = 64; g2.bias = m->bias2;
+    g2.C = w.C2; g2.ldc = CP; g2.c_gdiv = 1 << 30; g2.c_gmul = 0;
+    g2.n_cols = 64; g2.n_store = CP; g2.K = d.kh2 * CI; g2.relu = 0; g2.a_vec = 1;
+    DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g2, DCS_TAG_CONV2));
+    // bottleneck DenseLayer, rectify (separate_dsd.py:206): A row of tile k = h2 consecutive C2 rows
+    DcsGemm g3{};
+    g3.A = w.C2; g3.lda = (shared_frames ? tile_row_stride : d.h2) * (int64_t)CP; g3.a_gdiv = 1 << 30; g3.a_gmul = 0;
+    g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc;
+    g3.C = w.Z; g3.ldc = m->hid64; g3.c_gdiv = 1 << 30; g3.c_gmul = 0;
+    g3.M = n; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
+    DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g3, DCS_TAG_FC));
+    // per-source DenseLayers, rectify (separate_dsd.py:209,215,221)
+    DcsGemm g4{};
+    g4.A = w.Z; g4.lda = m->hid64; g4.a_gdiv = 1 << 30; g4.a_gmul = 0; g4.a_scale = 1.f;
+    g4.B = m->Bd; g4.ldb = m->nd64; g4.bias = m->biasd;
+    g4.C = w.D; g4.ldc = m->nd; g4.c_gdiv = 1 << 30; g4.c_gmul = 0;
+    g4.M = n; g4.n_cols = m->nd64; g4.n_store = m->nd; g4.K = m->hid64; g4.relu = 1; g4.a_vec = 1;
+    DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
+    // InverseLayer(., l_conv2) (separate_dsd.py:211,217,223)
+    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, w.G, n * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->ncp);
+}
+
+size_t dsd_scratch_bytes(const dcs_model* m, int64_t n, int64_t rows1, int64_t rows2) {
+    return align256((size_t)rows1 * m->CI * 4) + align256((size_t)rows2 * m->CP * 4) +
+           align256((size_t)n * m->hid64 * 4) + align256((size_t)n * m->nd * 4) +
+           align256((size_t)n * m->d.n_fc * m->tc * m->CI * 4);
+}
+
+char* dsd_carve(const dcs_model* m, char* p, int64_t n, int64_t rows1, int64_t rows2, DsdScratch* w) {
+    w->H1 = (float*)p; p += align256((size_t)rows1 * m->CI * 4);
+    w->C2 = (float*)p; p += align256((size_t)rows2 * m->CP * 4);
+    w->Z = (float*)p; p += align256((size_t)n * m->hid64 * 4);
+    w->D = (float*)p; p += align256((size_t)n * m->nd * 4);
+    w->G = (float*)p; p += align256((size_t)n * m->d.n_fc * m->tc * m->CI * 4);
+    return p;
+}
+
+int dsd_forward_tiles(dcs_model* m, const float* tiles, int64_t n, int mask_mode, float* out) {
+    const int tc = m->tc, F = m->F;
+    const int64_t rows1 = n * tc, rows2 = n * m->d.h2;
+    DCS_CHECK(m->ws.ensure(dsd_scratch_bytes(m, n, rows1, rows2)));
+    DsdScratch w;
+    dsd_carve(m, (char*)m->ws.ptr, n, rows1, rows2, &w);
+    const bool vec = (F % 4 == 0) && (((uintptr_t)tiles & 15) == 0);
+    DCS_CHECK(dsd_encode(m, tiles, F, vec, 1.f, n, tc, false, w));
+    DCS_CHECK(ensure_rise(m, 1));
+    DsdFinalArgs a{};
+    a.G = w.G; a.Bw = m->Bfin; a.ldb = m->F64; a.bias = m->bout;
+    a.mix = tiles; a.mix_ld = F; a.mix_scale = 1.f;
+    a.out = out; a.out_src_stride = n * tc * (int64_t)F; a.out_ld = F;
+    a.rise = m->rise_d; a.n = n; a.rows = n * tc; a.tc = tc; a.ov = 0; a.st = tc;
+    a.F = F; a.CI = m->CI; a.mmax = 1; a.mask_mode = mask_mode;
+    return dcs_launch_dsd_final(m->ctx, a, false);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int dcs_model_create(dcs_ctx* ctx, int arch, int C, int tc, int F, const float* const* params_d,
+                                const int64_t* shapes, int nparams, dcs_model** out) {
+    if (!ctx || !params_d || !shapes || !out) DCS_FAIL(DCS_EINVAL, "dcs_model_create: null argument");
+    if (tc < 2 || F < 1) DCS_FAIL(DCS_EINVAL, "dcs_model_create: bad time_context / feature size");
+    Dims d;
+    DCS_CHECK(arch_dims(arch, C, tc, F, &d));
+    // expected shapes in get_all_params order
+    std::vector<std::vector<int64_t>> expect;
+    expect.push_back({d.nf1, C, 1, d.kw1});
+    expect.push_back({d.nf1});
+    expect.push_back({d.nf1});
+    expect.push_back({d.nf2, d.nf1, d.kh2, d.kw2});
+    expect.push_back({d.nf2});
+    expect.push_back({d.nf2});
+    expect.push_back({d.flat, d.hidden});
+    expect.push_back({d.hidden});
+    for (int i = 0; i < d.n_fc; ++i) {
+        expect.push_back({d.hidden, d.flat});
+        expect.push_back({d.flat});
+    }
+    expect.push_back({(int64_t)d.n_branch * C});
+    if (nparams != (int)expect.size())
+        DCS_FAIL(DCS_ESHAPE, "mismatch: got %d values to set %d parameters", nparams, (int)expect.size());
+    std::vector<std::vector<float>> P(nparams);
+    DCS_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < nparams; ++i) {
+        int64_t cnt = 1;
+        for (int k = 0; k < 4; ++k) {
+            const int64_t want = k < (int)expect[i].size() ? expect[i][k] : 1;
+            if (shapes[i * 4 + k] != want)
+                DCS_FAIL(DCS_ESHAPE, "mismatch: parameter %d has shape dim %d = %lld but value to set has %lld", i, k,
+                         (long long)want, (long long)shapes[i * 4 + k]);
+            cnt *= want;
+        }
+        if (!params_d[i]) DCS_FAIL(DCS_EINVAL, "dcs_model_create: parameter %d is null", i);
+        P[i].resize((size_t)cnt);
+        DCS_HIP(hipMemcpy(P[i].data(), params_d[i], (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    dcs_model* m = new dcs_model();
+    m->ctx = ctx;
+    m->arch = arch;
+    m->C = C;
+    m->tc = tc;
+    m->F = F;
+    m->d = d;
+    int rc;
+    if (arch == DCS_ARCH_DSD) {
+        rc = pack_dsd(m, P);
+    } else {
+        DcsGenericDims gd{d.nf1, d.kw1, d.sw1, d.w1, d.pool_w, d.wp, d.nf2, d.kh2, d.kw2, d.h2, d.w2,
+                          d.flat, d.hidden, d.n_fc, d.n_branch, d.S, {d.branch_fc[0], d.branch_fc[1],
+                          d.branch_fc[2], d.branch_fc[3]}};
+        rc = dcs_generic_create(ctx, gd, C, tc, F, P, &m->gen);
+    }
+    if (rc != DCS_OK) {
+        dcs_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return DCS_OK;
+}
+
+extern "C" int dcs_model_destroy(dcs_model* m) {
+    if (!m) return DCS_OK;
+    float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bfin, m->bout,
+                     m->rise_d};
+    for (float* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (m->gen) dcs_generic_destroy(m->gen);
+    m->ws.release();
+    delete m;
+    return DCS_OK;
+}
+
+extern "C" int dcs_model_num_sources(const dcs_model* m) { return m ? m->d.S : DCS_EINVAL; }
+extern "C" int dcs_model_out_channels(const dcs_model* m) { return m ? m->d.n_branch * m->C : DCS_EINVAL; }
+
+static int forward_any(dcs_model* m, const float* tiles_d, int64_t n, int mask_mode, int tie_mode, float* out_d) {
+    if (!m || !tiles_d || !out_d) DCS_FAIL(DCS_EINVAL, "dcs_model_forward: null argument");
+    if (n < 0) DCS_FAIL(DCS_EINVAL, "dcs_model_forward: negative tile count");
+    if (tie_mode != DCS_TIE_ALL && tie_mode != DCS_TIE_FIRST) DCS_FAIL(DCS_EINVAL, "bad tie_mode");
+    if (n == 0) return DCS_OK;
+    DCS_HIP(hipSetDevice(m->ctx->device));
+    if (m->arch == DCS_ARCH_DSD) return dsd_forward_tiles(m, tiles_d, n, mask_mode, out_d);
+    return dcs_generic_forward(m->gen, tiles_d, n, mask_mode, tie_mode, out_d);
+}
+
+extern "C" int dcs_model_forward_masked(dcs_model* m, const float* tiles_d, int64_t n, int eps_mode, int tie_mode,
+                                        float* out_d) {
+    if (eps_mode != DCS_EPS_A && eps_mode != DCS_EPS_B) DCS_FAIL(DCS_EINVAL, "bad eps_mode");
+    return forward_any(m, tiles_d, n, eps_mode, tie_mode, out_d);
+}
+
+extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, int tie_mode, float* p_d) {
+    return forward_any(m, tiles_d, n, 2, tie_mode, p_d);
+}
+
+// ------------------------------------------------------------------------------------------------ fused path
+static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t L, int ov, int tiler, float scale,
+                         int eps_mode, int tie_mode, float* pcm_d, float* sep_out, float* mag_out, float* phase_out,
+                         int64_t ld_out, int64_t* n_tiles_out, int64_t* n_frames_out) {
+    if (!m || !plan || !audio_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: null argument");
+    if (plan->ctx != m->ctx) DCS_FAIL(DCS_EINVAL, "dcs_separate: plan and model belong to different contexts");
+    if (plan->frame / 2 + 1 != m->F)
+        DCS_FAIL(DCS_EINVAL, "dcs_separate: frameSize %d gives %d bins, network was built for %d", plan->frame,
+                 plan->frame / 2 + 1, m->F);
+    if (m->C != 1) DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate: multi-channel (score-informed) input needs the host front-end");
+    if (ov < 1 || ov >= m->tc) DCS_FAIL(DCS_EINVAL, "dcs_separate: overlap %d not in [1, %d)", ov, m->tc);
+    if (scale == 0.f) DCS_FAIL(DCS_EINVAL, "dcs_separate: scale_factor is zero");
+    if (eps_mode != DCS_EPS_A && eps_mode != DCS_EPS_B) DCS_FAIL(DCS_EINVAL, "bad eps_mode");
+    if (L < 1) DCS_FAIL(DCS_EINVAL, "dcs_separate: empty signal");
+    DCS_HIP(hipSetDevice(m->ctx->device));
+    const int tc = m->tc, F = m->F, st = tc - ov, S = m->d.S;
+    const int64_t T = dcs_frame_count(L, plan->hop);
+    const int64_t n = dcs_tile_count(T, tc, ov, tiler);
+    if (n_tiles_out) *n_tiles_out = n;
+    if (n_frames_out) *n_frames_out = T;
+    if (n < 1)
+        DCS_FAIL(DCS_EINVAL, "dcs_separate: %lld frames give no tile (the reference fails in overlapadd_multi)",
+                 (long long)T);
+    const int64_t Tcov = (n - 1) * st + tc;       // frames covered by the tiles
+    const int64_t Trows = Tcov > T ? Tcov : T;    // zero rows past T feed the zero-padding tiler
+    const int64_t ld = dcs_round_up(F, 4);
+    const size_t b_mag = align256((size_t)Trows * ld * 4), b_ph = b_mag;  // the STFT also zero-fills phase rows past T
+    const size_t b_sep = align256((size_t)S * T * ld * 4);
+
+    if (m->arch == DCS_ARCH_DSD) {
+        const int64_t rows2 = (n - 1) * st + m->d.h2;
+        DCS_CHECK(m->ws.ensure(b_mag + b_ph + b_sep + dsd_scratch_bytes(m, n, Tcov, rows2)));
+        char* p = (char*)m->ws.ptr;
+        float* mag = (float*)p; p += b_mag;
+        float* phase = (float*)p; p += b_ph;
+        float* sep = (float*)p; p += b_sep;
+        DsdScratch w;
+        dsd_carve(m, p, n, Tcov, rows2, &w);
+        DCS_CHECK(dcs_launch_stft_forward_f32(plan, audio_d, L, mag, phase, ld, Trows, T));
+        DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w));
+        DCS_CHECK(ensure_rise(m, ov));
+        DsdFinalArgs a{};
+        a.G = w.G; a.Bw = m->Bfin; a.ldb = m->F64; a.bias = m->bout;
+        a.mix = mag; a.mix_ld = ld; a.mix_scale = scale;
+        a.out = sep; a.out_src_stride = T * ld; a.out_ld = ld;
+        a.rise = m->rise_d; a.n = n; a.rows = T; a.tc = tc; a.ov = ov; a.st = st;
+        a.F = F; a.CI = m->CI; a.mmax = (ov + st - 1) / st + 1; a.mask_mode = eps_mode;
+        DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
+        if (pcm_d) DCS_CHECK(dcs_launch_stft_inverse_f32(plan, sep, T * ld, phase, ld, T, S, scale, pcm_d, L));
+        if (sep_out || mag_out || phase_out) {
+            for (int s = 0; s < S && sep_out; ++s)
+                DCS_HIP(hipMemcpy2DAsync(sep_out + (int64_t)s * T * ld_out, ld_out * 4, sep + (int64_t)s * T * ld, ld * 4,
+                                         (size_t)F * 4, (size_t)T, hipMemcpyDeviceToDevice, m->ctx->stream));
+            if (mag_out)
+                DCS_HIP(hipMemcpy2DAsync(mag_out, ld_out * 4, mag, ld * 4, (size_t)F * 4, (size_t)T,
+                                         hipMemcpyDeviceToDevice, m->ctx->stream));
+            if (phase_out)
+                DCS_HIP(hipMemcpy2DAsync(phase_out, ld_out * 4, phase, ld * 4, (size_t)F * 4, (size_t)T,
+                                         hipMemcpyDeviceToDevice, m->ctx->stream));
+        }
+        return DCS_OK;
+    }
+    return dcs_generic_separate(m->gen, plan, audio_d, L, ov, tiler, scale, eps_mode, tie_mode, pcm_d, sep_out, mag_out,
+                                phase_out, ld_out, &m->ws);
+}
+
+extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
+                            int tiler, float scale, int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
+                            int64_t* n_frames_out) {
+    if (!pcm_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: pcm_d is null");
+    return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr, nullptr,
+                         nullptr, 0, n_tiles_out, n_frames_out);
+}
+
+extern "C" int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
+                                    int tiler, float scale, int eps_mode, int tie_mode, float* sep_d, float* mag_d,
+                                    float* phase_d, int64_t ld_out) {
+    if (m && ld_out < m->F) DCS_FAIL(DCS_EINVAL, "dcs_separate_spectra: ld_out < bins");
+    return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, nullptr, sep_d, mag_d,
+                         phase_d, ld_out, nullptr, nullptr);
+}

@@ -1,0 +1,79 @@
+// Tiling and cross-fade overlap-add kernels (HBM-bound copies / blends).
+//
+// generate_overlapadd : examples/dsd100/separate_dsd.py:114-135 (script tiler), util.py:220-248
+// overlapadd_multi    : util.py:297-327 (= separate_dsd.py:139-169), 2-source util.py:251-294
+#include "dcs_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// tiles[i][c][j][:] = scale * mag[c][i*stride + j][:]  (zero rows past T: library tiler only;
+// the script tiler never produces such rows because start + tc < T)
+__global__ __launch_bounds__(kThreads) void tile_kernel(const float* __restrict__ mag, int64_t ch_stride,
+                                                        int64_t ld, int C, int64_t T, int F, int tc, int stride,
+                                                        float scale, float* __restrict__ tiles) {
+    const int64_t i = blockIdx.x;
+    const int cj = blockIdx.y;
+    const int c = cj / tc, j = cj % tc;
+    const int64_t t = i * stride + j;
+    float* dst = tiles + ((i * C + c) * tc + j) * (int64_t)F;
+    if (t < T) {
+        const float* src = mag + c * ch_stride + t * ld;
+        for (int f = threadIdx.x; f < F; f += kThreads) dst[f] = scale * src[f];
+    } else {
+        for (int f = threadIdx.x; f < F; f += kThreads) dst[f] = 0.f;
+    }
+}
+
+// Frame-parallel form of the sequential stitch.  Output frame t is owned by the last tile k0 whose
+// copy region [k0*st+ov, k0*st+tc) contains it (tile 0 also owns t < ov); every later tile k with
+// k*st <= t then blends:  acc = fall[j]*acc + rise[j]*tile[k][j],  j = t - k*st < ov, in increasing
+// k -- the same operands in the same order as util.py:321-325, so the float result is the
+// sequential one.
+__global__ __launch_bounds__(kThreads) void overlap_add_kernel(const float* __restrict__ out, int64_t n, int S,
+                                                               int tc, int ov, int F,
+                                                               const float* __restrict__ rise,
+                                                               float* __restrict__ sep, int64_t sep_stride,
+                                                               int64_t ld) {
+    const int64_t t = blockIdx.x;
+    const int s = blockIdx.y;
+    const int st = tc - ov;
+    float* dst = sep + s * sep_stride + t * ld;
+    int64_t k0 = (t < ov) ? 0 : (t - ov) / st;
+    if (k0 > n - 1) k0 = n - 1;
+    const int64_t j0 = (n > 0) ? t - k0 * st : tc;
+    if (j0 >= tc) {  // past the last tile: the zeros of util.py:313
+        for (int f = threadIdx.x; f < F; f += kThreads) dst[f] = 0.f;
+        return;
+    }
+    const float* src = out + (int64_t)s * n * tc * F;
+    for (int f = threadIdx.x; f < F; f += kThreads) {
+        float acc = src[(k0 * tc + j0) * F + f];
+        for (int64_t k = k0 + 1; k < n && k * st <= t; ++k) {
+            const int j = (int)(t - k * st);
+            acc = rise[ov - 1 - j] * acc + rise[j] * src[(k * tc + j) * F + f];
+        }
+        dst[f] = acc;
+    }
+}
+
+}  // namespace
+
+int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F, int tc,
+                    int ov, int tiler, float scale, float* tiles, int64_t n) {
+    (void)tiler;
+    hipLaunchKernelGGL(tile_kernel, dim3((unsigned)n, (unsigned)(C * tc)), dim3(kThreads), 0, ctx->stream, mag,
+                       ch_stride, ld, C, T, F, tc, tc - ov, scale, tiles);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+int dcs_launch_overlap_add(dcs_ctx* ctx, const float* out, int64_t n, int S, int tc, int ov, int F,
+                           const float* rise_d, float* sep, int64_t sep_stride, int64_t ld) {
+    const int64_t rows = n * (tc - ov) + tc;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)rows, (unsigned)S), dim3(kThreads), 0, ctx->stream, out,
+                       n, S, tc, ov, F, rise_d, sep, sep_stride, ld);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}

@@ -1,0 +1,294 @@
+"""Thin object layer over the C ABI: Context, StftPlan, Network.
+
+PyTorch-ROCm is used for exactly three things here: allocating device memory
+(``torch.empty(..., device='cuda')``), host<->device copies, and naming the HIP
+stream the kernels run on.  No torch operator computes anything on the path.
+"""
+import ctypes
+from ctypes import POINTER, byref, c_double, c_int64, c_void_p
+
+import numpy as np
+
+from . import _lib
+from .arch import ARCHS, EPS_A, EPS_B, TIE_ALL, TIE_FIRST, TILER_LIBRARY, TILER_SCRIPT, check_params
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("deepconvsep_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                           "and there is no CPU fallback")
+    return torch
+
+
+class Context(object):
+    """One device + one HIP stream (``dcs_ctx``)."""
+
+    def __init__(self, device=None):
+        torch = require_gpu()
+        lib = _lib.load()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        with torch.cuda.device(self.device_index):
+            stream = torch.cuda.current_stream().cuda_stream
+        h = c_void_p()
+        _lib.check(lib.dcs_create(self.device_index, c_void_p(stream), byref(h)))
+        self._h = h
+        self._lib = lib
+
+    # -- memory plumbing ------------------------------------------------------------------
+    def to_device(self, array, dtype):
+        torch = _torch()
+        a = np.ascontiguousarray(array, dtype=dtype)
+        return torch.from_numpy(a).to(self.device)
+
+    def empty(self, shape, dtype):
+        torch = _torch()
+        tdt = {np.float32: torch.float32, np.float64: torch.float64}[dtype]
+        return torch.empty(tuple(int(s) for s in shape), dtype=tdt, device=self.device)
+
+    def synchronize(self):
+        _lib.check(self._lib.dcs_synchronize(self._h))
+
+    # -- kernel timing (bench.py) ---------------------------------------------------------------
+    def timing(self, tags):
+        """Bracket the kernels of the named tags (``_lib.TAGS`` keys; ``'all'``; ``None`` = off) with HIP events."""
+        if not tags:
+            mask = 0
+        elif tags == 'all':
+            mask = (1 << len(_lib.TAGS)) - 1
+        else:
+            mask = 0
+            for t in tags:
+                mask |= 1 << _lib.TAGS[t]
+        _lib.check(self._lib.dcs_timing_enable(self._h, mask))
+
+    def timing_reset(self):
+        _lib.check(self._lib.dcs_timing_reset(self._h))
+
+    def timing_query(self, tag):
+        ms, cnt = c_double(), c_int64()
+        _lib.check(self._lib.dcs_timing_query(self._h, _lib.TAGS[tag], byref(ms), byref(cnt)))
+        return ms.value, cnt.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dcs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    torch = require_gpu()
+    idx = torch.cuda.current_device() if device is None else int(device)
+    if idx not in _default_ctx:
+        _default_ctx[idx] = Context(idx)
+    return _default_ctx[idx]
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(None)
+
+
+class StftPlan(object):
+    """``dcs_stft``: window + twiddle tables for one (frameSize, hopSize, window)."""
+
+    def __init__(self, ctx, frame, hop, window):
+        self.ctx = ctx
+        self.frame, self.hop = int(frame), int(hop)
+        self.bins = self.frame // 2 + 1
+        w = np.ascontiguousarray(window, dtype=np.float64)
+        if w.shape != (self.frame,):
+            raise ValueError("window must have frameSize=%d samples, got %r" % (self.frame, w.shape))
+        self.window = w
+        h = c_void_p()
+        _lib.check(ctx._lib.dcs_stft_plan(ctx._h, self.frame, self.hop, w.ctypes.data_as(POINTER(c_double)), byref(h)))
+        self._h = h
+
+    def forward(self, audio_t, phase=True, rows_out=None, ld=None):
+        """audio_t: 1-D float32/float64 device tensor.  Returns (mag, phase|None) device tensors
+        ``[rows_out, ld]`` (defaults: the reference's dense ``[T, bins]``)."""
+        torch = _torch()
+        L = int(audio_t.numel())
+        T = _lib.frame_count(L, self.hop)
+        rows = T if rows_out is None else int(rows_out)
+        ld = self.bins if ld is None else int(ld)
+        f64 = audio_t.dtype == torch.float64
+        mag = torch.empty((rows, ld), dtype=audio_t.dtype, device=audio_t.device)
+        ph = torch.empty((rows, ld), dtype=audio_t.dtype, device=audio_t.device) if phase else None
+        fn = self.ctx._lib.dcs_stft_forward_f64 if f64 else self.ctx._lib.dcs_stft_forward_f32
+        _lib.check(fn(self._h, _ptr(audio_t), L, _ptr(mag), _ptr(ph), ld, rows))
+        return mag, ph
+
+    def inverse(self, mag_t, phase_t, n_out=None, pre_div=1.0):
+        """mag_t ``[S, T, ld]`` or ``[T, ld]``, phase_t ``[T, ld]`` (same ld).  Returns ``[S, n_out]``
+        (or ``[n_out]``)."""
+        torch = _torch()
+        squeeze = mag_t.dim() == 2
+        if squeeze:
+            mag_t = mag_t.unsqueeze(0)
+        S, T, ld = (int(x) for x in mag_t.shape)
+        if tuple(phase_t.shape) != (T, ld):
+            raise ValueError("phase shape %r does not match magnitude %r" % (tuple(phase_t.shape), (T, ld)))
+        mag_t = mag_t.contiguous()
+        phase_t = phase_t.contiguous()
+        full = _lib.inverse_length(T, self.hop, self.frame)
+        n_out = full if n_out is None else min(int(n_out), full)
+        out = torch.empty((S, n_out), dtype=mag_t.dtype, device=mag_t.device)
+        if mag_t.dtype == torch.float64:
+            _lib.check(self.ctx._lib.dcs_stft_inverse_f64(self._h, _ptr(mag_t), T * ld, _ptr(phase_t), ld, T, S,
+                                                          float(pre_div), _ptr(out), n_out))
+        else:
+            _lib.check(self.ctx._lib.dcs_stft_inverse_f32(self._h, _ptr(mag_t), T * ld, _ptr(phase_t), ld, T, S,
+                                                          float(pre_div), _ptr(out), n_out))
+        return out[0] if squeeze else out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.dcs_stft_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Network(object):
+    """``dcs_model``: one ``build_ca`` graph with its parameters resident in HBM.
+
+    ``params`` is the list ``lasagne.layers.get_all_param_values`` pickled by the reference's
+    trainers (examples/dsd100/trainCNN.py:59-64); a count/shape mismatch raises ``ValueError``
+    like ``set_all_param_values`` does (examples/dsd100/separate_dsd.py:250).
+    """
+
+    def __init__(self, ctx, arch, params, time_context=30, feat_size=513):
+        self.ctx = ctx
+        self.arch = ARCHS[arch] if isinstance(arch, str) else arch
+        self.tc, self.F = int(time_context), int(feat_size)
+        params = [np.asarray(p) for p in params]
+        check_params(self.arch, params, self.tc, self.F)
+        # weight tensors hosted by torch (float32, as the pickles store them)
+        self._params = [ctx.to_device(p, np.float32) for p in params]
+        n = len(self._params)
+        ptrs = (c_void_p * n)(*[p.data_ptr() for p in self._params])
+        shapes = (c_int64 * (4 * n))()
+        for i, p in enumerate(params):
+            shp = list(p.shape) + [1] * (4 - p.ndim)
+            for k in range(4):
+                shapes[4 * i + k] = shp[k]
+        h = c_void_p()
+        _lib.check(ctx._lib.dcs_model_create(ctx._h, self.arch.code, self.arch.C, self.tc, self.F, ptrs, shapes, n,
+                                             byref(h)))
+        self._h = h
+        self.S = int(ctx._lib.dcs_model_num_sources(h))
+        self.out_channels = int(ctx._lib.dcs_model_out_channels(h))
+
+    def forward_masked(self, tiles_t, eps_mode=None, tie_mode=TIE_ALL):
+        """tiles_t ``[n, C, tc, F]`` float32 device tensor -> ``[S, n, tc, F]``."""
+        torch = _torch()
+        n = int(tiles_t.shape[0])
+        if tuple(tiles_t.shape[1:]) != (self.arch.C, self.tc, self.F):
+            raise ValueError("input tiles %r do not match network input (n, %d, %d, %d)"
+                             % (tuple(tiles_t.shape), self.arch.C, self.tc, self.F))
+        tiles_t = tiles_t.contiguous()
+        out = torch.empty((self.S, n, self.tc, self.F), dtype=torch.float32, device=tiles_t.device)
+        eps = self.arch.eps_mode if eps_mode is None else eps_mode
+        _lib.check(self.ctx._lib.dcs_model_forward_masked(self._h, _ptr(tiles_t), n, int(eps), int(tie_mode), _ptr(out)))
+        return out
+
+    def forward_raw(self, tiles_t, tie_mode=TIE_ALL):
+        """Network output before masking, ``[n, out_channels, tc, F]`` (testing aid).  For the DSD
+        graph the kernel emits channel-major ``[out_channels, n, tc, F]``; it is permuted here."""
+        torch = _torch()
+        n = int(tiles_t.shape[0])
+        tiles_t = tiles_t.contiguous()
+        out = torch.empty((self.out_channels, n, self.tc, self.F), dtype=torch.float32, device=tiles_t.device)
+        _lib.check(self.ctx._lib.dcs_model_forward(self._h, _ptr(tiles_t), n, int(tie_mode), _ptr(out)))
+        return out.permute(1, 0, 2, 3).contiguous()
+
+    def separate(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None, tie_mode=TIE_ALL,
+                 out=None):
+        """Fused file-level path: 1-D float32 device tensor -> ``[S, L]`` float32 PCM."""
+        torch = _torch()
+        L = int(audio_t.numel())
+        if out is None:
+            out = torch.empty((self.S, L), dtype=torch.float32, device=audio_t.device)
+        eps = self.arch.eps_mode if eps_mode is None else eps_mode
+        nt, nf = c_int64(), c_int64()
+        _lib.check(self.ctx._lib.dcs_separate(self._h, plan._h, _ptr(audio_t), L, int(overlap), int(tiler),
+                                              float(scale), int(eps), int(tie_mode), _ptr(out), byref(nt), byref(nf)))
+        self.last_tiles, self.last_frames = nt.value, nf.value
+        return out
+
+    def separate_spectra(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None,
+                         tie_mode=TIE_ALL):
+        """Fused path stopped before the iSTFT: (sep ``[S,T,F]``, mag ``[T,F]``, phase ``[T,F]``)."""
+        torch = _torch()
+        L = int(audio_t.numel())
+        T = _lib.frame_count(L, plan.hop)
+        F = self.F
+        sep = torch.empty((self.S, T, F), dtype=torch.float32, device=audio_t.device)
+        mag = torch.empty((T, F), dtype=torch.float32, device=audio_t.device)
+        ph = torch.empty((T, F), dtype=torch.float32, device=audio_t.device)
+        eps = self.arch.eps_mode if eps_mode is None else eps_mode
+        _lib.check(self.ctx._lib.dcs_separate_spectra(self._h, plan._h, _ptr(audio_t), L, int(overlap), int(tiler),
+                                                      float(scale), int(eps), int(tie_mode), _ptr(sep), _ptr(mag),
+                                                      _ptr(ph), F))
+        return sep, mag, ph
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.dcs_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tile(ctx, mag_t, time_context, overlap, tiler, scale=1.0):
+    """``generate_overlapadd`` on the device: mag_t ``[T,F]`` or ``[C,T,F]`` float32 -> (tiles
+    ``[n,C,tc,F]``, n)."""
+    torch = _torch()
+    if mag_t.dim() == 2:
+        mag_t = mag_t.unsqueeze(0)
+    mag_t = mag_t.contiguous()
+    C, T, F = (int(x) for x in mag_t.shape)
+    n = _lib.tile_count(T, time_context, overlap, tiler)
+    tiles = torch.empty((n, C, time_context, F), dtype=torch.float32, device=mag_t.device)
+    if n:
+        _lib.check(ctx._lib.dcs_tile(ctx._h, _ptr(mag_t), T * F, F, C, T, F, int(time_context), int(overlap),
+                                     int(tiler), float(scale), _ptr(tiles), n))
+    return tiles, n
+
+
+def overlap_add(ctx, out_t, overlap):
+    """``overlapadd_multi`` on the device: out_t ``[S, n, tc, F]`` float32 -> ``[S, n*(tc-ov)+tc, F]``."""
+    torch = _torch()
+    out_t = out_t.contiguous()
+    S, n, tc, F = (int(x) for x in out_t.shape)
+    rows = n * (tc - overlap) + tc
+    sep = torch.empty((S, rows, F), dtype=torch.float32, device=out_t.device)
+    rise = np.ascontiguousarray(np.linspace(0., 1.0, num=overlap), dtype=np.float64)
+    _lib.check(ctx._lib.dcs_overlap_add(ctx._h, _ptr(out_t), n, S, tc, int(overlap), F,
+                                        rise.ctypes.data_as(POINTER(c_double)), _ptr(sep), rows * F, F))
+    return sep

@@ -1,0 +1,234 @@
+"""Host-side mirror of the reference's separation scripts, running on the MI355X.
+
+Function names, argument meaning, defaults and error behaviour follow
+``examples/dsd100/separate_dsd.py`` (and its ikala / bach10 / hiphop siblings):
+
+  load_model            separate_dsd.py:17-21
+  generate_overlapadd   separate_dsd.py:114-135 (script tiler) / util.py:220-248 (library tiler)
+  overlapadd_multi      separate_dsd.py:139-169 = util.py:297-327
+  overlapadd            util.py:251-294 (2 sources, separate_ikala.py:138-169)
+  build_ca + theano.function(predict_function2)  ->  ``PredictFunction``   separate_dsd.py:172-273
+  train_auto            separate_dsd.py:239-313
+
+The arithmetic runs in libdcs (HIP); NumPy only moves data in and out.
+"""
+import os
+import pickle
+
+import numpy as np
+import scipy.io.wavfile
+
+from . import _lib
+from .arch import ARCHS, TIE_ALL, TILER_LIBRARY, TILER_SCRIPT
+from .runtime import Network, StftPlan, default_context, overlap_add, tile
+
+
+def blackmanharris(n):
+    """``scipy.signal.blackmanharris`` of the reference's era (separate_bach10.py:4) lives in
+    ``scipy.signal.windows`` today."""
+    from scipy.signal.windows import blackmanharris as _bh
+    return _bh(n)
+
+
+def load_model(filename):
+    """Python-2 cPickle list of float32 ndarrays (examples/dsd100/trainCNN.py:59-64)."""
+    with open(filename, 'rb') as f:
+        try:
+            params = pickle.load(f, encoding='latin1')
+        except TypeError:
+            params = pickle.load(f)
+    return params
+
+
+def save_model(filename, params):
+    with open(filename, 'wb') as f:
+        pickle.dump([np.asarray(p, dtype=np.float32) for p in params], f, protocol=2)
+
+
+_TILERS = {'script': TILER_SCRIPT, 'library': TILER_LIBRARY, TILER_SCRIPT: TILER_SCRIPT, TILER_LIBRARY: TILER_LIBRARY}
+
+
+def generate_overlapadd(allmix, input_size=513, time_context=30, overlap=10, batch_size=32, sampleRate=44100,
+                        tiler='script', device=None):
+    """Tiles of ``time_context`` frames every ``time_context-overlap`` frames, packed as
+    ``fbatch[nb, batch_size, C, time_context, input_size]`` (float64), plus the tile count.
+
+    ``tiler='script'`` drops the tail like separate_dsd.py:123 (``start+tc < T``); slots past the
+    last tile -- uninitialised ``np.empty`` memory in the reference -- are zero here.
+    ``tiler='library'`` zero-pads like util.py:230-243 and accepts ``[C, T, F]`` input.
+    """
+    allmix = np.asarray(allmix)
+    code = _TILERS[tiler]
+    if code == TILER_SCRIPT:
+        if allmix.ndim != 2 or input_size != allmix.shape[-1]:
+            # separate_dsd.py:119: the body is skipped and `fbatch` is unbound
+            raise UnboundLocalError("local variable 'fbatch' referenced before assignment")
+    else:
+        assert input_size == allmix.shape[-1], "Feature size must be the same as the last dimension of the spectrogram"
+    ctx = default_context(device)
+    tiles, n = tile(ctx, ctx.to_device(allmix, np.float32), time_context, overlap, code, 1.0)
+    C = tiles.shape[1]
+    nb = int(np.ceil(float(n) / batch_size))
+    fbatch = np.zeros([nb, batch_size, C, time_context, input_size])
+    if n:
+        fbatch.reshape(nb * batch_size, C, time_context, input_size)[:n] = tiles.cpu().numpy()
+    return fbatch, n
+
+
+def _tiles_from_batches(fbatch, nchunks):
+    """``[nb, S, B, 1, tc, F]`` (np.array of predict_function2 outputs) -> ``[S, nchunks, tc, F]``."""
+    fbatch = np.asarray(fbatch)
+    nb, S, B = fbatch.shape[0], fbatch.shape[1], fbatch.shape[2]
+    tc, F = fbatch.shape[-2], fbatch.shape[-1]
+    t = np.transpose(fbatch[:, :, :, 0], (1, 0, 2, 3, 4)).reshape(S, nb * B, tc, F)
+    return np.ascontiguousarray(t[:, :nchunks])
+
+
+def overlapadd_multi(fbatch, obatch, nchunks, overlap=10, device=None):
+    """Cross-fade stitch of the per-source network outputs (util.py:297-327) ->
+    ``sep[S, nchunks*(tc-overlap)+tc, F]`` float64."""
+    ctx = default_context(device)
+    tiles = _tiles_from_batches(fbatch, nchunks)
+    sep = overlap_add(ctx, ctx.to_device(tiles, np.float32), overlap)
+    return sep.cpu().numpy().astype(np.float64)
+
+
+def overlapadd(fbatch, obatch, nchunks, overlap=10, device=None):
+    """2-source form (util.py:251-294): returns ``(sep1, sep2)``."""
+    sep = overlapadd_multi(np.asarray(fbatch)[:, :2], obatch, nchunks, overlap=overlap, device=device)
+    return sep[0], sep[1]
+
+
+class PredictFunction(object):
+    """What ``theano.function([input_var2], [source_1..source_S])`` is in the reference
+    (separate_dsd.py:273): ``batch[B, C, tc, F] -> list of S arrays [B, 1, tc, F]``.
+
+    ``batch_size`` is not baked into the graph here (the reference fixes it through the
+    InputLayer / ReshapeLayer shapes, separate_dsd.py:192,210): any B works.
+    """
+
+    def __init__(self, arch, params, time_context=30, input_size=513, eps_mode=None, tie_mode=TIE_ALL, device=None):
+        self.ctx = default_context(device)
+        self.net = Network(self.ctx, arch, params, time_context, input_size)
+        self.eps_mode, self.tie_mode = eps_mode, tie_mode
+
+    def __call__(self, batch):
+        batch = np.asarray(batch)
+        out = self.net.forward_masked(self.ctx.to_device(batch, np.float32), self.eps_mode, self.tie_mode)
+        out = out.cpu().numpy().astype(np.float64)
+        return [out[s][:, None] for s in range(out.shape[0])]
+
+
+def read_wav(filein):
+    """wav -> float64 in [-1, 1] the way every script does it (separate_dsd.py:275-282)."""
+    sampleRate, audioObj = scipy.io.wavfile.read(filein)
+    try:
+        maxv = np.finfo(audioObj.dtype).max
+    except Exception:
+        maxv = np.iinfo(audioObj.dtype).max
+    return sampleRate, audioObj.astype('float') / maxv
+
+
+def write_wav(path, audio_out, sampleRate):
+    """``(audio * 32767).astype('int16')`` -- truncation, no clipping (separate_dsd.py:307-309)."""
+    maxn = np.iinfo(np.int16).max
+    scipy.io.wavfile.write(filename=path, rate=sampleRate, data=(audio_out * maxn).astype('int16'))
+
+
+def to_mono(audioObj, arch_name):
+    """DSD / Bach10: mean of L and R when stereo, mono passes through (separate_dsd.py:285-287).
+    iKala: L + R, no halving, and a mono file is an IndexError (separate_ikala.py:229)."""
+    if arch_name == 'ikala':
+        return audioObj[:, 0] + audioObj[:, 1]
+    if len(audioObj.shape) > 1 and audioObj.shape[1] > 1:
+        return (audioObj[:, 0] + audioObj[:, 1]) / 2
+    if len(audioObj.shape) > 1:
+        return audioObj[:, 0]
+    return audioObj
+
+
+class Separator(object):
+    """Model + STFT plan resident on one GPU; ``separate(audio)`` is the body of ``train_auto``
+    between reading and writing the wav files (separate_dsd.py:289-306)."""
+
+    def __init__(self, arch, params, scale_factor=0.3, time_context=30, overlap=25, batch_size=32, input_size=513,
+                 frameSize=1024, hopSize=512, window=np.hanning, tiler='script', tie_mode=TIE_ALL, device=None):
+        self.arch_name = arch
+        self.arch = ARCHS[arch]
+        self.scale_factor, self.tc, self.overlap, self.batch_size = scale_factor, time_context, overlap, batch_size
+        self.input_size, self.frameSize, self.hopSize = input_size, frameSize, hopSize
+        self.tiler, self.tie_mode = _TILERS[tiler], tie_mode
+        if frameSize // 2 + 1 != input_size:
+            raise ValueError("frameSize %d gives %d bins but the network takes %d" % (frameSize, frameSize // 2 + 1,
+                                                                                      input_size))
+        self.ctx = default_context(device)
+        self.window = window(frameSize)
+        self.plan = StftPlan(self.ctx, frameSize, hopSize, self.window)
+        self.net = Network(self.ctx, arch, params, time_context, input_size)
+
+    def separate(self, audio):
+        """Fused device path: float audio ``[L]`` -> float64 ``[S, L]``."""
+        a = self.ctx.to_device(np.asarray(audio), np.float32)
+        pcm = self.net.separate(self.plan, a, self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)
+        return pcm.cpu().numpy().astype(np.float64)
+
+    def separate_stepwise(self, audio):
+        """The reference's control flow, stage by stage through the public operators
+        (compute_file -> x scale -> generate_overlapadd -> predict_function2 per batch ->
+        overlapadd_multi -> compute_inverse); float32 on the device like ``separate``."""
+        import torch
+        a = self.ctx.to_device(np.asarray(audio), np.float32)
+        mag, ph = self.plan.forward(a, phase=True)
+        tiles, n = tile(self.ctx, mag, self.tc, self.overlap, self.tiler, self.scale_factor)
+        if n == 0:
+            raise IndexError("tuple index out of range")  # what overlapadd_multi hits on an empty output array
+        outs = []
+        for b0 in range(0, n, self.batch_size):
+            outs.append(self.net.forward_masked(tiles[b0:b0 + self.batch_size], None, self.tie_mode))
+        out = torch.cat(outs, dim=1)
+        mm = overlap_add(self.ctx, out, self.overlap)
+        T = mag.shape[0]
+        sep = mm[:, :T].contiguous()
+        pcm = self.plan.inverse(sep, ph, n_out=int(a.numel()), pre_div=self.scale_factor)
+        return pcm.cpu().numpy().astype(np.float64)
+
+
+_SCRIPT_DEFAULTS = {
+    # arch: (frameSize, hopSize, window, overlap in main(), input_size)     separate_<x>.py main()
+    'dsd': (1024, 512, np.hanning, 25, 513),       # separate_dsd.py:24,332
+    'hiphop': (1024, 512, np.hanning, 25, 513),    # separate_hhds.py
+    'ikala': (1024, 512, np.hanning, 20, 513),     # separate_ikala.py:24,275
+    'bach10': (4096, 512, blackmanharris, 25, 2049),  # separate_bach10.py:282,325
+}
+
+
+def output_paths(arch_name, filein, outdir):
+    """Output file names of each script (separate_dsd.py:309, separate_ikala.py:253-254,
+    separate_bach10.py:302)."""
+    path, filename = os.path.split(filein)
+    if arch_name in ('dsd', 'hiphop'):
+        return [os.path.join(outdir, s + ".wav") for s in ARCHS['dsd'].source_names]
+    if arch_name == 'ikala':
+        return [os.path.join(outdir, filename.replace(".wav", "-voice.wav")),
+                os.path.join(outdir, filename.replace(".wav", "-music.wav"))]
+    return [os.path.join(outdir, filename.replace(".wav", "_" + s + ".wav")) for s in ARCHS[arch_name].source_names]
+
+
+def train_auto(arch_name, filein, outdir, model, scale_factor=0.3, time_context=30, overlap=20, batch_size=32,
+               input_size=513, frameSize=None, hopSize=None, window=None, fused=True, device=None):
+    """``train_auto`` of the separate scripts: wav in, one wav per source out."""
+    d_frame, d_hop, d_win, _, _ = _SCRIPT_DEFAULTS[arch_name]
+    frameSize = d_frame if frameSize is None else frameSize
+    hopSize = d_hop if hopSize is None else hopSize
+    window = d_win if window is None else window
+    params = load_model(model) if isinstance(model, str) else model
+    sep = Separator(arch_name, params, scale_factor, time_context, overlap, batch_size, input_size, frameSize,
+                    hopSize, window, tiler='script', device=device)
+    sampleRate, audioObj = read_wav(filein)
+    if sampleRate == 44100:
+        audio = to_mono(audioObj, arch_name)
+        pcm = sep.separate(audio) if fused else sep.separate_stepwise(audio)
+        for path, audio_out in zip(output_paths(arch_name, filein, outdir), pcm):
+            write_wav(path, audio_out, sampleRate)
+    else:
+        print("Sample rate is not 44100")

@@ -1,0 +1,161 @@
+/*
+ * libdcs -- MI355X (gfx950) separation hot path of MTG/DeepConvSep behind a C ABI.
+ *
+ * The reference (pure Python 2 + Theano/Lasagne) has no FFI of its own; its
+ * integration surfaces are two Python call surfaces:
+ *
+ *   transformFFT.compute_file / compute_inverse          transform.py:224-274
+ *   the separate_*.py train_auto() body                  examples/dsd100/separate_dsd.py:239-313
+ *     compute_file -> generate_overlapadd -> predict_function2 ->
+ *     overlapadd_multi -> compute_inverse
+ *
+ * Every entry point below names the reference function whose arithmetic it
+ * replaces.  The Python package deepconvsep_amd/ binds these with ctypes and
+ * re-creates the reference's function signatures on top.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every function returns 0 (DCS_OK) or a negative
+ *     dcs_status; dcs_last_error() gives a thread-local message.
+ *   - pointers suffixed _d are DEVICE pointers (HBM), _h are host pointers.
+ *     The caller owns every buffer it passes in.
+ *   - a dcs_ctx binds one device + one HIP stream; all work of the handles
+ *     created from it is enqueued on that stream, asynchronously.  A ctx (and
+ *     its plans / models) is not thread-safe; distinct ctx objects are.
+ *   - spectrogram matrices are row-major [frames, ld] with ld >= bins; the
+ *     "dense" layout of the reference is ld == bins.
+ */
+#ifndef DCS_H
+#define DCS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dcs_ctx dcs_ctx;
+typedef struct dcs_stft dcs_stft;
+typedef struct dcs_model dcs_model;
+
+typedef enum {
+    DCS_OK = 0,
+    DCS_EINVAL = -1,       /* bad argument (shape, size, null pointer)            */
+    DCS_EUNSUPPORTED = -2, /* legal in the reference, not built here (see DESIGN) */
+    DCS_EHIP = -3,         /* a HIP runtime call failed                            */
+    DCS_ENOMEM = -4,       /* device allocation failed                             */
+    DCS_ESHAPE = -5        /* parameter count/shape mismatch (set_all_param_values) */
+} dcs_status;
+
+/* build_ca variants (examples/<x>/separate_<x>.py) */
+enum { DCS_ARCH_DSD = 0, DCS_ARCH_IKALA = 1, DCS_ARCH_BACH10 = 2, DCS_ARCH_BACH10_SI = 3 };
+/* soft-mask epsilon convention: A = separate_dsd.py:258-266, B = separate_bach10.py:251-259 */
+enum { DCS_EPS_A = 0, DCS_EPS_B = 1 };
+/* max-pool gradient tie routing: ALL = Theano 0.9 CPU MaxPoolGrad, FIRST = cuDNN */
+enum { DCS_TIE_ALL = 0, DCS_TIE_FIRST = 1 };
+/* tiler: SCRIPT = separate_dsd.py:114-135 (drops the tail), LIBRARY = util.py:220-248 (zero pads) */
+enum { DCS_TILER_SCRIPT = 0, DCS_TILER_LIBRARY = 1 };
+
+/* ------------------------------------------------------------------ library / context */
+int dcs_version(void);
+const char* dcs_last_error(void);
+
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the
+ * device's default stream. */
+int dcs_create(int device, void* hip_stream, dcs_ctx** out);
+int dcs_destroy(dcs_ctx* ctx);
+int dcs_synchronize(dcs_ctx* ctx);
+
+/* ------------------------------------------------------------------ framing integers (host) */
+/* numberFrames of stft_norm: int(ceil(L/hop) + 2)                      transform.py:309 */
+int64_t dcs_frame_count(int64_t n_samples, int hop);
+/* len(istft_norm(...)) = hop*(T-1) + N - N/2                            transform.py:373,390 */
+int64_t dcs_inverse_length(int64_t n_frames, int hop, int frame);
+/* number of tiles the reference tilers cut from T frames                separate_dsd.py:121-125, util.py:228-232 */
+int64_t dcs_tile_count(int64_t n_frames, int time_context, int overlap, int tiler);
+
+/* ------------------------------------------------------------------ STFT  (transform.py:224-396) */
+/* frame must be a power of two in [64, 8192]; window_h = window(frame) as the reference
+ * materialises it in Transforms.__init__ (transform.py:78). */
+int dcs_stft_plan(dcs_ctx* ctx, int frame, int hop, const double* window_h, dcs_stft** out);
+int dcs_stft_plan_destroy(dcs_stft* plan);
+
+/* compute_file: mag = |rfft(w * frame)| / sqrt(N), phase = angle(.)     transform.py:243-247
+ * audio_d [n_samples]; mag_d / phase_d [rows_out, ld] with rows >= dcs_frame_count() written
+ * as zero rows (used by the zero-padding tiler); phase_d may be NULL (phase=False). */
+int dcs_stft_forward_f32(dcs_stft* plan, const float* audio_d, int64_t n_samples, float* mag_d,
+                         float* phase_d, int64_t ld, int64_t rows_out);
+int dcs_stft_forward_f64(dcs_stft* plan, const double* audio_d, int64_t n_samples, double* mag_d,
+                         double* phase_d, int64_t ld, int64_t rows_out);
+
+/* compute_inverse for n_src magnitude matrices sharing one phase:       transform.py:271-273, 337-396
+ *   X = (mag / pre_div) * sqrt(N) * exp(j*phase) -> irfft -> window -> overlap-add -> / sum(w*w)
+ * mag_d [n_src][n_frames, ld] (source stride src_stride elements), phase_d [n_frames, ld],
+ * audio_d [n_src][n_out] with n_out <= dcs_inverse_length() (the caller's truncation,
+ * separate_dsd.py:305-306).  pre_div is the scale_factor division of separate_dsd.py:304 (1.0 for
+ * the plain transform API). */
+int dcs_stft_inverse_f32(dcs_stft* plan, const float* mag_d, int64_t src_stride, const float* phase_d,
+                         int64_t ld, int64_t n_frames, int n_src, float pre_div, float* audio_d,
+                         int64_t n_out);
+int dcs_stft_inverse_f64(dcs_stft* plan, const double* mag_d, int64_t src_stride, const double* phase_d,
+                         int64_t ld, int64_t n_frames, int n_src, double pre_div, double* audio_d,
+                         int64_t n_out);
+
+/* ------------------------------------------------------------------ tiling (separate_dsd.py:114-169, util.py:220-327) */
+/* generate_overlapadd: tiles_d [n, C, tc, F] = scale * mag_d[C][T, ld] windows; n = dcs_tile_count().
+ * (the reference multiplies by scale_factor before tiling, separate_dsd.py:290) */
+int dcs_tile(dcs_ctx* ctx, const float* mag_d, int64_t ch_stride, int64_t ld, int C, int64_t n_frames, int F,
+             int time_context, int overlap, int tiler, float scale, float* tiles_d, int64_t n_tiles);
+
+/* overlapadd_multi / overlapadd: cross-fade stitch of out_d [S, n, tc, F] into
+ * sep_d [S][n*(tc-ov)+tc, ld] (source stride sep_stride).  rise_h = np.linspace(0,1,overlap) as
+ * float64 (util.py:306); the fall ramp is its reverse (util.py:307). */
+int dcs_overlap_add(dcs_ctx* ctx, const float* out_d, int64_t n_tiles, int S, int time_context, int overlap,
+                    int F, const double* rise_h, float* sep_d, int64_t sep_stride, int64_t ld);
+
+/* ------------------------------------------------------------------ network (build_ca + mask) */
+/* params_d: device float32 arrays in lasagne.layers.get_all_params order (= the .pkl order),
+ * shapes: nparams x 4 int64 (unused trailing dims = 1).  Fails with DCS_ESHAPE exactly where
+ * lasagne.layers.set_all_param_values would raise (separate_dsd.py:250). */
+int dcs_model_create(dcs_ctx* ctx, int arch, int in_channels, int time_context, int F,
+                     const float* const* params_d, const int64_t* shapes, int nparams, dcs_model** out);
+int dcs_model_destroy(dcs_model* m);
+int dcs_model_num_sources(const dcs_model* m);
+
+/* predict_function2 (separate_dsd.py:273,298): tiles_d [n, C, tc, F] -> out_d [S, n, tc, F]
+ * = soft-masked magnitudes of the S sources. */
+int dcs_model_forward_masked(dcs_model* m, const float* tiles_d, int64_t n_tiles, int eps_mode, int tie_mode,
+                             float* out_d);
+/* lasagne.layers.get_output(network2): p_d [n, channels_out, tc, F] before masking (testing aid) */
+int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n_tiles, int tie_mode, float* p_d);
+int dcs_model_out_channels(const dcs_model* m);
+
+/* ------------------------------------------------------------------ fused file-level path */
+/* The separation block of train_auto (separate_dsd.py:289-306) for one mono signal already in
+ * HBM:  STFT -> x scale -> tiles -> network -> mask -> cross-fade overlap-add -> / scale ->
+ * iSTFT -> truncate to n_samples.  pcm_d [S, n_samples] float32.  n_tiles_out / n_frames_out
+ * (host, optional) receive the tile and frame counts.  Returns DCS_EINVAL when the tiler yields
+ * zero tiles (the reference raises in overlapadd_multi in that case). */
+int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap, int tiler,
+                 float scale, int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
+                 int64_t* n_frames_out);
+
+/* Same pipeline stopped before the iSTFT: sep_d [S][n_frames, ld_out] (scaled magnitudes, what the
+ * reference calls mm[i,:len(ph)]) and phase_d [n_frames, ld_out]; either may be NULL. */
+int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
+                         int tiler, float scale, int eps_mode, int tie_mode, float* sep_d, float* mag_d,
+                         float* phase_d, int64_t ld_out);
+
+/* ------------------------------------------------------------------ timing aid for bench.py */
+/* Average duration (ms) of the kernels tagged `which` since the last reset, measured with HIP events
+ * on the ctx stream.  tag_mask bit t enables the tag t (two event records per tagged launch);
+ * 0 disables all. */
+enum { DCS_TAG_STFT = 0, DCS_TAG_CONV1 = 1, DCS_TAG_CONV2 = 2, DCS_TAG_FC = 3, DCS_TAG_FC1X = 4,
+       DCS_TAG_DECONV2 = 5, DCS_TAG_FINAL = 6, DCS_TAG_ISTFT = 7, DCS_TAG_OLA = 8, DCS_TAG_COUNT = 9 };
+int dcs_timing_enable(dcs_ctx* ctx, unsigned tag_mask);
+int dcs_timing_reset(dcs_ctx* ctx);
+int dcs_timing_query(dcs_ctx* ctx, int which, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCS_H */

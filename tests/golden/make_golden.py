@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz FROM THE REFERENCE'S OWN CODE.
+
+Run in the build container (``/root/reference`` must exist):
+
+    python tests/golden/make_golden.py
+
+The reference's pure-NumPy helpers are executed by line range through
+``oracle.ref_exec`` (nothing is copied) on seeded inputs; inputs and outputs
+are written as small compressed fixtures.  The GPU box has no reference tree,
+so the parity tests there read these files.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import ref_exec  # noqa: E402
+
+
+def seeded_audio(n, seed):
+    """5 sinusoids + 0.1 uniform noise + a digital-silence gap, in [-1, 1]."""
+    rs = np.random.RandomState(seed)
+    t = np.arange(n) / 44100.0
+    x = np.zeros(n)
+    for f0, a in zip(rs.uniform(80.0, 6000.0, 5), rs.uniform(0.05, 0.2, 5)):
+        x += a * np.sin(2 * np.pi * f0 * t + rs.uniform(0, 2 * np.pi))
+    x += 0.1 * rs.uniform(-1, 1, n)
+    g0 = n // 3
+    x[g0:g0 + n // 8] = 0.0
+    # int16 quantise the way a wav read would deliver it (separate_dsd.py:275-282)
+    q = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+    return q.astype('float') / 32767.0
+
+
+def blackmanharris(n):
+    from scipy.signal.windows import blackmanharris as bh
+    return bh(n)
+
+
+def main():
+    if not ref_exec.available():
+        raise SystemExit("reference tree not found; fixtures can only be generated in the build container")
+    dsd = ref_exec.script_dsd()
+    ika = ref_exec.script_ikala()
+    lib = ref_exec.lib_stft()
+    libt = ref_exec.lib_tiling()
+
+    # ---- STFT / iSTFT through the script's compute_file / compute_inverse -------------
+    cases = [
+        ("stft_n1024_hann", 1024, 512, np.hanning, 5003, 11),
+        ("stft_n2048_hann", 2048, 512, np.hanning, 6000, 12),
+        ("stft_n4096_bh", 4096, 512, blackmanharris, 5121, 13),
+        ("stft_n1024_hop256_hann", 1024, 256, np.hanning, 3000, 14),   # transformFFT default hop
+        ("stft_n512_hop200_hann", 512, 200, np.hanning, 2111, 15),     # hop does not divide N
+    ]
+    for name, N, hop, win, L, seed in cases:
+        audio = seeded_audio(L, seed)
+        mag, ph = dsd.compute_file(audio, phase=True, frameSize=N, hopSize=hop, window=win)
+        back = dsd.compute_inverse(mag, ph, frameSize=N, hopSize=hop, window=win)
+        # library functions on the same input must agree with the script copies
+        X = lib.stft_norm(audio, window=win(N), hopsize=float(hop), nfft=float(N), fs=44100.0)
+        assert np.array_equal(np.abs(X) / np.sqrt(N), mag)
+        back_lib = lib.istft_norm((mag * np.sqrt(N)) * np.exp(1j * ph), window=win(N),
+                                  analysisWindow=win(N), hopsize=float(hop), nfft=float(N))
+        assert np.array_equal(back_lib, back)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), audio=audio, frame=N, hop=hop,
+                            window=win(N), mag=mag, phase=ph, inverse=back)
+        print(name, mag.shape, back.shape)
+
+    # ---- tilers ---------------------------------------------------------------------------
+    rs = np.random.RandomState(21)
+    F = 9
+    for name, T, tc, ov, B in [("tile_t83_tc30_ov25", 83, 30, 25, 4),
+                               ("tile_t61_tc30_ov20", 61, 30, 20, 4),
+                               ("tile_t30_tc30_ov25", 30, 30, 25, 4),     # script tiler: zero tiles
+                               ("tile_t131_tc30_ov25", 131, 30, 25, 32)]:
+        mag = rs.uniform(0, 1, (T, F)).astype(np.float32)
+        # script tiler leaves unused slots uninitialised (np.empty): record only the count
+        # and the filled tiles
+        fb_s, n_s = dsd.generate_overlapadd(mag, input_size=F, time_context=tc, overlap=ov, batch_size=B)
+        fb_s = fb_s.reshape((-1,) + fb_s.shape[2:])[:n_s] if n_s else np.zeros((0, 1, tc, F))
+        fb_l, n_l = libt.generate_overlapadd(mag, input_size=F, time_context=tc, overlap=ov, batch_size=B)
+        mag3 = rs.uniform(0, 1, (3, T, F)).astype(np.float32)
+        fb_l3, n_l3 = libt.generate_overlapadd(mag3, input_size=F, time_context=tc, overlap=ov, batch_size=B)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), mag=mag, mag3=mag3, tc=tc, ov=ov, B=B,
+                            script_tiles=fb_s, script_n=n_s, library_batches=fb_l, library_n=n_l,
+                            library3_batches=fb_l3, library3_n=n_l3)
+        print(name, "script n =", n_s, "library n =", n_l)
+
+    # ---- cross-fade overlap-add -------------------------------------------------------------
+    for name, n, tc, ov, B, S in [("ola_n11_tc30_ov25_s4", 11, 30, 25, 4, 4),
+                                  ("ola_n7_tc30_ov20_s2", 7, 30, 20, 4, 2),
+                                  ("ola_n1_tc30_ov25_s4", 1, 30, 25, 4, 4),
+                                  ("ola_n37_tc30_ov25_s4", 37, 30, 25, 32, 4)]:
+        nb = int(np.ceil(float(n) / B))
+        out = rs.uniform(0, 1, (nb, S, B, 1, tc, F))
+        sep = dsd.overlapadd_multi(out, None, n, overlap=ov)
+        sep_lib = libt.overlapadd_multi(out, None, n, overlap=ov)
+        assert np.array_equal(sep, sep_lib)
+        d = dict(out=out, n=n, tc=tc, ov=ov, B=B, sep=sep)
+        if S == 2:
+            s1, s2 = ika.overlapadd(out, None, n, overlap=ov)
+            assert np.array_equal(s1, sep[0]) and np.array_equal(s2, sep[1])
+            d["sep1"], d["sep2"] = s1, s2
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, sep.shape)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,278 @@
+"""Parity of the HIP path (through the C ABI) against the committed golden vectors of the
+reference's own code and against the CPU oracle on seeded inputs.  Run on the MI355X box:
+
+    python -m pytest tests -m gpu -x -q
+
+Tolerances: framing / indexing bit-exact; float64 kernels 1e-11; float32 kernels 1e-4 absolute
+on (scaled) magnitudes per masked bin (BASELINE.json north_star), PCM 1e-4.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import deepconvsep_amd as dcs  # noqa: E402
+from deepconvsep_amd import _lib  # noqa: E402
+from deepconvsep_amd.arch import ARCHS, EPS_A, EPS_B, TILER_LIBRARY, TILER_SCRIPT  # noqa: E402
+from deepconvsep_amd.runtime import Network, StftPlan, default_context, overlap_add, tile  # noqa: E402
+from deepconvsep_amd.synth import synth_audio, synth_params  # noqa: E402
+from oracle import net_ref, pipeline, stft_np, tiling_np  # noqa: E402
+
+STFT_CASES = ["stft_n1024_hann", "stft_n2048_hann", "stft_n4096_bh", "stft_n1024_hop256_hann",
+              "stft_n512_hop200_hann"]
+TILE_CASES = ["tile_t83_tc30_ov25", "tile_t61_tc30_ov20", "tile_t30_tc30_ov25", "tile_t131_tc30_ov25"]
+OLA_CASES = ["ola_n11_tc30_ov25_s4", "ola_n7_tc30_ov20_s2", "ola_n1_tc30_ov25_s4", "ola_n37_tc30_ov25_s4"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return default_context()
+
+
+def _tt(g, precision):
+    win = g["window"]
+    return dcs.transformFFT(frameSize=int(g["frame"]), hopSize=int(g["hop"]), window=lambda n: win,
+                            precision=precision)
+
+
+# ------------------------------------------------------------------------------------------ STFT
+@pytest.mark.parametrize("name", STFT_CASES)
+@pytest.mark.parametrize("precision,tol", [("float64", 1e-11), ("float32", 2e-5)])
+def test_compute_file_matches_reference(golden, name, precision, tol):
+    g = golden(name)
+    mag, ph = _tt(g, precision).compute_file(g["audio"], phase=True)
+    assert mag.shape == g["mag"].shape and mag.dtype == np.float64          # framing: bit-exact
+    assert np.max(np.abs(mag - g["mag"])) < tol
+    # raw phase is ill-conditioned where mag ~ 0 and at +-pi: compare mag * exp(j phase)
+    z = mag * np.exp(1j * ph)
+    zr = g["mag"] * np.exp(1j * g["phase"])
+    assert np.max(np.abs(z - zr)) < 2 * tol
+    only_mag = _tt(g, precision).compute_file(g["audio"], phase=False)
+    assert np.array_equal(only_mag, mag)
+
+
+@pytest.mark.parametrize("name", STFT_CASES)
+@pytest.mark.parametrize("precision,tol", [("float64", 1e-11), ("float32", 1e-5)])
+def test_compute_inverse_matches_reference(golden, name, precision, tol):
+    g = golden(name)
+    back = _tt(g, precision).compute_inverse(g["mag"], g["phase"])
+    assert back.shape == g["inverse"].shape
+    assert np.max(np.abs(back - g["inverse"])) < tol
+
+
+@pytest.mark.parametrize("N,hop", [(1024, 512), (2048, 512), (4096, 512), (256, 64), (8192, 2048)])
+def test_round_trip_property_full_size(N, hop):
+    """README.md:60-70 contract at BASELINE size (10 s): compute_inverse(compute_file(x)) == x."""
+    audio = synth_audio(441000, seed=4)
+    tt = dcs.transformFFT(frameSize=N, hopSize=hop, precision="float64")
+    mag, ph = tt.compute_file(audio, phase=True)
+    assert mag.shape == (stft_np.frame_count(audio.size, hop), N // 2 + 1)
+    back = tt.compute_inverse(mag, ph)
+    assert back.size == stft_np.inverse_length(mag.shape[0], hop, N)
+    assert np.max(np.abs(back[:audio.size] - audio)) < 1e-11
+    tt32 = dcs.transformFFT(frameSize=N, hopSize=hop, precision="float32")
+    m32, p32 = tt32.compute_file(audio, phase=True)
+    assert np.max(np.abs(m32 - mag)) < 3e-5
+    assert np.max(np.abs(tt32.compute_inverse(m32, p32)[:audio.size] - audio)) < 2e-5
+
+
+def test_stft_linearity_and_silence():
+    tt = dcs.transformFFT(frameSize=2048, hopSize=512, precision="float64")
+
+    def spec(x):
+        m, p = tt.compute_file(x, True)
+        return m * np.exp(1j * p)
+
+    a, b = synth_audio(30000, seed=1, silence=False), synth_audio(30000, seed=2, silence=False)
+    assert np.max(np.abs(spec(2.0 * a - 0.5 * b) - (2.0 * spec(a) - 0.5 * spec(b)))) < 1e-11
+    m0, p0 = tt.compute_file(np.zeros(5000), True)
+    assert not m0.any() and not (m0 * np.exp(1j * p0)).any()
+    assert not tt.compute_inverse(m0, p0).any()
+
+
+def test_compute_transform_writes_reference_format(tmp_path):
+    audio = np.stack([synth_audio(9000, seed=5), synth_audio(9000, seed=6)], axis=1)
+    tt = dcs.transformFFT(frameSize=1024, hopSize=512, suffix="x")
+    mags = tt.compute_transform(audio, phase=False, save=False)
+    assert mags.shape == (2, stft_np.frame_count(9000, 512), 513)
+    np.testing.assert_allclose(mags[1], stft_np.compute_file(audio[:, 1], frameSize=1024, hopSize=512), atol=1e-11)
+    out = str(tmp_path / "song.data")
+    assert tt.compute_transform(audio, out_path=out, phase=True, save=True) is None
+    back = np.fromfile(out.replace(".data", "_x_m_.data")).reshape(tt.get_shape(out.replace(".data", "_x_m_.shape")))
+    assert np.array_equal(back, mags)
+
+
+# ------------------------------------------------------------------------------------------ tiling
+@pytest.mark.parametrize("name", TILE_CASES)
+def test_generate_overlapadd_matches_reference(golden, name):
+    g = golden(name)
+    tc, ov, B = int(g["tc"]), int(g["ov"]), int(g["B"])
+    mag = g["mag"]
+    fb, n = dcs.generate_overlapadd(mag, input_size=mag.shape[-1], time_context=tc, overlap=ov, batch_size=B)
+    assert n == int(g["script_n"]) and fb.dtype == np.float64
+    assert fb.shape[0] == int(np.ceil(float(n) / B))
+    assert np.array_equal(fb.reshape((-1,) + fb.shape[2:])[:n], g["script_tiles"])           # copies: bit-exact
+    fb, n = dcs.generate_overlapadd(mag, mag.shape[-1], tc, ov, B, tiler='library')
+    assert n == int(g["library_n"]) and np.array_equal(fb, g["library_batches"])
+    fb, n = dcs.generate_overlapadd(g["mag3"], mag.shape[-1], tc, ov, B, tiler='library')
+    assert n == int(g["library3_n"]) and np.array_equal(fb, g["library3_batches"])
+
+
+@pytest.mark.parametrize("name", OLA_CASES)
+def test_overlapadd_matches_reference(golden, name):
+    g = golden(name)
+    n, ov = int(g["n"]), int(g["ov"])
+    sep = dcs.overlapadd_multi(g["out"], None, n, overlap=ov)
+    assert sep.shape == g["sep"].shape
+    assert np.max(np.abs(sep - g["sep"])) < 5e-7    # float32 blend vs the reference's float64
+    if "sep1" in g.files:
+        s1, s2 = dcs.overlapadd(g["out"], None, n, overlap=ov)
+        assert np.max(np.abs(s1 - g["sep1"])) < 5e-7 and np.max(np.abs(s2 - g["sep2"])) < 5e-7
+
+
+def test_overlapadd_of_identical_tiles_is_identity():
+    """Property: if every tile holds the same frames of one spectrogram, the cross-fade returns it."""
+    rs = np.random.RandomState(5)
+    T, F, tc, ov = 240, 33, 30, 25
+    spec = rs.uniform(0, 1, (T, F)).astype(np.float32)
+    fb, n = dcs.generate_overlapadd(spec, F, tc, ov, 32)
+    out = np.stack([fb, 2 * fb], axis=1)[:, :, :, :, :, :]          # [nb, S=2, B, 1, tc, F]
+    sep = dcs.overlapadd_multi(out, None, n, overlap=ov)
+    covered = (n - 1) * (tc - ov) + tc
+    assert np.max(np.abs(sep[0, :covered] - spec[:covered])) < 1e-6
+    assert np.max(np.abs(sep[1, :covered] - 2 * spec[:covered])) < 1e-6
+    assert not sep[:, covered:].any()
+
+
+# ------------------------------------------------------------------------------------------ network
+def _tiles(arch, n, tc, F, seed, silent_rows=True):
+    rs = np.random.RandomState(seed)
+    C = ARCHS[arch].C
+    x = (0.3 * rs.uniform(0, 3, (n, C, tc, F)).astype(np.float32))
+    if silent_rows and n > 1:
+        x[1, :, 4:9] = 0.0      # digital silence inside a tile
+        x[n - 1] = 0.0          # a fully silent tile: every p_i can be 0 -> mask edge case
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("F,n", [(513, 5), (1025, 3), (513, 37), (65, 2)])
+def test_dsd_predict_function_matches_oracle(F, n):
+    tc = 30
+    params = synth_params("dsd", tc, F, seed=2)
+    x = _tiles("dsd", n, tc, F, seed=8)
+    pf = dcs.PredictFunction("dsd", params, tc, F)
+    got = pf(x)
+    want = net_ref.predict("dsd", params, x.astype(np.float64), inverse='explicit')
+    assert len(got) == 4
+    for g_, w_ in zip(got, want):
+        assert g_.shape == w_.shape == (n, 1, tc, F)
+        assert np.max(np.abs(g_ - w_)) < 1e-4
+    # masks partition the mixture (convention A): sum of sources == input
+    assert np.max(np.abs(sum(got) - x.astype(np.float64))) < 1e-5
+
+
+def test_dsd_raw_output_and_mask_conventions():
+    tc, F, n = 30, 513, 3
+    params = synth_params("dsd", tc, F, seed=3)
+    x = _tiles("dsd", n, tc, F, seed=9)
+    ctx = default_context()
+    net = Network(ctx, "dsd", params, tc, F)
+    p = net.forward_raw(ctx.to_device(x, np.float32)).cpu().numpy()
+    want = net_ref.forward("dsd", params, x.astype(np.float64), inverse='explicit').numpy()
+    assert p.shape == want.shape == (n, 4, tc, F)
+    assert np.max(np.abs(p - want)) < 1e-4
+    for mode, name in ((EPS_A, 'A'), (EPS_B, 'B')):
+        got = net.forward_masked(ctx.to_device(x, np.float32), eps_mode=mode).cpu().numpy()
+        ref = net_ref.predict("dsd", params, x.astype(np.float64), inverse='explicit', eps_mode=name)
+        for s in range(4):
+            assert np.max(np.abs(got[s] - ref[s][:, 0])) < 1e-4
+
+
+def test_all_zero_network_output_gives_uniform_masks():
+    """p == 0 everywhere: convention A -> 1/S of the mixture, convention B -> 0."""
+    tc, F, n = 30, 513, 2
+    params = [np.zeros_like(p) for p in synth_params("dsd", tc, F, seed=4)]
+    x = _tiles("dsd", n, tc, F, seed=10, silent_rows=False)
+    ctx = default_context()
+    net = Network(ctx, "dsd", params, tc, F)
+    a = net.forward_masked(ctx.to_device(x, np.float32), eps_mode=EPS_A).cpu().numpy()
+    b = net.forward_masked(ctx.to_device(x, np.float32), eps_mode=EPS_B).cpu().numpy()
+    for s in range(4):
+        np.testing.assert_allclose(a[s], 0.25 * x[:, 0], rtol=1e-6)
+        assert not b[s].any()
+
+
+def test_param_mismatch_raises_like_set_all_param_values():
+    params = synth_params("dsd", 30, 513)
+    with pytest.raises(ValueError):
+        dcs.PredictFunction("dsd", params[:-1], 30, 513)
+    with pytest.raises(ValueError):
+        dcs.PredictFunction("dsd", params, 30, 1025)
+
+
+# ------------------------------------------------------------------------------------------ whole path
+@pytest.mark.parametrize("N,tiler", [(1024, 'script'), (2048, 'script'), (1024, 'library')])
+def test_dsd_separation_matches_oracle(N, tiler):
+    F = N // 2 + 1
+    params = synth_params("dsd", 30, F, seed=2)
+    audio = synth_audio(44100, seed=0)          # 1 s: 89 frames, 12 tiles (script) / 13 (library)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, N, 512, np.hanning, tiler=tiler)
+    want, mm, mag, ph = pipeline.separate("dsd", params, audio, 0.3, 30, 25, 32, N, 512, np.hanning,
+                                          tiler=tiling_np.SCRIPT if tiler == 'script' else tiling_np.LIBRARY,
+                                          return_spectra=True)
+    ctx = default_context()
+    a = ctx.to_device(audio, np.float32)
+    s_d, m_d, p_d = sep.net.separate_spectra(sep.plan, a, 25, sep.tiler, 0.3)
+    assert tuple(s_d.shape) == mm.shape                     # framing / tile bookkeeping: exact
+    assert np.max(np.abs(m_d.cpu().numpy() * 0.3 - mag)) < 1e-5
+    assert np.max(np.abs(s_d.cpu().numpy() - mm)) < 1e-4    # per masked bin
+    got = sep.separate(audio)
+    assert got.shape == want.shape == (4, audio.size)
+    assert np.max(np.abs(got - want)) < 1e-4
+    step = sep.separate_stepwise(audio)                     # stage-by-stage operators agree with the fused path
+    assert np.max(np.abs(step - got)) < 2e-5
+    # int16 files: at most one LSB apart from the float64 reference path (truncation, separate_dsd.py:309)
+    d = np.abs((got * 32767).astype('int16').astype(int) - (want * 32767).astype('int16').astype(int))
+    assert d.max() <= 2
+
+
+def test_separation_edge_cases():
+    F = 513
+    params = synth_params("dsd", 30, F, seed=2)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, 1024, 512)
+    # too short for a single tile: the reference dies in overlapadd_multi; we raise ValueError
+    with pytest.raises(ValueError):
+        sep.separate(synth_audio(512 * 20, seed=1))
+    # pure digital silence -> silence (masks 1/4 of zero)
+    out = sep.separate(np.zeros(44100))
+    assert out.shape == (4, 44100) and not out.any()
+    # the four sources add up to the part of the mixture the tiles cover (masks sum to 1)
+    audio = synth_audio(66150, seed=7)
+    got = sep.separate(audio)
+    n = _lib.tile_count(_lib.frame_count(audio.size, 512), 30, 25, TILER_SCRIPT)
+    covered = ((n - 1) * 5 + 30 - 2) * 512 - 1024     # samples whose every contributing frame is tiled
+    assert np.max(np.abs(got.sum(0)[:covered] - audio[:covered])) < 1e-4
+
+
+def test_train_auto_writes_the_reference_files(tmp_path):
+    import scipy.io.wavfile
+    F = 513
+    params = synth_params("dsd", 30, F, seed=2)
+    model = str(tmp_path / "model.pkl")
+    dcs.save_model(model, params)
+    audio = synth_audio(44100, seed=3, channels=2)
+    wav = str(tmp_path / "mix.wav")
+    scipy.io.wavfile.write(wav, 44100, (audio * 32767).astype('int16'))
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "separate_dsd", os.path.join(os.path.dirname(__file__), "..", "examples", "dsd100", "separate_dsd.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["-i", wav, "-o", str(tmp_path), "-m", model])
+    sr, mono = dcs.separation.read_wav(wav)
+    want = pipeline.separate("dsd", params, (mono[:, 0] + mono[:, 1]) / 2, 0.3, 30, 25, 32, 1024, 512, np.hanning)
+    for i, name in enumerate(["vocals", "bass", "drums", "other"]):
+        sr, data = scipy.io.wavfile.read(str(tmp_path / (name + ".wav")))
+        assert sr == 44100 and data.dtype == np.int16 and data.shape == (44100,)
+        assert np.abs(data.astype(int) - (want[i] * 32767).astype('int16').astype(int)).max() <= 2

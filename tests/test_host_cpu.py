@@ -1,0 +1,103 @@
+"""CPU-only checks of the host layer: the C-ABI library loads and exports every symbol
+include/dcs.h declares, the framing integers agree with the oracle, the product fails loudly
+without a GPU, and the script surface behaves like the reference's (no compute calls here)."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import deepconvsep_amd as dcs
+from deepconvsep_amd import _lib
+from deepconvsep_amd.arch import TILER_LIBRARY, TILER_SCRIPT
+from oracle import stft_np, tiling_np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _lib.header_symbols()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.dcs_version() >= 100
+
+
+def test_framing_integers_match_the_oracle():
+    for hop in (200, 256, 512):
+        for L in list(range(0, 2100, 37)) + [441000, 441001, 10 ** 7 + 3]:
+            assert _lib.frame_count(L, hop) == stft_np.frame_count(L, hop)
+    for N, hop in ((1024, 512), (2048, 512), (4096, 512), (1024, 256), (512, 200)):
+        for T in (1, 2, 3, 17, 864):
+            assert _lib.inverse_length(T, hop, N) == stft_np.inverse_length(T, hop, N)
+
+
+def test_tile_counts_match_both_reference_tilers():
+    for tc, ov in ((30, 25), (30, 20), (30, 10), (20, 19), (8, 1)):
+        for T in range(0, 260):
+            assert _lib.tile_count(T, tc, ov, TILER_SCRIPT) == len(tiling_np.tile_starts(T, tc, ov, tiling_np.SCRIPT))
+            assert _lib.tile_count(T, tc, ov, TILER_LIBRARY) == len(tiling_np.tile_starts(T, tc, ov, tiling_np.LIBRARY))
+    # 10 s at 44.1 kHz -> 864 frames -> 167 tiles (ov=25) / 84 tiles (ov=20)
+    assert _lib.frame_count(441000, 512) == 864
+    assert _lib.tile_count(864, 30, 25, TILER_SCRIPT) == 167
+    assert _lib.tile_count(864, 30, 20, TILER_SCRIPT) == 84
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dcs.transformFFT(frameSize=1024, hopSize=512).compute_file(np.zeros(2048))
+    with pytest.raises(RuntimeError):
+        dcs.generate_overlapadd(np.zeros((40, 5), np.float32), input_size=5)
+
+
+def test_transform_object_keeps_reference_attributes():
+    tt = dcs.transformFFT(frameSize=2048, hopSize=512, sampleRate=44100)
+    assert (tt.frameSize, tt.hopSize, tt.sampleRate, tt.ttype, tt.suffix) == (2048, 512, 44100, 'fft', '')
+    assert tt.window.shape == (2048,) and np.array_equal(tt.window, np.hanning(2048))
+    assert dcs.TransformFFT is dcs.transformFFT
+    np.testing.assert_allclose(dcs.sinebell(8), np.sin(np.pi * np.arange(8) / 8.0))
+
+
+def test_model_pickle_round_trip_py2_protocol(tmp_path):
+    from deepconvsep_amd.synth import synth_params
+    params = synth_params("dsd", 30, 33)
+    path = str(tmp_path / "model.pkl")
+    dcs.save_model(path, params)
+    back = dcs.load_model(path)
+    assert len(back) == 15 and all(np.array_equal(a, b) for a, b in zip(params, back))
+    with open(path, "rb") as fh:
+        assert pickle.load(fh, encoding="latin1")[0].dtype == np.float32
+
+
+@pytest.mark.parametrize("script", ["examples/dsd100/separate_dsd.py", "examples/ikala/separate_ikala.py",
+                                    "examples/bach10/separate_bach10.py", "examples/hiphopss/separate_hhds.py"])
+def test_cli_usage_and_bad_option_exit_code(script):
+    exe = os.path.join(ROOT, script)
+    r = subprocess.run([sys.executable, exe, "-h"], capture_output=True, text=True)
+    assert r.returncode == 0 and "-i <inputfile> -o <outputdir> -m <path_to_model.pkl>" in r.stdout
+    r = subprocess.run([sys.executable, exe, "--nonsense"], capture_output=True, text=True)
+    assert r.returncode == 2  # separate_dsd.py:319-321
+
+
+def test_output_names_follow_each_script():
+    from deepconvsep_amd.separation import output_paths
+    assert [os.path.basename(p) for p in output_paths("dsd", "/a/mix.wav", "/o")] == \
+        ["vocals.wav", "bass.wav", "drums.wav", "other.wav"]
+    assert [os.path.basename(p) for p in output_paths("ikala", "/a/x.wav", "/o")] == ["x-voice.wav", "x-music.wav"]
+    assert os.path.basename(output_paths("bach10", "/a/x.wav", "/o")[2]) == "x_saxphone.wav"  # sic, separate_bach10.py:236
+
+
+def test_mono_mixdown_rules():
+    from deepconvsep_amd.separation import to_mono
+    st = np.array([[0.2, 0.4], [1.0, -1.0]])
+    np.testing.assert_allclose(to_mono(st, "dsd"), [0.3, 0.0])
+    np.testing.assert_allclose(to_mono(st, "ikala"), [0.6, 0.0])  # sum, not mean (separate_ikala.py:229)
+    np.testing.assert_allclose(to_mono(st[:, 0], "dsd"), st[:, 0])
+    with pytest.raises(IndexError):
+        to_mono(st[:, 0], "ikala")

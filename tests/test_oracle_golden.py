@@ -1,0 +1,81 @@
+"""Pin the CPU oracle against outputs of the reference's own code
+(tests/golden/*.npz, produced by tests/golden/make_golden.py) and, when the
+reference tree is present (build container), against the live reference code."""
+import numpy as np
+import pytest
+
+from oracle import ref_exec, stft_np, tiling_np
+
+STFT_CASES = ["stft_n1024_hann", "stft_n2048_hann", "stft_n4096_bh",
+              "stft_n1024_hop256_hann", "stft_n512_hop200_hann"]
+TILE_CASES = ["tile_t83_tc30_ov25", "tile_t61_tc30_ov20", "tile_t30_tc30_ov25", "tile_t131_tc30_ov25"]
+OLA_CASES = ["ola_n11_tc30_ov25_s4", "ola_n7_tc30_ov20_s2", "ola_n1_tc30_ov25_s4", "ola_n37_tc30_ov25_s4"]
+
+
+@pytest.mark.parametrize("name", STFT_CASES)
+def test_stft_matches_reference_bitwise(golden, name):
+    g = golden(name)
+    N, hop = int(g["frame"]), int(g["hop"])
+    mag, ph = stft_np.compute_file(g["audio"], phase=True, frameSize=N, hopSize=hop, window=g["window"])
+    assert mag.shape == g["mag"].shape == (stft_np.frame_count(g["audio"].size, hop), stft_np.n_bins(N))
+    assert np.array_equal(mag, g["mag"])
+    assert np.array_equal(ph, g["phase"])
+
+
+@pytest.mark.parametrize("name", STFT_CASES)
+def test_istft_matches_reference_bitwise(golden, name):
+    g = golden(name)
+    N, hop = int(g["frame"]), int(g["hop"])
+    back = stft_np.compute_inverse(g["mag"], g["phase"], frameSize=N, hopSize=hop, window=g["window"])
+    assert back.size == stft_np.inverse_length(g["mag"].shape[0], hop, N)
+    assert np.array_equal(back, g["inverse"])
+    # README.md:60-70 round trip: the inverse reproduces the input on its support
+    L = g["audio"].size
+    assert np.max(np.abs(back[:L] - g["audio"])) < 1e-12
+
+
+@pytest.mark.parametrize("name", TILE_CASES)
+def test_tilers_match_reference(golden, name):
+    g = golden(name)
+    tc, ov, B = int(g["tc"]), int(g["ov"]), int(g["B"])
+    mag = g["mag"]
+    fb, n = tiling_np.generate_overlapadd(mag, mag.shape[-1], tc, ov, B, tiler=tiling_np.SCRIPT)
+    assert n == int(g["script_n"])
+    flat = fb.reshape((-1,) + fb.shape[2:])[:n]
+    assert np.array_equal(flat, g["script_tiles"])
+    fb, n = tiling_np.generate_overlapadd(mag, mag.shape[-1], tc, ov, B, tiler=tiling_np.LIBRARY)
+    assert n == int(g["library_n"])
+    assert np.array_equal(fb, g["library_batches"])
+    fb, n = tiling_np.generate_overlapadd(g["mag3"], mag.shape[-1], tc, ov, B, tiler=tiling_np.LIBRARY)
+    assert n == int(g["library3_n"])
+    assert np.array_equal(fb, g["library3_batches"])
+
+
+@pytest.mark.parametrize("name", OLA_CASES)
+def test_overlapadd_matches_reference_bitwise(golden, name):
+    g = golden(name)
+    n, ov, B = int(g["n"]), int(g["ov"]), int(g["B"])
+    sep = tiling_np.overlapadd_multi(g["out"], n, ov)
+    assert np.array_equal(sep, g["sep"])
+    if "sep1" in g.files:
+        s1, s2 = tiling_np.overlapadd(g["out"], n, ov)
+        assert np.array_equal(s1, g["sep1"]) and np.array_equal(s2, g["sep2"])
+    # the frame-parallel closed form (what the GPU kernel implements) is bit-identical too
+    out = g["out"]
+    S = out.shape[1]
+    tiles = np.stack([out[i // B, :, i % B, 0] for i in range(n)], axis=1)   # [S, n, tc, F]
+    for s in range(S):
+        assert np.array_equal(tiling_np.overlapadd_frame_parallel(tiles[s], ov), g["sep"][s])
+
+
+@pytest.mark.skipif(not ref_exec.available(), reason="reference tree only exists in the build container")
+def test_live_reference_agrees_on_fresh_input():
+    rs = np.random.RandomState(99)
+    audio = rs.uniform(-1, 1, 7001)
+    ref = ref_exec.script_dsd()
+    for N, hop in [(1024, 512), (2048, 512)]:
+        m0, p0 = ref.compute_file(audio, phase=True, frameSize=N, hopSize=hop)
+        m1, p1 = stft_np.compute_file(audio, phase=True, frameSize=N, hopSize=hop)
+        assert np.array_equal(m0, m1) and np.array_equal(p0, p1)
+        assert np.array_equal(ref.compute_inverse(m0, p0, frameSize=N, hopSize=hop),
+                              stft_np.compute_inverse(m1, p1, frameSize=N, hopSize=hop))

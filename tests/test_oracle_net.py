@@ -1,0 +1,108 @@
+"""Self-consistency of the network oracle (PARITY UNPINNED: Theano/Lasagne are not available,
+see oracle/__init__.py).  Two independent formulations of every InverseLayer must agree, and
+the documented edge semantics (mask conventions, tie routing, uncovered columns) must hold."""
+import numpy as np
+import pytest
+import torch
+
+from deepconvsep_amd.arch import ARCHS, check_params
+from deepconvsep_amd.synth import synth_params
+from oracle import net_ref
+
+CASES = [("dsd", 30, 513), ("dsd", 30, 65), ("ikala", 30, 513), ("bach10", 30, 257), ("bach10_si", 30, 129)]
+
+
+def _input(arch, B, tc, F, seed=3):
+    rs = np.random.RandomState(seed)
+    C = ARCHS[arch].C
+    return (0.3 * rs.uniform(0, 2, (B, C, tc, F)).astype(np.float32)).astype(np.float64)
+
+
+@pytest.mark.parametrize("arch,tc,F", CASES)
+def test_autograd_vjp_equals_explicit_transpose(arch, tc, F):
+    params = synth_params(arch, tc, F, seed=5)
+    check_params(ARCHS[arch], params, tc, F)
+    assert [tuple(p.shape) for p in params] == [tuple(s) for s in net_ref.SPECS[arch].param_shapes(tc, F)]
+    x = _input(arch, 2, tc, F)
+    a = net_ref.forward(arch, params, x, inverse='autograd').detach().numpy()
+    b = net_ref.forward(arch, params, x, inverse='explicit').detach().numpy()
+    assert a.shape == (2, len(ARCHS[arch].branch_fc) * ARCHS[arch].C, tc, F)
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+    assert (a >= 0).all()
+
+
+def test_param_counts_match_survey():
+    assert len(ARCHS["dsd"].param_shapes(30, 513)) == 15
+    assert len(ARCHS["ikala"].param_shapes(30, 513)) == 13
+    assert len(ARCHS["bach10"].param_shapes(30, 2049)) == 17
+    assert ARCHS["bach10_si"].param_shapes(30, 2049)[-1] == (16,)
+    assert ARCHS["dsd"].param_shapes(30, 513)[6] == (800, 128)
+    assert ARCHS["ikala"].param_shapes(30, 513)[6] == (13230, 256)
+    assert ARCHS["bach10"].param_shapes(30, 2049)[6] == (166650, 256)
+    # SURVEY 8a-4': 11.78 MFLOP per DSD tile (aliased branch computed once)
+    assert abs(ARCHS["dsd"].flops_per_tile(30, 513) / 1e6 - 11.78) < 0.02
+    assert abs(ARCHS["dsd"].flops_per_tile(30, 1025) / 1e6 - 17.92) < 0.02
+
+
+def test_dsd_fourth_channel_reuses_second_branch():
+    params = synth_params("dsd", 30, 65, seed=7)
+    x = _input("dsd", 1, 30, 65)
+    p = net_ref.forward("dsd", params, x, inverse='explicit')
+    pre1 = p[:, 1] - 0  # relu(o1 + b[1]);  channel 3 = relu(o1 + b[3])
+    b = params[-1]
+    o1 = None
+    # recover o1 where channel 1 is active, then check channel 3 there
+    act = (p[:, 1] > 0) & (p[:, 3] > 0)
+    o1 = p[:, 1][act] - float(b[1])
+    np.testing.assert_allclose((o1 + float(b[3])).numpy(), p[:, 3][act].numpy(), atol=1e-12)
+    assert pre1.shape == p[:, 3].shape
+
+
+def test_mask_conventions_on_silence():
+    # all-zero network output: convention A -> masks 1/S, convention B -> 0  
+    x = np.full((1, 1, 2, 3), 0.7)
+    p = torch.zeros((1, 4, 2, 3), dtype=torch.float64)
+    a = net_ref.soft_mask("dsd", p, x, eps_mode='A')
+    b = net_ref.soft_mask("dsd", p, x, eps_mode='B')
+    for m in a:
+        np.testing.assert_allclose(m.numpy(), 0.7 / 4)
+    for m in b:
+        np.testing.assert_allclose(m.numpy(), 0.0)
+    # masks of a non-degenerate output sum to the mixture
+    rs = np.random.RandomState(0)
+    p = torch.as_tensor(rs.uniform(0, 1, (1, 4, 2, 3)))
+    np.testing.assert_allclose(sum(m.numpy() for m in net_ref.soft_mask("dsd", p, x, 'A')), x, atol=1e-15)
+
+
+def test_pool_tie_modes_differ_only_on_ties():
+    params = synth_params("ikala", 30, 513, seed=9)
+    x = _input("ikala", 1, 30, 513)
+    x[0, 0, 5:9] = 0.0  # digital silence rows: conv1b output is constant -> every pooling window ties
+    all_ = net_ref.forward("ikala", params, x, tie_mode='all', inverse='explicit').numpy()
+    first = net_ref.forward("ikala", params, x, tie_mode='first', inverse='explicit').numpy()
+    rows = np.zeros(30, bool)
+    rows[5:9] = True
+    np.testing.assert_allclose(all_[:, :, ~rows], first[:, :, ~rows], atol=1e-12)
+    assert np.abs(all_[:, :, rows] - first[:, :, rows]).max() > 1e-6
+
+
+def test_uncovered_columns_only_see_the_bias():
+    # bach10 conv1: (F-30) % 4 trailing columns are not covered by any filter position (SURVEY 8a-4')
+    F = 257  # (257-30) % 4 = 3
+    params = synth_params("bach10", 30, F, seed=11)
+    x = _input("bach10", 1, 30, F)
+    p = net_ref.forward("bach10", params, x, inverse='explicit').numpy()
+    for c in range(4):
+        np.testing.assert_allclose(p[0, c, :, F - 3:], max(float(params[-1][c]), 0.0), atol=1e-15)
+
+
+def test_set_all_param_values_failure_modes():
+    params = synth_params("dsd", 30, 513)
+    with pytest.raises(ValueError):
+        check_params(ARCHS["dsd"], params[:-1], 30, 513)
+    bad = list(params)
+    bad[6] = bad[6][:, :100]
+    with pytest.raises(ValueError):
+        check_params(ARCHS["dsd"], bad, 30, 513)
+    with pytest.raises(ValueError):
+        net_ref.forward("dsd", bad, _input("dsd", 1, 30, 513))
