@@ -42,6 +42,11 @@ def load():
             "deepconvsep_amd: %s is missing -- build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or deepconvsep_amd/csrc/build.sh. "
             "There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7 / libhsa-runtime64 (same sonames as /opt/rocm's).  Whichever
+    # copy is mapped first serves the whole process, and a process that mixes the two runtimes loses the
+    # device ("no ROCm-capable device is detected").  Import torch first so that libdcs.so binds to the
+    # runtime torch uses -- device pointers and streams are then shared by construction.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i64, i32, f32, f64 = c_void_p, c_int64, c_int, c_float, c_double
 
