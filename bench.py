@@ -99,7 +99,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # HIP event pairs around the dominant kernel, on the stream it is launched on, inside the timed
+    # region -- but only around every 8th launch: an event record costs ~6 us of stream time on each
+    # side of a ~20 us kernel, and bracketing every launch would slow the measured steps by ~10 %.
     ctx.timing(["final"])
+    ctx.timing_stride(8)
     ctx.timing_reset()
     barrier()
     torch.cuda.synchronize()
@@ -111,6 +115,7 @@ def main():
     elapsed = time.perf_counter() - t0
     final_ms, final_launches = ctx.timing_query("final")
     ctx.timing(None)
+    ctx.timing_stride(1)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=audio.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -80,6 +80,7 @@ def load():
     proto("dcs_separate", i32, vp, vp, vp, i64, i32, i32, f32, i32, i32, vp, POINTER(i64), POINTER(i64))
     proto("dcs_separate_spectra", i32, vp, vp, vp, i64, i32, i32, f32, i32, i32, vp, vp, vp, i64)
     proto("dcs_timing_enable", i32, vp, ctypes.c_uint)
+    proto("dcs_timing_stride", i32, vp, i32)
     proto("dcs_timing_reset", i32, vp)
     proto("dcs_timing_query", i32, vp, i32, POINTER(c_double), POINTER(i64))
     _lib = lib

@@ -45,6 +45,10 @@ void DcsBuffer::release() {
 
 DcsTimer::DcsTimer(dcs_ctx* c, int t) : ctx(c), tag(t), idx(0), on((c->timing_mask >> t) & 1u) {
     if (!on) return;
+    if ((c->timing_seen[t]++ % (uint64_t)c->timing_stride) != 0) {
+        on = false;
+        return;
+    }
     DcsTimingSlot& s = ctx->slots[tag];
     if (s.used == s.start.size()) {
         hipEvent_t a, b;
@@ -69,9 +73,16 @@ extern "C" int dcs_timing_enable(dcs_ctx* ctx, unsigned tag_mask) {
     return DCS_OK;
 }
 
+extern "C" int dcs_timing_stride(dcs_ctx* ctx, int stride) {
+    if (!ctx || stride < 1) DCS_FAIL(DCS_EINVAL, "dcs_timing_stride: bad argument");
+    ctx->timing_stride = stride;
+    return DCS_OK;
+}
+
 extern "C" int dcs_timing_reset(dcs_ctx* ctx) {
     if (!ctx) DCS_FAIL(DCS_EINVAL, "dcs_timing_reset: null ctx");
     for (auto& s : ctx->slots) s.used = 0;
+    for (auto& v : ctx->timing_seen) v = 0;
     return DCS_OK;
 }
 

@@ -51,6 +51,8 @@ struct dcs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     unsigned timing_mask = 0;  // bit t set: kernels tagged t are bracketed by HIP events
+    int timing_stride = 1;     // ... every timing_stride-th launch of the tag only
+    uint64_t timing_seen[DCS_TAG_COUNT] = {0};
     DcsTimingSlot slots[DCS_TAG_COUNT];
     int n_cu = 256;
 };
@@ -98,7 +100,7 @@ int dcs_launch_stft_inverse_f64(dcs_stft* p, const double* mag, int64_t src_stri
 // C[row(r)][0..n_store) = act( a_scale * A[arow(r)][0..K) . B[K][ldb] + bias )
 //   arow(r) = ((r / a_gdiv) * a_gmul + r % a_gdiv) * lda      (elements)
 //   crow(r) = ((r / c_gdiv) * c_gmul + r % c_gdiv) * ldc
-// B is padded with zero rows to a multiple of 32 and ldb is a multiple of 64.
+// B is padded with zero rows to a multiple of 128 (the largest K tile) and ldb is a multiple of 64.
 struct DcsGemm {
     const float* A; int64_t lda; int a_gdiv; int64_t a_gmul; float a_scale;
     const float* B; int ldb;

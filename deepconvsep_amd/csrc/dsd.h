@@ -22,6 +22,7 @@ struct DsdFinalArgs {
     int mask_mode;        // 0 = convention A, 1 = convention B, 2 = raw network output
 };
 
+// Bw: [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]
 int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float* G, int64_t n_ks, int H2, int CP,
-                           int CI, int kh, int tc, int ncp);
+                           int CI, int kh, int tc, int NG, int GS, int gcols);
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold);

@@ -13,24 +13,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 
 // ------------------------------------------------------------------------------------------------
-// Transposed conv2 as "GEMM + col2im".  For one (tile, branch):
-//   P[t', dt*CI + ci] = sum_co D[t', co] * W2c[co, ci, dt]          (MFMA, M = H2, K = CP, N = kh*CI)
-//   G[t, ci]          = sum_dt P[t - dt, dt*CI + ci],  0 <= t-dt < H2 (LDS reduction)
+// Transposed conv2 as "GEMM + col2im".  For one (tile, branch) and one group of GS input channels:
+//   P[t', c*kh + dt] = sum_co D[t', co] * W2c[co, ci0 + c, dt]     (MFMA, M = H2, K = CP, N = GS*kh)
+//   G[t, ci0 + c]    = sum_dt P[t - dt, c*kh + dt],  0 <= t-dt < H2  (LDS reduction)
 // which spends kh*CI*CP*H2 MACs -- the exact count of the transposed convolution -- instead of the
-// (tc x kh*CP) x CI padded-GEMM form that multiplies mostly zeros.
+// (tc x kh*CP) x CI padded-GEMM form that multiplies mostly zeros.  Splitting the channels into NG
+// groups gives NG x more workgroups (the 32-tile batch has only 96 (tile, branch) pairs).
+// The A fragments (one row block of D) stay in registers; the NQ B values of a column block are
+// all requested before the first MFMA that needs them, and the next block's are in flight meanwhile.
 // ------------------------------------------------------------------------------------------------
+template <int NQ>
 __global__ __launch_bounds__(kThreads) void deconv2_kernel(const float* __restrict__ D, const float* __restrict__ Bw,
                                                            float* __restrict__ G, int H2, int CP, int CI, int kh,
-                                                           int tc, int ncp /* padded kh*CI, multiple of 16 */) {
+                                                           int tc, int GS, int gcols /* padded GS*kh, multiple of 16 */) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nrb = (H2 + 15) >> 4;  // 1 or 2 row blocks
     const int as = CP + 2;
     float* As = smem;                 // [16*nrb][CP+2]
-    float* P = smem + 16 * nrb * as;  // [16*nrb][ncp]
+    float* P = smem + 16 * nrb * as;  // [16*nrb][gcols]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
     const int64_t ks = blockIdx.x;
+    const int grp = blockIdx.y;
     const float* Dp = D + ks * (int64_t)H2 * CP;
 
     for (int idx = tid; idx < 16 * nrb * CP; idx += kThreads) {
@@ -39,38 +44,56 @@ __global__ __launch_bounds__(kThreads) void deconv2_kernel(const float* __restri
     }
     __syncthreads();
 
-    const int ncb = ncp >> 4;
-    const int nq = CP >> 2;
-    for (int cb = wave; cb < ncb; cb += 4) {
+    float a0[NQ], a1[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        a0[q] = As[fi * as + 4 * q + kq];
+        a1[q] = (nrb > 1) ? As[(16 + fi) * as + 4 * q + kq] : 0.f;
+    }
+
+    const int ncb = gcols >> 4;
+    const int ldb = gcols * (int)gridDim.y;
+    const float* bbase = Bw + (int64_t)kq * ldb + grp * gcols + fi;
+    float b[NQ], bn[NQ];
+    int cb = wave;
+    if (cb < ncb) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) b[q] = bbase[(int64_t)(4 * q) * ldb + cb * 16];
+    }
+    for (; cb < ncb; cb += 4) {
+        const int nxt = cb + 4;
+        if (nxt < ncb) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) bn[q] = bbase[(int64_t)(4 * q) * ldb + nxt * 16];
+        }
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* bcol = Bw + cb * 16 + fi;
-        for (int q = 0; q < nq; ++q) {
-            const float b = bcol[(int64_t)(4 * q + kq) * ncp];
-            const float a0 = As[fi * as + 4 * q + kq];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
-            if (nrb > 1) {
-                const float a1 = As[(16 + fi) * as + 4 * q + kq];
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
-            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], b[q], acc0, 0, 0, 0);
+            if (nrb > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b[q], acc1, 0, 0, 0);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            P[(kq * 4 + e) * ncp + cb * 16 + fi] = acc0[e];
-            if (nrb > 1) P[(16 + kq * 4 + e) * ncp + cb * 16 + fi] = acc1[e];
+            P[(kq * 4 + e) * gcols + cb * 16 + fi] = acc0[e];
+            if (nrb > 1) P[(16 + kq * 4 + e) * gcols + cb * 16 + fi] = acc1[e];
         }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) b[q] = bn[q];
     }
     __syncthreads();
 
+    const int ci0 = grp * GS;
     float* Gp = G + ks * (int64_t)tc * CI;
-    for (int o = tid; o < tc * CI; o += kThreads) {
-        const int t = o / CI, ci = o - t * CI;
+    for (int o = tid; o < tc * GS; o += kThreads) {
+        const int t = o / GS, c = o - t * GS;
+        if (ci0 + c >= CI) continue;
         int lo = t - (H2 - 1);
         if (lo < 0) lo = 0;
-        int hi = t < kh - 1 ? t : kh - 1;
+        const int hi = t < kh - 1 ? t : kh - 1;
         float sum = 0.f;
-        for (int dt = lo; dt <= hi; ++dt) sum += P[(t - dt) * ncp + dt * CI + ci];
-        Gp[o] = sum;
+        for (int dt = lo; dt <= hi; ++dt) sum += P[(t - dt) * gcols + c * kh + dt];
+        Gp[t * CI + ci0 + c] = sum;
     }
 }
 
@@ -86,7 +109,8 @@ template <bool FOLD>
 __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
     constexpr int NBR = 3;      // dense branches that reach the output (separate_dsd.py:228)
     constexpr int NQ_MAX = 16;  // CI <= 64
-    __shared__ __attribute__((aligned(16))) float As[NBR * 16 * (64 + 2)];
+    constexpr int kABuf = NBR * 16 * (64 + 2);
+    __shared__ __attribute__((aligned(16))) float As[2 * kABuf];  // double-buffered A set
     __shared__ int meta_k0[16];
     __shared__ int meta_j0[16];
 
@@ -143,24 +167,50 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
 
     __syncthreads();
 
-    const int slots = NBR * 16 * nq;  // float4 slots of one staged A set
+    // ---- staging plan of this thread: up to 3 float4 slots of the [3 branches][16 rows][CI] A set.
+    // Slot (s, i, c4) reads G[k0_i + m][s][j0_i - m*st][4 c4 ..]; going from m to m+1 moves the
+    // address by the constant (NBR*tc - st)*CI, so only validity has to be re-evaluated per m.
+    const int slots = NBR * 16 * nq;
+    const int64_t m_delta = ((int64_t)NBR * tc - st) * CI;
+    const float* src[3];
+    int dst[3], sk0[3], sj0[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int idx = tid + u * kThreads;
+        const int s = idx / (16 * nq);
+        const int rem = idx - s * 16 * nq;
+        const int i = rem / nq, c4 = rem - i * nq;
+        const bool in = idx < slots;
+        sk0[u] = in ? meta_k0[i] : 0;
+        sj0[u] = in ? meta_j0[i] : -1;
+        dst[u] = in ? (s * 16 + i) * as + c4 * 4 : 0;
+        src[u] = a.G + (((int64_t)sk0[u] * NBR + s) * tc + (sj0[u] < 0 ? 0 : sj0[u])) * (int64_t)CI + c4 * 4;
+    }
+    f32x4 pre[3];
+#define DCS_LOAD_A(m_)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                             \
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                    \
+        if (sj0[u] >= 0 && sj0[u] - (m_) * st >= 0 && (int64_t)sk0[u] + (m_) < n)               \
+            v = *reinterpret_cast<const f32x4*>(src[u] + (m_) * m_delta);                       \
+        pre[u] = v;                                                                             \
+    }
+#define DCS_STORE_A(buf_)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                             \
+        if (tid + u * kThreads < slots) {                                                       \
+            float* d = As + (buf_) * kABuf + dst[u];                                            \
+            *reinterpret_cast<float2*>(d) = make_float2(pre[u][0], pre[u][1]);                  \
+            *reinterpret_cast<float2*>(d + 2) = make_float2(pre[u][2], pre[u][3]);              \
+        }                                                                                       \
+    }
+
+    DCS_LOAD_A(0)
+    DCS_STORE_A(0)
+    __syncthreads();
+
     for (int m = 0; m < a.mmax; ++m) {
-        // ---- stage the decoder rows G[k0+m][branch][j0 - m*st][:] of the 16 rows, 3 branches
-        for (int idx = tid; idx < slots; idx += kThreads) {
-            const int s = idx / (16 * nq);
-            const int rem = idx - s * 16 * nq;
-            const int i = rem / nq, c4 = rem - i * nq;
-            const int j0 = meta_j0[i];
-            const int64_t k = (int64_t)meta_k0[i] + m;
-            const int j = j0 - m * st;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j0 >= 0 && j >= 0 && k < n)
-                v = *reinterpret_cast<const f32x4*>(a.G + ((k * NBR + s) * tc + j) * (int64_t)CI + c4 * 4);
-            float* d = As + (s * 16 + i) * as + c4 * 4;
-            *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
-            *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
-        }
-        __syncthreads();
+        const bool more = m + 1 < a.mmax;
+        if (more) DCS_LOAD_A(m + 1)  // in flight while this m's MFMAs and epilogue run
+        const float* Ab = As + (m & 1) * kABuf;
 
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -170,9 +220,9 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
             if (q < nq) {
                 const float b = breg[q];
                 const int off = fi * as + 4 * q + kq;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(As[off], b, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(As[16 * as + off], b, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(As[32 * as + off], b, acc2, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[off], b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[16 * as + off], b, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[32 * as + off], b, acc2, 0, 0, 0);
             }
         }
 
@@ -189,15 +239,15 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
             const float p2 = fmaxf(acc2[e] + bias2, 0.f);
             const float p3 = fmaxf(acc1[e] + bias3, 0.f);
             float v0, v1, v2, v3;
-            if (a.mask_mode == 0) {  // convention A
+            if (a.mask_mode == 0) {  // convention A: m_i = s_i / sum(s), s_i = p_i + eps*r
                 const float s0 = p0 + eps_r, s1 = p1 + eps_r, s2 = p2 + eps_r, s3 = p3 + eps_r;
-                const float den = ((s0 + s1) + s2) + s3;
-                const float x = mixv[e];
-                v0 = (s0 / den) * x; v1 = (s1 / den) * x; v2 = (s2 / den) * x; v3 = (s3 / den) * x;
-            } else if (a.mask_mode == 1) {  // convention B
+                const float den = ((s0 + s1) + s2) + s3;             // >= 4*eps*r: never zero or denormal
+                const float w = __builtin_amdgcn_rcpf(den) * mixv[e];  // one v_rcp_f32 (1 ulp) for 4 masks
+                v0 = s0 * w; v1 = s1 * w; v2 = s2 * w; v3 = s3 * w;
+            } else if (a.mask_mode == 1) {  // convention B: m_i = p_i / (sum(p) + eps*r)
                 const float den = (((p0 + p1) + p2) + p3) + eps_r;
-                const float x = mixv[e];
-                v0 = (p0 / den) * x; v1 = (p1 / den) * x; v2 = (p2 / den) * x; v3 = (p3 / den) * x;
+                const float w = __builtin_amdgcn_rcpf(den) * mixv[e];
+                v0 = p0 * w; v1 = p1 * w; v2 = p2 * w; v3 = p3 * w;
             } else {  // raw network output (get_output)
                 v0 = p0; v1 = p1; v2 = p2; v3 = p3;
             }
@@ -211,8 +261,13 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
                 res[3][e] = down * res[3][e] + up * v3;
             }
         }
-        __syncthreads();
+        if (more) {
+            DCS_STORE_A((m + 1) & 1)  // the other buffer: last read in iteration m-1, fenced by its barrier
+            __syncthreads();
+        }
     }
+#undef DCS_LOAD_A
+#undef DCS_STORE_A
 
     if (col < a.F) {
 #pragma unroll
@@ -229,18 +284,16 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
 }  // namespace
 
 int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float* G, int64_t n_ks, int H2, int CP,
-                           int CI, int kh, int tc, int ncp) {
+                           int CI, int kh, int tc, int NG, int GS, int gcols) {
     if (n_ks <= 0) return DCS_OK;
     const int nrb = (H2 + 15) / 16;
     if (nrb > 2) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: conv2 output height %d > 32", H2);
-    const size_t lds = (size_t)16 * nrb * ((CP + 2) + ncp) * sizeof(float);
-    if (lds > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: LDS %zu too large", lds);
-    if (lds > 48 * 1024)
-        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deconv2_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (CP != 52) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: built for 50 conv2 filters (CP=52), got CP=%d", CP);
+    const size_t lds = (size_t)16 * nrb * ((CP + 2) + gcols) * sizeof(float);
+    if (lds > 64 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: LDS %zu too large", lds);
     DcsTimer tm(ctx, DCS_TAG_DECONV2);
-    hipLaunchKernelGGL(deconv2_kernel, dim3((unsigned)n_ks), dim3(kThreads), lds, ctx->stream, D, Bw, G, H2, CP, CI,
-                       kh, tc, ncp);
+    hipLaunchKernelGGL(deconv2_kernel<13>, dim3((unsigned)n_ks, (unsigned)NG), dim3(kThreads), lds, ctx->stream, D, Bw,
+                       G, H2, CP, CI, kh, tc, GS, gcols);
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;

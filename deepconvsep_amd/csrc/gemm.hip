@@ -18,13 +18,14 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int BK = 32;
 constexpr int BN = 64;
-constexpr int AS = BK + 2;   // A tile row stride (floats): 2*i + kq distinct banks for the fragment read
 constexpr int BS = BN + 16;  // B tile row stride: rows kq, kq+1 land 16 banks apart
 
-template <int RB, bool VEC>
+// BK = 32: many workgroups, several resident per CU hide each other's K-tile latency.
+// BK = 128: few workgroups (the 32-tile batch): one memory latency per 128 of K instead of per 32.
+template <int RB, int BK, bool VEC>
 __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
+    constexpr int AS = BK + 2;  // A tile row stride (floats): 2*i + kq distinct banks for the fragment read
     constexpr int BM = 16 * RB;
     constexpr int A_F4 = BM * (BK / 4);                        // float4 slots in an A tile
     constexpr int A_PER = (A_F4 + kThreads - 1) / kThreads;    // per thread
@@ -150,13 +151,13 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
 #undef DCS_LOAD_TILES
 #undef DCS_STORE_TILES
 
-template <int RB>
+template <int RB, int BK>
 void launch_rb(dcs_ctx* ctx, const DcsGemm& g) {
     dim3 grid((unsigned)dcs_cdiv(g.M, 16 * RB), (unsigned)(g.n_cols / BN));
     if (g.a_vec)
-        hipLaunchKernelGGL((gemm_rows_kernel<RB, true>), grid, dim3(kThreads), 0, ctx->stream, g);
+        hipLaunchKernelGGL((gemm_rows_kernel<RB, BK, true>), grid, dim3(kThreads), 0, ctx->stream, g);
     else
-        hipLaunchKernelGGL((gemm_rows_kernel<RB, false>), grid, dim3(kThreads), 0, ctx->stream, g);
+        hipLaunchKernelGGL((gemm_rows_kernel<RB, BK, false>), grid, dim3(kThreads), 0, ctx->stream, g);
 }
 
 }  // namespace
@@ -169,12 +170,14 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     // few rows: maximise the number of workgroups; many rows: reuse each B fragment 4 times
     const int64_t groups16 = (g.M + 15) / 16;
     const int64_t col_groups = g.n_cols / BN;
-    if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu)
-        launch_rb<1>(ctx, g);
+    if (groups16 * col_groups <= 2 * (int64_t)ctx->n_cu)
+        launch_rb<1, 128>(ctx, g);
+    else if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu)
+        launch_rb<1, 32>(ctx, g);
     else if (groups16 * col_groups <= 16 * (int64_t)ctx->n_cu)
-        launch_rb<2>(ctx, g);
+        launch_rb<2, 32>(ctx, g);
     else
-        launch_rb<4>(ctx, g);
+        launch_rb<4, 32>(ctx, g);
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;

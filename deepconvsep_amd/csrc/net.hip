@@ -72,7 +72,8 @@ struct dcs_model {
     int arch = 0, C = 1, tc = 30, F = 0;
     Dims d;
     // ---- DSD packed weights
-    int CI = 0, CP = 0, K1 = 0, F64 = 0, ncp = 0, hid64 = 0, nd = 0, nd64 = 0;
+    int CI = 0, CP = 0, K1 = 0, F64 = 0, hid64 = 0, nd = 0, nd64 = 0;
+    int d2_ng = 4, d2_gs = 0, d2_gcols = 0;  // transposed conv2: channel groups, channels per group, padded columns
     float *B1 = nullptr, *bias1 = nullptr, *B2 = nullptr, *bias2 = nullptr, *Bfc = nullptr, *biasfc = nullptr;
     float *Bd = nullptr, *biasd = nullptr, *Bw2 = nullptr, *Bfin = nullptr, *bout = nullptr;
     // ---- generic path (ikala / bach10 / score-informed)
@@ -114,7 +115,9 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     m->CP = CP;
     m->K1 = (int)dcs_round_up(F, 4);
     m->F64 = (int)dcs_round_up(F, 64);
-    m->ncp = (int)dcs_round_up(d.kh2 * CI, 16);
+    m->d2_ng = 4;
+    m->d2_gs = (CI + m->d2_ng - 1) / m->d2_ng;
+    m->d2_gcols = (int)dcs_round_up(m->d2_gs * d.kh2, 16);
     m->hid64 = (int)dcs_round_up(d.hidden, 64);
     m->nd = d.n_fc * d.h2 * CP;
     m->nd64 = (int)dcs_round_up(m->nd, 64);
@@ -124,14 +127,14 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     const float *Wfc = P[6].data(), *bfc = P[7].data();
 
     // conv1 (true convolution = correlation with the flipped filter): B1[f][c] = W1[c,0,0,F-1-f]
-    std::vector<float> B1((size_t)dcs_round_up(m->K1, 32) * 64, 0.f), bias1(64, 0.f);
+    std::vector<float> B1((size_t)dcs_round_up(m->K1, 128) * 64, 0.f), bias1(64, 0.f);
     for (int c = 0; c < d.nf1; ++c) {
         for (int f = 0; f < F; ++f) B1[(size_t)f * 64 + c] = W1[(size_t)c * F + (F - 1 - f)];
         bias1[c] = b1[c] + b1b[c];
     }
     // conv2: B2[u*CI + ci][co] = W2[co,ci,kh-1-u,0]
     const int kh = d.kh2;
-    std::vector<float> B2((size_t)dcs_round_up(kh * CI, 32) * 64, 0.f), bias2(64, 0.f);
+    std::vector<float> B2((size_t)dcs_round_up(kh * CI, 128) * 64, 0.f), bias2(64, 0.f);
     for (int co = 0; co < d.nf2; ++co) {
         for (int ci = 0; ci < d.nf1; ++ci)
             for (int u = 0; u < kh; ++u)
@@ -139,14 +142,14 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
         bias2[co] = b2[co] + b2b[co];
     }
     // bottleneck: input index of the flattened [nf2, h2, 1] map is co*h2 + t'; ours is t'*CP + co
-    std::vector<float> Bfc((size_t)dcs_round_up(d.h2 * CP, 32) * m->hid64, 0.f), biasfc(m->hid64, 0.f);
+    std::vector<float> Bfc((size_t)dcs_round_up(d.h2 * CP, 128) * m->hid64, 0.f), biasfc(m->hid64, 0.f);
     for (int co = 0; co < d.nf2; ++co)
         for (int t = 0; t < d.h2; ++t)
             for (int h = 0; h < d.hidden; ++h)
                 Bfc[(size_t)(t * CP + co) * m->hid64 + h] = Wfc[(size_t)(co * d.h2 + t) * d.hidden + h];
     for (int h = 0; h < d.hidden; ++h) biasfc[h] = bfc[h];
     // per-source dense layers, concatenated along N and permuted to [branch][t'][co]
-    std::vector<float> Bd((size_t)dcs_round_up(m->hid64, 32) * m->nd64, 0.f), biasd(m->nd64, 0.f);
+    std::vector<float> Bd((size_t)dcs_round_up(m->hid64, 128) * m->nd64, 0.f), biasd(m->nd64, 0.f);
     for (int s = 0; s < d.n_fc; ++s) {
         const float* Ws = P[8 + 2 * s].data();
         const float* bs = P[9 + 2 * s].data();
@@ -157,12 +160,14 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
                 biasd[col] = bs[co * d.h2 + t];
             }
     }
-    // transposed conv2: Bw2[co][dt*CI + ci] = W2[co,ci,kh-1-dt,0]
-    std::vector<float> Bw2((size_t)CP * m->ncp, 0.f);
+    // transposed conv2: Bw2[co][g*gcols + c*kh + dt] = W2[co, g*GS + c, kh-1-dt, 0]
+    const int ldw2 = m->d2_ng * m->d2_gcols;
+    std::vector<float> Bw2((size_t)CP * ldw2, 0.f);
     for (int co = 0; co < d.nf2; ++co)
         for (int ci = 0; ci < d.nf1; ++ci)
             for (int dt = 0; dt < kh; ++dt)
-                Bw2[(size_t)co * m->ncp + dt * CI + ci] = W2[((size_t)co * d.nf1 + ci) * kh + (kh - 1 - dt)];
+                Bw2[(size_t)co * ldw2 + (ci / m->d2_gs) * m->d2_gcols + (ci % m->d2_gs) * kh + dt] =
+                    W2[((size_t)co * d.nf1 + ci) * kh + (kh - 1 - dt)];
     // transposed conv1: Bfin[c][f] = W1[c,0,0,F-1-f]
     std::vector<float> Bfin((size_t)CI * m->F64, 0.f);
     for (int c = 0; c < d.nf1; ++c)
@@ -228,7 +233,8 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g4.M = n; g4.n_cols = m->nd64; g4.n_store = m->nd; g4.K = m->hid64; g4.relu = 1; g4.a_vec = 1;
     DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
     // InverseLayer(., l_conv2) (separate_dsd.py:211,217,223)
-    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, w.G, n * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->ncp);
+    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, w.G, n * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
+                                  m->d2_gcols);
 }
 
 size_t dsd_scratch_bytes(const dcs_model* m, int64_t n, int64_t rows1, int64_t rows2) {

@@ -58,6 +58,9 @@ class Context(object):
         _lib.check(self._lib.dcs_synchronize(self._h))
 
     # -- kernel timing (bench.py) ---------------------------------------------------------------
+    def timing_stride(self, stride):
+        _lib.check(self._lib.dcs_timing_stride(self._h, int(stride)))
+
     def timing(self, tags):
         """Bracket the kernels of the named tags (``_lib.TAGS`` keys; ``'all'``; ``None`` = off) with HIP events."""
         if not tags:

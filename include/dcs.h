@@ -152,6 +152,8 @@ int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int
 enum { DCS_TAG_STFT = 0, DCS_TAG_CONV1 = 1, DCS_TAG_CONV2 = 2, DCS_TAG_FC = 3, DCS_TAG_FC1X = 4,
        DCS_TAG_DECONV2 = 5, DCS_TAG_FINAL = 6, DCS_TAG_ISTFT = 7, DCS_TAG_OLA = 8, DCS_TAG_COUNT = 9 };
 int dcs_timing_enable(dcs_ctx* ctx, unsigned tag_mask);
+/* bracket only every stride-th launch of an enabled tag (an event pair costs ~6 us of stream time each side) */
+int dcs_timing_stride(dcs_ctx* ctx, int stride);
 int dcs_timing_reset(dcs_ctx* ctx);
 int dcs_timing_query(dcs_ctx* ctx, int which, double* avg_ms, int64_t* launches);
 
