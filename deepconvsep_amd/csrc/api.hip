@@ -224,35 +224,35 @@ extern "C" int dcs_stft_plan_destroy(dcs_stft* p) {
     (void)hipFree(p->wsq_d);
     (void)hipFree(p->tw_f);
     (void)hipFree(p->tw_d);
-    p->frames.release();
     delete p;
     return DCS_OK;
 }
 
-template <typename R>
+template <typename R, typename R2>
 static int forward_checked(dcs_stft* p, const R* audio, int64_t L, R* mag, R* phase, int64_t ld, int64_t rows_out,
-                           int (*launch)(dcs_stft*, const R*, int64_t, R*, R*, int64_t, int64_t, int64_t)) {
+                           int (*launch)(dcs_stft*, const R*, int64_t, R*, R*, R2*, int64_t, int64_t, int64_t)) {
     if (!p || !mag || (!audio && L > 0)) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: null argument");
     if (L < 0) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: negative length");
     const int64_t T = dcs_frame_count(L, p->hop);
     if (ld < p->frame / 2 + 1) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: ld %lld < bins %d", (long long)ld, p->frame / 2 + 1);
     if (rows_out < T) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: rows_out %lld < frames %lld", (long long)rows_out, (long long)T);
-    return launch(p, audio, L, mag, phase, ld, rows_out, T);
+    return launch(p, audio, L, mag, phase, (R2*)nullptr, ld, rows_out, T);
 }
 
 extern "C" int dcs_stft_forward_f32(dcs_stft* p, const float* audio_d, int64_t n, float* mag_d, float* phase_d,
                                     int64_t ld, int64_t rows_out) {
-    return forward_checked<float>(p, audio_d, n, mag_d, phase_d, ld, rows_out, dcs_launch_stft_forward_f32);
+    return forward_checked<float, float2>(p, audio_d, n, mag_d, phase_d, ld, rows_out, dcs_launch_stft_forward_f32);
 }
 extern "C" int dcs_stft_forward_f64(dcs_stft* p, const double* audio_d, int64_t n, double* mag_d, double* phase_d,
                                     int64_t ld, int64_t rows_out) {
-    return forward_checked<double>(p, audio_d, n, mag_d, phase_d, ld, rows_out, dcs_launch_stft_forward_f64);
+    return forward_checked<double, double2>(p, audio_d, n, mag_d, phase_d, ld, rows_out, dcs_launch_stft_forward_f64);
 }
 
-template <typename R>
+template <typename R, typename R2>
 static int inverse_checked(dcs_stft* p, const R* mag, int64_t src_stride, const R* phase, int64_t ld, int64_t T,
                            int n_src, R pre_div, R* audio, int64_t n_out,
-                           int (*launch)(dcs_stft*, const R*, int64_t, const R*, int64_t, int64_t, int, R, R*, int64_t)) {
+                           int (*launch)(dcs_stft*, const R*, int64_t, const R*, const R2*, int64_t, int64_t, int, R, R*,
+                                         int64_t)) {
     if (!p || !mag || !phase || !audio) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: null argument");
     if (T <= 0 || n_src <= 0) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: empty input");
     if (ld < p->frame / 2 + 1) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: ld < bins");
@@ -260,18 +260,18 @@ static int inverse_checked(dcs_stft* p, const R* mag, int64_t src_stride, const 
         DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: n_out %lld exceeds %lld", (long long)n_out,
                  (long long)dcs_inverse_length(T, p->hop, p->frame));
     if (pre_div == R(0)) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: pre_div is zero");
-    return launch(p, mag, src_stride, phase, ld, T, n_src, pre_div, audio, n_out);
+    return launch(p, mag, src_stride, phase, (const R2*)nullptr, ld, T, n_src, pre_div, audio, n_out);
 }
 
 extern "C" int dcs_stft_inverse_f32(dcs_stft* p, const float* mag_d, int64_t src_stride, const float* phase_d,
                                     int64_t ld, int64_t T, int n_src, float pre_div, float* audio_d, int64_t n_out) {
-    return inverse_checked<float>(p, mag_d, src_stride, phase_d, ld, T, n_src, pre_div, audio_d, n_out,
+    return inverse_checked<float, float2>(p, mag_d, src_stride, phase_d, ld, T, n_src, pre_div, audio_d, n_out,
                                   dcs_launch_stft_inverse_f32);
 }
 extern "C" int dcs_stft_inverse_f64(dcs_stft* p, const double* mag_d, int64_t src_stride, const double* phase_d,
                                     int64_t ld, int64_t T, int n_src, double pre_div, double* audio_d,
                                     int64_t n_out) {
-    return inverse_checked<double>(p, mag_d, src_stride, phase_d, ld, T, n_src, pre_div, audio_d, n_out,
+    return inverse_checked<double, double2>(p, mag_d, src_stride, phase_d, ld, T, n_src, pre_div, audio_d, n_out,
                                    dcs_launch_stft_inverse_f64);
 }
 

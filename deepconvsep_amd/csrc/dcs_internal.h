@@ -83,18 +83,22 @@ struct dcs_stft {
     double2* tw_d = nullptr;
     float* wsq_f = nullptr;     // [N] window*window in float32 (normaliser terms)
     double* wsq_d = nullptr;
-    DcsBuffer frames;           // iSTFT scratch: windowed time frames [n_src][T][N]
 };
 
 // launchers implemented in fft.hip
-int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase,
+// `unit` (nullable) = exp(j*angle(X)) as X/|X|, [rows, ld] complex: the fused path carries it instead
+// of the angle so that neither atan2 nor sincos is evaluated.  The inverse takes `unit` when non-null,
+// else `phase`.
+int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit,
                                 int64_t ld, int64_t rows_out, int64_t T);
 int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, double* mag, double* phase,
-                                int64_t ld, int64_t rows_out, int64_t T);
+                                double2* unit, int64_t ld, int64_t rows_out, int64_t T);
 int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase,
-                                int64_t ld, int64_t T, int n_src, float pre_div, float* audio, int64_t n_out);
+                                const float2* unit, int64_t ld, int64_t T, int n_src, float pre_div, float* audio,
+                                int64_t n_out);
 int dcs_launch_stft_inverse_f64(dcs_stft* p, const double* mag, int64_t src_stride, const double* phase,
-                                int64_t ld, int64_t T, int n_src, double pre_div, double* audio, int64_t n_out);
+                                const double2* unit, int64_t ld, int64_t T, int n_src, double pre_div, double* audio,
+                                int64_t n_out);
 
 // ---------------------------------------------------------------------------------- GEMM on rows
 // C[row(r)][0..n_store) = act( a_scale * A[arow(r)][0..K) . B[K][ldb] + bias )

@@ -133,17 +133,20 @@ __device__ __forceinline__ void dcs_sincos(double a, double* s, double* c) { sin
 template <typename R, typename R2>
 __global__ __launch_bounds__(kThreads) void stft_forward_kernel(
     const R* __restrict__ audio, int64_t L, const R* __restrict__ win, const R2* __restrict__ tw,
-    R* __restrict__ mag, R* __restrict__ phase, int64_t ld, int N, int hop, int log2m, int64_t T, R sqrt_n) {
+    R* __restrict__ mag, R* __restrict__ phase, R2* __restrict__ unit, int64_t ld, int N, int hop, int log2m,
+    int64_t T, R sqrt_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = N >> 1;
     const int tid = threadIdx.x;
     const int64_t t = blockIdx.x;
     R* mrow = mag + t * ld;
     R* prow = phase ? phase + t * ld : nullptr;
+    R2* urow = unit ? unit + t * ld : nullptr;
     if (t >= T) {  // rows past the last frame: zeros (zero-padding tiler, util.py:233)
         for (int k = tid; k < ld; k += kThreads) {
             mrow[k] = R(0);
             if (prow) prow[k] = R(0);
+            if (urow) urow[k] = mk<R2, R>(R(1), R(0));
         }
         return;
     }
@@ -168,97 +171,112 @@ __global__ __launch_bounds__(kThreads) void stft_forward_kernel(
         const R2 w = tw[k];
         const R xr = er + (w.x * orr - w.y * oi);
         const R xi = ei + (w.x * oi + w.y * orr);
-        mrow[k] = dcs_sqrt(xr * xr + xi * xi) / sqrt_n;
+        const R ax = dcs_sqrt(xr * xr + xi * xi);
+        mrow[k] = ax / sqrt_n;
         if (prow) prow[k] = dcs_atan2(xi, xr);
+        // exp(j*angle(X)) without the angle: X/|X|, and 1 where X == 0 (np.angle(0) = 0)
+        if (urow) urow[k] = (ax > R(0)) ? mk<R2, R>(xr / ax, xi / ax) : mk<R2, R>(R(1), R(0));
     }
     for (int k = M + 1 + tid; k < ld; k += kThreads) {  // row padding
         mrow[k] = R(0);
         if (prow) prow[k] = R(0);
+        if (urow) urow[k] = mk<R2, R>(R(1), R(0));
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// inverse, step 1: X = (mag / pre_div) * sqrt(N) * exp(j phase) (transform.py:271-272,
-// separate_dsd.py:304) -> irfft (imaginary parts of DC / Nyquist ignored, as numpy does)
-// -> window * frame written to the scratch [src][t][N]  (transform.py:382-388)
+// inverse (compute_inverse, transform.py:271-273 + istft_norm, transform.py:337-396), one kernel:
+//   X = (mag / pre_div) * sqrt(N) * exp(j phase)   (separate_dsd.py:304: pre_div = scale_factor)
+//   frame = irfft(X)[:N]  (imaginary parts of DC / Nyquist ignored, as numpy does)
+//   data[n*hop : n*hop+N] += window * frame ; norm += window * window ; drop N/2 ; data / norm
+// A workgroup owns C consecutive hops of ONE source's output and walks the C + ceil(N/hop) - 1
+// frames that overlap it in increasing n (the reference's accumulation order), adding each
+// windowed frame into an LDS accumulator -- the [src][T][N] time-frame scratch of a two-pass
+// scheme (2*N*4 bytes per frame per source through HBM) never exists.  exp(j phase) comes either
+// from the angle (API path, sincos) or from the unit phasor the forward kernel stored (fused path).
 // ------------------------------------------------------------------------------------------
-template <typename R, typename R2>
-__global__ __launch_bounds__(kThreads) void stft_inverse_kernel(
-    const R* __restrict__ mag, int64_t src_stride, const R* __restrict__ phase, int64_t ld,
-    const R* __restrict__ win, const R2* __restrict__ tw, R* __restrict__ frames, int N, int log2m, int64_t T,
-    R pre_div, R sqrt_n) {
+template <typename R, typename R2, bool UNIT>
+__global__ __launch_bounds__(kThreads) void istft_fused_kernel(
+    const R* __restrict__ mag, int64_t src_stride, const R* __restrict__ phase, const R2* __restrict__ unit,
+    int64_t ld, const R* __restrict__ win, const R* __restrict__ wsq, const R2* __restrict__ tw,
+    R* __restrict__ audio, int64_t n_out, int N, int hop, int log2m, int64_t T, int C, R pre_div, R sqrt_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = N >> 1;
     const int tid = threadIdx.x;
-    const int64_t t = blockIdx.x;
     const int s = blockIdx.y;
     R2* buf0 = reinterpret_cast<R2*>(smem);
     R2* buf1 = buf0 + M;  // M+1 entries: holds X first, then serves as the FFT ping-pong buffer
     R2* X = buf1;
-    const R* mrow = mag + (int64_t)s * src_stride + t * ld;
-    const R* prow = phase + t * ld;
-    for (int k = tid; k <= M; k += kThreads) {
-        const R a = (mrow[k] / pre_div) * sqrt_n;
-        R sn, cs;
-        dcs_sincos(prow[k], &sn, &cs);
-        R2 x = mk<R2, R>(a * cs, a * sn);
-        if (k == 0 || k == M) x.y = R(0);
-        X[k] = x;
-    }
-    __syncthreads();
-    for (int k = tid; k < M; k += kThreads) {
-        const R2 xk = X[k];
-        const R2 xm = X[M - k];
-        // E = (xk + conj(xm))/2 ; D = (xk - conj(xm))/2 ; O = D * conj(w^k) ; Z = E + i O
-        const R er = R(0.5) * (xk.x + xm.x), ei = R(0.5) * (xk.y - xm.y);
-        const R dr = R(0.5) * (xk.x - xm.x), di = R(0.5) * (xk.y + xm.y);
-        const R2 w = tw[k];
-        const R orr = dr * w.x + di * w.y;
-        const R oi = di * w.x - dr * w.y;
-        buf0[k] = mk<R2, R>(er - oi, ei + orr);
-    }
-    __syncthreads();
-    const R2* z = fft_lds<R, R2, +1>(buf0, buf1, tw, M, log2m);
-    const R inv_m = R(1) / R(M);
-    R2* out = reinterpret_cast<R2*>(frames + ((int64_t)s * T + t) * N);
-    const R2* w2 = reinterpret_cast<const R2*>(win);
-    for (int m = tid; m < M; m += kThreads) {
-        const R2 v = z[m];
-        const R2 w = w2[m];
-        out[m] = mk<R2, R>((v.x * inv_m) * w.x, (v.y * inv_m) * w.y);
-    }
-}
+    R* acc = reinterpret_cast<R*>(buf1 + (M + 1));
+    const int span = C * hop;
+    const int64_t p0 = (int64_t)blockIdx.x * span;  // first padded position of this chunk
+    for (int q = tid; q < span; q += kThreads) acc[q] = R(0);
 
-// ------------------------------------------------------------------------------------------
-// inverse, step 2: gather overlap-add + normalisation (transform.py:384-394).  Output sample m
-// sits at padded position p = m + N/2 and receives frames n with n*hop <= p < n*hop + N, summed
-// in increasing n like the reference loop; the normaliser sums window*window over the same
-// frames, zeros -> 1.
-// ------------------------------------------------------------------------------------------
-template <typename R>
-__global__ __launch_bounds__(kThreads) void istft_ola_kernel(const R* __restrict__ frames,
-                                                             const R* __restrict__ wsq, R* __restrict__ audio,
-                                                             int64_t n_out, int N, int hop, int64_t T) {
-    const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    const int s = blockIdx.y;
-    if (m >= n_out) return;
-    const int64_t p = m + (N >> 1);
-    int64_t n_hi = p / hop;
+    int64_t n_hi = (p0 + span - 1) / hop;
     if (n_hi > T - 1) n_hi = T - 1;
-    const int64_t n_lo = (p < N) ? 0 : (p - N) / hop + 1;
-    R acc = R(0), norm = R(0);
-    const R* f = frames + (int64_t)s * T * N;
+    const int64_t n_lo = (p0 < N) ? 0 : (p0 - N) / hop + 1;
+    const R inv_m = R(1) / R(M);
+    const R2* w2 = reinterpret_cast<const R2*>(win);
+    const R* msrc = mag + (int64_t)s * src_stride;
+
     for (int64_t n = n_lo; n <= n_hi; ++n) {
-        const int64_t off = p - n * hop;
-        acc += f[n * N + off];
-        norm += wsq[off];
+        __syncthreads();  // previous frame: accumulator updates done, FFT buffers free
+        const R* mrow = msrc + n * ld;
+        for (int k = tid; k <= M; k += kThreads) {
+            const R a = (mrow[k] / pre_div) * sqrt_n;
+            R2 x;
+            if (UNIT) {
+                const R2 u = unit[n * ld + k];
+                x = mk<R2, R>(a * u.x, a * u.y);
+            } else {
+                R sn, cs;
+                dcs_sincos(phase[n * ld + k], &sn, &cs);
+                x = mk<R2, R>(a * cs, a * sn);
+            }
+            if (k == 0 || k == M) x.y = R(0);
+            X[k] = x;
+        }
+        __syncthreads();
+        for (int k = tid; k < M; k += kThreads) {
+            const R2 xk = X[k];
+            const R2 xm = X[M - k];
+            // E = (xk + conj(xm))/2 ; D = (xk - conj(xm))/2 ; O = D * conj(w^k) ; Z = E + i O
+            const R er = R(0.5) * (xk.x + xm.x), ei = R(0.5) * (xk.y - xm.y);
+            const R dr = R(0.5) * (xk.x - xm.x), di = R(0.5) * (xk.y + xm.y);
+            const R2 w = tw[k];
+            const R orr = dr * w.x + di * w.y;
+            const R oi = di * w.x - dr * w.y;
+            buf0[k] = mk<R2, R>(er - oi, ei + orr);
+        }
+        __syncthreads();
+        const R2* z = fft_lds<R, R2, +1>(buf0, buf1, tw, M, log2m);
+        const int64_t off = n * (int64_t)hop - p0;  // chunk-relative position of sample 0 of the frame
+        for (int m = tid; m < M; m += kThreads) {
+            const R2 v = z[m];
+            const R2 w = w2[m];
+            const int64_t q = off + 2 * m;
+            if (q >= 0 && q < span) acc[q] += (v.x * inv_m) * w.x;
+            if (q + 1 >= 0 && q + 1 < span) acc[q + 1] += (v.y * inv_m) * w.y;
+        }
     }
-    if (norm == R(0)) norm = R(1);
-    audio[(int64_t)s * n_out + m] = acc / norm;
+    __syncthreads();
+    const int half = N >> 1;
+    for (int q = tid; q < span; q += kThreads) {
+        const int64_t p = p0 + q;
+        const int64_t m = p - half;
+        if (m < 0 || m >= n_out) continue;
+        int64_t f_hi = p / hop;
+        if (f_hi > T - 1) f_hi = T - 1;
+        const int64_t f_lo = (p < N) ? 0 : (p - N) / hop + 1;
+        R norm = R(0);
+        for (int64_t n = f_lo; n <= f_hi; ++n) norm += wsq[p - n * hop];
+        if (norm == R(0)) norm = R(1);
+        audio[(int64_t)s * n_out + m] = acc[q] / norm;
+    }
 }
 
 template <typename R, typename R2>
-int launch_forward(dcs_stft* p, const R* win, const R2* tw, const R* audio, int64_t L, R* mag, R* phase,
+int launch_forward(dcs_stft* p, const R* win, const R2* tw, const R* audio, int64_t L, R* mag, R* phase, R2* unit,
                    int64_t ld, int64_t rows_out, int64_t T) {
     if (rows_out <= 0) return DCS_OK;
     const int M = p->frame / 2;
@@ -269,7 +287,7 @@ int launch_forward(dcs_stft* p, const R* win, const R2* tw, const R* audio, int6
                                     (int)lds));
     DcsTimer tm(p->ctx, DCS_TAG_STFT);
     hipLaunchKernelGGL(kern, dim3((unsigned)rows_out), dim3(kThreads), lds, p->ctx->stream, audio, L, win, tw,
-                       mag, phase, ld, p->frame, p->hop, p->log2m, T, (R)sqrt((double)p->frame));
+                       mag, phase, unit, ld, p->frame, p->hop, p->log2m, T, (R)sqrt((double)p->frame));
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
@@ -277,52 +295,64 @@ int launch_forward(dcs_stft* p, const R* win, const R2* tw, const R* audio, int6
 
 template <typename R, typename R2>
 int launch_inverse(dcs_stft* p, const R* win, const R2* tw, const R* wsq, const R* mag, int64_t src_stride,
-                   const R* phase, int64_t ld, int64_t T, int n_src, R pre_div, R* audio, int64_t n_out) {
+                   const R* phase, const R2* unit, int64_t ld, int64_t T, int n_src, R pre_div, R* audio,
+                   int64_t n_out) {
     if (T <= 0 || n_src <= 0 || n_out <= 0) return DCS_OK;
-    const int N = p->frame;
+    const int N = p->frame, hop = p->hop;
     const int M = N / 2;
-    DCS_CHECK(p->frames.ensure((size_t)n_src * T * N * sizeof(R)));
-    R* frames = reinterpret_cast<R*>(p->frames.ptr);
-    const size_t lds = (2 * (size_t)M + 1) * sizeof(R2);
-    auto kern = stft_inverse_kernel<R, R2>;
-    if (lds > 48 * 1024)
-        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-    {
-        DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
-        hipLaunchKernelGGL(kern, dim3((unsigned)T, (unsigned)n_src), dim3(kThreads), lds, p->ctx->stream, mag,
-                           src_stride, phase, ld, win, tw, frames, N, p->log2m, T, pre_div,
-                           (R)sqrt((double)N));
-        tm.done();
+    const int64_t hops = (n_out + N / 2 + hop - 1) / hop;  // padded positions [0, n_out + N/2)
+    // hops per workgroup: enough workgroups to fill the chip first, then fewer redundant halo FFTs
+    const int R_ = (N + hop - 1) / hop;
+    int64_t C = hops * n_src / (int64_t)p->ctx->n_cu;
+    if (C > 4 * R_) C = 4 * R_;
+    if (C < 1) C = 1;
+    size_t lds = (2 * (size_t)M + 1) * sizeof(R2) + (size_t)C * hop * sizeof(R);
+    while (lds > 64 * 1024 && C > 1) {
+        C = C / 2;
+        lds = (2 * (size_t)M + 1) * sizeof(R2) + (size_t)C * hop * sizeof(R);
     }
-    DCS_HIP(hipGetLastError());
-    {
-        DcsTimer tm(p->ctx, DCS_TAG_OLA);
-        hipLaunchKernelGGL(istft_ola_kernel<R>, dim3((unsigned)dcs_cdiv(n_out, kThreads), (unsigned)n_src),
-                           dim3(kThreads), 0, p->ctx->stream, frames, wsq, audio, n_out, N, p->hop, T);
-        tm.done();
+    if (lds > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "istft: frame %d needs %zu bytes of LDS", N, lds);
+    const dim3 grid((unsigned)((hops + C - 1) / C), (unsigned)n_src);
+    DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
+    if (unit) {
+        auto kern = istft_fused_kernel<R, R2, true>;
+        if (lds > 48 * 1024)
+            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, p->ctx->stream, mag, src_stride, phase, unit, ld, win, wsq,
+                           tw, audio, n_out, N, hop, p->log2m, T, (int)C, pre_div, (R)sqrt((double)N));
+    } else {
+        auto kern = istft_fused_kernel<R, R2, false>;
+        if (lds > 48 * 1024)
+            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, p->ctx->stream, mag, src_stride, phase, unit, ld, win, wsq,
+                           tw, audio, n_out, N, hop, p->log2m, T, (int)C, pre_div, (R)sqrt((double)N));
     }
+    tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }
 
 }  // namespace
 
-int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, int64_t ld,
-                                int64_t rows_out, int64_t T) {
-    return launch_forward<float, float2>(p, p->win_f, p->tw_f, audio, L, mag, phase, ld, rows_out, T);
+int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit,
+                                int64_t ld, int64_t rows_out, int64_t T) {
+    return launch_forward<float, float2>(p, p->win_f, p->tw_f, audio, L, mag, phase, unit, ld, rows_out, T);
 }
 int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, double* mag, double* phase,
-                                int64_t ld, int64_t rows_out, int64_t T) {
-    return launch_forward<double, double2>(p, p->win_d, p->tw_d, audio, L, mag, phase, ld, rows_out, T);
+                                double2* unit, int64_t ld, int64_t rows_out, int64_t T) {
+    return launch_forward<double, double2>(p, p->win_d, p->tw_d, audio, L, mag, phase, unit, ld, rows_out, T);
 }
-int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, int64_t ld,
-                                int64_t T, int n_src, float pre_div, float* audio, int64_t n_out) {
-    return launch_inverse<float, float2>(p, p->win_f, p->tw_f, p->wsq_f, mag, src_stride, phase, ld, T, n_src,
+int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase,
+                                const float2* unit, int64_t ld, int64_t T, int n_src, float pre_div, float* audio,
+                                int64_t n_out) {
+    return launch_inverse<float, float2>(p, p->win_f, p->tw_f, p->wsq_f, mag, src_stride, phase, unit, ld, T, n_src,
                                          pre_div, audio, n_out);
 }
 int dcs_launch_stft_inverse_f64(dcs_stft* p, const double* mag, int64_t src_stride, const double* phase,
-                                int64_t ld, int64_t T, int n_src, double pre_div, double* audio, int64_t n_out) {
-    return launch_inverse<double, double2>(p, p->win_d, p->tw_d, p->wsq_d, mag, src_stride, phase, ld, T, n_src,
+                                const double2* unit, int64_t ld, int64_t T, int n_src, double pre_div, double* audio,
+                                int64_t n_out) {
+    return launch_inverse<double, double2>(p, p->win_d, p->tw_d, p->wsq_d, mag, src_stride, phase, unit, ld, T, n_src,
                                            pre_div, audio, n_out);
 }

@@ -151,6 +151,83 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
 #undef DCS_LOAD_TILES
 #undef DCS_STORE_TILES
 
+// ------------------------------------------------------------------------------------------------
+// Few-rows variant (the 32-tile batch: 12 row groups for conv1, 2 for the dense layers).  With so
+// few workgroups a kernel's duration is the serial MFMA chain of one wave, so the chain is cut
+// instead of the traffic: workgroup = one 16 x 16 output tile, the 4 waves take interleaved
+// 64-wide slices of K, partial accumulators are reduced through LDS.  Operand fragments are
+// loaded straight from global memory (each element is used by exactly one wave, so LDS staging
+// would buy nothing); K is visited in the order k = kc + 16 j + 4 kq + e so that a lane's A values
+// of four consecutive steps are one 16-byte load.  Two accumulators alternate to stay issue-bound
+// (the 16x16x4 f32 MFMA has a 40-cycle dependent latency but a 32-cycle issue interval).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGemm g) {
+    __shared__ float red[3 * 64 * 4];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int n0 = blockIdx.y * 16;
+    const int gK = g.K, gldb = g.ldb;
+    const float gscale = g.a_scale;
+    const int64_t r = m0 + fi;
+    const bool row_ok = r < g.M;
+    const int64_t rr = row_ok ? r : 0;
+    const float* a_ptr = g.A + ((rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda + 4 * kq;
+    const float* b_ptr = g.B + (int64_t)(4 * kq) * gldb + n0 + fi;
+
+    f32x4 a_cur[4], a_nxt[4];
+    float b_cur[16], b_nxt[16];
+#define DCS_SK_LOAD(kc_, A_, B_)                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        const int k = (kc_) + 16 * j;                                                             \
+        A_[j] = (row_ok && k + 4 * kq < gK) ? *reinterpret_cast<const f32x4*>(a_ptr + k)          \
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};                          \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) B_[4 * j + e] = b_ptr[(int64_t)(k + e) * gldb]; \
+    }
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kc = wave * 64;
+    if (kc < gK) DCS_SK_LOAD(kc, a_cur, b_cur)
+    for (; kc < gK; kc += 256) {
+        const int kn = kc + 256;
+        if (kn < gK) DCS_SK_LOAD(kn, a_nxt, b_nxt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gscale * a_cur[j][0], b_cur[4 * j + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gscale * a_cur[j][1], b_cur[4 * j + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gscale * a_cur[j][2], b_cur[4 * j + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gscale * a_cur[j][3], b_cur[4 * j + 3], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b_cur[j] = b_nxt[j];
+    }
+#undef DCS_SK_LOAD
+    const f32x4 acc = acc0 + acc1;
+    if (wave > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 sum = acc;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) sum += *reinterpret_cast<const f32x4*>(red + (w * 64 + lane) * 4);
+        const int col = n0 + fi;
+        if (col < g.n_store) {
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = m0 + kq * 4 + e;
+                if (row < g.M) {
+                    float v = sum[e] + bias;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
 template <int RB, int BK>
 void launch_rb(dcs_ctx* ctx, const DcsGemm& g) {
     dim3 grid((unsigned)dcs_cdiv(g.M, 16 * RB), (unsigned)(g.n_cols / BN));
@@ -170,7 +247,10 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     // few rows: maximise the number of workgroups; many rows: reuse each B fragment 4 times
     const int64_t groups16 = (g.M + 15) / 16;
     const int64_t col_groups = g.n_cols / BN;
-    if (groups16 * col_groups <= 2 * (int64_t)ctx->n_cu)
+    if (g.a_vec && groups16 * col_groups <= (int64_t)ctx->n_cu / 2) {
+        dim3 grid((unsigned)groups16, (unsigned)(g.n_cols / 16));
+        hipLaunchKernelGGL(gemm_rows_splitk_kernel, grid, dim3(kThreads), 0, ctx->stream, g);
+    } else if (groups16 * col_groups <= 2 * (int64_t)ctx->n_cu)
         launch_rb<1, 128>(ctx, g);
     else if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu)
         launch_rb<1, 32>(ctx, g);

@@ -396,19 +396,21 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
     const int64_t Tcov = (n - 1) * st + tc;       // frames covered by the tiles
     const int64_t Trows = Tcov > T ? Tcov : T;    // zero rows past T feed the zero-padding tiler
     const int64_t ld = dcs_round_up(F, 4);
-    const size_t b_mag = align256((size_t)Trows * ld * 4), b_ph = b_mag;  // the STFT also zero-fills phase rows past T
+    // the STFT also fills rows past T of the phase / unit-phasor matrices
+    const size_t b_mag = align256((size_t)Trows * ld * 4), b_unit = 2 * b_mag, b_ph = phase_out ? b_mag : 0;
     const size_t b_sep = align256((size_t)S * T * ld * 4);
 
     if (m->arch == DCS_ARCH_DSD) {
         const int64_t rows2 = (n - 1) * st + m->d.h2;
-        DCS_CHECK(m->ws.ensure(b_mag + b_ph + b_sep + dsd_scratch_bytes(m, n, Tcov, rows2)));
+        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + dsd_scratch_bytes(m, n, Tcov, rows2)));
         char* p = (char*)m->ws.ptr;
         float* mag = (float*)p; p += b_mag;
-        float* phase = (float*)p; p += b_ph;
+        float2* unit = (float2*)p; p += b_unit;
+        float* phase = phase_out ? (float*)p : nullptr; p += b_ph;
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
         dsd_carve(m, p, n, Tcov, rows2, &w);
-        DCS_CHECK(dcs_launch_stft_forward_f32(plan, audio_d, L, mag, phase, ld, Trows, T));
+        DCS_CHECK(dcs_launch_stft_forward_f32(plan, audio_d, L, mag, phase, unit, ld, Trows, T));
         DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
@@ -418,7 +420,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         a.rise = m->rise_d; a.n = n; a.rows = T; a.tc = tc; a.ov = ov; a.st = st;
         a.F = F; a.CI = m->CI; a.mmax = (ov + st - 1) / st + 1; a.mask_mode = eps_mode;
         DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
-        if (pcm_d) DCS_CHECK(dcs_launch_stft_inverse_f32(plan, sep, T * ld, phase, ld, T, S, scale, pcm_d, L));
+        if (pcm_d) DCS_CHECK(dcs_launch_stft_inverse_f32(plan, sep, T * ld, nullptr, unit, ld, T, S, scale, pcm_d, L));
         if (sep_out || mag_out || phase_out) {
             for (int s = 0; s < S && sep_out; ++s)
                 DCS_HIP(hipMemcpy2DAsync(sep_out + (int64_t)s * T * ld_out, ld_out * 4, sep + (int64_t)s * T * ld, ld * 4,

@@ -240,6 +240,35 @@ def test_dsd_separation_matches_oracle(N, tiler):
     assert d.max() <= 2
 
 
+def test_long_clip_matches_oracle_on_interior_segments():
+    """BASELINE-size check of the many-rows kernel variants (4096 tiles, 3 min 58 s, N=2048): tiles only
+    see local audio, so the separated spectrogram / PCM of a segment cut on the tile grid equals the
+    whole-clip result away from the segment's edges.  The oracle runs on three 1.5 s segments."""
+    N, hop, F, tc, ov = 2048, 512, 1025, 30, 25
+    st = tc - ov
+    params = synth_params("dsd", tc, F, seed=2)
+    n_tiles = 4096
+    L = (tc + 1 + (n_tiles - 1) * st - 2) * hop
+    audio = synth_audio(L, seed=7)
+    sep = dcs.Separator("dsd", params, 0.3, tc, ov, 32, F, N, hop, np.hanning)
+    ctx = default_context()
+    s_d, _, _ = sep.net.separate_spectra(sep.plan, ctx.to_device(audio, np.float32), ov, sep.tiler, 0.3)
+    assert tuple(s_d.shape) == (4, _lib.frame_count(L, hop), F)
+    pcm = sep.separate(audio)
+    seg_frames = 130
+    for q in (0, 1531, 4040):            # segment starts, in tiles
+        a0 = q * st * hop
+        seg = audio[a0:a0 + (seg_frames - 2) * hop]
+        want_pcm, mm, _, _ = pipeline.separate("dsd", params, seg, 0.3, tc, ov, 32, N, hop, np.hanning,
+                                               return_spectra=True)
+        lo = 0 if q == 0 else tc + 4                     # frames whose covering tiles and samples are all inside
+        hi = mm.shape[1] - tc - 8
+        got = s_d[:, q * st + lo:q * st + hi].cpu().numpy()
+        assert np.max(np.abs(got - mm[:, lo:hi])) < 1e-4
+        s_lo, s_hi = lo * hop + N, (hi - 4) * hop
+        assert np.max(np.abs(pcm[:, a0 + s_lo:a0 + s_hi] - want_pcm[:, s_lo:s_hi])) < 1e-4
+
+
 def test_separation_edge_cases():
     F = 513
     params = synth_params("dsd", 30, F, seed=2)
