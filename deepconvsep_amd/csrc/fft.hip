@@ -15,6 +15,7 @@
 #include "dcs_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -134,7 +135,7 @@ template <typename R, typename R2>
 __global__ __launch_bounds__(kThreads) void stft_forward_kernel(
     const R* __restrict__ audio, int64_t L, const R* __restrict__ win, const R2* __restrict__ tw,
     R* __restrict__ mag, R* __restrict__ phase, R2* __restrict__ unit, int64_t ld, int N, int hop, int log2m,
-    int64_t T, R sqrt_n) {
+    int64_t T, R sqrt_n, int tw_lds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = N >> 1;
     const int tid = threadIdx.x;
@@ -152,6 +153,14 @@ __global__ __launch_bounds__(kThreads) void stft_forward_kernel(
     }
     R2* buf0 = reinterpret_cast<R2*>(smem);
     R2* buf1 = buf0 + M;
+    // Twiddle table staged in LDS together with the frame: one exposed memory latency instead of one
+    // dependent L1/L2 round trip per FFT pass (measured: ~10 us of workgroup time per 1024-point FFT
+    // with the table in global memory).
+    if (tw_lds) {
+        R2* twl = buf1 + M;
+        for (int k = tid; k <= M; k += kThreads) twl[k] = tw[k];
+        tw = twl;
+    }
     const int64_t base = t * (int64_t)hop - M;  // audio index of padded sample t*hop
     for (int m = tid; m < M; m += kThreads) {
         const int64_t p = base + 2 * m;
@@ -195,11 +204,14 @@ __global__ __launch_bounds__(kThreads) void stft_forward_kernel(
 // scheme (2*N*4 bytes per frame per source through HBM) never exists.  exp(j phase) comes either
 // from the angle (API path, sincos) or from the unit phasor the forward kernel stored (fused path).
 // ------------------------------------------------------------------------------------------
-template <typename R, typename R2, bool UNIT>
+// PF = bins per thread ( >= ceil((N/2+1)/256) ): the next frame's rows are prefetched into registers
+// while the current frame is transformed.
+template <typename R, typename R2, bool UNIT, int PF>
 __global__ __launch_bounds__(kThreads) void istft_fused_kernel(
     const R* __restrict__ mag, int64_t src_stride, const R* __restrict__ phase, const R2* __restrict__ unit,
     int64_t ld, const R* __restrict__ win, const R* __restrict__ wsq, const R2* __restrict__ tw,
-    R* __restrict__ audio, int64_t n_out, int N, int hop, int log2m, int64_t T, int C, R pre_div, R sqrt_n) {
+    R* __restrict__ audio, int64_t n_out, int N, int hop, int log2m, int64_t T, int C, R pre_div, R sqrt_n,
+    int tw_lds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = N >> 1;
     const int tid = threadIdx.x;
@@ -207,7 +219,12 @@ __global__ __launch_bounds__(kThreads) void istft_fused_kernel(
     R2* buf0 = reinterpret_cast<R2*>(smem);
     R2* buf1 = buf0 + M;  // M+1 entries: holds X first, then serves as the FFT ping-pong buffer
     R2* X = buf1;
-    R* acc = reinterpret_cast<R*>(buf1 + (M + 1));
+    R2* twl = buf1 + (M + 1);
+    R* acc = reinterpret_cast<R*>(tw_lds ? twl + (M + 1) : twl);
+    if (tw_lds) {
+        for (int k = tid; k <= M; k += kThreads) twl[k] = tw[k];
+        tw = twl;
+    }
     const int span = C * hop;
     const int64_t p0 = (int64_t)blockIdx.x * span;  // first padded position of this chunk
     for (int q = tid; q < span; q += kThreads) acc[q] = R(0);
@@ -219,23 +236,38 @@ __global__ __launch_bounds__(kThreads) void istft_fused_kernel(
     const R2* w2 = reinterpret_cast<const R2*>(win);
     const R* msrc = mag + (int64_t)s * src_stride;
 
+    R pm[PF];   // magnitudes of the frame about to be transformed
+    R2 pu[PF];  // unit phasors (UNIT) or {phase, -} (!UNIT)
+#define DCS_ROWS_LOAD(n_)                                                          \
+    _Pragma("unroll") for (int u = 0; u < PF; ++u) {                               \
+        const int k = tid + u * kThreads;                                          \
+        if (k <= M) {                                                              \
+            pm[u] = msrc[(n_) * ld + k];                                           \
+            if (UNIT) pu[u] = unit[(n_) * ld + k];                                 \
+            else pu[u].x = phase[(n_) * ld + k];                                   \
+        }                                                                          \
+    }
+    if (n_lo <= n_hi) DCS_ROWS_LOAD(n_lo)
     for (int64_t n = n_lo; n <= n_hi; ++n) {
         __syncthreads();  // previous frame: accumulator updates done, FFT buffers free
-        const R* mrow = msrc + n * ld;
-        for (int k = tid; k <= M; k += kThreads) {
-            const R a = (mrow[k] / pre_div) * sqrt_n;
-            R2 x;
-            if (UNIT) {
-                const R2 u = unit[n * ld + k];
-                x = mk<R2, R>(a * u.x, a * u.y);
-            } else {
-                R sn, cs;
-                dcs_sincos(phase[n * ld + k], &sn, &cs);
-                x = mk<R2, R>(a * cs, a * sn);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int k = tid + u * kThreads;
+            if (k <= M) {
+                const R a = (pm[u] / pre_div) * sqrt_n;
+                R2 x;
+                if (UNIT) {
+                    x = mk<R2, R>(a * pu[u].x, a * pu[u].y);
+                } else {
+                    R sn, cs;
+                    dcs_sincos(pu[u].x, &sn, &cs);
+                    x = mk<R2, R>(a * cs, a * sn);
+                }
+                if (k == 0 || k == M) x.y = R(0);
+                X[k] = x;
             }
-            if (k == 0 || k == M) x.y = R(0);
-            X[k] = x;
         }
+        if (n + 1 <= n_hi) DCS_ROWS_LOAD(n + 1)  // in flight during the transform of frame n
         __syncthreads();
         for (int k = tid; k < M; k += kThreads) {
             const R2 xk = X[k];
@@ -273,6 +305,7 @@ __global__ __launch_bounds__(kThreads) void istft_fused_kernel(
         if (norm == R(0)) norm = R(1);
         audio[(int64_t)s * n_out + m] = acc[q] / norm;
     }
+#undef DCS_ROWS_LOAD
 }
 
 template <typename R, typename R2>
@@ -280,17 +313,47 @@ int launch_forward(dcs_stft* p, const R* win, const R2* tw, const R* audio, int6
                    int64_t ld, int64_t rows_out, int64_t T) {
     if (rows_out <= 0) return DCS_OK;
     const int M = p->frame / 2;
-    const size_t lds = 2 * (size_t)M * sizeof(R2);
+    size_t lds = (3 * (size_t)M + 1) * sizeof(R2);
+    const int tw_lds = lds <= 64 * 1024;
+    if (!tw_lds) lds = 2 * (size_t)M * sizeof(R2);
     auto kern = stft_forward_kernel<R, R2>;
     if (lds > 48 * 1024)
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
     DcsTimer tm(p->ctx, DCS_TAG_STFT);
     hipLaunchKernelGGL(kern, dim3((unsigned)rows_out), dim3(kThreads), lds, p->ctx->stream, audio, L, win, tw,
-                       mag, phase, unit, ld, p->frame, p->hop, p->log2m, T, (R)sqrt((double)p->frame));
+                       mag, phase, unit, ld, p->frame, p->hop, p->log2m, T, (R)sqrt((double)p->frame), tw_lds);
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
+}
+
+template <typename R, typename R2, bool UNIT, int PF>
+int launch_inverse_pf(dcs_stft* p, const dim3& grid, size_t lds, const R* win, const R2* tw, const R* wsq, const R* mag,
+                      int64_t src_stride, const R* phase, const R2* unit, int64_t ld, int64_t T, R pre_div, R* audio,
+                      int64_t n_out, int C, int tw_lds) {
+    auto kern = istft_fused_kernel<R, R2, UNIT, PF>;
+    if (lds > 48 * 1024)
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, p->ctx->stream, mag, src_stride, phase, unit, ld, win, wsq, tw,
+                       audio, n_out, p->frame, p->hop, p->log2m, T, C, pre_div, (R)sqrt((double)p->frame), tw_lds);
+    return DCS_OK;
+}
+
+template <typename R, typename R2, bool UNIT>
+int launch_inverse_unit(dcs_stft* p, const dim3& grid, size_t lds, const R* win, const R2* tw, const R* wsq,
+                        const R* mag, int64_t src_stride, const R* phase, const R2* unit, int64_t ld, int64_t T,
+                        R pre_div, R* audio, int64_t n_out, int C, int tw_lds) {
+    const int need = (p->frame / 2 + 1 + kThreads - 1) / kThreads;
+#define DCS_PF(PF_)                                                                                                  \
+    return launch_inverse_pf<R, R2, UNIT, PF_>(p, grid, lds, win, tw, wsq, mag, src_stride, phase, unit, ld, T, pre_div, \
+                                               audio, n_out, C, tw_lds)
+    if (need <= 3) DCS_PF(3);
+    if (need <= 5) DCS_PF(5);
+    if (need <= 9) DCS_PF(9);
+    DCS_PF(17);
+#undef DCS_PF
 }
 
 template <typename R, typename R2>
@@ -306,30 +369,28 @@ int launch_inverse(dcs_stft* p, const R* win, const R2* tw, const R* wsq, const 
     int64_t C = hops * n_src / (int64_t)p->ctx->n_cu;
     if (C > 4 * R_) C = 4 * R_;
     if (C < 1) C = 1;
-    size_t lds = (2 * (size_t)M + 1) * sizeof(R2) + (size_t)C * hop * sizeof(R);
-    while (lds > 64 * 1024 && C > 1) {
+    const size_t fixed_tw = (3 * (size_t)M + 2) * sizeof(R2), fixed_notw = (2 * (size_t)M + 1) * sizeof(R2);
+    const int tw_lds = fixed_tw + (size_t)hop * sizeof(R) <= 64 * 1024;
+    const size_t fixed = tw_lds ? fixed_tw : fixed_notw;
+    size_t lds = fixed + (size_t)C * hop * sizeof(R);
+    // LDS per workgroup decides how many workgroups share a CU (their barriers overlap); 48 KiB = 3 per CU
+    static const size_t lds_cap = getenv("DCS_ISTFT_LDS_KB") ? (size_t)atoi(getenv("DCS_ISTFT_LDS_KB")) * 1024 : 48 * 1024;
+    while (lds > lds_cap && C > 1) {
         C = C / 2;
-        lds = (2 * (size_t)M + 1) * sizeof(R2) + (size_t)C * hop * sizeof(R);
+        lds = fixed + (size_t)C * hop * sizeof(R);
     }
     if (lds > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "istft: frame %d needs %zu bytes of LDS", N, lds);
     const dim3 grid((unsigned)((hops + C - 1) / C), (unsigned)n_src);
     DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
-    if (unit) {
-        auto kern = istft_fused_kernel<R, R2, true>;
-        if (lds > 48 * 1024)
-            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, p->ctx->stream, mag, src_stride, phase, unit, ld, win, wsq,
-                           tw, audio, n_out, N, hop, p->log2m, T, (int)C, pre_div, (R)sqrt((double)N));
-    } else {
-        auto kern = istft_fused_kernel<R, R2, false>;
-        if (lds > 48 * 1024)
-            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, p->ctx->stream, mag, src_stride, phase, unit, ld, win, wsq,
-                           tw, audio, n_out, N, hop, p->log2m, T, (int)C, pre_div, (R)sqrt((double)N));
-    }
+    int rc;
+    if (unit)
+        rc = launch_inverse_unit<R, R2, true>(p, grid, lds, win, tw, wsq, mag, src_stride, phase, unit, ld, T, pre_div,
+                                              audio, n_out, (int)C, tw_lds);
+    else
+        rc = launch_inverse_unit<R, R2, false>(p, grid, lds, win, tw, wsq, mag, src_stride, phase, unit, ld, T, pre_div,
+                                               audio, n_out, (int)C, tw_lds);
     tm.done();
+    DCS_CHECK(rc);
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }
