@@ -309,3 +309,99 @@ def test_train_auto_writes_the_reference_files(tmp_path):
         sr, data = scipy.io.wavfile.read(str(tmp_path / (name + ".wav")))
         assert sr == 44100 and data.dtype == np.int16 and data.shape == (44100,)
         assert np.abs(data.astype(int) - (want[i] * 32767).astype('int16').astype(int)).max() <= 2
+
+
+# ------------------------------------------------------------------------------------------ other graphs
+@pytest.mark.parametrize("arch,F,n", [("ikala", 513, 3), ("bach10", 257, 3), ("bach10_si", 257, 2), ("ikala", 1025, 2)])
+def test_generic_graphs_match_oracle(arch, F, n):
+    """iKala (max-pool / un-pool), Bach10 (strided conv1 with uncovered tail columns) and the 4-channel
+    score-informed graph: network output before masking and the masked sources."""
+    tc = 30
+    params = synth_params(arch, tc, F, seed=3)
+    x = _tiles(arch, n, tc, F, seed=12)
+    ctx = default_context()
+    net = Network(ctx, arch, params, tc, F)
+    xd = ctx.to_device(x, np.float32)
+    p = net.forward_raw(xd).cpu().numpy()
+    want = net_ref.forward(arch, params, x.astype(np.float64), inverse='explicit').numpy()
+    assert p.shape == want.shape
+    assert np.max(np.abs(p - want)) < 1e-4
+    got = net.forward_masked(xd).cpu().numpy()
+    ref = net_ref.predict(arch, params, x.astype(np.float64), inverse='explicit')
+    assert got.shape == (ARCHS[arch].S, n, tc, F)
+    for s in range(ARCHS[arch].S):
+        assert np.max(np.abs(got[s] - ref[s][:, 0])) < 1e-4
+
+
+def test_ikala_pool_tie_modes():
+    """Digital-silence rows make every pooling window tie: Theano's CPU gradient feeds all tied positions
+    (default), cuDNN only the first."""
+    from deepconvsep_amd.arch import TIE_ALL, TIE_FIRST
+    tc, F, n = 30, 513, 2
+    params = synth_params("ikala", tc, F, seed=9)
+    x = _tiles("ikala", n, tc, F, seed=13)
+    x[0, 0, 10:14] = 0.0
+    ctx = default_context()
+    net = Network(ctx, "ikala", params, tc, F)
+    xd = ctx.to_device(x, np.float32)
+    for mode, name in ((TIE_ALL, 'all'), (TIE_FIRST, 'first')):
+        p = net.forward_raw(xd, tie_mode=mode).cpu().numpy()
+        want = net_ref.forward("ikala", params, x.astype(np.float64), tie_mode=name, inverse='explicit').numpy()
+        assert np.max(np.abs(p - want)) < 1e-4
+    a = net.forward_raw(xd, tie_mode=TIE_ALL).cpu().numpy()
+    b = net.forward_raw(xd, tie_mode=TIE_FIRST).cpu().numpy()
+    assert np.abs(a - b).max() > 1e-5
+
+
+def test_generic_chunked_batch_equals_small_batches():
+    """More tiles than one scratch chunk (64): the chunked batch equals tile-by-tile evaluation."""
+    tc, F, n = 30, 257, 70
+    params = synth_params("bach10", tc, F, seed=4)
+    x = _tiles("bach10", n, tc, F, seed=14)
+    ctx = default_context()
+    net = Network(ctx, "bach10", params, tc, F)
+    xd = ctx.to_device(x, np.float32)
+    whole = net.forward_masked(xd).cpu().numpy()
+    parts = np.concatenate([net.forward_masked(xd[i:i + 7]).cpu().numpy() for i in range(0, n, 7)], axis=1)
+    assert np.max(np.abs(whole - parts)) < 1e-6
+
+
+def test_ikala_separation_matches_oracle():
+    """BASELINE configs[0]: iKala 2-source, frameSize 1024 hop 512, overlap 20, stereo wav summed L+R."""
+    F, N = 513, 1024
+    params = synth_params("ikala", 30, F, seed=1)
+    stereo = synth_audio(3 * 44100, seed=0, channels=2)
+    audio = stereo[:, 0] + stereo[:, 1]                       # separate_ikala.py:229
+    sep = dcs.Separator("ikala", params, 0.3, 30, 20, 32, F, N, 512, np.hanning)
+    got = sep.separate(audio)
+    want = pipeline.separate("ikala", params, audio, 0.3, 30, 20, 32, N, 512, np.hanning)
+    assert got.shape == want.shape == (2, audio.size)
+    assert np.max(np.abs(got - want)) < 1e-4
+    assert np.max(np.abs(sep.separate_stepwise(audio) - got)) < 2e-5
+
+
+def test_bach10_full_size_separation_matches_oracle():
+    """BASELINE configs[3] shapes: frameSize 4096 blackmanharris, 2049 bins, 17-array model (853 MB of
+    float32 weights, K = 166 650 dense layers), convention-B masks."""
+    F, N = 2049, 4096
+    params = synth_params("bach10", 30, F, seed=3)
+    audio = synth_audio(22050 + 9000, seed=5)
+    sep = dcs.Separator("bach10", params, 0.3, 30, 25, 32, F, N, 512, dcs.blackmanharris)
+    got = sep.separate(audio)
+    want = pipeline.separate("bach10", params, audio, 0.3, 30, 25, 32, N, 512, dcs.blackmanharris)
+    assert got.shape == want.shape == (4, audio.size)
+    assert np.max(np.abs(got - want)) < 1e-4
+
+
+def test_long_file_plan_on_one_gpu():
+    """deepconvsep_amd.dist.plan_long_file: separating the two halo-extended halves one after the other on
+    this GPU and keeping each one's interior reproduces the whole-file result."""
+    from deepconvsep_amd.dist import plan_long_file
+    F, N = 513, 1024
+    params = synth_params("dsd", 30, F, seed=2)
+    audio = synth_audio(4 * 44100, seed=8)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, N, 512, np.hanning)
+    whole = sep.separate(audio)
+    pieces = [sep.separate(audio[p['a0']:p['a1']])[:, p['s0'] - p['a0']:p['s1'] - p['a0']]
+              for p in plan_long_file(audio.size, 2, N, 512, 30, 25)]
+    assert np.max(np.abs(np.concatenate(pieces, axis=1) - whole)) < 2e-6
