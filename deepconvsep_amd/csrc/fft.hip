@@ -13,6 +13,7 @@
 // HBM traffic per frame (forward): hop new samples in (neighbouring frames hit L2), 2*(N/2+1)
 // values out -- the stage is HBM-bound.
 #include "dcs_internal.h"
+#include "fft_wave.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -399,6 +400,15 @@ int launch_inverse(dcs_stft* p, const R* win, const R2* tw, const R* wsq, const 
 
 int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit,
                                 int64_t ld, int64_t rows_out, int64_t T) {
+    if (dcs_fft_wave_supported(p)) {
+        if (rows_out <= 0) return DCS_OK;
+        DcsTimer tm(p->ctx, DCS_TAG_STFT);
+        const int rc = dcs_fft_wave_forward(p, audio, L, mag, phase, unit, ld, rows_out, T);
+        tm.done();
+        DCS_CHECK(rc);
+        DCS_HIP(hipGetLastError());
+        return DCS_OK;
+    }
     return launch_forward<float, float2>(p, p->win_f, p->tw_f, audio, L, mag, phase, unit, ld, rows_out, T);
 }
 int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, double* mag, double* phase,
@@ -408,6 +418,15 @@ int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, dou
 int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase,
                                 const float2* unit, int64_t ld, int64_t T, int n_src, float pre_div, float* audio,
                                 int64_t n_out) {
+    if (dcs_fft_wave_supported(p)) {
+        if (T <= 0 || n_src <= 0 || n_out <= 0) return DCS_OK;
+        DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
+        const int rc = dcs_fft_wave_inverse(p, mag, src_stride, phase, unit, ld, T, n_src, pre_div, audio, n_out);
+        tm.done();
+        DCS_CHECK(rc);
+        DCS_HIP(hipGetLastError());
+        return DCS_OK;
+    }
     return launch_inverse<float, float2>(p, p->win_f, p->tw_f, p->wsq_f, mag, src_stride, phase, unit, ld, T, n_src,
                                          pre_div, audio, n_out);
 }

@@ -1,0 +1,9 @@
+// Wave-per-frame float32 STFT kernels (fft_wave.hip) -- the fast path for N = 1024 / 2048 / 4096.
+#pragma once
+#include "dcs_internal.h"
+
+bool dcs_fft_wave_supported(const dcs_stft* p);
+int dcs_fft_wave_forward(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
+                         int64_t rows_out, int64_t T);
+int dcs_fft_wave_inverse(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, const float2* unit,
+                         int64_t ld, int64_t T, int n_src, float pre_div, float* audio, int64_t n_out);
