@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Batch-of-files driver: what examples/dsd100/separate_multiple.ipynb of the reference does with
+``os.system("python separate_dsd.py -i ... -o ... -m ...")`` per song, with the model resident on the GPU.
+
+    python separate_batch.py -a dsd -m model.pkl -o outdir  a.wav b.wav ...
+    python -m torch.distributed.run --nproc-per-node 8 separate_batch.py -a dsd -m model.pkl -o outdir *.wav
+
+Every file gets its own sub-directory ``outdir/<stem>/`` holding the wav files the single-file script
+writes.  With several ranks (one process per GPU) the files are dealt round-robin: replicas only, no
+collective on the data path.  While the GPU separates file i the host reads file i+1 and writes file i-1
+(two worker threads), so wav I/O overlaps the kernels.
+"""
+import argparse
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-a", "--arch", default="dsd", choices=["dsd", "hiphop", "ikala", "bach10"])
+    ap.add_argument("-m", "--mfile", required=True)
+    ap.add_argument("-o", "--odir", required=True)
+    ap.add_argument("files", nargs="+")
+    args = ap.parse_args(argv)
+
+    import torch
+    from deepconvsep_amd import separation as sp
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    frame, hop, window, overlap, bins = sp._SCRIPT_DEFAULTS[args.arch]
+    sep = sp.Separator(args.arch, sp.load_model(args.mfile), 0.3, 30, overlap, 32, bins, frame, hop, window)
+    mine = args.files[rank::world]
+
+    def read(path):
+        sr, audio = sp.read_wav(path)
+        return path, sr, (sp.to_mono(audio, args.arch) if sr == 44100 else None)
+
+    def write(path, sr, pcm):
+        out = os.path.join(args.odir, os.path.splitext(os.path.basename(path))[0])
+        os.makedirs(out, exist_ok=True)
+        for dst, sig in zip(sp.output_paths(args.arch, path, out), pcm):
+            sp.write_wav(dst, sig, sr)
+
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        nxt = pool.submit(read, mine[0]) if mine else None
+        pending = None
+        for i in range(len(mine)):
+            path, sr, audio = nxt.result()
+            nxt = pool.submit(read, mine[i + 1]) if i + 1 < len(mine) else None
+            if audio is None:
+                print("Sample rate is not 44100")          # separate_dsd.py:313
+                continue
+            pcm = sep.separate(audio)
+            if pending is not None:
+                pending.result()
+            pending = pool.submit(write, path, sr, pcm)
+        if pending is not None:
+            pending.result()
+
+
+if __name__ == "__main__":
+    main()

@@ -405,3 +405,33 @@ def test_long_file_plan_on_one_gpu():
     pieces = [sep.separate(audio[p['a0']:p['a1']])[:, p['s0'] - p['a0']:p['s1'] - p['a0']]
               for p in plan_long_file(audio.size, 2, N, 512, 30, 25)]
     assert np.max(np.abs(np.concatenate(pieces, axis=1) - whole)) < 2e-6
+
+
+def test_batch_driver_matches_single_file_runs(tmp_path):
+    import importlib.util
+    import os
+    import scipy.io.wavfile
+    F = 513
+    params = synth_params("dsd", 30, F, seed=2)
+    model = str(tmp_path / "model.pkl")
+    dcs.save_model(model, params)
+    wavs = []
+    for i in range(3):
+        a = synth_audio(30000 + 5000 * i, seed=20 + i)
+        w = str(tmp_path / ("song%d.wav" % i))
+        scipy.io.wavfile.write(w, 44100, (a * 32767).astype('int16'))
+        wavs.append(w)
+    spec = importlib.util.spec_from_file_location(
+        "separate_batch", os.path.join(os.path.dirname(__file__), "..", "examples", "separate_batch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "out"
+    out.mkdir()
+    mod.main(["-a", "dsd", "-m", model, "-o", str(out)] + wavs)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, 1024, 512, np.hanning)
+    for i, w in enumerate(wavs):
+        sr, audio = dcs.separation.read_wav(w)
+        want = sep.separate(audio)
+        for s, name in enumerate(["vocals", "bass", "drums", "other"]):
+            sr2, data = scipy.io.wavfile.read(str(out / ("song%d" % i) / (name + ".wav")))
+            assert np.array_equal(data, (want[s] * 32767).astype('int16'))
