@@ -105,10 +105,10 @@ __global__ __launch_bounds__(kThreads) void deconv2_kernel(const float* __restri
 // in the order of the reference's sequential cross-fade (owner tile first, then the blends), so
 // the masked tiles never exist in HBM.  !FOLD: a row is one frame of one tile (predict_function2).
 // ------------------------------------------------------------------------------------------------
-template <bool FOLD>
+template <bool FOLD, int NQ>
 __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
     constexpr int NBR = 3;      // dense branches that reach the output (separate_dsd.py:228)
-    constexpr int NQ_MAX = 16;  // CI <= 64
+    constexpr int NQ_MAX = NQ;  // CI / 4, compile time: the K loop unrolls into one block of MFMAs
     constexpr int kABuf = NBR * 16 * (64 + 2);
     __shared__ __attribute__((aligned(16))) float As[2 * kABuf];  // double-buffered A set
     __shared__ int meta_k0[16];
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
     const int fi = lane & 15, kq = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * 16;
     const int col = blockIdx.y * 64 + wave * 16 + fi;
-    const int CI = a.CI, as = a.CI + 2, nq = a.CI >> 2;
+    constexpr int nq = NQ;
+    const int CI = a.CI, as = a.CI + 2;
     const int tc = a.tc, st = a.st, ov = a.ov;
     const int64_t n = a.n;
 
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
     // B fragments: Bw[c][bin], this lane's bin, rows 4q+kq -- constant for the whole workgroup
     float breg[NQ_MAX];
 #pragma unroll
-    for (int q = 0; q < NQ_MAX; ++q) breg[q] = (q < nq) ? a.Bw[(int64_t)(4 * q + kq) * a.ldb + col] : 0.f;
+    for (int q = 0; q < NQ_MAX; ++q) breg[q] = a.Bw[(int64_t)(4 * q + kq) * a.ldb + col];
 
     // mixture value of this lane's 4 (row, bin) cells
     float mixv[4];
@@ -217,13 +218,11 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
         f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < NQ_MAX; ++q) {
-            if (q < nq) {
-                const float b = breg[q];
-                const int off = fi * as + 4 * q + kq;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[off], b, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[16 * as + off], b, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[32 * as + off], b, acc2, 0, 0, 0);
-            }
+            const float b = breg[q];
+            const int off = fi * as + 4 * q + kq;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[off], b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[16 * as + off], b, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[32 * as + off], b, acc2, 0, 0, 0);
         }
 
         // ---- bias + rectify (separate_dsd.py:234), soft mask (:258-271), cross-fade (util.py:321-325)
@@ -301,13 +300,13 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float*
 
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
     if (a.rows <= 0) return DCS_OK;
-    if (a.CI > 64 || (a.CI & 3)) DCS_FAIL(DCS_EUNSUPPORTED, "final: CI %d", a.CI);
+    if (a.CI != 52) DCS_FAIL(DCS_EUNSUPPORTED, "final: built for 50 conv1 filters (CI=52), got CI=%d", a.CI);
     dim3 grid((unsigned)dcs_cdiv(a.rows, 16), (unsigned)(a.ldb / 64));
     DcsTimer tm(ctx, DCS_TAG_FINAL);
     if (fold)
-        hipLaunchKernelGGL(final_kernel<true>, grid, dim3(kThreads), 0, ctx->stream, a);
+        hipLaunchKernelGGL((final_kernel<true, 13>), grid, dim3(kThreads), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(final_kernel<false>, grid, dim3(kThreads), 0, ctx->stream, a);
+        hipLaunchKernelGGL((final_kernel<false, 13>), grid, dim3(kThreads), 0, ctx->stream, a);
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;

@@ -215,21 +215,27 @@ __global__ void stft_forward_wave_kernel(const float* __restrict__ audio, int64_
     }
     float2 v[P];
     const int64_t base = t * (int64_t)hop - M;
+    // 32-bit window-relative bounds instead of two 64-bit compares per sample
+    const int r_lo = base < 0 ? (int)(-base) : 0;
+    const int64_t rem = L - base;
+    const int r_hi = rem < 2 * M ? (rem < 0 ? 0 : (int)rem) : 2 * M;
+    const float* ap = audio + base;
+    const float inv_sqrt_n = 1.f / sqrt_n;
     const float2* w2 = reinterpret_cast<const float2*>(win);
 #pragma unroll
     for (int b = 0; b < NB1; ++b)
 #pragma unroll
         for (int tt = 0; tt < R1; ++tt) {
             const int i = lane + 64 * b + tt * stride1;
-            const int64_t p = base + 2 * i;
+            const int r = 2 * i;
             const float2 w = (dbg & 8) ? mk2(0.5f, 0.25f) : w2[i];
             float x0 = 0.f, x1 = 0.f;
             if (dbg & 2) {
                 x0 = (float)i * w.x;
                 x1 = (float)(i + 1) * w.y;
             } else {
-                if (p >= 0 && p < L) x0 = audio[p] * w.x;
-                if (p + 1 >= 0 && p + 1 < L) x1 = audio[p + 1] * w.y;
+                if (r >= r_lo && r < r_hi) x0 = ap[r] * w.x;
+                if (r + 1 >= r_lo && r + 1 < r_hi) x1 = ap[r + 1] * w.y;
             }
             v[b * R1 + tt] = mk2(x0, x1);
         }
@@ -247,9 +253,12 @@ __global__ void stft_forward_wave_kernel(const float* __restrict__ audio, int64_
         const float xi = ei + (w.x * oi + w.y * orr);
         const float ax = sqrtf(xr * xr + xi * xi);
         if ((dbg & 1) && !(ax == 12345.678f)) continue;  // keeps the arithmetic, drops the stores
-        mrow[k] = ax / sqrt_n;
+        mrow[k] = ax * inv_sqrt_n;
         if (prow) prow[k] = atan2f(xi, xr);
-        if (urow) urow[k] = (ax > 0.f) ? mk2(xr / ax, xi / ax) : mk2(1.f, 0.f);
+        if (urow) {
+            const float ra = 1.f / ax;  // one division for both components
+            urow[k] = (ax > 0.f) ? mk2(xr * ra, xi * ra) : mk2(1.f, 0.f);
+        }
     }
     for (int k = M + 1 + lane; k < ld; k += 64) {
         mrow[k] = 0.f;
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
     if (n_hi > T - 1) n_hi = T - 1;
     const int64_t n_lo = (p0 < N) ? 0 : (p0 - N) / hop + 1;
     const float inv_m = 1.f / (float)M;
+    const float amp = sqrt_n / pre_div;  // (mag / scale_factor) * sqrt(N) with one multiply per bin
     const float* msrc = mag + (int64_t)s * src_stride;
     __syncthreads();
 
@@ -303,8 +313,8 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
                     const int km = M - k;                         // 1..M
                     float2 xk, xm;
                     {
-                        const float a = (mrow[k] / pre_div) * sqrt_n;
-                        const float b2 = (mrow[km] / pre_div) * sqrt_n;
+                        const float a = mrow[k] * amp;
+                        const float b2 = mrow[km] * amp;
                         if (UNIT) {
                             const float2 uk = unit[n * ld + k], um = unit[n * ld + km];
                             xk = mk2(a * uk.x, a * uk.y);
