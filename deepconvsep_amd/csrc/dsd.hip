@@ -7,6 +7,8 @@
 #include "dcs_internal.h"
 #include "dsd.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -280,6 +282,193 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Many-rows variant of final_kernel: one INDEPENDENT wave per 16 rows x (16*CBW) bins, no workgroup
+// barrier.  (PMC on the cooperative kernel: 4 waves meeting every 39 MFMAs leave the matrix pipe idle
+// ~55 % of the time.)  Each A fragment read from the wave-private LDS tile feeds CBW MFMAs; with CBW = 2
+// the 65 (F=1025) / 33 (F=513) column blocks split into 33 / 17 groups with one block of padding.
+// A wave's LDS operations are performed in program order, so staging the next covering tile's rows after
+// the current MFMAs needs no fence.  Blocks are renumbered so that the column groups of one row group run
+// on the same XCD (block b runs on XCD b % 8) and share its L2 for the G rows.
+// ------------------------------------------------------------------------------------------------
+template <bool FOLD, int CBW>
+__global__ __launch_bounds__(64, 2) void final_wave_kernel(const DsdFinalArgs a, int n_colg) {
+    constexpr int NBR = 3, NQ = 13, AS = 54, SLOTS = NBR * 16 * NQ, PER = (SLOTS + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float As[NBR * 16 * AS];
+    __shared__ int meta_k0[16];
+    __shared__ int meta_j0[16];
+    const int lane = threadIdx.x;
+    const int fi = lane & 15, kq = lane >> 4;
+    // XCD-aware renumbering (bijective for any grid size)
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int64_t row0 = (int64_t)(swz / n_colg) * 16;
+    const int col0 = (int)(swz % n_colg) * (16 * CBW);
+    const int CI = a.CI;
+    const int tc = a.tc, st = a.st, ov = a.ov;
+    const int64_t n = a.n;
+
+    if (lane < 16) {
+        const int64_t r = row0 + lane;
+        int k0 = 0, j0 = -1;
+        if (r < a.rows) {
+            if (FOLD) {
+                int64_t kk = (r < ov) ? 0 : (r - ov) / st;
+                if (kk > n - 1) kk = n - 1;
+                const int64_t jj = r - kk * st;
+                if (jj < tc) {
+                    k0 = (int)kk;
+                    j0 = (int)jj;
+                }
+            } else {
+                k0 = (int)(r / tc);
+                j0 = (int)(r - (int64_t)k0 * tc);
+            }
+        }
+        meta_k0[lane] = k0;
+        meta_j0[lane] = j0;
+    }
+
+    float breg[CBW][NQ];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) breg[cb][q] = a.Bw[(int64_t)(4 * q + kq) * a.ldb + col0 + cb * 16 + fi];
+    float mixv[CBW][4];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t r = row0 + kq * 4 + e;
+            const int col = col0 + cb * 16 + fi;
+            mixv[cb][e] = (r < a.rows && col < a.F) ? a.mix_scale * a.mix[r * a.mix_ld + col] : 0.f;
+        }
+    const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
+    const float eps_r = 5e-19f;
+    float res[CBW][4][4];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[cb][c][e] = 0.f;
+
+    // staging plan (see final_kernel): slot -> (branch s, row i, float4 c4).  Kept compact (32-bit offsets
+    // relative to the first row's tile, packed row state) so that two waves fit on a SIMD.
+    const int m_delta = (NBR * tc - st) * CI;
+    const int kbase = meta_k0[0];
+    const float* gbase = a.G + (int64_t)kbase * NBR * tc * CI;
+    int dst[PER], off[PER], kj[PER];  // kj = (k0 - kbase) << 8 | (j0 + 1); 0 = row not covered
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = lane + u * 64;
+        const int s = idx / (16 * NQ);
+        const int rem = idx - s * 16 * NQ;
+        const int i = rem / NQ, c4 = rem - i * NQ;
+        const bool in = idx < SLOTS && meta_j0[i] >= 0;
+        const int dk = in ? meta_k0[i] - kbase : 0;
+        const int j0 = in ? meta_j0[i] : -1;
+        kj[u] = in ? ((dk << 8) | (j0 + 1)) : 0;
+        dst[u] = (idx < SLOTS) ? (s * 16 + i) * AS + c4 * 4 : -1;
+        off[u] = ((dk * NBR + s) * tc + (j0 < 0 ? 0 : j0)) * CI + c4 * 4;
+    }
+    f32x4 pre[PER];
+#define DCS_LOAD_A(m_)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                           \
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                    \
+        const int j0p = kj[u] & 255;                                                            \
+        if (j0p > 0 && j0p - 1 - (m_) * st >= 0 && (int64_t)kbase + (kj[u] >> 8) + (m_) < n)    \
+            v = *reinterpret_cast<const f32x4*>(gbase + off[u] + (m_) * m_delta);               \
+        pre[u] = v;                                                                             \
+    }
+#define DCS_STORE_A()                                                                           \
+    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                           \
+        if (dst[u] >= 0) {                                                                      \
+            float* d = As + dst[u];                                                             \
+            *reinterpret_cast<float2*>(d) = make_float2(pre[u][0], pre[u][1]);                  \
+            *reinterpret_cast<float2*>(d + 2) = make_float2(pre[u][2], pre[u][3]);              \
+        }                                                                                       \
+    }
+    DCS_LOAD_A(0)
+    for (int m = 0; m < a.mmax; ++m) {
+        DCS_STORE_A()  // after the previous iteration's fragment reads (program order within the wave)
+        if (m + 1 < a.mmax) DCS_LOAD_A(m + 1)
+        f32x4 acc[NBR][CBW];
+#pragma unroll
+        for (int s = 0; s < NBR; ++s)
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int off = fi * AS + 4 * q + kq;
+            const float a0 = As[off], a1 = As[16 * AS + off], a2 = As[32 * AS + off];
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, breg[cb][q], acc[0][cb], 0, 0, 0);
+                acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, breg[cb][q], acc[1][cb], 0, 0, 0);
+                acc[2][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, breg[cb][q], acc[2][cb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = kq * 4 + e;
+            const int j0 = meta_j0[i];
+            const int j = j0 - m * st;
+            const bool valid = (j0 >= 0) && (j >= 0) && ((int64_t)meta_k0[i] + m < n);
+            float up = 0.f, down = 0.f;
+            if (m > 0 && valid) {
+                up = a.rise[j];
+                down = a.rise[ov - 1 - j];
+            }
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                const float p0 = fmaxf(acc[0][cb][e] + bias0, 0.f);
+                const float p1 = fmaxf(acc[1][cb][e] + bias1, 0.f);
+                const float p2 = fmaxf(acc[2][cb][e] + bias2, 0.f);
+                const float p3 = fmaxf(acc[1][cb][e] + bias3, 0.f);
+                float v0, v1, v2, v3;
+                if (a.mask_mode == 0) {
+                    const float s0 = p0 + eps_r, s1 = p1 + eps_r, s2 = p2 + eps_r, s3 = p3 + eps_r;
+                    const float den = ((s0 + s1) + s2) + s3;
+                    const float w = __builtin_amdgcn_rcpf(den) * mixv[cb][e];
+                    v0 = s0 * w; v1 = s1 * w; v2 = s2 * w; v3 = s3 * w;
+                } else if (a.mask_mode == 1) {
+                    const float den = (((p0 + p1) + p2) + p3) + eps_r;
+                    const float w = __builtin_amdgcn_rcpf(den) * mixv[cb][e];
+                    v0 = p0 * w; v1 = p1 * w; v2 = p2 * w; v3 = p3 * w;
+                } else {
+                    v0 = p0; v1 = p1; v2 = p2; v3 = p3;
+                }
+                if (m == 0) {
+                    if (valid) { res[cb][0][e] = v0; res[cb][1][e] = v1; res[cb][2][e] = v2; res[cb][3][e] = v3; }
+                } else if (valid) {
+                    res[cb][0][e] = down * res[cb][0][e] + up * v0;
+                    res[cb][1][e] = down * res[cb][1][e] + up * v1;
+                    res[cb][2][e] = down * res[cb][2][e] + up * v2;
+                    res[cb][3][e] = down * res[cb][3][e] + up * v3;
+                }
+            }
+        }
+    }
+#undef DCS_LOAD_A
+#undef DCS_STORE_A
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) {
+        const int col = col0 + cb * 16 + fi;
+        if (col < a.F) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t r = row0 + kq * 4 + e;
+                if (r < a.rows) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a.out[c * a.out_src_stride + r * a.out_ld + col] = res[cb][c][e];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float* G, int64_t n_ks, int H2, int CP,
@@ -303,7 +492,19 @@ int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
     if (a.CI != 52) DCS_FAIL(DCS_EUNSUPPORTED, "final: built for 50 conv1 filters (CI=52), got CI=%d", a.CI);
     dim3 grid((unsigned)dcs_cdiv(a.rows, 16), (unsigned)(a.ldb / 64));
     DcsTimer tm(ctx, DCS_TAG_FINAL);
-    if (fold)
+    // many rows: independent waves (16 rows x 48 bins each); few rows: the cooperative 4-wave kernel,
+    // which exposes 4x more parallelism per row group
+    static const int force = getenv("DCS_FINAL_KERNEL") ? atoi(getenv("DCS_FINAL_KERNEL")) : 0;  // 1 coop, 2 wave
+    constexpr int kCBW = 2;  // column blocks per wave: 3 needs > 256 registers with the prefetch set
+    const int n_colg = (a.F + 16 * kCBW - 1) / (16 * kCBW);
+    const int64_t n_waves = (int64_t)dcs_cdiv(a.rows, 16) * n_colg;
+    const bool wave_variant = force ? force == 2 : (n_waves >= 12 * (int64_t)ctx->n_cu && n_colg * 16 * kCBW <= a.ldb);
+    if (wave_variant) {
+        if (fold)
+            hipLaunchKernelGGL((final_wave_kernel<true, kCBW>), dim3((unsigned)n_waves), dim3(64), 0, ctx->stream, a, n_colg);
+        else
+            hipLaunchKernelGGL((final_wave_kernel<false, kCBW>), dim3((unsigned)n_waves), dim3(64), 0, ctx->stream, a, n_colg);
+    } else if (fold)
         hipLaunchKernelGGL((final_kernel<true, 13>), grid, dim3(kThreads), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL((final_kernel<false, 13>), grid, dim3(kThreads), 0, ctx->stream, a);
