@@ -492,13 +492,13 @@ int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
     if (a.CI != 52) DCS_FAIL(DCS_EUNSUPPORTED, "final: built for 50 conv1 filters (CI=52), got CI=%d", a.CI);
     dim3 grid((unsigned)dcs_cdiv(a.rows, 16), (unsigned)(a.ldb / 64));
     DcsTimer tm(ctx, DCS_TAG_FINAL);
-    // many rows: independent waves (16 rows x 48 bins each); few rows: the cooperative 4-wave kernel,
-    // which exposes 4x more parallelism per row group
+    // DCS_FINAL_KERNEL=2 selects the barrier-free wave-tile variant (A/B experiments)
     static const int force = getenv("DCS_FINAL_KERNEL") ? atoi(getenv("DCS_FINAL_KERNEL")) : 0;  // 1 coop, 2 wave
     constexpr int kCBW = 2;  // column blocks per wave: 3 needs > 256 registers with the prefetch set
     const int n_colg = (a.F + 16 * kCBW - 1) / (16 * kCBW);
     const int64_t n_waves = (int64_t)dcs_cdiv(a.rows, 16) * n_colg;
-    const bool wave_variant = force ? force == 2 : (n_waves >= 12 * (int64_t)ctx->n_cu && n_colg * 16 * kCBW <= a.ldb);
+    // measured at 4096 tiles (MI355X): cooperative 0.609 ms, wave-tile 0.649 ms -> cooperative is the default
+    const bool wave_variant = force == 2 && n_colg * 16 * kCBW <= a.ldb;
     if (wave_variant) {
         if (fold)
             hipLaunchKernelGGL((final_wave_kernel<true, kCBW>), dim3((unsigned)n_waves), dim3(64), 0, ctx->stream, a, n_colg);

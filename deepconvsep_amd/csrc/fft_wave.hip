@@ -272,7 +272,7 @@ __global__ void stft_forward_wave_kernel(const float* __restrict__ audio, int64_
 // frames at a time, then all threads add the 4 windowed frames into the chunk in frame order.
 // ------------------------------------------------------------------------------------------------
 template <int LOG2M, bool UNIT>
-__global__ __launch_bounds__(256, 2) void istft_wave_kernel(const float* __restrict__ mag, int64_t src_stride,
+__global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict__ mag, int64_t src_stride,
                                                          const float* __restrict__ phase,
                                                          const float2* __restrict__ unit, int64_t ld,
                                                          const float* __restrict__ win, const float* __restrict__ wsq,
@@ -286,27 +286,18 @@ __global__ __launch_bounds__(256, 2) void istft_wave_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2* fbuf = twl + (M + 1);
     float2* buf = fbuf + wave * MP;
-    float2* winl = fbuf + 4 * MP;  // window as M (even, odd) pairs
+    float* acc = reinterpret_cast<float*>(fbuf + 4 * MP);
     const int s = blockIdx.y;
-    const int span = C * hop;      // even: the host only takes this path for even hop
+    const int span = C * hop;
     const int64_t p0 = (int64_t)blockIdx.x * span;
-    const float2* w2g = reinterpret_cast<const float2*>(win);
     for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
-    for (int k = tid; k < M; k += 256) winl[k] = w2g[k];
+    for (int q = tid; q < span; q += 256) acc[q] = 0.f;
     int64_t n_hi = (p0 + span - 1) / hop;
     if (n_hi > T - 1) n_hi = T - 1;
     const int64_t n_lo = (p0 < N) ? 0 : (p0 - N) / hop + 1;
     const float inv_m = 1.f / (float)M;
     const float amp = sqrt_n / pre_div;  // (mag / scale_factor) * sqrt(N) with one multiply per bin
     const float* msrc = mag + (int64_t)s * src_stride;
-    // Each thread owns the output sample pairs (2 pi, 2 pi + 1), pi = tid + 256 i, of the chunk and keeps
-    // their running sums in registers: frame n contributes z[pi - (n*hop - p0)/2] to pair pi, so the
-    // overlap-add is one LDS read and two FMAs per frame and pair, in increasing n like the reference.
-    constexpr int MAXP = 12;
-    const int npairs = span >> 1;
-    float2 acc[MAXP];
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) acc[i] = mk2(0.f, 0.f);
     __syncthreads();
 
     for (int64_t nb = n_lo; nb <= n_hi; nb += 4) {
@@ -345,50 +336,38 @@ __global__ __launch_bounds__(256, 2) void istft_wave_kernel(const float* __restr
                     const float orr = dr * w.x + di * w.y;
                     const float oi = di * w.x - dr * w.y;
                     v[b * R1 + tt] = mk2(er - oi, ei + orr);
-                    if ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight (registers)
                 }
             fft_wave<LOG2M, +1>(v, lane, twl, buf);
         }
         __syncthreads();
+        for (int q = tid; q < span; q += 256) {
+            const int64_t p = p0 + q;
+            float a = acc[q];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int64_t n2 = nb + w;
-            if (n2 <= n_hi) {
-                const int shift = (int)((n2 * hop - p0) >> 1);  // pair index of the frame's first sample
-                const float2* fz = fbuf + w * MP;
-#pragma unroll
-                for (int i = 0; i < MAXP; ++i) {
-                    const int pi = tid + 256 * i;
-                    const int m = pi - shift;
-                    if (pi < npairs && m >= 0 && m < M) {
-                        const float2 z = fz[pad(m)];
-                        const float2 ww = winl[m];
-                        acc[i].x += (z.x * inv_m) * ww.x;
-                        acc[i].y += (z.y * inv_m) * ww.y;
-                    }
+            for (int w = 0; w < 4; ++w) {
+                const int64_t n2 = nb + w;
+                const int64_t off = p - n2 * hop;
+                if (n2 <= n_hi && off >= 0 && off < N) {
+                    const float2 z = fbuf[w * MP + pad((int)(off >> 1))];
+                    a += (((off & 1) ? z.y : z.x) * inv_m) * win[off];
                 }
             }
+            acc[q] = a;
         }
         __syncthreads();
     }
     const int half = N >> 1;
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int pi = tid + 256 * i;
-        if (pi >= npairs) continue;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t p = p0 + 2 * pi + h;
-            const int64_t m = p - half;
-            if (m < 0 || m >= n_out) continue;
-            int64_t f_hi = p / hop;
-            if (f_hi > T - 1) f_hi = T - 1;
-            const int64_t f_lo = (p < N) ? 0 : (p - N) / hop + 1;
-            float norm = 0.f;
-            for (int64_t n = f_lo; n <= f_hi; ++n) norm += wsq[p - n * hop];
-            if (norm == 0.f) norm = 1.f;
-            audio[(int64_t)s * n_out + m] = (h ? acc[i].y : acc[i].x) / norm;
-        }
+    for (int q = tid; q < span; q += 256) {
+        const int64_t p = p0 + q;
+        const int64_t m = p - half;
+        if (m < 0 || m >= n_out) continue;
+        int64_t f_hi = p / hop;
+        if (f_hi > T - 1) f_hi = T - 1;
+        const int64_t f_lo = (p < N) ? 0 : (p - N) / hop + 1;
+        float norm = 0.f;
+        for (int64_t n = f_lo; n <= f_hi; ++n) norm += wsq[p - n * hop];
+        if (norm == 0.f) norm = 1.f;
+        audio[(int64_t)s * n_out + m] = acc[q] / norm;
     }
 }
 
@@ -424,8 +403,12 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     if (C > 16 - (R_ - 1)) C = 16 - (R_ - 1);
     if (c_env > 0) C = c_env;
     if (C < 1) C = 1;
-    while (C > 1 && C * (int64_t)hop > 6144) --C;  // 12 sample pairs per thread in registers
-    const size_t lds = ((size_t)(M + 1) + 4 * (size_t)MP + (size_t)M) * sizeof(float2);
+    const size_t fixed = ((size_t)(M + 1) + 4 * (size_t)MP) * sizeof(float2);
+    size_t lds = fixed + (size_t)C * hop * sizeof(float);
+    while (lds > 96 * 1024 && C > 1) {
+        --C;
+        lds = fixed + (size_t)C * hop * sizeof(float);
+    }
     const dim3 grid((unsigned)((hops + C - 1) / C), (unsigned)n_src);
 #define DCS_GO(UNIT_)                                                                                             \
     {                                                                                                             \
@@ -445,7 +428,7 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
 
 bool dcs_fft_wave_supported(const dcs_stft* p) {
     static const bool off = getenv("DCS_FFT_BLOCK") != nullptr;  // debugging aid: force the block-level kernels
-    return !off && p->log2m >= 9 && p->log2m <= 11 && (p->hop & 1) == 0 && p->hop <= 6144;
+    return !off && p->log2m >= 9 && p->log2m <= 11;
 }
 
 int dcs_fft_wave_forward(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
