@@ -119,8 +119,15 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * 16;
-    const int col = blockIdx.y * 64 + wave * 16 + fi;
+    // XCD-aware renumbering (block b runs on XCD b % 8; bijective for any grid size): the column groups of
+    // one row group become consecutive on ONE XCD, so its L2 serves the G rows they all read.  PMC before:
+    // FETCH_SIZE 746 MB per launch at 4096 tiles against ~160 MB of distinct input.
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int n_colg = a.ldb / 64;
+    const int64_t row0 = (int64_t)(swz / n_colg) * 16;
+    const int col = (int)(swz % n_colg) * 64 + wave * 16 + fi;
     constexpr int nq = NQ;
     const int CI = a.CI, as = a.CI + 2;
     const int tc = a.tc, st = a.st, ov = a.ov;
@@ -490,7 +497,7 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float*
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
     if (a.rows <= 0) return DCS_OK;
     if (a.CI != 52) DCS_FAIL(DCS_EUNSUPPORTED, "final: built for 50 conv1 filters (CI=52), got CI=%d", a.CI);
-    dim3 grid((unsigned)dcs_cdiv(a.rows, 16), (unsigned)(a.ldb / 64));
+    dim3 grid((unsigned)(dcs_cdiv(a.rows, 16) * (a.ldb / 64)));
     DcsTimer tm(ctx, DCS_TAG_FINAL);
     // DCS_FINAL_KERNEL=2 selects the barrier-free wave-tile variant (A/B experiments)
     static const int force = getenv("DCS_FINAL_KERNEL") ? atoi(getenv("DCS_FINAL_KERNEL")) : 0;  // 1 coop, 2 wave
