@@ -138,11 +138,28 @@ def main():
     # algorithmic FLOPs of the dominant kernel: transposed conv1 of the 3 live branches
     # (separate_dsd.py:212,218,224): per tile 3 * 2 * tc * 50 * F  (DESIGN.md "roofline")
     final_flops_tile = 3 * 2 * TC * 50 * F
+    # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
+    # WRITE_SIZE need their own rocprofv3 runs, scripts/gpu_traffic.sh); 2*FETCH + WRITE per the gfx950
+    # correction of MI355X_MICROARCH.md.  None when the workload has no matching record.
+    traffic_rec = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            traffic_rec = json.load(fh)
+    except Exception:
+        pass
+
+    def traffic_bytes(n):
+        rec = traffic_rec.get("final_kernel_%d_tiles" % n) if N == 2048 else None
+        if not rec:
+            return None
+        return int((2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024)
+
     def roof(n, ms):
         ach = n * final_flops_tile / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         return {"bound": "mfma", "kernel": "final_kernel<fold> (deconv1+bias+relu+mask+crossfade)",
                 "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic_bytes(n),
+                "algorithmic_bytes": int(n * (3 * TC * 52 * 4) + ((n - 1) * (TC - OV) + TC) * F * 4 * 5),
                 "avg_kernel_ms": round(ms, 5), "launches": int(final_launches)}
     roofline = roof(n_tiles, final_ms)
 
