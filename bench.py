@@ -10,14 +10,20 @@ One *step* = one pass of the whole hot path (STFT -> x0.3 -> tiles -> conv encod
 soft mask -> cross-fade overlap-add -> /0.3 -> iSTFT -> truncate) over one batch of 32 tiles
 (BASELINE.json configs[1]: "DSD100 4-source separate_dsd.py, batch=32 tiles, fp32, 1xMI355X"),
 i.e. 2.14 s of synthetic 44.1 kHz audio already resident in HBM, producing 4 PCM signals in
-HBM.  With N GPUs every rank separates its own 32-tile batch (weak scaling, configs[2]) and
+HBM.  With N GPUs every rank separates its own 32-tile batches (weak scaling, configs[2]) and
 the PCM of all ranks is all-gathered over RCCL inside the timed region.
 
+A 32-tile batch holds 0.57 GFLOP -- 3.6 us of the chip's f32 peak -- spread over 8 dependent
+kernels, so one batch at a time leaves the GPU mostly idle.  Steps are independent, therefore
+`--streams S` (default 4) keeps S batches in flight on S HIP streams (each with its own libdcs
+context, plan, model handle and buffers), the way a server would overlap requests.  `value` is
+the resulting throughput; `single_stream` reports the same K steps issued on one stream.
+
 Rank 0 prints ONE JSON line.  `roofline` refers to the dominant kernel (transposed conv1 +
-bias + rectify + soft mask + cross-fade), timed with HIP events inside the timed region;
-`cpu_baseline` is the CPU oracle (reference-equivalent NumPy + torch-CPU float64 path) timed
-on this host; `saturating` repeats the measurement on a long clip (4096 tiles, 3 min 58 s) where
-the chip is full -- the 32-tile step is launch/latency-bound (DESIGN.md "measurement").
+bias + rectify + soft mask + cross-fade), timed with HIP events inside the timed region on the
+stream it is launched on; `cpu_baseline` is the CPU oracle (reference-equivalent NumPy +
+torch-CPU float64 path) timed on this host; `saturating` repeats the measurement on a long clip
+(4096 tiles, 3 min 58 s) where one launch fills the chip (DESIGN.md "measurement").
 """
 import argparse
 import json
@@ -44,10 +50,11 @@ def samples_for_tiles(n_tiles):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--tiles", type=int, default=32, help="tiles per GPU per step (BASELINE configs[1]: 32)")
     ap.add_argument("--frame-size", type=int, default=2048)
+    ap.add_argument("--streams", type=int, default=4, help="independent batches in flight per GPU")
     ap.add_argument("--sat-tiles", type=int, default=4096, help="tiles of the saturating extra run (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -70,73 +77,96 @@ def main():
     import deepconvsep_amd as dcs
     from deepconvsep_amd import _lib
     from deepconvsep_amd.arch import ARCHS, TILER_SCRIPT
+    from deepconvsep_amd.runtime import Context
     from deepconvsep_amd.synth import synth_audio, synth_params
 
     N = args.frame_size
     F = N // 2 + 1
     params = synth_params("dsd", TC, F, seed=2)
-    sep = dcs.Separator("dsd", params, SCALE, TC, OV, 32, F, N, HOP, np.hanning)
-    ctx, net, plan = sep.ctx, sep.net, sep.plan
-
     L = samples_for_tiles(args.tiles)
-    audio_h = synth_audio(L, seed=100 + rank)
-    audio = ctx.to_device(audio_h, np.float32)
     T = _lib.frame_count(L, HOP)
     n_tiles = _lib.tile_count(T, TC, OV, TILER_SCRIPT)
     assert n_tiles == args.tiles, (n_tiles, args.tiles)
     frames_per_step = (n_tiles - 1) * (TC - OV) + TC        # unique frames fully separated
-    pcm = torch.empty((4, L), dtype=torch.float32, device=audio.device)
-    gathered = torch.empty((world * 4, L), dtype=torch.float32, device=audio.device) if world > 1 else None
+    NS = max(1, args.streams)
 
-    def step():
-        net.separate(plan, audio, OV, TILER_SCRIPT, SCALE, out=pcm)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, pcm)      # RCCL over xGMI: the final gather
+    class Lane(object):                                      # one HIP stream with everything it needs
+        def __init__(self, idx):
+            self.stream = torch.cuda.Stream()
+            with torch.cuda.stream(self.stream):
+                self.ctx = Context()                         # binds libdcs to this stream
+                self.sep = dcs.Separator("dsd", params, SCALE, TC, OV, 32, F, N, HOP, np.hanning, ctx=self.ctx)
+                self.audio_h = synth_audio(L, seed=100 + rank * 16 + idx)
+                self.audio = self.ctx.to_device(self.audio_h, np.float32)
+                self.pcm = torch.empty((4, L), dtype=torch.float32, device=self.audio.device)
+                self.gathered = (torch.empty((world * 4, L), dtype=torch.float32, device=self.audio.device)
+                                 if world > 1 else None)
+            self.stream.synchronize()
+
+        def step(self):
+            with torch.cuda.stream(self.stream):
+                self.sep.net.separate(self.sep.plan, self.audio, OV, TILER_SCRIPT, SCALE, out=self.pcm)
+                if world > 1:
+                    dist.all_gather_into_tensor(self.gathered, self.pcm)   # RCCL over xGMI: the final gather
+
+    lanes = [Lane(i) for i in range(NS)]
+    ctx0 = lanes[0].ctx
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    # HIP event pairs around the dominant kernel, on the stream it is launched on, inside the timed
-    # region -- but only around every 8th launch: an event record costs ~6 us of stream time on each
-    # side of a ~20 us kernel, and bracketing every launch would slow the measured steps by ~10 %.
-    ctx.timing(["final"])
-    ctx.timing_stride(8)
-    ctx.timing_reset()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    final_ms, final_launches = ctx.timing_query("final")
-    ctx.timing(None)
-    ctx.timing_stride(1)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=audio.device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(k, use):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            use[i % len(use)].step()
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=lanes[0].audio.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
 
+    for i in range(args.warmup):
+        lanes[i % NS].step()
+    # HIP event pairs around the dominant kernel on stream 0, inside the timed region, around every 4th
+    # of its launches there (an event record costs ~6 us of stream time on each side of the kernel).
+    ctx0.timing(["final"])
+    ctx0.timing_stride(4)
+    ctx0.timing_reset()
+    elapsed = timed(args.steps, lanes)
+    final_ms, final_launches = ctx0.timing_query("final")
+    ctx0.timing(None)
+    ctx0.timing_stride(1)
     value = world * frames_per_step * args.steps / elapsed
 
-    # ---- per-kernel breakdown (separate instrumented pass, not part of `value`)
+    # ---- the same K steps on ONE stream (no overlap between batches)
+    ctx0.timing(["final"])
+    ctx0.timing_stride(8)
+    ctx0.timing_reset()
+    el1 = timed(args.steps, lanes[:1])
+    final_ms1, final_launches1 = ctx0.timing_query("final")
+    ctx0.timing(None)
+    ctx0.timing_stride(1)
+
+    # ---- per-kernel breakdown (separate instrumented pass on one stream)
     kernels_ms = {}
-    ctx.timing("all")
-    ctx.timing_reset()
-    for _ in range(min(args.steps, 20)):
-        net.separate(plan, audio, OV, TILER_SCRIPT, SCALE, out=pcm)
+    ctx0.timing("all")
+    ctx0.timing_reset()
+    for _ in range(20):
+        lanes[0].step()
     for tag in _lib.TAGS:
-        ms, cnt = ctx.timing_query(tag)
+        ms, cnt = ctx0.timing_query(tag)
         if cnt:
             kernels_ms[tag] = round(ms, 5)
-    ctx.timing(None)
+    ctx0.timing(None)
 
     # algorithmic FLOPs of the dominant kernel: transposed conv1 of the 3 live branches
-    # (separate_dsd.py:212,218,224): per tile 3 * 2 * tc * 50 * F  (DESIGN.md "roofline")
+    # (separate_dsd.py:212,218,224): per tile 3 * 2 * tc * 50 * F  (DESIGN.md "kernels")
     final_flops_tile = 3 * 2 * TC * 50 * F
     # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
     # WRITE_SIZE need their own rocprofv3 runs, scripts/gpu_traffic.sh); 2*FETCH + WRITE per the gfx950
@@ -148,52 +178,52 @@ def main():
     except Exception:
         pass
 
-    def traffic_bytes(n):
-        rec = traffic_rec.get("final_kernel_%d_tiles" % n) if N == 2048 else None
-        if not rec:
-            return None
-        return int((2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024)
-
-    def roof(n, ms):
+    def roof(n, ms, launches):
         ach = n * final_flops_tile / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        rec = traffic_rec.get("final_kernel_%d_tiles" % n) if N == 2048 else None
+        traffic = int((2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024) if rec else None
         return {"bound": "mfma", "kernel": "final_kernel<fold> (deconv1+bias+relu+mask+crossfade)",
                 "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic_bytes(n),
+                "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
                 "algorithmic_bytes": int(n * (3 * TC * 52 * 4) + ((n - 1) * (TC - OV) + TC) * F * 4 * 5),
-                "avg_kernel_ms": round(ms, 5), "launches": int(final_launches)}
-    roofline = roof(n_tiles, final_ms)
+                "avg_kernel_ms": round(ms, 5), "launches": int(launches)}
 
-    # ---- saturating regime (extra): same path, long clip
+    roofline = roof(n_tiles, final_ms, final_launches)
+    single = {"ms_per_step": round(el1 / args.steps * 1e3, 5),
+              "value": round(world * frames_per_step * args.steps / el1, 1),
+              "roofline": roof(n_tiles, final_ms1, final_launches1), "kernels_ms": kernels_ms}
+
+    # ---- saturating regime (extra): same path, one long clip per launch, one stream
     saturating = None
     if args.sat_tiles and rank == 0:
-        Ls = samples_for_tiles(args.sat_tiles)
-        a2 = ctx.to_device(synth_audio(Ls, seed=7), np.float32)
-        out2 = torch.empty((4, Ls), dtype=torch.float32, device=a2.device)
-        for _ in range(2):
-            net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
-        ctx.timing("all")
-        ctx.timing_reset()
-        torch.cuda.synchronize()
-        k2 = 10
-        t0 = time.perf_counter()
-        for _ in range(k2):
-            net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
-        torch.cuda.synchronize()
-        e2 = time.perf_counter() - t0
+        net, plan = lanes[0].sep.net, lanes[0].sep.plan
+        with torch.cuda.stream(lanes[0].stream):
+            Ls = samples_for_tiles(args.sat_tiles)
+            a2 = ctx0.to_device(synth_audio(Ls, seed=7), np.float32)
+            out2 = torch.empty((4, Ls), dtype=torch.float32, device=a2.device)
+            for _ in range(2):
+                net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
+            ctx0.timing("all")
+            ctx0.timing_reset()
+            torch.cuda.synchronize()
+            k2 = 10
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t0
         fr2 = (args.sat_tiles - 1) * (TC - OV) + TC
         sat_k = {}
         for tag in _lib.TAGS:
-            ms, cnt = ctx.timing_query(tag)
+            ms, cnt = ctx0.timing_query(tag)
             if cnt:
                 sat_k[tag] = round(ms, 5)
-        ctx.timing(None)
-        r2 = roof(args.sat_tiles, sat_k.get("final", 0.0))
-        r2["launches"] = k2
+        ctx0.timing(None)
         total_flops = args.sat_tiles * ARCHS["dsd"].flops_per_tile(TC, F)
         saturating = {"tiles": args.sat_tiles, "audio_seconds": round(Ls / SR, 2), "value": round(fr2 * k2 / e2, 1),
                       "unit": "frames/s", "x_realtime": round(fr2 * k2 / e2 * HOP / SR, 1),
-                      "ms_per_step": round(e2 / k2 * 1e3, 4), "roofline": r2, "kernels_ms": sat_k,
-                      "whole_path_algorithmic_tflops": round(total_flops * k2 / e2 / 1e12, 2)}
+                      "ms_per_step": round(e2 / k2 * 1e3, 4), "roofline": roof(args.sat_tiles, sat_k.get("final", 0.0), k2),
+                      "kernels_ms": sat_k, "whole_path_algorithmic_tflops": round(total_flops * k2 / e2 / 1e12, 2)}
         del a2, out2
     if world > 1:
         dist.barrier()
@@ -202,6 +232,7 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pipeline
+        audio_h = lanes[0].audio_h
         # pick the torch thread count that serves this small batch best (all 256 host threads on the
         # 50-channel float64 convolutions is far slower than a handful); the NumPy loops are serial
         best = None
@@ -236,12 +267,14 @@ def main():
             "config": {"workload": "DSD100 4-source separate_dsd path (BASELINE configs[1]): frameSize=%d hop=512 "
                                    "hann, time_context=30 overlap=25 scale=0.3, one batch of %d tiles = %.2f s of "
                                    "44.1 kHz audio per GPU per step, STFT->net->mask->overlap-add->iSTFT, "
-                                   "input and output resident in HBM%s"
-                                   % (N, n_tiles, L / SR, ", PCM all-gathered over RCCL" if world > 1 else ""),
+                                   "input and output resident in HBM, %d independent batches in flight per GPU "
+                                   "(HIP streams)%s"
+                                   % (N, n_tiles, L / SR, NS, ", PCM all-gathered over RCCL" if world > 1 else ""),
                        "tiles_per_gpu_per_step": n_tiles, "frames_per_gpu_per_step": frames_per_step,
-                       "frame_size": N, "bins": F, "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",
+                       "frame_size": N, "bins": F, "streams_per_gpu": NS,
+                       "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",
                        "parallelism": "tiles sharded by rank (dp%d)" % world},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_ms": kernels_ms, "saturating": saturating,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "single_stream": single, "saturating": saturating,
         }
         print(json.dumps(line))
     if world > 1:

@@ -400,8 +400,9 @@ int launch_inverse(dcs_stft* p, const R* win, const R2* tw, const R* wsq, const 
 
 int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit,
                                 int64_t ld, int64_t rows_out, int64_t T) {
-    if (dcs_fft_wave_supported(p)) {
-        if (rows_out <= 0) return DCS_OK;
+    // few frames: the block-level kernel (4 waves share one frame's FFT) has the shorter critical path
+    // (8.6 us vs 19 us for 186 frames); many frames: the wave-per-frame kernel has the higher throughput
+    if (dcs_fft_wave_supported(p) && rows_out >= 4 * (int64_t)p->ctx->n_cu) {
         DcsTimer tm(p->ctx, DCS_TAG_STFT);
         const int rc = dcs_fft_wave_forward(p, audio, L, mag, phase, unit, ld, rows_out, T);
         tm.done();

@@ -152,7 +152,8 @@ class Separator(object):
     between reading and writing the wav files (separate_dsd.py:289-306)."""
 
     def __init__(self, arch, params, scale_factor=0.3, time_context=30, overlap=25, batch_size=32, input_size=513,
-                 frameSize=1024, hopSize=512, window=np.hanning, tiler='script', tie_mode=TIE_ALL, device=None):
+                 frameSize=1024, hopSize=512, window=np.hanning, tiler='script', tie_mode=TIE_ALL, device=None,
+                 ctx=None):
         self.arch_name = arch
         self.arch = ARCHS[arch]
         self.scale_factor, self.tc, self.overlap, self.batch_size = scale_factor, time_context, overlap, batch_size
@@ -161,7 +162,7 @@ class Separator(object):
         if frameSize // 2 + 1 != input_size:
             raise ValueError("frameSize %d gives %d bins but the network takes %d" % (frameSize, frameSize // 2 + 1,
                                                                                       input_size))
-        self.ctx = default_context(device)
+        self.ctx = ctx if ctx is not None else default_context(device)   # ctx: one per HIP stream
         self.window = window(frameSize)
         self.plan = StftPlan(self.ctx, frameSize, hopSize, self.window)
         self.net = Network(self.ctx, arch, params, time_context, input_size)

@@ -1,21 +1,25 @@
 #!/bin/bash
-# Quick GPU visit: parity tests + a few bench variants (no rocprof).  Output in gpurun_out/quick_*.
+# Quick GPU visit: parity tests + bench variants (no rocprof).  Output in gpurun_out/quick_*.
+#   DCS_VARIANTS="default S8 ENV=VAL ..."   (S<k> = --streams k; NAME=VAL exported for that run)
 set -u
 OUT=gpurun_out; mkdir -p $OUT
+if [ "${DCS_SKIP_TESTS:-0}" != "1" ]; then
 timeout 900 python -m pytest tests -m gpu -q --maxfail=20 --timeout=240 -p no:cacheprovider > $OUT/quick_pytest.log 2>&1; echo "pytest exit $?"; tail -n 15 $OUT/quick_pytest.log
+fi
 for v in ${DCS_VARIANTS:-default}; do
+  envs=""; extra=""
   case $v in
-    default) envs="";;
-    lds64) envs="DCS_ISTFT_LDS_KB=64";;
-    lds36) envs="DCS_ISTFT_LDS_KB=36";;
+    default) ;;
+    S[0-9]*) extra="--streams ${v#S}";;
     *) envs="$v";;
   esac
-  echo "== bench variant $v ($envs)"
-  env $envs timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/quick_bench_$v.json 2> $OUT/quick_bench_$v.err; echo "exit $?"
+  echo "== bench variant $v ($envs $extra)"
+  env $envs timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline $extra > $OUT/quick_bench_$v.json 2> $OUT/quick_bench_$v.err; echo "exit $?"; tail -n 3 $OUT/quick_bench_$v.err
   python - <<PY
 import json
 d=json.load(open("$OUT/quick_bench_$v.json"))
-print("32t: value %.0f ms/step %.4f frac %.4f" % (d['value'], d['ms_per_step'], d['roofline']['frac']), d['kernels_ms'])
+print("32t x%d streams: value %.0f ms/step %.4f frac %.4f (final %.4f ms)" % (d['config']['streams_per_gpu'], d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_kernel_ms']))
+s1=d['single_stream']; print("32t single: value %.0f ms/step %.4f frac %.4f" % (s1['value'], s1['ms_per_step'], s1['roofline']['frac']), s1['kernels_ms'])
 s=d['saturating']; print("SAT: value %.0f ms/step %.4f frac %.4f" % (s['value'], s['ms_per_step'], s['roofline']['frac']), s['kernels_ms'])
 PY
 done
