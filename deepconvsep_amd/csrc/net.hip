@@ -1,6 +1,7 @@
 // Network handle (build_ca + set_all_param_values), predict_function2 and the fused file-level
 // separation path.  Reference: examples/dsd100/separate_dsd.py:172-311.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -82,6 +83,19 @@ struct dcs_model {
     DcsBuffer ws;
     float* rise_d = nullptr;
     int rise_ov = -1;
+    // ---- hipGraph of the fused step (dcs_separate): the 8 launches of one call replayed as one launch.
+    // A graph is captured the second time the same call (same buffers, sizes, options) arrives.
+    struct StepKey {
+        const void* plan = nullptr; const void* audio = nullptr; const void* pcm = nullptr; const void* ws = nullptr;
+        int64_t L = -1; int ov = 0, tiler = 0, eps = 0, tie = 0; float scale = 0.f;
+        bool operator==(const StepKey& o) const {
+            return plan == o.plan && audio == o.audio && pcm == o.pcm && ws == o.ws && L == o.L && ov == o.ov &&
+                   tiler == o.tiler && eps == o.eps && tie == o.tie && scale == o.scale;
+        }
+    };
+    StepKey seen, captured;
+    hipGraphExec_t step_exec = nullptr;
+    int64_t step_tiles = 0, step_frames = 0;
 };
 
 namespace {
@@ -342,6 +356,7 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     if (m->gen) dcs_generic_destroy(m->gen);
+    if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
     m->ws.release();
     delete m;
     return DCS_OK;
@@ -442,8 +457,62 @@ extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, 
                             int tiler, float scale, int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
                             int64_t* n_frames_out) {
     if (!pcm_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: pcm_d is null");
-    return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr, nullptr,
-                         nullptr, 0, n_tiles_out, n_frames_out);
+    if (!m) DCS_FAIL(DCS_EINVAL, "dcs_separate: null model");
+    static const bool graphs_on = !(getenv("DCS_GRAPH") && atoi(getenv("DCS_GRAPH")) == 0);
+    // graph replay needs a capturable (non-null) stream, no event timing, and an identical repeat call
+    const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD;
+    dcs_model::StepKey key;
+    key.plan = plan; key.audio = audio_d; key.pcm = pcm_d; key.ws = m->ws.ptr; key.L = n_samples; key.ov = overlap;
+    key.tiler = tiler; key.eps = eps_mode; key.tie = tie_mode; key.scale = scale;
+    if (can_graph && m->step_exec && m->captured == key) {
+        DCS_HIP(hipGraphLaunch(m->step_exec, m->ctx->stream));
+        if (n_tiles_out) *n_tiles_out = m->step_tiles;
+        if (n_frames_out) *n_frames_out = m->step_frames;
+        return DCS_OK;
+    }
+    if (can_graph && m->seen == key) {
+        // second identical call: every buffer is allocated and sized, nothing in the path synchronises
+        hipGraph_t graph = nullptr;
+        int64_t nt = 0, nf = 0;
+        DCS_HIP(hipStreamBeginCapture(m->ctx->stream, hipStreamCaptureModeRelaxed));
+        const int rc = separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
+                                     nullptr, nullptr, 0, &nt, &nf);
+        const hipError_t ce = hipStreamEndCapture(m->ctx->stream, &graph);
+        if (rc != DCS_OK || ce != hipSuccess || !graph || m->ws.ptr != key.ws) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            m->seen = dcs_model::StepKey();
+            if (rc != DCS_OK) return rc;
+            // capture failed: run this call eagerly and stop trying for this key
+            return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
+                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out);
+        }
+        if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
+        m->step_exec = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&m->step_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) {
+            m->step_exec = nullptr;
+            m->seen = dcs_model::StepKey();
+            (void)hipGetLastError();
+            return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
+                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out);
+        }
+        m->captured = key;
+        m->step_tiles = nt;
+        m->step_frames = nf;
+        DCS_HIP(hipGraphLaunch(m->step_exec, m->ctx->stream));
+        if (n_tiles_out) *n_tiles_out = nt;
+        if (n_frames_out) *n_frames_out = nf;
+        return DCS_OK;
+    }
+    const int rc = separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
+                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out);
+    if (rc == DCS_OK) {
+        key.ws = m->ws.ptr;  // the first call may have grown the workspace
+        m->seen = key;
+    }
+    return rc;
 }
 
 extern "C" int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
