@@ -20,6 +20,7 @@ struct DsdFinalArgs {
     int F, CI;
     int mmax;             // FOLD: ceil(ov/st)+1 covering tiles per frame; else 1
     int mask_mode;        // 0 = convention A, 1 = convention B, 2 = raw network output
+    int prio;             // 1: raise the wave priority during the MFMA block (scheduling experiment)
 };
 
 // Bw: [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.prio) __builtin_amdgcn_s_setprio(1);  // matrix phase outranks the other waves' epilogues
 #pragma unroll
         for (int q = 0; q < NQ_MAX; ++q) {
             const float b = breg[q];
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[16 * as + off], b, acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[32 * as + off], b, acc2, 0, 0, 0);
         }
+        if (a.prio) __builtin_amdgcn_s_setprio(0);
 
         // ---- bias + rectify (separate_dsd.py:234), soft mask (:258-271), cross-fade (util.py:321-325)
 #pragma unroll
@@ -494,13 +496,16 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float*
     return DCS_OK;
 }
 
-int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
-    if (a.rows <= 0) return DCS_OK;
-    if (a.CI != 52) DCS_FAIL(DCS_EUNSUPPORTED, "final: built for 50 conv1 filters (CI=52), got CI=%d", a.CI);
-    dim3 grid((unsigned)(dcs_cdiv(a.rows, 16) * (a.ldb / 64)));
-    DcsTimer tm(ctx, DCS_TAG_FINAL);
+int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a_in, bool fold) {
+    if (a_in.rows <= 0) return DCS_OK;
+    if (a_in.CI != 52) DCS_FAIL(DCS_EUNSUPPORTED, "final: built for 50 conv1 filters (CI=52), got CI=%d", a_in.CI);
     // DCS_FINAL_KERNEL=2 selects the barrier-free wave-tile variant (A/B experiments)
     static const int force = getenv("DCS_FINAL_KERNEL") ? atoi(getenv("DCS_FINAL_KERNEL")) : 0;  // 1 coop, 2 wave
+    static const int prio = getenv("DCS_FINAL_PRIO") ? atoi(getenv("DCS_FINAL_PRIO")) : 0;
+    DsdFinalArgs a = a_in;
+    a.prio = prio;
+    dim3 grid((unsigned)(dcs_cdiv(a.rows, 16) * (a.ldb / 64)));
+    DcsTimer tm(ctx, DCS_TAG_FINAL);
     constexpr int kCBW = 2;  // column blocks per wave: 3 needs > 256 registers with the prefetch set
     const int n_colg = (a.F + 16 * kCBW - 1) / (16 * kCBW);
     const int64_t n_waves = (int64_t)dcs_cdiv(a.rows, 16) * n_colg;
