@@ -74,6 +74,7 @@ def load():
     proto("dcs_model_create", i32, vp, i32, i32, i32, i32, POINTER(vp), POINTER(i64), i32, POINTER(vp))
     proto("dcs_model_destroy", i32, vp)
     proto("dcs_model_num_sources", i32, vp)
+    proto("dcs_model_set_conv_precision", i32, vp, i32)
     proto("dcs_model_out_channels", i32, vp)
     proto("dcs_model_forward_masked", i32, vp, vp, i64, i32, i32, vp)
     proto("dcs_model_forward", i32, vp, vp, i64, i32, vp)

@@ -15,6 +15,7 @@ struct DcsGenericNet;
 int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int F,
                        const std::vector<std::vector<float>>& params, DcsGenericNet** out);
 void dcs_generic_destroy(DcsGenericNet* g);
+int dcs_generic_set_conv_f16(DcsGenericNet* g, int on);
 // tiles [n, C, tc, F] -> mask_mode 0/1: out [S, n, tc, F] masked; mask_mode 2: p [n, n_branch*C, tc, F]
 int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mask_mode, int tie_mode, float* out);
 int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, int64_t L, int ov, int tiler, float scale,

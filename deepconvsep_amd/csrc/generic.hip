@@ -238,6 +238,111 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const IgemmArgs g)
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same implicit GEMM with f16 inputs and f32 accumulation (v_mfma_f32_16x16x32_f16, 16x the f32 MFMA
+// rate) -- the "fp16 MFMA conv path" of BASELINE config 3.  Activations are rounded to f16 when the
+// im2col tile is stored to LDS, weights are pre-rounded on the host and packed [k tile][32 channels][32 k]
+// so that a lane's 8 consecutive k values are one 16-byte LDS read for both operands.  Opt-in
+// (dcs_model_set_conv_precision): results differ from the f32 path at the 1e-3 level (f16 has an 11-bit
+// significand); the parity test states the tolerance it meets.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(kThreads) void conv_igemm_f16_kernel(const IgemmArgs g, const _Float16* __restrict__ Wh) {
+    constexpr int BM = 128, BK = 32, BN = 32, AS = BK + 8, BS = BK + 8;  // strides in halves (80 bytes)
+    __shared__ __attribute__((aligned(16))) float lds[BN * (BM + 1)];   // >= A tile + B tile; reused for the output
+    _Float16* As = reinterpret_cast<_Float16*>(lds);          // [BM][AS]
+    _Float16* Bs = As + BM * AS;                              // [BN][BS]  (channel-major, k contiguous)
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kg = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int HoWo = g.Ho * g.Wo;
+    const bool padded = (g.ph | g.pw) != 0;
+    const int row = tid & (BM - 1);
+    const int ksub = tid >> 7;
+    const int64_t m = m0 + row;
+    const bool row_ok = m < g.M;
+    int64_t n = 0;
+    int y = 0, x = 0;
+    if (row_ok) {
+        n = m / HoWo;
+        const int r = (int)(m - n * HoWo);
+        y = r / g.Wo;
+        x = r - y * g.Wo;
+    }
+    const float* in_base = g.in + n * g.in_n_stride + (int64_t)(y - g.ph) * g.W + (x - g.pw);
+    float ra[16];
+    f32x4 rb = f32x4{0.f, 0.f, 0.f, 0.f};  // 8 halves of the weight tile (threads 0..127)
+#define DCS_IGH_LOAD(kt_)                                                                      \
+    {                                                                                          \
+        const int k0_ = (kt_) * BK;                                                            \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                       \
+            const int k = k0_ + ksub + 2 * i;                                                  \
+            float v = 0.f;                                                                     \
+            if (row_ok && k < g.K) {                                                           \
+                bool ok = true;                                                                \
+                if (padded) {                                                                  \
+                    const int uv = g.kuv[k];                                                   \
+                    const int yy = y + (uv >> 16) - g.ph, xx = x + (uv & 0xffff) - g.pw;       \
+                    ok = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;                           \
+                }                                                                              \
+                if (ok) v = in_base[g.koff[k]];                                                \
+            }                                                                                  \
+            ra[i] = v;                                                                         \
+        }                                                                                      \
+        if (tid < 128) rb = *reinterpret_cast<const f32x4*>(Wh + (int64_t)(kt_) * (BN * BK) + tid * 8); \
+    }
+#define DCS_IGH_STORE()                                                                        \
+    {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) As[row * AS + ksub + 2 * i] = (_Float16)ra[i]; \
+        if (tid < 128) *reinterpret_cast<f32x4*>(Bs + (tid >> 2) * BS + (tid & 3) * 8) = rb;   \
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkt = (g.K + BK - 1) / BK;
+    DCS_IGH_LOAD(0)
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        DCS_IGH_STORE()
+        __syncthreads();
+        if (kt + 1 < nkt) DCS_IGH_LOAD(kt + 1)
+        const h8 b0 = *reinterpret_cast<const h8*>(Bs + fi * BS + kg * 8);
+        const h8 b1 = *reinterpret_cast<const h8*>(Bs + (16 + fi) * BS + kg * 8);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const h8 a = *reinterpret_cast<const h8*>(As + (wave * 32 + r * 16 + fi) * AS + kg * 8);
+            acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc[r][0], 0, 0, 0);
+            acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc[r][1], 0, 0, 0);
+        }
+    }
+#undef DCS_IGH_LOAD
+#undef DCS_IGH_STORE
+    __syncthreads();
+    float* Cs = lds;
+    constexpr int CS = BM + 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                Cs[(c * 16 + fi) * CS + wave * 32 + r * 16 + kg * 4 + e] = acc[r][c][e];
+    __syncthreads();
+    for (int idx = tid; idx < g.Cout * BM; idx += kThreads) {
+        const int co = idx / BM, p = idx - co * BM;
+        const int64_t mm = m0 + p;
+        if (mm < g.M) {
+            const int64_t nn = mm / HoWo;
+            const int r = (int)(mm - nn * HoWo);
+            g.out[nn * g.out_n_stride + (int64_t)co * HoWo + r] = Cs[co * CS + p] + g.bias[co];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // VJP of conv1: o[m, c, t, f] = sum_{o', j : 0 <= f - j*sw < kw} g[m, o', t, j] * Wc[o', c, f - j*sw]
 // block = 256 consecutive f of one (m, t) row, all C output channels.
 // ------------------------------------------------------------------------------------------------
@@ -334,6 +439,9 @@ struct DcsGenericNet {
     // transposed conv2
     float *W2t = nullptr, *bias0 = nullptr;
     int *kt_off = nullptr, *kt_uv = nullptr;
+    // f16 copies of the two conv2 weight matrices, packed [k tile][32 channels][32 k]
+    _Float16 *W2m_h = nullptr, *W2t_h = nullptr;
+    int conv_f16 = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
     float* Bd[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -393,6 +501,16 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
                 for (int ci = 0; ci < nf1; ++ci)
                     W2t[(size_t)k * 32 + ci] = W2[(((size_t)co * nf1 + ci) * kh + u) * kw + v];
             }
+    // f16 packing of both matrices (round-to-nearest-even from the f32 weights)
+    auto pack_h = [&](const std::vector<float>& Wm) {
+        std::vector<_Float16> h((size_t)K2p * 32);
+        for (int kt = 0; kt < K2p / 32; ++kt)
+            for (int c = 0; c < 32; ++c)
+                for (int kk = 0; kk < 32; ++kk)
+                    h[((size_t)kt * 32 + c) * 32 + kk] = (_Float16)Wm[(size_t)(kt * 32 + kk) * 32 + c];
+        return h;
+    };
+    const std::vector<_Float16> W2m_h = pack_h(W2m), W2t_h = pack_h(W2t);
     // dense layers: the flattened [nf2, h2, w2] order is the storage order of a2b, so no permutation
     const int Kfc = g->flat_p;
     std::vector<float> Bfc((size_t)dcs_round_up(Kfc, 128) * g->hid64, 0.f), biasfc(g->hid64, 0.f);
@@ -404,6 +522,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     if (rc == DCS_OK) rc = upload(&(dst), (src));
     UP(g->W1c, W1c) UP(g->bias1, bias1) UP(g->W2m, W2m) UP(g->bias2, bias2) UP(g->k2off, k2off) UP(g->k2uv, k2uv)
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
+    UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
     for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) {
         std::vector<float> Bd((size_t)dcs_round_up(g->hid64, 128) * g->flat64, 0.f), bd(g->flat64, 0.f);
         for (int h = 0; h < d.hidden; ++h)
@@ -424,7 +543,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d};
     for (void* p : ptrs)
@@ -477,7 +596,11 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         a.out = a2b; a.out_n_stride = g->flat_p; a.Cout = d.nf2; a.Ho = d.h2; a.Wo = d.w2;
         a.ph = 0; a.pw = 0; a.K = g->K2; a.M = n * d.h2 * d.w2;
         DcsTimer tm(ctx, DCS_TAG_CONV2);
-        hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
+        if (g->conv_f16)
+            hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
+                               g->W2m_h);
+        else
+            hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
         tm.done();
     }
     // bottleneck dense (rectify)
@@ -508,7 +631,11 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         a.out = g2; a.out_n_stride = (int64_t)d.nf1 * planep; a.Cout = d.nf1; a.Ho = tc; a.Wo = d.wp;
         a.ph = d.kh2 - 1; a.pw = d.kw2 - 1; a.K = g->K2; a.M = n * NB * planep;
         DcsTimer tm(ctx, DCS_TAG_DECONV2);
-        hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
+        if (g->conv_f16)
+            hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
+                               g->W2t_h);
+        else
+            hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
         tm.done();
     }
     // InverseLayer(., pool)
@@ -567,6 +694,12 @@ size_t chunk_bytes(const DcsGenericNet* g, int64_t n) {
 }
 
 }  // namespace
+
+int dcs_generic_set_conv_f16(DcsGenericNet* g, int on) {
+    if (!g) DCS_FAIL(DCS_EINVAL, "null network");
+    g->conv_f16 = on ? 1 : 0;
+    return DCS_OK;
+}
 
 int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mask_mode, int tie_mode, float* out) {
     if (!g) DCS_FAIL(DCS_EINVAL, "generic forward: null network");

@@ -362,6 +362,14 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     return DCS_OK;
 }
 
+extern "C" int dcs_model_set_conv_precision(dcs_model* m, int f16) {
+    if (!m) DCS_FAIL(DCS_EINVAL, "dcs_model_set_conv_precision: null model");
+    if (f16 && !m->gen)
+        DCS_FAIL(DCS_EUNSUPPORTED, "the f16 MFMA conv path exists for the ikala / bach10 / score-informed graphs");
+    if (m->gen) return dcs_generic_set_conv_f16(m->gen, f16);
+    return DCS_OK;
+}
+
 extern "C" int dcs_model_num_sources(const dcs_model* m) { return m ? m->d.S : DCS_EINVAL; }
 extern "C" int dcs_model_out_channels(const dcs_model* m) { return m ? m->d.n_branch * m->C : DCS_EINVAL; }
 

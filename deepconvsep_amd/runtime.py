@@ -203,6 +203,13 @@ class Network(object):
         self.S = int(ctx._lib.dcs_model_num_sources(h))
         self.out_channels = int(ctx._lib.dcs_model_out_channels(h))
 
+    def set_conv_precision(self, dtype):
+        """``'f16'``: conv2 and its transpose use f16-input / f32-accumulate MFMA (BASELINE config 3);
+        ``'f32'`` (default): exact f32."""
+        if dtype not in ('f16', 'f32'):
+            raise ValueError("conv precision must be 'f16' or 'f32'")
+        _lib.check(self.ctx._lib.dcs_model_set_conv_precision(self._h, 1 if dtype == 'f16' else 0))
+
     def forward_masked(self, tiles_t, eps_mode=None, tie_mode=TIE_ALL):
         """tiles_t ``[n, C, tc, F]`` float32 device tensor -> ``[S, n, tc, F]``."""
         torch = _torch()

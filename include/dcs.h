@@ -120,6 +120,9 @@ int dcs_model_create(dcs_ctx* ctx, int arch, int in_channels, int time_context, 
                      const float* const* params_d, const int64_t* shapes, int nparams, dcs_model** out);
 int dcs_model_destroy(dcs_model* m);
 int dcs_model_num_sources(const dcs_model* m);
+/* f16 = 1: conv2 and its transpose of the ikala / bach10 / score-informed graphs run with f16 inputs and
+ * f32 accumulation on the matrix cores (BASELINE config 3, "fp16 MFMA conv path"); 0 (default): f32. */
+int dcs_model_set_conv_precision(dcs_model* m, int f16);
 
 /* predict_function2 (separate_dsd.py:273,298): tiles_d [n, C, tc, F] -> out_d [S, n, tc, F]
  * = soft-masked magnitudes of the S sources. */
