@@ -470,30 +470,38 @@ def test_graph_replay_recomputes_on_a_side_stream():
 @pytest.mark.parametrize("arch,F,n", [("bach10", 257, 4), ("ikala", 513, 3)])
 def test_f16_mfma_conv_path_stated_tolerance(arch, F, n):
     """BASELINE config 3: conv2 and its transpose with f16 inputs / f32 accumulation on the matrix cores.
-    f16 keeps 11 significant bits, so this path does NOT meet the 1e-4 bar of the f32 path; the tolerance
-    it does meet is stated here: max |err| < 1e-2 and 99.9th percentile < 2e-3 on masked magnitudes of
-    order 1, and it must stay close to the f32 path."""
+    f16 keeps 11 significant bits, so this path does NOT meet the 1e-4 bar of the f32 path.  Tolerance it is
+    held to: network output before masking max |err| < 2e-3; masked magnitudes 99.9th percentile < 1e-3 and
+    max < 5e-3 over the bins where the mask is well conditioned (reference sum of branch outputs > 1e-2 --
+    where all branches are cut to ~0 by the rectifier the mask itself is discontinuous)."""
     import os
     tc = 30
+    S = ARCHS[arch].S
     params = synth_params(arch, tc, F, seed=3)
     x = _tiles(arch, n, tc, F, seed=12)
     ctx = default_context()
     net = Network(ctx, arch, params, tc, F)
     xd = ctx.to_device(x, np.float32)
+    p_ref = net_ref.forward(arch, params, x.astype(np.float64), inverse='explicit').numpy()
     ref = np.stack([r[:, 0] for r in net_ref.predict(arch, params, x.astype(np.float64), inverse='explicit')])
     f32 = net.forward_masked(xd).cpu().numpy()
     net.set_conv_precision('f16')
     f16 = net.forward_masked(xd).cpu().numpy()
+    p16 = net.forward_raw(xd).cpu().numpy()
     net.set_conv_precision('f32')
-    again = net.forward_masked(xd).cpu().numpy()
-    assert np.array_equal(again, f32)                       # the switch is reversible
+    assert np.array_equal(net.forward_masked(xd).cpu().numpy(), f32)     # the switch is reversible
+    perr = np.abs(p16 - p_ref)
     err = np.abs(f16 - ref)
-    stats = "%s F=%d: f16 path max|err| %.3e, p99.9 %.3e, mean %.3e (f32 path max %.3e); max|ref| %.3f" % (
-        arch, F, err.max(), np.percentile(err, 99.9), err.mean(), np.abs(f32 - ref).max(), np.abs(ref).max())
+    well = (p_ref[:, :S].sum(axis=1) > 1e-2)[None].repeat(S, axis=0)       # [S, n, tc, F]
+    stats = ("%s F=%d f16 conv path: raw output max|err| %.3e; masked p99.9 %.3e, mean %.3e, max over "
+             "well-conditioned bins %.3e (%.1f%% of bins), max overall %.3e; f32 path max %.3e" % (
+                 arch, F, perr.max(), np.percentile(err, 99.9), err.mean(), err[well].max(), 100.0 * well.mean(),
+                 err.max(), np.abs(f32 - ref).max()))
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/f16_stats.txt", "a") as fh:
         fh.write(stats + "\n")
-    assert err.max() < 1e-2 and np.percentile(err, 99.9) < 2e-3, stats
+    assert perr.max() < 2e-3, stats
+    assert np.percentile(err, 99.9) < 1e-3 and err[well].max() < 5e-3, stats
     assert np.abs(f32 - ref).max() < 1e-4
     with pytest.raises(NotImplementedError):
         Network(ctx, "dsd", synth_params("dsd", tc, 513), tc, 513).set_conv_precision('f16')
