@@ -100,6 +100,76 @@ __global__ __launch_bounds__(kThreads) void deconv2_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Many-tiles variant of deconv2_kernel: persistent workgroups.  With one workgroup per (tile, branch,
+// group) every workgroup streams its 52 x 208 weight slice (43 KB) from L2 for 42 MFMAs per wave -- 2.1 GB
+// of L2 traffic per launch at 4096 tiles.  Here a workgroup keeps the slice of its channel group in LDS
+// and walks a strided list of (tile, branch) pairs; the next pair's 16 x 52 input rows are prefetched
+// into registers while the current pair is multiplied and reduced.
+// ------------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ __launch_bounds__(kThreads) void deconv2_persistent_kernel(const float* __restrict__ D,
+                                                                      const float* __restrict__ Bw,
+                                                                      float* __restrict__ G, int64_t n_ks, int H2,
+                                                                      int CP, int CI, int kh, int tc, int GS, int gcols) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int as = CP + 2;
+    float* Bs = smem;                      // [CP][gcols]   (gcols % 32 == 16: rows kq, kq+1 hit disjoint banks)
+    float* As = Bs + CP * gcols;           // [16][CP+2]
+    float* P = As + 16 * as;               // [16][gcols]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int grp = blockIdx.y;
+    const int ldb = gcols * (int)gridDim.y;
+    for (int idx = tid; idx < CP * gcols; idx += kThreads) {
+        const int r = idx / gcols, c = idx - r * gcols;
+        Bs[idx] = Bw[(int64_t)r * ldb + grp * gcols + c];
+    }
+    const int a_slots = H2 * (CP >> 2);    // float4 slots of one (tile, branch) input block (H2 <= 16 rows)
+    const int ncb = gcols >> 4;
+    const int ci0 = grp * GS;
+    f32x4 pre = f32x4{0.f, 0.f, 0.f, 0.f};
+    int64_t ks = blockIdx.x;
+    if (ks < n_ks && tid < a_slots) pre = *reinterpret_cast<const f32x4*>(D + ks * (int64_t)H2 * CP + tid * 4);
+    for (; ks < n_ks; ks += gridDim.x) {
+        __syncthreads();  // previous pair: P fully reduced, As fully read
+        if (tid < 16 * (CP >> 2)) {
+            const int r = tid / (CP >> 2), c4 = tid - r * (CP >> 2);
+            const f32x4 v = (tid < a_slots) ? pre : f32x4{0.f, 0.f, 0.f, 0.f};
+            float* d = As + r * as + c4 * 4;
+            *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+        }
+        __syncthreads();
+        const int64_t nxt = ks + gridDim.x;
+        if (nxt < n_ks && tid < a_slots) pre = *reinterpret_cast<const f32x4*>(D + nxt * (int64_t)H2 * CP + tid * 4);
+        float a0[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) a0[q] = As[fi * as + 4 * q + kq];
+        for (int cb = wave; cb < ncb; cb += 4) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], Bs[(4 * q + kq) * gcols + cb * 16 + fi], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[(kq * 4 + e) * gcols + cb * 16 + fi] = acc[e];
+        }
+        __syncthreads();
+        float* Gp = G + ks * (int64_t)tc * CI;
+        for (int o = tid; o < tc * GS; o += kThreads) {
+            const int t = o / GS, c = o - t * GS;
+            if (ci0 + c >= CI) continue;
+            int lo = t - (H2 - 1);
+            if (lo < 0) lo = 0;
+            const int hi = t < kh - 1 ? t : kh - 1;
+            float sum = 0.f;
+            for (int dt = lo; dt <= hi; ++dt) sum += P[(t - dt) * gcols + c * kh + dt];
+            Gp[t * CI + ci0 + c] = sum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Transposed conv1 (K = CI input channels, N = F bins) fused with everything after it.
 // Workgroup = 16 rows x 64 bins; wave w owns 16 bins; the three branch accumulators of one
 // (row, bin) live in the same lane, so bias + rectify + soft mask + x mixture happen in
@@ -489,8 +559,21 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float*
     const size_t lds = (size_t)16 * nrb * ((CP + 2) + gcols) * sizeof(float);
     if (lds > 64 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: LDS %zu too large", lds);
     DcsTimer tm(ctx, DCS_TAG_DECONV2);
-    hipLaunchKernelGGL(deconv2_kernel<13>, dim3((unsigned)n_ks, (unsigned)NG), dim3(kThreads), lds, ctx->stream, D, Bw,
-                       G, H2, CP, CI, kh, tc, GS, gcols);
+    static const int force = getenv("DCS_DECONV2") ? atoi(getenv("DCS_DECONV2")) : 0;  // 1 one-shot, 2 persistent
+    const int per_group = 2 * ctx->n_cu / NG;                       // persistent workgroups per channel group
+    const bool persistent = force ? force == 2 : (nrb == 1 && n_ks >= 8 * (int64_t)per_group);
+    if (persistent) {
+        const size_t lds2 = ((size_t)CP * gcols + 16 * (CP + 2) + (size_t)16 * gcols) * sizeof(float);
+        auto kern = deconv2_persistent_kernel<13>;
+        if (lds2 > 48 * 1024)
+            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds2));
+        hipLaunchKernelGGL(kern, dim3((unsigned)per_group, (unsigned)NG), dim3(kThreads), lds2, ctx->stream, D, Bw, G,
+                           n_ks, H2, CP, CI, kh, tc, GS, gcols);
+    } else {
+        hipLaunchKernelGGL(deconv2_kernel<13>, dim3((unsigned)n_ks, (unsigned)NG), dim3(kThreads), lds, ctx->stream, D,
+                           Bw, G, H2, CP, CI, kh, tc, GS, gcols);
+    }
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
