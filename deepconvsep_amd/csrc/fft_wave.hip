@@ -290,6 +290,14 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
     const int s = blockIdx.y;
     const int span = C * hop;
     const int64_t p0 = (int64_t)blockIdx.x * span;
+    // hop | N and hop even (every reference config): a frame is N/hop whole hop-blocks of hop/2 sample pairs,
+    // so which block of which frame lands where is wave-uniform scalar arithmetic
+    const bool aligned = (N % hop) == 0 && (hop & 1) == 0;
+    float2* winl = reinterpret_cast<float2*>(acc + span);  // window as (even, odd) pairs (aligned path)
+    if (aligned) {
+        const float2* w2g = reinterpret_cast<const float2*>(win);
+        for (int k = tid; k < M; k += 256) winl[k] = w2g[k];
+    }
     for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
     for (int q = tid; q < span; q += 256) acc[q] = 0.f;
     int64_t n_hi = (p0 + span - 1) / hop;
@@ -340,19 +348,44 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
             fft_wave<LOG2M, +1>(v, lane, twl, buf);
         }
         __syncthreads();
-        for (int q = tid; q < span; q += 256) {
-            const int64_t p = p0 + q;
-            float a = acc[q];
-#pragma unroll
+        if (aligned) {
+            // frames in increasing order (the reference's accumulation order); frame n2 covers the global
+            // hop-blocks n2 .. n2 + N/hop - 1, chunk block j is global block p0/hop + j
+            const int hp = hop >> 1, R = N / hop;
+            const int64_t hb0 = p0 / hop;
+            float2* acc2 = reinterpret_cast<float2*>(acc);
             for (int w = 0; w < 4; ++w) {
                 const int64_t n2 = nb + w;
-                const int64_t off = p - n2 * hop;
-                if (n2 <= n_hi && off >= 0 && off < N) {
-                    const float2 z = fbuf[w * MP + pad((int)(off >> 1))];
-                    a += (((off & 1) ? z.y : z.x) * inv_m) * win[off];
+                if (n2 > n_hi) break;
+                for (int j = 0; j < C; ++j) {
+                    const int64_t d = hb0 + j - n2;
+                    if (d < 0 || d >= R) continue;
+                    const int fo = (int)d * hp;
+                    for (int r = tid; r < hp; r += 256) {
+                        const float2 z = fbuf[w * MP + pad(fo + r)];
+                        const float2 ww = winl[fo + r];
+                        float2 a2 = acc2[j * hp + r];
+                        a2.x += (z.x * inv_m) * ww.x;
+                        a2.y += (z.y * inv_m) * ww.y;
+                        acc2[j * hp + r] = a2;
+                    }
                 }
             }
-            acc[q] = a;
+        } else {
+            for (int q = tid; q < span; q += 256) {
+                const int64_t p = p0 + q;
+                float a = acc[q];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int64_t n2 = nb + w;
+                    const int64_t off = p - n2 * hop;
+                    if (n2 <= n_hi && off >= 0 && off < N) {
+                        const float2 z = fbuf[w * MP + pad((int)(off >> 1))];
+                        a += (((off & 1) ? z.y : z.x) * inv_m) * win[off];
+                    }
+                }
+                acc[q] = a;
+            }
         }
         __syncthreads();
     }
@@ -403,7 +436,7 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     if (C > 16 - (R_ - 1)) C = 16 - (R_ - 1);
     if (c_env > 0) C = c_env;
     if (C < 1) C = 1;
-    const size_t fixed = ((size_t)(M + 1) + 4 * (size_t)MP) * sizeof(float2);
+    const size_t fixed = ((size_t)(M + 1) + 4 * (size_t)MP + (size_t)M) * sizeof(float2);  // + window pairs
     size_t lds = fixed + (size_t)C * hop * sizeof(float);
     while (lds > 96 * 1024 && C > 1) {
         --C;
