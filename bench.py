@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--tiles", type=int, default=32, help="tiles per GPU per step (BASELINE configs[1]: 32)")
     ap.add_argument("--frame-size", type=int, default=2048)
     ap.add_argument("--streams", type=int, default=8, help="independent batches in flight per GPU")
+    ap.add_argument("--issue-threads", type=int, default=2,
+                    help="host threads issuing steps (single GPU only: with N ranks the RCCL gathers must be "
+                         "issued in the same order on every rank)")
     ap.add_argument("--sat-tiles", type=int, default=4096, help="tiles of the saturating extra run (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -127,12 +130,28 @@ def main():
         if world > 1:
             dist.barrier()
 
+    import threading
+    n_issue = max(1, min(args.issue_threads, NS)) if world == 1 else 1
+
     def timed(k, use):
+        """Exactly k steps, round-robin over the lanes in `use`, issued by n_issue host threads (ctypes
+        releases the GIL inside dcs_separate) when more than one lane is in play."""
+        nth = n_issue if len(use) > 1 else 1
+        share = [k // nth + (1 if t < k % nth else 0) for t in range(nth)]
+
+        def work(t):
+            mine = use[t::nth]
+            for i in range(share[t]):
+                mine[i % len(mine)].step()
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(1, nth)]
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(k):
-            use[i % len(use)].step()
+        for th in threads:
+            th.start()
+        work(0)
+        for th in threads:
+            th.join()
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
@@ -283,7 +302,7 @@ def main():
                                    "(HIP streams)%s"
                                    % (N, n_tiles, L / SR, NS, ", PCM all-gathered over RCCL" if world > 1 else ""),
                        "tiles_per_gpu_per_step": n_tiles, "frames_per_gpu_per_step": frames_per_step,
-                       "frame_size": N, "bins": F, "streams_per_gpu": NS,
+                       "frame_size": N, "bins": F, "streams_per_gpu": NS, "issue_threads": n_issue,
                        "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",
                        "parallelism": "tiles sharded by rank (dp%d)" % world},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_stream": single, "saturating": saturating,
