@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=32, help="tiles per GPU per step (BASELINE configs[1]: 32)")
     ap.add_argument("--frame-size", type=int, default=2048)
     ap.add_argument("--streams", type=int, default=8, help="independent batches in flight per GPU")
-    ap.add_argument("--issue-threads", type=int, default=2,
+    ap.add_argument("--issue-threads", type=int, default=1,
                     help="host threads issuing steps (single GPU only: with N ranks the RCCL gathers must be "
                          "issued in the same order on every rank)")
     ap.add_argument("--sat-tiles", type=int, default=4096, help="tiles of the saturating extra run (0 = skip)")
