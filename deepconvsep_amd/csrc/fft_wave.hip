@@ -1,7 +1,7 @@
 // Wave-per-frame STFT / iSTFT for the float32 fast path (N = 1024, 2048, 4096), gfx950.
 //
 // The block-level radix-4 FFT of fft.hip spends ~60 % of a wave's life parked at workgroup barriers
-// (PMC: SQ_WAIT_ANY, profiles/r01_v4_pmc_summary.txt): 5 passes x 256 threads x 1 butterfly.  Here one
+// (PMC: SQ_WAIT_ANY, profiles/r01_b_pmc_summary.txt): 5 passes x 256 threads x 1 butterfly.  Here one
 // 64-lane wavefront owns one frame: M = N/2 complex points, M/64 = 8/16/32 points per lane, three
 // Stockham passes of radix 16/16/4 (M=1024), 16/16/8 (M=2048), 8/8/8 (M=512) done in registers and
 // exchanged through a per-wave LDS buffer.  A wave's LDS operations are performed in program order, so
