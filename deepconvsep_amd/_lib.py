@@ -9,7 +9,7 @@ import re
 from ctypes import (POINTER, byref, c_char_p, c_double, c_float, c_int, c_int64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcs.so")
+LIB_PATH = os.environ.get("DCS_LIB") or os.path.join(_HERE, "libdcs.so")  # DCS_LIB: experiment builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcs.h")
 
 DCS_OK, DCS_EINVAL, DCS_EUNSUPPORTED, DCS_EHIP, DCS_ENOMEM, DCS_ESHAPE = 0, -1, -2, -3, -4, -5

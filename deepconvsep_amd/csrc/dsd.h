@@ -4,7 +4,7 @@
 
 struct DsdFinalArgs {
     const float* G;       // [n][3][tc][CI] transposed-conv2 outputs
-    const float* Bw;      // [CI][ldb]  Bw[c][f] = W1[c,0,0,F-1-f]; ldb = F rounded up to 64, zero padded
+    const float* Bw;      // [CI][ldb]  Bw[c][f] = W1[c,0,0,F-1-f]; ldb = F rounded up to 128, zero padded
     int ldb;
     const float* bias;    // [4] output BiasLayer
     const float* mix;     // mixture magnitudes: FOLD mag[T][mix_ld]; else tiles[n*tc][F]
@@ -20,7 +20,6 @@ struct DsdFinalArgs {
     int F, CI;
     int mmax;             // FOLD: ceil(ov/st)+1 covering tiles per frame; else 1
     int mask_mode;        // 0 = convention A, 1 = convention B, 2 = raw network output
-    int prio;             // 1: raise the wave priority during the MFMA block (scheduling experiment)
 };
 
 // Bw: [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]

@@ -171,18 +171,38 @@ __global__ __launch_bounds__(kThreads) void deconv2_persistent_kernel(const floa
 
 // ------------------------------------------------------------------------------------------------
 // Transposed conv1 (K = CI input channels, N = F bins) fused with everything after it.
-// Workgroup = 16 rows x 64 bins; wave w owns 16 bins; the three branch accumulators of one
-// (row, bin) live in the same lane, so bias + rectify + soft mask + x mixture happen in
-// registers.  FOLD: a row is an output frame t and the loop over m walks the tiles that cover it
-// in the order of the reference's sequential cross-fade (owner tile first, then the blends), so
-// the masked tiles never exist in HBM.  !FOLD: a row is one frame of one tile (predict_function2).
+// Workgroup = 16 rows x 128 bins; wave w owns 32 bins = two MFMA column blocks (lane fi holds the
+// adjacent bins 2fi, 2fi+1, so results leave as 8-byte stores in 128-byte row segments); the three
+// branch accumulators of one (row, bin) live in the same lane, so bias + rectify + soft mask +
+// x mixture happen in registers.  FOLD: a row is an output frame t and the loop over m walks the tiles
+// that cover it in the order of the reference's sequential cross-fade (owner tile first, then the
+// blends), so the masked tiles never exist in HBM.  !FOLD: a row is one frame of one tile
+// (predict_function2).
+//
+// What bounds it (scripts/ubench/mfma_valu.hip, MI355X): fp32 MFMA and VALU instructions do NOT
+// overlap on a SIMD -- not within a wave and not across waves (3 waves/SIMD: MFMA alone 13.6 ns,
+// +4 v_fma 20.5 ns, +8 25.1 ns per MFMA) -- so the kernel's time is MFMA cycles PLUS VALU cycles and
+// every non-MFMA instruction counts.  Hence: two column blocks per A fragment (staging, LDS reads and
+// per-row cross-fade state amortised over twice the bins), cross-fade weights from an LDS table built
+// once per workgroup (no per-m validity arithmetic), packed fp32 math (v_pk_add/mul/fma_f32 on the
+// (e, e+1) register pairs of an accumulator) in the epilogue, 128-bit LDS fragment reads (a K order
+// chosen so that a lane's 13 channels are 3 aligned float4 + 1 float).
 // ------------------------------------------------------------------------------------------------
-template <bool FOLD, int NQ>
-__global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
-    constexpr int NBR = 3;      // dense branches that reach the output (separate_dsd.py:228)
-    constexpr int NQ_MAX = NQ;  // CI / 4, compile time: the K loop unrolls into one block of MFMAs
-    constexpr int kABuf = NBR * 16 * (64 + 2);
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// channel multiplied in MFMA step q by the lanes of K-quarter kq: 12 contiguous channels + 1 of the last 4
+__device__ __forceinline__ constexpr int final_chan(int q, int kq) { return q < 12 ? 12 * kq + q : 48 + kq; }
+
+template <bool FOLD, int MODE, int CBW /* column blocks per wave: 2, or 1 when there are few rows */>
+__global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a, int n_colg) {
+    constexpr int NBR = 3;   // dense branches that reach the output (separate_dsd.py:228)
+    constexpr int NQ = 13;   // CI / 4 MFMA steps
+    constexpr int CI = 52, AS = 56;  // LDS row stride: multiple of 4 floats (128-bit reads and writes)
+    constexpr int kABuf = NBR * 16 * AS;
+    constexpr int kMaxM = 16;
     __shared__ __attribute__((aligned(16))) float As[2 * kABuf];  // double-buffered A set
+    __shared__ __attribute__((aligned(16))) float up_t[kMaxM * 16];    // cross-fade weight of tile m on row i
+    __shared__ __attribute__((aligned(16))) float down_t[kMaxM * 16];  // weight kept of what is already there
     __shared__ int meta_k0[16];
     __shared__ int meta_j0[16];
 
@@ -195,155 +215,204 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int n_colg = a.ldb / 64;
-    const int64_t row0 = (int64_t)(swz / n_colg) * 16;
-    const int col = (int)(swz % n_colg) * 64 + wave * 16 + fi;
-    constexpr int nq = NQ;
-    const int CI = a.CI, as = a.CI + 2;
-    const int tc = a.tc, st = a.st, ov = a.ov;
+    const unsigned rg = swz / (unsigned)n_colg;
+    const int64_t row0 = (int64_t)rg * 16;
+    const int colw = (int)(swz - rg * (unsigned)n_colg) * (64 * CBW) + wave * (16 * CBW);
+    const int col = colw + CBW * fi;  // this lane's bins: col (cb = 0), col + 1 (cb = 1)
+    const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
     const int64_t n = a.n;
 
-    if (tid < 16) {
-        const int64_t r = row0 + tid;
-        int k0 = 0, j0 = -1;
+    // ---- per-row state, once per workgroup: owner tile k0 / position j0 of each row, then the table of
+    // cross-fade weights (util.py:321-325): the owner tile (m = 0) overwrites (up 1, down 0), a later
+    // tile blends with up = rise[j], down = rise[ov-1-j], a tile that does not cover the row leaves it
+    // (up 0, down 1).
+    if (tid < 16 * mmax) {
+        const int i = tid & 15, m = tid >> 4;
+        const int64_t r = row0 + i;
+        int64_t k0 = 0;
+        int j0 = -1;
         if (r < a.rows) {
             if (FOLD) {
-                int64_t kk = (r < ov) ? 0 : (r - ov) / st;
+                int64_t kk = (r < ov) ? 0 : (int64_t)((uint64_t)(r - ov) / (unsigned)st);
                 if (kk > n - 1) kk = n - 1;
                 const int64_t jj = r - kk * st;
                 if (jj < tc) {
-                    k0 = (int)kk;
+                    k0 = kk;
                     j0 = (int)jj;
                 }
             } else {
-                k0 = (int)(r / tc);
-                j0 = (int)(r - (int64_t)k0 * tc);
+                k0 = (int64_t)((uint64_t)r / (unsigned)tc);
+                j0 = (int)(r - k0 * tc);
             }
         }
-        meta_k0[tid] = k0;
-        meta_j0[tid] = j0;
+        if (m == 0) {
+            meta_k0[i] = (int)k0;
+            meta_j0[i] = j0;
+        }
+        const int j = j0 - m * st;
+        const bool valid = j0 >= 0 && j >= 0 && k0 + m < n;
+        float up = 0.f, down = 1.f;
+        if (m == 0) {
+            up = valid ? 1.f : 0.f;
+            down = 0.f;
+        } else if (valid) {
+            up = a.rise[j];
+            down = a.rise[ov - 1 - j];
+        }
+        up_t[m * 16 + i] = up;
+        down_t[m * 16 + i] = down;
     }
 
-    // B fragments: Bw[c][bin], this lane's bin, rows 4q+kq -- constant for the whole workgroup
-    float breg[NQ_MAX];
+    const bool live = colw < a.F;  // a wave whose 32 bins are all padding only helps staging
+    // B fragments: Bw[c][bin] of this lane's two bins -- constant for the whole workgroup
+    float breg[CBW][NQ];
 #pragma unroll
-    for (int q = 0; q < NQ_MAX; ++q) breg[q] = a.Bw[(int64_t)(4 * q + kq) * a.ldb + col];
-
-    // mixture value of this lane's 4 (row, bin) cells
-    float mixv[4];
+    for (int q = 0; q < NQ; ++q) {
+        const float* bp = a.Bw + (int64_t)final_chan(q, kq) * a.ldb + col;
+        if constexpr (CBW == 2) {
+            const f32x2 b = live ? *reinterpret_cast<const f32x2*>(bp) : f32x2{0.f, 0.f};
+            breg[0][q] = b[0];
+            breg[1][q] = b[1];
+        } else {
+            breg[0][q] = live ? *bp : 0.f;
+        }
+    }
+    // mixture value of this lane's 4 rows x 2 bins
+    const bool vec = CBW == 2 && ((a.mix_ld | a.out_ld) & 1) == 0;  // rows 8-byte aligned (the fused path pads F to 4)
+    f32x4 mixv[CBW];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int64_t r = row0 + kq * 4 + e;
-        mixv[e] = (r < a.rows && col < a.F) ? a.mix_scale * a.mix[r * a.mix_ld + col] : 0.f;
+        float m0 = 0.f, m1 = 0.f;
+        if (r < a.rows) {
+            const float* mp = a.mix + r * a.mix_ld + col;
+            if (vec && col + 1 < a.F) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(mp);
+                m0 = v[0];
+                m1 = v[1];
+            } else {
+                if (col < a.F) m0 = mp[0];
+                if (CBW == 2 && col + 1 < a.F) m1 = mp[1];
+            }
+        }
+        mixv[0][e] = a.mix_scale * m0;
+        if constexpr (CBW == 2) mixv[1][e] = a.mix_scale * m1;
     }
     const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
     const float eps_r = 5e-19f;  // eps * rand_num with the unseeded draw replaced by 0.5 (separate_dsd.py:245,256)
 
-    float res[4][4];
+    f32x4 res[CBW][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) res[c][e] = 0.f;
+        for (int c = 0; c < 4; ++c) res[cb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();
 
     // ---- staging plan of this thread: up to 3 float4 slots of the [3 branches][16 rows][CI] A set.
-    // Slot (s, i, c4) reads G[k0_i + m][s][j0_i - m*st][4 c4 ..]; going from m to m+1 moves the
-    // address by the constant (NBR*tc - st)*CI, so only validity has to be re-evaluated per m.
-    const int slots = NBR * 16 * nq;
-    const int64_t m_delta = ((int64_t)NBR * tc - st) * CI;
-    const float* src[3];
-    int dst[3], sk0[3], sj0[3];
+    // Slot (s, i, c4) reads G[k0_i + m][s][j0_i - m*st][4 c4 ..]; going from m to m+1 moves the address by
+    // the constant (NBR*tc - st)*CI, and the slot is needed iff tile m has a non-zero weight on row i.
+    constexpr int slots = NBR * 16 * NQ;
+    const int m_delta = (NBR * tc - st) * CI;
+    const int kbase = meta_k0[0];
+    const float* gbase = a.G + (int64_t)kbase * NBR * tc * CI;  // workgroup-uniform; offsets stay 32-bit
+    int goff[3], dst[3], srow[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int idx = tid + u * kThreads;
-        const int s = idx / (16 * nq);
-        const int rem = idx - s * 16 * nq;
-        const int i = rem / nq, c4 = rem - i * nq;
+        const int s = idx / (16 * NQ);
+        const int rem = idx - s * 16 * NQ;
+        const int i = rem / NQ, c4 = rem - i * NQ;
         const bool in = idx < slots;
-        sk0[u] = in ? meta_k0[i] : 0;
-        sj0[u] = in ? meta_j0[i] : -1;
-        dst[u] = in ? (s * 16 + i) * as + c4 * 4 : 0;
-        src[u] = a.G + (((int64_t)sk0[u] * NBR + s) * tc + (sj0[u] < 0 ? 0 : sj0[u])) * (int64_t)CI + c4 * 4;
+        const int j0 = in ? meta_j0[i] : -1;
+        srow[u] = in ? i : -1;
+        dst[u] = (s * 16 + i) * AS + c4 * 4;
+        goff[u] = (((in ? meta_k0[i] - kbase : 0) * NBR + s) * tc + (j0 < 0 ? 0 : j0)) * CI + c4 * 4;
     }
     f32x4 pre[3];
 #define DCS_LOAD_A(m_)                                                                          \
     _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                             \
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                    \
-        if (sj0[u] >= 0 && sj0[u] - (m_) * st >= 0 && (int64_t)sk0[u] + (m_) < n)               \
-            v = *reinterpret_cast<const f32x4*>(src[u] + (m_) * m_delta);                       \
+        if (srow[u] >= 0 && up_t[(m_) * 16 + srow[u]] != 0.f)                                   \
+            v = *reinterpret_cast<const f32x4*>(gbase + (goff[u] + (m_) * m_delta));            \
         pre[u] = v;                                                                             \
     }
 #define DCS_STORE_A(buf_)                                                                       \
     _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                             \
-        if (tid + u * kThreads < slots) {                                                       \
-            float* d = As + (buf_) * kABuf + dst[u];                                            \
-            *reinterpret_cast<float2*>(d) = make_float2(pre[u][0], pre[u][1]);                  \
-            *reinterpret_cast<float2*>(d + 2) = make_float2(pre[u][2], pre[u][3]);              \
-        }                                                                                       \
+        if (srow[u] >= 0) *reinterpret_cast<f32x4*>(As + (buf_) * kABuf + dst[u]) = pre[u];     \
     }
 
     DCS_LOAD_A(0)
-    DCS_STORE_A(0)
-    __syncthreads();
-
-    for (int m = 0; m < a.mmax; ++m) {
-        const bool more = m + 1 < a.mmax;
-        if (more) DCS_LOAD_A(m + 1)  // in flight while this m's MFMAs and epilogue run
-        const float* Ab = As + (m & 1) * kABuf;
-
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.prio) __builtin_amdgcn_s_setprio(1);  // matrix phase outranks the other waves' epilogues
+    for (int m = 0; m < mmax; ++m) {
+        // buffer m&1 was last read in iteration m-2; the barrier of iteration m-1 fences those reads
+        DCS_STORE_A(m & 1)
+        __syncthreads();
+        if (m + 1 < mmax) DCS_LOAD_A(m + 1)
+        if (!live) continue;
+        const float* Ab = As + (m & 1) * kABuf + fi * AS + 12 * kq;
+        f32x4 acc[NBR][CBW];
 #pragma unroll
-        for (int q = 0; q < NQ_MAX; ++q) {
-            const float b = breg[q];
-            const int off = fi * as + 4 * q + kq;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[off], b, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[16 * as + off], b, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[32 * as + off], b, acc2, 0, 0, 0);
-        }
-        if (a.prio) __builtin_amdgcn_s_setprio(0);
-
-        // ---- bias + rectify (separate_dsd.py:234), soft mask (:258-271), cross-fade (util.py:321-325)
+        for (int s = 0; s < NBR; ++s)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = kq * 4 + e;
-            const int j0 = meta_j0[i];
-            const int j = j0 - m * st;
-            const bool valid = (j0 >= 0) && (j >= 0) && ((int64_t)meta_k0[i] + m < n);
-            // output channels 0..3 use branches 0,1,2,1
-            const float p0 = fmaxf(acc0[e] + bias0, 0.f);
-            const float p1 = fmaxf(acc1[e] + bias1, 0.f);
-            const float p2 = fmaxf(acc2[e] + bias2, 0.f);
-            const float p3 = fmaxf(acc1[e] + bias3, 0.f);
-            float v0, v1, v2, v3;
-            if (a.mask_mode == 0) {  // convention A: m_i = s_i / sum(s), s_i = p_i + eps*r
-                const float s0 = p0 + eps_r, s1 = p1 + eps_r, s2 = p2 + eps_r, s3 = p3 + eps_r;
-                const float den = ((s0 + s1) + s2) + s3;             // >= 4*eps*r: never zero or denormal
-                const float w = __builtin_amdgcn_rcpf(den) * mixv[e];  // one v_rcp_f32 (1 ulp) for 4 masks
-                v0 = s0 * w; v1 = s1 * w; v2 = s2 * w; v3 = s3 * w;
-            } else if (a.mask_mode == 1) {  // convention B: m_i = p_i / (sum(p) + eps*r)
-                const float den = (((p0 + p1) + p2) + p3) + eps_r;
-                const float w = __builtin_amdgcn_rcpf(den) * mixv[e];
-                v0 = p0 * w; v1 = p1 * w; v2 = p2 * w; v3 = p3 * w;
-            } else {  // raw network output (get_output)
-                v0 = p0; v1 = p1; v2 = p2; v3 = p3;
+            for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A fragments of K-quarter kq: channels 12kq .. 12kq+11 (three float4) and channel 48+kq
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 af[NBR];
+#pragma unroll
+            for (int s = 0; s < NBR; ++s) {
+                if (g < 3)
+                    af[s] = *reinterpret_cast<const f32x4*>(Ab + s * 16 * AS + 4 * g);
+                else
+                    af[s][0] = As[(m & 1) * kABuf + (s * 16 + fi) * AS + 48 + kq];
             }
-            if (m == 0) {
-                if (valid) { res[0][e] = v0; res[1][e] = v1; res[2][e] = v2; res[3][e] = v3; }
-            } else if (valid) {
-                const float up = a.rise[j], down = a.rise[ov - 1 - j];
-                res[0][e] = down * res[0][e] + up * v0;
-                res[1][e] = down * res[1][e] + up * v1;
-                res[2][e] = down * res[2][e] + up * v2;
-                res[3][e] = down * res[3][e] + up * v3;
+#pragma unroll
+            for (int t = 0; t < (g < 3 ? 4 : 1); ++t) {
+                const int q = 4 * g + t;
+#pragma unroll
+                for (int s = 0; s < NBR; ++s)
+#pragma unroll
+                    for (int cb = 0; cb < CBW; ++cb)
+                        acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][t], breg[cb][q], acc[s][cb], 0, 0, 0);
             }
         }
-        if (more) {
-            DCS_STORE_A((m + 1) & 1)  // the other buffer: last read in iteration m-1, fenced by its barrier
-            __syncthreads();
+        // bias + rectify (separate_dsd.py:234), soft mask (:258-271), cross-fade (util.py:321-325) as one
+        // fused multiply-add per source: res = down*res + s_c * (rcp(den) * mix * up), on (e, e+1) pairs.
+        const f32x4 up4 = *reinterpret_cast<const f32x4*>(up_t + m * 16 + kq * 4);
+        const f32x4 down4 = *reinterpret_cast<const f32x4*>(down_t + m * 16 + kq * 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 up = {up4[2 * h], up4[2 * h + 1]};
+            const f32x2 down = {down4[2 * h], down4[2 * h + 1]};
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                const f32x2 x0 = {acc[0][cb][2 * h], acc[0][cb][2 * h + 1]};
+                const f32x2 x1 = {acc[1][cb][2 * h], acc[1][cb][2 * h + 1]};
+                const f32x2 x2 = {acc[2][cb][2 * h], acc[2][cb][2 * h + 1]};
+                const f32x2 zero = {0.f, 0.f};
+                const f32x2 p0 = __builtin_elementwise_max(x0 + bias0, zero);
+                const f32x2 p1 = __builtin_elementwise_max(x1 + bias1, zero);
+                const f32x2 p2 = __builtin_elementwise_max(x2 + bias2, zero);
+                const f32x2 p3 = __builtin_elementwise_max(x1 + bias3, zero);  // 4th source: branch fc12 again (:228)
+                const f32x2 mu = f32x2{mixv[cb][2 * h], mixv[cb][2 * h + 1]} * up;
+                f32x2 s0 = p0, s1 = p1, s2 = p2, s3 = p3, w = up;
+                if (MODE == 0) {  // convention A: m_i = s_i / sum(s), s_i = p_i + eps*r
+                    s0 += eps_r; s1 += eps_r; s2 += eps_r; s3 += eps_r;
+                    const f32x2 den = ((s0 + s1) + s2) + s3;
+                    w = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])} * mu;
+                } else if (MODE == 1) {  // convention B: m_i = p_i / (sum(p) + eps*r)
+                    const f32x2 den = (((p0 + p1) + p2) + p3) + eps_r;
+                    w = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])} * mu;
+                }
+                const f32x2 o0 = __builtin_elementwise_fma(down, f32x2{res[cb][0][2 * h], res[cb][0][2 * h + 1]}, s0 * w);
+                const f32x2 o1 = __builtin_elementwise_fma(down, f32x2{res[cb][1][2 * h], res[cb][1][2 * h + 1]}, s1 * w);
+                const f32x2 o2 = __builtin_elementwise_fma(down, f32x2{res[cb][2][2 * h], res[cb][2][2 * h + 1]}, s2 * w);
+                const f32x2 o3 = __builtin_elementwise_fma(down, f32x2{res[cb][3][2 * h], res[cb][3][2 * h + 1]}, s3 * w);
+                res[cb][0][2 * h] = o0[0]; res[cb][0][2 * h + 1] = o0[1];
+                res[cb][1][2 * h] = o1[0]; res[cb][1][2 * h + 1] = o1[1];
+                res[cb][2][2 * h] = o2[0]; res[cb][2][2 * h + 1] = o2[1];
+                res[cb][3][2 * h] = o3[0]; res[cb][3][2 * h + 1] = o3[1];
+            }
         }
     }
 #undef DCS_LOAD_A
@@ -355,193 +424,18 @@ __global__ __launch_bounds__(kThreads) void final_kernel(const DsdFinalArgs a) {
             const int64_t r = row0 + kq * 4 + e;
             if (r < a.rows) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a.out[c * a.out_src_stride + r * a.out_ld + col] = res[c][e];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Many-rows variant of final_kernel: one INDEPENDENT wave per 16 rows x (16*CBW) bins, no workgroup
-// barrier.  (PMC on the cooperative kernel: 4 waves meeting every 39 MFMAs leave the matrix pipe idle
-// ~55 % of the time.)  Each A fragment read from the wave-private LDS tile feeds CBW MFMAs; with CBW = 2
-// the 65 (F=1025) / 33 (F=513) column blocks split into 33 / 17 groups with one block of padding.
-// A wave's LDS operations are performed in program order, so staging the next covering tile's rows after
-// the current MFMAs needs no fence.  Blocks are renumbered so that the column groups of one row group run
-// on the same XCD (block b runs on XCD b % 8) and share its L2 for the G rows.
-// ------------------------------------------------------------------------------------------------
-template <bool FOLD, int CBW>
-__global__ __launch_bounds__(64, 2) void final_wave_kernel(const DsdFinalArgs a, int n_colg) {
-    constexpr int NBR = 3, NQ = 13, AS = 54, SLOTS = NBR * 16 * NQ, PER = (SLOTS + 63) / 64;
-    __shared__ __attribute__((aligned(16))) float As[NBR * 16 * AS];
-    __shared__ int meta_k0[16];
-    __shared__ int meta_j0[16];
-    const int lane = threadIdx.x;
-    const int fi = lane & 15, kq = lane >> 4;
-    // XCD-aware renumbering (bijective for any grid size)
-    const unsigned nwg = gridDim.x, bid = blockIdx.x;
-    const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int64_t row0 = (int64_t)(swz / n_colg) * 16;
-    const int col0 = (int)(swz % n_colg) * (16 * CBW);
-    const int CI = a.CI;
-    const int tc = a.tc, st = a.st, ov = a.ov;
-    const int64_t n = a.n;
-
-    if (lane < 16) {
-        const int64_t r = row0 + lane;
-        int k0 = 0, j0 = -1;
-        if (r < a.rows) {
-            if (FOLD) {
-                int64_t kk = (r < ov) ? 0 : (r - ov) / st;
-                if (kk > n - 1) kk = n - 1;
-                const int64_t jj = r - kk * st;
-                if (jj < tc) {
-                    k0 = (int)kk;
-                    j0 = (int)jj;
-                }
-            } else {
-                k0 = (int)(r / tc);
-                j0 = (int)(r - (int64_t)k0 * tc);
-            }
-        }
-        meta_k0[lane] = k0;
-        meta_j0[lane] = j0;
-    }
-
-    float breg[CBW][NQ];
-#pragma unroll
-    for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) breg[cb][q] = a.Bw[(int64_t)(4 * q + kq) * a.ldb + col0 + cb * 16 + fi];
-    float mixv[CBW][4];
-#pragma unroll
-    for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int64_t r = row0 + kq * 4 + e;
-            const int col = col0 + cb * 16 + fi;
-            mixv[cb][e] = (r < a.rows && col < a.F) ? a.mix_scale * a.mix[r * a.mix_ld + col] : 0.f;
-        }
-    const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
-    const float eps_r = 5e-19f;
-    float res[CBW][4][4];
-#pragma unroll
-    for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) res[cb][c][e] = 0.f;
-
-    // staging plan (see final_kernel): slot -> (branch s, row i, float4 c4).  Kept compact (32-bit offsets
-    // relative to the first row's tile, packed row state) so that two waves fit on a SIMD.
-    const int m_delta = (NBR * tc - st) * CI;
-    const int kbase = meta_k0[0];
-    const float* gbase = a.G + (int64_t)kbase * NBR * tc * CI;
-    int dst[PER], off[PER], kj[PER];  // kj = (k0 - kbase) << 8 | (j0 + 1); 0 = row not covered
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int idx = lane + u * 64;
-        const int s = idx / (16 * NQ);
-        const int rem = idx - s * 16 * NQ;
-        const int i = rem / NQ, c4 = rem - i * NQ;
-        const bool in = idx < SLOTS && meta_j0[i] >= 0;
-        const int dk = in ? meta_k0[i] - kbase : 0;
-        const int j0 = in ? meta_j0[i] : -1;
-        kj[u] = in ? ((dk << 8) | (j0 + 1)) : 0;
-        dst[u] = (idx < SLOTS) ? (s * 16 + i) * AS + c4 * 4 : -1;
-        off[u] = ((dk * NBR + s) * tc + (j0 < 0 ? 0 : j0)) * CI + c4 * 4;
-    }
-    f32x4 pre[PER];
-#define DCS_LOAD_A(m_)                                                                          \
-    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                           \
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                    \
-        const int j0p = kj[u] & 255;                                                            \
-        if (j0p > 0 && j0p - 1 - (m_) * st >= 0 && (int64_t)kbase + (kj[u] >> 8) + (m_) < n)    \
-            v = *reinterpret_cast<const f32x4*>(gbase + off[u] + (m_) * m_delta);               \
-        pre[u] = v;                                                                             \
-    }
-#define DCS_STORE_A()                                                                           \
-    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                           \
-        if (dst[u] >= 0) {                                                                      \
-            float* d = As + dst[u];                                                             \
-            *reinterpret_cast<float2*>(d) = make_float2(pre[u][0], pre[u][1]);                  \
-            *reinterpret_cast<float2*>(d + 2) = make_float2(pre[u][2], pre[u][3]);              \
-        }                                                                                       \
-    }
-    DCS_LOAD_A(0)
-    for (int m = 0; m < a.mmax; ++m) {
-        DCS_STORE_A()  // after the previous iteration's fragment reads (program order within the wave)
-        if (m + 1 < a.mmax) DCS_LOAD_A(m + 1)
-        f32x4 acc[NBR][CBW];
-#pragma unroll
-        for (int s = 0; s < NBR; ++s)
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int off = fi * AS + 4 * q + kq;
-            const float a0 = As[off], a1 = As[16 * AS + off], a2 = As[32 * AS + off];
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) {
-                acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, breg[cb][q], acc[0][cb], 0, 0, 0);
-                acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, breg[cb][q], acc[1][cb], 0, 0, 0);
-                acc[2][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, breg[cb][q], acc[2][cb], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = kq * 4 + e;
-            const int j0 = meta_j0[i];
-            const int j = j0 - m * st;
-            const bool valid = (j0 >= 0) && (j >= 0) && ((int64_t)meta_k0[i] + m < n);
-            float up = 0.f, down = 0.f;
-            if (m > 0 && valid) {
-                up = a.rise[j];
-                down = a.rise[ov - 1 - j];
-            }
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) {
-                const float p0 = fmaxf(acc[0][cb][e] + bias0, 0.f);
-                const float p1 = fmaxf(acc[1][cb][e] + bias1, 0.f);
-                const float p2 = fmaxf(acc[2][cb][e] + bias2, 0.f);
-                const float p3 = fmaxf(acc[1][cb][e] + bias3, 0.f);
-                float v0, v1, v2, v3;
-                if (a.mask_mode == 0) {
-                    const float s0 = p0 + eps_r, s1 = p1 + eps_r, s2 = p2 + eps_r, s3 = p3 + eps_r;
-                    const float den = ((s0 + s1) + s2) + s3;
-                    const float w = __builtin_amdgcn_rcpf(den) * mixv[cb][e];
-                    v0 = s0 * w; v1 = s1 * w; v2 = s2 * w; v3 = s3 * w;
-                } else if (a.mask_mode == 1) {
-                    const float den = (((p0 + p1) + p2) + p3) + eps_r;
-                    const float w = __builtin_amdgcn_rcpf(den) * mixv[cb][e];
-                    v0 = p0 * w; v1 = p1 * w; v2 = p2 * w; v3 = p3 * w;
-                } else {
-                    v0 = p0; v1 = p1; v2 = p2; v3 = p3;
-                }
-                if (m == 0) {
-                    if (valid) { res[cb][0][e] = v0; res[cb][1][e] = v1; res[cb][2][e] = v2; res[cb][3][e] = v3; }
-                } else if (valid) {
-                    res[cb][0][e] = down * res[cb][0][e] + up * v0;
-                    res[cb][1][e] = down * res[cb][1][e] + up * v1;
-                    res[cb][2][e] = down * res[cb][2][e] + up * v2;
-                    res[cb][3][e] = down * res[cb][3][e] + up * v3;
-                }
-            }
-        }
-    }
-#undef DCS_LOAD_A
-#undef DCS_STORE_A
-#pragma unroll
-    for (int cb = 0; cb < CBW; ++cb) {
-        const int col = col0 + cb * 16 + fi;
-        if (col < a.F) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t r = row0 + kq * 4 + e;
-                if (r < a.rows) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) a.out[c * a.out_src_stride + r * a.out_ld + col] = res[cb][c][e];
+                for (int c = 0; c < 4; ++c) {
+                    float* op = a.out + c * a.out_src_stride + r * a.out_ld + col;
+                    if constexpr (CBW == 2) {
+                        if (vec && col + 1 < a.F) {
+                            *reinterpret_cast<f32x2*>(op) = f32x2{res[0][c][e], res[1][c][e]};
+                        } else {
+                            op[0] = res[0][c][e];
+                            if (col + 1 < a.F) op[1] = res[1][c][e];
+                        }
+                    } else {
+                        op[0] = res[0][c][e];
+                    }
                 }
             }
         }
@@ -579,30 +473,40 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float*
     return DCS_OK;
 }
 
-int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a_in, bool fold) {
-    if (a_in.rows <= 0) return DCS_OK;
-    if (a_in.CI != 52) DCS_FAIL(DCS_EUNSUPPORTED, "final: built for 50 conv1 filters (CI=52), got CI=%d", a_in.CI);
-    // DCS_FINAL_KERNEL=2 selects the barrier-free wave-tile variant (A/B experiments)
-    static const int force = getenv("DCS_FINAL_KERNEL") ? atoi(getenv("DCS_FINAL_KERNEL")) : 0;  // 1 coop, 2 wave
-    static const int prio = getenv("DCS_FINAL_PRIO") ? atoi(getenv("DCS_FINAL_PRIO")) : 0;
-    DsdFinalArgs a = a_in;
-    a.prio = prio;
-    dim3 grid((unsigned)(dcs_cdiv(a.rows, 16) * (a.ldb / 64)));
+int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
+    if (a.rows <= 0) return DCS_OK;
+    if (a.CI != 52) DCS_FAIL(DCS_EUNSUPPORTED, "final: built for 50 conv1 filters (CI=52), got CI=%d", a.CI);
+    if (a.mmax < 1 || a.mmax > 16) DCS_FAIL(DCS_EUNSUPPORTED, "final: %d covering tiles per frame (max 16)", a.mmax);
+    // workgroup = 16 rows x 128 bins (two column blocks per wave); with few rows (the 32-tile step has 12 row
+    // groups) 16 x 64 gives twice the workgroups and half the work in each: 32 tiles 17.8 vs 19.1 us
+    const int64_t n_rg = dcs_cdiv(a.rows, 16);
+    static const int force = getenv("DCS_FINAL_CBW") ? atoi(getenv("DCS_FINAL_CBW")) : 0;
+    const int cbw = force ? force : (n_rg * ((a.F + 127) / 128) >= 3 * (int64_t)ctx->n_cu ? 2 : 1);
+    const int n_colg = (a.F + 64 * cbw - 1) / (64 * cbw);
+    if (a.ldb < n_colg * 64 * cbw || (a.ldb & 1))
+        DCS_FAIL(DCS_EINVAL, "final: weight pitch %d < %d", a.ldb, n_colg * 64 * cbw);
+    const int64_t n_wg = n_rg * n_colg;
+    if (n_wg > 0x7fffffff) DCS_FAIL(DCS_EUNSUPPORTED, "final: %lld workgroups", (long long)n_wg);
     DcsTimer tm(ctx, DCS_TAG_FINAL);
-    constexpr int kCBW = 2;  // column blocks per wave: 3 needs > 256 registers with the prefetch set
-    const int n_colg = (a.F + 16 * kCBW - 1) / (16 * kCBW);
-    const int64_t n_waves = (int64_t)dcs_cdiv(a.rows, 16) * n_colg;
-    // measured at 4096 tiles (MI355X): cooperative 0.609 ms, wave-tile 0.649 ms -> cooperative is the default
-    const bool wave_variant = force == 2 && n_colg * 16 * kCBW <= a.ldb;
-    if (wave_variant) {
-        if (fold)
-            hipLaunchKernelGGL((final_wave_kernel<true, kCBW>), dim3((unsigned)n_waves), dim3(64), 0, ctx->stream, a, n_colg);
-        else
-            hipLaunchKernelGGL((final_wave_kernel<false, kCBW>), dim3((unsigned)n_waves), dim3(64), 0, ctx->stream, a, n_colg);
-    } else if (fold)
-        hipLaunchKernelGGL((final_kernel<true, 13>), grid, dim3(kThreads), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((final_kernel<false, 13>), grid, dim3(kThreads), 0, ctx->stream, a);
+#define DCS_FINAL(FOLD_, MODE_)                                                                                      \
+    do {                                                                                                             \
+        if (cbw == 2)                                                                                                \
+            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 2>), dim3((unsigned)n_wg), dim3(kThreads), 0, ctx->stream, a, \
+                               n_colg);                                                                              \
+        else                                                                                                         \
+            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 1>), dim3((unsigned)n_wg), dim3(kThreads), 0, ctx->stream, a, \
+                               n_colg);                                                                              \
+    } while (0)
+    if (fold) {
+        if (a.mask_mode == 0) DCS_FINAL(true, 0);
+        else if (a.mask_mode == 1) DCS_FINAL(true, 1);
+        else DCS_FINAL(true, 2);
+    } else {
+        if (a.mask_mode == 0) DCS_FINAL(false, 0);
+        else if (a.mask_mode == 1) DCS_FINAL(false, 1);
+        else DCS_FINAL(false, 2);
+    }
+#undef DCS_FINAL
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;

@@ -73,7 +73,7 @@ struct dcs_model {
     int arch = 0, C = 1, tc = 30, F = 0;
     Dims d;
     // ---- DSD packed weights
-    int CI = 0, CP = 0, K1 = 0, F64 = 0, hid64 = 0, nd = 0, nd64 = 0;
+    int CI = 0, CP = 0, K1 = 0, Fpad = 0, hid64 = 0, nd = 0, nd64 = 0;
     int d2_ng = 4, d2_gs = 0, d2_gcols = 0;  // transposed conv2: channel groups, channels per group, padded columns
     float *B1 = nullptr, *bias1 = nullptr, *B2 = nullptr, *bias2 = nullptr, *Bfc = nullptr, *biasfc = nullptr;
     float *Bd = nullptr, *biasd = nullptr, *Bw2 = nullptr, *Bfin = nullptr, *bout = nullptr;
@@ -128,7 +128,7 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     m->CI = CI;
     m->CP = CP;
     m->K1 = (int)dcs_round_up(F, 4);
-    m->F64 = (int)dcs_round_up(F, 64);
+    m->Fpad = (int)dcs_round_up(F, 128);  // pitch of the final kernel's weights: whole 128-bin workgroups
     m->d2_ng = 4;
     m->d2_gs = (CI + m->d2_ng - 1) / m->d2_ng;
     m->d2_gcols = (int)dcs_round_up(m->d2_gs * d.kh2, 16);
@@ -183,9 +183,9 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
                 Bw2[(size_t)co * ldw2 + (ci / m->d2_gs) * m->d2_gcols + (ci % m->d2_gs) * kh + dt] =
                     W2[((size_t)co * d.nf1 + ci) * kh + (kh - 1 - dt)];
     // transposed conv1: Bfin[c][f] = W1[c,0,0,F-1-f]
-    std::vector<float> Bfin((size_t)CI * m->F64, 0.f);
+    std::vector<float> Bfin((size_t)CI * m->Fpad, 0.f);
     for (int c = 0; c < d.nf1; ++c)
-        for (int f = 0; f < F; ++f) Bfin[(size_t)c * m->F64 + f] = W1[(size_t)c * F + (F - 1 - f)];
+        for (int f = 0; f < F; ++f) Bfin[(size_t)c * m->Fpad + f] = W1[(size_t)c * F + (F - 1 - f)];
     std::vector<float> bout(P[8 + 2 * d.n_fc].begin(), P[8 + 2 * d.n_fc].end());
 
     DCS_CHECK(upload(&m->B1, B1));
@@ -276,7 +276,7 @@ int dsd_forward_tiles(dcs_model* m, const float* tiles, int64_t n, int mask_mode
     DCS_CHECK(dsd_encode(m, tiles, F, vec, 1.f, n, tc, false, w));
     DCS_CHECK(ensure_rise(m, 1));
     DsdFinalArgs a{};
-    a.G = w.G; a.Bw = m->Bfin; a.ldb = m->F64; a.bias = m->bout;
+    a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
     a.mix = tiles; a.mix_ld = F; a.mix_scale = 1.f;
     a.out = out; a.out_src_stride = n * tc * (int64_t)F; a.out_ld = F;
     a.rise = m->rise_d; a.n = n; a.rows = n * tc; a.tc = tc; a.ov = 0; a.st = tc;
@@ -437,7 +437,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
-        a.G = w.G; a.Bw = m->Bfin; a.ldb = m->F64; a.bias = m->bout;
+        a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
         a.mix = mag; a.mix_ld = ld; a.mix_scale = scale;
         a.out = sep; a.out_src_stride = T * ld; a.out_ld = ld;
         a.rise = m->rise_d; a.n = n; a.rows = T; a.tc = tc; a.ov = ov; a.st = st;
