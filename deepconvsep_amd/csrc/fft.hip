@@ -419,7 +419,7 @@ int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, dou
 int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase,
                                 const float2* unit, int64_t ld, int64_t T, int n_src, float pre_div, float* audio,
                                 int64_t n_out) {
-    if (dcs_fft_wave_supported(p)) {
+    if (dcs_fft_wave_inverse_supported(p)) {
         if (T <= 0 || n_src <= 0 || n_out <= 0) return DCS_OK;
         DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
         const int rc = dcs_fft_wave_inverse(p, mag, src_stride, phase, unit, ld, T, n_src, pre_div, audio, n_out);

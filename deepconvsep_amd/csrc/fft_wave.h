@@ -3,6 +3,7 @@
 #include "dcs_internal.h"
 
 bool dcs_fft_wave_supported(const dcs_stft* p);
+bool dcs_fft_wave_inverse_supported(const dcs_stft* p);  // additionally: hop | N, hop even
 int dcs_fft_wave_forward(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
                          int64_t rows_out, int64_t T);
 int dcs_fft_wave_inverse(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, const float2* unit,

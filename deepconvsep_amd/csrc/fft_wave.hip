@@ -5,10 +5,18 @@
 // 64-lane wavefront owns one frame: M = N/2 complex points, M/64 = 8/16/32 points per lane, three
 // Stockham passes of radix 16/16/4 (M=1024), 16/16/8 (M=2048), 8/8/8 (M=512) done in registers and
 // exchanged through a per-wave LDS buffer.  A wave's LDS operations are performed in program order, so
-// no barrier is needed between passes; a 4-wave workgroup transforms 4 frames independently and only
-// meets once to stage the shared twiddle table (and, in the inverse, to hand the finished frames to
-// the overlap-add).  The exchange buffer is indexed through pad(i) = i + i/32 so that the stride-R
-// stores of the first pass spread over the banks.
+// no barrier is needed between passes; a 4-wave workgroup transforms 4 frames independently.
+//
+// These kernels are VALU-issue bound (PMC: ~3-4 k wave instructions per frame, HBM far from busy), so
+// the code is organised around the instruction count:
+//   * complex values are (re, im) register pairs and every butterfly is packed fp32 math
+//     (v_pk_add/mul/fma_f32); multiplications by +-i and complex products use the op_sel / neg
+//     operand modifiers instead of moving halves around (c_add_i, c_mul below);
+//   * the exchange buffer is indexed through pad(i) = i + i/32 (bank spread for the stride-R stores);
+//     every access is written as pad(lane part) + pad(compile-time part) -- exact for the index sets used
+//     here, see cpad() -- so the address of each ds_read/ds_write is one register plus an immediate;
+//   * the pass twiddles depend only on the lane, not on the frame: they are fetched once per wave into
+//     registers and reused for every frame the wave transforms.
 //
 // Semantics are those of fft.hip (reference transform.py:277-396); the host side picks this file's
 // kernels when the plan is float32 with N in {1024, 2048, 4096} and the block-level ones otherwise.
@@ -20,66 +28,90 @@
 
 namespace {
 
-__device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
+typedef float cx __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
 
-__device__ __forceinline__ float2 mk2(float x, float y) {
-    float2 r;
-    r.x = x;
-    r.y = y;
+__device__ __forceinline__ cx mk(float x, float y) { return cx{x, y}; }
+__device__ __forceinline__ cx ldc(const float2* p) { return *reinterpret_cast<const cx*>(p); }
+__device__ __forceinline__ void stc(float2* p, cx v) { *reinterpret_cast<cx*>(p) = v; }
+
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cx c_add_i(cx a, cx b) {
+    cx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return mk2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return mk2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return mk2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-
-// exp(DIR * 2 pi i j / N), 0 <= j < N, from the half-circle table tw[0..M] = exp(-2 pi i j / N), N = 2M
+// a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cx c_sub_i(cx a, cx b) {
+    cx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ cx c_add_conj(cx a, cx b) {
+    cx r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cx c_sub_conj(cx a, cx b) {
+    cx r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x): two packed instructions
+__device__ __forceinline__ cx c_mul(cx a, cx w) {
+    cx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
+__device__ __forceinline__ cx c_mul_conj(cx a, cx w) {
+    cx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// DIR < 0: forward transform, multiply by the table value w = exp(-i theta); DIR > 0: by its conjugate
 template <int DIR>
-__device__ __forceinline__ float2 tw_at(const float2* tw, int j, int M) {
-    float2 w;
-    if (j <= M) {
-        w = tw[j];
-    } else {
-        w = tw[j - M];
-        w.x = -w.x;
-        w.y = -w.y;
-    }
-    if (DIR > 0) w.y = -w.y;
-    return w;
+__device__ __forceinline__ cx c_tw(cx a, cx w) { return DIR < 0 ? c_mul(a, w) : c_mul_conj(a, w); }
+
+__device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
+// pad(l + c) == pad(l) + cpad(c) whenever (l & 31) + (c & 31) < 32; every (lane part, constant part) pair in
+// this file satisfies it: the constant parts are multiples of 64, or the lane part is a multiple of the radix
+// (a power of two <= 16... 32) while the constant's low bits stay below it (derivations at the call sites).
+__device__ __forceinline__ constexpr int cpad(int c) { return c + (c >> 5); }
+
+// exp(-2 pi i j / N), 0 <= j < N, from the half-circle table tw[0..M] (N = 2M)
+__device__ __forceinline__ cx tw_fwd(const float2* tw, int j, int M) {
+    const cx w = ldc(tw + (j <= M ? j : j - M));
+    return j <= M ? w : -w;
 }
 
 template <int DIR>
-__device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
-    const float2 a02 = cadd(a, c), s02 = csub(a, c), a13 = cadd(b, d), s13 = csub(b, d);
-    const float2 ym = mk2(s02.x + s13.y, s02.y - s13.x);  // s02 - i*s13
-    const float2 yp = mk2(s02.x - s13.y, s02.y + s13.x);  // s02 + i*s13
-    a = cadd(a02, a13);
-    c = csub(a02, a13);
+__device__ __forceinline__ void dft4(cx& a, cx& b, cx& c, cx& d) {
+    const cx a02 = a + c, s02 = a - c, a13 = b + d, s13 = b - d;
+    const cx ym = c_sub_i(s02, s13), yp = c_add_i(s02, s13);
+    a = a02 + a13;
+    c = a02 - a13;
     b = (DIR < 0) ? ym : yp;
     d = (DIR < 0) ? yp : ym;
 }
 
 // multiply by exp(DIR * 2 pi i m / 16)
 template <int DIR, int m>
-__device__ __forceinline__ float2 rot16(float2 v) {
+__device__ __forceinline__ cx rot16(cx v) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
     constexpr int mm = m & 15;
-    float cx, sx;  // exp(-2 pi i mm/16) = cx - i*sx ... expressed as (c, s) with s = sin(2 pi mm / 16)
     if (mm == 0) return v;
-    if (mm == 1) { cx = C1; sx = S1; }
-    else if (mm == 2) { cx = H; sx = H; }
-    else if (mm == 3) { cx = S1; sx = C1; }
-    else if (mm == 4) { cx = 0.f; sx = 1.f; }
-    else if (mm == 6) { cx = -H; sx = H; }
-    else if (mm == 9) { cx = -C1; sx = -S1; }
-    else { cx = 1.f; sx = 0.f; }
-    // forward: multiply by (cx, -sx); inverse: (cx, +sx)
-    const float wy = (DIR < 0) ? -sx : sx;
-    return mk2(v.x * cx - v.y * wy, v.x * wy + v.y * cx);
+    if (mm == 4) return DIR < 0 ? c_sub_i(mk(0.f, 0.f), v) : c_add_i(mk(0.f, 0.f), v);
+    // table value exp(-2 pi i mm / 16) = (cos, -sin)
+    const cx w = mm == 1 ? mk(C1, -S1) : mm == 2 ? mk(H, -H) : mm == 3 ? mk(S1, -C1) : mm == 6 ? mk(-H, -H) : mk(-C1, S1) /* 9 */;
+    return c_tw<DIR>(v, w);
 }
 
 // In-register DFTs.  Input v[n], n = 0..R-1; output X[k] is left at v[perm(k)].
 template <int DIR>
-__device__ __forceinline__ void dft16(float2* v) {
+__device__ __forceinline__ void dft16(cx* v) {
     // n = 4a + b: DFT over a for each b
 #pragma unroll
     for (int b = 0; b < 4; ++b) dft4<DIR>(v[b], v[4 + b], v[8 + b], v[12 + b]);
@@ -100,7 +132,7 @@ __device__ __forceinline__ void dft16(float2* v) {
 __device__ __forceinline__ constexpr int perm16(int k) { return 4 * (k & 3) + (k >> 2); }
 
 template <int DIR>
-__device__ __forceinline__ void dft8(float2* v) {
+__device__ __forceinline__ void dft8(cx* v) {
     // n = 2a + b (a = 0..3, b = 0..1): DFT over a for each b
     dft4<DIR>(v[0], v[2], v[4], v[6]);
     dft4<DIR>(v[1], v[3], v[5], v[7]);
@@ -111,15 +143,15 @@ __device__ __forceinline__ void dft8(float2* v) {
     // 2-point DFT over b: v[2c + d] = X[c + 4d]
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float2 t = v[2 * c];
-        v[2 * c] = cadd(t, v[2 * c + 1]);
-        v[2 * c + 1] = csub(t, v[2 * c + 1]);
+        const cx t = v[2 * c];
+        v[2 * c] = t + v[2 * c + 1];
+        v[2 * c + 1] = t - v[2 * c + 1];
     }
 }
 __device__ __forceinline__ constexpr int perm8(int k) { return 2 * (k & 3) + (k >> 2); }
 
 template <int R, int DIR>
-__device__ __forceinline__ void dftR(float2* v) {
+__device__ __forceinline__ void dftR(cx* v) {
     if (R == 16) dft16<DIR>(v);
     else if (R == 8) dft8<DIR>(v);
     else dft4<DIR>(v[0], v[1], v[2], v[3]);
@@ -127,78 +159,114 @@ __device__ __forceinline__ void dftR(float2* v) {
 template <int R>
 __device__ __forceinline__ constexpr int permR(int k) { return R == 16 ? perm16(k) : (R == 8 ? perm8(k) : k); }
 
-// One Stockham pass of radix R over the wave's M = 64*P points.  v holds the pass input
-// v[b*R + t] = x[j_b + t*M/R], j_b = lane + 64 b; the output goes to buf (padded, wave-private):
-// y[(j/Ns)*Ns*R + (j%Ns) + t*Ns].
-template <int R, int P, int DIR>
-__device__ __forceinline__ void fft_pass(float2 (&v)[P], int Ns, int lane, const float2* twl, float2* buf) {
-    constexpr int NB = P / R;
-    constexpr int M = 64 * P;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int j = lane + 64 * b;
-        const int k = j & (Ns - 1);
-        if (Ns > 1) {
-            const int step = ((2 * M) / R / Ns) * k;
-#pragma unroll
-            for (int t = 1; t < R; ++t) v[b * R + t] = cmul(v[b * R + t], tw_at<DIR>(twl, t * step, M));
-        }
-        dftR<R, DIR>(&v[b * R]);
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int j = lane + 64 * b;
-        const int k = j & (Ns - 1);
-        const int d = (j - k) * R + k;
-#pragma unroll
-        for (int t = 0; t < R; ++t) buf[pad(d + t * Ns)] = v[b * R + permR<R>(t)];
-    }
-}
-
-template <int R, int P>
-__device__ __forceinline__ void load_pass(float2 (&v)[P], int lane, const float2* buf) {
-    constexpr int NB = P / R;
-    constexpr int stride = 64 * NB;  // M / R
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int t = 0; t < R; ++t) v[b * R + t] = buf[pad(lane + 64 * b + t * stride)];
-}
-
 template <int LOG2M> struct Plan;
 template <> struct Plan<9> { static constexpr int R1 = 8, R2 = 8, R3 = 8; };
 template <> struct Plan<10> { static constexpr int R1 = 16, R2 = 16, R3 = 4; };
 template <> struct Plan<11> { static constexpr int R1 = 16, R2 = 16, R3 = 8; };
 
-// three passes; on entry v holds the first-pass input (index map of load_pass<R1>), on exit the
-// natural-order result is in buf[pad(k)]
-template <int LOG2M, int DIR>
-__device__ __forceinline__ void fft_wave(float2 (&v)[(1 << LOG2M) / 64], int lane, const float2* twl, float2* buf) {
-    constexpr int P = (1 << LOG2M) / 64;
+// Per-lane pass twiddles (table values exp(-i theta)), constant over the frames a wave transforms.
+// Pass 2 (Ns = R1): k = lane mod R1 for every block b.  Pass 3 (Ns = R1 R2): k = lane + 64 b.  For M = 2048
+// the 28 pass-3 twiddles would cost 56 registers on top of 64 for the data: they stay in the LDS table.
+template <int LOG2M>
+struct WaveTw {
     using PL = Plan<LOG2M>;
-    fft_pass<PL::R1, P, DIR>(v, 1, lane, twl, buf);
-    load_pass<PL::R2, P>(v, lane, buf);
-    fft_pass<PL::R2, P, DIR>(v, PL::R1, lane, twl, buf);
-    load_pass<PL::R3, P>(v, lane, buf);
-    fft_pass<PL::R3, P, DIR>(v, PL::R1 * PL::R2, lane, twl, buf);
+    static constexpr int M = 1 << LOG2M, P = M / 64, NB3 = P / PL::R3;
+    static constexpr bool REG3 = LOG2M <= 10;
+    cx t2[PL::R2 - 1];
+    cx t3[REG3 ? NB3 * (PL::R3 - 1) : 1];
+    __device__ __forceinline__ void init(const float2* tw, int lane) {
+        const int step2 = ((2 * M) / PL::R2 / PL::R1) * (lane & (PL::R1 - 1));
+#pragma unroll
+        for (int t = 1; t < PL::R2; ++t) t2[t - 1] = tw_fwd(tw, t * step2, M);
+        if (REG3) {
+#pragma unroll
+            for (int b = 0; b < NB3; ++b)
+#pragma unroll
+                for (int t = 1; t < PL::R3; ++t) t3[b * (PL::R3 - 1) + t - 1] = tw_fwd(tw, t * 2 * (lane + 64 * b), M);
+        }
+    }
+};
+
+// Three Stockham passes.  On entry v holds the first-pass input v[b*R1 + t] = x[lane + 64 b + t*M/R1]; on exit
+// the natural-order result is in buf[pad(k)] (wave-private).  Pass with sub-transform length Ns writes
+// y[(j/Ns)*Ns*R + (j%Ns) + t*Ns], j = lane + 64 b.
+template <int LOG2M, int DIR>
+__device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, const WaveTw<LOG2M>& w,
+                                         const float2* twl, float2* buf) {
+    using PL = Plan<LOG2M>;
+    constexpr int M = 1 << LOG2M, P = M / 64;
+    constexpr int R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
+    constexpr int NB1 = P / R1, NB2 = P / R2, NB3 = P / R3;
+    float2* bl = buf + pad(lane);  // loads of every pass: index lane + 64 (b + t NB), constant part % 64 == 0
+    // ---- pass 1 (Ns = 1, no twiddles): index R1 (lane + 64 b) + t; lane part % R1 == 0, constant low bits t < R1
+    {
+        float2* bs = buf + pad(R1 * lane);
+#pragma unroll
+        for (int b = 0; b < NB1; ++b) dftR<R1, DIR>(&v[b * R1]);
+#pragma unroll
+        for (int b = 0; b < NB1; ++b)
+#pragma unroll
+            for (int t = 0; t < R1; ++t) stc(bs + cpad(R1 * 64 * b + t), v[b * R1 + permR<R1>(t)]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB2; ++b)
+#pragma unroll
+        for (int t = 0; t < R2; ++t) v[b * R2 + t] = ldc(bl + cpad(64 * b + t * 64 * NB2));
+    // ---- pass 2 (Ns = R1): k = lane % R1, index (lane - k) R2 + k + 64 b R2 + t R1; lane part & 31 = k < R1,
+    // constant part & 31 is a multiple of R1 below 32
+    {
+        const int k = lane & (R1 - 1);
+        float2* bs = buf + pad((lane - k) * R2 + k);
+#pragma unroll
+        for (int b = 0; b < NB2; ++b) {
+#pragma unroll
+            for (int t = 1; t < R2; ++t) v[b * R2 + t] = c_tw<DIR>(v[b * R2 + t], w.t2[t - 1]);
+            dftR<R2, DIR>(&v[b * R2]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB2; ++b)
+#pragma unroll
+            for (int t = 0; t < R2; ++t) stc(bs + cpad(64 * b * R2 + t * R1), v[b * R2 + permR<R2>(t)]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB3; ++b)
+#pragma unroll
+        for (int t = 0; t < R3; ++t) v[b * R3 + t] = ldc(bl + cpad(64 * b + t * 64 * NB3));
+    // ---- pass 3 (Ns = R1 R2 = M / R3 >= 64 NB3): k = j, index lane + 64 b + t Ns
+    {
+        constexpr int Ns = R1 * R2;
+#pragma unroll
+        for (int b = 0; b < NB3; ++b) {
+#pragma unroll
+            for (int t = 1; t < R3; ++t) {
+                const cx tw = WaveTw<LOG2M>::REG3 ? w.t3[b * (R3 - 1) + t - 1] : tw_fwd(twl, t * 2 * (lane + 64 * b), M);
+                v[b * R3 + t] = c_tw<DIR>(v[b * R3 + t], tw);
+            }
+            dftR<R3, DIR>(&v[b * R3]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB3; ++b)
+#pragma unroll
+            for (int t = 0; t < R3; ++t) stc(bl + cpad(64 * b + t * Ns), v[b * R3 + permR<R3>(t)]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward (compute_file): FPW frames per workgroup, one per wave
 // ------------------------------------------------------------------------------------------------
 template <int LOG2M>
-__global__ void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
+__global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
                                          const float2* __restrict__ tw, float* __restrict__ mag,
                                          float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
-                                         int64_t T, int64_t rows_out, float sqrt_n, int dbg) {
+                                         int64_t T, int64_t rows_out, float sqrt_n) {
     constexpr int M = 1 << LOG2M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* twl = reinterpret_cast<float2*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row pointers stay in SGPRs
     float2* buf = twl + (M + 1) + wave * MP;
-    if (!(dbg & 4))
-        for (int k = tid; k <= M; k += blockDim.x) twl[k] = tw[k];
+    for (int k = tid; k <= M; k += blockDim.x) twl[k] = tw[k];
     __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (t >= rows_out) return;
@@ -209,11 +277,13 @@ __global__ void stft_forward_wave_kernel(const float* __restrict__ audio, int64_
         for (int k = lane; k < ld; k += 64) {
             mrow[k] = 0.f;
             if (prow) prow[k] = 0.f;
-            if (urow) urow[k] = mk2(1.f, 0.f);
+            if (urow) stc(urow + k, mk(1.f, 0.f));
         }
         return;
     }
-    float2 v[P];
+    WaveTw<LOG2M> wt;
+    wt.init(twl, lane);
+    cx v[P];
     const int64_t base = t * (int64_t)hop - M;
     // 32-bit window-relative bounds instead of two 64-bit compares per sample
     const int r_lo = base < 0 ? (int)(-base) : 0;
@@ -222,54 +292,63 @@ __global__ void stft_forward_wave_kernel(const float* __restrict__ audio, int64_
     const float* ap = audio + base;
     const float inv_sqrt_n = 1.f / sqrt_n;
     const float2* w2 = reinterpret_cast<const float2*>(win);
+    // whole frame in range and its sample pairs 8-byte aligned: one 64-bit load per pair
+    const bool inside = r_lo == 0 && r_hi == 2 * M && (reinterpret_cast<uintptr_t>(ap) & 7) == 0;
 #pragma unroll
     for (int b = 0; b < NB1; ++b)
 #pragma unroll
         for (int tt = 0; tt < R1; ++tt) {
             const int i = lane + 64 * b + tt * stride1;
             const int r = 2 * i;
-            const float2 w = (dbg & 8) ? mk2(0.5f, 0.25f) : w2[i];
-            float x0 = 0.f, x1 = 0.f;
-            if (dbg & 2) {
-                x0 = (float)i * w.x;
-                x1 = (float)(i + 1) * w.y;
+            const cx w = ldc(w2 + i);
+            cx x = mk(0.f, 0.f);
+            if (inside) {
+                x = *reinterpret_cast<const cx*>(ap + r);
             } else {
-                if (r >= r_lo && r < r_hi) x0 = ap[r] * w.x;
-                if (r + 1 >= r_lo && r + 1 < r_hi) x1 = ap[r + 1] * w.y;
+                if (r >= r_lo && r < r_hi) x[0] = ap[r];
+                if (r + 1 >= r_lo && r + 1 < r_hi) x[1] = ap[r + 1];
             }
-            v[b * R1 + tt] = mk2(x0, x1);
+            v[b * R1 + tt] = x * w;
         }
-    fft_wave<LOG2M, -1>(v, lane, twl, buf);
-    // even/odd split: X[k] = E + w^k O with E = (Z[k] + conj Z[M-k])/2, O = -i (Z[k] - conj Z[M-k])/2
+    fft_wave<LOG2M, -1>(v, lane, wt, twl, buf);
+    // even/odd split: X[k] = E + w^k O with E = (Z[k] + conj Z[M-k])/2, O = -i (Z[k] - conj Z[M-k])/2.
+    // k = lane + 64 u; M - k = (64 - lane) + (M - 64 (u + 1)): constant parts are multiples of 64.
+    const float2* bk = buf + pad(lane);
+    const float2* bm = buf + pad(64 - lane);
+#pragma unroll
     for (int u = 0; u <= P; ++u) {
         const int k = lane + 64 * u;
-        if (k > M) break;
-        const float2 zk = buf[pad(k & (M - 1))];
-        const float2 zm = buf[pad((M - k) & (M - 1))];
-        const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
-        const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-        const float2 w = twl[k];
-        const float xr = er + (w.x * orr - w.y * oi);
-        const float xi = ei + (w.x * oi + w.y * orr);
+        if (u == P && lane > 0) break;  // k <= M
+        const cx zk = u < P ? ldc(bk + cpad(64 * u)) : ldc(buf);                      // Z[k mod M]
+        const cx zm = (u == P || (u == 0 && lane == 0)) ? ldc(buf) : ldc(bm + cpad(M - 64 * (u + 1)));  // Z[(M-k) mod M]
+        const cx e2 = c_add_conj(zk, zm);  // 2 E
+        const cx d2 = c_sub_conj(zk, zm);  // 2 i O  ->  O = -i d2 / 2
+        const cx o2 = c_sub_i(mk(0.f, 0.f), d2);
+        const cx x2 = e2 + c_mul(o2, ldc(twl + k));
+        const float xr = 0.5f * x2[0], xi = 0.5f * x2[1];
         const float ax = sqrtf(xr * xr + xi * xi);
-        if ((dbg & 1) && !(ax == 12345.678f)) continue;  // keeps the arithmetic, drops the stores
         mrow[k] = ax * inv_sqrt_n;
         if (prow) prow[k] = atan2f(xi, xr);
         if (urow) {
             const float ra = 1.f / ax;  // one division for both components
-            urow[k] = (ax > 0.f) ? mk2(xr * ra, xi * ra) : mk2(1.f, 0.f);
+            stc(urow + k, (ax > 0.f) ? mk(xr * ra, xi * ra) : mk(1.f, 0.f));
         }
     }
     for (int k = M + 1 + lane; k < ld; k += 64) {
         mrow[k] = 0.f;
         if (prow) prow[k] = 0.f;
-        if (urow) urow[k] = mk2(1.f, 0.f);
+        if (urow) stc(urow + k, mk(1.f, 0.f));
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// inverse (compute_inverse): workgroup = C hops of one source; its 4 waves transform 4 consecutive
-// frames at a time, then all threads add the 4 windowed frames into the chunk in frame order.
+// inverse (compute_inverse): a workgroup walks C consecutive hop-blocks of one source.  Its 4 waves transform
+// 4 consecutive frames per step; then every thread adds the windowed frames -- in frame order, the
+// reference's accumulation order (transform.py:381-389) -- into a ring of hop-blocks in LDS, and the blocks
+// that no later frame touches are normalised by sum(w^2) and written out.  A thread always works on the same
+// sample pairs of a block, so the ring needs no synchronisation of its own, the accumulator is as small as
+// N/hop + 3 blocks whatever C is, and only the N/hop - 1 frames before the first block are transformed
+// twice (by this workgroup and by its left neighbour).  Requires hop | N and hop even.
 // ------------------------------------------------------------------------------------------------
 template <int LOG2M, bool UNIT>
 __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict__ mag, int64_t src_stride,
@@ -277,131 +356,145 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
                                                          const float2* __restrict__ unit, int64_t ld,
                                                          const float* __restrict__ win, const float* __restrict__ wsq,
                                                          const float2* __restrict__ tw, float* __restrict__ audio,
-                                                         int64_t n_out, int hop, int64_t T, int C, float pre_div,
-                                                         float sqrt_n) {
+                                                         int64_t n_out, int hop, int64_t T, int C, int64_t n_blocks,
+                                                         int ring_slots, float pre_div, float sqrt_n) {
     constexpr int M = 1 << LOG2M, N = 2 * M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* twl = reinterpret_cast<float2*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float2* fbuf = twl + (M + 1);
+    float2* twl = reinterpret_cast<float2*>(smem);      // [M + 1]
+    float2* fbuf = twl + (M + 1);                        // [4][MP] transformed frames
+    float2* winl = fbuf + 4 * MP;                        // [M] window as (even, odd) pairs
+    float2* ring = winl + M;                             // [ring_slots][hop/2]
+    float* norm_s = reinterpret_cast<float*>(ring + (size_t)ring_slots * (hop >> 1));  // [hop] steady-state sum(w^2)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2* buf = fbuf + wave * MP;
-    float* acc = reinterpret_cast<float*>(fbuf + 4 * MP);
     const int s = blockIdx.y;
-    const int span = C * hop;
-    const int64_t p0 = (int64_t)blockIdx.x * span;
-    // hop | N and hop even (every reference config): a frame is N/hop whole hop-blocks of hop/2 sample pairs,
-    // so which block of which frame lands where is wave-uniform scalar arithmetic
-    const bool aligned = (N % hop) == 0 && (hop & 1) == 0;
-    float2* winl = reinterpret_cast<float2*>(acc + span);  // window as (even, odd) pairs (aligned path)
-    if (aligned) {
+    const int hp = hop >> 1, R = N / hop, rmask = ring_slots - 1;
+    const int64_t hb0 = (int64_t)blockIdx.x * C;
+    const int64_t hb1 = (hb0 + C < n_blocks) ? hb0 + C : n_blocks;
+
+    {
         const float2* w2g = reinterpret_cast<const float2*>(win);
         for (int k = tid; k < M; k += 256) winl[k] = w2g[k];
+        for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
+        for (int q = tid; q < ring_slots * hp; q += 256) stc(ring + q, mk(0.f, 0.f));
+        for (int q = tid; q < hop; q += 256) {
+            float nrm = 0.f;
+            for (int d = R - 1; d >= 0; --d) nrm += wsq[q + d * hop];  // frames in increasing order
+            norm_s[q] = nrm == 0.f ? 1.f : nrm;
+        }
     }
-    for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
-    for (int q = tid; q < span; q += 256) acc[q] = 0.f;
-    int64_t n_hi = (p0 + span - 1) / hop;
+    int64_t n_hi = hb1 - 1;
     if (n_hi > T - 1) n_hi = T - 1;
-    const int64_t n_lo = (p0 < N) ? 0 : (p0 - N) / hop + 1;
+    const int64_t n_lo = (hb0 < R) ? 0 : hb0 - (R - 1);
     const float inv_m = 1.f / (float)M;
-    const float amp = sqrt_n / pre_div;  // (mag / scale_factor) * sqrt(N) with one multiply per bin
+    const float amp = 0.5f * (sqrt_n / pre_div);  // (mag / scale_factor) sqrt(N), and the 1/2 of the even/odd split
     const float* msrc = mag + (int64_t)s * src_stride;
+    float* dst = audio + (int64_t)s * n_out;
     __syncthreads();
+    WaveTw<LOG2M> wt;
+    wt.init(twl, lane);
+
+    int64_t g_done = hb0;  // next block to write out
+    // flush blocks [g_done, g_end): every frame that touches them has been added (or does not exist)
+    auto flush = [&](int64_t g_end, int64_t n_last) {
+        for (int64_t g = g_done; g < g_end; ++g) {
+            const int slot = (int)(g & rmask);
+            const bool steady = g >= R - 1 && g <= T - 1;
+            const bool live = g <= n_last + R - 1;  // beyond the last frame's reach: zeros
+            for (int r = tid; r < hp; r += 256) {
+                cx a = live ? ldc(ring + slot * hp + r) : mk(0.f, 0.f);
+                if (live) stc(ring + slot * hp + r, mk(0.f, 0.f));
+                const int64_t p = g * hop + 2 * r;
+                const int64_t m = p - M;
+                if (m + 1 < 0 || m >= n_out) continue;
+                float nx, ny;
+                if (steady) {
+                    nx = norm_s[2 * r];
+                    ny = norm_s[2 * r + 1];
+                } else {
+                    const int64_t f_hi = g < T - 1 ? g : T - 1;
+                    const int64_t f_lo = g < R ? 0 : g - (R - 1);
+                    nx = 0.f;
+                    ny = 0.f;
+                    for (int64_t n = f_lo; n <= f_hi; ++n) {
+                        nx += wsq[p - n * hop];
+                        ny += wsq[p + 1 - n * hop];
+                    }
+                    if (nx == 0.f) nx = 1.f;
+                    if (ny == 0.f) ny = 1.f;
+                }
+                if (m >= 0) dst[m] = a[0] / nx;
+                if (m + 1 < n_out) dst[m + 1] = a[1] / ny;  // m + 1 >= 0 here
+            }
+        }
+        if (g_end > g_done) g_done = g_end;
+    };
 
     for (int64_t nb = n_lo; nb <= n_hi; nb += 4) {
         const int64_t n = nb + wave;
         if (n <= n_hi) {
             const float* mrow = msrc + n * ld;
-            float2 v[P];
+            const float2* urow = unit + n * ld;
+            const float* prow = phase + n * ld;
+            cx v[P];
 #pragma unroll
             for (int b = 0; b < NB1; ++b)
 #pragma unroll
                 for (int tt = 0; tt < R1; ++tt) {
                     const int k = lane + 64 * b + tt * stride1;  // 0 <= k < M
                     const int km = M - k;                         // 1..M
-                    float2 xk, xm;
-                    {
-                        const float a = mrow[k] * amp;
-                        const float b2 = mrow[km] * amp;
-                        if (UNIT) {
-                            const float2 uk = unit[n * ld + k], um = unit[n * ld + km];
-                            xk = mk2(a * uk.x, a * uk.y);
-                            xm = mk2(b2 * um.x, b2 * um.y);
-                        } else {
-                            float sn, cs;
-                            sincosf(phase[n * ld + k], &sn, &cs);
-                            xk = mk2(a * cs, a * sn);
-                            sincosf(phase[n * ld + km], &sn, &cs);
-                            xm = mk2(b2 * cs, b2 * sn);
+                    const float a = mrow[k] * amp;
+                    const float b2 = mrow[km] * amp;
+                    cx xk, xm;
+                    if (UNIT) {
+                        xk = ldc(urow + k) * a;
+                        xm = ldc(urow + km) * b2;
+                    } else {
+                        float sn, cs;
+                        sincosf(prow[k], &sn, &cs);
+                        xk = mk(a * cs, a * sn);
+                        sincosf(prow[km], &sn, &cs);
+                        xm = mk(b2 * cs, b2 * sn);
+                    }
+                    if (b == 0 && tt == 0) {  // k == 0 only there: imaginary parts of DC / Nyquist are ignored (numpy irfft)
+                        if (lane == 0) {
+                            xk[1] = 0.f;
+                            xm[1] = 0.f;
                         }
                     }
-                    if (k == 0) xk.y = 0.f;      // imaginary parts of DC / Nyquist are ignored (numpy irfft)
-                    if (km == M) xm.y = 0.f;
-                    // E = (xk + conj xm)/2 ; D = (xk - conj xm)/2 ; O = D conj(w^k) ; Z = E + i O
-                    const float er = 0.5f * (xk.x + xm.x), ei = 0.5f * (xk.y - xm.y);
-                    const float dr = 0.5f * (xk.x - xm.x), di = 0.5f * (xk.y + xm.y);
-                    const float2 w = twl[k];
-                    const float orr = dr * w.x + di * w.y;
-                    const float oi = di * w.x - dr * w.y;
-                    v[b * R1 + tt] = mk2(er - oi, ei + orr);
+                    // E = (xk + conj xm)/2 ; D = (xk - conj xm)/2 ; O = D conj(w^k) ; Z = E + i O   (1/2 is in amp)
+                    const cx e = c_add_conj(xk, xm), d = c_sub_conj(xk, xm);
+                    const cx o = c_mul_conj(d, ldc(twl + k));
+                    v[b * R1 + tt] = c_add_i(e, o);
                 }
-            fft_wave<LOG2M, +1>(v, lane, twl, buf);
+            fft_wave<LOG2M, +1>(v, lane, wt, twl, buf);
         }
         __syncthreads();
-        if (aligned) {
-            // frames in increasing order (the reference's accumulation order); frame n2 covers the global
-            // hop-blocks n2 .. n2 + N/hop - 1, chunk block j is global block p0/hop + j
-            const int hp = hop >> 1, R = N / hop;
-            const int64_t hb0 = p0 / hop;
-            float2* acc2 = reinterpret_cast<float2*>(acc);
-            for (int w = 0; w < 4; ++w) {
-                const int64_t n2 = nb + w;
-                if (n2 > n_hi) break;
-                for (int j = 0; j < C; ++j) {
-                    const int64_t d = hb0 + j - n2;
-                    if (d < 0 || d >= R) continue;
-                    const int fo = (int)d * hp;
-                    for (int r = tid; r < hp; r += 256) {
-                        const float2 z = fbuf[w * MP + pad(fo + r)];
-                        const float2 ww = winl[fo + r];
-                        float2 a2 = acc2[j * hp + r];
-                        a2.x += (z.x * inv_m) * ww.x;
-                        a2.y += (z.y * inv_m) * ww.y;
-                        acc2[j * hp + r] = a2;
-                    }
+        // frame n2 covers the hop-blocks n2 .. n2 + R - 1
+        for (int w = 0; w < 4; ++w) {
+            const int64_t n2 = nb + w;
+            if (n2 > n_hi) break;
+            for (int d = 0; d < R; ++d) {
+                const int64_t g = n2 + d;
+                if (g < hb0 || g >= hb1) continue;
+                const int slot = (int)(g & rmask);
+                const int fo = d * hp;
+                for (int r = tid; r < hp; r += 256) {
+                    const cx z = ldc(fbuf + w * MP + pad(fo + r));
+                    const cx ww = ldc(winl + fo + r);
+                    cx a2 = ldc(ring + slot * hp + r);
+                    a2 += (z * inv_m) * ww;
+                    stc(ring + slot * hp + r, a2);
                 }
-            }
-        } else {
-            for (int q = tid; q < span; q += 256) {
-                const int64_t p = p0 + q;
-                float a = acc[q];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int64_t n2 = nb + w;
-                    const int64_t off = p - n2 * hop;
-                    if (n2 <= n_hi && off >= 0 && off < N) {
-                        const float2 z = fbuf[w * MP + pad((int)(off >> 1))];
-                        a += (((off & 1) ? z.y : z.x) * inv_m) * win[off];
-                    }
-                }
-                acc[q] = a;
             }
         }
+        const bool last = nb + 4 > n_hi;
+        flush(last ? hb1 : (nb + 4 < hb1 ? nb + 4 : hb1), n_hi);
         __syncthreads();
     }
-    const int half = N >> 1;
-    for (int q = tid; q < span; q += 256) {
-        const int64_t p = p0 + q;
-        const int64_t m = p - half;
-        if (m < 0 || m >= n_out) continue;
-        int64_t f_hi = p / hop;
-        if (f_hi > T - 1) f_hi = T - 1;
-        const int64_t f_lo = (p < N) ? 0 : (p - N) / hop + 1;
-        float norm = 0.f;
-        for (int64_t n = f_lo; n <= f_hi; ++n) norm += wsq[p - n * hop];
-        if (norm == 0.f) norm = 1.f;
-        audio[(int64_t)s * n_out + m] = acc[q] / norm;
-    }
+    flush(hb1, n_hi < n_lo ? -R : n_hi);  // a chunk no frame reaches: zeros
 }
 
 template <int LOG2M>
@@ -409,7 +502,6 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, float* mag, float* ph
                int64_t rows_out, int64_t T) {
     constexpr int M = 1 << LOG2M, MP = M + M / 32;
     // frames per workgroup: 4 when there are plenty of frames, 1 to spread a short signal over the CUs
-    static const int dbg = getenv("DCS_STFT_DBG") ? atoi(getenv("DCS_STFT_DBG")) : 0;
     static const int fpw_env = getenv("DCS_STFT_FPW") ? atoi(getenv("DCS_STFT_FPW")) : 0;
     int fpw = rows_out >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
     if (fpw_env) fpw = fpw_env;
@@ -419,7 +511,7 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, float* mag, float* ph
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(rows_out, fpw)), dim3(64 * fpw), lds, p->ctx->stream, audio, L,
-                       p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T, rows_out, (float)sqrt((double)p->frame), dbg);
+                       p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T, rows_out, (float)sqrt((double)p->frame));
     return DCS_OK;
 }
 
@@ -427,22 +519,27 @@ template <int LOG2M>
 int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, const float2* unit, int64_t ld,
                int64_t T, int n_src, float pre_div, float* audio, int64_t n_out) {
     constexpr int M = 1 << LOG2M, MP = M + M / 32, N = 2 * M;
-    const int hop = p->hop;
-    const int64_t hops = (n_out + N / 2 + hop - 1) / hop;
-    const int R_ = (N + hop - 1) / hop;
-    // C hops per workgroup: C + R_ - 1 frames are transformed, 4 at a time
+    const int hop = p->hop, R_ = N / hop;
+    const int64_t n_blocks = (n_out + N / 2 + hop - 1) / hop;
+    int ring_slots = 8;
+    while (ring_slots < R_ + 3) ring_slots *= 2;
+    const size_t lds = ((size_t)(M + 1) + 4 * (size_t)MP + (size_t)M + (size_t)ring_slots * (hop / 2)) * sizeof(float2) +
+                       (size_t)hop * sizeof(float);
+    if (lds > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "wave iSTFT: %zu bytes of LDS", lds);
+    // C hop-blocks per workgroup: C + R_ - 1 frames are transformed, 4 at a time.  Few blocks: one 4-frame step
+    // per workgroup (shortest critical path).  Many: about two rounds of resident workgroups, so that the
+    // R_ - 1 re-transformed frames per workgroup are a few per cent and the tail stays short.
     static const int c_env = getenv("DCS_ISTFT_HOPS") ? atoi(getenv("DCS_ISTFT_HOPS")) : 0;
-    int64_t C = hops * n_src / (int64_t)p->ctx->n_cu;
-    if (C > 16 - (R_ - 1)) C = 16 - (R_ - 1);
-    if (c_env > 0) C = c_env;
-    if (C < 1) C = 1;
-    const size_t fixed = ((size_t)(M + 1) + 4 * (size_t)MP + (size_t)M) * sizeof(float2);  // + window pairs
-    size_t lds = fixed + (size_t)C * hop * sizeof(float);
-    while (lds > 96 * 1024 && C > 1) {
-        --C;
-        lds = fixed + (size_t)C * hop * sizeof(float);
+    const int64_t total = n_blocks * n_src;
+    const int64_t resident = (int64_t)p->ctx->n_cu * (lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3));
+    int64_t C = 1;
+    if (total > 4 * resident) {
+        C = (total + 2 * resident - 1) / (2 * resident);
+        C = (C + R_ - 1 + 3) / 4 * 4 - (R_ - 1);  // C + R_ - 1 a multiple of 4: no half-empty last step
+        if (C < 1) C = 1;
     }
-    const dim3 grid((unsigned)((hops + C - 1) / C), (unsigned)n_src);
+    if (c_env > 0) C = c_env;
+    const dim3 grid((unsigned)((n_blocks + C - 1) / C), (unsigned)n_src);
 #define DCS_GO(UNIT_)                                                                                             \
     {                                                                                                             \
         auto kern = istft_wave_kernel<LOG2M, UNIT_>;                                                              \
@@ -450,7 +547,8 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, p->ctx->stream, mag, src_stride, phase, unit, ld, p->win_f, \
-                           p->wsq_f, p->tw_f, audio, n_out, hop, T, (int)C, pre_div, (float)sqrt((double)N));     \
+                           p->wsq_f, p->tw_f, audio, n_out, hop, T, (int)C, n_blocks, ring_slots, pre_div,        \
+                           (float)sqrt((double)N));                                                               \
     }
     if (unit) DCS_GO(true) else DCS_GO(false)
 #undef DCS_GO
@@ -462,6 +560,11 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
 bool dcs_fft_wave_supported(const dcs_stft* p) {
     static const bool off = getenv("DCS_FFT_BLOCK") != nullptr;  // debugging aid: force the block-level kernels
     return !off && p->log2m >= 9 && p->log2m <= 11;
+}
+
+bool dcs_fft_wave_inverse_supported(const dcs_stft* p) {
+    // hop | N and hop even (every reference configuration): a frame is N/hop whole hop-blocks of sample pairs
+    return dcs_fft_wave_supported(p) && p->hop > 0 && (p->frame % p->hop) == 0 && (p->hop & 1) == 0;
 }
 
 int dcs_fft_wave_forward(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
