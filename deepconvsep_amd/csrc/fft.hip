@@ -402,7 +402,9 @@ int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, floa
                                 int64_t ld, int64_t rows_out, int64_t T) {
     // few frames: the block-level kernel (4 waves share one frame's FFT) has the shorter critical path
     // (8.6 us vs 19 us for 186 frames); many frames: the wave-per-frame kernel has the higher throughput
-    if (dcs_fft_wave_supported(p) && rows_out >= 4 * (int64_t)p->ctx->n_cu) {
+    static const int64_t thr_env = getenv("DCS_STFT_WAVE_MIN") ? atoll(getenv("DCS_STFT_WAVE_MIN")) : -1;
+    const int64_t thr = thr_env >= 0 ? thr_env : 4 * (int64_t)p->ctx->n_cu;
+    if (dcs_fft_wave_supported(p) && rows_out >= thr) {
         DcsTimer tm(p->ctx, DCS_TAG_STFT);
         const int rc = dcs_fft_wave_forward(p, audio, L, mag, phase, unit, ld, rows_out, T);
         tm.done();
