@@ -2,8 +2,14 @@
 #pragma once
 #include "dcs_internal.h"
 
+// Transposed-conv2 outputs G are stored as [tile][branch][channel group][t][8]: a (tile, branch, group) block is
+// contiguous (the streaming deconv2 kernel writes it in one piece) and a row's 8 channels are two float4
+// slots of the final kernel's A operand.
+constexpr int kDsdGch = 8;
+inline int dsd_g_pitch(int CI, int tc) { return ((CI + kDsdGch - 1) / kDsdGch) * tc * kDsdGch; }  // floats per (tile, branch)
+
 struct DsdFinalArgs {
-    const float* G;       // [n][3][tc][CI] transposed-conv2 outputs
+    const float* G;       // [n][3][CI/8][tc][8] transposed-conv2 outputs
     const float* Bw;      // [CI][ldb]  Bw[c][f] = W1[c,0,0,F-1-f]; ldb = F rounded up to 128, zero padded
     int ldb;
     const float* bias;    // [4] output BiasLayer
@@ -22,7 +28,8 @@ struct DsdFinalArgs {
     int mask_mode;        // 0 = convention A, 1 = convention B, 2 = raw network output
 };
 
-// Bw: [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]
-int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float* G, int64_t n_ks, int H2, int CP,
-                           int CI, int kh, int tc, int NG, int GS, int gcols);
+// Bw:  [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]   (few tiles)
+// Bws: [ci][16 taps][CP] holds W2c[co, ci, dt], ci padded to whole groups of 8, tap 15 zero   (many tiles)
+int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const float* Bws, float* G, int64_t n_ks,
+                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols);
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold);

@@ -86,87 +86,155 @@ __global__ __launch_bounds__(kThreads) void deconv2_kernel(const float* __restri
     __syncthreads();
 
     const int ci0 = grp * GS;
-    float* Gp = G + ks * (int64_t)tc * CI;
+    const int ngg = (CI + kDsdGch - 1) / kDsdGch;
+    float* Gp = G + ks * (int64_t)ngg * tc * kDsdGch;  // [channel group][t][8]
     for (int o = tid; o < tc * GS; o += kThreads) {
         const int t = o / GS, c = o - t * GS;
-        if (ci0 + c >= CI) continue;
+        const int ci = ci0 + c;
+        if (ci >= CI) continue;
         int lo = t - (H2 - 1);
         if (lo < 0) lo = 0;
         const int hi = t < kh - 1 ? t : kh - 1;
         float sum = 0.f;
         for (int dt = lo; dt <= hi; ++dt) sum += P[(t - dt) * gcols + c * kh + dt];
-        Gp[t * CI + ci0 + c] = sum;
+        Gp[((ci / kDsdGch) * tc + t) * kDsdGch + (ci % kDsdGch)] = sum;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Many-tiles variant of deconv2_kernel: persistent workgroups.  With one workgroup per (tile, branch,
-// group) every workgroup streams its 52 x 208 weight slice (43 KB) from L2 for 42 MFMAs per wave -- 2.1 GB
-// of L2 traffic per launch at 4096 tiles.  Here a workgroup keeps the slice of its channel group in LDS
-// and walks a strided list of (tile, branch) pairs; the next pair's 16 x 52 input rows are prefetched
-// into registers while the current pair is multiplied and reduced.
+// Many-tiles variant: independent waves streaming over (tile, branch) items, no workgroup barrier after the
+// weight slice is in LDS.  A workgroup owns one group of 8 input channels; its weight slice
+// Bs[channel c][tap dt][52 output filters] (26.6 KB) stays in LDS.  (Keeping the B fragments in 104 registers
+// instead was not faster: 0.194 vs 0.181 ms at 4096 tiles.)  For an item, a wave
+//   * reads its A fragments straight from D (the K order final_chan() makes a lane's 13 filters of row t'
+//     three float4 and one float), prefetching the next item's while it works;
+//   * per pair of channels: 2 x 13 MFMAs give P[t'][dt] (one 16 x 16 block per channel, column = tap), which
+//     it writes SKEWED, Ps[c][t' + dt][dt], into a private LDS buffer, so that the col2im sum
+//     G[t, c] = sum_dt P[t - dt][dt] is a row sum: lane (t, c) reads 16 contiguous floats and adds them in
+//     tap order -- the order of deconv2_kernel.  Entries no (t', dt) maps to are zeroed once and stay zero;
+//   * collects the 30 x 8 outputs of the item in LDS and stores them as one contiguous 960-byte block of
+//     G[item][channel group][t][8].
+// fp32 MFMA and VALU instructions do not overlap on a SIMD (scripts/ubench/mfma_valu.hip), so what counts is
+// the non-MFMA instruction count per MFMA: here ~45 VALU/LDS instructions per 26 MFMAs, against the one-shot
+// kernel's staged A tile, P round trip with divisions in the reduction, and 3 barriers per item.
+// Groups of one item run on the same XCD at about the same time (block -> (group, column) mapping), so the item's
+// D rows are fetched from HBM once and served from that XCD's L2 to the other groups.
 // ------------------------------------------------------------------------------------------------
-template <int NQ>
-__global__ __launch_bounds__(kThreads) void deconv2_persistent_kernel(const float* __restrict__ D,
-                                                                      const float* __restrict__ Bw,
-                                                                      float* __restrict__ G, int64_t n_ks, int H2,
-                                                                      int CP, int CI, int kh, int tc, int GS, int gcols) {
+constexpr int kD2PsStride = 20;  // floats per skewed row: 16 taps + 4 (16-byte aligned, spreads the banks)
+
+__global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* __restrict__ D,
+                                                                  const float* __restrict__ Bws,
+                                                                  float* __restrict__ G, int64_t n_ks, int H2,
+                                                                  int kh, int tc, int ngg, int n_full, int X,
+                                                                  int tail_ch, int Xt) {
+    constexpr int CP = 52, GS = kDsdGch;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int as = CP + 2;
-    float* Bs = smem;                      // [CP][gcols]   (gcols % 32 == 16: rows kq, kq+1 hit disjoint banks)
-    float* As = Bs + CP * gcols;           // [16][CP+2]
-    float* P = As + 16 * as;               // [16][gcols]
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    float* Bs = smem;                                   // [GS*16][CP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* Ps = Bs + GS * 16 * CP + wave * (2 * 32 * kD2PsStride + 32 * GS);  // [2][32][20] skewed products
+    float* Os = Ps + 2 * 32 * kD2PsStride;                                     // [tc][8] outputs of the item
     const int fi = lane & 15, kq = lane >> 4;
-    const int grp = blockIdx.y;
-    const int ldb = gcols * (int)gridDim.y;
-    for (int idx = tid; idx < CP * gcols; idx += kThreads) {
-        const int r = idx / gcols, c = idx - r * gcols;
-        Bs[idx] = Bw[(int64_t)r * ldb + grp * gcols + c];
+
+    // block -> (channel group g, workgroup column x of nwx)
+    const int b = blockIdx.x;
+    int g, x, nwx, n_ch;
+    if (b < n_full * X) {
+        const int xl = b & 7, t = b >> 3;
+        g = t % n_full;
+        x = (t / n_full) * 8 + xl;
+        nwx = X;
+        n_ch = GS;
+    } else {
+        g = n_full;
+        x = b - n_full * X;
+        nwx = Xt;
+        n_ch = tail_ch;
     }
-    const int a_slots = H2 * (CP >> 2);    // float4 slots of one (tile, branch) input block (H2 <= 16 rows)
-    const int ncb = gcols >> 4;
-    const int ci0 = grp * GS;
-    f32x4 pre = f32x4{0.f, 0.f, 0.f, 0.f};
-    int64_t ks = blockIdx.x;
-    if (ks < n_ks && tid < a_slots) pre = *reinterpret_cast<const f32x4*>(D + ks * (int64_t)H2 * CP + tid * 4);
-    for (; ks < n_ks; ks += gridDim.x) {
-        __syncthreads();  // previous pair: P fully reduced, As fully read
-        if (tid < 16 * (CP >> 2)) {
-            const int r = tid / (CP >> 2), c4 = tid - r * (CP >> 2);
-            const f32x4 v = (tid < a_slots) ? pre : f32x4{0.f, 0.f, 0.f, 0.f};
-            float* d = As + r * as + c4 * 4;
-            *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
-            *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Bws + (int64_t)g * GS * 16 * CP);
+        f32x4* dst = reinterpret_cast<f32x4*>(Bs);
+        for (int i = tid; i < GS * 16 * CP / 4; i += kThreads) dst[i] = src[i];
+        for (int i = lane; i < 2 * 32 * kD2PsStride + 32 * GS; i += 64) Ps[i] = 0.f;
+    }
+    __syncthreads();
+
+    const int n_pairs = (n_ch + 1) >> 1;
+    // A fragments are fetched two items ahead (an item takes ~1.5 us).  Ablation at 4096 tiles, 0.183 ms in all:
+    // without the col2im and stores 0.160, without the D loads 0.156, without the G stores 0.176; the MFMAs
+    // alone would take 0.104 ms (scripts/ubench/mfma_chains.hip: 155 TFLOP/s sustained).
+    f32x4 pa[3], pb[3];
+    float pl = 0.f, pm = 0.f;
+#define DCS_LOAD_D(ks_, pa_, pl_)                                                                    \
+    {                                                                                                \
+        const float* dp = D + ((ks_) * (int64_t)H2 + fi) * CP + 12 * kq;                             \
+        const bool in = fi < H2;                                                  \
+        _Pragma("unroll") for (int u = 0; u < 3; ++u)                                                \
+            pa_[u] = in ? *reinterpret_cast<const f32x4*>(dp + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};   \
+        pl_ = in ? dp[48 - 11 * kq] : 0.f;                                                           \
+    }
+    const int64_t kstep = (int64_t)nwx * 4;
+    int64_t ks = (int64_t)x * 4 + wave;
+    if (ks < n_ks) DCS_LOAD_D(ks, pa, pl)
+    if (ks + kstep < n_ks) DCS_LOAD_D(ks + kstep, pb, pm)
+    for (; ks < n_ks; ks += kstep) {
+        float af[13];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) af[q] = pa[q >> 2][q & 3];
+        af[12] = pl;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) pa[u] = pb[u];
+        pl = pm;
+        if (ks + 2 * kstep < n_ks) DCS_LOAD_D(ks + 2 * kstep, pb, pm)
+        for (int cp = 0; cp < n_pairs; ++cp) {
+            const float* b0 = Bs + ((2 * cp) * 16 + fi) * CP + 12 * kq;
+            const float* b1 = b0 + 16 * CP;
+            f32x4 bf0[3], bf1[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                bf0[u] = *reinterpret_cast<const f32x4*>(b0 + 4 * u);
+                bf1[u] = *reinterpret_cast<const f32x4*>(b1 + 4 * u);
+            }
+            const float bl0 = b0[48 - 11 * kq], bl1 = b1[48 - 11 * kq];
+            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 13; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], q < 12 ? bf0[q >> 2][q & 3] : bl0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], q < 12 ? bf1[q >> 2][q & 3] : bl1, acc1, 0, 0, 0);
+            }
+            // acc[e] = P[t' = 4 kq + e][dt = fi]  ->  Ps[c][t' + dt][dt]
+            if (fi < kh) {
+                float* w0 = Ps + (4 * kq + fi) * kD2PsStride + fi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * kq + e < H2) {
+                        w0[e * kD2PsStride] = acc0[e];
+                        w0[32 * kD2PsStride + e * kD2PsStride] = acc1[e];
+                    }
+                }
+            }
+            if (lane < 2 * tc) {
+                const int cc = lane & 1, t = lane >> 1;
+                const f32x4* r = reinterpret_cast<const f32x4*>(Ps + (cc * 32 + t) * kD2PsStride);
+                const f32x4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                float sum = 0.f;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) sum += r0[d];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) sum += r1[d];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) sum += r2[d];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) sum += r3[d];
+                Os[t * GS + 2 * cp + cc] = sum;
+            }
         }
-        __syncthreads();
-        const int64_t nxt = ks + gridDim.x;
-        if (nxt < n_ks && tid < a_slots) pre = *reinterpret_cast<const f32x4*>(D + nxt * (int64_t)H2 * CP + tid * 4);
-        float a0[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) a0[q] = As[fi * as + 4 * q + kq];
-        for (int cb = wave; cb < ncb; cb += 4) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], Bs[(4 * q + kq) * gcols + cb * 16 + fi], acc, 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) P[(kq * 4 + e) * gcols + cb * 16 + fi] = acc[e];
-        }
-        __syncthreads();
-        float* Gp = G + ks * (int64_t)tc * CI;
-        for (int o = tid; o < tc * GS; o += kThreads) {
-            const int t = o / GS, c = o - t * GS;
-            if (ci0 + c >= CI) continue;
-            int lo = t - (H2 - 1);
-            if (lo < 0) lo = 0;
-            const int hi = t < kh - 1 ? t : kh - 1;
-            float sum = 0.f;
-            for (int dt = lo; dt <= hi; ++dt) sum += P[(t - dt) * gcols + c * kh + dt];
-            Gp[t * CI + ci0 + c] = sum;
+        if (lane < tc * GS / 4) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(Os)[lane];
+            reinterpret_cast<f32x4*>(G + (ks * ngg + g) * (int64_t)tc * GS)[lane] = v;
         }
     }
+#undef DCS_LOAD_D
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -310,12 +378,13 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
     __syncthreads();
 
     // ---- staging plan of this thread: up to 3 float4 slots of the [3 branches][16 rows][CI] A set.
-    // Slot (s, i, c4) reads G[k0_i + m][s][j0_i - m*st][4 c4 ..]; going from m to m+1 moves the address by
-    // the constant (NBR*tc - st)*CI, and the slot is needed iff tile m has a non-zero weight on row i.
+    // Slot (s, i, c4) reads G[k0_i + m][s][c4 / 2][j0_i - m*st][4 (c4 % 2) ..]; going from m to m+1 moves the
+    // address by a constant, and the slot is needed iff tile m has a non-zero weight on row i.
     constexpr int slots = NBR * 16 * NQ;
-    const int m_delta = (NBR * tc - st) * CI;
+    constexpr int NGG = (CI + kDsdGch - 1) / kDsdGch;  // G is [tile][branch][channel group][t][8]
+    const int m_delta = (NBR * NGG * tc - st) * kDsdGch;
     const int kbase = meta_k0[0];
-    const float* gbase = a.G + (int64_t)kbase * NBR * tc * CI;  // workgroup-uniform; offsets stay 32-bit
+    const float* gbase = a.G + (int64_t)kbase * NBR * NGG * tc * kDsdGch;  // workgroup-uniform; offsets stay 32-bit
     int goff[3], dst[3], srow[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -327,7 +396,8 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
         const int j0 = in ? meta_j0[i] : -1;
         srow[u] = in ? i : -1;
         dst[u] = (s * 16 + i) * AS + c4 * 4;
-        goff[u] = (((in ? meta_k0[i] - kbase : 0) * NBR + s) * tc + (j0 < 0 ? 0 : j0)) * CI + c4 * 4;
+        goff[u] = ((((in ? meta_k0[i] - kbase : 0) * NBR + s) * NGG + (c4 >> 1)) * tc + (j0 < 0 ? 0 : j0)) * kDsdGch +
+                  (c4 & 1) * 4;
     }
     f32x4 pre[3];
 #define DCS_LOAD_A(m_)                                                                          \
@@ -444,8 +514,8 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
 
 }  // namespace
 
-int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float* G, int64_t n_ks, int H2, int CP,
-                           int CI, int kh, int tc, int NG, int GS, int gcols) {
+int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const float* Bws, float* G, int64_t n_ks,
+                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols) {
     if (n_ks <= 0) return DCS_OK;
     const int nrb = (H2 + 15) / 16;
     if (nrb > 2) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: conv2 output height %d > 32", H2);
@@ -453,17 +523,27 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, float*
     const size_t lds = (size_t)16 * nrb * ((CP + 2) + gcols) * sizeof(float);
     if (lds > 64 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: LDS %zu too large", lds);
     DcsTimer tm(ctx, DCS_TAG_DECONV2);
-    static const int force = getenv("DCS_DECONV2") ? atoi(getenv("DCS_DECONV2")) : 0;  // 1 one-shot, 2 persistent
-    const int per_group = 2 * ctx->n_cu / NG;                       // persistent workgroups per channel group
-    const bool persistent = force ? force == 2 : (nrb == 1 && n_ks >= 8 * (int64_t)per_group);
-    if (persistent) {
-        const size_t lds2 = ((size_t)CP * gcols + 16 * (CP + 2) + (size_t)16 * gcols) * sizeof(float);
-        auto kern = deconv2_persistent_kernel<13>;
+    static const int force = getenv("DCS_DECONV2") ? atoi(getenv("DCS_DECONV2")) : 0;  // 1 one-shot, 2 streaming
+    const int ngg = (CI + kDsdGch - 1) / kDsdGch;
+    const bool can_stream = nrb == 1 && kh <= 16 && tc <= 32 && H2 + kh - 1 <= 32;
+    const bool stream = can_stream && (force ? force == 2 : n_ks >= 4 * (int64_t)ctx->n_cu);
+    if (stream) {
+        // 3 workgroups per CU (50.6 KB of LDS each), one round: X columns for each full channel group, and a
+        // proportionally smaller share for the last, partial group
+        const int n_full = CI / kDsdGch, tail_ch = CI - n_full * kDsdGch;
+        const int slots = 3 * ctx->n_cu;
+        const double units = n_full + (tail_ch ? (double)((tail_ch + 1) / 2) / (kDsdGch / 2) : 0.0);
+        int X = (int)(slots / units) / 8 * 8;
+        if (X < 8) X = 8;
+        int Xt = tail_ch ? slots - n_full * X : 0;
+        if (tail_ch && Xt < 1) Xt = 1;
+        const size_t lds2 = ((size_t)kDsdGch * 16 * CP + 4 * (2 * 32 * kD2PsStride + 32 * kDsdGch)) * sizeof(float);
+        auto kern = deconv2_stream_kernel;
         if (lds2 > 48 * 1024)
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds2));
-        hipLaunchKernelGGL(kern, dim3((unsigned)per_group, (unsigned)NG), dim3(kThreads), lds2, ctx->stream, D, Bw, G,
-                           n_ks, H2, CP, CI, kh, tc, GS, gcols);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(n_full * X + Xt)), dim3(kThreads), lds2, ctx->stream, D, Bws, G, n_ks,
+                           H2, kh, tc, ngg, n_full, X, tail_ch, Xt);
     } else {
         hipLaunchKernelGGL(deconv2_kernel<13>, dim3((unsigned)n_ks, (unsigned)NG), dim3(kThreads), lds, ctx->stream, D,
                            Bw, G, H2, CP, CI, kh, tc, GS, gcols);

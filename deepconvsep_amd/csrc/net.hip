@@ -76,7 +76,7 @@ struct dcs_model {
     int CI = 0, CP = 0, K1 = 0, Fpad = 0, hid64 = 0, nd = 0, nd64 = 0;
     int d2_ng = 4, d2_gs = 0, d2_gcols = 0;  // transposed conv2: channel groups, channels per group, padded columns
     float *B1 = nullptr, *bias1 = nullptr, *B2 = nullptr, *bias2 = nullptr, *Bfc = nullptr, *biasfc = nullptr;
-    float *Bd = nullptr, *biasd = nullptr, *Bw2 = nullptr, *Bfin = nullptr, *bout = nullptr;
+    float *Bd = nullptr, *biasd = nullptr, *Bw2 = nullptr, *Bw2s = nullptr, *Bfin = nullptr, *bout = nullptr;
     // ---- generic path (ikala / bach10 / score-informed)
     DcsGenericNet* gen = nullptr;
     // ---- scratch
@@ -182,6 +182,13 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
             for (int dt = 0; dt < kh; ++dt)
                 Bw2[(size_t)co * ldw2 + (ci / m->d2_gs) * m->d2_gcols + (ci % m->d2_gs) * kh + dt] =
                     W2[((size_t)co * d.nf1 + ci) * kh + (kh - 1 - dt)];
+    // the same weights for the streaming kernel: Bw2s[ci][dt][co], 16 tap slots per channel, whole groups of 8
+    std::vector<float> Bw2s((size_t)dcs_round_up(CI, kDsdGch) * 16 * CP, 0.f);
+    if (kh <= 16)
+        for (int co = 0; co < d.nf2; ++co)
+            for (int ci = 0; ci < d.nf1; ++ci)
+                for (int dt = 0; dt < kh; ++dt)
+                    Bw2s[((size_t)ci * 16 + dt) * CP + co] = W2[((size_t)co * d.nf1 + ci) * kh + (kh - 1 - dt)];
     // transposed conv1: Bfin[c][f] = W1[c,0,0,F-1-f]
     std::vector<float> Bfin((size_t)CI * m->Fpad, 0.f);
     for (int c = 0; c < d.nf1; ++c)
@@ -197,6 +204,7 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     DCS_CHECK(upload(&m->Bd, Bd));
     DCS_CHECK(upload(&m->biasd, biasd));
     DCS_CHECK(upload(&m->Bw2, Bw2));
+    DCS_CHECK(upload(&m->Bw2s, Bw2s));
     DCS_CHECK(upload(&m->Bfin, Bfin));
     DCS_CHECK(upload(&m->bout, bout));
     return DCS_OK;
@@ -247,14 +255,14 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g4.M = n; g4.n_cols = m->nd64; g4.n_store = m->nd; g4.K = m->hid64; g4.relu = 1; g4.a_vec = 1;
     DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
     // InverseLayer(., l_conv2) (separate_dsd.py:211,217,223)
-    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, w.G, n * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
+    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
                                   m->d2_gcols);
 }
 
 size_t dsd_scratch_bytes(const dcs_model* m, int64_t n, int64_t rows1, int64_t rows2) {
     return align256((size_t)rows1 * m->CI * 4) + align256((size_t)rows2 * m->CP * 4) +
            align256((size_t)n * m->hid64 * 4) + align256((size_t)n * m->nd * 4) +
-           align256((size_t)n * m->d.n_fc * m->tc * m->CI * 4);
+           align256((size_t)n * m->d.n_fc * dsd_g_pitch(m->CI, m->tc) * 4);
 }
 
 char* dsd_carve(const dcs_model* m, char* p, int64_t n, int64_t rows1, int64_t rows2, DsdScratch* w) {
@@ -262,7 +270,7 @@ char* dsd_carve(const dcs_model* m, char* p, int64_t n, int64_t rows1, int64_t r
     w->C2 = (float*)p; p += align256((size_t)rows2 * m->CP * 4);
     w->Z = (float*)p; p += align256((size_t)n * m->hid64 * 4);
     w->D = (float*)p; p += align256((size_t)n * m->nd * 4);
-    w->G = (float*)p; p += align256((size_t)n * m->d.n_fc * m->tc * m->CI * 4);
+    w->G = (float*)p; p += align256((size_t)n * m->d.n_fc * dsd_g_pitch(m->CI, m->tc) * 4);
     return p;
 }
 
@@ -351,7 +359,7 @@ extern "C" int dcs_model_create(dcs_ctx* ctx, int arch, int C, int tc, int F, co
 
 extern "C" int dcs_model_destroy(dcs_model* m) {
     if (!m) return DCS_OK;
-    float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bfin, m->bout,
+    float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bw2s, m->Bfin, m->bout,
                      m->rise_d};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
