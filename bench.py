@@ -14,10 +14,13 @@ HBM.  With N GPUs every rank separates its own 32-tile batches (weak scaling, co
 the PCM of all ranks is all-gathered over RCCL inside the timed region.
 
 A 32-tile batch holds 0.57 GFLOP -- 3.6 us of the chip's f32 peak -- spread over 8 dependent
-kernels, so one batch at a time leaves the GPU mostly idle.  Steps are independent, therefore
-`--streams S` (default 8) keeps S batches in flight on S HIP streams (each with its own libdcs
-context, plan, model handle and buffers), the way a server would overlap requests.  `value` is
-the resulting throughput; `single_stream` reports the same K steps issued on one stream.
+kernels, so one batch at a time leaves the GPU mostly idle (`single_stream` reports that regime:
+the same K steps, one batch per launch, one stream).  Steps are independent, therefore
+`--clips-per-launch B` (default 16) batches share one set of kernel launches (dcs_separate_batch:
+every batch is tiled, cross-faded and inverted exactly as if it were alone) and `--streams S`
+(default 2) such launch groups are in flight on S HIP streams, each with its own libdcs context,
+plan, model handle and buffers -- the way a batch-of-files server overlaps requests.  `value` is
+the resulting throughput: K steps = K batches, whatever the grouping.
 
 Rank 0 prints ONE JSON line.  `roofline` refers to the dominant kernel (transposed conv1 +
 bias + rectify + soft mask + cross-fade), timed with HIP events inside the timed region on the
@@ -54,7 +57,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--tiles", type=int, default=32, help="tiles per GPU per step (BASELINE configs[1]: 32)")
     ap.add_argument("--frame-size", type=int, default=2048)
-    ap.add_argument("--streams", type=int, default=8, help="independent batches in flight per GPU")
+    ap.add_argument("--clips-per-launch", type=int, default=16,
+                    help="independent 32-tile batches that share one set of kernel launches (dcs_separate_batch); "
+                         "every batch still counts as one step")
+    ap.add_argument("--streams", type=int, default=2, help="launch groups in flight per GPU (HIP streams)")
     ap.add_argument("--issue-threads", type=int, default=1,
                     help="host threads issuing steps (single GPU only: with N ranks the RCCL gathers must be "
                          "issued in the same order on every rank)")
@@ -92,6 +98,7 @@ def main():
     assert n_tiles == args.tiles, (n_tiles, args.tiles)
     frames_per_step = (n_tiles - 1) * (TC - OV) + TC        # unique frames fully separated
     NS = max(1, args.streams)
+    CPL = max(1, args.clips_per_launch)
 
     class Lane(object):                                      # one HIP stream with everything it needs
         def __init__(self, idx):
@@ -99,29 +106,34 @@ def main():
             with torch.cuda.stream(self.stream):
                 self.ctx = Context()                         # binds libdcs to this stream
                 self.sep = dcs.Separator("dsd", params, SCALE, TC, OV, 32, F, N, HOP, np.hanning, ctx=self.ctx)
-                self.audio_h = synth_audio(L, seed=100 + rank * 16 + idx)
-                self.audio = self.ctx.to_device(self.audio_h, np.float32)
-                self.pcm = torch.empty((4, L), dtype=torch.float32, device=self.audio.device)
-                self.gathered = (torch.empty((world * 4, L), dtype=torch.float32, device=self.audio.device)
+                self.audio_h = np.stack([synth_audio(L, seed=100 + (rank * 16 + idx) * CPL + c) for c in range(CPL)])
+                self.audio = self.ctx.to_device(self.audio_h, np.float32)          # [CPL, L]
+                self.pcm = torch.empty((CPL, 4, L), dtype=torch.float32, device=self.audio.device)
+                self.gathered = (torch.empty((world * CPL * 4, L), dtype=torch.float32, device=self.audio.device)
                                  if world > 1 else None)
             self.stream.synchronize()
-            # the C entry point with its arguments bound once: dcs_separate() enqueues on the context's
-            # own stream, so the per-step host cost is one ctypes call (and, from the second identical
+            # the C entry point with its arguments bound once: dcs_separate_batch() enqueues on the context's
+            # own stream, so the host cost of a launch group is one ctypes call (and, from the second identical
             # call on, one hipGraphLaunch inside it)
             import ctypes
             net, plan = self.sep.net, self.sep.plan
-            self._call = (self.ctx._lib.dcs_separate, (net._h, plan._h, ctypes.c_void_p(self.audio.data_ptr()), L, OV,
-                                                       TILER_SCRIPT, ctypes.c_float(SCALE), net.arch.eps_mode, 0,
-                                                       ctypes.c_void_p(self.pcm.data_ptr()), None, None))
+            self._fn = self.ctx._lib.dcs_separate_batch
+            self._args = lambda nclips: (net._h, plan._h, ctypes.c_void_p(self.audio.data_ptr()), L, nclips, L, OV,
+                                         TILER_SCRIPT, ctypes.c_float(SCALE), net.arch.eps_mode, 0,
+                                         ctypes.c_void_p(self.pcm.data_ptr()), None, None)
+            self._bound = {CPL: self._args(CPL), 1: self._args(1)}
 
-        def step(self):
-            fn, a = self._call
-            rc = fn(*a)
+        def step(self, nclips=None):
+            """One launch group = nclips steps (independent 32-tile batches)."""
+            nclips = CPL if nclips is None else nclips
+            a = self._bound.get(nclips) or self._args(nclips)
+            rc = self._fn(*a)
             if rc:
                 _lib.check(rc)
             if world > 1:
                 with torch.cuda.stream(self.stream):
-                    dist.all_gather_into_tensor(self.gathered, self.pcm)   # RCCL over xGMI: the final gather
+                    # RCCL over xGMI: the final gather of the separated PCM
+                    dist.all_gather_into_tensor(self.gathered[: world * nclips * 4], self.pcm.view(-1, L)[: nclips * 4])
 
     lanes = [Lane(i) for i in range(NS)]
     ctx0 = lanes[0].ctx
@@ -133,16 +145,17 @@ def main():
     import threading
     n_issue = max(1, min(args.issue_threads, NS)) if world == 1 else 1
 
-    def timed(k, use):
-        """Exactly k steps, round-robin over the lanes in `use`, issued by n_issue host threads (ctypes
-        releases the GIL inside dcs_separate) when more than one lane is in play."""
+    def timed(k, use, cpl):
+        """Exactly k steps = k 32-tile batches, in launch groups of cpl batches (the last group takes the
+        remainder), round-robin over the lanes in `use`, issued by n_issue host threads (ctypes releases the
+        GIL inside the call) when more than one lane is in play."""
         nth = n_issue if len(use) > 1 else 1
-        share = [k // nth + (1 if t < k % nth else 0) for t in range(nth)]
+        groups = [cpl] * (k // cpl) + ([k % cpl] if k % cpl else [])
 
         def work(t):
             mine = use[t::nth]
-            for i in range(share[t]):
-                mine[i % len(mine)].step()
+            for i, g in enumerate(groups[t::nth]):
+                mine[i % len(mine)].step(g)
         threads = [threading.Thread(target=work, args=(t,)) for t in range(1, nth)]
         barrier()
         torch.cuda.synchronize()
@@ -161,15 +174,18 @@ def main():
             el = float(tt.item())
         return el
 
-    for i in range(args.warmup):
-        lanes[i % NS].step()
+    for i in range(0, max(args.warmup, 2 * NS * CPL), CPL):      # >= 2 groups per lane: the second call captures the graph
+        lanes[(i // CPL) % NS].step()
+    for ln in lanes:
+        ln.step(1)
+        ln.step(1)
     # HIP event pairs around the dominant kernel on stream 0, inside the timed region, around every 4th
     # of its launches there (an event record costs ~6 us of stream time on each side of the kernel).
     if not os.environ.get("DCS_BENCH_NOEVENTS"):
         ctx0.timing(["final"])
     ctx0.timing_stride(4)
     ctx0.timing_reset()
-    elapsed = timed(args.steps, lanes)
+    elapsed = timed(args.steps, lanes, CPL)
     final_ms, final_launches = ctx0.timing_query("final")
     ctx0.timing(None)
     ctx0.timing_stride(1)
@@ -179,7 +195,7 @@ def main():
     ctx0.timing(["final"])
     ctx0.timing_stride(8)
     ctx0.timing_reset()
-    el1 = timed(args.steps, lanes[:1])
+    el1 = timed(args.steps, lanes[:1], 1)
     final_ms1, final_launches1 = ctx0.timing_query("final")
     ctx0.timing(None)
     ctx0.timing_stride(1)
@@ -189,7 +205,7 @@ def main():
     ctx0.timing("all")
     ctx0.timing_reset()
     for _ in range(20):
-        lanes[0].step()
+        lanes[0].step(1)
     for tag in _lib.TAGS:
         ms, cnt = ctx0.timing_query(tag)
         if cnt:
@@ -209,17 +225,19 @@ def main():
     except Exception:
         pass
 
-    def roof(n, ms, launches):
+    def roof(n, ms, launches, key=None):
         ach = n * final_flops_tile / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        rec = traffic_rec.get("final_kernel_%d_tiles" % n) if N == 2048 else None
+        rec = traffic_rec.get(key or "final_kernel_%d_tiles" % n) if N == 2048 else None
         traffic = int((2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024) if rec else None
         return {"bound": "mfma", "kernel": "final_kernel<fold> (deconv1+bias+relu+mask+crossfade)",
                 "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
-                "algorithmic_bytes": int(n * (3 * TC * 52 * 4) + ((n - 1) * (TC - OV) + TC) * F * 4 * 5),
+                # G rows read once (3 branches x tc x 56 stored channels) + mixture read + 4 sources written
+                "algorithmic_bytes": int(n * (3 * TC * 56 * 4) + (n * (TC - OV) + TC - (TC - OV)) * F * 4 * 5),
                 "avg_kernel_ms": round(ms, 5), "launches": int(launches)}
 
-    roofline = roof(n_tiles, final_ms, final_launches)
+    roofline = roof(n_tiles * CPL, final_ms, final_launches, "final_kernel_%dx%d_tiles" % (CPL, n_tiles))
+    roofline["tiles_per_launch"] = n_tiles * CPL
     single = {"ms_per_step": round(el1 / args.steps * 1e3, 5),
               "value": round(world * frames_per_step * args.steps / el1, 1),
               "roofline": roof(n_tiles, final_ms1, final_launches1), "kernels_ms": kernels_ms}
@@ -263,7 +281,7 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pipeline
-        audio_h = lanes[0].audio_h
+        audio_h = lanes[0].audio_h[0]
         # pick the torch thread count that serves this small batch best (all 256 host threads on the
         # 50-channel float64 convolutions is far slower than a handful); the NumPy loops are serial
         best = None
@@ -298,11 +316,13 @@ def main():
             "config": {"workload": "DSD100 4-source separate_dsd path (BASELINE configs[1]): frameSize=%d hop=512 "
                                    "hann, time_context=30 overlap=25 scale=0.3, one batch of %d tiles = %.2f s of "
                                    "44.1 kHz audio per GPU per step, STFT->net->mask->overlap-add->iSTFT, "
-                                   "input and output resident in HBM, %d independent batches in flight per GPU "
-                                   "(HIP streams)%s"
-                                   % (N, n_tiles, L / SR, NS, ", PCM all-gathered over RCCL" if world > 1 else ""),
+                                   "input and output resident in HBM; %d independent batches share one set of "
+                                   "kernel launches (dcs_separate_batch, the batch-of-files driver) and %d such "
+                                   "groups are in flight per GPU (HIP streams)%s"
+                                   % (N, n_tiles, L / SR, CPL, NS, ", PCM all-gathered over RCCL" if world > 1 else ""),
                        "tiles_per_gpu_per_step": n_tiles, "frames_per_gpu_per_step": frames_per_step,
-                       "frame_size": N, "bins": F, "streams_per_gpu": NS, "issue_threads": n_issue,
+                       "frame_size": N, "bins": F, "clips_per_launch": CPL, "streams_per_gpu": NS,
+                       "issue_threads": n_issue,
                        "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",
                        "parallelism": "tiles sharded by rank (dp%d)" % world},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_stream": single, "saturating": saturating,

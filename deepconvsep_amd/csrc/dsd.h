@@ -26,6 +26,8 @@ struct DsdFinalArgs {
     int F, CI;
     int mmax;             // FOLD: ceil(ov/st)+1 covering tiles per frame; else 1
     int mask_mode;        // 0 = convention A, 1 = convention B, 2 = raw network output
+    int n_clips;          // stacked clips of equal length (0 or 1: a single clip); clip c uses G + c*g_clip_stride,
+    int64_t g_clip_stride, mix_clip_stride, out_clip_stride;  // mix + c*mix_clip_stride, out + c*out_clip_stride
 };
 
 // Bw:  [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]   (few tiles)

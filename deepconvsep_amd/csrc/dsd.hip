@@ -283,6 +283,7 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int64_t clip = blockIdx.y;  // stacked clips of equal length (dcs_separate_batch): same fold, shifted buffers
     const unsigned rg = swz / (unsigned)n_colg;
     const int64_t row0 = (int64_t)rg * 16;
     const int colw = (int)(swz - rg * (unsigned)n_colg) * (64 * CBW) + wave * (16 * CBW);
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
         const int64_t r = row0 + kq * 4 + e;
         float m0 = 0.f, m1 = 0.f;
         if (r < a.rows) {
-            const float* mp = a.mix + r * a.mix_ld + col;
+            const float* mp = a.mix + clip * a.mix_clip_stride + r * a.mix_ld + col;
             if (vec && col + 1 < a.F) {
                 const f32x2 v = *reinterpret_cast<const f32x2*>(mp);
                 m0 = v[0];
@@ -384,7 +385,8 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
     constexpr int NGG = (CI + kDsdGch - 1) / kDsdGch;  // G is [tile][branch][channel group][t][8]
     const int m_delta = (NBR * NGG * tc - st) * kDsdGch;
     const int kbase = meta_k0[0];
-    const float* gbase = a.G + (int64_t)kbase * NBR * NGG * tc * kDsdGch;  // workgroup-uniform; offsets stay 32-bit
+    // workgroup-uniform base; the per-slot offsets stay 32-bit
+    const float* gbase = a.G + clip * a.g_clip_stride + (int64_t)kbase * NBR * NGG * tc * kDsdGch;
     int goff[3], dst[3], srow[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
             if (r < a.rows) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float* op = a.out + c * a.out_src_stride + r * a.out_ld + col;
+                    float* op = a.out + clip * a.out_clip_stride + c * a.out_src_stride + r * a.out_ld + col;
                     if constexpr (CBW == 2) {
                         if (vec && col + 1 < a.F) {
                             *reinterpret_cast<f32x2*>(op) = f32x2{res[0][c][e], res[1][c][e]};
@@ -561,7 +563,8 @@ int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
     // groups) 16 x 64 gives twice the workgroups and half the work in each: 32 tiles 17.8 vs 19.1 us
     const int64_t n_rg = dcs_cdiv(a.rows, 16);
     static const int force = getenv("DCS_FINAL_CBW") ? atoi(getenv("DCS_FINAL_CBW")) : 0;
-    const int cbw = force ? force : (n_rg * ((a.F + 127) / 128) >= 3 * (int64_t)ctx->n_cu ? 2 : 1);
+    const unsigned n_clips = a.n_clips > 0 ? (unsigned)a.n_clips : 1u;
+    const int cbw = force ? force : (n_rg * ((a.F + 127) / 128) * n_clips >= 3 * (int64_t)ctx->n_cu ? 2 : 1);
     const int n_colg = (a.F + 64 * cbw - 1) / (64 * cbw);
     if (a.ldb < n_colg * 64 * cbw || (a.ldb & 1))
         DCS_FAIL(DCS_EINVAL, "final: weight pitch %d < %d", a.ldb, n_colg * 64 * cbw);
@@ -571,11 +574,11 @@ int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
 #define DCS_FINAL(FOLD_, MODE_)                                                                                      \
     do {                                                                                                             \
         if (cbw == 2)                                                                                                \
-            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 2>), dim3((unsigned)n_wg), dim3(kThreads), 0, ctx->stream, a, \
-                               n_colg);                                                                              \
+            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 2>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0,       \
+                               ctx->stream, a, n_colg);                                                              \
         else                                                                                                         \
-            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 1>), dim3((unsigned)n_wg), dim3(kThreads), 0, ctx->stream, a, \
-                               n_colg);                                                                              \
+            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 1>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0,       \
+                               ctx->stream, a, n_colg);                                                              \
     } while (0)
     if (fold) {
         if (a.mask_mode == 0) DCS_FINAL(true, 0);

@@ -258,7 +258,8 @@ template <int LOG2M>
 __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
                                          const float2* __restrict__ tw, float* __restrict__ mag,
                                          float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
-                                         int64_t T, int64_t rows_out, float sqrt_n) {
+                                         int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
+                                         float sqrt_n) {
     constexpr int M = 1 << LOG2M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,11 +269,15 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     float2* buf = twl + (M + 1) + wave * MP;
     for (int k = tid; k <= M; k += blockDim.x) twl[k] = tw[k];
     __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (t >= rows_out) return;
-    float* mrow = mag + t * ld;
-    float* prow = phase ? phase + t * ld : nullptr;
-    float2* urow = unit ? unit + t * ld : nullptr;
+    // output row -> (clip, frame): clips of equal length are stacked with a pitch of rows_pc rows
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (row >= rows_pc * n_clips) return;
+    const int64_t clip = row / rows_pc;
+    const int64_t t = row - clip * rows_pc;
+    audio += clip * audio_stride;
+    float* mrow = mag + row * ld;
+    float* prow = phase ? phase + row * ld : nullptr;
+    float2* urow = unit ? unit + row * ld : nullptr;
     if (t >= T) {
         for (int k = lane; k < ld; k += 64) {
             mrow[k] = 0.f;
@@ -357,7 +362,8 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
                                                          const float* __restrict__ win, const float* __restrict__ wsq,
                                                          const float2* __restrict__ tw, float* __restrict__ audio,
                                                          int64_t n_out, int hop, int64_t T, int C, int64_t n_blocks,
-                                                         int ring_slots, float pre_div, float sqrt_n) {
+                                                         int n_chunks, int n_src, int ring_slots, float pre_div,
+                                                         float sqrt_n, int64_t unit_clip_stride, int src_per_clip) {
     constexpr int M = 1 << LOG2M, N = 2 * M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -369,9 +375,22 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2* buf = fbuf + wave * MP;
-    const int s = blockIdx.y;
+    // block -> (chunk, source): the n_src sources of a chunk read the same phasor rows; they get block ids 8
+    // apart (same XCD, dispatched together), so one of them pulls a row from HBM and the others hit that L2
+    int chunk, s;
+    {
+        const int b = blockIdx.x, full = (n_chunks >> 3) * 8 * n_src;
+        if (b < full) {
+            chunk = (b / (8 * n_src)) * 8 + (b & 7);
+            s = (b >> 3) % n_src;
+        } else {
+            const int r = n_chunks & 7, b2 = b - full;
+            chunk = (n_chunks >> 3) * 8 + b2 % r;
+            s = b2 / r;
+        }
+    }
     const int hp = hop >> 1, R = N / hop, rmask = ring_slots - 1;
-    const int64_t hb0 = (int64_t)blockIdx.x * C;
+    const int64_t hb0 = (int64_t)chunk * C;
     const int64_t hb1 = (hb0 + C < n_blocks) ? hb0 + C : n_blocks;
 
     {
@@ -391,6 +410,7 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
     const float inv_m = 1.f / (float)M;
     const float amp = 0.5f * (sqrt_n / pre_div);  // (mag / scale_factor) sqrt(N), and the 1/2 of the even/odd split
     const float* msrc = mag + (int64_t)s * src_stride;
+    unit += (int64_t)(s / src_per_clip) * unit_clip_stride;  // stacked clips: each has its own phasor rows
     float* dst = audio + (int64_t)s * n_out;
     __syncthreads();
     WaveTw<LOG2M> wt;
@@ -498,26 +518,29 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
 }
 
 template <int LOG2M>
-int launch_fwd(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
-               int64_t rows_out, int64_t T) {
+int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips, float* mag,
+               float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T) {
     constexpr int M = 1 << LOG2M, MP = M + M / 32;
     // frames per workgroup: 4 when there are plenty of frames, 1 to spread a short signal over the CUs
     static const int fpw_env = getenv("DCS_STFT_FPW") ? atoi(getenv("DCS_STFT_FPW")) : 0;
-    int fpw = rows_out >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
+    const int64_t rows_all = rows_out * n_clips;
+    int fpw = rows_all >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
     if (fpw_env) fpw = fpw_env;
     const size_t lds = ((size_t)(M + 1) + (size_t)fpw * MP) * sizeof(float2);
     auto kern = stft_forward_wave_kernel<LOG2M>;
     if (lds > 48 * 1024)
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(rows_out, fpw)), dim3(64 * fpw), lds, p->ctx->stream, audio, L,
-                       p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T, rows_out, (float)sqrt((double)p->frame));
+    hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(rows_all, fpw)), dim3(64 * fpw), lds, p->ctx->stream, audio, L,
+                       p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T, rows_out, n_clips, audio_stride,
+                       (float)sqrt((double)p->frame));
     return DCS_OK;
 }
 
 template <int LOG2M>
-int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, const float2* unit, int64_t ld,
-               int64_t T, int n_src, float pre_div, float* audio, int64_t n_out) {
+int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, const float2* unit,
+               int64_t unit_clip_stride, int src_per_clip, int64_t ld, int64_t T, int n_src, float pre_div, float* audio,
+               int64_t n_out) {
     constexpr int M = 1 << LOG2M, MP = M + M / 32, N = 2 * M;
     const int hop = p->hop, R_ = N / hop;
     const int64_t n_blocks = (n_out + N / 2 + hop - 1) / hop;
@@ -525,7 +548,9 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     while (ring_slots < R_ + 3) ring_slots *= 2;
     const size_t lds = ((size_t)(M + 1) + 4 * (size_t)MP + (size_t)M + (size_t)ring_slots * (hop / 2)) * sizeof(float2) +
                        (size_t)hop * sizeof(float);
-    if (lds > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "wave iSTFT: %zu bytes of LDS", lds);
+    static const int pad_env = getenv("DCS_ISTFT_LDSPAD") ? atoi(getenv("DCS_ISTFT_LDSPAD")) : 0;  // occupancy experiments
+    const size_t lds_req = lds + (size_t)pad_env;
+    if (lds_req > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "wave iSTFT: %zu bytes of LDS", lds_req);
     // C hop-blocks per workgroup (C + R_ - 1 frames are transformed, 4 per step): one round of resident
     // workgroups, all of the same length.  Measured on MI355X, N = 2048: 4096 tiles C = 161 0.384 ms, 81 0.403,
     // 41 0.425, 9 0.548; 32 tiles (752 blocks) C = 2 18.1 us, 1 22.3, 5 19.4.
@@ -536,16 +561,17 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     if (C >= 8) C = (C + R_ - 1 + 3) / 4 * 4 - (R_ - 1);  // C + R_ - 1 a multiple of 4: no half-empty last step
     if (C < 1) C = 1;
     if (c_env > 0) C = c_env;
-    const dim3 grid((unsigned)((n_blocks + C - 1) / C), (unsigned)n_src);
+    const int n_chunks = (int)((n_blocks + C - 1) / C);
+    const dim3 grid((unsigned)n_chunks * (unsigned)n_src);
 #define DCS_GO(UNIT_)                                                                                             \
     {                                                                                                             \
         auto kern = istft_wave_kernel<LOG2M, UNIT_>;                                                              \
-        if (lds > 48 * 1024)                                                                                      \
+        if (lds_req > 48 * 1024)                                                                                  \
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, p->ctx->stream, mag, src_stride, phase, unit, ld, p->win_f, \
-                           p->wsq_f, p->tw_f, audio, n_out, hop, T, (int)C, n_blocks, ring_slots, pre_div,        \
-                           (float)sqrt((double)N));                                                               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req));               \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_req, p->ctx->stream, mag, src_stride, phase, unit, ld, p->win_f, \
+                           p->wsq_f, p->tw_f, audio, n_out, hop, T, (int)C, n_blocks, n_chunks, n_src, ring_slots,  \
+                           pre_div, (float)sqrt((double)N), unit_clip_stride, src_per_clip > 0 ? src_per_clip : n_src);  \
     }
     if (unit) DCS_GO(true) else DCS_GO(false)
 #undef DCS_GO
@@ -564,22 +590,23 @@ bool dcs_fft_wave_inverse_supported(const dcs_stft* p) {
     return dcs_fft_wave_supported(p) && p->hop > 0 && (p->frame % p->hop) == 0 && (p->hop & 1) == 0;
 }
 
-int dcs_fft_wave_forward(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
-                         int64_t rows_out, int64_t T) {
+int dcs_fft_wave_forward(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips, float* mag,
+                         float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T) {
     switch (p->log2m) {
-        case 9: return launch_fwd<9>(p, audio, L, mag, phase, unit, ld, rows_out, T);
-        case 10: return launch_fwd<10>(p, audio, L, mag, phase, unit, ld, rows_out, T);
-        case 11: return launch_fwd<11>(p, audio, L, mag, phase, unit, ld, rows_out, T);
+        case 9: return launch_fwd<9>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T);
+        case 10: return launch_fwd<10>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T);
+        case 11: return launch_fwd<11>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T);
     }
     DCS_FAIL(DCS_EUNSUPPORTED, "wave FFT: frame size");
 }
 
 int dcs_fft_wave_inverse(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, const float2* unit,
-                         int64_t ld, int64_t T, int n_src, float pre_div, float* audio, int64_t n_out) {
+                         int64_t unit_clip_stride, int src_per_clip, int64_t ld, int64_t T, int n_src, float pre_div,
+                         float* audio, int64_t n_out) {
     switch (p->log2m) {
-        case 9: return launch_inv<9>(p, mag, src_stride, phase, unit, ld, T, n_src, pre_div, audio, n_out);
-        case 10: return launch_inv<10>(p, mag, src_stride, phase, unit, ld, T, n_src, pre_div, audio, n_out);
-        case 11: return launch_inv<11>(p, mag, src_stride, phase, unit, ld, T, n_src, pre_div, audio, n_out);
+        case 9: return launch_inv<9>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out);
+        case 10: return launch_inv<10>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out);
+        case 11: return launch_inv<11>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out);
     }
     DCS_FAIL(DCS_EUNSUPPORTED, "wave FFT: frame size");
 }

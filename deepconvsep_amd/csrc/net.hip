@@ -87,10 +87,11 @@ struct dcs_model {
     // A graph is captured the second time the same call (same buffers, sizes, options) arrives.
     struct StepKey {
         const void* plan = nullptr; const void* audio = nullptr; const void* pcm = nullptr; const void* ws = nullptr;
-        int64_t L = -1; int ov = 0, tiler = 0, eps = 0, tie = 0; float scale = 0.f;
+        int64_t L = -1, n_clips = 1, audio_stride = 0; int ov = 0, tiler = 0, eps = 0, tie = 0; float scale = 0.f;
         bool operator==(const StepKey& o) const {
             return plan == o.plan && audio == o.audio && pcm == o.pcm && ws == o.ws && L == o.L && ov == o.ov &&
-                   tiler == o.tiler && eps == o.eps && tie == o.tie && scale == o.scale;
+                   tiler == o.tiler && eps == o.eps && tie == o.tie && scale == o.scale && n_clips == o.n_clips &&
+                   audio_stride == o.audio_stride;
         }
     };
     StepKey seen, captured;
@@ -217,13 +218,20 @@ struct DsdScratch {
 // Encoder + dense layers + transposed conv2 for n tiles whose frames are rows of `rows_src`.
 //   fused   : rows_src = scaled spectrogram rows (frame t), tile k starts at frame k*st
 //   per tile: rows_src = tile frames (k*tc + j)
+//   clips   : n_clips > 1 stacked clips of n tiles each (fused only); clip c's frames start at row c * clip_pitch
+//             (a multiple of st).  conv1 / conv2 simply run over all rows -- positions that straddle two clips are
+//             computed and never read -- and the bottleneck's A row of tile (c, k) is row c*clip_pitch + k*st.
 int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, float a_scale, int64_t n,
-               int64_t tile_row_stride /* st or tc */, bool shared_frames, const DsdScratch& w) {
+               int64_t tile_row_stride /* st or tc */, bool shared_frames, const DsdScratch& w, int64_t n_clips = 1,
+               int64_t clip_pitch = 0) {
     const Dims& d = m->d;
     const int tc = m->tc, CI = m->CI, CP = m->CP;
     const int64_t BIG = (int64_t)1 << 40;
+    const bool clips = n_clips > 1;
+    if (clips && (!shared_frames || clip_pitch % tile_row_stride != 0 || n > 0x7fffffff))
+        DCS_FAIL(DCS_EINVAL, "dsd_encode: bad clip batch");
     // conv1 + both biases  (separate_dsd.py:198-199)
-    const int64_t n_rows1 = shared_frames ? (n - 1) * tile_row_stride + tc : n * tc;
+    const int64_t n_rows1 = clips ? n_clips * clip_pitch : (shared_frames ? (n - 1) * tile_row_stride + tc : n * tc);
     DcsGemm g1{};
     g1.A = rows_src; g1.lda = lda; g1.a_gdiv = 1 << 30; g1.a_gmul = 0; g1.a_scale = a_scale;
     g1.B = m->B1; g1.ldb = 64; g1.bias = m->bias1;
@@ -234,7 +242,8 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     // conv2 + both biases (separate_dsd.py:202-203): output row = position; its A row is kh consecutive H1 rows
     DcsGemm g2{};
     g2.A = w.H1; g2.lda = CI; g2.a_scale = 1.f;
-    if (shared_frames) { g2.a_gdiv = 1 << 30; g2.a_gmul = 0; g2.M = (n - 1) * tile_row_stride + d.h2; }
+    if (clips) { g2.a_gdiv = 1 << 30; g2.a_gmul = 0; g2.M = n_rows1 - (d.kh2 - 1); }
+    else if (shared_frames) { g2.a_gdiv = 1 << 30; g2.a_gmul = 0; g2.M = (n - 1) * tile_row_stride + d.h2; }
     else { g2.a_gdiv = d.h2; g2.a_gmul = tc; g2.M = n * d.h2; }
     g2.B = m->B2; g2.ldb = 64; g2.bias = m->bias2;
     g2.C = w.C2; g2.ldc = CP; g2.c_gdiv = 1 << 30; g2.c_gmul = 0;
@@ -243,19 +252,20 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     // bottleneck DenseLayer, rectify (separate_dsd.py:206): A row of tile k = h2 consecutive C2 rows
     DcsGemm g3{};
     g3.A = w.C2; g3.lda = (shared_frames ? tile_row_stride : d.h2) * (int64_t)CP; g3.a_gdiv = 1 << 30; g3.a_gmul = 0;
+    if (clips) { g3.a_gdiv = (int)n; g3.a_gmul = clip_pitch / tile_row_stride; }
     g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc;
     g3.C = w.Z; g3.ldc = m->hid64; g3.c_gdiv = 1 << 30; g3.c_gmul = 0;
-    g3.M = n; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
+    g3.M = n * n_clips; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
     DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g3, DCS_TAG_FC));
     // per-source DenseLayers, rectify (separate_dsd.py:209,215,221)
     DcsGemm g4{};
     g4.A = w.Z; g4.lda = m->hid64; g4.a_gdiv = 1 << 30; g4.a_gmul = 0; g4.a_scale = 1.f;
     g4.B = m->Bd; g4.ldb = m->nd64; g4.bias = m->biasd;
     g4.C = w.D; g4.ldc = m->nd; g4.c_gdiv = 1 << 30; g4.c_gmul = 0;
-    g4.M = n; g4.n_cols = m->nd64; g4.n_store = m->nd; g4.K = m->hid64; g4.relu = 1; g4.a_vec = 1;
+    g4.M = n * n_clips; g4.n_cols = m->nd64; g4.n_store = m->nd; g4.K = m->hid64; g4.relu = 1; g4.a_vec = 1;
     DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
     // InverseLayer(., l_conv2) (separate_dsd.py:211,217,223)
-    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
+    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n * n_clips * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
                                   m->d2_gcols);
 }
 
@@ -404,7 +414,8 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 // ------------------------------------------------------------------------------------------------ fused path
 static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm_d, float* sep_out, float* mag_out, float* phase_out,
-                         int64_t ld_out, int64_t* n_tiles_out, int64_t* n_frames_out) {
+                         int64_t ld_out, int64_t* n_tiles_out, int64_t* n_frames_out, int64_t n_clips = 1,
+                         int64_t audio_stride = 0) {
     if (!m || !plan || !audio_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: null argument");
     if (plan->ctx != m->ctx) DCS_FAIL(DCS_EINVAL, "dcs_separate: plan and model belong to different contexts");
     if (plan->frame / 2 + 1 != m->F)
@@ -415,6 +426,9 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
     if (scale == 0.f) DCS_FAIL(DCS_EINVAL, "dcs_separate: scale_factor is zero");
     if (eps_mode != DCS_EPS_A && eps_mode != DCS_EPS_B) DCS_FAIL(DCS_EINVAL, "bad eps_mode");
     if (L < 1) DCS_FAIL(DCS_EINVAL, "dcs_separate: empty signal");
+    if (n_clips < 1 || n_clips > 65535) DCS_FAIL(DCS_EINVAL, "dcs_separate_batch: %lld clips", (long long)n_clips);
+    if (n_clips > 1 && (m->arch != DCS_ARCH_DSD || sep_out || mag_out || phase_out || audio_stride < L))
+        DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_batch: DSD graph, PCM output and clip stride >= length only");
     DCS_HIP(hipSetDevice(m->ctx->device));
     const int tc = m->tc, F = m->F, st = tc - ov, S = m->d.S;
     const int64_t T = dcs_frame_count(L, plan->hop);
@@ -425,24 +439,27 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         DCS_FAIL(DCS_EINVAL, "dcs_separate: %lld frames give no tile (the reference fails in overlapadd_multi)",
                  (long long)T);
     const int64_t Tcov = (n - 1) * st + tc;       // frames covered by the tiles
-    const int64_t Trows = Tcov > T ? Tcov : T;    // zero rows past T feed the zero-padding tiler
+    // zero rows past T feed the zero-padding tiler; stacked clips get a row pitch that is a multiple of st
+    const int64_t Trows = n_clips > 1 ? dcs_round_up(Tcov > T ? Tcov : T, st) : (Tcov > T ? Tcov : T);
     const int64_t ld = dcs_round_up(F, 4);
     // the STFT also fills rows past T of the phase / unit-phasor matrices
-    const size_t b_mag = align256((size_t)Trows * ld * 4), b_unit = 2 * b_mag, b_ph = phase_out ? b_mag : 0;
-    const size_t b_sep = align256((size_t)S * T * ld * 4);
+    const size_t b_mag = align256((size_t)n_clips * Trows * ld * 4), b_unit = 2 * b_mag, b_ph = phase_out ? b_mag : 0;
+    const size_t b_sep = align256((size_t)n_clips * S * T * ld * 4);
 
     if (m->arch == DCS_ARCH_DSD) {
-        const int64_t rows2 = (n - 1) * st + m->d.h2;
-        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + dsd_scratch_bytes(m, n, Tcov, rows2)));
+        const int64_t rows1 = n_clips > 1 ? n_clips * Trows : Tcov;
+        const int64_t rows2 = n_clips > 1 ? rows1 : (n - 1) * st + m->d.h2;
+        const int64_t n_all = n * n_clips;
+        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + dsd_scratch_bytes(m, n_all, rows1, rows2)));
         char* p = (char*)m->ws.ptr;
         float* mag = (float*)p; p += b_mag;
         float2* unit = (float2*)p; p += b_unit;
         float* phase = phase_out ? (float*)p : nullptr; p += b_ph;
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
-        dsd_carve(m, p, n, Tcov, rows2, &w);
-        DCS_CHECK(dcs_launch_stft_forward_f32(plan, audio_d, L, mag, phase, unit, ld, Trows, T));
-        DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w));
+        dsd_carve(m, p, n_all, rows1, rows2, &w);
+        DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T));
+        DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
         a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
@@ -450,8 +467,13 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         a.out = sep; a.out_src_stride = T * ld; a.out_ld = ld;
         a.rise = m->rise_d; a.n = n; a.rows = T; a.tc = tc; a.ov = ov; a.st = st;
         a.F = F; a.CI = m->CI; a.mmax = (ov + st - 1) / st + 1; a.mask_mode = eps_mode;
+        a.n_clips = (int)n_clips;
+        a.g_clip_stride = n * m->d.n_fc * (int64_t)dsd_g_pitch(m->CI, tc);
+        a.mix_clip_stride = Trows * ld;
+        a.out_clip_stride = (int64_t)S * T * ld;
         DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
-        if (pcm_d) DCS_CHECK(dcs_launch_stft_inverse_f32(plan, sep, T * ld, nullptr, unit, ld, T, S, scale, pcm_d, L));
+        if (pcm_d)
+            DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, T * ld, unit, Trows * ld, ld, T, S, n_clips, scale, pcm_d, L));
         if (sep_out || mag_out || phase_out) {
             for (int s = 0; s < S && sep_out; ++s)
                 DCS_HIP(hipMemcpy2DAsync(sep_out + (int64_t)s * T * ld_out, ld_out * 4, sep + (int64_t)s * T * ld, ld * 4,
@@ -469,9 +491,9 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
                                 phase_out, ld_out, &m->ws);
 }
 
-extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
-                            int tiler, float scale, int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
-                            int64_t* n_frames_out) {
+static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,
+                            int64_t audio_stride, int overlap, int tiler, float scale, int eps_mode, int tie_mode,
+                            float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out) {
     if (!pcm_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: pcm_d is null");
     if (!m) DCS_FAIL(DCS_EINVAL, "dcs_separate: null model");
     static const bool graphs_on = !(getenv("DCS_GRAPH") && atoi(getenv("DCS_GRAPH")) == 0);
@@ -480,6 +502,7 @@ extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     dcs_model::StepKey key;
     key.plan = plan; key.audio = audio_d; key.pcm = pcm_d; key.ws = m->ws.ptr; key.L = n_samples; key.ov = overlap;
     key.tiler = tiler; key.eps = eps_mode; key.tie = tie_mode; key.scale = scale;
+    key.n_clips = n_clips; key.audio_stride = audio_stride;
     if (can_graph && m->step_exec && m->captured == key) {
         DCS_HIP(hipGraphLaunch(m->step_exec, m->ctx->stream));
         if (n_tiles_out) *n_tiles_out = m->step_tiles;
@@ -492,7 +515,7 @@ extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, 
         int64_t nt = 0, nf = 0;
         DCS_HIP(hipStreamBeginCapture(m->ctx->stream, hipStreamCaptureModeRelaxed));
         const int rc = separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
-                                     nullptr, nullptr, 0, &nt, &nf);
+                                     nullptr, nullptr, 0, &nt, &nf, n_clips, audio_stride);
         const hipError_t ce = hipStreamEndCapture(m->ctx->stream, &graph);
         if (rc != DCS_OK || ce != hipSuccess || !graph || m->ws.ptr != key.ws) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -501,7 +524,7 @@ extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, 
             if (rc != DCS_OK) return rc;
             // capture failed: run this call eagerly and stop trying for this key
             return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
-                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out);
+                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);
         }
         if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
         m->step_exec = nullptr;
@@ -512,7 +535,7 @@ extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, 
             m->seen = dcs_model::StepKey();
             (void)hipGetLastError();
             return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
-                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out);
+                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);
         }
         m->captured = key;
         m->step_tiles = nt;
@@ -523,12 +546,26 @@ extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, 
         return DCS_OK;
     }
     const int rc = separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
-                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out);
+                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);
     if (rc == DCS_OK) {
         key.ws = m->ws.ptr;  // the first call may have grown the workspace
         m->seen = key;
     }
     return rc;
+}
+
+extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
+                            int tiler, float scale, int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
+                            int64_t* n_frames_out) {
+    return separate_graphed(m, plan, audio_d, n_samples, 1, 0, overlap, tiler, scale, eps_mode, tie_mode, pcm_d,
+                            n_tiles_out, n_frames_out);
+}
+
+extern "C" int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples,
+                                  int64_t n_clips, int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode,
+                                  int tie_mode, float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out) {
+    return separate_graphed(m, plan, audio_d, n_samples, n_clips, n_clips > 1 ? clip_stride : 0, overlap, tiler, scale,
+                            eps_mode, tie_mode, pcm_d, n_tiles_out, n_frames_out);
 }
 
 extern "C" int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,

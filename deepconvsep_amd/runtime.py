@@ -247,6 +247,25 @@ class Network(object):
         self.last_tiles, self.last_frames = nt.value, nf.value
         return out
 
+    def separate_batch(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None, tie_mode=TIE_ALL,
+                       out=None):
+        """Fused path for equal-length clips sharing one set of launches: ``[B, L]`` float32 device tensor
+        (rows contiguous) -> ``[B, S, L]`` float32 PCM; every clip gets the tiles and cross-fade :meth:`separate`
+        would give it alone (DSD / hiphop graph)."""
+        torch = _torch()
+        if audio_t.dim() != 2 or audio_t.stride(1) != 1:
+            raise ValueError("separate_batch expects a [clips, samples] tensor with contiguous rows")
+        B, L = int(audio_t.shape[0]), int(audio_t.shape[1])
+        if out is None:
+            out = torch.empty((B, self.S, L), dtype=torch.float32, device=audio_t.device)
+        eps = self.arch.eps_mode if eps_mode is None else eps_mode
+        nt, nf = c_int64(), c_int64()
+        _lib.check(self.ctx._lib.dcs_separate_batch(self._h, plan._h, _ptr(audio_t), L, B, int(audio_t.stride(0)),
+                                                    int(overlap), int(tiler), float(scale), int(eps), int(tie_mode),
+                                                    _ptr(out), byref(nt), byref(nf)))
+        self.last_tiles, self.last_frames = nt.value, nf.value
+        return out
+
     def separate_spectra(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None,
                          tie_mode=TIE_ALL):
         """Fused path stopped before the iSTFT: (sep ``[S,T,F]``, mag ``[T,F]``, phase ``[T,F]``)."""

@@ -142,6 +142,17 @@ int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_s
                  float scale, int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
                  int64_t* n_frames_out);
 
+/* The same pipeline for n_clips mono signals of EQUAL length in one set of launches (the batch-of-files
+ * driver of SURVEY 8f.1 / separate_multiple.ipynb; equal-length segments of one long file): clip c starts at
+ * audio_d + c * clip_stride (clip_stride >= n_samples), pcm_d [n_clips][S][n_samples].  Every clip is processed
+ * exactly as dcs_separate would process it alone (same tiles, same cross-fade) -- the clips only share kernel
+ * launches; outputs agree with the single-clip call to fp32 rounding (the FFT / GEMM kernel variants are
+ * chosen by the total amount of work).  DSD / hiphop graph only (DCS_EUNSUPPORTED otherwise: loop over
+ * dcs_separate).  n_tiles_out / n_frames_out are per clip. */
+int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,
+                       int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode, int tie_mode,
+                       float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out);
+
 /* Same pipeline stopped before the iSTFT: sep_d [S][n_frames, ld_out] (scaled magnitudes, what the
  * reference calls mm[i,:len(ph)]) and phase_d [n_frames, ld_out]; either may be NULL. */
 int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Quick GPU visit: parity tests + bench variants (no rocprof).  Output in gpurun_out/quick_*.
-#   DCS_VARIANTS="default S8 ENV=VAL ..."   (S<k> = --streams k; NAME=VAL exported for that run)
+#   DCS_VARIANTS="default S8 B16 B8S3 ENV=VAL ..."   (S<k> = --streams k; B<b> = --clips-per-launch b; NAME=VAL exported)
 set -u
 OUT=gpurun_out; mkdir -p $OUT
 if [ "${DCS_SKIP_TESTS:-0}" != "1" ]; then
@@ -10,15 +10,17 @@ for v in ${DCS_VARIANTS:-default}; do
   envs=""; extra=""
   case $v in
     default) ;;
+    B[0-9]*S[0-9]*) b=${v#B}; extra="--clips-per-launch ${b%%S*} --streams ${v##*S}";;
     S[0-9]*) extra="--streams ${v#S}";;
+    B[0-9]*) extra="--clips-per-launch ${v#B}";;
     *) envs="$v";;
   esac
   echo "== bench variant $v ($envs $extra)"
-  env $envs timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline $extra > $OUT/quick_bench_$v.json 2> $OUT/quick_bench_$v.err; echo "exit $?"; tail -n 3 $OUT/quick_bench_$v.err
+  env $envs timeout 600 python bench.py --steps 400 --warmup 40 --no-cpu-baseline $extra > $OUT/quick_bench_$v.json 2> $OUT/quick_bench_$v.err; echo "exit $?"; tail -n 3 $OUT/quick_bench_$v.err
   python - <<PY
 import json
 d=json.load(open("$OUT/quick_bench_$v.json"))
-print("32t x%d streams: value %.0f ms/step %.4f frac %.4f (final %.4f ms)" % (d['config']['streams_per_gpu'], d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_kernel_ms']))
+print("32t x%d clips/launch x%d streams: value %.0f ms/step %.4f frac %.4f (final %.4f ms)" % (d['config']['clips_per_launch'], d['config']['streams_per_gpu'], d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_kernel_ms']))
 s1=d['single_stream']; print("32t single: value %.0f ms/step %.4f frac %.4f" % (s1['value'], s1['ms_per_step'], s1['roofline']['frac']), s1['kernels_ms'])
 s=d['saturating']; print("SAT: value %.0f ms/step %.4f frac %.4f" % (s['value'], s['ms_per_step'], s['roofline']['frac']), s['kernels_ms'])
 PY

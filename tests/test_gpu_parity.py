@@ -467,6 +467,43 @@ def test_graph_replay_recomputes_on_a_side_stream():
     assert np.max(np.abs(other - res[0])) > 1e-3
 
 
+@pytest.mark.parametrize("N,seconds,clips,tiler", [(1024, 1.0, 3, "script"), (2048, 2.14, 8, "script"),
+                                                     (1024, 0.9, 5, "library")])
+def test_separate_batch_equals_clip_by_clip(N, seconds, clips, tiler):
+    """dcs_separate_batch: equal-length clips sharing one set of launches are each separated exactly as
+    dcs_separate separates them alone -- same tiles, same cross-fade; only fp32 rounding may differ, because the
+    FFT / GEMM kernel variants are picked by the total amount of work -- and match the oracle."""
+    import torch
+    F = N // 2 + 1
+    params = synth_params("dsd", 30, F, seed=2)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, N, 512, np.hanning, tiler=tiler)
+    L = int(44100 * seconds)
+    audio = np.stack([synth_audio(L, seed=40 + c) for c in range(clips)]).astype(np.float32)
+    audio[1, L // 3: L // 2] = 0.0                               # a digital-silence gap in one clip
+    buf = sep.ctx.to_device(audio, np.float32)
+    got = sep.net.separate_batch(sep.plan, buf, 25, sep.tiler, 0.3).cpu().numpy()
+    assert got.shape == (clips, 4, L)
+    for c in range(clips):
+        alone = sep.net.separate(sep.plan, buf[c], 25, sep.tiler, 0.3).cpu().numpy()
+        assert np.max(np.abs(got[c] - alone)) < 2e-6, "clip %d differs from the single-clip path" % c
+    want = pipeline.separate("dsd", params, audio[1].astype(np.float64), 0.3, 30, 25, 32, N, 512, np.hanning,
+                             tiler=tiling_np.SCRIPT if tiler == 'script' else tiling_np.LIBRARY)
+    assert np.max(np.abs(got[1] - want)) < 1e-4
+    # a strided view (clip stride > length) goes through the same entry point
+    wide = sep.ctx.to_device(np.concatenate([audio, np.zeros((clips, 37), np.float32)], axis=1), np.float32)
+    got2 = sep.net.separate_batch(sep.plan, wide[:, :L], 25, sep.tiler, 0.3).cpu().numpy()
+    assert np.array_equal(got2, got)
+
+
+def test_separate_batch_rejects_other_graphs():
+    import torch
+    params = synth_params("ikala", 30, 513, seed=1)
+    sep = dcs.Separator("ikala", params, 0.3, 30, 20, 32, 513, 1024, 512, np.hanning)
+    buf = sep.ctx.to_device(np.zeros((2, 30000), np.float32), np.float32)
+    with pytest.raises(NotImplementedError):                    # DCS_EUNSUPPORTED: loop over separate() instead
+        sep.net.separate_batch(sep.plan, buf, 20, sep.tiler, 0.3)
+
+
 @pytest.mark.parametrize("arch,F,n", [("bach10", 257, 4), ("ikala", 513, 3)])
 def test_f16_mfma_conv_path_stated_tolerance(arch, F, n):
     """BASELINE config 3: conv2 and its transpose with f16 inputs / f32 accumulation on the matrix cores.
