@@ -8,13 +8,9 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/traffic_$c -o p -- \
-     python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --sat-tiles 4096 > $OUT/traffic_$c.json 2> $OUT/traffic_$c.err
+     python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 16 --no-cpu-baseline --sat-tiles 4096 > $OUT/traffic_$c.json 2> $OUT/traffic_$c.err
   echo "pmc $c exit $?"
 done
-# also a plain kernel-stats pass of the default bench for profiles/
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_final -o bench -- \
-     python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/prof_final.json 2> $OUT/prof_final.err
-echo "stats exit $?"
 python - <<'PY'
 import csv, glob, os, collections, json
 out=os.environ['GRAFT_REPO_ROOT']+'/gpurun_out'
@@ -33,8 +29,11 @@ doc={'all':{k:res[k] for k in sorted(res)}}
 fin=sorted((int(k.split('=')[1]),k) for k in res if k.startswith('final_kernel@'))
 if fin:
     doc['final_kernel_32_tiles']=res[fin[0][1]]; doc['final_kernel_4096_tiles']=res[fin[-1][1]]
+    if len(fin) >= 3:   # the launch group of the headline run: clips_per_launch x 32 tiles
+        cfg=json.loads(open(out+'/traffic_FETCH_SIZE.json').read().strip().splitlines()[-1])['config']
+        doc['final_kernel_%dx%d_tiles' % (cfg['clips_per_launch'], cfg['tiles_per_gpu_per_step'])]=res[fin[1][1]]
 doc['note']=('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/gpu_traffic.sh), '
-  'bench.py --steps 20 --sat-tiles 4096, MI355X; per launch, KiB (averaged over launches of the same kernel and grid). '
+  'bench.py --steps 32 --sat-tiles 4096, MI355X; per launch, KiB (averaged over launches of the same kernel and grid). '
   'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half the bytes of 16-byte-per-lane coalesced reads; bench.py reports '
   'traffic = 2*FETCH + WRITE as an upper bound.')
 json.dump(doc, open(out+'/traffic.json','w'), indent=1)
