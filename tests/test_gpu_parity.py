@@ -6,10 +6,14 @@ reference's own code and against the CPU oracle on seeded inputs.  Run on the MI
 Tolerances: framing / indexing bit-exact; float64 kernels 1e-11; float32 kernels 1e-4 absolute
 on (scaled) magnitudes per masked bin (BASELINE.json north_star), PCM 1e-4.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import deepconvsep_amd as dcs  # noqa: E402
 from deepconvsep_amd import _lib  # noqa: E402
@@ -542,3 +546,44 @@ def test_f16_mfma_conv_path_stated_tolerance(arch, F, n):
     assert np.abs(f32 - ref).max() < 1e-4
     with pytest.raises(NotImplementedError):
         Network(ctx, "dsd", synth_params("dsd", tc, 513), tc, 513).set_conv_precision('f16')
+
+
+_VARIANT_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepconvsep_amd as dcs
+from deepconvsep_amd.synth import synth_params
+z = np.load(sys.argv[2])
+N = int(z['N']); F = N // 2 + 1
+sep = dcs.Separator('dsd', synth_params('dsd', 30, F, seed=2), 0.3, 30, 25, 32, F, N, 512, np.hanning)
+for rep in range(3):                      # eager, graph capture, graph replay
+    got = sep.separate(z['audio'])
+err = float(np.max(np.abs(got - z['want'])))
+print('max err %.3e' % err)
+sys.exit(0 if err < 1e-4 else 3)
+"""
+
+
+@pytest.mark.parametrize("env", [
+    {"DCS_FINAL_CBW": "2"}, {"DCS_FINAL_CBW": "1"},               # 128- / 64-bin workgroups of the final kernel
+    {"DCS_DECONV2": "2"}, {"DCS_DECONV2": "1"},                   # streaming / one-shot transposed conv2
+    {"DCS_ISTFT_HOPS": "1"}, {"DCS_ISTFT_HOPS": "7"}, {"DCS_ISTFT_HOPS": "64"},   # hop-blocks per iSTFT workgroup
+    {"DCS_STFT_WAVE_MIN": "1"}, {"DCS_FFT_BLOCK": "1"},           # wave-per-frame / block-level FFT everywhere
+    {"DCS_GRAPH": "0"},
+])
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_kernel_variants_selected_by_size_agree_with_the_oracle(env, N, tmp_path):
+    """The launchers pick kernel variants by problem size; the debugging switches force each variant on the
+    same 3 s clip (fresh process: the switches are read once) and every one must meet the parity bar."""
+    import subprocess
+    audio = synth_audio(3 * 44100, seed=77)
+    audio[40000:52000] = 0.0
+    want = pipeline.separate("dsd", synth_params("dsd", 30, N // 2 + 1, seed=2), audio, 0.3, 30, 25, 32, N, 512,
+                             np.hanning)
+    f = tmp_path / "case.npz"
+    np.savez(f, audio=audio, want=want, N=N)
+    child_env = dict(os.environ)
+    child_env.update(env)
+    r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, ROOT, str(f)], env=child_env, capture_output=True,
+                       text=True, timeout=200)
+    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
