@@ -194,13 +194,45 @@ class Separator(object):
         return pcm.cpu().numpy().astype(np.float64)
 
 
+    def separate_scoreinformed(self, audio, melody):
+        """Score-informed separation (examples/bach10_scoreinformed/separate_bach10.py:497-541), stage by stage on the
+        device: STFT -> x scale -> harmonic masks of the score x spectrogram (``dcs_score_masks``) -> library tiler
+        with one input channel per instrument (``util.generate_overlapadd``, :531) -> network (masks from the first
+        ``S`` output channels, mixture = input channel 0, :473-486) -> overlapadd_multi -> iSTFT.
+        ``melody``: note tables ``[instruments, notes, 2*nharmonics+3]`` (``score.melody_table``)."""
+        import torch
+        from .score import score_masks
+        if self.arch.C != np.asarray(melody).shape[0]:
+            raise ValueError("the network takes %d score channels, the note table has %d"
+                             % (self.arch.C, np.asarray(melody).shape[0]))
+        a = self.ctx.to_device(np.asarray(audio), np.float32)
+        mag, ph = self.plan.forward(a, phase=True)
+        T = int(mag.shape[0])
+        mag = mag * np.float32(self.scale_factor)                       # :503
+        inp, _ = score_masks(self.ctx, mag, melody, 0, T)               # :520-527, [C, T, F]
+        tiles, n = tile(self.ctx, inp, self.tc, self.overlap, TILER_LIBRARY, 1.0)
+        outs = []
+        for b0 in range(0, n, self.batch_size):
+            outs.append(self.net.forward_masked(tiles[b0:b0 + self.batch_size], None, self.tie_mode))
+        out = torch.cat(outs, dim=1)
+        mm = overlap_add(self.ctx, out, self.overlap)
+        sep = mm[:, :T].contiguous()
+        pcm = self.plan.inverse(sep, ph, n_out=int(a.numel()), pre_div=self.scale_factor)
+        return pcm.cpu().numpy().astype(np.float64)
+
+
 _SCRIPT_DEFAULTS = {
     # arch: (frameSize, hopSize, window, overlap in main(), input_size)     separate_<x>.py main()
     'dsd': (1024, 512, np.hanning, 25, 513),       # separate_dsd.py:24,332
     'hiphop': (1024, 512, np.hanning, 25, 513),    # separate_hhds.py
     'ikala': (1024, 512, np.hanning, 20, 513),     # separate_ikala.py:24,275
     'bach10': (4096, 512, blackmanharris, 25, 2049),  # separate_bach10.py:282,325
+    'bach10_si': (4096, 512, blackmanharris, 25, 2049),  # bach10_scoreinformed/separate_bach10.py:450,572
 }
+
+# score files next to the wav, one per instrument (bach10_scoreinformed/separate_bach10.py:455)
+SI_SCORE_FILES = ['bassoon_b.txt', 'clarinet_b.txt', 'saxophone_b.txt', 'violin_b.txt']
+SI_SCORE_PARAMS = dict(interval=50, tuning_freq=440, nharmonics=20)     # :457-460
 
 
 def output_paths(arch_name, filein, outdir):
@@ -224,11 +256,18 @@ def train_auto(arch_name, filein, outdir, model, scale_factor=0.3, time_context=
     window = d_win if window is None else window
     params = load_model(model) if isinstance(model, str) else model
     sep = Separator(arch_name, params, scale_factor, time_context, overlap, batch_size, input_size, frameSize,
-                    hopSize, window, tiler='script', device=device)
+                    hopSize, window, tiler='library' if arch_name == 'bach10_si' else 'script', device=device)
     sampleRate, audioObj = read_wav(filein)
     if sampleRate == 44100:
         audio = to_mono(audioObj, arch_name)
-        pcm = sep.separate(audio) if fused else sep.separate_stepwise(audio)
+        if arch_name == 'bach10_si':
+            from .score import melody_table
+            nframes = int(np.ceil(len(audio) / np.double(hopSize))) + 2     # :500
+            melody = melody_table(SI_SCORE_FILES, os.path.dirname(filein), nframes, sampleRate, hopSize, frameSize,
+                                  **SI_SCORE_PARAMS)
+            pcm = sep.separate_scoreinformed(audio, melody)
+        else:
+            pcm = sep.separate(audio) if fused else sep.separate_stepwise(audio)
         for path, audio_out in zip(output_paths(arch_name, filein, outdir), pcm):
             write_wav(path, audio_out, sampleRate)
     else:

@@ -159,6 +159,18 @@ int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int
                          int tiler, float scale, int eps_mode, int tie_mode, float* sep_d, float* mag_d,
                          float* phase_d, int64_t ld_out);
 
+/* ------------------------------------------------------------------ score-informed front-end */
+/* filterSpec (examples/bach10_scoreinformed/separate_bach10.py:172-200) and the network input of :520-527.
+ * notes_h: HOST table [ninst][n_notes][width] of doubles exactly as expandMidi returns it (util.py:424-512),
+ * width = 2*nharmonics+3: begin frame, end frame, midi number, then (first bin, one-past-last bin) pairs, zeros
+ * unused.  start/stop: filterSpec's frame window (0, nframes in the script).  Per instrument j the mask is 1 on
+ * the note rectangles and 1e-18 elsewhere, divided by its maximum (so an instrument without notes gets an all-ones
+ * mask, as in the reference).  out_d [ninst][n_frames][F] = mask_j * mag_d (mag_d [n_frames, ld], already scaled by
+ * the caller like :503); mask_d [n_frames][ninst*F] = filterSpec's return value.  Either output may be NULL.
+ * A bin range outside [0, F) is DCS_ESHAPE (NumPy raises IndexError there).  Synchronises the ctx stream. */
+int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
+                    int ninst, int n_notes, int width, int64_t start, int64_t stop, float* out_d, float* mask_d);
+
 /* ------------------------------------------------------------------ timing aid for bench.py */
 /* Average duration (ms) of the kernels tagged `which` since the last reset, measured with HIP events
  * on the ctx stream.  tag_mask bit t enables the tag t (two event records per tagged launch);

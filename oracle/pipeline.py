@@ -45,3 +45,40 @@ def separate(arch, params, audio, scale_factor=0.3, time_context=30, overlap=25,
     if return_spectra:
         return pcm, mm[:, :len(ph)], mag, ph
     return pcm
+
+
+def separate_scoreinformed(params, audio, melody, scale_factor=0.3, time_context=30, overlap=25, batch_size=32,
+                           frameSize=4096, hopSize=512, window=None, tie_mode='all', return_input=False):
+    """``examples/bach10_scoreinformed/separate_bach10.py:497-541``: the network input is one channel per instrument,
+    ``filterSpec`` mask x scaled magnitudes (:520-527); tiles come from the LIBRARY tiler (:531, ``util.
+    generate_overlapadd``, ``toverlap`` there is an undefined name -- the script's ``overlap`` is meant); the masks
+    are built from the first four output channels and applied to input channel 0 (:473-486); ``overlapadd_multi``
+    and the iSTFT as in the other scripts."""
+    from . import score_np
+    if window is None:
+        from scipy.signal.windows import blackmanharris as window
+    audio = np.asarray(audio, dtype=np.float64)
+    nframes = int(np.ceil(len(audio) / np.double(hopSize))) + 2
+    mag, ph = stft_np.compute_file(audio, phase=True, frameSize=frameSize, hopSize=hopSize, window=window)
+    mag = scale_factor * mag.astype(np.float32)
+    masks = score_np.network_input(mag, np.asarray(melody), nframes)          # [C, T, F] float64
+    batches, nchunks = tiling_np.generate_overlapadd(masks, masks.shape[-1], time_context, overlap, batch_size,
+                                                     tiler=tiling_np.LIBRARY, fill=0.0)
+    if nchunks == 0:
+        raise IndexError("tuple index out of range")
+    output = []
+    for batch in batches:
+        output.append(net_ref.predict('bach10_si', params, batch, tie_mode=tie_mode))
+    output = np.array(output)
+    mm = tiling_np.overlapadd_multi(output, nchunks, overlap=overlap)
+    pcm = []
+    for i in range(mm.shape[0]):
+        audio_out = stft_np.compute_inverse(mm[i, :len(ph)] / scale_factor, ph, frameSize=frameSize,
+                                            hopSize=hopSize, window=window)
+        if len(audio_out) > len(audio):
+            audio_out = audio_out[:len(audio)]
+        pcm.append(audio_out)
+    pcm = np.stack(pcm)
+    if return_input:
+        return pcm, masks
+    return pcm

@@ -30,6 +30,14 @@ _SLICES = {
     "lib_stft": ("transform.py", 277, 396),
     # library: generate_overlapadd (zero-padding tiler), overlapadd, overlapadd_multi
     "lib_tiling": ("util.py", 220, 327),
+    # score-informed front-end.  library: MIDI constants + midi2freq, remove_overlap, slicefft_slices + getfreqs,
+    # expandMidi, getMidiNum + str2midi; script: filterSpec
+    "lib_midi_const": ("util.py", 123, 127),
+    "lib_remove_overlap": ("util.py", 140, 157),
+    "lib_slices": ("util.py", 171, 191),
+    "lib_expandmidi": ("util.py", 424, 512),
+    "lib_midinum": ("util.py", 526, 606),
+    "script_si_filterspec": ("examples/bach10_scoreinformed/separate_bach10.py", 172, 200),
 }
 
 
@@ -57,6 +65,40 @@ def load(name):
         # stft_norm's default argument calls sinebell() at def time
         exec(compile(_slice(*_SLICES["lib_sinebell"]), "transform.py[sinebell]", "exec"), ns)
     exec(compile(_slice(relpath, first, last), relpath, "exec"), ns)
+    return ns
+
+
+class _NpText(object):
+    """numpy with ONE Python-2 text semantic restored: ``genfromtxt(dtype=[..., "S3"])`` yields ``str`` note names
+    (under Python 3 they would be ``bytes`` and str2midi's character tests would compare ints)."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def genfromtxt(fname, **kw):
+        dt = kw.get("dtype")
+        if isinstance(dt, (list, tuple)):
+            kw["dtype"] = [d.replace("S", "U") if isinstance(d, str) else d for d in dt]
+        return np.genfromtxt(fname, **kw)
+
+
+def score():
+    """expandMidi / getMidiNum / filterSpec and their helpers, executed from the reference tree.  Python-2 names the
+    bodies expect are supplied: ``filter`` returning a list, ``bisect``/``itertools`` imports of util.py:28-29,
+    ``nan``.  Integer divisions: ``samplerate / hop`` only appears inside ``round(float(...))`` or multiplied and
+    rounded, and ``size/2+1`` in a comparison -- for sr=44100 and the hop sizes used here (512, 256, 441) Python 2
+    and 3 give the same integers (checked in tests/test_oracle_golden.py)."""
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    import bisect
+    import itertools
+    ns = _NS(np=_NpText(), os=os, bisect_left=bisect.bisect_left, bisect_right=bisect.bisect_right, it=itertools,
+             nan=float("nan"), filter=lambda f, xs: [x for x in xs if f(x)], pickle=None, __name__="ref_exec.score")
+    for name in ("lib_midi_const", "lib_remove_overlap", "lib_slices", "lib_expandmidi", "lib_midinum",
+                 "script_si_filterspec"):
+        relpath, first, last = _SLICES[name]
+        exec(compile(_slice(relpath, first, last), relpath, "exec"), ns)
     return ns
 
 

@@ -109,6 +109,41 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         print(name, sep.shape)
 
+    # ---- score-informed front-end: util.expandMidi / getMidiNum / script filterSpec ---------------
+    import tempfile
+    from oracle import score_np
+    sc = ref_exec.score()
+    for name, N, hop, seconds, seed in [("score_n4096_hop512", 4096, 512, 10.0, 301),
+                                        ("score_n1024_hop512", 1024, 512, 4.0, 302),
+                                        ("score_n2048_hop256", 2048, 256, 5.0, 303)]:
+        L = int(seconds * 44100)
+        nframes = int(np.ceil(L / np.double(hop))) + 2
+        F = N // 2 + 1
+        with tempfile.TemporaryDirectory() as d:
+            texts, tables, nums = [], [], []
+            insts = ["bassoon_b", "clarinet_b", "saxophone_b", "violin_b"]
+            for i, ins in enumerate(insts):
+                pth = score_np.synth_score(os.path.join(d, ins + ".txt"), seed * 10 + i, n_notes=40,
+                                           total=seconds + 1.5, lo=36 + 6 * i, hi=60 + 8 * i)
+                texts.append(open(pth).read())
+                tables.append(sc.expandMidi(ins, d, 0, 40.0, 50, 440, 20, 44100, hop, N, 0.2, 0.2, nframes, 0.5))
+                nums.append(sc.getMidiNum(ins, d, 0, 40.0))
+            P = max(max(nums), 1)
+            melody = np.zeros((4, P, 43))
+            for i, t in enumerate(tables):
+                melody[i, :t.shape[0]] = t
+            mag = (0.3 * np.abs(np.random.RandomState(seed).randn(nframes, F)).astype(np.float32)).astype(np.float32)
+            mask = sc.filterSpec(mag, melody, 4, 0, nframes)
+            # a window that does not start at 0 and an instrument without notes (all-ones mask)
+            melody2 = melody.copy()
+            melody2[2] = 0
+            mask_win = sc.filterSpec(mag[40:140], melody2, 4, 40, 140)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), frame=N, hop=hop, n_samples=L, nframes=nframes,
+                            texts=np.array(texts), melody=melody, nums=np.array(nums), mag_seed=seed,
+                            mask_rowsum=mask.astype(np.float64).sum(axis=1), mask_colsum=mask.astype(np.float64).sum(axis=0),
+                            mask_ones=np.int64((mask == 1).sum()), mask_win=mask_win)
+        print(name, melody.shape, nums, int((mask == 1).sum()))
+
 
 if __name__ == "__main__":
     main()

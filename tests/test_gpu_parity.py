@@ -587,3 +587,104 @@ def test_kernel_variants_selected_by_size_agree_with_the_oracle(env, N, tmp_path
     r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, ROOT, str(f)], env=child_env, capture_output=True,
                        text=True, timeout=200)
     assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
+
+
+# ------------------------------------------------------------------ score-informed path
+SI_INSTS = ["bassoon_b", "clarinet_b", "saxophone_b", "violin_b"]
+
+
+def _golden_scores(g, d):
+    for ins, text in zip(SI_INSTS, g["texts"]):
+        (d / (ins + ".txt")).write_text(str(text))
+
+
+@pytest.mark.parametrize("name", ["score_n4096_hop512", "score_n1024_hop512", "score_n2048_hop256"])
+def test_score_masks_match_the_reference_filterSpec(golden, name, tmp_path):
+    """dcs_score_masks against the masks the reference's own filterSpec produced (golden) and against the oracle's
+    mask x spectrogram products: binary float32 masks and single float32 products -- bit exact."""
+    from deepconvsep_amd import score
+    from oracle import score_np
+    g = golden(name)
+    N, nframes = int(g["frame"]), int(g["nframes"])
+    rs = np.random.RandomState(int(g["mag_seed"]))
+    mag = (0.3 * np.abs(rs.randn(nframes, N // 2 + 1)).astype(np.float32)).astype(np.float32)
+    ctx = default_context()
+    mag_t = ctx.to_device(mag, np.float32)
+    inp, mask = score.score_masks(ctx, mag_t, g["melody"], 0, nframes, want_input=True, want_mask=True)
+    mask = mask.cpu().numpy()
+    assert int((mask == 1).sum()) == int(g["mask_ones"])
+    assert np.array_equal(mask.astype(np.float64).sum(axis=1), g["mask_rowsum"])
+    assert np.array_equal(mask.astype(np.float64).sum(axis=0), g["mask_colsum"])
+    want = score_np.network_input(mag, g["melody"], nframes)
+    assert np.array_equal(inp.cpu().numpy().astype(np.float64), want)
+    # frame window not starting at 0, one instrument without notes (all-ones mask), drop-in filterSpec signature
+    melody2 = g["melody"].copy()
+    melody2[2] = 0
+    got = score.filterSpec(mag[40:140], melody2, 4, 40, 140)
+    assert got.dtype == np.float32 and np.array_equal(got, g["mask_win"])
+    # a strided spectrogram (rows padded) and fewer instruments than table rows
+    wide = ctx.to_device(np.concatenate([mag, np.zeros((nframes, 3), np.float32)], axis=1), np.float32)
+    inp2, _ = score.score_masks(ctx, wide[:, :mag.shape[1]], g["melody"][:2], 0, nframes)
+    assert np.array_equal(inp2.cpu().numpy(), inp.cpu().numpy()[:2])
+    bad = g["melody"].copy()
+    bad[0, 0, 4] = N // 2 + 5                                        # bin range past the spectrum: IndexError in NumPy
+    with pytest.raises(ValueError):
+        score.score_masks(ctx, mag_t, bad, 0, nframes)
+
+
+@pytest.mark.parametrize("N,seconds", [(1024, 3.0), (4096, 2.0)])
+def test_scoreinformed_separation_matches_oracle(N, seconds, tmp_path):
+    """The whole score-informed path (STFT, harmonic masks x spectrogram, 4-channel library tiling, network, mask on
+    input channel 0, cross-fade, iSTFT) against oracle.pipeline.separate_scoreinformed."""
+    from scipy.signal.windows import blackmanharris
+    from deepconvsep_amd import score
+    from oracle import score_np
+    F = N // 2 + 1
+    L = int(seconds * 44100)
+    audio = synth_audio(L, seed=91)
+    audio[L // 2: L // 2 + 6000] = 0.0
+    for i, ins in enumerate(SI_INSTS):
+        score_np.synth_score(str(tmp_path / (ins + ".txt")), 700 + i, n_notes=16, total=seconds + 0.5, lo=40 + 5 * i,
+                             hi=64 + 6 * i)
+    nframes = int(np.ceil(L / 512.0)) + 2
+    melody = score.melody_table([i + ".txt" for i in SI_INSTS], str(tmp_path), nframes, 44100, 512, N)
+    params = synth_params("bach10_si", 30, F, seed=5)
+    sep = dcs.Separator("bach10_si", params, 0.3, 30, 25, 32, F, N, 512, blackmanharris, tiler='library')
+    got = sep.separate_scoreinformed(audio, melody)
+    want = pipeline.separate_scoreinformed(params, audio, melody, 0.3, 30, 25, 32, N, 512, blackmanharris)
+    assert got.shape == want.shape == (4, L)
+    assert np.max(np.abs(got - want)) < 1e-4
+    assert np.max(np.abs(want)) > 1e-3
+
+
+def test_scoreinformed_command_line(tmp_path):
+    """examples/bach10_scoreinformed/separate_bach10.py end to end on a 1.5 s wav with its four score files."""
+    import importlib.util
+    import scipy.io.wavfile
+    from scipy.signal.windows import blackmanharris
+    from oracle import score_np
+    L = int(1.5 * 44100)
+    audio = synth_audio(L, seed=92)
+    wav = tmp_path / "mix.wav"
+    scipy.io.wavfile.write(str(wav), 44100, (audio * 32767).astype(np.int16))
+    for i, ins in enumerate(SI_INSTS):
+        score_np.synth_score(str(tmp_path / (ins + ".txt")), 800 + i, n_notes=10, total=2.0, lo=40 + 5 * i, hi=64 + 6 * i)
+    params = synth_params("bach10_si", 30, 2049, seed=6)
+    model = tmp_path / "model.pkl"
+    dcs.save_model(str(model), params)
+    out = tmp_path / "out"
+    out.mkdir()
+    spec = importlib.util.spec_from_file_location("si_cli", os.path.join(ROOT, "examples", "bach10_scoreinformed",
+                                                                         "separate_bach10.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    cli.main(["-i", str(wav), "-o", str(out), "-m", str(model)])
+    sr, a16 = scipy.io.wavfile.read(str(wav))
+    a = a16.astype('float') / 32767
+    nframes = int(np.ceil(len(a) / 512.0)) + 2
+    melody = score_np.melody_table([str(tmp_path / (i + ".txt")) for i in SI_INSTS], nframes, 44100, 512, 4096)
+    want = pipeline.separate_scoreinformed(params, a, melody, 0.3, 30, 25, 32, 4096, 512, blackmanharris)
+    for i, s in enumerate(["bassoon", "clarinet", "saxphone", "violin"]):
+        sr2, got = scipy.io.wavfile.read(str(out / ("mix_%s.wav" % s)))
+        assert sr2 == 44100 and got.dtype == np.int16 and len(got) == L
+        assert np.max(np.abs(got.astype(np.int64) - (want[i] * 32767).astype('int16').astype(np.int64))) <= 2

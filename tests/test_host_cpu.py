@@ -101,3 +101,52 @@ def test_mono_mixdown_rules():
     np.testing.assert_allclose(to_mono(st[:, 0], "dsd"), st[:, 0])
     with pytest.raises(IndexError):
         to_mono(st[:, 0], "ikala")
+
+
+# ------------------------------------------------------------------ score-informed front-end, host logic
+@pytest.mark.parametrize("name", ["score_n4096_hop512", "score_n1024_hop512", "score_n2048_hop256"])
+def test_product_note_tables_match_the_reference(golden, name, tmp_path):
+    """deepconvsep_amd.score (the shipped host code: vectorised, own structure) against the tables the reference's
+    own expandMidi / getMidiNum produced (tests/golden/score_*.npz) -- integers, bit exact."""
+    from deepconvsep_amd import score
+    g = golden(name)
+    insts = ["bassoon_b", "clarinet_b", "saxophone_b", "violin_b"]
+    for ins, text in zip(insts, g["texts"]):
+        (tmp_path / (ins + ".txt")).write_text(str(text))
+    N, hop, nframes = int(g["frame"]), int(g["hop"]), int(g["nframes"])
+    for i, ins in enumerate(insts):
+        assert score.getMidiNum(ins, str(tmp_path), 0, 40.0) == int(g["nums"][i])
+        t = score.expandMidi(ins, str(tmp_path), 0, 40.0, 50, 440, 20, 44100, hop, N, 0.2, 0.2, nframes, 0.5)
+        assert t.dtype == np.float64 and np.array_equal(t, g["melody"][i, :t.shape[0]])
+        # the script passes file names with their extension (separate_bach10.py:455), util.py appends it (:426)
+        t2 = score.expandMidi(ins + ".txt", str(tmp_path), 0, 40.0, 50, 440, 20, 44100, hop, N, 0.2, 0.2, nframes, 0.5)
+        assert np.array_equal(t, t2)
+    mel = score.melody_table([i + ".txt" for i in insts], str(tmp_path), nframes, 44100, hop, N)
+    assert np.array_equal(mel, g["melody"])
+
+
+def test_product_score_helpers_against_the_oracle(tmp_path):
+    from deepconvsep_amd import score
+    from oracle import score_np
+    for note in ("C4", "A4", "Bb3", "F#5", "Cx2", "Db1", "B0", "G9", "a#4", " E3"):
+        assert score.str2midi(note) == score_np.str2midi(note)
+    assert np.isnan(score.str2midi("?"))
+    for midi in (24, 36, 45.0, 60, 72, 84, 96, 108, 120):
+        for N, itv, nh in ((4096, 50, 20), (1024, 30, 20), (2048, 100, 12)):
+            want = score_np.slicefft_ranges(midi, N, interval=itv, nharmonics=nh)
+            got = score.harmonic_bins(midi, N, interval=itv, nharmonics=nh)
+            assert got.tolist() == [list(r) for r in want]
+    assert score.harmonic_bins(float("nan"), 4096).shape == (0, 2) and score.harmonic_bins(0, 4096).shape == (0, 2)
+    # windows, tunings and time spans other than the script's, and a single-note score (reference returns None)
+    for seed in range(12):
+        p = score_np.synth_score(str(tmp_path / "v_b.txt"), 500 + seed, n_notes=26, total=11.0)
+        for args in ((0, 40.0, 50, 440, 20, 44100, 512, 4096, 0.2, 0.2, 864, 0.5),
+                     (2.0, 8.0, 30, 442, 20, 44100, 512, 4096, 0.1, 0.3, 500, 0.0),
+                     (1.0, 6.5, 80, 415, 10, 44100, 256, 1024, 0.05, 0.0, 900, 1.0)):
+            want = score_np.expandMidi(p, *args)
+            got = score.expandMidi("v_b", str(tmp_path), *args)
+            assert np.array_equal(got, want)
+            assert score.getMidiNum("v_b", str(tmp_path), args[0], args[1]) == score_np.getMidiNum(p, args[0], args[1])
+    (tmp_path / "one_b.txt").write_text("0.5,1.5,C4\n")
+    assert score.expandMidi("one_b", str(tmp_path), 0, 40.0, 50, 440, 20, 44100, 512, 4096, 0.2, 0.2, 100, 0.5) is None
+    assert score.getMidiNum("one_b", str(tmp_path), 0, 40.0) == 1

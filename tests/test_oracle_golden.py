@@ -79,3 +79,70 @@ def test_live_reference_agrees_on_fresh_input():
         assert np.array_equal(m0, m1) and np.array_equal(p0, p1)
         assert np.array_equal(ref.compute_inverse(m0, p0, frameSize=N, hopSize=hop),
                               stft_np.compute_inverse(m1, p1, frameSize=N, hopSize=hop))
+
+
+# ------------------------------------------------------------------ score-informed front-end
+SCORE_CASES = ["score_n4096_hop512", "score_n1024_hop512", "score_n2048_hop256"]
+SCORE_INSTS = ["bassoon_b", "clarinet_b", "saxophone_b", "violin_b"]
+
+
+def write_scores(g, d):
+    paths = []
+    for ins, text in zip(SCORE_INSTS, g["texts"]):
+        p = d / (ins + ".txt")
+        p.write_text(str(text))
+        paths.append(str(p))
+    return paths
+
+
+def golden_mag(g):
+    N = int(g["frame"])
+    rs = np.random.RandomState(int(g["mag_seed"]))
+    return (0.3 * np.abs(rs.randn(int(g["nframes"]), N // 2 + 1)).astype(np.float32)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", SCORE_CASES)
+def test_score_oracle_matches_reference_tables_and_masks(golden, name, tmp_path):
+    from oracle import score_np
+    g = golden(name)
+    paths = write_scores(g, tmp_path)
+    N, hop, nframes = int(g["frame"]), int(g["hop"]), int(g["nframes"])
+    for i, p in enumerate(paths):
+        t = score_np.expandMidi(p, 0, 40.0, 50, 440, 20, 44100, hop, N, 0.2, 0.2, nframes, 0.5)
+        assert score_np.getMidiNum(p, 0, 40.0) == int(g["nums"][i])
+        assert np.array_equal(t, g["melody"][i, :t.shape[0]])
+        assert not g["melody"][i, t.shape[0]:].any()
+    assert np.array_equal(score_np.melody_table(paths, nframes, 44100, hop, N), g["melody"])
+    mag = golden_mag(g)
+    mask = score_np.filterSpec(mag, g["melody"], 4, 0, nframes)
+    assert mask.dtype == np.float32 and int((mask == 1).sum()) == int(g["mask_ones"])
+    assert np.array_equal(mask.astype(np.float64).sum(axis=1), g["mask_rowsum"])
+    assert np.array_equal(mask.astype(np.float64).sum(axis=0), g["mask_colsum"])
+    melody2 = g["melody"].copy()
+    melody2[2] = 0
+    assert np.array_equal(score_np.filterSpec(mag[40:140], melody2, 4, 40, 140), g["mask_win"])
+
+
+@pytest.mark.skipif(not ref_exec.available(), reason="reference tree only exists in the build container")
+def test_live_reference_score_code_agrees_on_fresh_scores(tmp_path):
+    """The reference's own expandMidi / getMidiNum / filterSpec (Python-2 bodies executed with the shims of
+    oracle.ref_exec.score) against the restatement, many seeded scores, three (frameSize, hop) pairs and a window
+    that does not start at zero.  For sr = 44100 and these hops Python 2's integer ``samplerate / hop`` and Python 3's
+    true division give the same frame numbers, which is what makes the executed reference a valid pin."""
+    from oracle import score_np
+    sc = ref_exec.score()
+    for hop in (512, 256, 441):
+        assert round(float(44100 / hop)) == round(float(44100 // hop))
+        assert int(round(0.2 * float(44100 / hop))) == int(round(0.2 * float(44100 // hop)))
+    for seed in range(25):
+        p = score_np.synth_score(str(tmp_path / "s_b.txt"), seed, n_notes=30, total=12.0 if seed % 2 else 9.5)
+        for hop, N, nfr in ((512, 4096, 864), (256, 1024, 1725), (441, 2048, 1002)):
+            a = sc.expandMidi("s_b", str(tmp_path), 0, 40.0, 50, 440, 20, 44100, hop, N, 0.2, 0.2, nfr, 0.5)
+            b = score_np.expandMidi(p, 0, 40.0, 50, 440, 20, 44100, hop, N, 0.2, 0.2, nfr, 0.5)
+            assert np.array_equal(a, b)
+            assert sc.getMidiNum("s_b", str(tmp_path), 0, 40.0) == score_np.getMidiNum(p, 0, 40.0)
+        a = sc.expandMidi("s_b", str(tmp_path), 2.0, 8.0, 30, 442, 20, 44100, 512, 4096, 0.1, 0.3, 500, 0.0)
+        b = score_np.expandMidi(p, 2.0, 8.0, 30, 442, 20, 44100, 512, 4096, 0.1, 0.3, 500, 0.0)
+        assert np.array_equal(a, b)
+    for note in ("C4", "A4", "Bb3", "F#5", "Cx2", "Db1", "B0", "E10"[:3]):
+        assert sc.str2midi(note) == score_np.str2midi(note)
