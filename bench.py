@@ -78,10 +78,15 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs; there is no CPU path to measure")
+    if os.environ.get("DCS_BENCH_SAME_DEVICE"):                 # code-path check of the N > 1 leg on a 1-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("DCS_BENCH_SAME_DEVICE"):             # RCCL refuses two ranks on one GPU: gloo for the check
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import deepconvsep_amd as dcs
     from deepconvsep_amd import _lib
@@ -100,6 +105,8 @@ def main():
     NS = max(1, args.streams)
     CPL = max(1, args.clips_per_launch)
 
+    import ctypes
+
     class Lane(object):                                      # one HIP stream with everything it needs
         def __init__(self, idx):
             self.stream = torch.cuda.Stream()
@@ -109,15 +116,18 @@ def main():
                 self.audio_h = np.stack([synth_audio(L, seed=100 + (rank * 16 + idx) * CPL + c) for c in range(CPL)])
                 self.audio = self.ctx.to_device(self.audio_h, np.float32)          # [CPL, L]
                 self.pcm = torch.empty((CPL, 4, L), dtype=torch.float32, device=self.audio.device)
-                self.gathered = (torch.empty((world * CPL * 4, L), dtype=torch.float32, device=self.audio.device)
+                # multi-GPU: the separated PCM is gathered in the wav sample format (int16, separate_dsd.py:307-309);
+                # RCCL has no int16 type, so the buffers travel as bytes
+                self.pcm16 = torch.empty((CPL * 4, L), dtype=torch.int16, device=self.audio.device) if world > 1 else None
+                self.gathered = (torch.empty((world * CPL * 4, L), dtype=torch.int16, device=self.audio.device)
                                  if world > 1 else None)
             self.stream.synchronize()
             # the C entry point with its arguments bound once: dcs_separate_batch() enqueues on the context's
             # own stream, so the host cost of a launch group is one ctypes call (and, from the second identical
             # call on, one hipGraphLaunch inside it)
-            import ctypes
             net, plan = self.sep.net, self.sep.plan
             self._fn = self.ctx._lib.dcs_separate_batch
+            self._to16 = self.ctx._lib.dcs_pcm_to_int16
             self._args = lambda nclips: (net._h, plan._h, ctypes.c_void_p(self.audio.data_ptr()), L, nclips, L, OV,
                                          TILER_SCRIPT, ctypes.c_float(SCALE), net.arch.eps_mode, 0,
                                          ctypes.c_void_p(self.pcm.data_ptr()), None, None)
@@ -131,9 +141,14 @@ def main():
             if rc:
                 _lib.check(rc)
             if world > 1:
+                rc = self._to16(self.ctx._h, ctypes.c_void_p(self.pcm.data_ptr()), nclips * 4 * L,
+                                ctypes.c_void_p(self.pcm16.data_ptr()))
+                if rc:
+                    _lib.check(rc)
                 with torch.cuda.stream(self.stream):
                     # RCCL over xGMI: the final gather of the separated PCM
-                    dist.all_gather_into_tensor(self.gathered[: world * nclips * 4], self.pcm.view(-1, L)[: nclips * 4])
+                    dist.all_gather_into_tensor(self.gathered[: world * nclips * 4].view(torch.uint8),
+                                                self.pcm16[: nclips * 4].view(torch.uint8))
 
     lanes = [Lane(i) for i in range(NS)]
     ctx0 = lanes[0].ctx
@@ -323,7 +338,7 @@ def main():
                                    "input and output resident in HBM; %d independent batches share one set of "
                                    "kernel launches (dcs_separate_batch, the batch-of-files driver) and %d such "
                                    "groups are in flight per GPU (HIP streams)%s"
-                                   % (N, n_tiles, L / SR, CPL, NS, ", PCM all-gathered over RCCL" if world > 1 else ""),
+                                   % (N, n_tiles, L / SR, CPL, NS, ", int16 PCM all-gathered over RCCL" if world > 1 else ""),
                        "tiles_per_gpu_per_step": n_tiles, "frames_per_gpu_per_step": frames_per_step,
                        "frame_size": N, "bins": F, "clips_per_launch": CPL, "streams_per_gpu": NS,
                        "issue_threads": n_issue,

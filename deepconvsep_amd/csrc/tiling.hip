@@ -58,7 +58,36 @@ __global__ __launch_bounds__(kThreads) void overlap_add_kernel(const float* __re
     }
 }
 
+// (audio_out * 32767).astype('int16') of the scripts (separate_dsd.py:307-309): truncation toward zero, no
+// clipping -- an out-of-range product wraps the way NumPy's float -> int16 cast does on x86-64 (through int32).
+__global__ __launch_bounds__(kThreads) void pcm_int16_kernel(const float* __restrict__ pcm, int64_t n,
+                                                             int16_t* __restrict__ out) {
+    const int64_t i0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (i0 + 3 < n && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(pcm + i0);
+        short4 o;
+        o.x = (int16_t)(int32_t)(v.x * 32767.f);
+        o.y = (int16_t)(int32_t)(v.y * 32767.f);
+        o.z = (int16_t)(int32_t)(v.z * 32767.f);
+        o.w = (int16_t)(int32_t)(v.w * 32767.f);
+        *reinterpret_cast<short4*>(out + i0) = o;
+    } else {
+        for (int64_t i = i0; i < n && i < i0 + 4; ++i) out[i] = (int16_t)(int32_t)(pcm[i] * 32767.f);
+    }
+}
+
 }  // namespace
+
+extern "C" int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d) {
+    if (!ctx || !pcm_d || !out_d || n < 0) DCS_FAIL(DCS_EINVAL, "dcs_pcm_to_int16: bad argument");
+    if (n == 0) return DCS_OK;
+    DCS_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(pcm_int16_kernel, dim3((unsigned)dcs_cdiv(n, (int64_t)kThreads * 4)), dim3(kThreads), 0, ctx->stream,
+                       pcm_d, n, out_d);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
 
 int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F, int tc,
                     int ov, int tiler, float scale, float* tiles, int64_t n) {

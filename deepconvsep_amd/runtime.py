@@ -310,6 +310,17 @@ def tile(ctx, mag_t, time_context, overlap, tiler, scale=1.0):
     return tiles, n
 
 
+def pcm_to_int16(ctx, pcm_t, out=None):
+    """``(audio_out * 32767).astype('int16')`` on the device (separate_dsd.py:307-309): float32 tensor of any shape
+    (contiguous) -> int16 tensor of the same shape."""
+    torch = _torch()
+    pcm_t = pcm_t.contiguous()
+    if out is None:
+        out = torch.empty(pcm_t.shape, dtype=torch.int16, device=pcm_t.device)
+    _lib.check(ctx._lib.dcs_pcm_to_int16(ctx._h, _ptr(pcm_t), int(pcm_t.numel()), _ptr(out)))
+    return out
+
+
 def overlap_add(ctx, out_t, overlap):
     """``overlapadd_multi`` on the device: out_t ``[S, n, tc, F]`` float32 -> ``[S, n*(tc-ov)+tc, F]``."""
     torch = _torch()

@@ -159,6 +159,10 @@ int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int
                          int tiler, float scale, int eps_mode, int tie_mode, float* sep_d, float* mag_d,
                          float* phase_d, int64_t ld_out);
 
+/* The wav sample format of every script: out_d[i] = (int16)(pcm_d[i] * 32767), truncation toward zero, no
+ * clipping (separate_dsd.py:307-309).  Halves the bytes of the multi-GPU PCM gather. */
+int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d);
+
 /* ------------------------------------------------------------------ score-informed front-end */
 /* filterSpec (examples/bach10_scoreinformed/separate_bach10.py:172-200) and the network input of :520-527.
  * notes_h: HOST table [ninst][n_notes][width] of doubles exactly as expandMidi returns it (util.py:424-512),

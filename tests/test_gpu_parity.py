@@ -688,3 +688,27 @@ def test_scoreinformed_command_line(tmp_path):
         sr2, got = scipy.io.wavfile.read(str(out / ("mix_%s.wav" % s)))
         assert sr2 == 44100 and got.dtype == np.int16 and len(got) == L
         assert np.max(np.abs(got.astype(np.int64) - (want[i] * 32767).astype('int16').astype(np.int64))) <= 2
+
+
+def test_pcm_to_int16_is_the_scripts_wav_format():
+    """dcs_pcm_to_int16 = (audio_out * 32767).astype('int16') of separate_dsd.py:307-309: truncation toward zero,
+    no clipping (out-of-range values wrap like NumPy's cast), any length / alignment."""
+    from deepconvsep_amd.runtime import pcm_to_int16
+    ctx = default_context()
+    rs = np.random.RandomState(3)
+    for n in (1, 3, 4, 5, 1023, 94208, 94211):
+        x = rs.uniform(-1.0, 1.0, n).astype(np.float32)
+        x[:min(n, 4)] = np.array([0.99999, -0.99999, 3.05e-5, -3.06e-5], np.float32)[:min(n, 4)]
+        if n > 100:
+            x[50:54] = np.array([1.0, -1.0, 1.2, -1.3], np.float32)          # clipping input: wraps, as in the reference
+        want = (x.astype(np.float32) * np.float32(32767)).astype(np.int32).astype(np.int16)
+        got = pcm_to_int16(ctx, ctx.to_device(x, np.float32)).cpu().numpy()
+        assert got.dtype == np.int16 and np.array_equal(got, want)
+        if n > 8:                                                             # unaligned views
+            t = ctx.to_device(x, np.float32)
+            assert np.array_equal(pcm_to_int16(ctx, t[1:]).cpu().numpy(), want[1:])
+    # against the float64 product of the scripts: at most one LSB apart (float32 product)
+    x = rs.uniform(-1.0, 1.0, 5000)
+    ref = (x * 32767).astype('int16')
+    got = pcm_to_int16(ctx, ctx.to_device(x, np.float32)).cpu().numpy()
+    assert np.max(np.abs(got.astype(np.int32) - ref.astype(np.int32))) <= 1
