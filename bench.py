@@ -229,6 +229,18 @@ def main():
             kernels_ms[tag] = round(ms, 5)
     ctx0.timing(None)
 
+    # ---- the same breakdown for one full launch group (CPL batches per launch) on one stream
+    group_ms = {}
+    ctx0.timing("all")
+    ctx0.timing_reset()
+    for _ in range(10):
+        lanes[0].step(CPL)
+    for tag in _lib.TAGS:
+        ms, cnt = ctx0.timing_query(tag)
+        if cnt:
+            group_ms[tag] = round(ms, 5)
+    ctx0.timing(None)
+
     # algorithmic FLOPs of the dominant kernel: transposed conv1 of the 3 live branches
     # (separate_dsd.py:212,218,224): per tile 3 * 2 * tc * 50 * F  (DESIGN.md "kernels")
     final_flops_tile = 3 * 2 * TC * 50 * F
@@ -260,6 +272,8 @@ def main():
     single = {"ms_per_step": round(el1 / args.steps * 1e3, 5),
               "value": round(world * frames_per_step * args.steps / el1, 1),
               "roofline": roof(n_tiles, final_ms1, final_launches1), "kernels_ms": kernels_ms}
+    launch_group = {"clips": CPL, "tiles": CPL * n_tiles, "kernels_ms": group_ms,
+                    "kernels_ms_sum": round(sum(group_ms.values()), 5)}
 
     # ---- saturating regime (extra): same path, one long clip per launch, one stream
     saturating = None
@@ -344,7 +358,8 @@ def main():
                        "issue_threads": n_issue,
                        "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",
                        "parallelism": "tiles sharded by rank (dp%d)" % world},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "single_stream": single, "saturating": saturating,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "single_stream": single, "launch_group": launch_group,
+            "saturating": saturating,
         }
         print(json.dumps(line))
     if world > 1:

@@ -247,7 +247,9 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     // few rows: maximise the number of workgroups; many rows: reuse each B fragment 4 times
     const int64_t groups16 = (g.M + 15) / 16;
     const int64_t col_groups = g.n_cols / BN;
-    if (g.a_vec && groups16 * col_groups <= (int64_t)ctx->n_cu / 2) {
+    static const int64_t sk_env = getenv("DCS_GEMM_SPLITK_MAX") ? atoll(getenv("DCS_GEMM_SPLITK_MAX")) : -1;
+    const int64_t sk_max = sk_env >= 0 ? sk_env : (int64_t)ctx->n_cu / 2;
+    if (g.a_vec && groups16 * col_groups <= sk_max) {
         dim3 grid((unsigned)groups16, (unsigned)(g.n_cols / 16));
         hipLaunchKernelGGL(gemm_rows_splitk_kernel, grid, dim3(kThreads), 0, ctx->stream, g);
     } else if (groups16 * col_groups <= 2 * (int64_t)ctx->n_cu)
