@@ -22,10 +22,16 @@ Contents
                semantics written out in ``net_ref``'s docstring.
 ``pipeline``   restatement of the ``train_auto`` separation block
                (``examples/dsd100/separate_dsd.py:275-311`` and siblings).
+``score_np``   NumPy restatement of the score-informed front-end: ``expandMidi`` /
+               ``getMidiNum`` / ``str2midi`` / ``slicefft_slices`` /
+               ``remove_overlap`` (``util.py:126-191, 424-606``) and ``filterSpec``
+               + the network-input products
+               (``examples/bach10_scoreinformed/separate_bach10.py:172-200,
+               500-527``).
 ``ref_exec``   executes the reference's OWN pure-NumPy function bodies by line
                range from ``/root/reference`` (build container only -- that
                tree does not exist on the GPU box).  Used to pin ``stft_np`` /
-               ``tiling_np`` and to generate ``tests/golden/*.npz``.
+               ``tiling_np`` / ``score_np`` and to generate ``tests/golden/*.npz``.
 
 Parity status
 -------------
@@ -33,6 +39,10 @@ Parity status
   outputs of the reference's own code (``ref_exec``) on seeded inputs, and
   ``stft_np`` / ``tiling_np`` reproduce them bit-for-bit
   (``tests/test_oracle_golden.py``).
+* Score-informed front-end: PINNED.  ``score_np`` reproduces bit-for-bit the note
+  tables and masks of the reference's own ``expandMidi`` / ``getMidiNum`` /
+  ``filterSpec`` (executed by ``ref_exec.score()`` with Python-2 shims;
+  ``tests/golden/score_*.npz``).
 * Network (``build_ca`` + mask): PARITY UNPINNED.  The arithmetic lives in
   Theano==0.9.0 and Lasagne (git master, unpinned) -- ``requirements.txt:1-2``
   of the reference -- neither of which is vendored, installed or installable
