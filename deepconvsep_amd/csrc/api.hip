@@ -127,6 +127,7 @@ extern "C" int dcs_destroy(dcs_ctx* ctx) {
         for (auto e : s.start) (void)hipEventDestroy(e);
         for (auto e : s.stop) (void)hipEventDestroy(e);
     }
+    ctx->gemm_ws.release();
     delete ctx;
     return DCS_OK;
 }

@@ -55,6 +55,7 @@ struct dcs_ctx {
     uint64_t timing_seen[DCS_TAG_COUNT] = {0};
     DcsTimingSlot slots[DCS_TAG_COUNT];
     int n_cu = 256;
+    DcsBuffer gemm_ws;         // partial sums of the K-split GEMM (grown on demand, never inside a graph capture)
 };
 
 // RAII-ish helper: records a start event on construction and a stop event in done().
@@ -120,6 +121,9 @@ struct DcsGemm {
     int K;                   // valid K (A columns); multiple of 4 when a_vec
     int relu;
     int a_vec;               // 1: A rows are 16-byte aligned and lda % 4 == 0 -> float4 loads
+    // set by the launcher only: K split over workgroups (few rows, very long K -- the 166 650-wide dense layer of
+    // the Bach10 graph): slice z covers [z*kchunk, (z+1)*kchunk) and writes raw sums to partial[z][M][n_cols]
+    float* partial; int kchunk;
 };
 int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag);
 

@@ -187,11 +187,14 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
     }
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    int kc = wave * 64;
-    if (kc < gK) DCS_SK_LOAD(kc, a_cur, b_cur)
-    for (; kc < gK; kc += 256) {
+    // K range of this workgroup: all of K, or slice blockIdx.z of the K-split launch (kchunk % 256 == 0)
+    const int k_begin = g.partial ? (int)blockIdx.z * g.kchunk : 0;
+    const int k_end = g.partial ? (k_begin + g.kchunk < gK ? k_begin + g.kchunk : gK) : gK;
+    int kc = k_begin + wave * 64;
+    if (kc < k_end) DCS_SK_LOAD(kc, a_cur, b_cur)
+    for (; kc < k_end; kc += 256) {
         const int kn = kc + 256;
-        if (kn < gK) DCS_SK_LOAD(kn, a_nxt, b_nxt)
+        if (kn < k_end) DCS_SK_LOAD(kn, a_nxt, b_nxt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(gscale * a_cur[j][0], b_cur[4 * j + 0], acc0, 0, 0, 0);
@@ -213,7 +216,13 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
 #pragma unroll
         for (int w = 0; w < 3; ++w) sum += *reinterpret_cast<const f32x4*>(red + (w * 64 + lane) * 4);
         const int col = n0 + fi;
-        if (col < g.n_store) {
+        if (g.partial) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = m0 + kq * 4 + e;
+                if (row < g.M) g.partial[((int64_t)blockIdx.z * g.M + row) * g.n_cols + col] = sum[e];
+            }
+        } else if (col < g.n_store) {
             const float bias = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -226,6 +235,20 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
             }
         }
     }
+}
+
+// second pass of the K-split launch: slices added in slice order (deterministic), then bias / rectify / store
+__global__ __launch_bounds__(kThreads) void gemm_ksplit_reduce_kernel(const DcsGemm g, int ksplit) {
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= g.M * g.n_cols) return;
+    const int64_t row = idx / g.n_cols;
+    const int col = (int)(idx - row * g.n_cols);
+    if (col >= g.n_store) return;
+    float v = 0.f;
+    for (int z = 0; z < ksplit; ++z) v += g.partial[(int64_t)z * g.M * g.n_cols + idx];
+    v += g.bias ? g.bias[col] : 0.f;
+    if (g.relu) v = fmaxf(v, 0.f);
+    g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
 }
 
 template <int RB, int BK>
@@ -247,6 +270,29 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     // few rows: maximise the number of workgroups; many rows: reuse each B fragment 4 times
     const int64_t groups16 = (g.M + 15) / 16;
     const int64_t col_groups = g.n_cols / BN;
+    // few rows and a very long K (Bach10's bottleneck layer: 167 x 166 650 x 256): the 16 x 16 tiles alone are ~176
+    // workgroups streaming 170 MB of weights at 0.24 TB/s -> also split K over workgroups, two passes
+    static const int ks_env = getenv("DCS_GEMM_KSPLIT") ? atoi(getenv("DCS_GEMM_KSPLIT")) : -1;   // 0 disables
+    const int64_t tiles16 = groups16 * (g.n_cols / 16);
+    if (g.a_vec && ks_env != 0 && g.K >= 16384 && tiles16 < 4 * (int64_t)ctx->n_cu) {
+        int ksplit = ks_env > 0 ? ks_env : (int)((8 * (int64_t)ctx->n_cu + tiles16 - 1) / tiles16);
+        if (ksplit > 64) ksplit = 64;
+        int kchunk = (int)dcs_round_up((g.K + ksplit - 1) / ksplit, 256);
+        ksplit = (g.K + kchunk - 1) / kchunk;
+        if (ksplit > 1) {
+            DCS_CHECK(ctx->gemm_ws.ensure((size_t)ksplit * g.M * g.n_cols * sizeof(float)));
+            DcsGemm q = g;
+            q.partial = (float*)ctx->gemm_ws.ptr;
+            q.kchunk = kchunk;
+            hipLaunchKernelGGL(gemm_rows_splitk_kernel, dim3((unsigned)groups16, (unsigned)(g.n_cols / 16), (unsigned)ksplit),
+                               dim3(kThreads), 0, ctx->stream, q);
+            hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((unsigned)dcs_cdiv(g.M * g.n_cols, kThreads)), dim3(kThreads),
+                               0, ctx->stream, q, ksplit);
+            tm.done();
+            DCS_HIP(hipGetLastError());
+            return DCS_OK;
+        }
+    }
     static const int64_t sk_env = getenv("DCS_GEMM_SPLITK_MAX") ? atoll(getenv("DCS_GEMM_SPLITK_MAX")) : -1;
     const int64_t sk_max = sk_env >= 0 ? sk_env : (int64_t)ctx->n_cu / 2;
     if (g.a_vec && groups16 * col_groups <= sk_max) {

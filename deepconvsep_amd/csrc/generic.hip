@@ -128,7 +128,34 @@ struct IgemmArgs {
     float* out; int64_t out_n_stride; int Cout, Ho, Wo;
     int ph, pw, K;
     int64_t M;                  // n*Ho*Wo
+    int kh, k_per_u;            // k_per_u > 0: K is ordered tap-row major, k = u*k_per_u + ..., u = 0..kh-1 (see below)
 };
+
+// Zero-tap skipping for the transposed ('full') correlation.  With ph = kh-1 rows of implicit zero padding only
+// the taps u with 0 <= y + u - ph < H touch real input: for the Bach10 graph (H = 11, kh = 20, 30 output rows)
+// that is 7.3 of 20 on average -- 63 % of a dense K loop multiplies zeros.  With the K axis ordered tap-row major
+// the taps that can be non-zero for the rows of a workgroup form one interval of k; the K loop runs over the
+// tiles of that interval only (the per-element bounds test still zeroes what is outside at its ends).
+__device__ __forceinline__ void igemm_k_range(const IgemmArgs& g, int64_t m0, int BM, int BK, int& kt0, int& kt1) {
+    kt0 = 0;
+    kt1 = (g.K + BK - 1) / BK;
+    if (g.k_per_u <= 0 || g.ph == 0) return;
+    const int HoWo = g.Ho * g.Wo;
+    int64_t ma = m0, mb = m0 + BM - 1;
+    if (mb > g.M - 1) mb = g.M - 1;
+    const int64_t na = ma / HoWo, nb = mb / HoWo;
+    const int ya = (int)((ma - na * HoWo) / g.Wo), yb = (int)((mb - nb * HoWo) / g.Wo);
+    if (nb != na) return;                            // the workgroup straddles two images: keep the full loop
+    int u_lo = g.ph - yb, u_hi = g.ph - ya + g.H - 1;
+    if (u_lo < 0) u_lo = 0;
+    if (u_hi > g.kh - 1) u_hi = g.kh - 1;
+    if (u_hi < u_lo) { kt1 = 0; return; }
+    kt0 = (u_lo * g.k_per_u) / BK;
+    const int ke = (u_hi + 1) * g.k_per_u;
+    kt1 = (ke + BK - 1) / BK;
+    const int kmax = (g.K + BK - 1) / BK;
+    if (kt1 > kmax) kt1 = kmax;
+}
 
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const IgemmArgs g) {
     constexpr int BM = 128, BK = 32, BN = 32, AS = BK + 2, BS = BN + 16;
@@ -192,9 +219,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const IgemmArgs g)
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (g.K + BK - 1) / BK;
-    DCS_IG_LOAD(0)
-    for (int kt = 0; kt < nkt; ++kt) {
+    int kt_first, nkt;
+    igemm_k_range(g, m0, BM, BK, kt_first, nkt);
+    if (kt_first < nkt) DCS_IG_LOAD(kt_first)
+    for (int kt = kt_first; kt < nkt; ++kt) {
         __syncthreads();
         DCS_IG_STORE()
         __syncthreads();
@@ -302,9 +330,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f16_kernel(const IgemmArg
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nkt = (g.K + BK - 1) / BK;
-    DCS_IGH_LOAD(0)
-    for (int kt = 0; kt < nkt; ++kt) {
+    int kt_first, nkt;
+    igemm_k_range(g, m0, BM, BK, kt_first, nkt);
+    if (kt_first < nkt) DCS_IGH_LOAD(kt_first)
+    for (int kt = kt_first; kt < nkt; ++kt) {
         __syncthreads();
         DCS_IGH_STORE()
         __syncthreads();
@@ -492,10 +521,11 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
             }
     for (int co = 0; co < nf2; ++co) bias2[co] = b2[co] + b2b[co];
     // transposed conv2 = 'full' correlation of d[n, co, h2, w2] with Wt[(co,u,v)][ci] = W2[co][ci][u][v]
+    // K ordered tap-row major, k = (u, co, v): see igemm_k_range
     for (int co = 0; co < nf2; ++co)
         for (int u = 0; u < kh; ++u)
             for (int v = 0; v < kw; ++v) {
-                const int k = (co * kh + u) * kw + v;
+                const int k = (u * nf2 + co) * kw + v;
                 kt_off[k] = co * d.h2 * d.w2 + u * d.w2 + v;
                 kt_uv[k] = (u << 16) | v;
                 for (int ci = 0; ci < nf1; ++ci)
@@ -630,6 +660,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         a.Wm = g->W2t; a.koff = g->kt_off; a.kuv = g->kt_uv; a.bias = g->bias0;
         a.out = g2; a.out_n_stride = (int64_t)d.nf1 * planep; a.Cout = d.nf1; a.Ho = tc; a.Wo = d.wp;
         a.ph = d.kh2 - 1; a.pw = d.kw2 - 1; a.K = g->K2; a.M = n * NB * planep;
+        a.kh = d.kh2; a.k_per_u = d.nf2 * d.kw2;
         DcsTimer tm(ctx, DCS_TAG_DECONV2);
         if (g->conv_f16)
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
@@ -703,7 +734,11 @@ int dcs_generic_set_conv_f16(DcsGenericNet* g, int on) {
 
 int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mask_mode, int tie_mode, float* out) {
     if (!g) DCS_FAIL(DCS_EINVAL, "generic forward: null network");
-    const int64_t chunk = 64;  // bounds the scratch: the Bach10 graph needs ~13 MB per tile
+    // Tiles go through the graph in chunks that bound the scratch (the Bach10 graph needs ~13 MB per tile) at 4 GiB of
+    // the 288 GB: every chunk re-reads the dense weights (170 MB + 4 x 170 MB for Bach10), so few large chunks.
+    static const int64_t chunk_env = getenv("DCS_GENERIC_CHUNK") ? atoll(getenv("DCS_GENERIC_CHUNK")) : 0;
+    int64_t chunk = chunk_env > 0 ? chunk_env : (int64_t)(((size_t)4 << 30) / (chunk_bytes(g, 64) / 64 + 1));
+    if (chunk < 64 && chunk_env <= 0) chunk = 64;
     const int64_t per = n < chunk ? n : chunk;
     DCS_CHECK(g->ws.ensure(chunk_bytes(g, per)));
     const int64_t tile_elems = (int64_t)g->C * g->tc * g->F;
