@@ -266,6 +266,116 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const IgemmArgs g)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column convolution (filter kh x 1: conv2 of the Bach10 / score-informed graphs and its transpose).
+//   out[co][y][x] = bias[co] + sum_u sum_ci Wk[u][ci][co] * in[ci][y + u - ph][x]     (zero outside 0 <= row < H)
+// forward: ph = 0, Ho = H - kh + 1;  transposed ('full' correlation): ph = kh - 1, Ho = H + kh - 1.
+// Every x is an independent 1-D problem along y, and an input element feeds up to kh outputs.  The implicit GEMM
+// above re-gathers each of them from L2 (16 scalar loads + bounds logic per thread per K tile -- as many issue
+// cycles as the MFMAs) and, for the transpose, multiplied the zero padding.  Here a workgroup owns 16 columns x of
+// one image: the input slab [ci][H][16 x] and ALL the weights [u][ci][co] sit in LDS, each of the 8 waves takes
+// output rows y = w, w+8, ... and walks only the taps with a real input row (7.3 of 20 on average for the
+// Bach10 transpose).  MFMA operands: A = weights (rows = co), B = slab (columns = x), so a lane ends up with 4
+// channels of one x and a store instruction writes 16 consecutive x of one (co, y).  A workgroup keeps its
+// weights for several column blocks of the same image.  LDS strides / the co swizzle keep the two K-quarters of a
+// 32-lane half on disjoint banks.  Measured (Bach10, 10 s): transpose 5.2 -> see DESIGN.md, forward 0.95 -> idem.
+// ------------------------------------------------------------------------------------------------
+struct ColConvArgs {
+    const float* in; int64_t in_n_stride; int Cin, H, W;
+    const float* Wk;            // [kh][32][32] (ci, co swizzled: see colconv_wslot)
+    const float* bias;          // [32]
+    float* out; int64_t out_n_stride; int Cout, Ho;
+    int ph, kh;
+    int xb_per_wg;              // column blocks (16 x each) a workgroup walks
+    int n_xb;                   // column blocks per image
+};
+
+__host__ __device__ __forceinline__ int colconv_wslot(int u, int ci, int co) {
+    return (u * 32 + ci) * 32 + ((co + 16 * (ci & 1)) & 31);
+}
+
+constexpr int kColThreads = 512;
+
+__global__ __launch_bounds__(kColThreads) void colconv_kernel(const ColConvArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                         // [kh*32*32]
+    const int PS = g.H * 16 + ((g.H & 1) ? 0 : 16);  // plane stride = 16 (mod 32): K-quarters kq, kq+1 land 16 banks apart
+    float* slab = smem + g.kh * 1024;         // [32][PS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kq = lane >> 4;
+    const int groups = (g.n_xb + g.xb_per_wg - 1) / g.xb_per_wg;
+    const int64_t img = blockIdx.x / groups;
+    const int xb0 = (int)(blockIdx.x - img * groups) * g.xb_per_wg;
+    const float* in = g.in + img * g.in_n_stride;
+    float* out = g.out + img * g.out_n_stride;
+    const int HoW = g.Ho * g.W;
+
+    for (int i = tid; i < g.kh * 256; i += kColThreads)
+        reinterpret_cast<f32x4*>(Wl)[i] = reinterpret_cast<const f32x4*>(g.Wk)[i];
+    for (int i = tid; i < (32 - g.Cin) * PS; i += kColThreads) slab[g.Cin * PS + i] = 0.f;   // unused K planes
+    const float bias_lo[4] = {g.bias[4 * kq], g.bias[4 * kq + 1], g.bias[4 * kq + 2], g.bias[4 * kq + 3]};
+    const float bias_hi[4] = {g.bias[16 + 4 * kq], g.bias[17 + 4 * kq], g.bias[18 + 4 * kq], g.bias[19 + 4 * kq]};
+
+    // slab staging plan: element e = tid + 512 i  ->  (x = e % 16, cr = e / 16 = ci*H + r); the next column block's
+    // elements are fetched into registers while the current one is multiplied (one workgroup per CU: nothing else
+    // would hide the loads)
+    constexpr int kPre = 32;
+    const int n_el = g.Cin * g.H * 16;
+    int soff[kPre];
+    float pre[kPre];
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+        const int e = tid + i * kColThreads;
+        const int cr = e >> 4, ci = cr / g.H;
+        soff[i] = e < n_el ? ci * PS + (cr - ci * g.H) * 16 + (e & 15) : -1;
+    }
+#define DCS_COL_FETCH(x0_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < kPre; ++i) {                                                   \
+        const int e = tid + i * kColThreads;                                                             \
+        pre[i] = (soff[i] >= 0 && (x0_) + (e & 15) < g.W) ? in[(int64_t)(e >> 4) * g.W + (x0_) + (e & 15)] : 0.f; \
+    }
+    const int xb_end = xb0 + g.xb_per_wg < g.n_xb ? xb0 + g.xb_per_wg : g.n_xb;
+    if (xb0 < xb_end) DCS_COL_FETCH(xb0 * 16)
+    for (int xb = xb0; xb < xb_end; ++xb) {
+        const int x0 = xb * 16;
+        __syncthreads();                      // previous slab fully read (and, first time, the weights staged)
+#pragma unroll
+        for (int i = 0; i < kPre; ++i)
+            if (soff[i] >= 0) slab[soff[i]] = pre[i];
+        __syncthreads();
+        if (xb + 1 < xb_end) DCS_COL_FETCH((xb + 1) * 16)
+        for (int y = wave; y < g.Ho; y += kColThreads / 64) {
+            int u_lo = g.ph - y, u_hi = g.ph - y + g.H - 1;            // 0 <= y + u - ph < H
+            if (u_lo < 0) u_lo = 0;
+            if (u_hi > g.kh - 1) u_hi = g.kh - 1;
+            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = u_lo; u <= u_hi; ++u) {
+                const float* sp = slab + kq * PS + (y + u - g.ph) * 16 + fi;
+                const float* wp = Wl + (u * 32 + kq) * 32;
+                const int c0 = (fi + 16 * (kq & 1)) & 31, c1 = (fi + 16 + 16 * (kq & 1)) & 31;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float b = sp[4 * kk * PS];
+                    const float a0 = wp[4 * kk * 32 + c0], a1 = wp[4 * kk * 32 + c1];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+                }
+            }
+            if (x0 + fi < g.W) {
+                float* op = out + (int64_t)y * g.W + x0 + fi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = 4 * kq + e;
+                    if (co < g.Cout) op[(int64_t)co * HoW] = acc0[e] + bias_lo[e];
+                    if (co + 16 < g.Cout) op[(int64_t)(co + 16) * HoW] = acc1[e] + bias_hi[e];
+                }
+            }
+        }
+    }
+#undef DCS_COL_FETCH
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same implicit GEMM with f16 inputs and f32 accumulation (v_mfma_f32_16x16x32_f16, 16x the f32 MFMA
 // rate) -- the "fp16 MFMA conv path" of BASELINE config 3.  Activations are rounded to f16 when the
 // im2col tile is stored to LDS, weights are pre-rounded on the host and packed [k tile][32 channels][32 k]
@@ -471,6 +581,9 @@ struct DcsGenericNet {
     // f16 copies of the two conv2 weight matrices, packed [k tile][32 channels][32 k]
     _Float16 *W2m_h = nullptr, *W2t_h = nullptr;
     int conv_f16 = 0;
+    // column convolution (kw2 == 1): weights [kh][32 ci][32 co swizzled] of conv2 and of its transpose
+    float *Wcol = nullptr, *Wcol_t = nullptr;
+    int use_colconv = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
     float* Bd[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -541,6 +654,21 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         return h;
     };
     const std::vector<_Float16> W2m_h = pack_h(W2m), W2t_h = pack_h(W2t);
+    // column convolution (kw == 1): Wcol[u][ci][co] = W2[co][ci][kh-1-u] (true convolution), transpose
+    // Wcol_t[u][co][ci] = W2[co][ci][u]
+    std::vector<float> Wcol, Wcol_t;
+    static const int col_env = getenv("DCS_COLCONV") ? atoi(getenv("DCS_COLCONV")) : 1;
+    g->use_colconv = (kw == 1 && nf1 <= 32 && nf2 <= 32 && col_env) ? 1 : 0;
+    if (g->use_colconv) {
+        Wcol.assign((size_t)kh * 1024, 0.f);
+        Wcol_t.assign((size_t)kh * 1024, 0.f);
+        for (int co = 0; co < nf2; ++co)
+            for (int ci = 0; ci < nf1; ++ci)
+                for (int u = 0; u < kh; ++u) {
+                    Wcol[colconv_wslot(u, ci, co)] = W2[((size_t)co * nf1 + ci) * kh + (kh - 1 - u)];
+                    Wcol_t[colconv_wslot(u, co, ci)] = W2[((size_t)co * nf1 + ci) * kh + u];
+                }
+    }
     // dense layers: the flattened [nf2, h2, w2] order is the storage order of a2b, so no permutation
     const int Kfc = g->flat_p;
     std::vector<float> Bfc((size_t)dcs_round_up(Kfc, 128) * g->hid64, 0.f), biasfc(g->hid64, 0.f);
@@ -553,6 +681,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     UP(g->W1c, W1c) UP(g->bias1, bias1) UP(g->W2m, W2m) UP(g->bias2, bias2) UP(g->k2off, k2off) UP(g->k2uv, k2uv)
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
+    if (g->use_colconv) { UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) }
     for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) {
         std::vector<float> Bd((size_t)dcs_round_up(g->hid64, 128) * g->flat64, 0.f), bd(g->flat64, 0.f);
         for (int h = 0; h < d.hidden; ++h)
@@ -573,7 +702,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->Wcol, g->Wcol_t, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d};
     for (void* p : ptrs)
@@ -583,6 +712,23 @@ void dcs_generic_destroy(DcsGenericNet* g) {
 }
 
 namespace {
+
+int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images) {
+    a.n_xb = (a.W + 15) / 16;
+    // column blocks per workgroup: amortise the 80 KB weight staging, but keep >= 4 workgroups per CU
+    int per = 8;
+    while (per > 1 && n_images * ((a.n_xb + per - 1) / per) < 4 * (int64_t)ctx->n_cu) per >>= 1;
+    a.xb_per_wg = per;
+    const size_t lds = ((size_t)a.kh * 1024 + (size_t)32 * (a.H * 16 + 16)) * sizeof(float);
+    if (lds > 160 * 1024 || a.Cin * a.H * 16 > 32 * kColThreads)
+        DCS_FAIL(DCS_EUNSUPPORTED, "column convolution: %zu bytes of LDS, %d x %d input rows", lds, a.Cin, a.H);
+    auto kern = colconv_kernel;
+    if (lds > 48 * 1024)
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t groups = (a.n_xb + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * groups)), dim3(kColThreads), lds, ctx->stream, a);
+    return DCS_OK;
+}
 
 // one chunk of tiles through the graph; scratch carved from `w`
 int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_total, int64_t k_first, int mask_mode,
@@ -629,7 +775,13 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         if (g->conv_f16)
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2m_h);
-        else
+        else if (g->use_colconv) {
+            ColConvArgs c{};
+            c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
+            c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
+            c.ph = 0; c.kh = d.kh2;
+            DCS_CHECK(launch_colconv(ctx, c, n));
+        } else
             hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
         tm.done();
     }
@@ -665,7 +817,13 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         if (g->conv_f16)
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2t_h);
-        else
+        else if (g->use_colconv) {
+            ColConvArgs c{};
+            c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
+            c.Wk = g->Wcol_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
+            c.ph = d.kh2 - 1; c.kh = d.kh2;
+            DCS_CHECK(launch_colconv(ctx, c, n * NB));
+        } else
             hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
         tm.done();
     }
