@@ -12,6 +12,8 @@ for arch, N, F, ov, win in (("ikala", 1024, 513, 20, np.hanning), ("bach10", 409
     params = synth_params(arch, 30, F, seed=3)
     audio = synth_audio(441000, seed=0)
     sep = dcs.Separator(arch, params, 0.3, 30, ov, 32, F, N, 512, win)
+    if os.environ.get("DCS_ARCH_F16") and arch != "dsd":
+        sep.net.set_conv_precision('f16')
     a = ctx.to_device(audio, np.float32)
     out = sep.net.separate(sep.plan, a, ov, sep.tiler, 0.3)
     torch.cuda.synchronize()
