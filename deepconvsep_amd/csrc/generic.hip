@@ -482,6 +482,85 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f16_kernel(const IgemmArg
 }
 
 // ------------------------------------------------------------------------------------------------
+// The column convolution with f16 inputs and f32 accumulation (v_mfma_f32_16x16x32_f16): one MFMA covers a whole
+// tap (32 input channels) for a 16 co x 16 x block, 16x the f32 rate, so this variant is LDS- and store-bound.
+// Slab and weights are stored channel-fastest -- slab [row][x][ci], weights [u][co][ci], rows of 32 halves padded to
+// 40 (80 bytes, the bank-friendly stride of conv_igemm_f16_kernel) -- so both operands are one 16-byte LDS read per
+// lane.  Activations are rounded to f16 when the slab is written, weights are pre-rounded on the host.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kColThreads) void colconv_f16_kernel(const ColConvArgs g, const _Float16* __restrict__ Wh) {
+    constexpr int RS = 40;                                   // halves per (row, x) / (u, co) line
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Wl = reinterpret_cast<_Float16*>(smem);         // [kh][32 co][RS]
+    _Float16* slab = Wl + g.kh * 32 * RS;                      // [H][16 x][RS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kg = lane >> 4;
+    const int groups = (g.n_xb + g.xb_per_wg - 1) / g.xb_per_wg;
+    const int64_t img = blockIdx.x / groups;
+    const int xb0 = (int)(blockIdx.x - img * groups) * g.xb_per_wg;
+    const float* in = g.in + img * g.in_n_stride;
+    float* out = g.out + img * g.out_n_stride;
+    const int HoW = g.Ho * g.W;
+
+    for (int i = tid; i < g.kh * 32 * RS / 8; i += kColThreads)
+        reinterpret_cast<f32x4*>(Wl)[i] = reinterpret_cast<const f32x4*>(Wh)[i];
+    for (int i = tid; i < g.H * 16 * RS / 2; i += kColThreads) reinterpret_cast<float*>(slab)[i] = 0.f;  // pad channels
+    const float bias_lo[4] = {g.bias[4 * kg], g.bias[4 * kg + 1], g.bias[4 * kg + 2], g.bias[4 * kg + 3]};
+    const float bias_hi[4] = {g.bias[16 + 4 * kg], g.bias[17 + 4 * kg], g.bias[18 + 4 * kg], g.bias[19 + 4 * kg]};
+
+    constexpr int kPre = 32;
+    const int n_el = g.Cin * g.H * 16;
+    int soff[kPre];
+    float pre[kPre];
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+        const int e = tid + i * kColThreads;
+        const int cr = e >> 4, ci = cr / g.H;
+        soff[i] = e < n_el ? ((cr - ci * g.H) * 16 + (e & 15)) * RS + ci : -1;
+    }
+#define DCS_COL_FETCH(x0_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < kPre; ++i) {                                                   \
+        const int e = tid + i * kColThreads;                                                             \
+        pre[i] = (soff[i] >= 0 && (x0_) + (e & 15) < g.W) ? in[(int64_t)(e >> 4) * g.W + (x0_) + (e & 15)] : 0.f; \
+    }
+    const int xb_end = xb0 + g.xb_per_wg < g.n_xb ? xb0 + g.xb_per_wg : g.n_xb;
+    if (xb0 < xb_end) DCS_COL_FETCH(xb0 * 16)
+    for (int xb = xb0; xb < xb_end; ++xb) {
+        const int x0 = xb * 16;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kPre; ++i)
+            if (soff[i] >= 0) slab[soff[i]] = (_Float16)pre[i];
+        __syncthreads();
+        if (xb + 1 < xb_end) DCS_COL_FETCH((xb + 1) * 16)
+        for (int y = wave; y < g.Ho; y += kColThreads / 64) {
+            int u_lo = g.ph - y, u_hi = g.ph - y + g.H - 1;
+            if (u_lo < 0) u_lo = 0;
+            if (u_hi > g.kh - 1) u_hi = g.kh - 1;
+            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = u_lo; u <= u_hi; ++u) {
+                const h8 b = *reinterpret_cast<const h8*>(slab + ((y + u - g.ph) * 16 + fi) * RS + kg * 8);
+                const h8 a0 = *reinterpret_cast<const h8*>(Wl + (u * 32 + fi) * RS + kg * 8);
+                const h8 a1 = *reinterpret_cast<const h8*>(Wl + (u * 32 + 16 + fi) * RS + kg * 8);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, acc1, 0, 0, 0);
+            }
+            if (x0 + fi < g.W) {
+                float* op = out + (int64_t)y * g.W + x0 + fi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = 4 * kg + e;
+                    if (co < g.Cout) op[(int64_t)co * HoW] = acc0[e] + bias_lo[e];
+                    if (co + 16 < g.Cout) op[(int64_t)(co + 16) * HoW] = acc1[e] + bias_hi[e];
+                }
+            }
+        }
+    }
+#undef DCS_COL_FETCH
+}
+
+// ------------------------------------------------------------------------------------------------
 // VJP of conv1: o[m, c, t, f] = sum_{o', j : 0 <= f - j*sw < kw} g[m, o', t, j] * Wc[o', c, f - j*sw]
 // block = 256 consecutive f of one (m, t) row, all C output channels.
 // ------------------------------------------------------------------------------------------------
@@ -583,6 +662,7 @@ struct DcsGenericNet {
     int conv_f16 = 0;
     // column convolution (kw2 == 1): weights [kh][32 ci][32 co swizzled] of conv2 and of its transpose
     float *Wcol = nullptr, *Wcol_t = nullptr;
+    _Float16 *Wcol_h = nullptr, *Wcol_t_h = nullptr;     // [kh][32 co][40] halves, channel-fastest
     int use_colconv = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
@@ -657,16 +737,22 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     // column convolution (kw == 1): Wcol[u][ci][co] = W2[co][ci][kh-1-u] (true convolution), transpose
     // Wcol_t[u][co][ci] = W2[co][ci][u]
     std::vector<float> Wcol, Wcol_t;
+    std::vector<_Float16> Wcol_h, Wcol_t_h;
     static const int col_env = getenv("DCS_COLCONV") ? atoi(getenv("DCS_COLCONV")) : 1;
     g->use_colconv = (kw == 1 && nf1 <= 32 && nf2 <= 32 && col_env) ? 1 : 0;
     if (g->use_colconv) {
         Wcol.assign((size_t)kh * 1024, 0.f);
         Wcol_t.assign((size_t)kh * 1024, 0.f);
+        Wcol_h.assign((size_t)kh * 32 * 40, (_Float16)0.f);
+        Wcol_t_h.assign((size_t)kh * 32 * 40, (_Float16)0.f);
         for (int co = 0; co < nf2; ++co)
             for (int ci = 0; ci < nf1; ++ci)
                 for (int u = 0; u < kh; ++u) {
-                    Wcol[colconv_wslot(u, ci, co)] = W2[((size_t)co * nf1 + ci) * kh + (kh - 1 - u)];
-                    Wcol_t[colconv_wslot(u, co, ci)] = W2[((size_t)co * nf1 + ci) * kh + u];
+                    const float wf = W2[((size_t)co * nf1 + ci) * kh + (kh - 1 - u)], wt = W2[((size_t)co * nf1 + ci) * kh + u];
+                    Wcol[colconv_wslot(u, ci, co)] = wf;
+                    Wcol_t[colconv_wslot(u, co, ci)] = wt;
+                    Wcol_h[((size_t)u * 32 + co) * 40 + ci] = (_Float16)wf;      // forward: out channel co, in channel ci
+                    Wcol_t_h[((size_t)u * 32 + ci) * 40 + co] = (_Float16)wt;    // transpose: out channel ci, in channel co
                 }
     }
     // dense layers: the flattened [nf2, h2, w2] order is the storage order of a2b, so no permutation
@@ -681,7 +767,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     UP(g->W1c, W1c) UP(g->bias1, bias1) UP(g->W2m, W2m) UP(g->bias2, bias2) UP(g->k2off, k2off) UP(g->k2uv, k2uv)
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
-    if (g->use_colconv) { UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) }
+    if (g->use_colconv) { UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) }
     for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) {
         std::vector<float> Bd((size_t)dcs_round_up(g->hid64, 128) * g->flat64, 0.f), bd(g->flat64, 0.f);
         for (int h = 0; h < d.hidden; ++h)
@@ -702,7 +788,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->Wcol, g->Wcol_t, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d};
     for (void* p : ptrs)
@@ -713,8 +799,22 @@ void dcs_generic_destroy(DcsGenericNet* g) {
 
 namespace {
 
-int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images) {
+int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16* Wh = nullptr) {
     a.n_xb = (a.W + 15) / 16;
+    if (Wh) {
+        int per = 8;
+        while (per > 1 && n_images * ((a.n_xb + per - 1) / per) < 4 * (int64_t)ctx->n_cu) per >>= 1;
+        a.xb_per_wg = per;
+        const size_t lds = ((size_t)a.kh * 32 * 40 + (size_t)a.H * 16 * 40) * sizeof(_Float16);
+        if (lds > 160 * 1024 || a.Cin * a.H * 16 > 32 * kColThreads || a.Cin > 32)
+            DCS_FAIL(DCS_EUNSUPPORTED, "column convolution (f16): %zu bytes of LDS", lds);
+        auto kern = colconv_f16_kernel;
+        if (lds > 48 * 1024)
+            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * ((a.n_xb + per - 1) / per))), dim3(kColThreads), lds, ctx->stream,
+                           a, Wh);
+        return DCS_OK;
+    }
     // column blocks per workgroup: amortise the 80 KB weight staging, but keep >= 4 workgroups per CU
     int per = 8;
     while (per > 1 && n_images * ((a.n_xb + per - 1) / per) < 4 * (int64_t)ctx->n_cu) per >>= 1;
@@ -772,16 +872,16 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         a.out = a2b; a.out_n_stride = g->flat_p; a.Cout = d.nf2; a.Ho = d.h2; a.Wo = d.w2;
         a.ph = 0; a.pw = 0; a.K = g->K2; a.M = n * d.h2 * d.w2;
         DcsTimer tm(ctx, DCS_TAG_CONV2);
-        if (g->conv_f16)
-            hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
-                               g->W2m_h);
-        else if (g->use_colconv) {
+        if (g->use_colconv) {
             ColConvArgs c{};
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = 0; c.kh = d.kh2;
-            DCS_CHECK(launch_colconv(ctx, c, n));
-        } else
+            DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr));
+        } else if (g->conv_f16)
+            hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
+                               g->W2m_h);
+        else
             hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
         tm.done();
     }
@@ -814,16 +914,16 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         a.ph = d.kh2 - 1; a.pw = d.kw2 - 1; a.K = g->K2; a.M = n * NB * planep;
         a.kh = d.kh2; a.k_per_u = d.nf2 * d.kw2;
         DcsTimer tm(ctx, DCS_TAG_DECONV2);
-        if (g->conv_f16)
-            hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
-                               g->W2t_h);
-        else if (g->use_colconv) {
+        if (g->use_colconv) {
             ColConvArgs c{};
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = d.kh2 - 1; c.kh = d.kh2;
-            DCS_CHECK(launch_colconv(ctx, c, n * NB));
-        } else
+            DCS_CHECK(launch_colconv(ctx, c, n * NB, g->conv_f16 ? g->Wcol_t_h : nullptr));
+        } else if (g->conv_f16)
+            hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
+                               g->W2t_h);
+        else
             hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
         tm.done();
     }
