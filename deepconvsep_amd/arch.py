@@ -7,12 +7,14 @@ script; the HIP model (``csrc/``) is instantiated from it.
   ikala         examples/ikala/separate_ikala.py:172-192   (max-pool variant)
   bach10        examples/bach10/separate_bach10.py:172-229
   bach10_si     examples/bach10_scoreinformed/separate_bach10.py:388-447
+  dsd_ild       examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115   (stereo input, 4 branches x 2 channels)
 """
 import numpy as np
 
 # enum values shared with include/dcs.h
-ARCH_DSD, ARCH_IKALA, ARCH_BACH10, ARCH_BACH10_SI = 0, 1, 2, 3
+ARCH_DSD, ARCH_IKALA, ARCH_BACH10, ARCH_BACH10_SI, ARCH_DSD_ILD = 0, 1, 2, 3, 4
 EPS_A, EPS_B = 0, 1
+EPS_ILD = 3   # per input channel, p / (sum + 1e-12 r), + 1e-12 r (trainCNN_ILD_DSD100.py:176-180); dcs_separate_stereo only
 TIE_ALL, TIE_FIRST = 0, 1
 TILER_SCRIPT, TILER_LIBRARY = 0, 1
 
@@ -76,6 +78,8 @@ ARCHS = {
     'bach10_si': Arch('bach10_si', ARCH_BACH10_SI, 4, (30, 30, 4), 0,
                       (30, lambda tc: int(2 * tc / 3), 1), 256, [0, 1, 2, 3], 4, EPS_B,
                       ['bassoon', 'clarinet', 'saxphone', 'violin']),
+    'dsd_ild': Arch('dsd_ild', ARCH_DSD_ILD, 2, (50, 'F', 1), 0, (50, lambda tc: int(tc / 2), 1), 256,
+                    [0, 1, 2, 3], 4, EPS_ILD, ['vocals', 'bass', 'drums', 'other']),
 }
 ARCHS['hiphop'] = ARCHS['dsd']
 

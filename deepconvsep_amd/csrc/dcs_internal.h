@@ -93,7 +93,8 @@ struct dcs_stft {
 int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit,
                                 int64_t ld, int64_t rows_out, int64_t T);
 int dcs_launch_stft_forward_f32_clips(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips,
-                                      float* mag, float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T);
+                                      float* mag, float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T,
+                                      bool interleave = false);  // interleave: rows ordered [frame][clip]
 int dcs_launch_stft_inverse_f32_clips(dcs_stft* p, const float* mag, int64_t src_stride, const float2* unit,
                                       int64_t unit_clip_stride, int64_t ld, int64_t T, int n_src, int64_t n_clips,
                                       float pre_div, float* audio, int64_t n_out);

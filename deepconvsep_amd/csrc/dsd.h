@@ -25,7 +25,9 @@ struct DsdFinalArgs {
     int tc, ov, st;
     int F, CI;
     int mmax;             // FOLD: ceil(ov/st)+1 covering tiles per frame; else 1
-    int mask_mode;        // 0 = convention A, 1 = convention B, 2 = raw network output
+    int mask_mode;        // 0 = convention A, 1 = convention B, 2 = raw network output, 3 = stereo trainer (per input channel)
+    int nbr;              // 3: the DSD graph (4th output = branch 1 again); 4: one branch per source (stereo trainer)
+    int bias_half;        // 0: bias[4] per source; > 0: two input channels side by side, bins >= bias_half use bias[2 s + 1]
     int n_clips;          // stacked clips of equal length (0 or 1: a single clip); clip c uses G + c*g_clip_stride,
     int64_t g_clip_stride, mix_clip_stride, out_clip_stride;  // mix + c*mix_clip_stride, out + c*out_clip_stride
 };

@@ -261,9 +261,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // channel multiplied in MFMA step q by the lanes of K-quarter kq: 12 contiguous channels + 1 of the last 4
 __device__ __forceinline__ constexpr int final_chan(int q, int kq) { return q < 12 ? 12 * kq + q : 48 + kq; }
 
-template <bool FOLD, int MODE, int CBW /* column blocks per wave: 2, or 1 when there are few rows */>
-__global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a, int n_colg) {
-    constexpr int NBR = 3;   // dense branches that reach the output (separate_dsd.py:228)
+template <bool FOLD, int MODE, int CBW /* column blocks per wave: 2, or 1 when there are few rows */,
+          int NBR /* dense branches that reach the output: 3 in the DSD graph (separate_dsd.py:228, the 4th source
+                     re-uses branch 1), 4 in the stereo trainer's graph (trainCNN_ILD_DSD100.py:98-104) */>
+__global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const DsdFinalArgs a, int n_colg) {
     constexpr int NQ = 13;   // CI / 4 MFMA steps
     constexpr int CI = 52, AS = 56;  // LDS row stride: multiple of 4 floats (128-bit reads and writes)
     constexpr int kABuf = NBR * 16 * AS;
@@ -367,8 +368,14 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
         mixv[0][e] = a.mix_scale * m0;
         if constexpr (CBW == 2) mixv[1][e] = a.mix_scale * m1;
     }
-    const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
-    const float eps_r = 5e-19f;  // eps * rand_num with the unseeded draw replaced by 0.5 (separate_dsd.py:245,256)
+    // output BiasLayer: one value per source, or per (source, input channel) when two channels sit side by side
+    const int bsel = (a.bias_half > 0 && col >= a.bias_half) ? 1 : 0;
+    const int bstr = a.bias_half > 0 ? 2 : 1;
+    const float bias0 = a.bias[0 * bstr + bsel], bias1 = a.bias[1 * bstr + bsel], bias2 = a.bias[2 * bstr + bsel],
+                bias3 = a.bias[3 * bstr + bsel];
+    // eps * rand_num with the unseeded draw replaced by 0.5 (separate_dsd.py:245,256); stereo trainer: 1e-12 * one
+    // standard deviation of its N(0, 0.1) draw (trainCNN_ILD_DSD100.py:155,166)
+    const float eps_r = MODE == 3 ? 1e-13f : 5e-19f;
 
     f32x4 res[CBW][4];
 #pragma unroll
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
 
     __syncthreads();
 
-    // ---- staging plan of this thread: up to 3 float4 slots of the [3 branches][16 rows][CI] A set.
+    // ---- staging plan of this thread: up to NSL float4 slots of the [NBR branches][16 rows][CI] A set.
     // Slot (s, i, c4) reads G[k0_i + m][s][c4 / 2][j0_i - m*st][4 (c4 % 2) ..]; going from m to m+1 moves the
     // address by a constant, and the slot is needed iff tile m has a non-zero weight on row i.
     constexpr int slots = NBR * 16 * NQ;
@@ -387,9 +394,10 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
     const int kbase = meta_k0[0];
     // workgroup-uniform base; the per-slot offsets stay 32-bit
     const float* gbase = a.G + clip * a.g_clip_stride + (int64_t)kbase * NBR * NGG * tc * kDsdGch;
-    int goff[3], dst[3], srow[3];
+    constexpr int NSL = (slots + kThreads - 1) / kThreads;   // float4 slots per thread: 3 (NBR = 3) or 4
+    int goff[NSL], dst[NSL], srow[NSL];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NSL; ++u) {
         const int idx = tid + u * kThreads;
         const int s = idx / (16 * NQ);
         const int rem = idx - s * 16 * NQ;
@@ -401,16 +409,16 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
         goff[u] = ((((in ? meta_k0[i] - kbase : 0) * NBR + s) * NGG + (c4 >> 1)) * tc + (j0 < 0 ? 0 : j0)) * kDsdGch +
                   (c4 & 1) * 4;
     }
-    f32x4 pre[3];
+    f32x4 pre[NSL];
 #define DCS_LOAD_A(m_)                                                                          \
-    _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                             \
+    _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                    \
         if (srow[u] >= 0 && up_t[(m_) * 16 + srow[u]] != 0.f)                                   \
             v = *reinterpret_cast<const f32x4*>(gbase + (goff[u] + (m_) * m_delta));            \
         pre[u] = v;                                                                             \
     }
 #define DCS_STORE_A(buf_)                                                                       \
-    _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                             \
+    _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
         if (srow[u] >= 0) *reinterpret_cast<f32x4*>(As + (buf_) * kABuf + dst[u]) = pre[u];     \
     }
 
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
         if (m + 1 < mmax) DCS_LOAD_A(m + 1)
         if (!live) continue;
         const float* Ab = As + (m & 1) * kABuf + fi * AS + 12 * kq;
-        f32x4 acc[NBR][CBW];
+        f32x4 acc[4][CBW];   // acc[3] only with NBR == 4
 #pragma unroll
         for (int s = 0; s < NBR; ++s)
 #pragma unroll
@@ -465,14 +473,16 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
                 const f32x2 p0 = __builtin_elementwise_max(x0 + bias0, zero);
                 const f32x2 p1 = __builtin_elementwise_max(x1 + bias1, zero);
                 const f32x2 p2 = __builtin_elementwise_max(x2 + bias2, zero);
-                const f32x2 p3 = __builtin_elementwise_max(x1 + bias3, zero);  // 4th source: branch fc12 again (:228)
+                // 4th source: branch fc12 again in the DSD graph (:228), its own branch in the stereo trainer's
+                const f32x2 x3 = NBR == 4 ? f32x2{acc[NBR - 1][cb][2 * h], acc[NBR - 1][cb][2 * h + 1]} : x1;
+                const f32x2 p3 = __builtin_elementwise_max(x3 + bias3, zero);
                 const f32x2 mu = f32x2{mixv[cb][2 * h], mixv[cb][2 * h + 1]} * up;
                 f32x2 s0 = p0, s1 = p1, s2 = p2, s3 = p3, w = up;
                 if (MODE == 0) {  // convention A: m_i = s_i / sum(s), s_i = p_i + eps*r
                     s0 += eps_r; s1 += eps_r; s2 += eps_r; s3 += eps_r;
                     const f32x2 den = ((s0 + s1) + s2) + s3;
                     w = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])} * mu;
-                } else if (MODE == 1) {  // convention B: m_i = p_i / (sum(p) + eps*r)
+                } else if (MODE == 1 || MODE == 3) {  // convention B: m_i = p_i / (sum(p) + eps*r)
                     const f32x2 den = (((p0 + p1) + p2) + p3) + eps_r;
                     w = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])} * mu;
                 }
@@ -498,15 +508,18 @@ __global__ __launch_bounds__(kThreads, 3) void final_kernel(const DsdFinalArgs a
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float* op = a.out + clip * a.out_clip_stride + c * a.out_src_stride + r * a.out_ld + col;
+                    // stereo trainer: source = mask * input + eps*r (trainCNN_ILD_DSD100.py:180); the cross-fade weights of
+                    // a frame sum to one, so the constant is added once, after the fold
+                    const float add = MODE == 3 ? eps_r : 0.f;
                     if constexpr (CBW == 2) {
                         if (vec && col + 1 < a.F) {
-                            *reinterpret_cast<f32x2*>(op) = f32x2{res[0][c][e], res[1][c][e]};
+                            *reinterpret_cast<f32x2*>(op) = f32x2{res[0][c][e] + add, res[1][c][e] + add};
                         } else {
-                            op[0] = res[0][c][e];
-                            if (col + 1 < a.F) op[1] = res[1][c][e];
+                            op[0] = res[0][c][e] + add;
+                            if (col + 1 < a.F) op[1] = res[1][c][e] + add;
                         }
                     } else {
-                        op[0] = res[0][c][e];
+                        op[0] = res[0][c][e] + add;
                     }
                 }
             }
@@ -574,12 +587,29 @@ int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
 #define DCS_FINAL(FOLD_, MODE_)                                                                                      \
     do {                                                                                                             \
         if (cbw == 2)                                                                                                \
-            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 2>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0,       \
+            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 2, 3>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0,    \
                                ctx->stream, a, n_colg);                                                              \
         else                                                                                                         \
-            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 1>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0,       \
+            hipLaunchKernelGGL((final_kernel<FOLD_, MODE_, 1, 3>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0,    \
                                ctx->stream, a, n_colg);                                                              \
     } while (0)
+    if (a.nbr == 4) {   // stereo trainer's graph: fused path only (fold, its own mask) or raw output
+        if (a.mask_mode != 3 && a.mask_mode != 2) DCS_FAIL(DCS_EINVAL, "final: 4-branch graph with mask mode %d", a.mask_mode);
+        if (a.mask_mode == 3) {
+            if (fold) hipLaunchKernelGGL((final_kernel<true, 3, 1, 4>), dim3((unsigned)(n_rg * ((a.F + 63) / 64)), n_clips),
+                                         dim3(kThreads), 0, ctx->stream, a, (a.F + 63) / 64);
+            else hipLaunchKernelGGL((final_kernel<false, 3, 1, 4>), dim3((unsigned)(n_rg * ((a.F + 63) / 64)), n_clips),
+                                    dim3(kThreads), 0, ctx->stream, a, (a.F + 63) / 64);
+        } else {
+            if (fold) hipLaunchKernelGGL((final_kernel<true, 2, 1, 4>), dim3((unsigned)(n_rg * ((a.F + 63) / 64)), n_clips),
+                                         dim3(kThreads), 0, ctx->stream, a, (a.F + 63) / 64);
+            else hipLaunchKernelGGL((final_kernel<false, 2, 1, 4>), dim3((unsigned)(n_rg * ((a.F + 63) / 64)), n_clips),
+                                    dim3(kThreads), 0, ctx->stream, a, (a.F + 63) / 64);
+        }
+        tm.done();
+        DCS_HIP(hipGetLastError());
+        return DCS_OK;
+    }
     if (fold) {
         if (a.mask_mode == 0) DCS_FINAL(true, 0);
         else if (a.mask_mode == 1) DCS_FINAL(true, 1);

@@ -136,18 +136,20 @@ template <typename R, typename R2>
 __global__ __launch_bounds__(kThreads) void stft_forward_kernel(
     const R* __restrict__ audio, int64_t L, const R* __restrict__ win, const R2* __restrict__ tw,
     R* __restrict__ mag, R* __restrict__ phase, R2* __restrict__ unit, int64_t ld, int N, int hop, int log2m,
-    int64_t T, R sqrt_n, int tw_lds, int64_t rows_pc, int64_t audio_stride) {
+    int64_t T, R sqrt_n, int tw_lds, int64_t rows_pc, int64_t audio_stride, int64_t il_clips) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = N >> 1;
     const int tid = threadIdx.x;
     // output row -> (clip, frame): clips of equal length are stacked with a pitch of rows_pc rows
+    // (il_clips > 0: the clips are the channels of one signal and their rows are interleaved, [frame][channel])
     const int64_t row = blockIdx.x;
     const int64_t clip = row / rows_pc;
     const int64_t t = row - clip * rows_pc;
     audio += clip * audio_stride;
-    R* mrow = mag + row * ld;
-    R* prow = phase ? phase + row * ld : nullptr;
-    R2* urow = unit ? unit + row * ld : nullptr;
+    const int64_t orow = il_clips > 0 ? t * il_clips + clip : row;
+    R* mrow = mag + orow * ld;
+    R* prow = phase ? phase + orow * ld : nullptr;
+    R2* urow = unit ? unit + orow * ld : nullptr;
     if (t >= T) {  // rows past the last frame: zeros (zero-padding tiler, util.py:233)
         for (int k = tid; k < ld; k += kThreads) {
             mrow[k] = R(0);
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(kThreads) void istft_fused_kernel(
 
 template <typename R, typename R2>
 int launch_forward(dcs_stft* p, const R* win, const R2* tw, const R* audio, int64_t L, R* mag, R* phase, R2* unit,
-                   int64_t ld, int64_t rows_out, int64_t T, int64_t n_clips = 1, int64_t audio_stride = 0) {
+                   int64_t ld, int64_t rows_out, int64_t T, int64_t n_clips = 1, int64_t audio_stride = 0,
+                   bool interleave = false) {
     if (rows_out <= 0 || n_clips <= 0) return DCS_OK;
     const int M = p->frame / 2;
     size_t lds = (3 * (size_t)M + 1) * sizeof(R2);
@@ -328,7 +331,7 @@ int launch_forward(dcs_stft* p, const R* win, const R2* tw, const R* audio, int6
     DcsTimer tm(p->ctx, DCS_TAG_STFT);
     hipLaunchKernelGGL(kern, dim3((unsigned)(rows_out * n_clips)), dim3(kThreads), lds, p->ctx->stream, audio, L, win, tw,
                        mag, phase, unit, ld, p->frame, p->hop, p->log2m, T, (R)sqrt((double)p->frame), tw_lds, rows_out,
-                       audio_stride);
+                       audio_stride, interleave ? n_clips : (int64_t)0);
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
@@ -404,25 +407,27 @@ int launch_inverse(dcs_stft* p, const R* win, const R2* tw, const R* wsq, const 
 }  // namespace
 
 int dcs_launch_stft_forward_f32_clips(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips,
-                                      float* mag, float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T) {
+                                      float* mag, float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T,
+                                      bool interleave) {
     // few frames: the block-level kernel (4 waves share one frame's FFT) has the shorter critical path
     // (8.6 us vs 19 us for 186 frames); many frames: the wave-per-frame kernel has the higher throughput
     static const int64_t thr_env = getenv("DCS_STFT_WAVE_MIN") ? atoll(getenv("DCS_STFT_WAVE_MIN")) : -1;
     const int64_t thr = thr_env >= 0 ? thr_env : 4 * (int64_t)p->ctx->n_cu;
     if (dcs_fft_wave_supported(p) && rows_out * n_clips >= thr) {
         DcsTimer tm(p->ctx, DCS_TAG_STFT);
-        const int rc = dcs_fft_wave_forward(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T);
+        const int rc = dcs_fft_wave_forward(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T,
+                                            interleave);
         tm.done();
         DCS_CHECK(rc);
         DCS_HIP(hipGetLastError());
         return DCS_OK;
     }
     return launch_forward<float, float2>(p, p->win_f, p->tw_f, audio, L, mag, phase, unit, ld, rows_out, T, n_clips,
-                                         audio_stride);
+                                         audio_stride, interleave);
 }
 int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit,
                                 int64_t ld, int64_t rows_out, int64_t T) {
-    return dcs_launch_stft_forward_f32_clips(p, audio, L, 0, 1, mag, phase, unit, ld, rows_out, T);
+    return dcs_launch_stft_forward_f32_clips(p, audio, L, 0, 1, mag, phase, unit, ld, rows_out, T, false);
 }
 int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, double* mag, double* phase,
                                 double2* unit, int64_t ld, int64_t rows_out, int64_t T) {

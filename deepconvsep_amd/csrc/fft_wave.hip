@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
                                          const float2* __restrict__ tw, float* __restrict__ mag,
                                          float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
                                          int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
-                                         float sqrt_n) {
+                                         float sqrt_n, int interleave) {
     constexpr int M = 1 << LOG2M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,9 +275,10 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     const int64_t clip = row / rows_pc;
     const int64_t t = row - clip * rows_pc;
     audio += clip * audio_stride;
-    float* mrow = mag + row * ld;
-    float* prow = phase ? phase + row * ld : nullptr;
-    float2* urow = unit ? unit + row * ld : nullptr;
+    const int64_t orow = interleave ? t * n_clips + clip : row;   // interleave: rows ordered [frame][clip]
+    float* mrow = mag + orow * ld;
+    float* prow = phase ? phase + orow * ld : nullptr;
+    float2* urow = unit ? unit + orow * ld : nullptr;
     if (t >= T) {
         for (int k = lane; k < ld; k += 64) {
             mrow[k] = 0.f;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
 
 template <int LOG2M>
 int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips, float* mag,
-               float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T) {
+               float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave) {
     constexpr int M = 1 << LOG2M, MP = M + M / 32;
     // frames per workgroup: 4 when there are plenty of frames, 1 to spread a short signal over the CUs
     static const int fpw_env = getenv("DCS_STFT_FPW") ? atoi(getenv("DCS_STFT_FPW")) : 0;
@@ -533,7 +534,7 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride,
                                     (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(rows_all, fpw)), dim3(64 * fpw), lds, p->ctx->stream, audio, L,
                        p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T, rows_out, n_clips, audio_stride,
-                       (float)sqrt((double)p->frame));
+                       (float)sqrt((double)p->frame), interleave ? 1 : 0);
     return DCS_OK;
 }
 
@@ -591,11 +592,11 @@ bool dcs_fft_wave_inverse_supported(const dcs_stft* p) {
 }
 
 int dcs_fft_wave_forward(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips, float* mag,
-                         float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T) {
+                         float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave) {
     switch (p->log2m) {
-        case 9: return launch_fwd<9>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T);
-        case 10: return launch_fwd<10>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T);
-        case 11: return launch_fwd<11>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T);
+        case 9: return launch_fwd<9>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave);
+        case 10: return launch_fwd<10>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave);
+        case 11: return launch_fwd<11>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave);
     }
     DCS_FAIL(DCS_EUNSUPPORTED, "wave FFT: frame size");
 }

@@ -27,6 +27,13 @@ int arch_dims(int arch, int C, int tc, int F, Dims* d) {
             d->branch_fc[0] = 0; d->branch_fc[1] = 1; d->branch_fc[2] = 2; d->branch_fc[3] = 1;
             if (C != 1) DCS_FAIL(DCS_EINVAL, "dsd network takes 1 input channel");
             break;
+        case DCS_ARCH_DSD_ILD:  // dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:86-115: stereo input, one branch per source
+            d->nf1 = 50; d->kw1 = F; d->sw1 = 1; d->pool_w = 0;
+            d->nf2 = 50; d->kh2 = tc / 2; d->kw2 = 1; d->hidden = 256;
+            d->n_fc = 4; d->n_branch = 4; d->S = 4;
+            for (int i = 0; i < 4; ++i) d->branch_fc[i] = i;
+            if (C != 2) DCS_FAIL(DCS_EINVAL, "the stereo (ILD) network takes 2 input channels");
+            break;
         case DCS_ARCH_IKALA:  // separate_ikala.py:173-191
             d->nf1 = 30; d->kw1 = 30; d->sw1 = 3; d->pool_w = 4;
             d->nf2 = 30; d->kh2 = 10; d->kw2 = 20; d->hidden = 256;
@@ -128,8 +135,11 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     const int CI = (int)dcs_round_up(d.nf1, 4), CP = (int)dcs_round_up(d.nf2, 4);
     m->CI = CI;
     m->CP = CP;
-    m->K1 = (int)dcs_round_up(F, 4);
-    m->Fpad = (int)dcs_round_up(F, 128);  // pitch of the final kernel's weights: whole 128-bin workgroups
+    // C input channels sit side by side in a spectrogram row of C * ld floats (ld = F rounded up to 4): conv1's K axis
+    // and the final kernel's bin axis both run over (channel, bin)
+    const int C = m->C, ldF = (int)dcs_round_up(F, 4);
+    m->K1 = C * ldF;
+    m->Fpad = (int)dcs_round_up((int64_t)(C - 1) * ldF + F, 128);  // pitch of the final kernel's weights: whole 128-bin workgroups
     m->d2_ng = 4;
     m->d2_gs = (CI + m->d2_ng - 1) / m->d2_ng;
     m->d2_gcols = (int)dcs_round_up(m->d2_gs * d.kh2, 16);
@@ -144,7 +154,9 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     // conv1 (true convolution = correlation with the flipped filter): B1[f][c] = W1[c,0,0,F-1-f]
     std::vector<float> B1((size_t)dcs_round_up(m->K1, 128) * 64, 0.f), bias1(64, 0.f);
     for (int c = 0; c < d.nf1; ++c) {
-        for (int f = 0; f < F; ++f) B1[(size_t)f * 64 + c] = W1[(size_t)c * F + (F - 1 - f)];
+        for (int ch = 0; ch < C; ++ch)
+            for (int f = 0; f < F; ++f)
+                B1[(size_t)(ch * ldF + f) * 64 + c] = W1[((size_t)c * C + ch) * F + (F - 1 - f)];
         bias1[c] = b1[c] + b1b[c];
     }
     // conv2: B2[u*CI + ci][co] = W2[co,ci,kh-1-u,0]
@@ -193,7 +205,9 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     // transposed conv1: Bfin[c][f] = W1[c,0,0,F-1-f]
     std::vector<float> Bfin((size_t)CI * m->Fpad, 0.f);
     for (int c = 0; c < d.nf1; ++c)
-        for (int f = 0; f < F; ++f) Bfin[(size_t)c * m->Fpad + f] = W1[(size_t)c * F + (F - 1 - f)];
+        for (int ch = 0; ch < C; ++ch)
+            for (int f = 0; f < F; ++f)
+                Bfin[(size_t)c * m->Fpad + ch * ldF + f] = W1[((size_t)c * C + ch) * F + (F - 1 - f)];
     std::vector<float> bout(P[8 + 2 * d.n_fc].begin(), P[8 + 2 * d.n_fc].end());
 
     DCS_CHECK(upload(&m->B1, B1));
@@ -351,7 +365,7 @@ extern "C" int dcs_model_create(dcs_ctx* ctx, int arch, int C, int tc, int F, co
     m->F = F;
     m->d = d;
     int rc;
-    if (arch == DCS_ARCH_DSD) {
+    if (arch == DCS_ARCH_DSD || arch == DCS_ARCH_DSD_ILD) {
         rc = pack_dsd(m, P);
     } else {
         DcsGenericDims gd{d.nf1, d.kw1, d.sw1, d.w1, d.pool_w, d.wp, d.nf2, d.kh2, d.kw2, d.h2, d.w2,
@@ -398,6 +412,8 @@ static int forward_any(dcs_model* m, const float* tiles_d, int64_t n, int mask_m
     if (n == 0) return DCS_OK;
     DCS_HIP(hipSetDevice(m->ctx->device));
     if (m->arch == DCS_ARCH_DSD) return dsd_forward_tiles(m, tiles_d, n, mask_mode, out_d);
+    if (m->arch == DCS_ARCH_DSD_ILD)
+        DCS_FAIL(DCS_EUNSUPPORTED, "the stereo (ILD) graph runs through dcs_separate_stereo (frames shared between tiles)");
     return dcs_generic_forward(m->gen, tiles_d, n, mask_mode, tie_mode, out_d);
 }
 
@@ -566,6 +582,63 @@ extern "C" int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* aud
                                   int tie_mode, float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out) {
     return separate_graphed(m, plan, audio_d, n_samples, n_clips, n_clips > 1 ? clip_stride : 0, overlap, tiler, scale,
                             eps_mode, tie_mode, pcm_d, n_tiles_out, n_frames_out);
+}
+
+// ------------------------------------------------------------------------------------------------ stereo (ILD) path
+// The "Separating" block of examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:291-325 on the DSD kernel family: the two
+// channel spectrograms live side by side in rows of 2*ld floats ([frame][channel][ld]), so conv1's K axis and the
+// final kernel's bin axis run over (channel, bin); every other stage is the DSD one with 4 independent branches.
+extern "C" int dcs_separate_stereo(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t L, int64_t channel_stride,
+                                   int ov, int tiler, float scale, float* pcm_d, float* sep_d, int64_t ld_out,
+                                   int64_t* n_tiles_out, int64_t* n_frames_out) {
+    if (!m || !plan || !audio_d) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: null argument");
+    if (m->arch != DCS_ARCH_DSD_ILD) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: not a stereo (ILD) model");
+    if (plan->ctx != m->ctx) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: plan and model belong to different contexts");
+    if (plan->frame / 2 + 1 != m->F) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: frameSize does not match the network");
+    if (ov < 1 || ov >= m->tc) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: overlap %d not in [1, %d)", ov, m->tc);
+    if (scale == 0.f || L < 1 || channel_stride < L) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: bad scale / length / stride");
+    if (!pcm_d && !sep_d) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: nothing to write");
+    if (sep_d && ld_out < m->F) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: ld_out < bins");
+    DCS_HIP(hipSetDevice(m->ctx->device));
+    const int tc = m->tc, F = m->F, st = tc - ov, S = m->d.S, C = m->C;
+    const int64_t T = dcs_frame_count(L, plan->hop);
+    const int64_t n = dcs_tile_count(T, tc, ov, tiler);
+    if (n_tiles_out) *n_tiles_out = n;
+    if (n_frames_out) *n_frames_out = T;
+    if (n < 1) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: %lld frames give no tile", (long long)T);
+    const int64_t Tcov = (n - 1) * st + tc, Trows = Tcov > T ? Tcov : T;
+    const int64_t ld = dcs_round_up(F, 4), row = C * ld;
+    const size_t b_mag = align256((size_t)Trows * row * 4), b_unit = 2 * b_mag, b_sep = align256((size_t)S * T * row * 4);
+    const int64_t rows2 = (n - 1) * st + m->d.h2;
+    DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_sep + dsd_scratch_bytes(m, n, Tcov, rows2)));
+    char* p = (char*)m->ws.ptr;
+    float* mag = (float*)p; p += b_mag;
+    float2* unit = (float2*)p; p += b_unit;
+    float* sep = (float*)p; p += b_sep;
+    DsdScratch w;
+    dsd_carve(m, p, n, Tcov, rows2, &w);
+    // one STFT per channel (compute_transform, transform.py:80-131), rows written [frame][channel]
+    DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, channel_stride, C, mag, nullptr, unit, ld, Trows, T, true));
+    DCS_CHECK(dsd_encode(m, mag, row, true, scale, n, st, true, w));
+    DCS_CHECK(ensure_rise(m, ov));
+    DsdFinalArgs a{};
+    a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
+    a.mix = mag; a.mix_ld = row; a.mix_scale = scale;
+    a.out = sep; a.out_src_stride = T * row; a.out_ld = row;
+    a.rise = m->rise_d; a.n = n; a.rows = T; a.tc = tc; a.ov = ov; a.st = st;
+    a.F = (int)((C - 1) * ld + F); a.CI = m->CI; a.mmax = (ov + st - 1) / st + 1;
+    a.mask_mode = 3; a.nbr = 4; a.bias_half = (int)ld;
+    DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
+    for (int c = 0; c < C; ++c) {
+        // per channel the S sources are inverted with that channel's phase (:313-316)
+        if (pcm_d)
+            DCS_CHECK(dcs_launch_stft_inverse_f32(plan, sep + c * ld, T * row, nullptr, unit + c * ld, row, T, S, scale,
+                                                  pcm_d + (int64_t)c * S * L, L));
+        for (int s = 0; s < S && sep_d; ++s)
+            DCS_HIP(hipMemcpy2DAsync(sep_d + ((int64_t)c * S + s) * T * ld_out, ld_out * 4, sep + (int64_t)s * T * row + c * ld,
+                                     row * 4, (size_t)F * 4, (size_t)T, hipMemcpyDeviceToDevice, m->ctx->stream));
+    }
+    return DCS_OK;
 }
 
 extern "C" int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,

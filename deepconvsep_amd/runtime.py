@@ -266,6 +266,23 @@ class Network(object):
         self.last_tiles, self.last_frames = nt.value, nf.value
         return out
 
+    def separate_stereo(self, plan, audio_t, overlap, tiler=TILER_LIBRARY, scale=0.3, want_spectra=False):
+        """Stereo (ILD) graph: ``[2, L]`` float32 device tensor (rows contiguous) -> PCM ``[2, S, L]`` (and, with
+        ``want_spectra``, the cross-faded scaled magnitudes ``[2, S, T, F]``)."""
+        torch = _torch()
+        if audio_t.dim() != 2 or audio_t.shape[0] != 2 or audio_t.stride(1) != 1:
+            raise ValueError("separate_stereo expects a [2, samples] tensor with contiguous rows")
+        L = int(audio_t.shape[1])
+        T = _lib.frame_count(L, plan.hop)
+        out = torch.empty((2, self.S, L), dtype=torch.float32, device=audio_t.device)
+        sep = torch.empty((2, self.S, T, self.F), dtype=torch.float32, device=audio_t.device) if want_spectra else None
+        nt, nf = c_int64(), c_int64()
+        _lib.check(self.ctx._lib.dcs_separate_stereo(self._h, plan._h, _ptr(audio_t), L, int(audio_t.stride(0)),
+                                                     int(overlap), int(tiler), float(scale), _ptr(out),
+                                                     _ptr(sep) if sep is not None else None, self.F, byref(nt), byref(nf)))
+        self.last_tiles, self.last_frames = nt.value, nf.value
+        return (out, sep) if want_spectra else out
+
     def separate_spectra(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None,
                          tie_mode=TIE_ALL):
         """Fused path stopped before the iSTFT: (sep ``[S,T,F]``, mag ``[T,F]``, phase ``[T,F]``)."""

@@ -194,6 +194,13 @@ class Separator(object):
         return pcm.cpu().numpy().astype(np.float64)
 
 
+    def separate_stereo(self, audio):
+        """The "Separating" block of the stereo trainer (examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:291-325):
+        ``audio [L, 2]`` -> ``sep_audio [L, S, 2]`` (one stereo signal per source, :299,316)."""
+        a = self.ctx.to_device(np.ascontiguousarray(np.asarray(audio).T), np.float32)          # [2, L]
+        pcm = self.net.separate_stereo(self.plan, a, self.overlap, TILER_LIBRARY, self.scale_factor)
+        return np.ascontiguousarray(pcm.cpu().numpy().astype(np.float64).transpose(2, 1, 0))   # [L, S, 2]
+
     def separate_scoreinformed(self, audio, melody):
         """Score-informed separation (examples/bach10_scoreinformed/separate_bach10.py:497-541), stage by stage on the
         device: STFT -> x scale -> harmonic masks of the score x spectrogram (``dcs_score_masks``) -> library tiler

@@ -47,7 +47,8 @@ typedef enum {
 } dcs_status;
 
 /* build_ca variants (examples/<x>/separate_<x>.py) */
-enum { DCS_ARCH_DSD = 0, DCS_ARCH_IKALA = 1, DCS_ARCH_BACH10 = 2, DCS_ARCH_BACH10_SI = 3 };
+enum { DCS_ARCH_DSD = 0, DCS_ARCH_IKALA = 1, DCS_ARCH_BACH10 = 2, DCS_ARCH_BACH10_SI = 3,
+       DCS_ARCH_DSD_ILD = 4 /* stereo DSD100 graph of examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115 */ };
 /* soft-mask epsilon convention: A = separate_dsd.py:258-266, B = separate_bach10.py:251-259 */
 enum { DCS_EPS_A = 0, DCS_EPS_B = 1 };
 /* max-pool gradient tie routing: ALL = Theano 0.9 CPU MaxPoolGrad, FIRST = cuDNN */
@@ -152,6 +153,16 @@ int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_s
 int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,
                        int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode, int tie_mode,
                        float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out);
+
+/* Stereo separation, the "Separating" block of examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:291-325, for a
+ * DCS_ARCH_DSD_ILD model: audio_d holds the two channels (channel c at audio_d + c * channel_stride), one STFT per
+ * channel, 2-channel tiles (pass DCS_TILER_LIBRARY: the trainer calls util.generate_overlapadd), one network pass,
+ * per input channel the mask of :176-180 (p / (sum over sources + 1e-12 r), source = mask * input + 1e-12 r, r = 0.1
+ * standing in for the trainer's N(0, 0.1) draw), cross-fade, and the iSTFT with that channel's phase.
+ * pcm_d [2][S][n_samples]; sep_d (optional) [2][S][n_frames, ld_out] scaled magnitudes.  Either may be NULL. */
+int dcs_separate_stereo(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t channel_stride,
+                        int overlap, int tiler, float scale, float* pcm_d, float* sep_d, int64_t ld_out,
+                        int64_t* n_tiles_out, int64_t* n_frames_out);
 
 /* Same pipeline stopped before the iSTFT: sep_d [S][n_frames, ld_out] (scaled magnitudes, what the
  * reference calls mm[i,:len(ph)]) and phase_d [n_frames, ld_out]; either may be NULL. */

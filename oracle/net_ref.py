@@ -6,8 +6,11 @@ Graphs restated (all ``build_ca``):
   ikala (pool)   ``examples/ikala/separate_ikala.py:172-192``
   bach10         ``examples/bach10/separate_bach10.py:172-229``
   bach10_si      ``examples/bach10_scoreinformed/separate_bach10.py:388-447``
+  dsd_ild        ``examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115`` (stereo input, one branch
+                 per source, every branch returns both channels: output channel ``s*C + c``)
 Mask expressions: ``separate_dsd.py:258-271`` (convention A),
-``separate_bach10.py:251-264`` (convention B).
+``separate_bach10.py:251-264`` (convention B), ``trainCNN_ILD_DSD100.py:176-189`` (per input
+channel, ``predict_ild``).
 
 Third-party semantics encoded here (Lasagne master / Theano 0.9, the versions
 ``requirements.txt:1-2`` names; neither is vendored in the reference):
@@ -87,7 +90,12 @@ SPECS = {
                       [0, 1, 2, 3], 4, 'B'),
     'bach10_si': NetSpec('bach10_si', 4, (30, 30, 4), None, (30, lambda tc: int(2 * tc / 3), 1),
                          256, [0, 1, 2, 3], 4, 'B'),
+    'dsd_ild': NetSpec('dsd_ild', 2, (50, 'F', 1), None, (50, lambda tc: int(tc / 2), 1), 256,
+                       [0, 1, 2, 3], 4, 'ILD'),
 }
+
+EPS_ILD = 1e-12   # trainCNN_ILD_DSD100.py:155
+RAND_ILD = 0.1    # deterministic stand-in for theano_rng.normal(avg=0, std=0.1) (:166): one standard deviation
 
 
 def _t(a):
@@ -212,3 +220,26 @@ def predict(arch, params, x, tie_mode='all', inverse='autograd', eps_mode=None):
         p = forward(arch, params, x, tie_mode=tie_mode, inverse=inverse)
         outs = soft_mask(arch, p.detach(), x, eps_mode=eps_mode)
     return [o.detach().numpy() for o in outs]
+
+
+def predict_ild(params, x, inverse='autograd'):
+    """``predict_function`` of the stereo trainer (trainCNN_ILD_DSD100.py:176-189, 231): a list over the input
+    channels j of ``[B, S, tc, F]`` arrays,
+
+        mask   = p[:, j::C] / (sum_s p[:, j::C] + eps*r)
+        source = mask * x[:, j:j+1] + eps*r
+
+    with eps = 1e-12 and r a draw from N(0, 0.1) in the reference (one standard deviation here)."""
+    spec = SPECS['dsd_ild']
+    with torch.no_grad() if inverse != 'autograd' else torch.enable_grad():
+        p = forward('dsd_ild', params, x, inverse=inverse).detach()
+    xt = _t(x)
+    e = EPS_ILD * RAND_ILD
+    out = []
+    for j in range(spec.C):
+        pj = p[:, j::spec.C]
+        den = pj[:, 0:1]
+        for s in range(1, pj.shape[1]):
+            den = den + pj[:, s:s + 1]
+        out.append(((pj / (den + e)) * xt[:, j:j + 1] + e).numpy())
+    return out

@@ -82,3 +82,38 @@ def separate_scoreinformed(params, audio, melody, scale_factor=0.3, time_context
     if return_input:
         return pcm, masks
     return pcm
+
+
+def separate_stereo(params, audio, scale_factor=0.3, time_context=30, overlap=25, batch_size=32, frameSize=1024,
+                    hopSize=512, window=np.hanning, return_spectra=False):
+    """The "Separating" block of the stereo trainer (examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:291-325):
+    ``audio [L, 2]``; ``compute_transform`` gives ``mag, ph [2, T, F]`` (one STFT per channel, transform.py:80-131);
+    the LIBRARY tiler cuts 2-channel tiles (:303); ``predict_function`` returns per input channel the S masked
+    sources (:176-189); per channel j the sources are cross-faded (``np.swapaxes(output[:, j:j+1], 1, 3)``, :313) and
+    inverted with that channel's phase (:315).  Returns ``[L, S, 2]`` like ``sep_audio`` (:299)."""
+    audio = np.asarray(audio, dtype=np.float64)
+    L, C = audio.shape
+    mags, phs = [], []
+    for c in range(C):
+        m, p = stft_np.compute_file(audio[:, c], phase=True, frameSize=frameSize, hopSize=hopSize, window=window)
+        mags.append(m)
+        phs.append(p)
+    mag = scale_factor * np.stack(mags).astype(np.float32)
+    batches, nchunks = tiling_np.generate_overlapadd(mag, mag.shape[-1], time_context, overlap, batch_size,
+                                                     tiler=tiling_np.LIBRARY, fill=0.0)
+    if nchunks == 0:
+        raise IndexError("tuple index out of range")
+    output = np.array([net_ref.predict_ild(params, batch, inverse='explicit') for batch in batches])   # [nb, C, B, S, tc, F]
+    T = phs[0].shape[0]
+    sep_audio = np.zeros((L, output.shape[3], C))
+    spectra = []
+    for j in range(C):
+        mm = tiling_np.overlapadd_multi(np.swapaxes(output[:, j:j + 1], 1, 3), nchunks, overlap=overlap)
+        spectra.append(mm[:, :T])
+        for i in range(mm.shape[0]):
+            audio_out = stft_np.compute_inverse(mm[i, :T] / scale_factor, phs[j], frameSize=frameSize, hopSize=hopSize,
+                                                window=window)
+            sep_audio[:, i, j] = audio_out[:L]
+    if return_spectra:
+        return sep_audio, np.stack(spectra, axis=1), mag, np.stack(phs)    # spectra [S, C, T, F]
+    return sep_audio

@@ -106,3 +106,28 @@ def test_set_all_param_values_failure_modes():
         check_params(ARCHS["dsd"], bad, 30, 513)
     with pytest.raises(ValueError):
         net_ref.forward("dsd", bad, _input("dsd", 1, 30, 513))
+
+
+def test_stereo_ild_graph_autograd_equals_explicit_and_masks_per_channel():
+    """The stereo trainer's graph (examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115): VJP by autograd vs explicit
+    transposed convolutions, 17 parameter arrays, output channel s*2 + c, and the per-input-channel masks of
+    :176-180 summing to (almost) the input where any source is active."""
+    import numpy as np
+    from oracle import net_ref
+    spec = net_ref.SPECS['dsd_ild']
+    tc, F = 30, 65
+    rs = np.random.RandomState(0)
+    shapes = spec.param_shapes(tc, F)
+    assert len(shapes) == 17 and shapes[0] == (50, 2, 1, F) and shapes[6] == (800, 256) and shapes[-1] == (8,)
+    params = [rs.uniform(-0.1, 0.1, s) for s in shapes]
+    x = np.abs(rs.randn(2, 2, tc, F))
+    a = net_ref.forward('dsd_ild', params, x, inverse='autograd').detach().numpy()
+    b = net_ref.forward('dsd_ild', params, x, inverse='explicit').numpy()
+    assert a.shape == (2, 8, tc, F) and np.max(np.abs(a - b)) < 1e-12
+    out = net_ref.predict_ild(params, x, inverse='explicit')
+    assert len(out) == 2 and out[0].shape == (2, 4, tc, F)
+    for j in range(2):
+        den = b[:, j::2].sum(axis=1)
+        tot = out[j].sum(axis=1)
+        ok = den > 1e-6
+        assert np.max(np.abs(tot[ok] - x[:, j][ok])) < 1e-6
