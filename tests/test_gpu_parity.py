@@ -491,16 +491,17 @@ def test_graph_replay_recomputes_on_a_side_stream():
     assert np.max(np.abs(other - res[0])) > 1e-3
 
 
-@pytest.mark.parametrize("N,seconds,clips,tiler", [(1024, 1.0, 3, "script"), (2048, 2.14, 8, "script"),
-                                                     (1024, 0.9, 5, "library")])
-def test_separate_batch_equals_clip_by_clip(N, seconds, clips, tiler):
+@pytest.mark.parametrize("N,seconds,clips,tiler,hop", [(1024, 1.0, 3, "script", 512), (2048, 2.14, 8, "script", 512),
+                                                         (1024, 0.9, 5, "library", 512),
+                                                         (512, 0.8, 3, "script", 200)])   # block-level FFT kernels
+def test_separate_batch_equals_clip_by_clip(N, seconds, clips, tiler, hop):
     """dcs_separate_batch: equal-length clips sharing one set of launches are each separated exactly as
     dcs_separate separates them alone -- same tiles, same cross-fade; only fp32 rounding may differ, because the
     FFT / GEMM kernel variants are picked by the total amount of work -- and match the oracle."""
     import torch
     F = N // 2 + 1
     params = synth_params("dsd", 30, F, seed=2)
-    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, N, 512, np.hanning, tiler=tiler)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, N, hop, np.hanning, tiler=tiler)
     L = int(44100 * seconds)
     audio = np.stack([synth_audio(L, seed=40 + c) for c in range(clips)]).astype(np.float32)
     audio[1, L // 3: L // 2] = 0.0                               # a digital-silence gap in one clip
@@ -510,7 +511,7 @@ def test_separate_batch_equals_clip_by_clip(N, seconds, clips, tiler):
     for c in range(clips):
         alone = sep.net.separate(sep.plan, buf[c], 25, sep.tiler, 0.3).cpu().numpy()
         assert np.max(np.abs(got[c] - alone)) < 2e-6, "clip %d differs from the single-clip path" % c
-    want = pipeline.separate("dsd", params, audio[1].astype(np.float64), 0.3, 30, 25, 32, N, 512, np.hanning,
+    want = pipeline.separate("dsd", params, audio[1].astype(np.float64), 0.3, 30, 25, 32, N, hop, np.hanning,
                              tiler=tiling_np.SCRIPT if tiler == 'script' else tiling_np.LIBRARY)
     assert np.max(np.abs(got[1] - want)) < 1e-4
     # a strided view (clip stride > length) goes through the same entry point
@@ -771,8 +772,8 @@ def test_pcm_to_int16_is_the_scripts_wav_format():
 
 
 # ------------------------------------------------------------------ stereo (ILD) graph, SURVEY 8f-4
-@pytest.mark.parametrize("N,seconds", [(1024, 2.0), (2048, 1.2)])
-def test_stereo_ild_separation_matches_oracle(N, seconds):
+@pytest.mark.parametrize("N,seconds,hop", [(1024, 2.0, 512), (2048, 1.2, 512), (512, 1.0, 200)])
+def test_stereo_ild_separation_matches_oracle(N, seconds, hop):
     """dcs_separate_stereo (examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:291-325 on the DSD kernel family:
     per-channel STFT, 2-channel library tiles, 4 branches x 2 channels, per-channel masks, per-channel phase)
     against oracle.pipeline.separate_stereo: cross-faded magnitudes per masked bin and PCM."""
@@ -781,8 +782,8 @@ def test_stereo_ild_separation_matches_oracle(N, seconds):
     stereo = synth_audio(L, seed=61, channels=2)
     stereo[L // 3: L // 3 + 5000, 1] = 0.0                      # one channel silent for a while
     params = synth_params("dsd_ild", 30, F, seed=7)
-    sep = dcs.Separator("dsd_ild", params, 0.3, 30, 25, 32, F, N, 512, np.hanning, tiler='library')
-    want, spectra, mag, ph = pipeline.separate_stereo(params, stereo, 0.3, 30, 25, 32, N, 512, np.hanning,
+    sep = dcs.Separator("dsd_ild", params, 0.3, 30, 25, 32, F, N, hop, np.hanning, tiler='library')
+    want, spectra, mag, ph = pipeline.separate_stereo(params, stereo, 0.3, 30, 25, 32, N, hop, np.hanning,
                                                       return_spectra=True)
     a = sep.ctx.to_device(np.ascontiguousarray(stereo.T), np.float32)
     pcm, spec = sep.net.separate_stereo(sep.plan, a, 25, sep.tiler, 0.3, want_spectra=True)
