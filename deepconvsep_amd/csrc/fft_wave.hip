@@ -150,6 +150,20 @@ __device__ __forceinline__ void dft8(cx* v) {
 }
 __device__ __forceinline__ constexpr int perm8(int k) { return 2 * (k & 3) + (k >> 2); }
 
+// rot16 with the exponent known only after loop unrolling (m in {0,1,2,3,4,6,9})
+template <int DIR>
+__device__ __forceinline__ cx rot16_sel(cx v, int m) {
+    switch (m) {
+        case 0: return v;
+        case 1: return rot16<DIR, 1>(v);
+        case 2: return rot16<DIR, 2>(v);
+        case 3: return rot16<DIR, 3>(v);
+        case 4: return rot16<DIR, 4>(v);
+        case 6: return rot16<DIR, 6>(v);
+        default: return rot16<DIR, 9>(v);
+    }
+}
+
 template <int R, int DIR>
 __device__ __forceinline__ void dftR(cx* v) {
     if (R == 16) dft16<DIR>(v);
@@ -165,24 +179,25 @@ template <> struct Plan<10> { static constexpr int R1 = 16, R2 = 16, R3 = 4; };
 template <> struct Plan<11> { static constexpr int R1 = 16, R2 = 16, R3 = 8; };
 
 // Per-lane pass twiddles (table values exp(-i theta)), constant over the frames a wave transforms.
-// Pass 2 (Ns = R1): k = lane mod R1 for every block b.  Pass 3 (Ns = R1 R2): k = lane + 64 b.  For M = 2048
-// the 28 pass-3 twiddles would cost 56 registers on top of 64 for the data: they stay in the LDS table.
+// Pass 2 (Ns = R1): k = lane mod R1 for every block b.  Pass 3 (Ns = R1 R2): k = lane + 64 b, twiddle
+// w^(2 t (lane + 64 b)) = w^(2 t lane) * W16^(t b) for M = 1024: only the lane part is kept (R3 - 1 registers pairs),
+// the block part is one of the constant rotations of rot16 (7 of the 12 are trivial or absent).  For M = 2048 the
+// pass-3 twiddles stay in the LDS table (64 registers of data already).
 template <int LOG2M>
 struct WaveTw {
     using PL = Plan<LOG2M>;
     static constexpr int M = 1 << LOG2M, P = M / 64, NB3 = P / PL::R3;
     static constexpr bool REG3 = LOG2M <= 10;
     cx t2[PL::R2 - 1];
-    cx t3[REG3 ? NB3 * (PL::R3 - 1) : 1];
+    cx t3[REG3 ? (PL::R3 - 1) : 1];
+    static_assert(!REG3 || NB3 == 1 || M == 1024, "block part of the pass-3 twiddle is W16^(t b) only for M = 1024");
     __device__ __forceinline__ void init(const float2* tw, int lane) {
         const int step2 = ((2 * M) / PL::R2 / PL::R1) * (lane & (PL::R1 - 1));
 #pragma unroll
         for (int t = 1; t < PL::R2; ++t) t2[t - 1] = tw_fwd(tw, t * step2, M);
         if (REG3) {
 #pragma unroll
-            for (int b = 0; b < NB3; ++b)
-#pragma unroll
-                for (int t = 1; t < PL::R3; ++t) t3[b * (PL::R3 - 1) + t - 1] = tw_fwd(tw, t * 2 * (lane + 64 * b), M);
+            for (int t = 1; t < PL::R3; ++t) t3[t - 1] = tw_fwd(tw, t * 2 * lane, M);
         }
     }
 };
@@ -239,8 +254,11 @@ __device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, c
         for (int b = 0; b < NB3; ++b) {
 #pragma unroll
             for (int t = 1; t < R3; ++t) {
-                const cx tw = WaveTw<LOG2M>::REG3 ? w.t3[b * (R3 - 1) + t - 1] : tw_fwd(twl, t * 2 * (lane + 64 * b), M);
-                v[b * R3 + t] = c_tw<DIR>(v[b * R3 + t], tw);
+                if (WaveTw<LOG2M>::REG3) {
+                    v[b * R3 + t] = rot16_sel<DIR>(c_tw<DIR>(v[b * R3 + t], w.t3[t - 1]), t * b);
+                } else {
+                    v[b * R3 + t] = c_tw<DIR>(v[b * R3 + t], tw_fwd(twl, t * 2 * (lane + 64 * b), M));
+                }
             }
             dftR<R3, DIR>(&v[b * R3]);
         }
@@ -356,8 +374,23 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
 // N/hop + 3 blocks whatever C is, and only the N/hop - 1 frames before the first block are transformed
 // twice (by this workgroup and by its left neighbour).  Requires hop | N and hop even.
 // ------------------------------------------------------------------------------------------------
-template <int LOG2M, bool UNIT>
-__global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict__ mag, int64_t src_stride,
+// exp(-i pi j / 16), j = 0..15: the part w^(64 j) of the pre-processing twiddle w^(lane + 64 j) for M = 1024 (every
+// second entry for M = 512)
+__device__ __forceinline__ cx w_pi16(int j) {
+    constexpr float c[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                             0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.f, -0.19509032201612825f,
+                             -0.38268343236508977f, -0.55557023301960218f, -0.70710678118654752f, -0.83146961230254524f,
+                             -0.92387953251128674f, -0.98078528040323043f};
+    // -sin(pi j/16) = cos(pi (j+8)/16) for j < 8, = -cos(pi (j-8)/16) for j >= 8
+    return mk(c[j & 15], c[(j + 8) & 15] * ((j & 15) >= 8 ? -1.f : 1.f));
+}
+
+// WREG = N / hop when the window pairs a thread needs fit in registers (hop/2 <= 256, N/hop in {2, 4}), else 0.
+// With WREG > 0 and M <= 1024 the kernel keeps neither the twiddle table nor the window in LDS -- the pre-processing
+// twiddle w^k, k = lane + 64 j, is w^lane (one register pair) times a constant -- which brings a workgroup to
+// 52 KB and 3 of them onto a CU (measured: 2 -> 1 workgroups per CU costs 1.6x).
+template <int LOG2M, bool UNIT, int WREG>
+__global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_wave_kernel(const float* __restrict__ mag, int64_t src_stride,
                                                          const float* __restrict__ phase,
                                                          const float2* __restrict__ unit, int64_t ld,
                                                          const float* __restrict__ win, const float* __restrict__ wsq,
@@ -367,11 +400,16 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
                                                          float sqrt_n, int64_t unit_clip_stride, int src_per_clip) {
     constexpr int M = 1 << LOG2M, N = 2 * M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
+    constexpr bool LEAN = WREG > 0 && WaveTw<LOG2M>::REG3;   // no twiddle / window tables in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* twl = reinterpret_cast<float2*>(smem);      // [M + 1]
-    float2* fbuf = twl + (M + 1);                        // [4][MP] transformed frames
-    float2* winl = fbuf + 4 * MP;                        // [M] window as (even, odd) pairs
-    float2* ring = winl + M;                             // [ring_slots][hop/2]
+    float2* lp = reinterpret_cast<float2*>(smem);
+    float2* twl = lp;                                    // [M + 1]   (not LEAN)
+    if (!LEAN) lp += M + 1;
+    float2* fbuf = lp;                                   // [4][MP] transformed frames
+    lp += 4 * MP;
+    float2* winl = lp;                                   // [M] window as (even, odd) pairs   (WREG == 0)
+    if (WREG == 0) lp += M;
+    float2* ring = lp;                                   // [ring_slots][hop/2]
     float* norm_s = reinterpret_cast<float*>(ring + (size_t)ring_slots * (hop >> 1));  // [hop] steady-state sum(w^2)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -394,10 +432,17 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
     const int64_t hb0 = (int64_t)chunk * C;
     const int64_t hb1 = (hb0 + C < n_blocks) ? hb0 + C : n_blocks;
 
+    cx wreg[WREG > 0 ? WREG : 1];                        // window pairs of this thread's column, one per frame block
     {
         const float2* w2g = reinterpret_cast<const float2*>(win);
-        for (int k = tid; k < M; k += 256) winl[k] = w2g[k];
-        for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
+        if (WREG == 0) {
+            for (int k = tid; k < M; k += 256) winl[k] = w2g[k];
+        } else {
+#pragma unroll
+            for (int d = 0; d < WREG; ++d) wreg[d] = tid < hp ? ldc(w2g + d * hp + tid) : mk(0.f, 0.f);
+        }
+        if (!LEAN)
+            for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
         for (int q = tid; q < ring_slots * hp; q += 256) stc(ring + q, mk(0.f, 0.f));
         for (int q = tid; q < hop; q += 256) {
             float nrm = 0.f;
@@ -415,7 +460,8 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
     float* dst = audio + (int64_t)s * n_out;
     __syncthreads();
     WaveTw<LOG2M> wt;
-    wt.init(twl, lane);
+    wt.init(LEAN ? tw : twl, lane);
+    const cx wl = ldc(tw + lane);                        // w^lane (LEAN)
 
     int64_t g_done = hb0;  // next block to write out
     // flush blocks [g_done, g_end): every frame that touches them has been added (or does not exist)
@@ -487,13 +533,36 @@ __global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict
                     }
                     // E = (xk + conj xm)/2 ; D = (xk - conj xm)/2 ; O = D conj(w^k) ; Z = E + i O   (1/2 is in amp)
                     const cx e = c_add_conj(xk, xm), d = c_sub_conj(xk, xm);
-                    const cx o = c_mul_conj(d, ldc(twl + k));
+                    cx wk;
+                    if (LEAN) {   // k = lane + 64 j: w^k = w^lane * exp(-i pi 64 j / M)
+                        const int jj = (b + tt * NB1) * (1024 / M);
+                        wk = jj == 0 ? wl : c_mul(wl, w_pi16(jj));
+                    } else {
+                        wk = ldc(twl + k);
+                    }
+                    const cx o = c_mul_conj(d, wk);
                     v[b * R1 + tt] = c_add_i(e, o);
                 }
             fft_wave<LOG2M, +1>(v, lane, wt, twl, buf);
         }
         __syncthreads();
         // frame n2 covers the hop-blocks n2 .. n2 + R - 1
+        if (WREG > 0) {
+            if (tid < hp) {
+                for (int w = 0; w < 4; ++w) {
+                    const int64_t n2 = nb + w;
+                    if (n2 > n_hi) break;
+#pragma unroll
+                    for (int d = 0; d < WREG; ++d) {
+                        const int64_t g = n2 + d;
+                        if (g < hb0 || g >= hb1) continue;
+                        float2* rp = ring + (int)(g & rmask) * hp + tid;
+                        const cx z = ldc(fbuf + w * MP + pad(d * hp + tid));
+                        stc(rp, ldc(rp) + (z * inv_m) * wreg[d]);
+                    }
+                }
+            }
+        } else
         for (int w = 0; w < 4; ++w) {
             const int64_t n2 = nb + w;
             if (n2 > n_hi) break;
@@ -547,8 +616,12 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     const int64_t n_blocks = (n_out + N / 2 + hop - 1) / hop;
     int ring_slots = 8;
     while (ring_slots < R_ + 3) ring_slots *= 2;
-    const size_t lds = ((size_t)(M + 1) + 4 * (size_t)MP + (size_t)M + (size_t)ring_slots * (hop / 2)) * sizeof(float2) +
-                       (size_t)hop * sizeof(float);
+    // window pairs in registers when a thread owns one pair per hop-block and a frame is 2 or 4 blocks; then (M <= 1024)
+    // neither the window nor the twiddle table take LDS
+    static const int lean_env = getenv("DCS_ISTFT_LEAN") ? atoi(getenv("DCS_ISTFT_LEAN")) : 1;
+    const int wreg = (lean_env && hop / 2 <= 256 && (R_ == 2 || R_ == 4) && LOG2M <= 10) ? R_ : 0;
+    const size_t lds = ((wreg ? 0 : (size_t)(M + 1)) + 4 * (size_t)MP + (wreg ? 0 : (size_t)M) +
+                        (size_t)ring_slots * (hop / 2)) * sizeof(float2) + (size_t)hop * sizeof(float);
     static const int pad_env = getenv("DCS_ISTFT_LDSPAD") ? atoi(getenv("DCS_ISTFT_LDSPAD")) : 0;  // occupancy experiments
     const size_t lds_req = lds + (size_t)pad_env;
     if (lds_req > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "wave iSTFT: %zu bytes of LDS", lds_req);
@@ -564,9 +637,11 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     if (c_env > 0) C = c_env;
     const int n_chunks = (int)((n_blocks + C - 1) / C);
     const dim3 grid((unsigned)n_chunks * (unsigned)n_src);
-#define DCS_GO(UNIT_)                                                                                             \
+#define DCS_GO(UNIT_) \
+    { if (wreg == 4) { DCS_GO2(UNIT_, 4) } else if (wreg == 2) { DCS_GO2(UNIT_, 2) } else { DCS_GO2(UNIT_, 0) } }
+#define DCS_GO2(UNIT_, WREG_)                                                                                     \
     {                                                                                                             \
-        auto kern = istft_wave_kernel<LOG2M, UNIT_>;                                                              \
+        auto kern = istft_wave_kernel<LOG2M, UNIT_, (LOG2M <= 10 ? WREG_ : 0)>;                                    \
         if (lds_req > 48 * 1024)                                                                                  \
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req));               \
@@ -576,6 +651,7 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     }
     if (unit) DCS_GO(true) else DCS_GO(false)
 #undef DCS_GO
+#undef DCS_GO2
     return DCS_OK;
 }
 

@@ -626,6 +626,7 @@ def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
     {"DCS_DECONV2": "2"}, {"DCS_DECONV2": "1"},                   # streaming / one-shot transposed conv2
     {"DCS_ISTFT_HOPS": "1"}, {"DCS_ISTFT_HOPS": "7"}, {"DCS_ISTFT_HOPS": "64"},   # hop-blocks per iSTFT workgroup
     {"DCS_STFT_WAVE_MIN": "1"}, {"DCS_FFT_BLOCK": "1"},           # wave-per-frame / block-level FFT everywhere
+    {"DCS_ISTFT_LEAN": "0"},                                       # iSTFT with its twiddle / window tables in LDS
     {"DCS_GRAPH": "0"},
 ])
 @pytest.mark.parametrize("N", [1024, 2048])
