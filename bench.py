@@ -103,7 +103,7 @@ def main():
     assert n_tiles == args.tiles, (n_tiles, args.tiles)
     frames_per_step = (n_tiles - 1) * (TC - OV) + TC        # unique frames fully separated
     NS = max(1, args.streams)
-    CPL = max(1, args.clips_per_launch)
+    CPL = max(1, min(args.clips_per_launch, args.steps))     # a run shorter than one launch group is one smaller group
 
     import ctypes
 
