@@ -257,6 +257,18 @@ __global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* _
 // chosen so that a lane's 13 channels are 3 aligned float4 + 1 float).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// max(x, lo), lo >= 0, on both halves, as a SIGNED INTEGER max of the bit patterns: non-negative floats order like
+// their bits and every negative float (sign bit set) is a negative integer, so this is exact for lo >= 0.  fmaxf on a
+// value that comes straight out of an MFMA makes the compiler canonicalise it first (one more v_max_f32 per element);
+// the integer form needs no canonical input.
+__device__ __forceinline__ f32x2 max2(f32x2 x, float lo) {
+    const int l = __builtin_bit_cast(int, lo);
+    const i32x2 xi = __builtin_bit_cast(i32x2, x);
+    const i32x2 r = {xi[0] > l ? xi[0] : l, xi[1] > l ? xi[1] : l};
+    return __builtin_bit_cast(f32x2, r);
+}
 
 // channel multiplied in MFMA step q by the lanes of K-quarter kq: 12 contiguous channels + 1 of the last 4
 __device__ __forceinline__ constexpr int final_chan(int q, int kq) { return q < 12 ? 12 * kq + q : 48 + kq; }
@@ -430,11 +442,15 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
         if (m + 1 < mmax) DCS_LOAD_A(m + 1)
         if (!live) continue;
         const float* Ab = As + (m & 1) * kABuf + fi * AS + 12 * kq;
+        // the output bias (separate_dsd.py:232) rides in as the MFMAs' initial accumulator value: no add afterwards
         f32x4 acc[4][CBW];   // acc[3] only with NBR == 4
 #pragma unroll
-        for (int s = 0; s < NBR; ++s)
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < CBW; ++cb) {
+            acc[0][cb] = f32x4{bias0, bias0, bias0, bias0};
+            acc[1][cb] = f32x4{bias1, bias1, bias1, bias1};
+            acc[2][cb] = f32x4{bias2, bias2, bias2, bias2};
+            if (NBR == 4) acc[3][cb] = f32x4{bias3, bias3, bias3, bias3};
+        }
         // A fragments of K-quarter kq: channels 12kq .. 12kq+11 (three float4) and channel 48+kq
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -469,17 +485,16 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
                 const f32x2 x0 = {acc[0][cb][2 * h], acc[0][cb][2 * h + 1]};
                 const f32x2 x1 = {acc[1][cb][2 * h], acc[1][cb][2 * h + 1]};
                 const f32x2 x2 = {acc[2][cb][2 * h], acc[2][cb][2 * h + 1]};
-                const f32x2 zero = {0.f, 0.f};
-                const f32x2 p0 = __builtin_elementwise_max(x0 + bias0, zero);
-                const f32x2 p1 = __builtin_elementwise_max(x1 + bias1, zero);
-                const f32x2 p2 = __builtin_elementwise_max(x2 + bias2, zero);
-                // 4th source: branch fc12 again in the DSD graph (:228), its own branch in the stereo trainer's
-                const f32x2 x3 = NBR == 4 ? f32x2{acc[NBR - 1][cb][2 * h], acc[NBR - 1][cb][2 * h + 1]} : x1;
-                const f32x2 p3 = __builtin_elementwise_max(x3 + bias3, zero);
+                // 4th source: branch fc12 again in the DSD graph (:228; its accumulator carries bias1, so bias3 - bias1 is
+                // added), its own branch in the stereo trainer's
+                const f32x2 x3 = NBR == 4 ? f32x2{acc[NBR - 1][cb][2 * h], acc[NBR - 1][cb][2 * h + 1]} : x1 + (bias3 - bias1);
+                // rectify; convention A adds eps*r = 5e-19 to every rectified value: max(x, 0) + eps == max(x, eps) in
+                // float32 except for 0 < x < ~1e-11, where the two differ by at most eps itself
+                const float lo = MODE == 0 ? eps_r : 0.f;
+                const f32x2 p0 = max2(x0, lo), p1 = max2(x1, lo), p2 = max2(x2, lo), p3 = max2(x3, lo);
                 const f32x2 mu = f32x2{mixv[cb][2 * h], mixv[cb][2 * h + 1]} * up;
                 f32x2 s0 = p0, s1 = p1, s2 = p2, s3 = p3, w = up;
                 if (MODE == 0) {  // convention A: m_i = s_i / sum(s), s_i = p_i + eps*r
-                    s0 += eps_r; s1 += eps_r; s2 += eps_r; s3 += eps_r;
                     const f32x2 den = ((s0 + s1) + s2) + s3;
                     w = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])} * mu;
                 } else if (MODE == 1 || MODE == 3) {  // convention B: m_i = p_i / (sum(p) + eps*r)
