@@ -561,6 +561,62 @@ __global__ __launch_bounds__(kColThreads) void colconv_f16_kernel(const ColConvA
 }
 
 // ------------------------------------------------------------------------------------------------
+// VJP of conv1 for a frequency stride that divides 16 (Bach10 / score-informed: kw = 30, stride 4), register-blocked.
+// With f = sw q + r the sum is  o[f] = sum_o' sum_mm g[o'][q - mm] * W[o'][sw mm + r],  mm < ceil(kw / sw): a thread
+// owns 16 consecutive f (16/sw values of q, all r) of one row, keeps the 16 sums and the 16/sw + ceil(kw/sw) - 1 inputs
+// of the current channel in registers, and reads the filter row of that channel -- the same for every thread -- with
+// scalar loads (the filter is padded to sw*ceil(kw/sw) taps so the unrolled loop needs no tap test).  128 multiply-adds
+// per 11 vector loads for the Bach10 shape; the direct kernel below does one LDS read per operand (2 per
+// multiply-add) and is LDS-bandwidth bound: 1.3 ms -> see DESIGN.md for 167 tiles.
+// ------------------------------------------------------------------------------------------------
+template <int SW, int NT /* taps per residue = ceil(kw / SW) */>
+__global__ __launch_bounds__(kThreads) void deconv1_reg_kernel(const float* __restrict__ g, const float* __restrict__ Wp,
+                                                               float* __restrict__ out, int NF, int C, int tc, int F,
+                                                               int w1, int nqb) {
+    constexpr int QB = 16 / SW, XI = QB + NT - 1;
+    const int64_t m = blockIdx.y;
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= tc * nqb) return;
+    const int t = idx / nqb, qb = idx - t * nqb;
+    const int q0 = qb * QB, j0 = q0 - (NT - 1);            // inputs j0 .. j0 + XI - 1
+    const float* grow = g + (m * NF * tc + t) * (int64_t)w1;
+    for (int c = 0; c < C; ++c) {
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int o = 0; o < NF; ++o) {
+            const float* gp = grow + (int64_t)o * tc * w1;
+            float gw[XI];
+            if (XI <= 12 && j0 >= 0 && j0 + 12 <= w1) {   // interior: three (unaligned) 16-byte loads
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(gp + j0), v1 = *reinterpret_cast<const f32x4*>(gp + j0 + 4),
+                            v2 = *reinterpret_cast<const f32x4*>(gp + j0 + 8);
+#pragma unroll
+                for (int x = 0; x < XI; ++x) gw[x] = x < 4 ? v0[x & 3] : (x < 8 ? v1[x & 3] : v2[x & 3]);
+            } else {
+#pragma unroll
+                for (int x = 0; x < XI; ++x) {
+                    const int j = j0 + x;
+                    gw[x] = (j >= 0 && j < w1) ? gp[j] : 0.f;
+                }
+            }
+            const float* wr = Wp + ((int64_t)o * C + c) * (SW * NT);   // uniform: scalar loads
+#pragma unroll
+            for (int mm = 0; mm < NT; ++mm)
+#pragma unroll
+                for (int r = 0; r < SW; ++r) {
+                    const float w = wr[SW * mm + r];
+#pragma unroll
+                    for (int i = 0; i < QB; ++i) acc[i * SW + r] = fmaf(gw[i + (NT - 1) - mm], w, acc[i * SW + r]);
+                }
+        }
+        float* op = out + ((m * C + c) * tc + t) * (int64_t)F + (int64_t)q0 * SW;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (q0 * SW + i < F) op[i] = acc[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // VJP of conv1: o[m, c, t, f] = sum_{o', j : 0 <= f - j*sw < kw} g[m, o', t, j] * Wc[o', c, f - j*sw]
 // block = 256 consecutive f of one (m, t) row, all C output channels.
 // ------------------------------------------------------------------------------------------------
@@ -661,6 +717,7 @@ struct DcsGenericNet {
     _Float16 *W2m_h = nullptr, *W2t_h = nullptr;
     int conv_f16 = 0;
     // column convolution (kw2 == 1): weights [kh][32 ci][32 co swizzled] of conv2 and of its transpose
+    float* W1p = nullptr;      // conv1 filters padded to sw1*ceil(kw1/sw1) taps (register-blocked transpose of conv1)
     float *Wcol = nullptr, *Wcol_t = nullptr;
     _Float16 *Wcol_h = nullptr, *Wcol_t_h = nullptr;     // [kh][32 co][40] halves, channel-fastest
     int use_colconv = 0;
@@ -696,6 +753,15 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         for (int c = 0; c < C; ++c)
             for (int u = 0; u < kw1; ++u) W1c[((size_t)o * C + c) * kw1 + u] = W1[((size_t)o * C + c) * kw1 + (kw1 - 1 - u)];
         bias1[o] = b1[o] + b1b[o];
+    }
+    // the same filters with the tap axis zero-padded to a multiple of the stride (deconv1_reg_kernel)
+    std::vector<float> W1p;
+    if (16 % d.sw1 == 0) {
+        const int ntap = d.sw1 * ((kw1 + d.sw1 - 1) / d.sw1);
+        W1p.assign((size_t)nf1 * C * ntap, 0.f);
+        for (int o = 0; o < nf1; ++o)
+            for (int c = 0; c < C; ++c)
+                for (int u = 0; u < kw1; ++u) W1p[((size_t)o * C + c) * ntap + u] = W1c[((size_t)o * C + c) * kw1 + u];
     }
     // conv2: k = (ci, u, v); Wm[k][co] = W2[co][ci][kh-1-u][kw-1-v]; input plane = [tc, wp]
     const int K2 = nf1 * kh * kw;
@@ -767,6 +833,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     UP(g->W1c, W1c) UP(g->bias1, bias1) UP(g->W2m, W2m) UP(g->bias2, bias2) UP(g->k2off, k2off) UP(g->k2uv, k2uv)
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
+    if (!W1p.empty()) { UP(g->W1p, W1p) }
     if (g->use_colconv) { UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) }
     for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) {
         std::vector<float> Bd((size_t)dcs_round_up(g->hid64, 128) * g->flat64, 0.f), bd(g->flat64, 0.f);
@@ -788,7 +855,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d};
     for (void* p : ptrs)
@@ -941,8 +1008,15 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
         DcsTimer tm(ctx, DCS_TAG_FINAL);
-        hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(F, kThreads), (unsigned)(n * NB * tc)), dim3(kThreads), lds,
-                           ctx->stream, g1, g->W1c, o, C, tc, F, d.kw1, d.sw1, d.w1);
+        static const int reg_env = getenv("DCS_DECONV1_REG") ? atoi(getenv("DCS_DECONV1_REG")) : 1;
+        if (g->W1p && reg_env && d.sw1 == 4 && (d.kw1 + 3) / 4 == 8) {
+            const int nqb = (F + 15) / 16;
+            hipLaunchKernelGGL((deconv1_reg_kernel<4, 8>), dim3((unsigned)dcs_cdiv((int64_t)tc * nqb, kThreads), (unsigned)(n * NB)),
+                               dim3(kThreads), 0, ctx->stream, g1, g->W1p, o, d.nf1, C, tc, F, d.w1, nqb);
+        } else {
+            hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(F, kThreads), (unsigned)(n * NB * tc)), dim3(kThreads), lds,
+                               ctx->stream, g1, g->W1c, o, C, tc, F, d.kw1, d.sw1, d.w1);
+        }
         tm.done();
     }
     // concat + bias + rectify + mask.  out is [S or CH][n_total][tc][F]; this chunk starts at tile k_first.
