@@ -111,9 +111,12 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (gK + BK - 1) / BK;
-    DCS_LOAD_TILES(0)
-    for (int kt = 0; kt < nkt; ++kt) {
+    // K tiles of this workgroup: all of them, or slice blockIdx.z of a K-split launch (kchunk % BK == 0)
+    const int kt0 = g.partial ? (int)blockIdx.z * (g.kchunk / BK) : 0;
+    int nkt = (gK + BK - 1) / BK;
+    if (g.partial && kt0 + g.kchunk / BK < nkt) nkt = kt0 + g.kchunk / BK;
+    if (kt0 < nkt) DCS_LOAD_TILES(kt0)
+    for (int kt = kt0; kt < nkt; ++kt) {
         __syncthreads();
         DCS_STORE_TILES()
         __syncthreads();
@@ -131,7 +134,15 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
 
     // epilogue: C/D layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
     const int col = n0 + wave * 16 + fi;
-    if (col < g.n_store) {
+    if (g.partial) {   // raw sums of this K slice; gemm_ksplit_reduce_kernel adds the slices, bias, rectifier
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = m0 + r * 16 + kq * 4 + e;
+                if (row < g.M) g.partial[((int64_t)blockIdx.z * g.M + row) * g.n_cols + col] = acc[r][e];
+            }
+    } else if (col < g.n_store) {
         const float bias = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -275,7 +286,10 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     static const int ks_env = getenv("DCS_GEMM_KSPLIT") ? atoi(getenv("DCS_GEMM_KSPLIT")) : -1;   // 0 disables
     const int64_t tiles16 = groups16 * (g.n_cols / 16);
     if (g.a_vec && ks_env != 0 && g.K >= 16384 && tiles16 < 4 * (int64_t)ctx->n_cu) {
-        int ksplit = ks_env > 0 ? ks_env : (int)((8 * (int64_t)ctx->n_cu + tiles16 - 1) / tiles16);
+        static const int ks_tile = getenv("DCS_GEMM_KSPLIT_TILED") ? atoi(getenv("DCS_GEMM_KSPLIT_TILED")) : 1;
+        const bool tiled = ks_tile && g.M >= 48;
+        const int64_t units = tiled ? dcs_cdiv(g.M, 64) * (g.n_cols / BN) : tiles16;
+        int ksplit = ks_env > 0 ? ks_env : (int)(((tiled ? 3 : 8) * (int64_t)ctx->n_cu + units - 1) / units);
         if (ksplit > 64) ksplit = 64;
         int kchunk = (int)dcs_round_up((g.K + ksplit - 1) / ksplit, 256);
         ksplit = (g.K + kchunk - 1) / kchunk;
@@ -284,8 +298,15 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
             DcsGemm q = g;
             q.partial = (float*)ctx->gemm_ws.ptr;
             q.kchunk = kchunk;
-            hipLaunchKernelGGL(gemm_rows_splitk_kernel, dim3((unsigned)groups16, (unsigned)(g.n_cols / 16), (unsigned)ksplit),
-                               dim3(kThreads), 0, ctx->stream, q);
+            // 64 x 64 LDS tiles reuse every operand 4x more often than the 16 x 16 register tiles (which stream A and B
+            // from L2 with 4 flop/B): worth it from a few row groups on
+            if (tiled)
+                hipLaunchKernelGGL((gemm_rows_kernel<4, 32, true>), dim3((unsigned)dcs_cdiv(g.M, 64), (unsigned)(g.n_cols / BN),
+                                                                          (unsigned)ksplit),
+                                   dim3(kThreads), 0, ctx->stream, q);
+            else
+                hipLaunchKernelGGL(gemm_rows_splitk_kernel, dim3((unsigned)groups16, (unsigned)(g.n_cols / 16), (unsigned)ksplit),
+                                   dim3(kThreads), 0, ctx->stream, q);
             hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((unsigned)dcs_cdiv(g.M * g.n_cols, kThreads)), dim3(kThreads),
                                0, ctx->stream, q, ksplit);
             tm.done();
