@@ -603,12 +603,14 @@ sys.exit(0 if err < 1e-4 else 3)
 
 
 @pytest.mark.parametrize("env", [{"DCS_GENERIC_CHUNK": "8"}, {"DCS_GEMM_KSPLIT": "0"}, {"DCS_GEMM_KSPLIT": "5"},
-                                 {"DCS_GEMM_KSPLIT": "64"}])
+                                 {"DCS_GEMM_KSPLIT": "64"}, {"DCS_GEMM_KSPLIT_TILED": "0"},
+                                 {"DCS_COLCONV": "0"}, {"DCS_DECONV1_REG": "0"}])
 def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
-    """Scratch chunking and the K-split of the long dense layer are chosen by size; force each on a 20-tile Bach10
-    batch (fresh process) and compare the network output with the oracle."""
+    """Scratch chunking, the K-split of the long dense layer (register- and LDS-tiled), the column convolution and the
+    register-blocked transposed conv1 all have a fallback or a size rule; force each on a 52-tile Bach10 batch (fresh
+    process) and compare the network output with the oracle."""
     import subprocess
-    F, n = 257, 20
+    F, n = 257, 52
     x = _tiles("bach10", n, 30, F, seed=15)
     want = net_ref.forward("bach10", synth_params("bach10", 30, F, seed=4), x.astype(np.float64),
                            inverse='explicit').numpy()
