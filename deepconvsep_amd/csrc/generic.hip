@@ -482,6 +482,141 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f16_kernel(const IgemmArg
 }
 
 // ------------------------------------------------------------------------------------------------
+// Slab convolution for general kh x kw filters (conv2 of the iKala graph, 10 x 20, and its transpose).
+//   out[co][y][x] = bias[co] + sum_{u,v} sum_ci Wk[u][v][ci][co] * in[ci][y + u - ph][x + v - pw]   (zero outside)
+// A workgroup owns a band of output rows of one image.  The input rows the band can touch -- at most band + kh - 1
+// -- sit in LDS for the whole workgroup, the weights stream through LDS a few taps at a time (double buffered), and
+// each wave keeps the accumulators of its (row, 16-column) blocks in registers across all taps.  Per tap a wave reads
+// the 16 weight fragments once and, for each of its blocks, 8 slab values (lane = column; a lane whose shifted column
+// falls outside the input gets 0) for 16 MFMAs; taps whose input row lies outside the image, and (tap, block) pairs
+// whose shifted columns all do, are skipped -- the implicit GEMM multiplies all of them (63 % of its K loop for the
+// iKala transpose) and re-gathers every operand from L2.
+// ------------------------------------------------------------------------------------------------
+struct SlabConvArgs {
+    const float* in; int64_t in_n_stride; int Cin, H, W;
+    const float* Wk;            // [kh][kw][32][32] (ci, co swizzled: colconv_wslot(0, ci, co) within a tap)
+    const float* bias;          // [32]
+    float* out; int64_t out_n_stride; int Cout, Ho, Wo;
+    int kh, kw, ph, pw;
+    int band, n_bands;          // output rows per workgroup, workgroups per image
+    int rows_max;               // band + kh - 1 (slab rows allocated)
+    int tstage;                 // taps (along v) staged per step
+};
+
+__global__ __launch_bounds__(kColThreads) void slabconv_kernel(const SlabConvArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wstage = g.tstage * 1024;            // floats per weight stage
+    float* Wl = smem;                              // [2][tstage][32][32]
+    float* slab = smem + 2 * wstage;               // [32][rows_max][W]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t img = blockIdx.x / g.n_bands;
+    const int y0 = (int)(blockIdx.x - img * g.n_bands) * g.band;
+    const int yb = y0 + g.band < g.Ho ? y0 + g.band : g.Ho;   // rows [y0, yb)
+    const float* in = g.in + img * g.in_n_stride;
+    float* out = g.out + img * g.out_n_stride;
+    // input rows the band can touch
+    int rbase = y0 - g.ph, rtop = yb - 1 - g.ph + g.kh - 1;
+    if (rbase < 0) rbase = 0;
+    if (rtop > g.H - 1) rtop = g.H - 1;
+    const int rows = rtop - rbase + 1;
+    const int PS = g.rows_max * g.W;               // plane stride of the slab
+    for (int i = tid; i < 32 * PS; i += kColThreads) {
+        const int ci = i / PS, rem = i - ci * PS;
+        const int r = rem / g.W;
+        slab[i] = (ci < g.Cin && r < rows) ? in[((int64_t)ci * g.H + rbase + r) * g.W + (rem - r * g.W)] : 0.f;
+    }
+    // this wave's blocks: b = wave + 8 i -> (row y0 + b / nxb, column block b % nxb)
+    const int nxb = (g.Wo + 15) >> 4, nblk = (yb - y0) * nxb;
+    int by[4], bx[4];
+    f32x4 acc0[4], acc1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = wave + 8 * i;
+        by[i] = b < nblk ? y0 + b / nxb : -1;
+        bx[i] = b < nblk ? (b % nxb) * 16 : 0;
+        acc0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int c0 = (fi + 16 * (kq & 1)) & 31, c1 = (fi + 16 + 16 * (kq & 1)) & 31;
+    const int nvs = (g.kw + g.tstage - 1) / g.tstage;   // stages per tap row
+    // taps rows u that touch the band at all: 0 <= y + u - ph < H for some y in [y0, yb)
+    int u_lo = g.ph - (yb - 1), u_hi = g.ph - y0 + g.H - 1;
+    if (u_lo < 0) u_lo = 0;
+    if (u_hi > g.kh - 1) u_hi = g.kh - 1;
+    const int n_stage = (u_hi - u_lo + 1) * nvs;
+    f32x4 wpre[2];                                  // 2 float4 per thread cover a stage of <= 4 taps (4096 floats)
+#define DCS_SLAB_WFETCH(st_)                                                                             \
+    {                                                                                                    \
+        const int u_ = u_lo + (st_) / nvs, v_ = ((st_) % nvs) * g.tstage;                                \
+        const int nt_ = v_ + g.tstage <= g.kw ? g.tstage : g.kw - v_;                                     \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                  \
+            const int e = (tid + q * kColThreads) * 4;                                                   \
+            wpre[q] = e < nt_ * 1024 ? *reinterpret_cast<const f32x4*>(g.Wk + ((int64_t)(u_ * g.kw + v_)) * 1024 + e) \
+                                     : f32x4{0.f, 0.f, 0.f, 0.f};                                        \
+        }                                                                                                \
+    }
+    if (n_stage > 0) DCS_SLAB_WFETCH(0)
+    for (int st = 0; st < n_stage; ++st) {
+        float* Wb = Wl + (st & 1) * wstage;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = (tid + q * kColThreads) * 4;
+            if (e < wstage) *reinterpret_cast<f32x4*>(Wb + e) = wpre[q];
+        }
+        __syncthreads();       // also orders the slab fill before the first use; buffer st&1 was last read at st-2
+        if (st + 1 < n_stage) DCS_SLAB_WFETCH(st + 1)
+        const int u = u_lo + st / nvs, v0 = (st % nvs) * g.tstage;
+        const int nt = v0 + g.tstage <= g.kw ? g.tstage : g.kw - v0;
+        for (int tv = 0; tv < nt; ++tv) {
+            const int v = v0 + tv;
+            const float* wp = Wb + tv * 1024 + kq * 32;
+            float a0[8], a1[8];
+            bool have = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (by[i] < 0) continue;
+                const int r = by[i] + u - g.ph;                      // input row (uniform per block)
+                const int xs = bx[i] + v - g.pw;                     // shifted column of lane 0
+                if (r < 0 || r >= g.H || xs + 15 < 0 || xs >= g.W) continue;
+                if (!have) {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        a0[kk] = wp[4 * kk * 32 + c0];
+                        a1[kk] = wp[4 * kk * 32 + c1];
+                    }
+                    have = true;
+                }
+                const int xl = xs + fi;
+                const bool ok = xl >= 0 && xl < g.W;
+                const float* sp = slab + kq * PS + (r - rbase) * g.W + (ok ? xl : 0);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float bv = sp[4 * kk * PS];
+                    const float b = ok ? bv : 0.f;
+                    acc0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kk], b, acc0[i], 0, 0, 0);
+                    acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kk], b, acc1[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef DCS_SLAB_WFETCH
+    const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (by[i] < 0 || bx[i] + fi >= g.Wo) continue;
+        float* op = out + (int64_t)by[i] * g.Wo + bx[i] + fi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = 4 * kq + e;
+            if (co < g.Cout) op[(int64_t)co * HoWo] = acc0[i][e] + g.bias[co];
+            if (co + 16 < g.Cout) op[(int64_t)(co + 16) * HoWo] = acc1[i][e] + g.bias[co + 16];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The column convolution with f16 inputs and f32 accumulation (v_mfma_f32_16x16x32_f16): one MFMA covers a whole
 // tap (32 input channels) for a 16 co x 16 x block, 16x the f32 rate, so this variant is LDS- and store-bound.
 // Slab and weights are stored channel-fastest -- slab [row][x][ci], weights [u][co][ci], rows of 32 halves padded to
@@ -717,6 +852,8 @@ struct DcsGenericNet {
     _Float16 *W2m_h = nullptr, *W2t_h = nullptr;
     int conv_f16 = 0;
     // column convolution (kw2 == 1): weights [kh][32 ci][32 co swizzled] of conv2 and of its transpose
+    float *Wslab = nullptr, *Wslab_t = nullptr;   // [kh][kw][32][32] conv2 / its transpose for slabconv_kernel
+    int use_slabconv = 0;
     float* W1p = nullptr;      // conv1 filters padded to sw1*ceil(kw1/sw1) taps (register-blocked transpose of conv1)
     float *Wcol = nullptr, *Wcol_t = nullptr;
     _Float16 *Wcol_h = nullptr, *Wcol_t_h = nullptr;     // [kh][32 co][40] halves, channel-fastest
@@ -800,6 +937,24 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         return h;
     };
     const std::vector<_Float16> W2m_h = pack_h(W2m), W2t_h = pack_h(W2t);
+    // slab convolution (general kh x kw): Wslab[u][v][ci][co] = W2[co][ci][kh-1-u][kw-1-v]; transpose
+    // Wslab_t[u][v][co][ci] = W2[co][ci][u][v]
+    std::vector<float> Wslab, Wslab_t;
+    static const int slab_env = getenv("DCS_SLABCONV") ? atoi(getenv("DCS_SLABCONV")) : 1;
+    g->use_slabconv = (kw > 1 && nf1 <= 32 && nf2 <= 32 && slab_env) ? 1 : 0;
+    if (g->use_slabconv) {
+        Wslab.assign((size_t)kh * kw * 1024, 0.f);
+        Wslab_t.assign((size_t)kh * kw * 1024, 0.f);
+        for (int co = 0; co < nf2; ++co)
+            for (int ci = 0; ci < nf1; ++ci)
+                for (int u = 0; u < kh; ++u)
+                    for (int v = 0; v < kw; ++v) {
+                        Wslab[(size_t)(u * kw + v) * 1024 + colconv_wslot(0, ci, co)] =
+                            W2[(((size_t)co * nf1 + ci) * kh + (kh - 1 - u)) * kw + (kw - 1 - v)];
+                        Wslab_t[(size_t)(u * kw + v) * 1024 + colconv_wslot(0, co, ci)] =
+                            W2[(((size_t)co * nf1 + ci) * kh + u) * kw + v];
+                    }
+    }
     // column convolution (kw == 1): Wcol[u][ci][co] = W2[co][ci][kh-1-u] (true convolution), transpose
     // Wcol_t[u][co][ci] = W2[co][ci][u]
     std::vector<float> Wcol, Wcol_t;
@@ -834,6 +989,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
     if (!W1p.empty()) { UP(g->W1p, W1p) }
+    if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) }
     if (g->use_colconv) { UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) }
     for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) {
         std::vector<float> Bd((size_t)dcs_round_up(g->hid64, 128) * g->flat64, 0.f), bd(g->flat64, 0.f);
@@ -855,7 +1011,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->Wslab, g->Wslab_t, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d};
     for (void* p : ptrs)
@@ -865,6 +1021,34 @@ void dcs_generic_destroy(DcsGenericNet* g) {
 }
 
 namespace {
+
+// false: the shape does not fit (LDS); the caller falls back to the implicit GEMM
+bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images) {
+    const int nxb = (a.Wo + 15) / 16;
+    a.tstage = a.kw < 4 ? a.kw : 4;
+    int band = 32 / nxb;                                   // 4 blocks per wave at most
+    if (band < 1) return false;
+    if (band > a.Ho) band = a.Ho;
+    // more workgroups than two per CU if the image count alone does not give them
+    // a workgroup streams all kh*kw weight tiles whatever its band: shrink the band only until every CU has a workgroup
+    while (band > 1 && n_images * ((a.Ho + band - 1) / band) < (int64_t)ctx->n_cu) --band;
+    band = (a.Ho + (a.Ho + band - 1) / band - 1) / ((a.Ho + band - 1) / band);   // equal bands
+    size_t lds;
+    for (;; --band) {
+        if (band < 1) return false;
+        lds = ((size_t)2 * a.tstage * 1024 + (size_t)32 * (band + a.kh - 1) * a.W) * sizeof(float);
+        if (lds <= 160 * 1024) break;
+    }
+    a.band = band;
+    a.n_bands = (a.Ho + band - 1) / band;
+    a.rows_max = band + a.kh - 1;
+    auto kern = slabconv_kernel;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * a.n_bands)), dim3(kColThreads), lds, ctx->stream, a);
+    return true;
+}
 
 int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16* Wh = nullptr) {
     a.n_xb = (a.W + 15) / 16;
@@ -948,8 +1132,18 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         } else if (g->conv_f16)
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2m_h);
-        else
-            hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
+        else {
+            bool done = false;
+            if (g->use_slabconv) {
+                SlabConvArgs c{};
+                c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
+                c.Wk = g->Wslab; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride;
+                c.Cout = a.Cout; c.Ho = a.Ho; c.Wo = a.Wo; c.kh = d.kh2; c.kw = d.kw2; c.ph = 0; c.pw = 0;
+                done = launch_slabconv(ctx, c, n);
+            }
+            if (!done)
+                hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
+        }
         tm.done();
     }
     // bottleneck dense (rectify)
@@ -990,8 +1184,18 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         } else if (g->conv_f16)
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2t_h);
-        else
-            hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
+        else {
+            bool done = false;
+            if (g->use_slabconv) {
+                SlabConvArgs c{};
+                c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
+                c.Wk = g->Wslab_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride;
+                c.Cout = a.Cout; c.Ho = a.Ho; c.Wo = a.Wo; c.kh = d.kh2; c.kw = d.kw2; c.ph = d.kh2 - 1; c.pw = d.kw2 - 1;
+                done = launch_slabconv(ctx, c, n * NB);
+            }
+            if (!done)
+                hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
+        }
         tm.done();
     }
     // InverseLayer(., pool)

@@ -586,6 +586,39 @@ sys.exit(0 if err < 1e-4 else 3)
 """
 
 
+_IKALA_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from deepconvsep_amd.runtime import Network, default_context
+from deepconvsep_amd.synth import synth_params
+z = np.load(sys.argv[2])
+ctx = default_context()
+F = int(z['F'])
+net = Network(ctx, 'ikala', synth_params('ikala', 30, F, seed=4), 30, F)
+p = net.forward_raw(ctx.to_device(z['x'], np.float32)).cpu().numpy()
+err = float(np.max(np.abs(p - z['want'])))
+print('max err %.3e' % err)
+sys.exit(0 if err < 1e-4 else 3)
+"""
+
+
+@pytest.mark.parametrize("env", [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}])
+@pytest.mark.parametrize("F,n", [(513, 9), (1025, 3)])
+def test_ikala_conv2_kernels_agree_with_the_oracle(env, F, n, tmp_path):
+    """conv2 of the iKala graph (10 x 20) and its transpose: slab kernel (default) and implicit-GEMM fallback, on batch
+    sizes that give several row bands per image."""
+    import subprocess
+    x = _tiles("ikala", n, 30, F, seed=16)
+    want = net_ref.forward("ikala", synth_params("ikala", 30, F, seed=4), x.astype(np.float64), inverse='explicit').numpy()
+    f = tmp_path / "case.npz"
+    np.savez(f, x=x, want=want, F=F)
+    child_env = dict(os.environ)
+    child_env.update(env)
+    r = subprocess.run([sys.executable, "-c", _IKALA_CHILD, ROOT, str(f)], env=child_env, capture_output=True, text=True,
+                       timeout=200)
+    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
+
+
 _GENERIC_CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
