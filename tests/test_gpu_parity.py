@@ -846,3 +846,27 @@ def test_stereo_ild_model_rejects_other_entry_points():
     mono = dcs.Separator("dsd", synth_params("dsd", 30, 513, seed=2), 0.3, 30, 25, 32, 513, 1024, 512, np.hanning)
     with pytest.raises(ValueError):
         mono.net.separate_stereo(mono.plan, sep.ctx.to_device(np.zeros((2, 30000), np.float32), np.float32), 25)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_randomised_lengths_and_batches_match_oracle(seed):
+    """Size-dependent launch decisions (hop-blocks per iSTFT workgroup and its block -> (chunk, source) map, column
+    groups of the final kernel, row counts that are not multiples of anything): random clip lengths, both tilers,
+    both frame sizes, single clips and stacked clips against the oracle."""
+    rs = np.random.RandomState(1000 + seed)
+    N = int(rs.choice([1024, 2048]))
+    F = N // 2 + 1
+    tiler = str(rs.choice(["script", "library"]))
+    L = int(rs.randint(16500, 120000))
+    clips = int(rs.choice([1, 2, 5, 7]))
+    params = synth_params("dsd", 30, F, seed=2)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, N, 512, np.hanning, tiler=tiler)
+    audio = np.stack([synth_audio(L, seed=2000 + 10 * seed + c) for c in range(clips)]).astype(np.float32)
+    buf = sep.ctx.to_device(audio, np.float32)
+    got = (sep.net.separate_batch(sep.plan, buf, 25, sep.tiler, 0.3) if clips > 1
+           else sep.net.separate(sep.plan, buf[0], 25, sep.tiler, 0.3)[None]).cpu().numpy()
+    for c in sorted(set([0, clips - 1])):
+        want = pipeline.separate("dsd", params, audio[c].astype(np.float64), 0.3, 30, 25, 32, N, 512, np.hanning,
+                                 tiler=tiling_np.SCRIPT if tiler == 'script' else tiling_np.LIBRARY)
+        assert got[c].shape == want.shape
+        assert np.max(np.abs(got[c] - want)) < 1e-4, (N, tiler, L, clips, c)
