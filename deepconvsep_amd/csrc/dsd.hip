@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     float breg[CBW][NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const float* bp = a.Bw + (int64_t)final_chan(q, kq) * a.ldb + col;
+        const float* bp = a.Bw + (final_chan(q, kq) * a.ldb + col);   // 32-bit offset from a uniform base
         if constexpr (CBW == 2) {
             const f32x2 b = live ? *reinterpret_cast<const f32x2*>(bp) : f32x2{0.f, 0.f};
             breg[0][q] = b[0];
@@ -362,12 +362,14 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     // mixture value of this lane's 4 rows x 2 bins
     const bool vec = CBW == 2 && ((a.mix_ld | a.out_ld) & 1) == 0;  // rows 8-byte aligned (the fused path pads F to 4)
     f32x4 mixv[CBW];
+    const float* mix0 = a.mix + clip * a.mix_clip_stride + row0 * a.mix_ld;   // workgroup-uniform
+    const int rows_here = a.rows - row0 < 16 ? (int)(a.rows - row0) : 16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int64_t r = row0 + kq * 4 + e;
+        const int ri = kq * 4 + e;
         float m0 = 0.f, m1 = 0.f;
-        if (r < a.rows) {
-            const float* mp = a.mix + clip * a.mix_clip_stride + r * a.mix_ld + col;
+        if (ri < rows_here) {
+            const float* mp = mix0 + (ri * (int)a.mix_ld + col);
             if (vec && col + 1 < a.F) {
                 const f32x2 v = *reinterpret_cast<const f32x2*>(mp);
                 m0 = v[0];
@@ -515,26 +517,38 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
 #undef DCS_LOAD_A
 #undef DCS_STORE_A
 
-    if (col < a.F) {
+    {
+        float* out0 = a.out + clip * a.out_clip_stride + row0 * a.out_ld;   // workgroup-uniform; offsets below are 32-bit
+        // stereo trainer: source = mask * input + eps*r (trainCNN_ILD_DSD100.py:180); the cross-fade weights of a frame
+        // sum to one, so the constant is added once, after the fold
+        if (MODE == 3) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int64_t r = row0 + kq * 4 + e;
-            if (r < a.rows) {
+            for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float* op = a.out + clip * a.out_clip_stride + c * a.out_src_stride + r * a.out_ld + col;
-                    // stereo trainer: source = mask * input + eps*r (trainCNN_ILD_DSD100.py:180); the cross-fade weights of
-                    // a frame sum to one, so the constant is added once, after the fold
-                    const float add = MODE == 3 ? eps_r : 0.f;
-                    if constexpr (CBW == 2) {
-                        if (vec && col + 1 < a.F) {
-                            *reinterpret_cast<f32x2*>(op) = f32x2{res[0][c][e] + add, res[1][c][e] + add};
-                        } else {
-                            op[0] = res[0][c][e] + add;
-                            if (col + 1 < a.F) op[1] = res[1][c][e] + add;
-                        }
-                    } else {
-                        op[0] = res[0][c][e] + add;
+                for (int c = 0; c < 4; ++c) res[cb][c] += eps_r;
+        }
+        if (CBW == 2 && vec && colw + 16 * CBW <= a.F) {
+            // the whole wave inside the spectrum (wave-uniform): straight 8-byte stores
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ri = kq * 4 + e;
+                if (ri < rows_here) {
+                    float* op = out0 + (ri * (int)a.out_ld + col);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        *reinterpret_cast<f32x2*>(op + c * a.out_src_stride) = f32x2{res[0][c][e], res[CBW - 1][c][e]};
+                }
+            }
+        } else if (col < a.F) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ri = kq * 4 + e;
+                if (ri < rows_here) {
+                    float* op = out0 + (ri * (int)a.out_ld + col);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        op[c * a.out_src_stride] = res[0][c][e];
+                        if (CBW == 2 && col + 1 < a.F) op[c * a.out_src_stride + 1] = res[CBW - 1][c][e];
                     }
                 }
             }
