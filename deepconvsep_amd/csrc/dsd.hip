@@ -257,6 +257,10 @@ __global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* _
 // chosen so that a lane's 13 channels are 3 aligned float4 + 1 float).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 // max(x, lo), lo >= 0, on both halves, as a SIGNED INTEGER max of the bit patterns: non-negative floats order like
@@ -299,7 +303,10 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     const int64_t clip = blockIdx.y;  // stacked clips of equal length (dcs_separate_batch): same fold, shifted buffers
     const unsigned rg = swz / (unsigned)n_colg;
     const int64_t row0 = (int64_t)rg * 16;
-    const int colw = (int)(swz - rg * (unsigned)n_colg) * (64 * CBW) + wave * (16 * CBW);
+    // Which wave takes which 16*CBW bins rotates with the row group: F = 64k + 1 leaves the last column group one
+    // live wave (the Nyquist bin), and a fixed choice would put all of those on the same SIMD of every CU
+    // (45 instead of 40 waves' worth of MFMAs at F = 1025).
+    const int colw = (int)(swz - rg * (unsigned)n_colg) * (64 * CBW) + ((wave + (int)rg) & 3) * (16 * CBW);
     const int col = colw + CBW * fi;  // this lane's bins: col (cb = 0), col + 1 (cb = 1)
     const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
     const int64_t n = a.n;
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     }
 
     const bool live = colw < a.F;  // a wave whose 32 bins are all padding only helps staging
+    const bool cb1_live = CBW == 2 && colw + 1 < a.F;  // wave-uniform; false for the wave that holds only the Nyquist bin
     // B fragments: Bw[c][bin] of this lane's two bins -- constant for the whole workgroup
     float breg[CBW][NQ];
 #pragma unroll
@@ -443,11 +451,13 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
         __syncthreads();
         if (m + 1 < mmax) DCS_LOAD_A(m + 1)
         if (!live) continue;
+        auto compute = [&](auto ncb_tag) __attribute__((always_inline)) {
+        constexpr int NCB = decltype(ncb_tag)::value;   // column blocks with live bins: CBW, or 1 (second block all padding)
         const float* Ab = As + (m & 1) * kABuf + fi * AS + 12 * kq;
         // the output bias (separate_dsd.py:232) rides in as the MFMAs' initial accumulator value: no add afterwards
         f32x4 acc[4][CBW];   // acc[3] only with NBR == 4
 #pragma unroll
-        for (int cb = 0; cb < CBW; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
             acc[0][cb] = f32x4{bias0, bias0, bias0, bias0};
             acc[1][cb] = f32x4{bias1, bias1, bias1, bias1};
             acc[2][cb] = f32x4{bias2, bias2, bias2, bias2};
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
 #pragma unroll
                 for (int s = 0; s < NBR; ++s)
 #pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb)
+                    for (int cb = 0; cb < NCB; ++cb)
                         acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][t], breg[cb][q], acc[s][cb], 0, 0, 0);
             }
         }
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
             const f32x2 up = {up4[2 * h], up4[2 * h + 1]};
             const f32x2 down = {down4[2 * h], down4[2 * h + 1]};
 #pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) {
+            for (int cb = 0; cb < NCB; ++cb) {
                 const f32x2 x0 = {acc[0][cb][2 * h], acc[0][cb][2 * h + 1]};
                 const f32x2 x1 = {acc[1][cb][2 * h], acc[1][cb][2 * h + 1]};
                 const f32x2 x2 = {acc[2][cb][2 * h], acc[2][cb][2 * h + 1]};
@@ -513,6 +523,11 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
                 res[cb][3][2 * h] = o3[0]; res[cb][3][2 * h + 1] = o3[1];
             }
         }
+        };
+        if (CBW == 2 && !cb1_live)
+            compute(IntTag<1>{});
+        else
+            compute(IntTag<CBW>{});
     }
 #undef DCS_LOAD_A
 #undef DCS_STORE_A
