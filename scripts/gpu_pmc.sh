@@ -7,7 +7,7 @@ cd /tmp
 run() { # name, counters...
   name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -o p -- \
-     python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --sat-tiles ${SAT:-1024} > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+     python $GRAFT_REPO_ROOT/bench.py --steps ${STEPS:-20} --warmup 3 --streams ${STREAMS:-2} --no-cpu-baseline --sat-tiles ${SAT:-1024} > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
   echo "pmc $name exit $?"
 }
 run a GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU
@@ -24,9 +24,10 @@ for tag in 'ab':
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         k=r['Kernel_Name']
-        for key in ('final_kernel','deconv2','istft_fused','gemm_rows_splitk','gemm_rows_kernel','stft_forward'):
+        for key in ('final_kernel','deconv2_stream','deconv2','istft_wave','gemm_rows_splitk','gemm_rows_kernel','stft_forward_wave','stft_forward','conv1','colconv'):
             if key in k: k=key; break
         gs=r.get('Grid_Size','?')
+        if int(gs) < int(os.environ.get('MIN_GRID','0')): continue
         agg[(k,gs)][r['Counter_Name']].append(float(r['Counter_Value']))
     for (k,gs),d in sorted(agg.items()):
         print(k[:24], gs, {c: round(sum(v)/len(v),1) for c,v in d.items()}, 'n', len(next(iter(d.values()))))
