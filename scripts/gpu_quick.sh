@@ -25,6 +25,8 @@ d=json.load(open("$OUT/quick_bench_$vn.json"))
 print("32t x%d clips/launch x%d streams: value %.0f ms/step %.4f frac %.4f (final %.4f ms)" % (d['config']['clips_per_launch'], d['config']['streams_per_gpu'], d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_kernel_ms']))
 s1=d['single_stream']; print("32t single: value %.0f ms/step %.4f frac %.4f" % (s1['value'], s1['ms_per_step'], s1['roofline']['frac']), s1['kernels_ms'])
 g=d['launch_group']; print("GROUP %d clips: sum %.4f" % (g['clips'], g['kernels_ms_sum']), g['kernels_ms'])
+h=d.get('host_fed')
+if h: print("HOST-FED: value %.0f ms/step %.4f PCIe %.1f GB/s" % (h['value'], h['ms_per_step'], h['pcie_GBps']))
 s=d.get('saturating')
 if s: print("SAT: value %.0f ms/step %.4f frac %.4f" % (s['value'], s['ms_per_step'], s['roofline']['frac']), s['kernels_ms'])
 PY
