@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
     float2* winl = lp;                                   // [M] window as (even, odd) pairs   (WREG == 0)
     if (WREG == 0) lp += M;
     float2* ring = lp;                                   // [ring_slots][hop/2]
-    float* norm_s = reinterpret_cast<float*>(ring + (size_t)ring_slots * (hop >> 1));  // [hop] steady-state sum(w^2)
+    float* norm_s = reinterpret_cast<float*>(ring + (size_t)ring_slots * (hop >> 1));  // [hop] steady-state 1 / sum(w^2)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2* buf = fbuf + wave * MP;
@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
         for (int q = tid; q < hop; q += 256) {
             float nrm = 0.f;
             for (int d = R - 1; d >= 0; --d) nrm += wsq[q + d * hop];  // frames in increasing order
-            norm_s[q] = nrm == 0.f ? 1.f : nrm;
+            norm_s[q] = nrm == 0.f ? 1.f : 1.f / nrm;  // reciprocal: the steady-state blocks multiply (one IEEE division
+                                                       // is ~10 VALU instructions, 8 of them per lane and frame)
         }
     }
     int64_t n_hi = hb1 - 1;
@@ -478,8 +479,9 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
                 if (m + 1 < 0 || m >= n_out) continue;
                 float nx, ny;
                 if (steady) {
-                    nx = norm_s[2 * r];
-                    ny = norm_s[2 * r + 1];
+                    if (m >= 0) dst[m] = a[0] * norm_s[2 * r];
+                    if (m + 1 < n_out) dst[m + 1] = a[1] * norm_s[2 * r + 1];
+                    continue;
                 } else {
                     const int64_t f_hi = g < T - 1 ? g : T - 1;
                     const int64_t f_lo = g < R ? 0 : g - (R - 1);
