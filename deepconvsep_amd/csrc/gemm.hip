@@ -314,6 +314,22 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
             return DCS_OK;
         }
     }
+    static const int force = getenv("DCS_GEMM_FORCE") ? atoi(getenv("DCS_GEMM_FORCE")) : 0;   // experiments: RB * 1000 + BK
+    if (force) {
+        switch (force) {
+            case 1032: launch_rb<1, 32>(ctx, g); break;
+            case 1128: launch_rb<1, 128>(ctx, g); break;
+            case 2032: launch_rb<2, 32>(ctx, g); break;
+            case 2064: launch_rb<2, 64>(ctx, g); break;
+            case 2128: launch_rb<2, 128>(ctx, g); break;
+            case 4032: launch_rb<4, 32>(ctx, g); break;
+            case 4064: launch_rb<4, 64>(ctx, g); break;
+            default: DCS_FAIL(DCS_EINVAL, "DCS_GEMM_FORCE=%d", force);
+        }
+        tm.done();
+        DCS_HIP(hipGetLastError());
+        return DCS_OK;
+    }
     static const int64_t sk_env = getenv("DCS_GEMM_SPLITK_MAX") ? atoll(getenv("DCS_GEMM_SPLITK_MAX")) : -1;
     const int64_t sk_max = sk_env >= 0 ? sk_env : (int64_t)ctx->n_cu / 2;
     if (g.a_vec && groups16 * col_groups <= sk_max) {
