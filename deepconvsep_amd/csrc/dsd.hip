@@ -121,6 +121,10 @@ __global__ __launch_bounds__(kThreads) void deconv2_kernel(const float* __restri
 // D rows are fetched from HBM once and served from that XCD's L2 to the other groups.
 // ------------------------------------------------------------------------------------------------
 constexpr int kD2PsStride = 20;  // floats per skewed row: 16 taps + 4 (16-byte aligned, spreads the banks)
+// the second channel of a pair starts 32 banks further: the col2im reader lanes (t, 0) and (t, 1) of one 16-lane pass
+// would otherwise hit the same banks (32 rows x 20 floats = 0 mod 64)
+constexpr int kD2PsChan = 32 * kD2PsStride + 32;
+constexpr int kD2PsSize = 2 * kD2PsChan;
 
 __global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* __restrict__ D,
                                                                   const float* __restrict__ Bws,
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* _
     float* Bs = smem;                                   // [GS*16][CP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* Ps = Bs + GS * 16 * CP + wave * (2 * 32 * kD2PsStride + 32 * GS);  // [2][32][20] skewed products
-    float* Os = Ps + 2 * 32 * kD2PsStride;                                     // [tc][8] outputs of the item
+    float* Ps = Bs + GS * 16 * CP + wave * (kD2PsSize + 32 * GS);  // [2][32][20] skewed products
+    float* Os = Ps + kD2PsSize;                                     // [tc][8] outputs of the item
     const int fi = lane & 15, kq = lane >> 4;
 
     // block -> (channel group g, workgroup column x of nwx)
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* _
         const f32x4* src = reinterpret_cast<const f32x4*>(Bws + (int64_t)g * GS * 16 * CP);
         f32x4* dst = reinterpret_cast<f32x4*>(Bs);
         for (int i = tid; i < GS * 16 * CP / 4; i += kThreads) dst[i] = src[i];
-        for (int i = lane; i < 2 * 32 * kD2PsStride + 32 * GS; i += 64) Ps[i] = 0.f;
+        for (int i = lane; i < kD2PsSize + 32 * GS; i += 64) Ps[i] = 0.f;
     }
     __syncthreads();
 
@@ -209,13 +213,13 @@ __global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* _
                 for (int e = 0; e < 4; ++e) {
                     if (4 * kq + e < H2) {
                         w0[e * kD2PsStride] = acc0[e];
-                        w0[32 * kD2PsStride + e * kD2PsStride] = acc1[e];
+                        w0[kD2PsChan + e * kD2PsStride] = acc1[e];
                     }
                 }
             }
             if (lane < 2 * tc) {
                 const int cc = lane & 1, t = lane >> 1;
-                const f32x4* r = reinterpret_cast<const f32x4*>(Ps + (cc * 32 + t) * kD2PsStride);
+                const f32x4* r = reinterpret_cast<const f32x4*>(Ps + cc * kD2PsChan + t * kD2PsStride);
                 const f32x4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
                 float sum = 0.f;
 #pragma unroll
@@ -596,7 +600,7 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const 
         if (X < 8) X = 8;
         int Xt = tail_ch ? slots - n_full * X : 0;
         if (tail_ch && Xt < 1) Xt = 1;
-        const size_t lds2 = ((size_t)kDsdGch * 16 * CP + 4 * (2 * 32 * kD2PsStride + 32 * kDsdGch)) * sizeof(float);
+        const size_t lds2 = ((size_t)kDsdGch * 16 * CP + 4 * (kD2PsSize + 32 * kDsdGch)) * sizeof(float);
         auto kern = deconv2_stream_kernel;
         if (lds2 > 48 * 1024)
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
