@@ -173,6 +173,27 @@ class Separator(object):
         pcm = self.net.separate(self.plan, a, self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)
         return pcm.cpu().numpy().astype(np.float64)
 
+    def separate_many(self, audios):
+        """A list of clips -> a list of float64 ``[S, L_i]``.  Clips of the same length share one set of kernel launches
+        (``dcs_separate_batch``, DSD / hiphop graph); every clip gets exactly the tiles and the cross-fade
+        :meth:`separate` gives it alone.  Other graphs, and lengths that occur once, go through :meth:`separate`."""
+        audios = [np.asarray(a) for a in audios]
+        out = [None] * len(audios)
+        groups = {}
+        for i, a in enumerate(audios):
+            groups.setdefault(int(a.size), []).append(i)
+        for L, idx in groups.items():
+            if len(idx) == 1 or self.arch_name not in ("dsd", "hiphop") or L == 0:
+                for i in idx:
+                    out[i] = self.separate(audios[i])
+                continue
+            stack = self.ctx.to_device(np.stack([audios[i].reshape(-1) for i in idx]), np.float32)      # [B, L]
+            pcm = self.net.separate_batch(self.plan, stack, self.overlap, self.tiler, self.scale_factor, None,
+                                          self.tie_mode).cpu().numpy()
+            for b, i in enumerate(idx):
+                out[i] = pcm[b].astype(np.float64)
+        return out
+
     def separate_stepwise(self, audio):
         """The reference's control flow, stage by stage through the public operators
         (compute_file -> x scale -> generate_overlapadd -> predict_function2 per batch ->

@@ -8,7 +8,8 @@
 Every file gets its own sub-directory ``outdir/<stem>/`` holding the wav files the single-file script
 writes.  With several ranks (one process per GPU) the files are dealt round-robin: replicas only, no
 collective on the data path.  While the GPU separates file i the host reads file i+1 and writes file i-1
-(two worker threads), so wav I/O overlaps the kernels.
+(two worker threads), so wav I/O overlaps the kernels.  ``--group G`` (default 8) takes G files at a time; those
+of equal length share one set of kernel launches.
 """
 import argparse
 import os
@@ -23,6 +24,7 @@ def main(argv=None):
     ap.add_argument("-a", "--arch", default="dsd", choices=["dsd", "hiphop", "ikala", "bach10"])
     ap.add_argument("-m", "--mfile", required=True)
     ap.add_argument("-o", "--odir", required=True)
+    ap.add_argument("-g", "--group", type=int, default=8, help="files read ahead and separated together")
     ap.add_argument("files", nargs="+")
     args = ap.parse_args(argv)
 
@@ -46,21 +48,28 @@ def main(argv=None):
         for dst, sig in zip(sp.output_paths(args.arch, path, out), pcm):
             sp.write_wav(dst, sig, sr)
 
+    # --group G: G files are read ahead and separated together; those of equal length (a dataset cut into fixed
+    # excerpts) share one set of kernel launches (dcs_separate_batch), the rest go one by one
+    G = max(1, args.group)
     with ThreadPoolExecutor(max_workers=2) as pool:
-        nxt = pool.submit(read, mine[0]) if mine else None
-        pending = None
-        for i in range(len(mine)):
-            path, sr, audio = nxt.result()
-            nxt = pool.submit(read, mine[i + 1]) if i + 1 < len(mine) else None
-            if audio is None:
-                print("Sample rate is not 44100")          # separate_dsd.py:313
-                continue
-            pcm = sep.separate(audio)
-            if pending is not None:
-                pending.result()
-            pending = pool.submit(write, path, sr, pcm)
-        if pending is not None:
-            pending.result()
+        chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
+        nxt = [pool.submit(read, f) for f in chunks[0]] if chunks else []
+        pending = []
+        for ci in range(len(chunks)):
+            got = [f.result() for f in nxt]
+            nxt = [pool.submit(read, f) for f in chunks[ci + 1]] if ci + 1 < len(chunks) else []
+            ok = []
+            for path, sr, audio in got:
+                if audio is None:
+                    print("Sample rate is not 44100")          # separate_dsd.py:313
+                else:
+                    ok.append((path, sr, audio))
+            pcms = sep.separate_many([a for _, _, a in ok]) if G > 1 else [sep.separate(a) for _, _, a in ok]
+            for f in pending:
+                f.result()
+            pending = [pool.submit(write, path, sr, pcm) for (path, sr, _), pcm in zip(ok, pcms)]
+        for f in pending:
+            f.result()
 
 
 if __name__ == "__main__":

@@ -461,6 +461,44 @@ def test_batch_driver_matches_single_file_runs(tmp_path):
             assert np.array_equal(data, (want[s] * 32767).astype('int16'))
 
 
+def test_batch_driver_groups_equal_lengths(tmp_path):
+    """--group: files of equal length share one set of launches (Separator.separate_many -> dcs_separate_batch); every
+    file still gets what the single-file path gives it (kernel variants depend on the launch size, so float results
+    agree to ~1e-6 and the int16 samples to one step), files of other lengths keep their own launches."""
+    import importlib.util
+    import os
+    import scipy.io.wavfile
+    F = 513
+    params = synth_params("dsd", 30, F, seed=2)
+    model = str(tmp_path / "model.pkl")
+    dcs.save_model(model, params)
+    lengths = [40000, 31000, 40000, 40000, 52000]
+    wavs = []
+    for i, n in enumerate(lengths):
+        w = str(tmp_path / ("clip%d.wav" % i))
+        scipy.io.wavfile.write(w, 44100, (synth_audio(n, seed=40 + i) * 32767).astype('int16'))
+        wavs.append(w)
+    spec = importlib.util.spec_from_file_location(
+        "separate_batch", os.path.join(os.path.dirname(__file__), "..", "examples", "separate_batch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "out"
+    out.mkdir()
+    mod.main(["-a", "dsd", "-m", model, "-o", str(out), "--group", "5"] + wavs)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, 1024, 512, np.hanning)
+    many = sep.separate_many([dcs.separation.to_mono(dcs.separation.read_wav(w)[1], "dsd") for w in wavs])
+    for i, w in enumerate(wavs):
+        sr, audio = dcs.separation.read_wav(w)
+        want = sep.separate(dcs.separation.to_mono(audio, "dsd"))
+        assert many[i].shape == want.shape and np.max(np.abs(many[i] - want)) < 5e-6
+        ref = pipeline.separate("dsd", params, dcs.separation.to_mono(audio, "dsd"), 0.3, 30, 25, 32, 1024, 512, np.hanning)
+        assert np.max(np.abs(many[i] - ref)) < 1e-4
+        for s_, name in enumerate(["vocals", "bass", "drums", "other"]):
+            sr2, data = scipy.io.wavfile.read(str(out / ("clip%d" % i) / (name + ".wav")))
+            d = data.astype(np.int32) - (want[s_] * 32767).astype('int16').astype(np.int32)
+            assert data.shape[0] == lengths[i] and np.max(np.abs(d)) <= 1
+
+
 def test_graph_replay_recomputes_on_a_side_stream():
     """The fused step is captured into a hipGraph on the second identical call (non-default stream) and
     replayed afterwards: replays must track new input written into the same buffers."""
