@@ -381,7 +381,11 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
         const int ri = kq * 4 + e;
         float m0 = 0.f, m1 = 0.f;
         if (ri < rows_here) {
-            const float* mp = mix0 + (ri * (int)a.mix_ld + col);
+            // CBW == 1 is the few-workgroups variant, where the duration is one workgroup's dependent chain: with the
+            // full 64-bit address the compiler issues these loads ahead of the staging plan (15.3 -> 12.6 us at 32 tiles);
+            // with many workgroups the cheaper 32-bit offset wins
+            const float* mp = CBW == 1 ? a.mix + clip * a.mix_clip_stride + (row0 + ri) * a.mix_ld + col
+                                       : mix0 + (ri * (int)a.mix_ld + col);
             if (vec && col + 1 < a.F) {
                 const f32x2 v = *reinterpret_cast<const f32x2*>(mp);
                 m0 = v[0];

@@ -18,7 +18,7 @@ timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exi
 if [ "${DCS_PROFILE:-1}" = "1" ]; then
   echo "== rocprofv3 kernel stats"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 160 --warmup 32 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err)
+      python $GRAFT_REPO_ROOT/bench.py --steps 160 --warmup 32 --no-cpu-baseline --no-host-fed > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err)
   echo "rocprof exit $?"
   find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -n 25 $f; done
 fi
