@@ -94,10 +94,12 @@ int dcs_launch_stft_forward_f32(dcs_stft* p, const float* audio, int64_t L, floa
                                 int64_t ld, int64_t rows_out, int64_t T);
 int dcs_launch_stft_forward_f32_clips(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips,
                                       float* mag, float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T,
-                                      bool interleave = false);  // interleave: rows ordered [frame][clip]
+                                      bool interleave = false,   // interleave: rows ordered [frame][clip]
+                                      const int64_t* clip_tab = nullptr);  // device {samples, frames, tiles} per clip
 int dcs_launch_stft_inverse_f32_clips(dcs_stft* p, const float* mag, int64_t src_stride, const float2* unit,
                                       int64_t unit_clip_stride, int64_t ld, int64_t T, int n_src, int64_t n_clips,
-                                      float pre_div, float* audio, int64_t n_out);
+                                      float pre_div, float* audio, int64_t n_out, const int64_t* clip_tab = nullptr,
+                                      int64_t out_stride = 0);
 int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, double* mag, double* phase,
                                 double2* unit, int64_t ld, int64_t rows_out, int64_t T);
 int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase,

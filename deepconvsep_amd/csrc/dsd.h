@@ -30,6 +30,8 @@ struct DsdFinalArgs {
     int bias_half;        // 0: bias[4] per source; > 0: two input channels side by side, bins >= bias_half use bias[2 s + 1]
     int n_clips;          // stacked clips of equal length (0 or 1: a single clip); clip c uses G + c*g_clip_stride,
     int64_t g_clip_stride, mix_clip_stride, out_clip_stride;  // mix + c*mix_clip_stride, out + c*out_clip_stride
+    const int64_t* clip_tab;  // device {samples, frames, tiles} per clip when the stacked clips differ in length (n and
+                              // rows above are then the maxima that size the grid and the strides), else null
 };
 
 // Bw:  [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]   (few tiles)

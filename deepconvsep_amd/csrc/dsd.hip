@@ -313,7 +313,12 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     const int colw = (int)(swz - rg * (unsigned)n_colg) * (64 * CBW) + ((wave + (int)rg) & 3) * (16 * CBW);
     const int col = colw + CBW * fi;  // this lane's bins: col (cb = 0), col + 1 (cb = 1)
     const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
-    const int64_t n = a.n;
+    int64_t n = a.n, rows = a.rows;
+    if (a.clip_tab) {   // stacked clips of different lengths: this clip's own tile and frame counts
+        rows = a.clip_tab[3 * clip + 1];
+        n = a.clip_tab[3 * clip + 2];
+        if (row0 >= rows) return;   // workgroup-uniform, before any barrier
+    }
 
     // ---- per-row state, once per workgroup: owner tile k0 / position j0 of each row, then the table of
     // cross-fade weights (util.py:321-325): the owner tile (m = 0) overwrites (up 1, down 0), a later
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
         const int64_t r = row0 + i;
         int64_t k0 = 0;
         int j0 = -1;
-        if (r < a.rows) {
+        if (r < rows) {
             if (FOLD) {
                 int64_t kk = (r < ov) ? 0 : (int64_t)((uint64_t)(r - ov) / (unsigned)st);
                 if (kk > n - 1) kk = n - 1;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     const bool vec = CBW == 2 && ((a.mix_ld | a.out_ld) & 1) == 0;  // rows 8-byte aligned (the fused path pads F to 4)
     f32x4 mixv[CBW];
     const float* mix0 = a.mix + clip * a.mix_clip_stride + row0 * a.mix_ld;   // workgroup-uniform
-    const int rows_here = a.rows - row0 < 16 ? (int)(a.rows - row0) : 16;
+    const int rows_here = rows - row0 < 16 ? (int)(rows - row0) : 16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int ri = kq * 4 + e;

@@ -408,15 +408,17 @@ int launch_inverse(dcs_stft* p, const R* win, const R2* tw, const R* wsq, const 
 
 int dcs_launch_stft_forward_f32_clips(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips,
                                       float* mag, float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T,
-                                      bool interleave) {
+                                      bool interleave, const int64_t* clip_tab) {
     // few frames: the block-level kernel (4 waves share one frame's FFT) has the shorter critical path
     // (8.6 us vs 19 us for 186 frames); many frames: the wave-per-frame kernel has the higher throughput
     static const int64_t thr_env = getenv("DCS_STFT_WAVE_MIN") ? atoll(getenv("DCS_STFT_WAVE_MIN")) : -1;
     const int64_t thr = thr_env >= 0 ? thr_env : 4 * (int64_t)p->ctx->n_cu;
-    if (dcs_fft_wave_supported(p) && rows_out * n_clips >= thr) {
+    if (clip_tab && !dcs_fft_wave_supported(p))
+        DCS_FAIL(DCS_EUNSUPPORTED, "clips of different lengths need the wave STFT kernels (frameSize 1024 / 2048 / 4096)");
+    if (dcs_fft_wave_supported(p) && (clip_tab || rows_out * n_clips >= thr)) {
         DcsTimer tm(p->ctx, DCS_TAG_STFT);
         const int rc = dcs_fft_wave_forward(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T,
-                                            interleave);
+                                            interleave, clip_tab);
         tm.done();
         DCS_CHECK(rc);
         DCS_HIP(hipGetLastError());
@@ -451,8 +453,11 @@ int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_strid
 // n_clips clips of n_src sources each: sources are stacked (clip-major), the unit phasors are per clip
 int dcs_launch_stft_inverse_f32_clips(dcs_stft* p, const float* mag, int64_t src_stride, const float2* unit,
                                       int64_t unit_clip_stride, int64_t ld, int64_t T, int n_src, int64_t n_clips,
-                                      float pre_div, float* audio, int64_t n_out) {
+                                      float pre_div, float* audio, int64_t n_out, const int64_t* clip_tab,
+                                      int64_t out_stride) {
     if (T <= 0 || n_src <= 0 || n_out <= 0 || n_clips <= 0) return DCS_OK;
+    if (clip_tab && (!dcs_fft_wave_inverse_supported(p) || !unit))
+        DCS_FAIL(DCS_EUNSUPPORTED, "clips of different lengths need the wave iSTFT kernel (frameSize 1024 / 2048 / 4096, hop | frameSize)");
     if (!dcs_fft_wave_inverse_supported(p) || !unit) {
         for (int64_t c = 0; c < n_clips; ++c)
             DCS_CHECK(dcs_launch_stft_inverse_f32(p, mag + c * n_src * src_stride, src_stride, nullptr,
@@ -462,7 +467,7 @@ int dcs_launch_stft_inverse_f32_clips(dcs_stft* p, const float* mag, int64_t src
     }
     DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
     const int rc = dcs_fft_wave_inverse(p, mag, src_stride, nullptr, unit, unit_clip_stride, n_src, ld, T,
-                                        (int)(n_src * n_clips), pre_div, audio, n_out);
+                                        (int)(n_src * n_clips), pre_div, audio, n_out, clip_tab, out_stride);
     tm.done();
     DCS_CHECK(rc);
     DCS_HIP(hipGetLastError());

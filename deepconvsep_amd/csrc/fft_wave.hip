@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
                                          const float2* __restrict__ tw, float* __restrict__ mag,
                                          float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
                                          int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
-                                         float sqrt_n, int interleave) {
+                                         float sqrt_n, int interleave, const int64_t* __restrict__ clip_tab) {
     constexpr int M = 1 << LOG2M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -292,6 +292,10 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     if (row >= rows_pc * n_clips) return;
     const int64_t clip = row / rows_pc;
     const int64_t t = row - clip * rows_pc;
+    if (clip_tab) {   // clips of different lengths share the launch: {samples, frames, tiles} per clip
+        L = clip_tab[3 * clip];
+        T = clip_tab[3 * clip + 1];
+    }
     audio += clip * audio_stride;
     const int64_t orow = interleave ? t * n_clips + clip : row;   // interleave: rows ordered [frame][clip]
     float* mrow = mag + orow * ld;
@@ -399,7 +403,8 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
                                                          const float2* __restrict__ tw, float* __restrict__ audio,
                                                          int64_t n_out, int hop, int64_t T, int C, int64_t n_blocks,
                                                          int n_chunks, int n_src, int ring_slots, float pre_div,
-                                                         float sqrt_n, int64_t unit_clip_stride, int src_per_clip) {
+                                                         float sqrt_n, int64_t unit_clip_stride, int src_per_clip,
+                                                         const int64_t* __restrict__ clip_tab, int64_t out_stride) {
     constexpr int M = 1 << LOG2M, N = 2 * M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     constexpr bool LEAN = WREG > 0 && WaveTw<LOG2M>::REG3;   // no twiddle / window tables in LDS
@@ -431,6 +436,13 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
         }
     }
     const int hp = hop >> 1, R = N / hop, rmask = ring_slots - 1;
+    if (clip_tab) {   // clips of different lengths: this source's own sample / frame / hop-block counts
+        const int64_t c = s / src_per_clip;
+        n_out = clip_tab[3 * c];
+        T = clip_tab[3 * c + 1];
+        n_blocks = (n_out + M + hop - 1) / hop;
+        if ((int64_t)chunk * C >= n_blocks) return;   // workgroup-uniform, before any barrier
+    }
     const int64_t hb0 = (int64_t)chunk * C;
     const int64_t hb1 = (hb0 + C < n_blocks) ? hb0 + C : n_blocks;
 
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
     const float amp = 0.5f * (sqrt_n / pre_div);  // (mag / scale_factor) sqrt(N), and the 1/2 of the even/odd split
     const float* msrc = mag + (int64_t)s * src_stride;
     unit += (int64_t)(s / src_per_clip) * unit_clip_stride;  // stacked clips: each has its own phasor rows
-    float* dst = audio + (int64_t)s * n_out;
+    float* dst = audio + (int64_t)s * out_stride;
     __syncthreads();
     WaveTw<LOG2M> wt;
     wt.init(LEAN ? tw : twl, lane);
@@ -593,7 +605,8 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
 
 template <int LOG2M>
 int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips, float* mag,
-               float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave) {
+               float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave,
+               const int64_t* clip_tab) {
     constexpr int M = 1 << LOG2M, MP = M + M / 32;
     // frames per workgroup: 4 when there are plenty of frames, 1 to spread a short signal over the CUs
     static const int fpw_env = getenv("DCS_STFT_FPW") ? atoi(getenv("DCS_STFT_FPW")) : 0;
@@ -607,14 +620,14 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride,
                                     (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(rows_all, fpw)), dim3(64 * fpw), lds, p->ctx->stream, audio, L,
                        p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T, rows_out, n_clips, audio_stride,
-                       (float)sqrt((double)p->frame), interleave ? 1 : 0);
+                       (float)sqrt((double)p->frame), interleave ? 1 : 0, clip_tab);
     return DCS_OK;
 }
 
 template <int LOG2M>
 int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, const float2* unit,
                int64_t unit_clip_stride, int src_per_clip, int64_t ld, int64_t T, int n_src, float pre_div, float* audio,
-               int64_t n_out) {
+               int64_t n_out, const int64_t* clip_tab, int64_t out_stride) {
     constexpr int M = 1 << LOG2M, MP = M + M / 32, N = 2 * M;
     const int hop = p->hop, R_ = N / hop;
     const int64_t n_blocks = (n_out + N / 2 + hop - 1) / hop;
@@ -651,7 +664,8 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req));               \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds_req, p->ctx->stream, mag, src_stride, phase, unit, ld, p->win_f, \
                            p->wsq_f, p->tw_f, audio, n_out, hop, T, (int)C, n_blocks, n_chunks, n_src, ring_slots,  \
-                           pre_div, (float)sqrt((double)N), unit_clip_stride, src_per_clip > 0 ? src_per_clip : n_src);  \
+                           pre_div, (float)sqrt((double)N), unit_clip_stride, src_per_clip > 0 ? src_per_clip : n_src, \
+                           clip_tab, out_stride > 0 ? out_stride : n_out);                                         \
     }
     if (unit) DCS_GO(true) else DCS_GO(false)
 #undef DCS_GO
@@ -672,22 +686,23 @@ bool dcs_fft_wave_inverse_supported(const dcs_stft* p) {
 }
 
 int dcs_fft_wave_forward(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips, float* mag,
-                         float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave) {
+                         float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave,
+                         const int64_t* clip_tab) {
     switch (p->log2m) {
-        case 9: return launch_fwd<9>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave);
-        case 10: return launch_fwd<10>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave);
-        case 11: return launch_fwd<11>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave);
+        case 9: return launch_fwd<9>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave, clip_tab);
+        case 10: return launch_fwd<10>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave, clip_tab);
+        case 11: return launch_fwd<11>(p, audio, L, audio_stride, n_clips, mag, phase, unit, ld, rows_out, T, interleave, clip_tab);
     }
     DCS_FAIL(DCS_EUNSUPPORTED, "wave FFT: frame size");
 }
 
 int dcs_fft_wave_inverse(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase, const float2* unit,
                          int64_t unit_clip_stride, int src_per_clip, int64_t ld, int64_t T, int n_src, float pre_div,
-                         float* audio, int64_t n_out) {
+                         float* audio, int64_t n_out, const int64_t* clip_tab, int64_t out_stride) {
     switch (p->log2m) {
-        case 9: return launch_inv<9>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out);
-        case 10: return launch_inv<10>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out);
-        case 11: return launch_inv<11>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out);
+        case 9: return launch_inv<9>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out, clip_tab, out_stride);
+        case 10: return launch_inv<10>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out, clip_tab, out_stride);
+        case 11: return launch_inv<11>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out, clip_tab, out_stride);
     }
     DCS_FAIL(DCS_EUNSUPPORTED, "wave FFT: frame size");
 }

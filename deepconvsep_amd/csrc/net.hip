@@ -88,6 +88,7 @@ struct dcs_model {
     DcsGenericNet* gen = nullptr;
     // ---- scratch
     DcsBuffer ws;
+    DcsBuffer clip_tab;   // {samples, frames, tiles} per clip of a batch of different lengths (dcs_separate_ragged)
     float* rise_d = nullptr;
     int rise_ov = -1;
     // ---- hipGraph of the fused step (dcs_separate): the 8 launches of one call replayed as one launch.
@@ -390,6 +391,7 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     if (m->gen) dcs_generic_destroy(m->gen);
     if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
     m->ws.release();
+    m->clip_tab.release();
     delete m;
     return DCS_OK;
 }
@@ -431,7 +433,7 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm_d, float* sep_out, float* mag_out, float* phase_out,
                          int64_t ld_out, int64_t* n_tiles_out, int64_t* n_frames_out, int64_t n_clips = 1,
-                         int64_t audio_stride = 0) {
+                         int64_t audio_stride = 0, const int64_t* lens_h = nullptr, int64_t pcm_stride = 0) {
     if (!m || !plan || !audio_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: null argument");
     if (plan->ctx != m->ctx) DCS_FAIL(DCS_EINVAL, "dcs_separate: plan and model belong to different contexts");
     if (plan->frame / 2 + 1 != m->F)
@@ -447,10 +449,36 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_batch: DSD graph, PCM output and clip stride >= length only");
     DCS_HIP(hipSetDevice(m->ctx->device));
     const int tc = m->tc, F = m->F, st = tc - ov, S = m->d.S;
-    const int64_t T = dcs_frame_count(L, plan->hop);
-    const int64_t n = dcs_tile_count(T, tc, ov, tiler);
-    if (n_tiles_out) *n_tiles_out = n;
-    if (n_frames_out) *n_frames_out = T;
+    int64_t T = dcs_frame_count(L, plan->hop);
+    int64_t n = dcs_tile_count(T, tc, ov, tiler);
+    const int64_t* clip_tab_d = nullptr;
+    if (lens_h) {
+        // clips of different lengths in one set of launches: strides and grids are sized by the longest clip (L on
+        // entry), every kernel that depends on a clip's own length reads {samples, frames, tiles} from a device table
+        if (m->arch != DCS_ARCH_DSD || !pcm_d || pcm_stride < L || n_clips < 2)
+            DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_ragged: DSD graph with PCM output and pcm_stride >= longest clip only");
+        std::vector<int64_t> tab((size_t)n_clips * 3);
+        T = 0;
+        n = 0;
+        for (int64_t c = 0; c < n_clips; ++c) {
+            const int64_t Lc = lens_h[c];
+            if (Lc < 1 || Lc > L) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: clip %lld has %lld samples", (long long)c, (long long)Lc);
+            const int64_t Tc = dcs_frame_count(Lc, plan->hop), nc = dcs_tile_count(Tc, tc, ov, tiler);
+            if (nc < 1) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: clip %lld: %lld frames give no tile", (long long)c, (long long)Tc);
+            tab[3 * c] = Lc; tab[3 * c + 1] = Tc; tab[3 * c + 2] = nc;
+            if (n_tiles_out) n_tiles_out[c] = nc;
+            if (n_frames_out) n_frames_out[c] = Tc;
+            if (Tc > T) T = Tc;
+            if (nc > n) n = nc;
+        }
+        DCS_CHECK(m->clip_tab.ensure(tab.size() * sizeof(int64_t)));
+        DCS_HIP(hipMemcpyAsync(m->clip_tab.ptr, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, m->ctx->stream));
+        DCS_HIP(hipStreamSynchronize(m->ctx->stream));   // tab goes out of scope; this path is not graph-captured
+        clip_tab_d = (const int64_t*)m->clip_tab.ptr;
+    } else {
+        if (n_tiles_out) *n_tiles_out = n;
+        if (n_frames_out) *n_frames_out = T;
+    }
     if (n < 1)
         DCS_FAIL(DCS_EINVAL, "dcs_separate: %lld frames give no tile (the reference fails in overlapadd_multi)",
                  (long long)T);
@@ -474,7 +502,8 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
         dsd_carve(m, p, n_all, rows1, rows2, &w);
-        DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T));
+        DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,
+                                                    false, clip_tab_d));
         DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
@@ -487,9 +516,11 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         a.g_clip_stride = n * m->d.n_fc * (int64_t)dsd_g_pitch(m->CI, tc);
         a.mix_clip_stride = Trows * ld;
         a.out_clip_stride = (int64_t)S * T * ld;
+        a.clip_tab = clip_tab_d;
         DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
         if (pcm_d)
-            DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, T * ld, unit, Trows * ld, ld, T, S, n_clips, scale, pcm_d, L));
+            DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, T * ld, unit, Trows * ld, ld, T, S, n_clips, scale, pcm_d, L,
+                                                        clip_tab_d, lens_h ? pcm_stride : 0));
         if (sep_out || mag_out || phase_out) {
             for (int s = 0; s < S && sep_out; ++s)
                 DCS_HIP(hipMemcpy2DAsync(sep_out + (int64_t)s * T * ld_out, ld_out * 4, sep + (int64_t)s * T * ld, ld * 4,
@@ -582,6 +613,34 @@ extern "C" int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* aud
                                   int tie_mode, float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out) {
     return separate_graphed(m, plan, audio_d, n_samples, n_clips, n_clips > 1 ? clip_stride : 0, overlap, tiler, scale,
                             eps_mode, tie_mode, pcm_d, n_tiles_out, n_frames_out);
+}
+
+extern "C" int dcs_separate_ragged(dcs_model* m, dcs_stft* plan, const float* audio_d, const int64_t* n_samples_h,
+                                   int64_t n_clips, int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode,
+                                   int tie_mode, float* pcm_d, int64_t pcm_stride, int64_t* n_tiles_out,
+                                   int64_t* n_frames_out) {
+    if (!m || !plan || !audio_d || !n_samples_h || !pcm_d) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: null argument");
+    if (n_clips < 1) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: %lld clips", (long long)n_clips);
+    int64_t lmax = 0;
+    bool same = true;
+    for (int64_t c = 0; c < n_clips; ++c) {
+        if (n_samples_h[c] > lmax) lmax = n_samples_h[c];
+        same = same && n_samples_h[c] == n_samples_h[0];
+    }
+    if (lmax > clip_stride && n_clips > 1) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: a clip is longer than the clip stride");
+    if (same && (n_clips == 1 || pcm_stride == lmax)) {   // nothing ragged about it: the equal-length path (graph-replayed)
+        int64_t nt = 0, nf = 0;
+        const int rc = separate_graphed(m, plan, audio_d, lmax, n_clips, n_clips > 1 ? clip_stride : 0, overlap, tiler, scale,
+                                        eps_mode, tie_mode, pcm_d, &nt, &nf);
+        for (int64_t c = 0; c < n_clips && rc == DCS_OK; ++c) {
+            if (n_tiles_out) n_tiles_out[c] = nt;
+            if (n_frames_out) n_frames_out[c] = nf;
+        }
+        return rc;
+    }
+    if (n_clips == 1) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: one clip with pcm_stride != its length");
+    return separate_impl(m, plan, audio_d, lmax, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr, nullptr, nullptr, 0,
+                         n_tiles_out, n_frames_out, n_clips, clip_stride, n_samples_h, pcm_stride);
 }
 
 // ------------------------------------------------------------------------------------------------ stereo (ILD) path

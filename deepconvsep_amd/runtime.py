@@ -266,6 +266,29 @@ class Network(object):
         self.last_tiles, self.last_frames = nt.value, nf.value
         return out
 
+    def separate_ragged(self, plan, audio_t, lengths, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None,
+                        tie_mode=TIE_ALL, out=None):
+        """Clips of different lengths sharing one set of launches: ``audio_t [B, Lmax]`` float32 device tensor (row c
+        holds ``lengths[c]`` samples), returns ``[B, S, Lmax]`` float32 PCM of which ``[c, :, :lengths[c]]`` is valid.
+        Every clip gets the frames, tiles and cross-fade :meth:`separate` would give it alone (DSD / hiphop graph,
+        frameSize 1024 / 2048 / 4096)."""
+        torch = _torch()
+        if audio_t.dim() != 2 or audio_t.stride(1) != 1:
+            raise ValueError("separate_ragged expects a [clips, samples] tensor with contiguous rows")
+        B, Lmax = int(audio_t.shape[0]), int(audio_t.shape[1])
+        lens = (c_int64 * B)(*[int(x) for x in lengths])
+        if len(lengths) != B or max(lens) > Lmax:
+            raise ValueError("separate_ragged: %d lengths for %d clips of at most %d samples" % (len(lengths), B, Lmax))
+        if out is None:
+            out = torch.zeros((B, self.S, Lmax), dtype=torch.float32, device=audio_t.device)
+        eps = self.arch.eps_mode if eps_mode is None else eps_mode
+        nt, nf = (c_int64 * B)(), (c_int64 * B)()
+        _lib.check(self.ctx._lib.dcs_separate_ragged(self._h, plan._h, _ptr(audio_t), lens, B, int(audio_t.stride(0)),
+                                                     int(overlap), int(tiler), float(scale), int(eps), int(tie_mode),
+                                                     _ptr(out), int(out.stride(1)), nt, nf))
+        self.last_tiles, self.last_frames = list(nt), list(nf)
+        return out
+
     def separate_stereo(self, plan, audio_t, overlap, tiler=TILER_LIBRARY, scale=0.3, want_spectra=False):
         """Stereo (ILD) graph: ``[2, L]`` float32 device tensor (rows contiguous) -> PCM ``[2, S, L]`` (and, with
         ``want_spectra``, the cross-faded scaled magnitudes ``[2, S, T, F]``)."""

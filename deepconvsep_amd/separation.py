@@ -173,25 +173,45 @@ class Separator(object):
         pcm = self.net.separate(self.plan, a, self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)
         return pcm.cpu().numpy().astype(np.float64)
 
-    def separate_many(self, audios):
-        """A list of clips -> a list of float64 ``[S, L_i]``.  Clips of the same length share one set of kernel launches
-        (``dcs_separate_batch``, DSD / hiphop graph); every clip gets exactly the tiles and the cross-fade
-        :meth:`separate` gives it alone.  Other graphs, and lengths that occur once, go through :meth:`separate`."""
-        audios = [np.asarray(a) for a in audios]
+    def separate_many(self, audios, max_group=16, max_ratio=1.5):
+        """A list of clips -> a list of float64 ``[S, L_i]``.  Clips share sets of kernel launches (DSD / hiphop graph):
+        sorted by length, they are cut into groups of at most ``max_group`` clips whose longest is at most
+        ``max_ratio`` times the shortest (a group costs what its longest clip costs, times its size); a group goes
+        through ``dcs_separate_ragged`` (``dcs_separate_batch`` when its lengths are equal).  Every clip gets exactly
+        the frames, the tiles and the cross-fade :meth:`separate` gives it alone.  Other graphs, frame sizes the
+        wave STFT kernels do not cover, and groups of one go through :meth:`separate`."""
+        audios = [np.asarray(a).reshape(-1) for a in audios]
         out = [None] * len(audios)
-        groups = {}
-        for i, a in enumerate(audios):
-            groups.setdefault(int(a.size), []).append(i)
-        for L, idx in groups.items():
-            if len(idx) == 1 or self.arch_name not in ("dsd", "hiphop") or L == 0:
-                for i in idx:
-                    out[i] = self.separate(audios[i])
+        shared = (self.arch_name in ("dsd", "hiphop") and self.frameSize in (1024, 2048, 4096)
+                  and self.frameSize % self.hopSize == 0 and self.hopSize % 2 == 0)
+        order = sorted(range(len(audios)), key=lambda i: audios[i].size)
+        groups, cur = [], []
+        for i in order:
+            if cur and (len(cur) >= max_group or audios[i].size > max_ratio * audios[cur[0]].size or not shared
+                        or audios[cur[0]].size == 0):
+                groups.append(cur)
+                cur = []
+            cur.append(i)
+        if cur:
+            groups.append(cur)
+        for idx in groups:
+            if len(idx) == 1:
+                out[idx[0]] = self.separate(audios[idx[0]])
                 continue
-            stack = self.ctx.to_device(np.stack([audios[i].reshape(-1) for i in idx]), np.float32)      # [B, L]
-            pcm = self.net.separate_batch(self.plan, stack, self.overlap, self.tiler, self.scale_factor, None,
-                                          self.tie_mode).cpu().numpy()
+            lens = [int(audios[i].size) for i in idx]
+            stack = np.zeros((len(idx), max(lens)), dtype=np.float32)
             for b, i in enumerate(idx):
-                out[i] = pcm[b].astype(np.float64)
+                stack[b, :lens[b]] = audios[i]
+            dev = self.ctx.to_device(stack, np.float32)                                              # [B, Lmax]
+            if min(lens) == max(lens):
+                pcm = self.net.separate_batch(self.plan, dev, self.overlap, self.tiler, self.scale_factor, None,
+                                              self.tie_mode)
+            else:
+                pcm = self.net.separate_ragged(self.plan, dev, lens, self.overlap, self.tiler, self.scale_factor, None,
+                                               self.tie_mode)
+            pcm = pcm.cpu().numpy()
+            for b, i in enumerate(idx):
+                out[i] = pcm[b, :, :lens[b]].astype(np.float64)
         return out
 
     def separate_stepwise(self, audio):

@@ -154,6 +154,19 @@ int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64
                        int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode, int tie_mode,
                        float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out);
 
+/* The same for clips of DIFFERENT lengths (a directory of songs, separate_multiple.ipynb): clip c has
+ * n_samples_h[c] samples (host array) starting at audio_d + c * clip_stride, and its S signals are written to
+ * pcm_d + (c * S + s) * pcm_stride (pcm_stride >= the longest clip; samples past a clip's own length are not
+ * written).  Strides and grids are sized by the longest clip; the STFT, the cross-fade fold and the iSTFT read
+ * every clip's own sample / frame / tile counts from a small device table, so each clip gets exactly the frames,
+ * the tiles and the cross-fade dcs_separate gives it alone (shorter clips cost the launch the work of the longest).
+ * Needs the wave STFT kernels (frameSize 1024 / 2048 / 4096 with hop | frameSize, DCS_EUNSUPPORTED otherwise).
+ * n_tiles_out / n_frames_out: [n_clips] or NULL.  Equal lengths with pcm_stride == length take the
+ * dcs_separate_batch path. */
+int dcs_separate_ragged(dcs_model* m, dcs_stft* plan, const float* audio_d, const int64_t* n_samples_h,
+                        int64_t n_clips, int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode,
+                        int tie_mode, float* pcm_d, int64_t pcm_stride, int64_t* n_tiles_out, int64_t* n_frames_out);
+
 /* Stereo separation, the "Separating" block of examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:291-325, for a
  * DCS_ARCH_DSD_ILD model: audio_d holds the two channels (channel c at audio_d + c * channel_stride), one STFT per
  * channel, 2-channel tiles (pass DCS_TILER_LIBRARY: the trainer calls util.generate_overlapadd), one network pass,

@@ -451,7 +451,7 @@ def test_batch_driver_matches_single_file_runs(tmp_path):
     spec.loader.exec_module(mod)
     out = tmp_path / "out"
     out.mkdir()
-    mod.main(["-a", "dsd", "-m", model, "-o", str(out)] + wavs)
+    mod.main(["-a", "dsd", "-m", model, "-o", str(out), "--group", "1"] + wavs)      # one file per set of launches
     sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, 1024, 512, np.hanning)
     for i, w in enumerate(wavs):
         sr, audio = dcs.separation.read_wav(w)
@@ -462,9 +462,9 @@ def test_batch_driver_matches_single_file_runs(tmp_path):
 
 
 def test_batch_driver_groups_equal_lengths(tmp_path):
-    """--group: files of equal length share one set of launches (Separator.separate_many -> dcs_separate_batch); every
+    """--group: files share sets of launches (Separator.separate_many -> dcs_separate_ragged / dcs_separate_batch); every
     file still gets what the single-file path gives it (kernel variants depend on the launch size, so float results
-    agree to ~1e-6 and the int16 samples to one step), files of other lengths keep their own launches."""
+    agree to ~1e-6 and the int16 samples to one step)."""
     import importlib.util
     import os
     import scipy.io.wavfile
@@ -497,6 +497,55 @@ def test_batch_driver_groups_equal_lengths(tmp_path):
             sr2, data = scipy.io.wavfile.read(str(out / ("clip%d" % i) / (name + ".wav")))
             d = data.astype(np.int32) - (want[s_] * 32767).astype('int16').astype(np.int32)
             assert data.shape[0] == lengths[i] and np.max(np.abs(d)) <= 1
+
+
+@pytest.mark.parametrize("N,hop,tiler,lengths", [
+    (1024, 512, "script", [40000, 31000, 40000, 52000, 19000, 47011]),
+    (2048, 512, "script", [94208, 60000, 94208, 70001]),
+    (1024, 256, "library", [30000, 20011, 25000]),
+])
+def test_separate_ragged_equals_clip_by_clip(N, hop, tiler, lengths):
+    """dcs_separate_ragged: clips of different lengths in one set of launches -- each clip's frames, tiles and
+    cross-fade are its own (device table of {samples, frames, tiles}); results agree with the single-clip call to
+    fp32 rounding (kernel variants depend on the launch size) and with the oracle within 1e-4."""
+    import torch
+    F = N // 2 + 1
+    params = synth_params("dsd", 30, F, seed=2)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, N, hop, np.hanning, tiler=tiler)
+    clips = [synth_audio(n, seed=60 + i) for i, n in enumerate(lengths)]
+    Lmax = max(lengths)
+    stack = np.zeros((len(clips), Lmax + 17), dtype=np.float32)          # a row pitch larger than the longest clip
+    for b, a in enumerate(clips):
+        stack[b, :a.size] = a
+    dev = sep.ctx.to_device(stack, np.float32)
+    got = sep.net.separate_ragged(sep.plan, dev[:, :Lmax], lengths, 25, sep.tiler, 0.3).cpu().numpy()
+    assert list(sep.net.last_frames) == [stft_np.frame_count(n, hop) for n in lengths]
+    for b, a in enumerate(clips):
+        alone = sep.separate(a)
+        assert np.max(np.abs(got[b, :, :a.size] - alone)) < 5e-6
+        assert not got[b, :, a.size:].any()                               # nothing written past a clip's own length
+        want = pipeline.separate("dsd", params, a, 0.3, 30, 25, 32, N, hop, np.hanning,
+                                 tiler=tiling_np.SCRIPT if tiler == "script" else tiling_np.LIBRARY)
+        assert np.max(np.abs(got[b, :, :a.size] - want)) < 1e-4
+    many = sep.separate_many(clips)
+    for b, a in enumerate(clips):
+        assert many[b].shape == (4, a.size) and np.max(np.abs(many[b] - sep.separate(a))) < 5e-6
+
+
+def test_separate_ragged_rejects_what_it_cannot_do():
+    import torch
+    params = synth_params("dsd", 30, 257, seed=2)
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, 257, 512, 200, np.hanning)      # block-level FFT only
+    dev = sep.ctx.to_device(np.zeros((2, 30000), dtype=np.float32), np.float32)
+    with pytest.raises(NotImplementedError):
+        sep.net.separate_ragged(sep.plan, dev, [30000, 20000], 25, sep.tiler, 0.3)
+    many = sep.separate_many([synth_audio(30000, seed=1), synth_audio(20000, seed=2)])   # falls back to one by one
+    assert many[0].shape == (4, 30000) and many[1].shape == (4, 20000)
+    params2 = synth_params("dsd", 30, 513, seed=2)
+    sep2 = dcs.Separator("dsd", params2, 0.3, 30, 25, 32, 513, 1024, 512, np.hanning)
+    dev2 = sep2.ctx.to_device(np.zeros((2, 30000), dtype=np.float32), np.float32)
+    with pytest.raises(ValueError):
+        sep2.net.separate_ragged(sep2.plan, dev2, [30000, 5], 25, sep2.tiler, 0.3)     # 5 samples: no tile
 
 
 def test_graph_replay_recomputes_on_a_side_stream():
