@@ -147,6 +147,22 @@ def to_mono(audioObj, arch_name):
     return audioObj
 
 
+def length_groups(sizes, max_group=16, max_ratio=1.5):
+    """Indices of ``sizes`` sorted by size and cut into runs of at most ``max_group`` entries whose largest is at most
+    ``max_ratio`` times the smallest (a launch group costs what its longest clip costs, times its size).  Empty
+    clips stay alone (the single-clip path raises for them what the reference raises)."""
+    order = sorted(range(len(sizes)), key=lambda i: (sizes[i], i))
+    groups, cur = [], []
+    for i in order:
+        if cur and (len(cur) >= max_group or sizes[cur[0]] == 0 or sizes[i] > max_ratio * sizes[cur[0]]):
+            groups.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        groups.append(cur)
+    return groups
+
+
 class Separator(object):
     """Model + STFT plan resident on one GPU; ``separate(audio)`` is the body of ``train_auto``
     between reading and writing the wav files (separate_dsd.py:289-306)."""
@@ -184,16 +200,7 @@ class Separator(object):
         out = [None] * len(audios)
         shared = (self.arch_name in ("dsd", "hiphop") and self.frameSize in (1024, 2048, 4096)
                   and self.frameSize % self.hopSize == 0 and self.hopSize % 2 == 0)
-        order = sorted(range(len(audios)), key=lambda i: audios[i].size)
-        groups, cur = [], []
-        for i in order:
-            if cur and (len(cur) >= max_group or audios[i].size > max_ratio * audios[cur[0]].size or not shared
-                        or audios[cur[0]].size == 0):
-                groups.append(cur)
-                cur = []
-            cur.append(i)
-        if cur:
-            groups.append(cur)
+        groups = length_groups([a.size for a in audios], max_group if shared else 1, max_ratio)
         for idx in groups:
             if len(idx) == 1:
                 out[idx[0]] = self.separate(audios[idx[0]])

@@ -150,3 +150,20 @@ def test_product_score_helpers_against_the_oracle(tmp_path):
     (tmp_path / "one_b.txt").write_text("0.5,1.5,C4\n")
     assert score.expandMidi("one_b", str(tmp_path), 0, 40.0, 50, 440, 20, 44100, 512, 4096, 0.2, 0.2, 100, 0.5) is None
     assert score.getMidiNum("one_b", str(tmp_path), 0, 40.0) == 1
+
+
+def test_length_groups_policy():
+    """Separator.separate_many: clips sorted by length, groups of bounded size and bounded longest / shortest ratio."""
+    from deepconvsep_amd.separation import length_groups
+    sizes = [40000, 31000, 40000, 40000, 52000, 0, 100, 149, 151]
+    groups = length_groups(sizes, max_group=3, max_ratio=1.5)
+    assert sorted(i for g in groups for i in g) == list(range(len(sizes)))          # a partition
+    assert groups[0] == [5]                                                            # the empty clip stays alone
+    for g in groups:
+        assert len(g) <= 3
+        lo, hi = min(sizes[i] for i in g), max(sizes[i] for i in g)
+        assert hi <= 1.5 * lo or lo == 0
+    assert [6, 7] in groups and [8] in groups                                          # 151 > 1.5 * 100
+    assert length_groups([5, 5, 5], max_group=1) == [[0], [1], [2]]
+    assert length_groups([]) == []
+
