@@ -15,7 +15,7 @@ rows=list(csv.DictReader(open(glob.glob(out+'/pmc2_m/*counter_collection.csv')[0
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k=r['Kernel_Name']
-    for key in ('final_kernel','deconv2_persistent','deconv2','istft_wave','gemm_rows_splitk','gemm_rows_kernel','stft_forward_wave','stft_forward'):
+    for key in ('final_kernel','deconv2_stream','deconv2','istft_wave','gemm_rows_splitk','gemm_rows_kernel','stft_forward_wave','stft_forward'):
         if key in k: k=key; break
     gs=int(r['Grid_Size'])
     agg[(k,gs)]['dur_us'].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
