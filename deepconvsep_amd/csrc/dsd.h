@@ -30,6 +30,11 @@ struct DsdFinalArgs {
     int bias_half;        // 0: bias[4] per source; > 0: two input channels side by side, bins >= bias_half use bias[2 s + 1]
     int n_clips;          // stacked clips of equal length (0 or 1: a single clip); clip c uses G + c*g_clip_stride,
     int64_t g_clip_stride, mix_clip_stride, out_clip_stride;  // mix + c*mix_clip_stride, out + c*out_clip_stride
+    // opt-in bf16x3 path (dsd_bf16x3.hip): G split into three bf16 planes [item][t][3][64] and the weights split and
+    // laid out per (bin, plane, K block, lane group); null = the f32 kernel
+    const void* Gs;
+    const void* Bpk;
+    int64_t gs_clip_stride;   // 16-byte units
     const int64_t* clip_tab;  // device {samples, frames, tiles} per clip when the stacked clips differ in length (n and
                               // rows above are then the maxima that size the grid and the strides), else null
 };
@@ -39,3 +44,8 @@ struct DsdFinalArgs {
 int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const float* Bws, float* G, int64_t n_ks,
                            int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols);
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold);
+
+// ---- opt-in bf16x3 variant of the fused final kernel (DCS_FINAL_BF16X3=1; dsd_bf16x3.hip)
+constexpr int kDsdSplitRowU4 = 24;   // 16-byte units per (item, t) row of the split G: 3 planes x 64 channels x bf16
+int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg, int ci);
+int dcs_launch_dsd_final_bf16x3(dcs_ctx* ctx, const DsdFinalArgs& a, int n_colg, int64_t n_wg, unsigned n_clips);

@@ -641,6 +641,11 @@ int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
     const int64_t n_wg = n_rg * n_colg;
     if (n_wg > 0x7fffffff) DCS_FAIL(DCS_EUNSUPPORTED, "final: %lld workgroups", (long long)n_wg);
     DcsTimer tm(ctx, DCS_TAG_FINAL);
+    if (a.Gs && a.Bpk && fold && a.nbr != 4 && cbw == 2 && a.mask_mode < 2 && a.bias_half == 0) {   // opt-in bf16x3 path
+        const int rc = dcs_launch_dsd_final_bf16x3(ctx, a, n_colg, n_wg, n_clips);
+        tm.done();
+        return rc;
+    }
 #define DCS_FINAL(FOLD_, MODE_)                                                                                      \
     do {                                                                                                             \
         if (cbw == 2)                                                                                                \

@@ -1,0 +1,352 @@
+// OPT-IN experiment (DCS_FINAL_BF16X3=1, off by default): the final kernel of dsd.hip on the 16-bit-input matrix pipe
+// with fp32-class results.
+//
+// Why: scripts/ubench/mfma16_valu.hip (profiles/r01_d_ubench_mfma16_valu.txt) -- v_mfma_f32_16x16x32_bf16 takes 6.9 ns
+// per SIMD for 16 384 flop and runs BESIDE the VALU, while the f32 MFMA (13.9 ns for 2 048 flop) executes on the
+// vector FMA lanes and serialises with every VALU instruction of the epilogue.
+//
+// How: every f32 operand is split exactly into three bf16 terms by truncation, x = hi + mid + lo (8 + 8 + 8
+// significand bits), and the product sum keeps the six term pairs above 2^-24:
+//     a.b ~= a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)          dropped: a1 b2 + a2 b1 + a2 b2 <= 3 * 2^-24 |a b|
+// Each pair is a K = 64 (50 channels, zero padded) bf16 MFMA chain with f32 accumulation: 12 MFMAs per (branch,
+// column block, covering tile) instead of 13 f32 ones.  bf16 products are exact in f32, so the only roundings are the
+// accumulator's -- the class of the f32 kernel.  G arrives already split (g_split_kernel: one pass over G, 4 -> 6
+// bytes per value), the transposed-conv1 weights are split when the model is packed.
+//
+// Everything else -- row/tile bookkeeping, cross-fade tables, soft mask, fold, stores -- is final_kernel<true, MODE, 2, 3>.
+#include "dcs_internal.h"
+#include "dsd.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kThreads = 256;
+constexpr int kRowU4 = kDsdSplitRowU4;  // 24 x 16 bytes per (item, t): 3 planes x 64 channels x bf16
+constexpr int kRowLds = 25;             // LDS row stride in 16-byte units: 100 words, fi * 100 mod 64 = 16 distinct bank quads
+
+__device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+// G f32 [item][channel group][t][8]  ->  Gs bf16 [item][t][plane][64 channels], x = plane0 + plane1 + plane2 exactly
+__global__ __launch_bounds__(kThreads) void g_split_kernel(const float* __restrict__ G, u32x4* __restrict__ Gs,
+                                                           int64_t n_rows /* items * tc */, int tc, int ngg, int ci /* channels that carry data */) {
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int g8 = (int)(idx & 7);
+    const int64_t it = idx >> 3;
+    if (it >= n_rows) return;
+    const int64_t item = it / tc;
+    const int t = (int)(it - item * tc);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (g8 < ngg) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(G + ((item * ngg + g8) * tc + t) * 8);
+        const f32x4 x0 = p[0], x1 = p[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = g8 * 8 + j < ci ? x0[j] : 0.f;
+            v[4 + j] = g8 * 8 + 4 + j < ci ? x1[j] : 0.f;
+        }
+    }
+    unsigned pl[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned h = bf_trunc(v[j]);
+        const float r1 = v[j] - __uint_as_float(h);      // exact
+        const unsigned m = bf_trunc(r1);
+        const float r2 = r1 - __uint_as_float(m);        // exact, at most 8 significant bits left
+        pl[0][j] = h;
+        pl[1][j] = m;
+        pl[2][j] = bf_trunc(r2);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        u32x4 w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (pl[p][2 * q] >> 16) | (pl[p][2 * q + 1] & 0xffff0000u);
+        Gs[it * kRowU4 + p * 8 + g8] = w;
+    }
+}
+
+__device__ __forceinline__ f32x2 max2(f32x2 x, float lo) {
+    const int l = __builtin_bit_cast(int, lo);
+    const i32x2 xi = __builtin_bit_cast(i32x2, x);
+    const i32x2 r = {xi[0] > l ? xi[0] : l, xi[1] > l ? xi[1] : l};
+    return __builtin_bit_cast(f32x2, r);
+}
+
+__device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFinalArgs a, int n_colg) {
+    constexpr int CBW = 2, NBR = 3;
+    constexpr int kABuf = NBR * 16 * kRowLds;
+    constexpr int kMaxM = 16;
+    __shared__ u32x4 As[2 * kABuf];
+    __shared__ __attribute__((aligned(16))) float up_t[kMaxM * 16];
+    __shared__ __attribute__((aligned(16))) float down_t[kMaxM * 16];
+    __shared__ int meta_k0[16];
+    __shared__ int meta_j0[16];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int64_t clip = blockIdx.y;
+    const unsigned rg = swz / (unsigned)n_colg;
+    const int64_t row0 = (int64_t)rg * 16;
+    const int colw = (int)(swz - rg * (unsigned)n_colg) * (64 * CBW) + ((wave + (int)rg) & 3) * (16 * CBW);
+    const int col = colw + CBW * fi;
+    const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
+    int64_t n = a.n, rows = a.rows;
+    if (a.clip_tab) {
+        rows = a.clip_tab[3 * clip + 1];
+        n = a.clip_tab[3 * clip + 2];
+        if (row0 >= rows) return;
+    }
+
+    if (tid < 16 * mmax) {
+        const int i = tid & 15, m = tid >> 4;
+        const int64_t r = row0 + i;
+        int64_t k0 = 0;
+        int j0 = -1;
+        if (r < rows) {
+            int64_t kk = (r < ov) ? 0 : (int64_t)((uint64_t)(r - ov) / (unsigned)st);
+            if (kk > n - 1) kk = n - 1;
+            const int64_t jj = r - kk * st;
+            if (jj < tc) {
+                k0 = kk;
+                j0 = (int)jj;
+            }
+        }
+        if (m == 0) {
+            meta_k0[i] = (int)k0;
+            meta_j0[i] = j0;
+        }
+        const int j = j0 - m * st;
+        const bool valid = j0 >= 0 && j >= 0 && k0 + m < n;
+        float up = 0.f, down = 1.f;
+        if (m == 0) {
+            up = valid ? 1.f : 0.f;
+            down = 0.f;
+        } else if (valid) {
+            up = a.rise[j];
+            down = a.rise[ov - 1 - j];
+        }
+        up_t[m * 16 + i] = up;
+        down_t[m * 16 + i] = down;
+    }
+
+    const bool live = colw < a.F;
+    // B fragments: the three planes of Bw[c][bin] for this lane's two bins and K-quarter, constant for the workgroup
+    const u32x4* Bpk = reinterpret_cast<const u32x4*>(a.Bpk);
+    u32x4 breg[CBW][3][2];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                breg[cb][p][kb] = live ? Bpk[(((col + cb) * 3 + p) * 2 + kb) * 4 + kq] : u32x4{0u, 0u, 0u, 0u};
+
+    const bool vec = ((a.mix_ld | a.out_ld) & 1) == 0;
+    f32x4 mixv[CBW];
+    const float* mix0 = a.mix + clip * a.mix_clip_stride + row0 * a.mix_ld;
+    const int rows_here = rows - row0 < 16 ? (int)(rows - row0) : 16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ri = kq * 4 + e;
+        float m0 = 0.f, m1 = 0.f;
+        if (ri < rows_here) {
+            const float* mp = mix0 + (ri * (int)a.mix_ld + col);
+            if (vec && col + 1 < a.F) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(mp);
+                m0 = v[0];
+                m1 = v[1];
+            } else {
+                if (col < a.F) m0 = mp[0];
+                if (col + 1 < a.F) m1 = mp[1];
+            }
+        }
+        mixv[0][e] = a.mix_scale * m0;
+        mixv[1][e] = a.mix_scale * m1;
+    }
+    const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
+    const float eps_r = 5e-19f;
+
+    f32x4 res[CBW][4];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) res[cb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+
+    // staging plan: NSL 16-byte slots of the [3 branches][16 rows][24] A set per thread
+    constexpr int slots = NBR * 16 * kRowU4;                 // 1152
+    constexpr int NSL = (slots + kThreads - 1) / kThreads;   // 5
+    const int m_delta = (NBR * tc - st) * kRowU4;            // 16-byte units from covering tile m to m + 1
+    const int kbase = meta_k0[0];
+    const u32x4* gbase = reinterpret_cast<const u32x4*>(a.Gs) + clip * a.gs_clip_stride + (int64_t)kbase * NBR * tc * kRowU4;
+    int goff[NSL], dst[NSL], srow[NSL];
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+        const int idx = tid + u * kThreads;
+        const int s = idx / (16 * kRowU4);
+        const int rem = idx - s * 16 * kRowU4;
+        const int i = rem / kRowU4, c = rem - i * kRowU4;
+        const bool in = idx < slots;
+        const int j0 = in ? meta_j0[i] : -1;
+        srow[u] = in ? i : -1;
+        dst[u] = (s * 16 + i) * kRowLds + c;
+        goff[u] = (((in ? meta_k0[i] - kbase : 0) * NBR + s) * tc + (j0 < 0 ? 0 : j0)) * kRowU4 + c;
+    }
+    u32x4 pre[NSL];
+#define DCS_LOAD_A(m_)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};                                                        \
+        if (srow[u] >= 0 && up_t[(m_) * 16 + srow[u]] != 0.f) v = gbase[goff[u] + (m_) * m_delta]; \
+        pre[u] = v;                                                                             \
+    }
+#define DCS_STORE_A(buf_)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
+        if (srow[u] >= 0) As[(buf_) * kABuf + dst[u]] = pre[u];                                 \
+    }
+
+    DCS_LOAD_A(0)
+    for (int m = 0; m < mmax; ++m) {
+        DCS_STORE_A(m & 1)
+        __syncthreads();
+        if (m + 1 < mmax) DCS_LOAD_A(m + 1)
+        if (!live) continue;
+        const u32x4* Ab = As + (m & 1) * kABuf + fi * kRowLds + kq;
+        f32x4 acc[NBR][CBW];
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+            acc[0][cb] = f32x4{bias0, bias0, bias0, bias0};
+            acc[1][cb] = f32x4{bias1, bias1, bias1, bias1};
+            acc[2][cb] = f32x4{bias2, bias2, bias2, bias2};
+        }
+#pragma unroll
+        for (int s = 0; s < NBR; ++s) {
+            u32x4 af[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) af[p][kb] = Ab[s * 16 * kRowLds + p * 8 + kb * 4];
+            // smallest terms first; the two column blocks alternate so that no MFMA waits for the one before it
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[2][kb], breg[cb][0][kb], acc[s][cb]);
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[0][kb], breg[cb][2][kb], acc[s][cb]);
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[1][kb], breg[cb][1][kb], acc[s][cb]);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[1][kb], breg[cb][0][kb], acc[s][cb]);
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[0][kb], breg[cb][1][kb], acc[s][cb]);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[0][kb], breg[cb][0][kb], acc[s][cb]);
+        }
+        const f32x4 up4 = *reinterpret_cast<const f32x4*>(up_t + m * 16 + kq * 4);
+        const f32x4 down4 = *reinterpret_cast<const f32x4*>(down_t + m * 16 + kq * 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 up = {up4[2 * h], up4[2 * h + 1]};
+            const f32x2 down = {down4[2 * h], down4[2 * h + 1]};
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                const f32x2 x0 = {acc[0][cb][2 * h], acc[0][cb][2 * h + 1]};
+                const f32x2 x1 = {acc[1][cb][2 * h], acc[1][cb][2 * h + 1]};
+                const f32x2 x2 = {acc[2][cb][2 * h], acc[2][cb][2 * h + 1]};
+                const f32x2 x3 = x1 + (bias3 - bias1);
+                const float lo = MODE == 0 ? eps_r : 0.f;
+                const f32x2 p0 = max2(x0, lo), p1 = max2(x1, lo), p2 = max2(x2, lo), p3 = max2(x3, lo);
+                const f32x2 mu = f32x2{mixv[cb][2 * h], mixv[cb][2 * h + 1]} * up;
+                f32x2 w;
+                if (MODE == 0) {
+                    const f32x2 den = ((p0 + p1) + p2) + p3;
+                    w = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])} * mu;
+                } else {
+                    const f32x2 den = (((p0 + p1) + p2) + p3) + eps_r;
+                    w = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])} * mu;
+                }
+                const f32x2 o0 = __builtin_elementwise_fma(down, f32x2{res[cb][0][2 * h], res[cb][0][2 * h + 1]}, p0 * w);
+                const f32x2 o1 = __builtin_elementwise_fma(down, f32x2{res[cb][1][2 * h], res[cb][1][2 * h + 1]}, p1 * w);
+                const f32x2 o2 = __builtin_elementwise_fma(down, f32x2{res[cb][2][2 * h], res[cb][2][2 * h + 1]}, p2 * w);
+                const f32x2 o3 = __builtin_elementwise_fma(down, f32x2{res[cb][3][2 * h], res[cb][3][2 * h + 1]}, p3 * w);
+                res[cb][0][2 * h] = o0[0]; res[cb][0][2 * h + 1] = o0[1];
+                res[cb][1][2 * h] = o1[0]; res[cb][1][2 * h + 1] = o1[1];
+                res[cb][2][2 * h] = o2[0]; res[cb][2][2 * h + 1] = o2[1];
+                res[cb][3][2 * h] = o3[0]; res[cb][3][2 * h + 1] = o3[1];
+            }
+        }
+    }
+#undef DCS_LOAD_A
+#undef DCS_STORE_A
+
+    float* out0 = a.out + clip * a.out_clip_stride + row0 * a.out_ld;
+    if (vec && colw + 16 * CBW <= a.F) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ri = kq * 4 + e;
+            if (ri < rows_here) {
+                float* op = out0 + (ri * (int)a.out_ld + col);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    *reinterpret_cast<f32x2*>(op + c * a.out_src_stride) = f32x2{res[0][c][e], res[1][c][e]};
+            }
+        }
+    } else if (col < a.F) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ri = kq * 4 + e;
+            if (ri < rows_here) {
+                float* op = out0 + (ri * (int)a.out_ld + col);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    op[c * a.out_src_stride] = res[0][c][e];
+                    if (col + 1 < a.F) op[c * a.out_src_stride + 1] = res[1][c][e];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg, int ci) {
+    if (n_items <= 0) return DCS_OK;
+    const int64_t n_rows = n_items * tc;
+    hipLaunchKernelGGL(g_split_kernel, dim3((unsigned)dcs_cdiv(n_rows * 8, kThreads)), dim3(kThreads), 0, ctx->stream, G,
+                       reinterpret_cast<u32x4*>(Gs), n_rows, tc, ngg, ci);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+int dcs_launch_dsd_final_bf16x3(dcs_ctx* ctx, const DsdFinalArgs& a, int n_colg, int64_t n_wg, unsigned n_clips) {
+    if (a.mask_mode == 0)
+        hipLaunchKernelGGL((final_bf16x3_kernel<0>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0, ctx->stream, a, n_colg);
+    else
+        hipLaunchKernelGGL((final_bf16x3_kernel<1>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0, ctx->stream, a, n_colg);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}

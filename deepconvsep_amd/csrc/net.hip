@@ -88,6 +88,9 @@ struct dcs_model {
     DcsGenericNet* gen = nullptr;
     // ---- scratch
     DcsBuffer ws;
+    // opt-in bf16x3 final kernel (DCS_FINAL_BF16X3=1): split weights and the split copy of G
+    uint16_t* Bpk = nullptr;
+    DcsBuffer gs_buf;
     DcsBuffer clip_tab;   // {samples, frames, tiles} per clip of a batch of different lengths (dcs_separate_ragged)
     float* rise_d = nullptr;
     int rise_ov = -1;
@@ -223,6 +226,27 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     DCS_CHECK(upload(&m->Bw2s, Bw2s));
     DCS_CHECK(upload(&m->Bfin, Bfin));
     DCS_CHECK(upload(&m->bout, bout));
+    if (C == 1) {
+        // bf16x3 variant of the final kernel: Bpk[bin][plane 3][K block 2][lane group 4][8 channels], channel
+        // c = 32 kb + 8 g + j; planes by truncation, w = p0 + p1 + p2 exactly
+        std::vector<uint16_t> Bpk((size_t)m->Fpad * 3 * 2 * 4 * 8, 0);
+        for (int f = 0; f < m->Fpad; ++f)
+            for (int c = 0; c < d.nf1 && c < 64; ++c) {
+                const float w = Bfin[(size_t)c * m->Fpad + f];
+                float r = w;
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t bits;
+                    memcpy(&bits, &r, 4);
+                    bits &= 0xffff0000u;
+                    float part;
+                    memcpy(&part, &bits, 4);
+                    r -= part;
+                    const int kb = c >> 5, g = (c & 31) >> 3, j = c & 7;
+                    Bpk[((((size_t)f * 3 + pl) * 2 + kb) * 4 + g) * 8 + j] = (uint16_t)(bits >> 16);
+                }
+            }
+        DCS_CHECK(upload(&m->Bpk, Bpk));
+    }
     return DCS_OK;
 }
 
@@ -392,6 +416,8 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
     m->ws.release();
     m->clip_tab.release();
+    m->gs_buf.release();
+    if (m->Bpk) (void)hipFree(m->Bpk);
     delete m;
     return DCS_OK;
 }
@@ -517,6 +543,15 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         a.mix_clip_stride = Trows * ld;
         a.out_clip_stride = (int64_t)S * T * ld;
         a.clip_tab = clip_tab_d;
+        static const bool bf16x3 = getenv("DCS_FINAL_BF16X3") && atoi(getenv("DCS_FINAL_BF16X3")) != 0;
+        if (bf16x3 && m->Bpk) {   // opt-in: split G once, then the final kernel on the bf16 matrix pipe (dsd_bf16x3.hip)
+            const int64_t items = n_all * m->d.n_fc;
+            DCS_CHECK(m->gs_buf.ensure((size_t)items * tc * kDsdSplitRowU4 * 16));
+            DCS_CHECK(dcs_launch_dsd_gsplit(m->ctx, w.G, m->gs_buf.ptr, items, tc, (m->CI + kDsdGch - 1) / kDsdGch, m->d.nf1));
+            a.Gs = m->gs_buf.ptr;
+            a.Bpk = m->Bpk;
+            a.gs_clip_stride = n * m->d.n_fc * (int64_t)tc * kDsdSplitRowU4;
+        }
         DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
         if (pcm_d)
             DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, T * ld, unit, Trows * ld, ld, T, S, n_clips, scale, pcm_d, L,
@@ -545,7 +580,9 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     if (!m) DCS_FAIL(DCS_EINVAL, "dcs_separate: null model");
     static const bool graphs_on = !(getenv("DCS_GRAPH") && atoi(getenv("DCS_GRAPH")) == 0);
     // graph replay needs a capturable (non-null) stream, no event timing, and an identical repeat call
-    const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD;
+    static const bool bf16x3 = getenv("DCS_FINAL_BF16X3") && atoi(getenv("DCS_FINAL_BF16X3")) != 0;   // its buffer grows on demand
+    const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD &&
+                           !bf16x3;
     dcs_model::StepKey key;
     key.plan = plan; key.audio = audio_d; key.pcm = pcm_d; key.ws = m->ws.ptr; key.L = n_samples; key.ov = overlap;
     key.tiler = tiler; key.eps = eps_mode; key.tie = tie_mode; key.scale = scale;

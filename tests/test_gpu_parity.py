@@ -769,6 +769,25 @@ def test_kernel_variants_selected_by_size_agree_with_the_oracle(env, N, tmp_path
     assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
 
 
+def test_optin_bf16x3_final_kernel_meets_the_parity_bar(tmp_path):
+    """DCS_FINAL_BF16X3=1 (off by default, dsd_bf16x3.hip): the final kernel on the bf16 matrix pipe with both operands
+    split exactly into three bf16 terms and the six products above 2^-24 kept -- fp32-class results, same 1e-4 bar
+    (measured 1e-7 on this clip, 6e-8 from the f32 kernel)."""
+    import subprocess
+    N = 2048
+    audio = synth_audio(3 * 44100, seed=77)
+    audio[40000:52000] = 0.0
+    want = pipeline.separate("dsd", synth_params("dsd", 30, N // 2 + 1, seed=2), audio, 0.3, 30, 25, 32, N, 512,
+                             np.hanning)
+    f = tmp_path / "case.npz"
+    np.savez(f, audio=audio, want=want, N=N)
+    child_env = dict(os.environ)
+    child_env.update({"DCS_FINAL_BF16X3": "1", "DCS_FINAL_CBW": "2"})     # CBW=2: the 128-bin workgroups it is built for
+    r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, ROOT, str(f)], env=child_env, capture_output=True,
+                       text=True, timeout=200)
+    assert r.returncode == 0, (r.stdout[-400:], r.stderr[-800:])
+
+
 # ------------------------------------------------------------------ score-informed path (SURVEY 8a-10, config 5)
 SI_INSTS = ["bassoon_b", "clarinet_b", "saxophone_b", "violin_b"]
 
