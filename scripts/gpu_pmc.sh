@@ -24,7 +24,7 @@ for tag in 'ab':
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         k=r['Kernel_Name']
-        for key in ('final_kernel','deconv2_stream','deconv2','istft_wave','gemm_rows_splitk','gemm_rows_kernel','stft_forward_wave','stft_forward','conv1','colconv'):
+        for key in ('final_bf16x3','g_split','final_kernel','deconv2_stream','deconv2','istft_wave','gemm_rows_splitk','gemm_rows_kernel','stft_forward_wave','stft_forward','conv1','colconv'):
             if key in k: k=key; break
         gs=r.get('Grid_Size','?')
         if int(gs) < int(os.environ.get('MIN_GRID','0')): continue
