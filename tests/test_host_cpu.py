@@ -167,3 +167,37 @@ def test_length_groups_policy():
     assert length_groups([5, 5, 5], max_group=1) == [[0], [1], [2]]
     assert length_groups([]) == []
 
+
+
+def test_bf16_three_way_split_is_exact_and_six_products_are_fp32_class():
+    """The arithmetic behind the opt-in bf16x3 kernel (csrc/dsd_bf16x3.hip), restated in NumPy: truncating a float32 to
+    its top 16 bits three times gives x = hi + mid + lo EXACTLY, and the six kept term pairs reproduce a 50-long dot
+    product to within a few 2^-24 of sum |a b| -- the error class of a float32 accumulation."""
+    rs = np.random.RandomState(5)
+
+    def split(x):
+        parts, r = [], x.astype(np.float32)
+        for _ in range(3):
+            p = (r.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+            parts.append(p)
+            r = (r - p).astype(np.float32)                      # exact: no rounding happens in these subtractions
+        return parts, r
+
+    x = np.concatenate([rs.randn(4000), 1e-3 * rs.randn(2000), 300.0 * rs.randn(2000), [0.0, 1.0, -2.5, 3e-20]]).astype(np.float32)
+    (h, m, l), rest = split(x)
+    assert not rest.any()                                          # nothing left after three 8-bit pieces
+    assert np.array_equal((h.astype(np.float64) + m + l).astype(np.float32), x)
+    for p in (h, m, l):
+        assert not (p.view(np.uint32) & np.uint32(0xffff)).any()   # every piece is a bf16 value
+
+    a = rs.randn(64, 50).astype(np.float32) * 10.0
+    b = (rs.randn(50, 33) * 0.05).astype(np.float32)
+    (a0, a1, a2), _ = split(a)
+    (b0, b1, b2), _ = split(b)
+    f = np.float64
+    kept = (a2.astype(f) @ b0 + a0.astype(f) @ b2 + a1.astype(f) @ b1) + (a1.astype(f) @ b0 + a0.astype(f) @ b1) + a0.astype(f) @ b0
+    exact = a.astype(f) @ b.astype(f)
+    scale = np.abs(a).astype(f) @ np.abs(b).astype(f)
+    assert np.max(np.abs(kept - exact) / scale) < 3.0 * 2.0 ** -24   # the three dropped pairs
+    f32 = (a @ b).astype(f)                                        # a float32 accumulation for comparison
+    assert np.max(np.abs(kept - exact) / scale) < 4.0 * np.max(np.abs(f32 - exact) / scale) + 2.0 ** -24
