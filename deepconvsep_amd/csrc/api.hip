@@ -26,10 +26,11 @@ int DcsBuffer::ensure(size_t need) {
     if (need <= bytes) return DCS_OK;
     if (ptr) {
         // other work on the stream may still read the old block
-        (void)hipDeviceSynchronize();
-        (void)hipFree(ptr);
+        DCS_HIP(hipDeviceSynchronize());
+        void* old = ptr;
         ptr = nullptr;
         bytes = 0;
+        DCS_HIP(hipFree(old));
     }
     size_t want = need + need / 8;
     DCS_HIP(hipMalloc(&ptr, want));
@@ -88,6 +89,7 @@ extern "C" int dcs_timing_reset(dcs_ctx* ctx) {
 
 extern "C" int dcs_timing_query(dcs_ctx* ctx, int which, double* avg_ms, int64_t* launches) {
     if (!ctx || which < 0 || which >= DCS_TAG_COUNT) DCS_FAIL(DCS_EINVAL, "dcs_timing_query: bad argument");
+    DCS_ON_DEVICE(ctx->device);
     DCS_HIP(hipStreamSynchronize(ctx->stream));
     DcsTimingSlot& s = ctx->slots[which];
     double total = 0.0;
@@ -107,7 +109,7 @@ extern "C" int dcs_create(int device, void* hip_stream, dcs_ctx** out) {
     int count = 0;
     DCS_HIP(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) DCS_FAIL(DCS_EINVAL, "dcs_create: device %d of %d", device, count);
-    DCS_HIP(hipSetDevice(device));
+    DCS_ON_DEVICE(device);   // the caller's current device is restored on return
     hipDeviceProp_t prop;
     DCS_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -123,17 +125,20 @@ extern "C" int dcs_create(int device, void* hip_stream, dcs_ctx** out) {
 
 extern "C" int dcs_destroy(dcs_ctx* ctx) {
     if (!ctx) return DCS_OK;
+    DCS_ON_DEVICE(ctx->device);
     for (auto& s : ctx->slots) {
         for (auto e : s.start) (void)hipEventDestroy(e);
         for (auto e : s.stop) (void)hipEventDestroy(e);
     }
     ctx->gemm_ws.release();
+    if (ctx->ola_rise_d) (void)hipFree(ctx->ola_rise_d);
     delete ctx;
     return DCS_OK;
 }
 
 extern "C" int dcs_synchronize(dcs_ctx* ctx) {
     if (!ctx) DCS_FAIL(DCS_EINVAL, "dcs_synchronize: null ctx");
+    DCS_ON_DEVICE(ctx->device);
     DCS_HIP(hipStreamSynchronize(ctx->stream));
     return DCS_OK;
 }
@@ -166,7 +171,7 @@ extern "C" int dcs_stft_plan(dcs_ctx* ctx, int frame, int hop, const double* win
     if (frame < 16 || frame > 8192 || (frame & (frame - 1)))
         DCS_FAIL(DCS_EUNSUPPORTED, "dcs_stft_plan: frameSize %d is not a power of two in [16, 8192]", frame);
     if (hop <= 0 || hop > frame) DCS_FAIL(DCS_EINVAL, "dcs_stft_plan: hopSize %d not in (0, %d]", hop, frame);
-    DCS_HIP(hipSetDevice(ctx->device));
+    DCS_ON_DEVICE(ctx->device);
     dcs_stft* p = new dcs_stft();
     p->ctx = ctx;
     p->frame = frame;
@@ -219,6 +224,7 @@ extern "C" int dcs_stft_plan(dcs_ctx* ctx, int frame, int hop, const double* win
 
 extern "C" int dcs_stft_plan_destroy(dcs_stft* p) {
     if (!p) return DCS_OK;
+    DCS_ON_DEVICE(p->ctx->device);
     (void)hipFree(p->win_f);
     (void)hipFree(p->win_d);
     (void)hipFree(p->wsq_f);
@@ -234,6 +240,7 @@ static int forward_checked(dcs_stft* p, const R* audio, int64_t L, R* mag, R* ph
                            int (*launch)(dcs_stft*, const R*, int64_t, R*, R*, R2*, int64_t, int64_t, int64_t)) {
     if (!p || !mag || (!audio && L > 0)) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: null argument");
     if (L < 0) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: negative length");
+    DCS_ON_DEVICE(p->ctx->device);
     const int64_t T = dcs_frame_count(L, p->hop);
     if (ld < p->frame / 2 + 1) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: ld %lld < bins %d", (long long)ld, p->frame / 2 + 1);
     if (rows_out < T) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: rows_out %lld < frames %lld", (long long)rows_out, (long long)T);
@@ -256,6 +263,7 @@ static int inverse_checked(dcs_stft* p, const R* mag, int64_t src_stride, const 
                                          int64_t)) {
     if (!p || !mag || !phase || !audio) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: null argument");
     if (T <= 0 || n_src <= 0) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: empty input");
+    DCS_ON_DEVICE(p->ctx->device);
     if (ld < p->frame / 2 + 1) DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: ld < bins");
     if (n_out < 0 || n_out > dcs_inverse_length(T, p->hop, p->frame))
         DCS_FAIL(DCS_EINVAL, "dcs_stft_inverse: n_out %lld exceeds %lld", (long long)n_out,
@@ -288,23 +296,29 @@ extern "C" int dcs_tile(dcs_ctx* ctx, const float* mag_d, int64_t ch_stride, int
         DCS_FAIL(DCS_EINVAL, "dcs_tile: n_tiles %lld != %lld", (long long)n_tiles,
                  (long long)dcs_tile_count(T, tc, ov, tiler));
     if (n_tiles == 0) return DCS_OK;
+    DCS_ON_DEVICE(ctx->device);
     return dcs_launch_tile(ctx, mag_d, ch_stride, ld, C, T, F, tc, ov, tiler, scale, tiles_d, n_tiles);
 }
 
 extern "C" int dcs_overlap_add(dcs_ctx* ctx, const float* out_d, int64_t n, int S, int tc, int ov, int F,
                                const double* rise_h, float* sep_d, int64_t sep_stride, int64_t ld) {
-    if (!ctx || !out_d || !rise_h || !sep_d) DCS_FAIL(DCS_EINVAL, "dcs_overlap_add: null argument");
-    if (n < 0 || S < 1 || tc < 1 || ov < 1 || ov >= tc || F < 1 || ld < F)
+    if (!ctx || !out_d || !sep_d || (!rise_h && ov > 0)) DCS_FAIL(DCS_EINVAL, "dcs_overlap_add: null argument");
+    // overlap == 0 is legal in the reference (util.py:306-325 with an empty ramp): the tiles are laid end to end
+    if (n < 0 || S < 1 || tc < 1 || ov < 0 || ov >= tc || F < 1 || ld < F)
         DCS_FAIL(DCS_EINVAL, "dcs_overlap_add: bad shape");
     if (ov > 256) DCS_FAIL(DCS_EUNSUPPORTED, "dcs_overlap_add: overlap > 256");
+    DCS_ON_DEVICE(ctx->device);
     std::vector<float> rise(ov);
     for (int i = 0; i < ov; ++i) rise[i] = (float)rise_h[i];
-    float* rise_d = nullptr;
-    DCS_HIP(hipMalloc((void**)&rise_d, ov * sizeof(float)));
-    DCS_HIP(hipMemcpyAsync(rise_d, rise.data(), ov * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    DCS_HIP(hipStreamSynchronize(ctx->stream));  // rise[] is a stack-lifetime host buffer
-    int rc = dcs_launch_overlap_add(ctx, out_d, n, S, tc, ov, F, rise_d, sep_d, sep_stride, ld);
-    DCS_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(rise_d);
-    return rc;
+    if (ov > 0 && (rise != ctx->ola_rise_h || !ctx->ola_rise_d)) {
+        // a new ramp: earlier launches on the stream may still read the old table
+        DCS_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->ola_rise_d) (void)hipFree(ctx->ola_rise_d);
+        ctx->ola_rise_d = nullptr;
+        ctx->ola_rise_h.clear();
+        DCS_HIP(hipMalloc((void**)&ctx->ola_rise_d, ov * sizeof(float)));
+        DCS_HIP(hipMemcpy(ctx->ola_rise_d, rise.data(), ov * sizeof(float), hipMemcpyHostToDevice));
+        ctx->ola_rise_h = rise;
+    }
+    return dcs_launch_overlap_add(ctx, out_d, n, S, tc, ov, F, ctx->ola_rise_d, sep_d, sep_stride, ld);
 }

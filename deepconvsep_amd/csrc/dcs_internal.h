@@ -33,6 +33,30 @@ void dcs_set_error(const char* fmt, ...);
         if (rc__ != DCS_OK) return rc__; \
     } while (0)
 
+// Every public entry point runs on its context's device and leaves the calling thread's current device as it
+// found it (a process may hold contexts on several GPUs; dcs_create itself must not switch the caller).
+struct DcsDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DcsDeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DcsDeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DcsDeviceGuard(const DcsDeviceGuard&) = delete;
+    DcsDeviceGuard& operator=(const DcsDeviceGuard&) = delete;
+};
+#define DCS_ON_DEVICE(dev_)                                                                         \
+    DcsDeviceGuard dcs_guard__(dev_);                                                               \
+    if (dcs_guard__.err != hipSuccess)                                                              \
+        DCS_FAIL(DCS_EHIP, "cannot select device %d: %s", (int)(dev_), hipGetErrorString(dcs_guard__.err))
+
 // A grow-only device scratch buffer.  Regions handed out keep their address until the
 // buffer has to grow (then `generation` changes and zero-initialised regions are re-zeroed).
 struct DcsBuffer {
@@ -56,6 +80,10 @@ struct dcs_ctx {
     DcsTimingSlot slots[DCS_TAG_COUNT];
     int n_cu = 256;
     DcsBuffer gemm_ws;         // partial sums of the K-split GEMM (grown on demand, never inside a graph capture)
+    // cross-fade ramp of dcs_overlap_add, uploaded when its values change (one table per context; the fused paths keep
+    // their own per model)
+    float* ola_rise_d = nullptr;
+    std::vector<float> ola_rise_h;
 };
 
 // RAII-ish helper: records a start event on construction and a stop event in done().

@@ -105,9 +105,20 @@ struct dcs_model {
                    audio_stride == o.audio_stride;
         }
     };
-    StepKey seen, captured;
-    hipGraphExec_t step_exec = nullptr;
-    int64_t step_tiles = 0, step_frames = 0;
+    // A small LRU: a server alternates between a few call shapes (full launch groups and a remainder group, two clip
+    // lengths); each keeps its own captured graph.  `seen` holds the keys that arrived once and are captured on their
+    // second arrival.
+    struct StepGraph {
+        StepKey key;
+        hipGraphExec_t exec = nullptr;
+        int64_t tiles = 0, frames = 0;
+        uint64_t stamp = 0;
+    };
+    static constexpr int kStepGraphs = 4;
+    StepGraph graphs[kStepGraphs];
+    StepKey seen[kStepGraphs];
+    uint64_t seen_stamp[kStepGraphs] = {0, 0, 0, 0};
+    uint64_t step_clock = 0;
 };
 
 namespace {
@@ -368,7 +379,7 @@ extern "C" int dcs_model_create(dcs_ctx* ctx, int arch, int C, int tc, int F, co
     if (nparams != (int)expect.size())
         DCS_FAIL(DCS_ESHAPE, "mismatch: got %d values to set %d parameters", nparams, (int)expect.size());
     std::vector<std::vector<float>> P(nparams);
-    DCS_HIP(hipSetDevice(ctx->device));
+    DCS_ON_DEVICE(ctx->device);
     for (int i = 0; i < nparams; ++i) {
         int64_t cnt = 1;
         for (int k = 0; k < 4; ++k) {
@@ -408,12 +419,14 @@ extern "C" int dcs_model_create(dcs_ctx* ctx, int arch, int C, int tc, int F, co
 
 extern "C" int dcs_model_destroy(dcs_model* m) {
     if (!m) return DCS_OK;
+    DCS_ON_DEVICE(m->ctx->device);
     float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bw2s, m->Bfin, m->bout,
                      m->rise_d};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     if (m->gen) dcs_generic_destroy(m->gen);
-    if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
+    for (auto& g : m->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->ws.release();
     m->clip_tab.release();
     m->gs_buf.release();
@@ -438,7 +451,7 @@ static int forward_any(dcs_model* m, const float* tiles_d, int64_t n, int mask_m
     if (n < 0) DCS_FAIL(DCS_EINVAL, "dcs_model_forward: negative tile count");
     if (tie_mode != DCS_TIE_ALL && tie_mode != DCS_TIE_FIRST) DCS_FAIL(DCS_EINVAL, "bad tie_mode");
     if (n == 0) return DCS_OK;
-    DCS_HIP(hipSetDevice(m->ctx->device));
+    DCS_ON_DEVICE(m->ctx->device);
     if (m->arch == DCS_ARCH_DSD) return dsd_forward_tiles(m, tiles_d, n, mask_mode, out_d);
     if (m->arch == DCS_ARCH_DSD_ILD)
         DCS_FAIL(DCS_EUNSUPPORTED, "the stereo (ILD) graph runs through dcs_separate_stereo (frames shared between tiles)");
@@ -473,7 +486,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
     if (n_clips < 1 || n_clips > 65535) DCS_FAIL(DCS_EINVAL, "dcs_separate_batch: %lld clips", (long long)n_clips);
     if (n_clips > 1 && (m->arch != DCS_ARCH_DSD || sep_out || mag_out || phase_out || audio_stride < L))
         DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_batch: DSD graph, PCM output and clip stride >= length only");
-    DCS_HIP(hipSetDevice(m->ctx->device));
+    DCS_ON_DEVICE(m->ctx->device);
     const int tc = m->tc, F = m->F, st = tc - ov, S = m->d.S;
     int64_t T = dcs_frame_count(L, plan->hop);
     int64_t n = dcs_tile_count(T, tc, ov, tiler);
@@ -578,64 +591,91 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
                             float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out) {
     if (!pcm_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: pcm_d is null");
     if (!m) DCS_FAIL(DCS_EINVAL, "dcs_separate: null model");
+    DCS_ON_DEVICE(m->ctx->device);
     static const bool graphs_on = !(getenv("DCS_GRAPH") && atoi(getenv("DCS_GRAPH")) == 0);
     // graph replay needs a capturable (non-null) stream, no event timing, and an identical repeat call
     static const bool bf16x3 = getenv("DCS_FINAL_BF16X3") && atoi(getenv("DCS_FINAL_BF16X3")) != 0;   // its buffer grows on demand
     const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD &&
                            !bf16x3;
+    auto eager = [&]() {
+        return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr, nullptr,
+                             nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);
+    };
+    if (!can_graph) return eager();
     dcs_model::StepKey key;
     key.plan = plan; key.audio = audio_d; key.pcm = pcm_d; key.ws = m->ws.ptr; key.L = n_samples; key.ov = overlap;
     key.tiler = tiler; key.eps = eps_mode; key.tie = tie_mode; key.scale = scale;
     key.n_clips = n_clips; key.audio_stride = audio_stride;
-    if (can_graph && m->step_exec && m->captured == key) {
-        DCS_HIP(hipGraphLaunch(m->step_exec, m->ctx->stream));
-        if (n_tiles_out) *n_tiles_out = m->step_tiles;
-        if (n_frames_out) *n_frames_out = m->step_frames;
-        return DCS_OK;
-    }
-    if (can_graph && m->seen == key) {
-        // second identical call: every buffer is allocated and sized, nothing in the path synchronises
-        hipGraph_t graph = nullptr;
-        int64_t nt = 0, nf = 0;
-        DCS_HIP(hipStreamBeginCapture(m->ctx->stream, hipStreamCaptureModeRelaxed));
-        const int rc = separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
-                                     nullptr, nullptr, 0, &nt, &nf, n_clips, audio_stride);
-        const hipError_t ce = hipStreamEndCapture(m->ctx->stream, &graph);
-        if (rc != DCS_OK || ce != hipSuccess || !graph || m->ws.ptr != key.ws) {
-            if (graph) (void)hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            m->seen = dcs_model::StepKey();
-            if (rc != DCS_OK) return rc;
-            // capture failed: run this call eagerly and stop trying for this key
-            return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
-                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);
+    const uint64_t now = ++m->step_clock;
+    // graphs recorded against a workspace that has since been re-allocated point at freed memory: drop them
+    for (auto& g : m->graphs)
+        if (g.exec && g.key.ws != m->ws.ptr) {
+            (void)hipGraphExecDestroy(g.exec);
+            g = dcs_model::StepGraph();
         }
-        if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
-        m->step_exec = nullptr;
-        const hipError_t ie = hipGraphInstantiate(&m->step_exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) {
-            m->step_exec = nullptr;
-            m->seen = dcs_model::StepKey();
-            (void)hipGetLastError();
-            return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
-                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);
+    for (auto& g : m->graphs)
+        if (g.exec && g.key == key) {
+            g.stamp = now;
+            DCS_HIP(hipGraphLaunch(g.exec, m->ctx->stream));
+            if (n_tiles_out) *n_tiles_out = g.tiles;
+            if (n_frames_out) *n_frames_out = g.frames;
+            return DCS_OK;
         }
-        m->captured = key;
-        m->step_tiles = nt;
-        m->step_frames = nf;
-        DCS_HIP(hipGraphLaunch(m->step_exec, m->ctx->stream));
-        if (n_tiles_out) *n_tiles_out = nt;
-        if (n_frames_out) *n_frames_out = nf;
-        return DCS_OK;
+    int seen_at = -1, seen_lru = 0;
+    for (int i = 0; i < dcs_model::kStepGraphs; ++i) {
+        if (m->seen_stamp[i] && m->seen[i] == key) seen_at = i;
+        if (m->seen_stamp[i] < m->seen_stamp[seen_lru]) seen_lru = i;
     }
+    if (seen_at < 0) {
+        // first arrival of this call shape: run it eagerly (it sizes every buffer) and remember it
+        const int rc = eager();
+        if (rc == DCS_OK) {
+            key.ws = m->ws.ptr;  // the call may have grown the workspace
+            m->seen[seen_lru] = key;
+            m->seen_stamp[seen_lru] = now;
+        }
+        return rc;
+    }
+    // second identical call: every buffer is allocated and sized, nothing in the path synchronises
+    m->seen_stamp[seen_at] = 0;
+    hipGraph_t graph = nullptr;
+    int64_t nt = 0, nf = 0;
+    DCS_HIP(hipStreamBeginCapture(m->ctx->stream, hipStreamCaptureModeRelaxed));
     const int rc = separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
-                                 nullptr, nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);
-    if (rc == DCS_OK) {
-        key.ws = m->ws.ptr;  // the first call may have grown the workspace
-        m->seen = key;
+                                 nullptr, nullptr, 0, &nt, &nf, n_clips, audio_stride);
+    const hipError_t ce = hipStreamEndCapture(m->ctx->stream, &graph);
+    if (rc != DCS_OK || ce != hipSuccess || !graph || m->ws.ptr != key.ws) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (rc != DCS_OK) return rc;
+        return eager();   // capture failed: run this call eagerly
     }
-    return rc;
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        return eager();
+    }
+    int slot = 0;
+    for (int i = 0; i < dcs_model::kStepGraphs; ++i) {
+        if (!m->graphs[i].exec) { slot = i; break; }
+        if (m->graphs[i].stamp < m->graphs[slot].stamp) slot = i;
+    }
+    if (m->graphs[slot].exec) {
+        // the evicted graph may still be executing on the stream
+        DCS_HIP(hipStreamSynchronize(m->ctx->stream));
+        (void)hipGraphExecDestroy(m->graphs[slot].exec);
+    }
+    m->graphs[slot].key = key;
+    m->graphs[slot].exec = exec;
+    m->graphs[slot].tiles = nt;
+    m->graphs[slot].frames = nf;
+    m->graphs[slot].stamp = now;
+    DCS_HIP(hipGraphLaunch(exec, m->ctx->stream));
+    if (n_tiles_out) *n_tiles_out = nt;
+    if (n_frames_out) *n_frames_out = nf;
+    return DCS_OK;
 }
 
 extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
@@ -695,7 +735,7 @@ extern "C" int dcs_separate_stereo(dcs_model* m, dcs_stft* plan, const float* au
     if (scale == 0.f || L < 1 || channel_stride < L) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: bad scale / length / stride");
     if (!pcm_d && !sep_d) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: nothing to write");
     if (sep_d && ld_out < m->F) DCS_FAIL(DCS_EINVAL, "dcs_separate_stereo: ld_out < bins");
-    DCS_HIP(hipSetDevice(m->ctx->device));
+    DCS_ON_DEVICE(m->ctx->device);
     const int tc = m->tc, F = m->F, st = tc - ov, S = m->d.S, C = m->C;
     const int64_t T = dcs_frame_count(L, plan->hop);
     const int64_t n = dcs_tile_count(T, tc, ov, tiler);

@@ -55,7 +55,7 @@ extern "C" int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int
     if (ninst < 1 || ninst > 65535 || n_notes < 0 || width < 5 || ((width - 3) & 1) || F < 1 || ld < F || n_frames < 0)
         DCS_FAIL(DCS_EINVAL, "dcs_score_masks: bad shape (ninst %d, notes %d, width %d, F %d)", ninst, n_notes, width, F);
     if (n_frames == 0) return DCS_OK;
-    DCS_HIP(hipSetDevice(ctx->device));
+    DCS_ON_DEVICE(ctx->device);
     // the reference's Python slicing: filtered[j, begin:end, range(start_f, stop_f)] with begin/end relative to
     // `start`; slices clip to the array, the fancy bin index would raise past F -- reported here as DCS_ESHAPE
     std::vector<ScoreRect> rects;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void pcm_int16_kernel(const float* __rest
 extern "C" int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d) {
     if (!ctx || !pcm_d || !out_d || n < 0) DCS_FAIL(DCS_EINVAL, "dcs_pcm_to_int16: bad argument");
     if (n == 0) return DCS_OK;
-    DCS_HIP(hipSetDevice(ctx->device));
+    DCS_ON_DEVICE(ctx->device);
     hipLaunchKernelGGL(pcm_int16_kernel, dim3((unsigned)dcs_cdiv(n, (int64_t)kThreads * 4)), dim3(kThreads), 0, ctx->stream,
                        pcm_d, n, out_d);
     DCS_HIP(hipGetLastError());

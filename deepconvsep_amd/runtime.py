@@ -26,33 +26,64 @@ def require_gpu():
     return torch
 
 
-class Context(object):
-    """One device + one HIP stream (``dcs_ctx``)."""
+def _on_ctx_stream(method):
+    """Run a method of an object with a ``.ctx`` inside ``torch.cuda.stream(ctx.torch_stream)``: the tensors it
+    allocates belong to that stream in torch's caching allocator and the copies it issues are ordered with the
+    kernels libdcs enqueues there, whatever stream is current in the caller."""
+    import functools
 
-    def __init__(self, device=None):
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with self.ctx.stream_scope():
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
+class Context(object):
+    """One device + one HIP stream (``dcs_ctx``).
+
+    The stream is the one current on ``device`` when the context is made (or ``stream=``); it is kept as a
+    ``torch.cuda.Stream`` so that every host<->device copy, allocation and ``.cpu()`` the package issues runs on the
+    stream the kernels run on (:meth:`stream_scope`).  A caller that produces inputs or consumes outputs on another
+    stream synchronises with :attr:`torch_stream` as with any torch stream."""
+
+    def __init__(self, device=None, stream=None):
         torch = require_gpu()
         lib = _lib.load()
         if device is None:
-            device = torch.cuda.current_device()
+            device = stream.device.index if stream is not None else torch.cuda.current_device()
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
-        with torch.cuda.device(self.device_index):
-            stream = torch.cuda.current_stream().cuda_stream
+        self.torch_stream = stream if stream is not None else torch.cuda.current_stream(self.device_index)
+        if self.torch_stream.device.index != self.device_index:
+            raise ValueError("stream belongs to device %d, context to device %d"
+                             % (self.torch_stream.device.index, self.device_index))
         h = c_void_p()
-        _lib.check(lib.dcs_create(self.device_index, c_void_p(stream), byref(h)))
+        _lib.check(lib.dcs_create(self.device_index, c_void_p(self.torch_stream.cuda_stream), byref(h)))
         self._h = h
         self._lib = lib
+
+    def stream_scope(self):
+        """``with ctx.stream_scope():`` makes the context's stream torch's current stream."""
+        return _torch().cuda.stream(self.torch_stream)
 
     # -- memory plumbing ------------------------------------------------------------------
     def to_device(self, array, dtype):
         torch = _torch()
         a = np.ascontiguousarray(array, dtype=dtype)
-        return torch.from_numpy(a).to(self.device)
+        with self.stream_scope():
+            return torch.from_numpy(a).to(self.device)
+
+    def to_host(self, tensor):
+        """Device tensor -> ndarray, ordered after everything enqueued on the context's stream."""
+        with self.stream_scope():
+            return tensor.cpu().numpy()
 
     def empty(self, shape, dtype):
         torch = _torch()
         tdt = {np.float32: torch.float32, np.float64: torch.float64}[dtype]
-        return torch.empty(tuple(int(s) for s in shape), dtype=tdt, device=self.device)
+        with self.stream_scope():
+            return torch.empty(tuple(int(s) for s in shape), dtype=tdt, device=self.device)
 
     def synchronize(self):
         _lib.check(self._lib.dcs_synchronize(self._h))
@@ -123,6 +154,7 @@ class StftPlan(object):
         _lib.check(ctx._lib.dcs_stft_plan(ctx._h, self.frame, self.hop, w.ctypes.data_as(POINTER(c_double)), byref(h)))
         self._h = h
 
+    @_on_ctx_stream
     def forward(self, audio_t, phase=True, rows_out=None, ld=None):
         """audio_t: 1-D float32/float64 device tensor.  Returns (mag, phase|None) device tensors
         ``[rows_out, ld]`` (defaults: the reference's dense ``[T, bins]``)."""
@@ -138,6 +170,7 @@ class StftPlan(object):
         _lib.check(fn(self._h, _ptr(audio_t), L, _ptr(mag), _ptr(ph), ld, rows))
         return mag, ph
 
+    @_on_ctx_stream
     def inverse(self, mag_t, phase_t, n_out=None, pre_div=1.0):
         """mag_t ``[S, T, ld]`` or ``[T, ld]``, phase_t ``[T, ld]`` (same ld).  Returns ``[S, n_out]``
         (or ``[n_out]``)."""
@@ -210,6 +243,7 @@ class Network(object):
             raise ValueError("conv precision must be 'f16' or 'f32'")
         _lib.check(self.ctx._lib.dcs_model_set_conv_precision(self._h, 1 if dtype == 'f16' else 0))
 
+    @_on_ctx_stream
     def forward_masked(self, tiles_t, eps_mode=None, tie_mode=TIE_ALL):
         """tiles_t ``[n, C, tc, F]`` float32 device tensor -> ``[S, n, tc, F]``."""
         torch = _torch()
@@ -223,6 +257,7 @@ class Network(object):
         _lib.check(self.ctx._lib.dcs_model_forward_masked(self._h, _ptr(tiles_t), n, int(eps), int(tie_mode), _ptr(out)))
         return out
 
+    @_on_ctx_stream
     def forward_raw(self, tiles_t, tie_mode=TIE_ALL):
         """Network output before masking, ``[n, out_channels, tc, F]`` (testing aid).  For the DSD
         graph the kernel emits channel-major ``[out_channels, n, tc, F]``; it is permuted here."""
@@ -233,6 +268,7 @@ class Network(object):
         _lib.check(self.ctx._lib.dcs_model_forward(self._h, _ptr(tiles_t), n, int(tie_mode), _ptr(out)))
         return out.permute(1, 0, 2, 3).contiguous()
 
+    @_on_ctx_stream
     def separate(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None, tie_mode=TIE_ALL,
                  out=None):
         """Fused file-level path: 1-D float32 device tensor -> ``[S, L]`` float32 PCM."""
@@ -247,6 +283,7 @@ class Network(object):
         self.last_tiles, self.last_frames = nt.value, nf.value
         return out
 
+    @_on_ctx_stream
     def separate_batch(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None, tie_mode=TIE_ALL,
                        out=None):
         """Fused path for equal-length clips sharing one set of launches: ``[B, L]`` float32 device tensor
@@ -266,6 +303,7 @@ class Network(object):
         self.last_tiles, self.last_frames = nt.value, nf.value
         return out
 
+    @_on_ctx_stream
     def separate_ragged(self, plan, audio_t, lengths, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None,
                         tie_mode=TIE_ALL, out=None):
         """Clips of different lengths sharing one set of launches: ``audio_t [B, Lmax]`` float32 device tensor (row c
@@ -289,6 +327,7 @@ class Network(object):
         self.last_tiles, self.last_frames = list(nt), list(nf)
         return out
 
+    @_on_ctx_stream
     def separate_stereo(self, plan, audio_t, overlap, tiler=TILER_LIBRARY, scale=0.3, want_spectra=False):
         """Stereo (ILD) graph: ``[2, L]`` float32 device tensor (rows contiguous) -> PCM ``[2, S, L]`` (and, with
         ``want_spectra``, the cross-faded scaled magnitudes ``[2, S, T, F]``)."""
@@ -306,6 +345,7 @@ class Network(object):
         self.last_tiles, self.last_frames = nt.value, nf.value
         return (out, sep) if want_spectra else out
 
+    @_on_ctx_stream
     def separate_spectra(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None,
                          tie_mode=TIE_ALL):
         """Fused path stopped before the iSTFT: (sep ``[S,T,F]``, mag ``[T,F]``, phase ``[T,F]``)."""
@@ -340,13 +380,15 @@ def tile(ctx, mag_t, time_context, overlap, tiler, scale=1.0):
     torch = _torch()
     if mag_t.dim() == 2:
         mag_t = mag_t.unsqueeze(0)
-    mag_t = mag_t.contiguous()
+    with ctx.stream_scope():
+        mag_t = mag_t.contiguous()
     C, T, F = (int(x) for x in mag_t.shape)
     n = _lib.tile_count(T, time_context, overlap, tiler)
-    tiles = torch.empty((n, C, time_context, F), dtype=torch.float32, device=mag_t.device)
-    if n:
-        _lib.check(ctx._lib.dcs_tile(ctx._h, _ptr(mag_t), T * F, F, C, T, F, int(time_context), int(overlap),
-                                     int(tiler), float(scale), _ptr(tiles), n))
+    with ctx.stream_scope():
+        tiles = torch.empty((n, C, time_context, F), dtype=torch.float32, device=mag_t.device)
+        if n:
+            _lib.check(ctx._lib.dcs_tile(ctx._h, _ptr(mag_t), T * F, F, C, T, F, int(time_context), int(overlap),
+                                         int(tiler), float(scale), _ptr(tiles), n))
     return tiles, n
 
 
@@ -354,21 +396,23 @@ def pcm_to_int16(ctx, pcm_t, out=None):
     """``(audio_out * 32767).astype('int16')`` on the device (separate_dsd.py:307-309): float32 tensor of any shape
     (contiguous) -> int16 tensor of the same shape."""
     torch = _torch()
-    pcm_t = pcm_t.contiguous()
-    if out is None:
-        out = torch.empty(pcm_t.shape, dtype=torch.int16, device=pcm_t.device)
-    _lib.check(ctx._lib.dcs_pcm_to_int16(ctx._h, _ptr(pcm_t), int(pcm_t.numel()), _ptr(out)))
+    with ctx.stream_scope():
+        pcm_t = pcm_t.contiguous()
+        if out is None:
+            out = torch.empty(pcm_t.shape, dtype=torch.int16, device=pcm_t.device)
+        _lib.check(ctx._lib.dcs_pcm_to_int16(ctx._h, _ptr(pcm_t), int(pcm_t.numel()), _ptr(out)))
     return out
 
 
 def overlap_add(ctx, out_t, overlap):
     """``overlapadd_multi`` on the device: out_t ``[S, n, tc, F]`` float32 -> ``[S, n*(tc-ov)+tc, F]``."""
     torch = _torch()
-    out_t = out_t.contiguous()
     S, n, tc, F = (int(x) for x in out_t.shape)
     rows = n * (tc - overlap) + tc
-    sep = torch.empty((S, rows, F), dtype=torch.float32, device=out_t.device)
     rise = np.ascontiguousarray(np.linspace(0., 1.0, num=overlap), dtype=np.float64)
-    _lib.check(ctx._lib.dcs_overlap_add(ctx._h, _ptr(out_t), n, S, tc, int(overlap), F,
-                                        rise.ctypes.data_as(POINTER(c_double)), _ptr(sep), rows * F, F))
+    with ctx.stream_scope():
+        out_t = out_t.contiguous()
+        sep = torch.empty((S, rows, F), dtype=torch.float32, device=out_t.device)
+        _lib.check(ctx._lib.dcs_overlap_add(ctx._h, _ptr(out_t), n, S, tc, int(overlap), F,
+                                            rise.ctypes.data_as(POINTER(c_double)), _ptr(sep), rows * F, F))
     return sep

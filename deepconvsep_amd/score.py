@@ -197,12 +197,13 @@ def score_masks(ctx, mag_t, notes, start, stop, want_input=True, want_mask=False
         raise ValueError("notes must be [instruments, notes, 2*nharmonics+3]")
     ninst, P, W = notes.shape
     T, F = int(mag_t.shape[0]), int(mag_t.shape[1])
-    inp = torch.empty((ninst, T, F), dtype=torch.float32, device=mag_t.device) if want_input else None
-    mask = torch.empty((T, ninst * F), dtype=torch.float32, device=mag_t.device) if want_mask else None
-    _lib.check(ctx._lib.dcs_score_masks(ctx._h, _ptr(mag_t), int(mag_t.stride(0)), T, F,
-                                        notes.ctypes.data_as(POINTER(c_double)), ninst, P, W, int(start), int(stop),
-                                        _ptr(inp) if inp is not None else None,
-                                        _ptr(mask) if mask is not None else None))
+    with ctx.stream_scope():
+        inp = torch.empty((ninst, T, F), dtype=torch.float32, device=mag_t.device) if want_input else None
+        mask = torch.empty((T, ninst * F), dtype=torch.float32, device=mag_t.device) if want_mask else None
+        _lib.check(ctx._lib.dcs_score_masks(ctx._h, _ptr(mag_t), int(mag_t.stride(0)), T, F,
+                                            notes.ctypes.data_as(POINTER(c_double)), ninst, P, W, int(start), int(stop),
+                                            _ptr(inp) if inp is not None else None,
+                                            _ptr(mask) if mask is not None else None))
     return inp, mask
 
 
@@ -214,4 +215,4 @@ def filterSpec(mag, notes, ninst, start, stop, timbre_model_path=None, ctx=None)
     ctx = ctx if ctx is not None else default_context()
     mag_t = ctx.to_device(np.asarray(mag), np.float32)
     _, mask = score_masks(ctx, mag_t, np.asarray(notes)[:ninst], start, stop, want_input=False, want_mask=True)
-    return mask.cpu().numpy()
+    return ctx.to_host(mask)

@@ -20,7 +20,7 @@ import scipy.io.wavfile
 
 from . import _lib
 from .arch import ARCHS, TIE_ALL, TILER_LIBRARY, TILER_SCRIPT
-from .runtime import Network, StftPlan, default_context, overlap_add, tile
+from .runtime import Network, StftPlan, _on_ctx_stream, default_context, overlap_add, tile
 
 
 def blackmanharris(n):
@@ -71,7 +71,7 @@ def generate_overlapadd(allmix, input_size=513, time_context=30, overlap=10, bat
     nb = int(np.ceil(float(n) / batch_size))
     fbatch = np.zeros([nb, batch_size, C, time_context, input_size])
     if n:
-        fbatch.reshape(nb * batch_size, C, time_context, input_size)[:n] = tiles.cpu().numpy()
+        fbatch.reshape(nb * batch_size, C, time_context, input_size)[:n] = ctx.to_host(tiles)
     return fbatch, n
 
 
@@ -90,7 +90,7 @@ def overlapadd_multi(fbatch, obatch, nchunks, overlap=10, device=None):
     ctx = default_context(device)
     tiles = _tiles_from_batches(fbatch, nchunks)
     sep = overlap_add(ctx, ctx.to_device(tiles, np.float32), overlap)
-    return sep.cpu().numpy().astype(np.float64)
+    return ctx.to_host(sep).astype(np.float64)
 
 
 def overlapadd(fbatch, obatch, nchunks, overlap=10, device=None):
@@ -115,7 +115,7 @@ class PredictFunction(object):
     def __call__(self, batch):
         batch = np.asarray(batch)
         out = self.net.forward_masked(self.ctx.to_device(batch, np.float32), self.eps_mode, self.tie_mode)
-        out = out.cpu().numpy().astype(np.float64)
+        out = self.ctx.to_host(out).astype(np.float64)
         return [out[s][:, None] for s in range(out.shape[0])]
 
 
@@ -183,27 +183,47 @@ class Separator(object):
         self.plan = StftPlan(self.ctx, frameSize, hopSize, self.window)
         self.net = Network(self.ctx, arch, params, time_context, input_size)
 
+    @_on_ctx_stream
     def separate(self, audio):
         """Fused device path: float audio ``[L]`` -> float64 ``[S, L]``."""
         a = self.ctx.to_device(np.asarray(audio), np.float32)
         pcm = self.net.separate(self.plan, a, self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)
-        return pcm.cpu().numpy().astype(np.float64)
+        return self.ctx.to_host(pcm).astype(np.float64)
 
-    def separate_many(self, audios, max_group=16, max_ratio=1.5):
+    def separate_many(self, audios, max_group=16, max_ratio=1.5, on_error='raise'):
         """A list of clips -> a list of float64 ``[S, L_i]``.  Clips share sets of kernel launches (DSD / hiphop graph):
         sorted by length, they are cut into groups of at most ``max_group`` clips whose longest is at most
         ``max_ratio`` times the shortest (a group costs what its longest clip costs, times its size); a group goes
         through ``dcs_separate_ragged`` (``dcs_separate_batch`` when its lengths are equal).  Every clip gets exactly
         the frames, the tiles and the cross-fade :meth:`separate` gives it alone.  Other graphs, frame sizes the
-        wave STFT kernels do not cover, and groups of one go through :meth:`separate`."""
-        audios = [np.asarray(a).reshape(-1) for a in audios]
+        wave STFT kernels do not cover, and groups of one go through :meth:`separate`.  Clips that cannot be separated
+        (empty, or too short for one tile) never join a shared launch; ``on_error='return'`` puts the exception the
+        single-clip path raises for them into their slot of the result instead of raising it."""
+        audios = [np.asarray(a) for a in audios]
+        for a in audios:
+            if a.ndim != 1:
+                # reshape(-1) would interleave the channels of a [L, 2] array; mix down first (to_mono)
+                raise ValueError("separate_many takes mono clips ([L] arrays), got shape %r" % (a.shape,))
         out = [None] * len(audios)
         shared = (self.arch_name in ("dsd", "hiphop") and self.frameSize in (1024, 2048, 4096)
                   and self.frameSize % self.hopSize == 0 and self.hopSize % 2 == 0)
-        groups = length_groups([a.size for a in audios], max_group if shared else 1, max_ratio)
+        # a clip too short to yield a tile makes the shared launch fail as a whole: such clips go through the single-clip
+        # path, where the failure stays confined to that clip (the reference runs one process per file)
+        def n_tiles(a):
+            return _lib.tile_count(_lib.frame_count(a.size, self.hopSize), self.tc, self.overlap, self.tiler)
+        alone = set(i for i, a in enumerate(audios) if a.size == 0 or n_tiles(a) < 1)
+        sizes = [0 if i in alone else a.size for i, a in enumerate(audios)]
+        groups = length_groups(sizes, max_group if shared else 1, max_ratio)
         for idx in groups:
             if len(idx) == 1:
-                out[idx[0]] = self.separate(audios[idx[0]])
+                i = idx[0]
+                if on_error == 'raise' or i not in alone:
+                    out[i] = self.separate(audios[i])
+                else:
+                    try:
+                        out[i] = self.separate(audios[i])
+                    except (ValueError, IndexError) as exc:
+                        out[i] = exc
                 continue
             lens = [int(audios[i].size) for i in idx]
             stack = np.zeros((len(idx), max(lens)), dtype=np.float32)
@@ -216,11 +236,12 @@ class Separator(object):
             else:
                 pcm = self.net.separate_ragged(self.plan, dev, lens, self.overlap, self.tiler, self.scale_factor, None,
                                                self.tie_mode)
-            pcm = pcm.cpu().numpy()
+            pcm = self.ctx.to_host(pcm)
             for b, i in enumerate(idx):
                 out[i] = pcm[b, :, :lens[b]].astype(np.float64)
         return out
 
+    @_on_ctx_stream
     def separate_stepwise(self, audio):
         """The reference's control flow, stage by stage through the public operators
         (compute_file -> x scale -> generate_overlapadd -> predict_function2 per batch ->
@@ -239,16 +260,18 @@ class Separator(object):
         T = mag.shape[0]
         sep = mm[:, :T].contiguous()
         pcm = self.plan.inverse(sep, ph, n_out=int(a.numel()), pre_div=self.scale_factor)
-        return pcm.cpu().numpy().astype(np.float64)
+        return self.ctx.to_host(pcm).astype(np.float64)
 
 
+    @_on_ctx_stream
     def separate_stereo(self, audio):
         """The "Separating" block of the stereo trainer (examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:291-325):
         ``audio [L, 2]`` -> ``sep_audio [L, S, 2]`` (one stereo signal per source, :299,316)."""
         a = self.ctx.to_device(np.ascontiguousarray(np.asarray(audio).T), np.float32)          # [2, L]
         pcm = self.net.separate_stereo(self.plan, a, self.overlap, TILER_LIBRARY, self.scale_factor)
-        return np.ascontiguousarray(pcm.cpu().numpy().astype(np.float64).transpose(2, 1, 0))   # [L, S, 2]
+        return np.ascontiguousarray(self.ctx.to_host(pcm).astype(np.float64).transpose(2, 1, 0))   # [L, S, 2]
 
+    @_on_ctx_stream
     def separate_scoreinformed(self, audio, melody):
         """Score-informed separation (examples/bach10_scoreinformed/separate_bach10.py:497-541), stage by stage on the
         device: STFT -> x scale -> harmonic masks of the score x spectrogram (``dcs_score_masks``) -> library tiler
@@ -273,7 +296,7 @@ class Separator(object):
         mm = overlap_add(self.ctx, out, self.overlap)
         sep = mm[:, :T].contiguous()
         pcm = self.plan.inverse(sep, ph, n_out=int(a.numel()), pre_div=self.scale_factor)
-        return pcm.cpu().numpy().astype(np.float64)
+        return self.ctx.to_host(pcm).astype(np.float64)
 
 
 _SCRIPT_DEFAULTS = {

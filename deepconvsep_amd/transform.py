@@ -24,23 +24,41 @@ def sinebell(lengthWindow):
     return np.sin((np.pi * (np.arange(lengthWindow))) / (1.0 * lengthWindow))
 
 
+def tensor_paths(out_path, name):
+    """File pair of one saved tensor: ``<stem><name>.data`` (raw float64, C order) and ``<stem><name>.shape``
+    (one text line ``#d0<TAB>d1<TAB>...``) -- the on-disk format of transform.py:159-166,180-185."""
+    return out_path.replace('.data', name + '.data'), out_path.replace('.data', name + '.shape')
+
+
+def write_shape_file(path, dims):
+    with open(path, 'w') as fh:
+        fh.write('#%s\n' % '\t'.join('%s' % d for d in dims))
+
+
+def read_shape_file(path):
+    with open(path, 'rb') as fh:
+        first = fh.readline().decode('ascii')
+    if not first.startswith('#'):
+        raise IOError('Failed to find shape in file')
+    return tuple(int(tok) for tok in re.findall(r'\d+', first))
+
+
 class Transforms(object):
-    """Base class (transform.py:52-198): parameters, tensor save/load helpers."""
+    """Base class (transform.py:52-198): analysis parameters plus the ``.data`` / ``.shape`` tensor files."""
+
+    _PARAMS = ('bins', 'frameSize', 'hopSize', 'iscale', 'suffix', 'sampleRate')
 
     def __init__(self, ttype='fft', bins=48, frameSize=1024, hopSize=256, tffmin=25, tffmax=18000, iscale='lin',
                  suffix='', sampleRate=44100, window=np.hanning, precision='float64', device=None):
-        self.bins = bins
-        self.frameSize = frameSize
-        self.hopSize = hopSize
-        self.fmin = tffmin
-        self.fmax = tffmax
-        self.iscale = iscale
-        self.suffix = suffix
-        self.sampleRate = sampleRate
-        self.ttype = ttype
-        self.window = window(self.frameSize)  # materialised once, transform.py:78
         if precision not in ('float64', 'float32'):
             raise ValueError("precision must be 'float64' or 'float32'")
+        given = dict(bins=bins, frameSize=frameSize, hopSize=hopSize, iscale=iscale, suffix=suffix,
+                     sampleRate=sampleRate)
+        for key in self._PARAMS:
+            setattr(self, key, given[key])
+        self.fmin, self.fmax = tffmin, tffmax     # attribute names of transform.py:72-73
+        self.ttype = ttype
+        self.window = window(frameSize)           # the window is evaluated once, here (transform.py:78)
         self.precision = precision
         self._device = device
         self._plan = None
@@ -78,29 +96,29 @@ class Transforms(object):
     def compute_inverse(self, mag, phase):
         return None
 
-    # -- transform.py:159-197 ---------------------------------------------------------------------
+    # -- tensor files (transform.py:159-197) -------------------------------------------------------
     def saveTensor(self, t, name='_cqt_m_'):
-        t.tofile(self.out_path.replace('.data', name + '.data'))
-        self.shape = t.shape
-        self.save_shape(self.out_path.replace('.data', name + '.shape'), t.shape)
+        data_file, shape_file = tensor_paths(self.out_path, name)
+        np.asarray(t).tofile(data_file)
+        self.shape = tuple(t.shape)
+        self.save_shape(shape_file, self.shape)
 
     def loadTensor(self, name='_cqt_m_'):
-        f_in = np.fromfile(self.out_path.replace('.data', name + '.data'))
-        shape = self.get_shape(self.out_path.replace('.data', '.shape'))
-        if self.shape == shape:
-            return f_in.reshape(shape)
-        print('Shape of loaded array does not match with the original shape of the transform')
+        """The reference looks for the shape next to ``out_path`` itself (``<stem>.shape``, without ``name``,
+        transform.py:173) and returns None after a message when it differs from the last saved shape."""
+        data_file, _ = tensor_paths(self.out_path, name)
+        flat = np.fromfile(data_file)
+        on_disk = self.get_shape(self.out_path.replace('.data', '.shape'))
+        if tuple(self.shape) != tuple(on_disk):
+            print('Shape of loaded array does not match with the original shape of the transform')
+            return None
+        return flat.reshape(on_disk)
 
     def save_shape(self, shape_file, shape):
-        with open(shape_file, 'w') as fout:
-            fout.write(u'#' + '\t'.join(str(e) for e in shape) + '\n')
+        write_shape_file(shape_file, shape)
 
     def get_shape(self, shape_file):
-        with open(shape_file, 'rb') as f:
-            line = f.readline().decode('ascii')
-            if line.startswith('#'):
-                return tuple(map(int, re.findall(r'(\d+)', line)))
-            raise IOError('Failed to find shape in file')
+        return read_shape_file(shape_file)
 
 
 class transformFFT(Transforms):
@@ -134,9 +152,9 @@ class transformFFT(Transforms):
             audio = audio.reshape(-1)  # stft_norm uses data.size / 1-D concatenation (transform.py:303,316)
         a = plan.ctx.to_device(audio, self._np_dtype())
         mag, ph = plan.forward(a, phase=phase)
-        mag = mag.cpu().numpy().astype(np.float64, copy=False)
+        mag = plan.ctx.to_host(mag).astype(np.float64, copy=False)
         if phase:
-            return mag, ph.cpu().numpy().astype(np.float64, copy=False)
+            return mag, plan.ctx.to_host(ph).astype(np.float64, copy=False)
         return mag
 
     def compute_inverse(self, mag, phase, sampleRate=44100):
@@ -152,7 +170,7 @@ class transformFFT(Transforms):
         m = plan.ctx.to_device(mag, self._np_dtype())
         p = plan.ctx.to_device(phase, self._np_dtype())
         out = plan.inverse(m, p)
-        return out.cpu().numpy().astype(np.float64, copy=False)
+        return plan.ctx.to_host(out).astype(np.float64, copy=False)
 
 
 # BASELINE.json spells the class with a capital T

@@ -38,9 +38,15 @@ def main(argv=None):
     sep = sp.Separator(args.arch, sp.load_model(args.mfile), 0.3, 30, overlap, 32, bins, frame, hop, window)
     mine = args.files[rank::world]
 
+    failed = []
+
     def read(path):
-        sr, audio = sp.read_wav(path)
-        return path, sr, (sp.to_mono(audio, args.arch) if sr == 44100 else None)
+        # a file that cannot be read or mixed down fails alone (the notebook runs one process per file)
+        try:
+            sr, audio = sp.read_wav(path)
+            return path, sr, (sp.to_mono(audio, args.arch) if sr == 44100 else None)
+        except Exception as exc:
+            return path, None, exc
 
     def write(path, sr, pcm):
         out = os.path.join(args.odir, os.path.splitext(os.path.basename(path))[0])
@@ -60,17 +66,27 @@ def main(argv=None):
             nxt = [pool.submit(read, f) for f in chunks[ci + 1]] if ci + 1 < len(chunks) else []
             ok = []
             for path, sr, audio in got:
-                if audio is None:
+                if isinstance(audio, Exception):
+                    failed.append((path, audio))
+                elif audio is None:
                     print("Sample rate is not 44100")          # separate_dsd.py:313
                 else:
                     ok.append((path, sr, audio))
-            pcms = sep.separate_many([a for _, _, a in ok]) if G > 1 else [sep.separate(a) for _, _, a in ok]
+            pcms = sep.separate_many([a for _, _, a in ok], on_error='return')
             for f in pending:
                 f.result()
-            pending = [pool.submit(write, path, sr, pcm) for (path, sr, _), pcm in zip(ok, pcms)]
+            pending = []
+            for (path, sr, _), pcm in zip(ok, pcms):
+                if isinstance(pcm, Exception):
+                    failed.append((path, pcm))
+                else:
+                    pending.append(pool.submit(write, path, sr, pcm))
         for f in pending:
             f.result()
+    for path, exc in failed:
+        print("%s: %s: %s" % (path, type(exc).__name__, exc), file=sys.stderr)
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
