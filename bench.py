@@ -13,25 +13,35 @@ i.e. 2.14 s of synthetic 44.1 kHz audio already resident in HBM, producing 4 PCM
 HBM.  With N GPUs every rank separates its own 32-tile batches (weak scaling, configs[2]) and
 the PCM of all ranks is all-gathered over RCCL inside the timed region.
 
-A 32-tile batch holds 0.57 GFLOP -- 3.6 us of the chip's f32 peak -- spread over 8 dependent
+A 32-tile batch holds 0.57 GFLOP -- 3.6 us of the chip's f32 peak -- spread over dependent
 kernels, so one batch at a time leaves the GPU mostly idle (`single_stream` reports that regime:
-the same K steps, one batch per launch, one stream).  Steps are independent, therefore
-`--clips-per-launch B` (default 16) batches share one set of kernel launches (dcs_separate_batch:
-every batch is tiled, cross-faded and inverted exactly as if it were alone) and `--streams S`
-(default 2) such launch groups are in flight on S HIP streams, each with its own libdcs context,
-plan, model handle and buffers -- the way a batch-of-files server overlaps requests.  `value` is
-the resulting throughput: K steps = K batches, whatever the grouping.
+one batch per launch, one stream).  Steps are independent, therefore the K steps of a round are
+cut into launch groups of about `--clips-per-launch` (16) batches that share one set of kernel
+launches (dcs_separate_batch: every batch is tiled, cross-faded and inverted exactly as if it
+were alone) and `--streams S` (default 2) such groups are in flight on S HIP streams, each with
+its own libdcs context, plan, model handle and buffers -- the way a batch-of-files server overlaps
+requests.  K steps are always K batches; the groups of a round differ in size by at most one
+batch, so the launch shape does not depend on how K divides by 16.
 
-Rank 0 prints ONE JSON line.  `roofline` refers to the dominant kernel (transposed conv1 +
-bias + rectify + soft mask + cross-fade), timed with HIP events inside the timed region on the
-stream it is launched on; `cpu_baseline` is the CPU oracle (reference-equivalent NumPy +
-torch-CPU float64 path) timed on this host; `saturating` repeats the measurement on a long clip
-(4096 tiles, 3 min 58 s) where one launch fills the chip (DESIGN.md "measurement").
+Timing: a *round* is EXACTLY K steps bracketed by a barrier + torch.cuda.synchronize() on both
+sides (max over ranks).  Rounds are repeated until `--min-time` (0.25 s) has been timed; `value`
+comes from the MEDIAN round, so it does not depend on K being large (`rounds`, `round_ms` in the
+line).  Every 4th round brackets the launches of the dominant kernel on stream 0 with HIP events
+(those rounds launch stream 0 kernel by kernel instead of replaying its hipGraph).
+
+Rank 0 prints ONE JSON line.  `roofline` refers to the dominant kernel of the headline workload
+(transposed conv1 + bias + rectify + soft mask + cross-fade); `cpu_baseline` is the CPU oracle
+(reference-equivalent NumPy + torch-CPU float64 path) timed on this host; `legs` holds the other
+BASELINE configs (iKala 10 s, Bach10 with the f16 MFMA conv path, score-informed batch of 128),
+each with its own `roofline` and `cpu_baseline`; `saturating` repeats the headline measurement on
+a long clip (4096 tiles, 3 min 58 s) where one launch fills the chip (DESIGN.md "measurement").
 """
 import argparse
 import json
 import os
+import statistics
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -41,13 +51,49 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HOP, TC, OV, SCALE, SR = 512, 30, 25, 0.3, 44100
-PEAK_F32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
+PEAK_F32_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
+PEAK_F16_TFLOPS = 2500.0   # dense f16 / bf16 MFMA
+PEAK_HBM_GBPS = 8000.0
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
-def samples_for_tiles(n_tiles):
-    """Shortest signal (whole hops) whose script tiling (separate_dsd.py:123) yields n_tiles."""
-    frames = TC + 1 + (n_tiles - 1) * (TC - OV)
-    return (frames - 2) * HOP
+def samples_for_tiles(n_tiles, tc=TC, ov=OV, hop=HOP, library=False):
+    """Shortest signal (whole hops) whose tiling yields n_tiles (script tiler: start + tc < T,
+    separate_dsd.py:123; library tiler: start + ov < T, util.py:230)."""
+    guard = ov if library else tc
+    frames = guard + 1 + (n_tiles - 1) * (tc - ov)
+    return (frames - 2) * hop
+
+
+def split_groups(k, per_group, lanes):
+    """K steps -> launch groups of about per_group steps, at least one group per lane, sizes differing by <= 1."""
+    g = max(1, int(round(k / float(per_group))))
+    if k >= lanes:
+        g = max(g, lanes)
+    g = min(g, k)
+    base, extra = divmod(k, g)
+    return [base + 1] * extra + [base] * (g - extra)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def time_cpu(fn, min_seconds, max_reps=1000):
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds or reps >= max_reps:
+            return el / reps, reps, el
 
 
 def main():
@@ -58,13 +104,14 @@ def main():
     ap.add_argument("--tiles", type=int, default=32, help="tiles per GPU per step (BASELINE configs[1]: 32)")
     ap.add_argument("--frame-size", type=int, default=2048)
     ap.add_argument("--clips-per-launch", type=int, default=16,
-                    help="independent 32-tile batches that share one set of kernel launches (dcs_separate_batch); "
-                         "every batch still counts as one step")
+                    help="target number of independent 32-tile batches that share one set of kernel launches "
+                         "(dcs_separate_batch); every batch still counts as one step")
     ap.add_argument("--streams", type=int, default=2, help="launch groups in flight per GPU (HIP streams)")
-    ap.add_argument("--issue-threads", type=int, default=1,
-                    help="host threads issuing steps (single GPU only: with N ranks the RCCL gathers must be "
-                         "issued in the same order on every rank)")
+    ap.add_argument("--min-time", type=float, default=0.25, help="seconds of timed rounds to accumulate")
+    ap.add_argument("--max-rounds", type=int, default=4000)
     ap.add_argument("--sat-tiles", type=int, default=4096, help="tiles of the saturating extra run (0 = skip)")
+    ap.add_argument("--legs", default="ikala,bach10_f16,score_informed",
+                    help="comma list of extra BASELINE configs to measure on rank 0 at N=1 ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive extra leg")
     args = ap.parse_args()
@@ -79,24 +126,28 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs; there is no CPU path to measure")
-    if os.environ.get("DCS_BENCH_SAME_DEVICE"):                 # code-path check of the N > 1 leg on a 1-GPU box
+    same_device = bool(os.environ.get("DCS_BENCH_SAME_DEVICE"))   # code-path check of the N > 1 leg on a 1-GPU box
+    if same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("DCS_BENCH_SAME_DEVICE"):             # RCCL refuses two ranks on one GPU: gloo for the check
+        if same_device:                                           # RCCL refuses two ranks on one GPU: gloo for the check
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    import ctypes
+
     import deepconvsep_amd as dcs
     from deepconvsep_amd import _lib
-    from deepconvsep_amd.arch import ARCHS, TILER_SCRIPT
+    from deepconvsep_amd.arch import ARCHS, TILER_LIBRARY, TILER_SCRIPT
     from deepconvsep_amd.runtime import Context
-    from deepconvsep_amd.synth import synth_audio, synth_params
+    from deepconvsep_amd.synth import synth_audio, synth_params, synth_score_text
 
     N = args.frame_size
     F = N // 2 + 1
+    K = max(1, args.steps)
     params = synth_params("dsd", TC, F, seed=2)
     L = samples_for_tiles(args.tiles)
     T = _lib.frame_count(L, HOP)
@@ -104,15 +155,14 @@ def main():
     assert n_tiles == args.tiles, (n_tiles, args.tiles)
     frames_per_step = (n_tiles - 1) * (TC - OV) + TC        # unique frames fully separated
     NS = max(1, args.streams)
-    CPL = max(1, min(args.clips_per_launch, args.steps))     # a run shorter than one launch group is one smaller group
-
-    import ctypes
+    groups = split_groups(K, max(1, args.clips_per_launch), NS)
+    CPL = max(groups)                                        # buffers are sized for the largest group
 
     class Lane(object):                                      # one HIP stream with everything it needs
         def __init__(self, idx):
             self.stream = torch.cuda.Stream()
+            self.ctx = Context(stream=self.stream)           # binds libdcs (and every copy the package issues) to it
             with torch.cuda.stream(self.stream):
-                self.ctx = Context()                         # binds libdcs to this stream
                 self.sep = dcs.Separator("dsd", params, SCALE, TC, OV, 32, F, N, HOP, np.hanning, ctx=self.ctx)
                 self.audio_h = np.stack([synth_audio(L, seed=100 + (rank * 16 + idx) * CPL + c) for c in range(CPL)])
                 self.audio = self.ctx.to_device(self.audio_h, np.float32)          # [CPL, L]
@@ -132,15 +182,18 @@ def main():
             self._args = lambda nclips: (net._h, plan._h, ctypes.c_void_p(self.audio.data_ptr()), L, nclips, L, OV,
                                          TILER_SCRIPT, ctypes.c_float(SCALE), net.arch.eps_mode, 0,
                                          ctypes.c_void_p(self.pcm.data_ptr()), None, None)
-            self._bound = {CPL: self._args(CPL), 1: self._args(1)}
+            self._bound = {}
+            self.launched_tiles = 0
 
-        def step(self, nclips=None):
+        def step(self, nclips):
             """One launch group = nclips steps (independent 32-tile batches)."""
-            nclips = CPL if nclips is None else nclips
-            a = self._bound.get(nclips) or self._args(nclips)
+            a = self._bound.get(nclips)
+            if a is None:
+                a = self._bound[nclips] = self._args(nclips)
             rc = self._fn(*a)
             if rc:
                 _lib.check(rc)
+            self.launched_tiles += nclips * n_tiles
             if world > 1:
                 rc = self._to16(self.ctx._h, ctypes.c_void_p(self.pcm.data_ptr()), nclips * 4 * L,
                                 ctypes.c_void_p(self.pcm16.data_ptr()))
@@ -158,31 +211,13 @@ def main():
         if world > 1:
             dist.barrier()
 
-    import threading
-    n_issue = max(1, min(args.issue_threads, NS)) if world == 1 else 1
-
-    def timed(k, use, cpl):
-        """Exactly k steps = k 32-tile batches, in launch groups of cpl batches (the last group takes the
-        remainder), round-robin over the lanes in `use`, issued by n_issue host threads (ctypes releases the
-        GIL inside the call) when more than one lane is in play."""
-        nth = n_issue if len(use) > 1 else 1
-        groups = [cpl] * (k // cpl) + ([k % cpl] if k % cpl else [])
-
-        def work(t):
-            mine = use[t::nth]
-            for i, g in enumerate(groups[t::nth]):
-                # a remainder group goes to the last lane: lane 0 carries the HIP events of the roofline figure,
-                # which is priced for full groups
-                (mine[-1] if g != cpl else mine[i % len(mine)]).step(g)
-        threads = [threading.Thread(target=work, args=(t,)) for t in range(1, nth)]
+    def timed(group_sizes, use):
+        """Exactly sum(group_sizes) steps, round-robin over the lanes in `use`, bracketed by barrier + synchronize."""
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for th in threads:
-            th.start()
-        work(0)
-        for th in threads:
-            th.join()
+        for i, g in enumerate(group_sizes):
+            use[i % len(use)].step(g)
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
@@ -192,55 +227,95 @@ def main():
             el = float(tt.item())
         return el
 
-    for i in range(0, max(args.warmup, 2 * NS * CPL), CPL):      # >= 2 groups per lane: the second call captures the graph
-        lanes[(i // CPL) % NS].step()
+    # ---- warm-up: at least W steps, and every (lane, group size) pair of the schedule at least twice -- the second
+    # identical call captures its hipGraph -- plus once more so that the first timed round replays
+    warm = 0
+    while warm < max(args.warmup, 3 * K):
+        for i, g in enumerate(groups):
+            lanes[i % NS].step(g)
+        warm += K
     for ln in lanes:
-        ln.step(1)
-        ln.step(1)
-    # HIP event pairs around the dominant kernel on stream 0, inside the timed region, around every 4th
-    # of its launches there (an event record costs ~6 us of stream time on each side of the kernel).
-    if not os.environ.get("DCS_BENCH_NOEVENTS"):
-        ctx0.timing(["final"])
-    ctx0.timing_stride(4)
-    ctx0.timing_reset()
-    elapsed = timed(args.steps, lanes, CPL)
-    final_ms, final_launches = ctx0.timing_query("final")
-    ctx0.timing(None)
-    ctx0.timing_stride(1)
-    value = world * frames_per_step * args.steps / elapsed
+        for _ in range(3):
+            ln.step(1)
+    torch.cuda.synchronize()
 
-    # ---- the same K steps on ONE stream (no overlap between batches)
+    # ---- timed rounds
+    round_s, events_tiles, events_rounds = [], 0, 0
+    ctx0.timing_stride(1)
+    ctx0.timing_reset()
+    total = 0.0
+    while (total < args.min_time or len(round_s) < 3) and len(round_s) < args.max_rounds:
+        instrumented = (len(round_s) % 4 == 3) and not os.environ.get("DCS_BENCH_NOEVENTS")
+        if instrumented:
+            ctx0.timing(["final"])
+            before = lanes[0].launched_tiles
+        el = timed(groups, lanes)
+        if instrumented:
+            ctx0.timing(None)
+            events_tiles += lanes[0].launched_tiles - before
+            events_rounds += 1
+        round_s.append(el)
+        total += el
+    final_ms, final_launches = ctx0.timing_query("final")
+    ctx0.timing_reset()
+    med = statistics.median(round_s)
+    value = world * frames_per_step * K / med
+    clean = [t for i, t in enumerate(round_s) if i % 4 != 3] or round_s
+
+    # ---- optional self-check of the gather (tests): every rank's slice of the gathered buffer must be that rank's own
+    # int16 PCM, bit for bit (digests exchanged out of band)
+    gather_check = None
+    if world > 1 and os.environ.get("DCS_BENCH_CHECK_GATHER"):
+        import hashlib
+        ln, g0 = lanes[0], groups[0]
+        ln.step(g0)
+        torch.cuda.synchronize()
+        mine = hashlib.sha1(ln.pcm16[: g0 * 4].cpu().numpy().tobytes()).hexdigest()
+        digests = [None] * world
+        dist.all_gather_object(digests, mine)
+        got = ln.gathered[: world * g0 * 4].cpu().numpy()
+        ok = all(hashlib.sha1(got[r * g0 * 4:(r + 1) * g0 * 4].tobytes()).hexdigest() == digests[r] for r in range(world))
+        # ranks separate different audio: equal digests would mean the check compares a buffer with itself
+        ok = ok and len(set(digests)) == world and bool(np.any(got))
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        gather_check = "ok" if all(flags) else "MISMATCH"
+
+    # ---- one batch per launch on ONE stream (no overlap between batches): the BASELINE batch of 32 as one call
+    k1 = max(K, 200)
+    for _ in range(3):
+        lanes[0].step(1)
+    single_rounds = []
+    tot1 = 0.0
+    while tot1 < 0.1 or len(single_rounds) < 3:
+        e = timed([1] * k1, lanes[:1])
+        single_rounds.append(e / k1)
+        tot1 += e
+    el1 = statistics.median(single_rounds)
     ctx0.timing(["final"])
     ctx0.timing_stride(8)
     ctx0.timing_reset()
-    el1 = timed(args.steps, lanes[:1], 1)
+    timed([1] * k1, lanes[:1])
     final_ms1, final_launches1 = ctx0.timing_query("final")
     ctx0.timing(None)
     ctx0.timing_stride(1)
 
-    # ---- per-kernel breakdown (separate instrumented pass on one stream)
-    kernels_ms = {}
-    ctx0.timing("all")
-    ctx0.timing_reset()
-    for _ in range(20):
-        lanes[0].step(1)
-    for tag in _lib.TAGS:
-        ms, cnt = ctx0.timing_query(tag)
-        if cnt:
-            kernels_ms[tag] = round(ms, 5)
-    ctx0.timing(None)
+    def breakdown(nclips, reps):
+        out = {}
+        ctx0.timing("all")
+        ctx0.timing_reset()
+        for _ in range(reps):
+            lanes[0].step(nclips)
+        for tag in _lib.TAGS:
+            ms, cnt = ctx0.timing_query(tag)
+            if cnt:
+                out[tag] = round(ms * cnt / reps, 5)
+        ctx0.timing(None)
+        ctx0.timing_reset()
+        return out
 
-    # ---- the same breakdown for one full launch group (CPL batches per launch) on one stream
-    group_ms = {}
-    ctx0.timing("all")
-    ctx0.timing_reset()
-    for _ in range(10):
-        lanes[0].step(CPL)
-    for tag in _lib.TAGS:
-        ms, cnt = ctx0.timing_query(tag)
-        if cnt:
-            group_ms[tag] = round(ms, 5)
-    ctx0.timing(None)
+    kernels_ms = breakdown(1, 20)            # per-kernel breakdown of one batch (separate instrumented pass)
+    group_ms = breakdown(groups[0], 10)      # the same for one full launch group
 
     # algorithmic FLOPs of the dominant kernel: transposed conv1 of the 3 live branches
     # (separate_dsd.py:212,218,224): per tile 3 * 2 * tc * 50 * F  (DESIGN.md "kernels")
@@ -250,30 +325,36 @@ def main():
     # correction of MI355X_MICROARCH.md.  None when the workload has no matching record.
     traffic_rec = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
             traffic_rec = json.load(fh)
     except Exception:
         pass
 
-    def roof(n, ms, launches, key=None, frames=None):
-        frames = (n - 1) * (TC - OV) + TC if frames is None else frames
-        ach = n * final_flops_tile / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        rec = traffic_rec.get(key or "final_kernel_%d_tiles" % n) if N == 2048 else None
+    def roof(tiles_per_launch, ms, launches, frames=None, key=None):
+        frames = (tiles_per_launch - 1) * (TC - OV) + TC if frames is None else frames
+        ach = tiles_per_launch * final_flops_tile / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        rec = traffic_rec.get(key or "final_kernel_%d_tiles" % int(tiles_per_launch)) if N == 2048 else None
         traffic = int((2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024) if rec else None
         return {"bound": "mfma", "kernel": "final_kernel<fold> (deconv1+bias+relu+mask+crossfade)",
                 "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": (TRAFFIC_FILE + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "command, 2*FETCH+WRITE; not measured in this run)") if rec else None,
                 # G rows read once (3 branches x tc x 56 stored channels) + mixture read + 4 sources written
-                "algorithmic_bytes": int(n * (3 * TC * 56 * 4) + frames * F * 4 * 5),
-                "avg_kernel_ms": round(ms, 5), "launches": int(launches)}
+                "algorithmic_bytes": int(tiles_per_launch * (3 * TC * 56 * 4) + frames * F * 4 * 5),
+                "avg_kernel_ms": round(ms, 5), "launches": int(launches),
+                "tiles_per_launch": round(float(tiles_per_launch), 2)}
 
-    roofline = roof(n_tiles * CPL, final_ms, final_launches, "final_kernel_%dx%d_tiles" % (CPL, n_tiles),
-                    frames_per_step * CPL)
-    roofline["tiles_per_launch"] = n_tiles * CPL
-    single = {"ms_per_step": round(el1 / args.steps * 1e3, 5),
-              "value": round(world * frames_per_step * args.steps / el1, 1),
-              "roofline": roof(n_tiles, final_ms1, final_launches1), "kernels_ms": kernels_ms}
-    launch_group = {"clips": CPL, "tiles": CPL * n_tiles, "kernels_ms": group_ms,
+    ev_tiles = events_tiles / float(final_launches) if final_launches else groups[0] * n_tiles
+    roofline = roof(ev_tiles, final_ms, final_launches, frames=ev_tiles / n_tiles * frames_per_step,
+                    key="final_kernel_%dx%d_tiles" % (groups[0], n_tiles))
+    roofline["timed"] = ("HIP events around every launch of the kernel on stream 0 in %d of the %d timed rounds"
+                         % (events_rounds, len(round_s)))
+    single = {"ms_per_step": round(el1 * 1e3, 5), "value": round(world * frames_per_step / el1, 1),
+              "steps_per_round": k1, "rounds": len(single_rounds),
+              "roofline": roof(n_tiles, final_ms1, final_launches1), "kernels_ms": kernels_ms,
+              "kernels_ms_sum": round(sum(kernels_ms.values()), 5)}
+    launch_group = {"clips": groups[0], "tiles": groups[0] * n_tiles, "kernels_ms": group_ms,
                     "kernels_ms_sum": round(sum(group_ms.values()), 5)}
 
     # ---- saturating regime (extra): same path, one long clip per launch, one stream
@@ -284,35 +365,47 @@ def main():
             Ls = samples_for_tiles(args.sat_tiles)
             a2 = ctx0.to_device(synth_audio(Ls, seed=7), np.float32)
             out2 = torch.empty((4, Ls), dtype=torch.float32, device=a2.device)
-            for _ in range(2):
+            for _ in range(3):
                 net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
+            torch.cuda.synchronize()
+            reps2, tot2, per2 = 0, 0.0, []
+            while tot2 < 0.1 or reps2 < 5:
+                t0 = time.perf_counter()
+                net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
+                torch.cuda.synchronize()
+                per2.append(time.perf_counter() - t0)
+                tot2 += per2[-1]
+                reps2 += 1
+            e2 = statistics.median(per2)
             ctx0.timing("all")
             ctx0.timing_reset()
-            torch.cuda.synchronize()
-            k2 = 10
-            t0 = time.perf_counter()
+            k2 = 5
             for _ in range(k2):
                 net.separate(plan, a2, OV, TILER_SCRIPT, SCALE, out=out2)
-            torch.cuda.synchronize()
-            e2 = time.perf_counter() - t0
         fr2 = (args.sat_tiles - 1) * (TC - OV) + TC
         sat_k = {}
         for tag in _lib.TAGS:
             ms, cnt = ctx0.timing_query(tag)
             if cnt:
-                sat_k[tag] = round(ms, 5)
+                sat_k[tag] = round(ms * cnt / k2, 5)
         ctx0.timing(None)
+        ctx0.timing_reset()
         total_flops = args.sat_tiles * ARCHS["dsd"].flops_per_tile(TC, F)
-        saturating = {"tiles": args.sat_tiles, "audio_seconds": round(Ls / SR, 2), "value": round(fr2 * k2 / e2, 1),
-                      "unit": "frames/s", "x_realtime": round(fr2 * k2 / e2 * HOP / SR, 1),
-                      "ms_per_step": round(e2 / k2 * 1e3, 4), "roofline": roof(args.sat_tiles, sat_k.get("final", 0.0), k2),
-                      "kernels_ms": sat_k, "whole_path_algorithmic_tflops": round(total_flops * k2 / e2 / 1e12, 2)}
+        saturating = {"tiles": args.sat_tiles, "audio_seconds": round(Ls / SR, 2), "value": round(fr2 / e2, 1),
+                      "unit": "frames/s", "x_realtime": round(fr2 / e2 * HOP / SR, 1),
+                      "ms_per_step": round(e2 * 1e3, 4), "rounds": reps2,
+                      "roofline": roof(args.sat_tiles, sat_k.get("final", 0.0), k2),
+                      "kernels_ms": sat_k, "kernels_ms_sum": round(sum(sat_k.values()), 5),
+                      "whole_path_algorithmic_tflops": round(total_flops / e2 / 1e12, 2),
+                      "whole_path_frac_of_f32_peak": round(total_flops / e2 / 1e12 / PEAK_F32_TFLOPS, 4)}
         del a2, out2
+
     # ---- host-fed regime (extra, never `value`): float32 audio comes from pinned host memory and the int16 PCM goes
     # back to it, every launch group, over PCIe; the copies ride on the lanes' streams so one lane's transfers overlap
     # the other lane's kernels
     host_fed = None
     if rank == 0 and world == 1 and not args.no_host_fed:
+        G0 = groups[0]
         for ln in lanes:
             with torch.cuda.stream(ln.stream):
                 ln.audio_pin = torch.from_numpy(ln.audio_h.astype(np.float32)).pin_memory()
@@ -321,15 +414,15 @@ def main():
 
         def host_group(ln):
             with torch.cuda.stream(ln.stream):
-                ln.audio.copy_(ln.audio_pin, non_blocking=True)
-            ln.step(CPL)
-            rc = ln._to16(ln.ctx._h, ctypes.c_void_p(ln.pcm.data_ptr()), CPL * 4 * L, ctypes.c_void_p(ln.pcm16.data_ptr()))
+                ln.audio[:G0].copy_(ln.audio_pin[:G0], non_blocking=True)
+            ln.step(G0)
+            rc = ln._to16(ln.ctx._h, ctypes.c_void_p(ln.pcm.data_ptr()), G0 * 4 * L, ctypes.c_void_p(ln.pcm16.data_ptr()))
             if rc:
                 _lib.check(rc)
             # SDMA copy; letting the conversion kernel write the pinned buffer directly (2-byte stores over PCIe)
             # measured 6.8 GB/s against 29.5 GB/s this way
             with torch.cuda.stream(ln.stream):
-                ln.out_pin.copy_(ln.pcm16, non_blocking=True)
+                ln.out_pin[:G0 * 4].copy_(ln.pcm16[:G0 * 4], non_blocking=True)
 
         for ln in lanes:
             host_group(ln)
@@ -340,68 +433,283 @@ def main():
             host_group(lanes[i % NS])
         torch.cuda.synchronize()
         eh = time.perf_counter() - t0
-        host_fed = {"value": round(frames_per_step * CPL * kg / eh, 1), "unit": "frames/s",
-                    "ms_per_step": round(eh / (kg * CPL) * 1e3, 5),
+        host_fed = {"value": round(frames_per_step * G0 * kg / eh, 1), "unit": "frames/s",
+                    "ms_per_step": round(eh / (kg * G0) * 1e3, 5),
                     "bytes_per_step": {"h2d_f32_audio": int(L * 4), "d2h_int16_pcm": int(4 * L * 2)},
-                    "pcie_GBps": round((L * 4 + 4 * L * 2) * CPL * kg / eh / 1e9, 1),
+                    "pcie_GBps": round((L * 4 + 4 * L * 2) * G0 * kg / eh / 1e9, 1),
                     "note": "pinned host buffers, async copies on the lanes' streams; not part of `value`"}
     if world > 1:
         dist.barrier()
 
     # ---- CPU baseline: the oracle on this host's cores, same 32-tile batch (rank 0, N=1 only)
+    ncpu = os.cpu_count() or 1
+    cpu_name = cpu_model()
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pipeline
         audio_h = lanes[0].audio_h[0]
-        # pick the torch thread count that serves this small batch best (all 256 host threads on the
-        # 50-channel float64 convolutions is far slower than a handful); the NumPy loops are serial
-        best = None
-        for nt in sorted(set([1, 4, 8, 16, min(32, os.cpu_count() or 1)])):
+
+        def run_oracle():
+            pipeline.separate("dsd", params, audio_h, SCALE, TC, OV, 32, N, HOP, np.hanning)
+
+        # the reference's own loops are single-threaded Python; its Theano convolutions / dots may use BLAS threads.
+        # Reported: one thread, the best of a few thread counts (all 256 hardware threads on 50-channel float64
+        # convolutions are far slower than a handful), and all hardware threads.
+        per_threads = {}
+        for nt in sorted(set([1, 4, 8, 16, min(32, ncpu)])):
             torch.set_num_threads(nt)
-            t0 = time.perf_counter()
-            pipeline.separate("dsd", params, audio_h, SCALE, TC, OV, 32, N, HOP, np.hanning)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[1]:
-                best = (nt, dt)
-        torch.set_num_threads(best[0])
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            pipeline.separate("dsd", params, audio_h, SCALE, TC, OV, 32, N, HOP, np.hanning)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el >= 10.0 or reps >= 200:
-                break
-        cpu_baseline = {"value": round(frames_per_step * reps / el, 1), "unit": "frames/s",
-                        "cores": int(torch.get_num_threads()), "kind": "port",
+            run_oracle()
+            sec, reps, el = time_cpu(run_oracle, 1.5)
+            per_threads[nt] = (sec, reps, el)
+        best_nt = min(per_threads, key=lambda k: per_threads[k][0])
+        torch.set_num_threads(best_nt)
+        sec_b, reps_b, el_b = time_cpu(run_oracle, 8.0, 400)
+        torch.set_num_threads(ncpu)
+        run_oracle()
+        sec_all, reps_all, el_all = time_cpu(run_oracle, 2.0)
+        torch.set_num_threads(best_nt)
+        cpu_baseline = {"value": round(frames_per_step / sec_b, 1), "unit": "frames/s",
+                        "cores": int(best_nt), "kind": "port",
+                        "single_thread": {"value": round(frames_per_step / per_threads[1][0], 1), "cores": 1},
+                        "all_cores": {"value": round(frames_per_step / sec_all, 1), "cores": int(ncpu)},
+                        "by_threads": {str(k): round(frames_per_step / v[0], 1) for k, v in per_threads.items()},
+                        "cpu_model": cpu_name, "host_cpu_count": int(ncpu),
+                        "label": "reference-equivalent CPU path (Theano unavailable)",
                         "sample": "%d x the same 32-tile / %.2f s batch through oracle.pipeline.separate "
                                   "(reference NumPy STFT/tiling/overlap-add loops + torch-CPU float64 network; "
-                                  "Theano/Lasagne unavailable), %.1f s of CPU time, host cpu_count=%d"
-                                  % (reps, L / SR, el, os.cpu_count() or 0)}
+                                  "Theano/Lasagne unavailable), %.1f s of CPU time at %d threads (the best of "
+                                  "1/4/8/16/32); %.1f s more for the thread sweep and the all-core run"
+                                  % (reps_b, L / SR, el_b, best_nt,
+                                     sum(v[2] for v in per_threads.values()) + el_all)}
+
+    # ---- the other BASELINE configs (rank 0, N=1): whole path per clip, per-kernel breakdown, roofline of the
+    # dominant kernel, CPU oracle on a bounded sample of the same input
+    legs = None
+    if rank == 0 and world == 1 and args.legs:
+        legs = {}
+        for name in [x for x in args.legs.split(",") if x]:
+            try:
+                legs[name] = run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_audio, synth_params,
+                                     synth_score_text, not args.no_cpu_baseline, cpu_name, ncpu)
+            except Exception as exc:     # a leg must not take the headline line down with it
+                legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     if rank == 0:
         line = {
             "metric": "spectrogram-frames/s", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "steps": K, "warmup": args.warmup, "ms_per_step": round(med / K * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "x_realtime": round(value * HOP / SR, 1),
+            "rounds": len(round_s), "timed_region_s": round(total, 4),
+            "round_ms": {"median": round(med * 1e3, 4), "min": round(min(round_s) * 1e3, 4),
+                         "max": round(max(round_s) * 1e3, 4),
+                         "median_without_event_rounds": round(statistics.median(clean) * 1e3, 4)},
             "config": {"workload": "DSD100 4-source separate_dsd path (BASELINE configs[1]): frameSize=%d hop=512 "
                                    "hann, time_context=30 overlap=25 scale=0.3, one batch of %d tiles = %.2f s of "
                                    "44.1 kHz audio per GPU per step, STFT->net->mask->overlap-add->iSTFT, "
-                                   "input and output resident in HBM; %d independent batches share one set of "
-                                   "kernel launches (dcs_separate_batch, the batch-of-files driver) and %d such "
-                                   "groups are in flight per GPU (HIP streams)%s"
-                                   % (N, n_tiles, L / SR, CPL, NS, ", int16 PCM all-gathered over RCCL" if world > 1 else ""),
+                                   "input and output resident in HBM; the %d steps of a round go out as launch "
+                                   "groups of %s batches (dcs_separate_batch, the batch-of-files driver) over %d "
+                                   "HIP streams per GPU%s; a round = exactly %d steps between barrier+synchronize, "
+                                   "median of %d rounds"
+                                   % (N, n_tiles, L / SR, K, "/".join(str(g) for g in sorted(set(groups), reverse=True)),
+                                      NS, ", int16 PCM all-gathered over RCCL" if world > 1 else "", K, len(round_s)),
                        "tiles_per_gpu_per_step": n_tiles, "frames_per_gpu_per_step": frames_per_step,
-                       "frame_size": N, "bins": F, "clips_per_launch": CPL, "streams_per_gpu": NS,
-                       "issue_threads": n_issue,
+                       "frame_size": N, "bins": F, "launch_groups_per_round": groups, "streams_per_gpu": NS,
                        "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",
                        "parallelism": "tiles sharded by rank (dp%d)" % world},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_stream": single, "launch_group": launch_group,
-            "saturating": saturating, "host_fed": host_fed,
+            "saturating": saturating, "host_fed": host_fed, "legs": legs,
         }
+        if gather_check is not None:
+            line["gather_check"] = gather_check
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ other configs
+def arch_work(arch, tc, F, n, f16):
+    """Per launch of n tiles: algorithmic FLOPs and HBM bytes of every kernel tag of the generic graphs
+    (SURVEY 8a-4', 8d), the matrix peak that applies to it."""
+    d = arch.dims(tc, F)
+    NB, C = len(arch.branch_fc), arch.C
+    conv1 = 2.0 * d['nf1'] * C * d['kw1'] * tc * d['w1']
+    conv2 = 2.0 * d['nf2'] * d['nf1'] * d['kh2'] * d['kw2'] * d['h2'] * d['w2']
+    fc = 2.0 * d['flat'] * arch.hidden
+    plane_in, plane1, plane2 = C * tc * F * 4.0, d['nf1'] * tc * d['wp'] * 4.0, d['flat'] * 4.0
+    mfma16 = PEAK_F16_TFLOPS if f16 else PEAK_F32_TFLOPS
+    return {
+        "conv1": (n * conv1, n * (plane_in + d['nf1'] * tc * d['w1'] * 4.0), PEAK_F32_TFLOPS),
+        "conv2": (n * conv2, n * (plane1 + plane2), mfma16),
+        "fc": (n * fc, d['flat'] * arch.hidden * 4.0 + n * (plane2 + arch.hidden * 4.0), PEAK_F32_TFLOPS),
+        "fc1x": (n * NB * fc, NB * d['flat'] * arch.hidden * 4.0 + n * NB * plane2, PEAK_F32_TFLOPS),
+        "deconv2": (n * NB * conv2, n * NB * (plane2 + plane1), mfma16),
+        "final": (n * NB * conv1, n * NB * (d['nf1'] * tc * d['w1'] * 4.0 + plane_in), PEAK_F32_TFLOPS),
+    }
+
+
+def kernel_roofline(tag, ms, flops, nbytes, peak_tf, name):
+    """Roofline of one kernel: the bound is whichever of flops / peak and bytes / 8 TB/s is the longer time."""
+    t = ms * 1e-3
+    t_mfma, t_hbm = flops / (peak_tf * 1e12), nbytes / (PEAK_HBM_GBPS * 1e9)
+    if t_mfma >= t_hbm:
+        ach = flops / t / 1e12 if t > 0 else 0.0
+        return {"bound": "mfma", "kernel": name, "tag": tag, "achieved": round(ach, 3), "peak": peak_tf,
+                "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": None,
+                "algorithmic_flops": int(flops), "algorithmic_bytes": int(nbytes), "avg_kernel_ms": round(ms, 5)}
+    ach = nbytes / t / 1e9 if t > 0 else 0.0
+    return {"bound": "hbm", "kernel": name, "tag": tag, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS,
+            "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None,
+            "algorithmic_flops": int(flops), "algorithmic_bytes": int(nbytes), "avg_kernel_ms": round(ms, 5)}
+
+
+KERNEL_NAMES = {
+    "conv1": "conv1_kernel (strided conv1 + biases)", "conv2": "conv2 (slab / column convolution, MFMA)",
+    "fc": "gemm_rows (bottleneck DenseLayer)", "fc1x": "gemm_rows (per-source DenseLayers)",
+    "deconv2": "transposed conv2 (slab / column convolution, MFMA)", "final": "transposed conv1 (deconv1_reg / deconv1)",
+}
+
+
+def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_audio, synth_params, synth_score_text,
+            with_cpu, cpu_name, ncpu):
+    from deepconvsep_amd.runtime import default_context
+    ctx = default_context()
+    if name == "ikala":
+        # BASELINE configs[0]: iKala 2-source, frameSize=2048 hop=512, time_context=30, one 10 s wav (the script sums
+        # L+R of a stereo file, separate_ikala.py:229; overlap 20, :275)
+        arch_name, Nf, ov, window, f16, batch, seed = "ikala", 2048, 20, np.hanning, False, 32, 1
+        Lc = 441000
+        st = synth_audio(Lc, seed=0, channels=2)
+        audio = st[:, 0] + st[:, 1]
+        library, melody = False, None
+        what = "iKala 2-source separate_ikala path (BASELINE configs[0]): frameSize=2048 hop=512 hann, overlap 20, 10 s stereo wav summed L+R, f32"
+    elif name == "bach10_f16":
+        # BASELINE configs[3]: Bach10 4-instrument, fp16 MFMA conv path (frameSize 4096 blackmanharris, separate_bach10.py:325)
+        arch_name, Nf, ov, window, f16, batch, seed = "bach10", 4096, 25, dcs.blackmanharris, True, 32, 3
+        Lc = 441000
+        audio = synth_audio(Lc, seed=0)
+        library, melody = False, None
+        what = "Bach10 4-instrument separate_bach10 path (BASELINE configs[3]): frameSize=4096 hop=512 blackmanharris, overlap 25, 10 s mono, conv2 / conv2^T with f16 inputs + f32 accumulation (MFMA), everything else f32"
+    elif name == "score_informed":
+        # BASELINE configs[4]: score-conditioned masks, batch=128 (4-channel input [128,4,30,2049])
+        arch_name, Nf, ov, window, f16, batch, seed = "bach10_si", 4096, 25, dcs.blackmanharris, False, 128, 5
+        Lc = samples_for_tiles(128, library=True)
+        audio = synth_audio(Lc, seed=4)
+        library = True
+        from deepconvsep_amd import score
+        tmp = tempfile.mkdtemp(prefix="dcs_score_")
+        files = []
+        for i in range(4):
+            files.append("inst%d.txt" % i)
+            with open(os.path.join(tmp, files[-1]), "w") as fh:
+                fh.write(synth_score_text(40 + i, Lc / float(SR) + 0.5, 40 + 5 * i, 64 + 6 * i))
+        nframes = int(np.ceil(Lc / float(HOP))) + 2
+        melody = score.melody_table(files, tmp, nframes, SR, HOP, Nf)
+        what = "bach10_scoreinformed path (BASELINE configs[4]): frameSize=4096 hop=512 blackmanharris, 4 score channels, one batch of 128 library tiles (7.67 s), f32"
+    else:
+        raise ValueError("unknown leg %r" % name)
+
+    arch = ARCHS[arch_name]
+    Fb = Nf // 2 + 1
+    params = synth_params(arch_name, TC, Fb, seed=seed)
+    sep = dcs.Separator(arch_name, params, SCALE, TC, ov, batch, Fb, Nf, HOP, window,
+                        tiler='library' if library else 'script')
+    if f16:
+        sep.net.set_conv_precision('f16')
+    tiler = TILER_LIBRARY if library else TILER_SCRIPT
+    Tfr = _lib.frame_count(Lc, HOP)
+    n = _lib.tile_count(Tfr, TC, ov, tiler)
+    a = ctx.to_device(audio, np.float32)
+    out = torch.empty((arch.S, Lc), dtype=torch.float32, device=a.device)
+
+    def run():
+        if melody is not None:
+            return sep.separate_scoreinformed_device(a, melody)
+        return sep.net.separate(sep.plan, a, ov, tiler, SCALE, out=out)
+
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    per, tot = [], 0.0
+    while tot < 0.25 or len(per) < 3:
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        per.append(time.perf_counter() - t0)
+        tot += per[-1]
+    sec = statistics.median(per)
+    ctx.timing("all")
+    ctx.timing_reset()
+    reps = 3
+    for _ in range(reps):
+        run()
+    k_ms, k_launch = {}, {}
+    for tag in _lib.TAGS:
+        ms, cnt = ctx.timing_query(tag)
+        if cnt:
+            k_ms[tag] = round(ms * cnt / reps, 5)
+            k_launch[tag] = cnt // reps
+    ctx.timing(None)
+    ctx.timing_reset()
+    # dominant kernel among the network's kernels; priced per launch (a clip may go through in several chunks /
+    # batches: launches-per-clip launches of n / launches tiles each)
+    work_tags = [t for t in ("conv1", "conv2", "fc", "fc1x", "deconv2", "final") if t in k_ms]
+    dom = max(work_tags, key=lambda t: k_ms[t])
+    per_tag_launches = {"fc1x": len(arch.branch_fc)}          # one GEMM per branch
+    calls = max(1, k_launch[dom] // per_tag_launches.get(dom, 1))   # network passes per clip
+    tiles_per_pass = n / float(calls)
+    work = arch_work(arch, TC, Fb, tiles_per_pass, f16)
+    flops, nbytes, peak = work[dom]
+    roofline = kernel_roofline(dom, k_ms[dom] / calls, flops, nbytes, peak, KERNEL_NAMES[dom])
+    roofline["tiles_per_launch"] = round(tiles_per_pass, 1)
+    roofline["timed"] = "HIP events around every kernel of %d instrumented whole-path passes (separate from the timed passes)" % reps
+    table = {}
+    for t in work_tags:
+        fl, by, pk = arch_work(arch, TC, Fb, n / float(max(1, k_launch[t] // per_tag_launches.get(t, 1))), f16)[t]
+        r = kernel_roofline(t, k_ms[t] / max(1, k_launch[t] // per_tag_launches.get(t, 1)), fl, by, pk, KERNEL_NAMES[t])
+        table[t] = {"ms_per_clip": k_ms[t], "bound": r["bound"], "frac": r["frac"]}
+    frames = Tfr
+    total_flops = n * arch.flops_per_tile(TC, Fb)
+    res = {"workload": what, "tiles": int(n), "frames": int(frames), "audio_seconds": round(Lc / float(SR), 2),
+           "batch_size": batch, "ms_per_clip": round(sec * 1e3, 4), "rounds": len(per),
+           "value": round(frames / sec, 1), "unit": "frames/s", "x_realtime": round(Lc / float(SR) / sec, 1),
+           "dtype": "f16 conv2 inputs / f32 accumulate, f32 elsewhere" if f16 else "f32",
+           "kernels_ms": k_ms, "kernels_ms_sum": round(sum(k_ms.values()), 5), "kernel_rooflines": table,
+           "whole_path_algorithmic_tflops": round(total_flops / sec / 1e12, 2),
+           "roofline": roofline}
+    if with_cpu:
+        from oracle import pipeline, tiling_np
+        # bounded sample of the same input: the first ~32 tiles (the reference's batch), about 10 s of CPU work
+        n_s = min(int(n), 32)
+        Ls = min(Lc, samples_for_tiles(n_s, ov=ov, library=library))
+        audio_s = np.asarray(audio[:Ls], dtype=np.float64)
+        T_s = int(np.ceil(Ls / float(HOP))) + 2
+        if melody is not None:
+            mel_s = melody.copy()
+
+            def run_cpu():
+                pipeline.separate_scoreinformed(params, audio_s, mel_s, SCALE, TC, ov, 32, Nf, HOP, window)
+        else:
+            def run_cpu():
+                pipeline.separate(arch_name, params, audio_s, SCALE, TC, ov, 32, Nf, HOP, window,
+                                  tiler=tiling_np.LIBRARY if library else tiling_np.SCRIPT)
+        nt = min(16, ncpu)
+        torch.set_num_threads(nt)
+        sec_c, reps_c, el_c = time_cpu(run_cpu, 6.0, 50)
+        torch.set_num_threads(1)
+        sec_1, reps_1, el_1 = time_cpu(run_cpu, 4.0, 50)
+        torch.set_num_threads(nt)
+        res["cpu_baseline"] = {"value": round(T_s / sec_c, 1), "unit": "frames/s", "cores": int(nt), "kind": "port",
+                               "single_thread": {"value": round(T_s / sec_1, 1), "cores": 1},
+                               "cpu_model": cpu_name, "host_cpu_count": int(ncpu),
+                               "label": "reference-equivalent CPU path (Theano unavailable)",
+                               "sample": "the first %.2f s (%d tiles, %d frames) of the same clip through the oracle "
+                                         "(reference NumPy loops + torch-CPU float64 network), %d x at %d threads "
+                                         "(%.1f s) and %d x at 1 thread (%.1f s)"
+                                         % (Ls / float(SR), n_s, T_s, reps_c, nt, el_c, reps_1, el_1)}
+    del sep, a, out, params
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

@@ -1111,9 +1111,12 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                            ctx->stream, tiles, g->W1c, g->bias1, a1b, C, tc, F, d.kw1, d.sw1, d.w1);
         tm.done();
     }
-    if (d.pool_w)
+    if (d.pool_w) {
+        DcsTimer tm(ctx, DCS_TAG_POOL);
         hipLaunchKernelGGL(pool_kernel, dim3((unsigned)dcs_cdiv(n * d.nf1 * tc * d.wp, kThreads)), dim3(kThreads), 0,
                            ctx->stream, a1b, p1, n * d.nf1 * tc, d.w1, d.wp, d.pool_w);
+        tm.done();
+    }
     // conv2 + both biases -> a2b[n][flat_p] (pad columns zeroed)
     if (g->flat_p != d.flat) DCS_HIP(hipMemsetAsync(a2b, 0, (size_t)n * g->flat_p * 4, ctx->stream));
     {
@@ -1199,10 +1202,13 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         tm.done();
     }
     // InverseLayer(., pool)
-    if (d.pool_w)
+    if (d.pool_w) {
+        DcsTimer tm(ctx, DCS_TAG_UNPOOL);
         hipLaunchKernelGGL(unpool_kernel, dim3((unsigned)dcs_cdiv(n * NB * d.nf1 * plane1, kThreads)), dim3(kThreads), 0,
                            ctx->stream, g2, a1b, g1, n * NB * d.nf1 * tc, d.nf1 * tc, NB, d.w1, d.wp, d.pool_w,
                            tie_mode == DCS_TIE_FIRST ? 1 : 0);
+        tm.done();
+    }
     // InverseLayer(., conv1): [n*NB, nf1, tc, w1] -> [n*NB, C, tc, F] = [n, NB*C, tc, F]
     {
         const int span = kThreads / d.sw1 + d.kw1 / d.sw1 + 3;
@@ -1227,6 +1233,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     {
         const int64_t plane = (int64_t)tc * F;
         const int CH = NB * C;
+        DcsTimer tm(ctx, DCS_TAG_MASK);
         // the kernel indexes out as [ch][n][plane] with n = chunk size; point it at the chunk and pass the
         // total tile count as the channel stride through a strided launch: do it per channel group instead
         // -> simplest exact form: launch with n_total as `n` stride when the chunk is the whole batch.
@@ -1243,6 +1250,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                 DCS_HIP(hipMemcpyAsync(out + ((int64_t)ch * n_total + k_first) * plane, stage + (int64_t)ch * n * plane,
                                        (size_t)n * plane * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
+        tm.done();
     }
     DCS_HIP(hipGetLastError());
     return DCS_OK;

@@ -97,11 +97,13 @@ extern "C" int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int
     if (b_rect) DCS_HIP(hipMemcpyAsync(base, rects.data(), b_rect, hipMemcpyHostToDevice, ctx->stream));
     DCS_HIP(hipMemcpyAsync(base + off_lo, lo.data(), b_val, hipMemcpyHostToDevice, ctx->stream));
     DCS_HIP(hipMemcpyAsync(base + off_hi, hi.data(), b_val, hipMemcpyHostToDevice, ctx->stream));
+    DcsTimer tm(ctx, DCS_TAG_SCORE);
     hipLaunchKernelGGL(score_floor_kernel, dim3((unsigned)n_frames, (unsigned)ninst), dim3(256), 0, ctx->stream, mag_d, ld,
                        n_frames, F, ninst, (const float*)(base + off_lo), out_d, mask_d);
     if (!rects.empty())
         hipLaunchKernelGGL(score_rect_kernel, dim3((unsigned)rects.size()), dim3(256), 0, ctx->stream, mag_d, ld, n_frames,
                            F, ninst, (const ScoreRect*)base, (const float*)(base + off_hi), out_d, mask_d);
+    tm.done();
     DCS_HIP(hipGetLastError());
     // the staging buffer and the host vectors must outlive the copies and the kernels
     DCS_HIP(hipStreamSynchronize(ctx->stream));

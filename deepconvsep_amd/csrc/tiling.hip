@@ -92,8 +92,10 @@ extern "C" int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int
 int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F, int tc,
                     int ov, int tiler, float scale, float* tiles, int64_t n) {
     (void)tiler;
+    DcsTimer tm(ctx, DCS_TAG_TILE);
     hipLaunchKernelGGL(tile_kernel, dim3((unsigned)n, (unsigned)(C * tc)), dim3(kThreads), 0, ctx->stream, mag,
                        ch_stride, ld, C, T, F, tc, tc - ov, scale, tiles);
+    tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }
@@ -101,8 +103,10 @@ int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t l
 int dcs_launch_overlap_add(dcs_ctx* ctx, const float* out, int64_t n, int S, int tc, int ov, int F,
                            const float* rise_d, float* sep, int64_t sep_stride, int64_t ld) {
     const int64_t rows = n * (tc - ov) + tc;
+    DcsTimer tm(ctx, DCS_TAG_OLA);
     hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)rows, (unsigned)S), dim3(kThreads), 0, ctx->stream, out,
                        n, S, tc, ov, F, rise_d, sep, sep_stride, ld);
+    tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }

@@ -278,12 +278,18 @@ class Separator(object):
         with one input channel per instrument (``util.generate_overlapadd``, :531) -> network (masks from the first
         ``S`` output channels, mixture = input channel 0, :473-486) -> overlapadd_multi -> iSTFT.
         ``melody``: note tables ``[instruments, notes, 2*nharmonics+3]`` (``score.melody_table``)."""
+        a = self.ctx.to_device(np.asarray(audio), np.float32)
+        return self.ctx.to_host(self.separate_scoreinformed_device(a, melody)).astype(np.float64)
+
+    @_on_ctx_stream
+    def separate_scoreinformed_device(self, a, melody):
+        """:meth:`separate_scoreinformed` on a float32 device tensor ``[L]``; returns the float32 PCM ``[S, L]`` on the
+        device.  The network runs ``batch_size`` tiles at a time, like ``predict_function2`` in the script's loop."""
         import torch
         from .score import score_masks
         if self.arch.C != np.asarray(melody).shape[0]:
             raise ValueError("the network takes %d score channels, the note table has %d"
                              % (self.arch.C, np.asarray(melody).shape[0]))
-        a = self.ctx.to_device(np.asarray(audio), np.float32)
         mag, ph = self.plan.forward(a, phase=True)
         T = int(mag.shape[0])
         mag = mag * np.float32(self.scale_factor)                       # :503
@@ -292,11 +298,10 @@ class Separator(object):
         outs = []
         for b0 in range(0, n, self.batch_size):
             outs.append(self.net.forward_masked(tiles[b0:b0 + self.batch_size], None, self.tie_mode))
-        out = torch.cat(outs, dim=1)
+        out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
         mm = overlap_add(self.ctx, out, self.overlap)
         sep = mm[:, :T].contiguous()
-        pcm = self.plan.inverse(sep, ph, n_out=int(a.numel()), pre_div=self.scale_factor)
-        return self.ctx.to_host(pcm).astype(np.float64)
+        return self.plan.inverse(sep, ph, n_out=int(a.numel()), pre_div=self.scale_factor)
 
 
 _SCRIPT_DEFAULTS = {

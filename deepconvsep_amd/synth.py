@@ -28,9 +28,10 @@ def synth_audio(n_samples, seed=0, channels=1, silence=True):
     return out[:, 0] if channels == 1 else out
 
 
-def synth_params(arch_name, tc=30, F=513, seed=1, bias_scale=0.05):
+def synth_params(arch_name, tc=30, F=513, seed=1, bias_scale=0.05, gain=1.0):
     """Glorot-uniform float32 weights with the exact ``.pkl`` shape list of the
-    architecture; small non-zero biases so every bias term is exercised."""
+    architecture; small non-zero biases so every bias term is exercised.  ``gain`` scales every weight
+    matrix / filter bank (trained networks have larger activations than a fresh Glorot draw)."""
     arch = ARCHS[arch_name]
     rs = np.random.RandomState(seed)
     params = []
@@ -38,11 +39,30 @@ def synth_params(arch_name, tc=30, F=513, seed=1, bias_scale=0.05):
         if len(shp) == 1:
             p = rs.uniform(-bias_scale, bias_scale, shp)
         elif len(shp) == 2:
-            lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+            lim = gain * np.sqrt(6.0 / (shp[0] + shp[1]))
             p = rs.uniform(-lim, lim, shp)
         else:
             rf = shp[2] * shp[3]
-            lim = np.sqrt(6.0 / ((shp[0] + shp[1]) * rf))
+            lim = gain * np.sqrt(6.0 / ((shp[0] + shp[1]) * rf))
             p = rs.uniform(-lim, lim, shp)
         params.append(p.astype(np.float32))
     return params
+
+
+_NOTE_NAMES = ("C", "C#", "D", "Eb", "E", "F", "F#", "G", "Ab", "A", "Bb", "B")
+
+
+def synth_score_text(seed, seconds, lo=45, hi=76, mean_note=0.35):
+    """A seeded monophonic score in the text format the score-informed script reads
+    (``onset,offset,name`` per line, examples/bach10_scoreinformed/separate_bach10.py:455-518): notes of random
+    length and pitch in MIDI ``[lo, hi)`` back to back with occasional rests, until ``seconds``."""
+    rs = np.random.RandomState(seed)
+    t, lines = float(rs.uniform(0.0, 0.3)), []
+    while True:
+        dur = float(rs.uniform(0.4, 1.6)) * mean_note
+        if t + dur > seconds:
+            break
+        midi = int(rs.randint(lo, hi))
+        lines.append("%.3f,%.3f,%s%d" % (t, t + dur, _NOTE_NAMES[midi % 12], midi // 12 - 1))
+        t += dur + (float(rs.uniform(0.05, 0.4)) if rs.uniform() < 0.25 else 0.0)
+    return "\n".join(lines) + "\n"

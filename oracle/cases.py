@@ -1,0 +1,105 @@
+"""Seeded network test cases shared by ``tests/golden/make_golden.py`` and the tests (test infrastructure).
+
+A case = (graph, feature size, batch, seed, weight kind).  The weight kinds go beyond a fresh Glorot draw, whose
+activations are dense and well conditioned:
+
+``glorot``    ``deepconvsep_amd.synth.synth_params`` as is.
+``sparse``    trained-like statistics: larger weights (gain 1.6), dense-layer biases in ``[-0.5, 0.05]``, and the output
+              bias of every channel set so that about 92 % of the network outputs are cut to exactly zero by the final
+              rectifier -- whole regions where every source is 0 (convention A: masks 1/S; convention B: 0).
+``tiny``      like ``sparse`` at 50 %, but each output channel's bias is shifted so that one of its bins comes out as
+              ``1e-10`` (and others land within 1e-9 .. 1e-6 of zero on either side): the region where
+              ``max(x, 0) + eps`` and ``max(x, eps)`` differ and where float32 cannot tell a tiny positive from 0.
+``dominant``  one branch dominant: output bias of channel 0 raised by the 99th percentile of the pre-bias output, the
+              others cut at 90 %.
+
+The output biases are calibrated on the float64 oracle and STORED in the fixture, so the GPU box rebuilds exactly
+the same parameters from (seed, kind, stored bias) without the reference tree.
+"""
+import numpy as np
+
+from deepconvsep_amd.arch import ARCHS
+from deepconvsep_amd.synth import synth_params
+
+from . import net_ref
+
+KINDS = ("glorot", "sparse", "tiny", "dominant")
+
+
+def make_input(arch, B, tc, F, seed):
+    """float32-valued tiles: 0.3 * U(0, 3), digital-silence rows inside tile 0 (max-pool ties), a silent last tile when
+    B > 1."""
+    rs = np.random.RandomState(seed)
+    C = ARCHS[arch].C
+    x = (0.3 * rs.uniform(0, 3, (B, C, tc, F))).astype(np.float32)
+    x[0, :, 4:9] = 0.0
+    if B > 1:
+        x[B - 1] = 0.0
+    return x
+
+
+def base_params(arch, tc, F, seed, kind):
+    if kind == "glorot":
+        return synth_params(arch, tc, F, seed=seed)
+    params = synth_params(arch, tc, F, seed=seed, gain=1.6)
+    rs = np.random.RandomState(seed + 1000)
+    n_fc = ARCHS[arch].n_fc
+    for i in [7] + [9 + 2 * k for k in range(n_fc)]:      # bottleneck and per-source dense biases
+        params[i] = rs.uniform(-0.5, 0.05, params[i].shape).astype(np.float32)
+    return params
+
+
+def pre_bias_output(arch, params, x):
+    """Network output before the output BiasLayer / rectifier (float64): evaluated with a bias large enough to keep
+    the rectifier inactive, which is then subtracted (exact to ~1e-13 at these magnitudes)."""
+    big = 64.0
+    probe = [np.array(p) for p in params]
+    probe[-1] = np.full(probe[-1].shape, big, dtype=np.float32)
+    y = net_ref.forward(arch, probe, np.asarray(x, dtype=np.float64), inverse='explicit').numpy()
+    assert y.min() > 0
+    return y - big
+
+
+def calibrate(arch, tc, F, seed, kind, x):
+    """Parameters of the case with the output bias calibrated for ``kind`` (float32, like a ``.pkl``)."""
+    params = base_params(arch, tc, F, seed, kind)
+    if kind == "glorot":
+        return params
+    y = pre_bias_output(arch, params, x)                     # [B, ch, tc, F]
+    ch = y.shape[1]
+    live = y[np.abs(x).sum(axis=(1, 2, 3)) > 0]              # calibrate on the tiles that have input
+    bias = np.zeros(ch)
+    for c in range(ch):
+        v = live[:, c].ravel()
+        if kind == "sparse":
+            bias[c] = -np.quantile(v, 0.92)
+        elif kind == "dominant":
+            bias[c] = np.quantile(np.abs(v), 0.99) if c == 0 else -np.quantile(v, 0.90)
+        else:                                                # tiny: one bin of the channel comes out as 1e-10
+            bias[c] = -(np.sort(v)[v.size // 2]) + 1e-10
+    params[-1] = bias.astype(np.float32)
+    return params
+
+
+def case_params(arch, tc, F, seed, kind, out_bias=None):
+    """Rebuild the parameters of a case from its seed and the stored calibrated output bias."""
+    params = base_params(arch, tc, F, seed, kind)
+    if out_bias is not None:
+        params[-1] = np.asarray(out_bias, dtype=np.float32)
+    return params
+
+
+# (name, graph, F, batch, seed, kind): the committed network fixtures tests/golden/net_*.npz
+NET_CASES = [
+    ("net_dsd_f65_glorot", "dsd", 65, 2, 31, "glorot"),
+    ("net_dsd_f33_sparse", "dsd", 33, 2, 32, "sparse"),
+    ("net_dsd_f33_tiny", "dsd", 33, 2, 33, "tiny"),
+    ("net_dsd_f33_dominant", "dsd", 33, 2, 34, "dominant"),
+    ("net_ikala_f270_glorot", "ikala", 270, 1, 35, "glorot"),
+    ("net_ikala_f270_sparse", "ikala", 270, 1, 36, "sparse"),
+    ("net_bach10_f129_glorot", "bach10", 129, 1, 37, "glorot"),
+    ("net_bach10_f129_sparse", "bach10", 129, 1, 38, "sparse"),
+    ("net_bach10_f129_tiny", "bach10", 129, 1, 39, "tiny"),
+    ("net_bach10si_f129_sparse", "bach10_si", 129, 1, 40, "sparse"),
+    ("net_dsdild_f33_glorot", "dsd_ild", 33, 1, 41, "glorot"),
+]

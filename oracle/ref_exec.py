@@ -116,3 +116,93 @@ def lib_stft():
 
 def lib_tiling():
     return load("lib_tiling")
+
+
+# ------------------------------------------------------------------------------------------------ networks
+# The reference's own build_ca source and mask expressions, executed with oracle.lasagne_np standing in for
+# ``lasagne`` (eager NumPy float64).  Graph construction, filter sizes, the fc12 alias, the parameter order of
+# set_all_param_values and the mask arithmetic then come from the reference's code; the semantics of the nine Lasagne
+# layer classes are restated third-party behaviour (lasagne_np's docstring).
+_NET_FILES = {
+    "dsd": "examples/dsd100/separate_dsd.py",
+    "hiphop": "examples/hiphopss/separate_hhds.py",
+    "ikala": "examples/ikala/separate_ikala.py",
+    "bach10": "examples/bach10/separate_bach10.py",
+    "bach10_si": "examples/bach10_scoreinformed/separate_bach10.py",
+    "dsd_ild": "examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py",     # a trainer: build_ca only, returns a dict of layers
+}
+
+
+def _file_lines(relpath):
+    with open(os.path.join(REFERENCE_ROOT, relpath), "r") as fh:
+        return fh.readlines()
+
+
+def _def_block(lines, name):
+    """Source of the top-level function ``name``: from its ``def`` to the line before the next top-level statement."""
+    start = next(i for i, l in enumerate(lines) if l.startswith("def %s(" % name))
+    end = start + 1
+    while end < len(lines) and (lines[end].strip() == "" or lines[end][0] in " \t#"):
+        end += 1
+    return "".join(lines[start:end]), start + 1
+
+
+def build_network(arch, x, time_context=None, **extra):
+    """Run the reference's ``build_ca`` of ``arch`` on the input batch ``x [B, C, tc, F]`` (the ndarray is what the
+    script passes as ``input_var``).  Returns (output layer, lasagne stand-in module)."""
+    import textwrap  # noqa: F401
+    from . import lasagne_np
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    x = np.asarray(x, dtype=np.float64)
+    B, C, tc, F = x.shape
+    src, first = _def_block(_file_lines(_NET_FILES[arch]), "build_ca")
+    ns = dict(np=np, lasagne=lasagne_np, __name__="ref_exec.net." + arch)
+    exec(compile("\n" * (first - 1) + src, _NET_FILES[arch], "exec"), ns)
+    kw = dict(input_var=x, batch_size=B, time_context=tc, feat_size=F)
+    if arch in ("bach10_si", "dsd_ild"):
+        kw["nchannels"] = C
+    kw.update(extra)
+    net = ns["build_ca"](**kw)
+    return (net["l_out"] if isinstance(net, dict) else net), lasagne_np
+
+
+def network_param_shapes(arch, B, C, tc, F):
+    """Shapes in the order ``lasagne.layers.set_all_param_values`` expects for the reference's graph."""
+    out, L = build_network(arch, np.zeros((B, C, tc, F)))
+    return [p.shape for p in L.get_all_params(out)]
+
+
+def network_output(arch, params, x, tie_mode="all"):
+    """``lasagne.layers.get_output(network2, deterministic=True)`` of the reference's graph with ``params`` set by
+    ``set_all_param_values`` (separate_dsd.py:246-252): float64 ``[B, branches*C, tc, F]``."""
+    out, L = build_network(arch, x)
+    L.set_all_param_values(out, [np.asarray(p, dtype=np.float64) for p in params])
+    L.TIE_MODE[0] = tie_mode
+    try:
+        return L.get_output(out, deterministic=True)
+    finally:
+        L.TIE_MODE[0] = "all"
+
+
+def mask_sources(arch, prediction2, x, rand=0.5):
+    """The reference's mask expressions (the lines of ``train_auto`` between the last ``rand_num = np.random.uniform``
+    draw and ``predict_function2=theano.function(...)``), executed on ndarrays; the unseeded draw is replaced by the
+    constant ``rand``.  Returns the list of outputs named in the ``theano.function`` call."""
+    import re
+    import textwrap
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    lines = _file_lines(_NET_FILES[arch])
+    t0 = next(i for i, l in enumerate(lines) if l.startswith("def train_auto("))
+    fn = next(i for i in range(t0, len(lines)) if "predict_function2" in lines[i] and "theano.function" in lines[i])
+    draw = max(i for i in range(t0, fn) if "rand_num = np.random.uniform" in lines[i])
+    eps_line = next(l for l in lines[t0:fn] if re.match(r"\s*eps\s*=", l))
+    body = textwrap.dedent("".join(lines[draw + 1:fn]))
+    names = re.search(r"\[input_var2\]\s*,\s*\[([^\]]*)\]", lines[fn]).group(1).split(",")
+    x = np.asarray(x, dtype=np.float64)
+    ns = dict(np=np, prediction2=np.asarray(prediction2, dtype=np.float64), input_var2=x,
+              rand_num=np.full((x.shape[0], 1) + x.shape[2:], float(rand)))
+    exec(textwrap.dedent(eps_line), ns)
+    exec(compile("\n" * (draw + 1) + body, _NET_FILES[arch], "exec"), ns)
+    return [np.asarray(ns[n.strip()]) for n in names]

@@ -145,5 +145,30 @@ def main():
         print(name, melody.shape, nums, int((mask == 1).sum()))
 
 
+def networks():
+    """Network fixtures: the reference's OWN ``build_ca`` source and mask expressions executed on the NumPy Lasagne
+    stand-in (oracle/lasagne_np.py) -- graph wiring, filter sizes, parameter order and mask arithmetic come from the
+    reference's code; the layer semantics are restated Lasagne / Theano behaviour (PARITY of those stays unpinned)."""
+    from oracle import cases
+    for name, arch, F, B, seed, kind in cases.NET_CASES:
+        x = cases.make_input(arch, B, 30, F, seed + 500)
+        params = cases.calibrate(arch, 30, F, seed, kind, x)
+        shapes = ref_exec.network_param_shapes(arch, B, x.shape[1], 30, F)
+        assert [tuple(s_) for s_ in shapes] == [tuple(p_.shape) for p_ in params], name
+        p = ref_exec.network_output(arch, params, x)
+        d = dict(arch=arch, F=F, B=B, seed=seed, kind=kind, x=x, out_bias=params[-1], p=p,
+                 n_params=len(params), zero_fraction=float((p == 0).mean()))
+        if arch == "ikala":
+            d["p_tie_first"] = ref_exec.network_output(arch, params, x, tie_mode="first")
+        if arch != "dsd_ild":
+            d["masked"] = np.stack(ref_exec.mask_sources(arch, p, x))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, p.shape, "zeros %.3f" % d["zero_fraction"], "max %.3f" % p.max())
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "networks":
+        networks()
+        raise SystemExit(0)
+
     main()

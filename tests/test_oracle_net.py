@@ -131,3 +131,91 @@ def test_stereo_ild_graph_autograd_equals_explicit_and_masks_per_channel():
         tot = out[j].sum(axis=1)
         ok = den > 1e-6
         assert np.max(np.abs(tot[ok] - x[:, j][ok])) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ reference graphs
+# tests/golden/net_*.npz: the reference's own build_ca source and mask expressions executed on the NumPy Lasagne
+# stand-in (oracle/lasagne_np.py, oracle/ref_exec.py:build_network) -- see make_golden.py:networks().
+from oracle import cases, ref_exec  # noqa: E402
+
+NET_NAMES = [c[0] for c in cases.NET_CASES]
+
+
+def _case(golden, name):
+    g = golden(name)
+    arch, F, seed, kind = str(g["arch"]), int(g["F"]), int(g["seed"]), str(g["kind"])
+    params = cases.case_params(arch, 30, F, seed, kind, g["out_bias"] if kind != "glorot" else None)
+    assert len(params) == int(g["n_params"])
+    return g, arch, params
+
+
+@pytest.mark.parametrize("name", NET_NAMES)
+def test_net_ref_matches_the_reference_graph_fixtures(golden, name):
+    """oracle.net_ref (torch float64, both InverseLayer formulations) against the outputs of the reference's own
+    graph-construction code on the Lasagne stand-in: network output, tie routing, masks -- 1e-12."""
+    g, arch, params = _case(golden, name)
+    x = g["x"].astype(np.float64)
+    for how in ("explicit", "autograd"):
+        p = net_ref.forward(arch, params, x, inverse=how).detach().numpy()
+        assert p.shape == g["p"].shape
+        assert np.max(np.abs(p - g["p"])) < 1e-12
+    assert abs(float((g["p"] == 0).mean()) - float(g["zero_fraction"])) < 1e-12
+    if str(g["kind"]) == "sparse":
+        live = g["p"][np.abs(x).sum(axis=(1, 2, 3)) > 0]
+        assert (live == 0).mean() >= 0.9            # trained-like statistics: >= 90 % of the outputs are exactly zero
+    if "p_tie_first" in g.files:
+        p1 = net_ref.forward(arch, params, x, tie_mode='first', inverse='explicit').numpy()
+        assert np.max(np.abs(p1 - g["p_tie_first"])) < 1e-12
+        assert np.max(np.abs(g["p_tie_first"] - g["p"])) > 1e-6      # the silent rows do tie
+    if "masked" in g.files:
+        m = net_ref.predict(arch, params, x, inverse='explicit')
+        assert len(m) == g["masked"].shape[0]
+        for a, b in zip(m, g["masked"]):
+            assert np.max(np.abs(a - b)) < 1e-12
+
+
+@pytest.mark.skipif(not ref_exec.available(), reason="needs /root/reference (build container only)")
+@pytest.mark.parametrize("arch,C,F", [("dsd", 1, 513), ("dsd", 1, 1025), ("hiphop", 1, 513), ("ikala", 1, 513),
+                                      ("ikala", 1, 1025), ("bach10", 1, 2049), ("bach10_si", 4, 2049),
+                                      ("dsd_ild", 2, 513)])
+def test_parameter_order_comes_from_the_reference_graph(arch, C, F):
+    """``get_all_params`` of the reference's own build_ca at the real sizes == the shape list the HIP model checks
+    (deepconvsep_amd.arch) and the one the torch oracle uses -- count, order and shapes (13 / 15 / 17 arrays)."""
+    shapes = [tuple(s) for s in ref_exec.network_param_shapes(arch, 32, C, 30, F)]
+    a = "dsd" if arch == "hiphop" else arch
+    assert shapes == [tuple(s) for s in ARCHS[a].param_shapes(30, F)]
+    assert shapes == [tuple(s) for s in net_ref.SPECS[a].param_shapes(30, F)]
+
+
+@pytest.mark.skipif(not ref_exec.available(), reason="needs /root/reference (build container only)")
+@pytest.mark.parametrize("name", ["net_dsd_f33_tiny", "net_ikala_f270_sparse", "net_bach10si_f129_sparse"])
+def test_fixtures_regenerate_bit_for_bit(golden, name):
+    g, arch, params = _case(golden, name)
+    p = ref_exec.network_output(arch, params, g["x"])
+    assert np.array_equal(p, g["p"])
+    assert np.array_equal(np.stack(ref_exec.mask_sources(arch, p, g["x"])), g["masked"])
+    x = g["x"]
+    fresh = cases.calibrate(arch, 30, int(g["F"]), int(g["seed"]), str(g["kind"]), x)
+    assert np.array_equal(fresh[-1], g["out_bias"])
+
+
+def test_lasagne_standin_layer_order_and_alias():
+    """The stand-in's get_all_layers / get_all_params on a hand-built graph with a shared layer and an InverseLayer:
+    incoming layers before the layer, each once, W before b."""
+    from oracle import lasagne_np as L
+    x = np.zeros((2, 1, 6, 8))
+    l_in = L.InputLayer((2, 1, 6, 8), input_var=x)
+    c1 = L.Conv2DLayer(l_in, 3, (1, 8), nonlinearity=None)
+    b1 = L.BiasLayer(c1)
+    d = L.DenseLayer(b1, 5)
+    d2 = L.DenseLayer(d, 3 * 6)
+    r = L.ReshapeLayer(d2, (2, 3, 6, 1))
+    inv = L.InverseLayer(r, c1)
+    out = L.NonlinearityLayer(L.BiasLayer(L.ConcatLayer([inv, inv], axis=1)))
+    names = [type(l).__name__ for l in L.get_all_layers(out)]
+    assert names == ["InputLayer", "Conv2DLayer", "BiasLayer", "DenseLayer", "DenseLayer", "ReshapeLayer",
+                     "InverseLayer", "ConcatLayer", "BiasLayer", "NonlinearityLayer"]
+    assert [p.shape for p in L.get_all_params(out)] == [(3, 1, 1, 8), (3,), (3,), (18, 5), (5,), (5, 18), (18,), (2,)]
+    with pytest.raises(ValueError):
+        L.set_all_param_values(out, [np.zeros(1)])
+    assert L.get_output(out).shape == (2, 2, 6, 8)
