@@ -161,5 +161,6 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag);
 // ---------------------------------------------------------------------------------- tiling kernels
 int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F,
                     int tc, int ov, int tiler, float scale, float* tiles, int64_t n);
+// out: source s of the n tiles at out + s * out_src_stride (0: dense [S][n][tc][F])
 int dcs_launch_overlap_add(dcs_ctx* ctx, const float* out, int64_t n, int S, int tc, int ov, int F,
-                           const float* rise_d, float* sep, int64_t sep_stride, int64_t ld);
+                           const float* rise_d, float* sep, int64_t sep_stride, int64_t ld, int64_t out_src_stride = 0);

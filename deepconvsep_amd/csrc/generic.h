@@ -18,6 +18,8 @@ void dcs_generic_destroy(DcsGenericNet* g);
 int dcs_generic_set_conv_f16(DcsGenericNet* g, int on);
 // tiles [n, C, tc, F] -> mask_mode 0/1: out [S, n, tc, F] masked; mask_mode 2: p [n, n_branch*C, tc, F]
 int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mask_mode, int tie_mode, float* out);
+// n_clips equal-length clips (clip c at audio + c * audio_stride) go through one set of launches: their tiles are
+// stacked into one batch for the network; pcm [n_clips][S][L].  The spectra outputs are single-clip only.
 int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm, float* sep_out, float* mag_out, float* phase_out,
-                         int64_t ld_out, DcsBuffer* ws);
+                         int64_t ld_out, DcsBuffer* ws, int64_t n_clips = 1, int64_t audio_stride = 0);

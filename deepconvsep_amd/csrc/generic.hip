@@ -1081,6 +1081,8 @@ int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16
     return DCS_OK;
 }
 
+static const bool kF16Igemm = getenv("DCS_F16_IGEMM") && atoi(getenv("DCS_F16_IGEMM")) != 0;
+
 // one chunk of tiles through the graph; scratch carved from `w`
 int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_total, int64_t k_first, int mask_mode,
                   int tie_mode, float* out, char* w) {
@@ -1132,7 +1134,9 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = 0; c.kh = d.kh2;
             DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr));
-        } else if (g->conv_f16)
+        } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
+            // general filters (iKala, 10 x 20): the f32 slab kernel beats the f16 implicit GEMM (10 s: 1.9 vs 2.4 ms), so the
+            // switch keeps it unless DCS_F16_IGEMM=1 asks for the f16 kernel
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2m_h);
         else {
@@ -1184,7 +1188,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.Wk = g->Wcol_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = d.kh2 - 1; c.kh = d.kh2;
             DCS_CHECK(launch_colconv(ctx, c, n * NB, g->conv_f16 ? g->Wcol_t_h : nullptr));
-        } else if (g->conv_f16)
+        } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2t_h);
         else {
@@ -1295,17 +1299,20 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
 
 int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm, float* sep_out, float* mag_out, float* phase_out,
-                         int64_t ld_out, DcsBuffer* ws) {
-    // The un-fused composition of the public operators: STFT -> tiles -> network -> cross-fade -> iSTFT.
+                         int64_t ld_out, DcsBuffer* ws, int64_t n_clips, int64_t audio_stride) {
+    // The un-fused composition of the public operators: STFT -> tiles -> network -> cross-fade -> iSTFT.  Equal-length
+    // clips share the launches: one STFT / iSTFT launch over all clips and ONE pass of all their tiles through the
+    // network (the dense layers' weights -- 853 MB for Bach10 -- are then read once for the whole group).
     dcs_ctx* ctx = g->ctx;
     const int tc = g->tc, F = g->F, st = tc - ov, S = g->d.S;
     const int64_t T = dcs_frame_count(L, plan->hop);
     const int64_t n = dcs_tile_count(T, tc, ov, tiler);
     const int64_t ld = dcs_round_up(F, 4);
     const int64_t rows = n * st + tc;  // rows of the stitched spectrogram (>= T)
-    const size_t b_mag = align256((size_t)T * ld * 4), b_unit = 2 * b_mag, b_ph = phase_out ? b_mag : 0;
-    const size_t b_tiles = align256((size_t)n * tc * F * 4), b_out = align256((size_t)S * n * tc * F * 4);
-    const size_t b_sep = align256((size_t)S * rows * ld * 4);
+    const int64_t n_all = n * n_clips;
+    const size_t b_mag = align256((size_t)n_clips * T * ld * 4), b_unit = 2 * b_mag, b_ph = phase_out ? b_mag : 0;
+    const size_t b_tiles = align256((size_t)n_all * tc * F * 4), b_out = align256((size_t)S * n_all * tc * F * 4);
+    const size_t b_sep = align256((size_t)n_clips * S * rows * ld * 4);
     DCS_CHECK(ws->ensure(b_mag + b_unit + b_ph + b_tiles + b_out + b_sep));
     char* p = (char*)ws->ptr;
     float* mag = (float*)p; p += b_mag;
@@ -1314,9 +1321,10 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
     float* tiles = (float*)p; p += b_tiles;
     float* outm = (float*)p; p += b_out;
     float* sep = (float*)p; p += b_sep;
-    DCS_CHECK(dcs_launch_stft_forward_f32(plan, audio, L, mag, phase, unit, ld, T, T));
-    DCS_CHECK(dcs_launch_tile(ctx, mag, 0, ld, 1, T, F, tc, ov, tiler, scale, tiles, n));
-    DCS_CHECK(dcs_generic_forward(g, tiles, n, eps_mode, tie_mode, outm));
+    DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio, L, audio_stride, n_clips, mag, phase, unit, ld, T, T));
+    for (int64_t c = 0; c < n_clips; ++c)
+        DCS_CHECK(dcs_launch_tile(ctx, mag + c * T * ld, 0, ld, 1, T, F, tc, ov, tiler, scale, tiles + c * n * tc * F, n));
+    DCS_CHECK(dcs_generic_forward(g, tiles, n_all, eps_mode, tie_mode, outm));
     if (g->rise_ov != ov) {
         std::vector<float> r(ov > 0 ? ov : 1, 0.f);
         if (ov > 1) {
@@ -1333,9 +1341,13 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
         DCS_HIP(hipMemcpy(g->rise_d, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
         g->rise_ov = ov;
     }
-    DCS_CHECK(dcs_launch_overlap_add(ctx, outm, n, S, tc, ov, F, g->rise_d, sep, rows * ld, ld));
+    // outm is [S][n_all][tc][F]: clip c's tiles of source s start at (s * n_all + c * n) tiles
+    for (int64_t c = 0; c < n_clips; ++c)
+        DCS_CHECK(dcs_launch_overlap_add(ctx, outm + c * n * tc * F, n, S, tc, ov, F, g->rise_d, sep + c * S * rows * ld,
+                                         rows * ld, ld, n_all * tc * (int64_t)F));
     // pad columns of sep (F..ld) are never written by the stitch; the iSTFT only reads bins < F
-    if (pcm) DCS_CHECK(dcs_launch_stft_inverse_f32(plan, sep, rows * ld, nullptr, unit, ld, T, S, scale, pcm, L));
+    if (pcm)
+        DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, rows * ld, unit, T * ld, ld, T, S, n_clips, scale, pcm, L));
     for (int s = 0; s < S && sep_out; ++s)
         DCS_HIP(hipMemcpy2DAsync(sep_out + (int64_t)s * T * ld_out, ld_out * 4, sep + (int64_t)s * rows * ld, ld * 4,
                                  (size_t)F * 4, (size_t)T, hipMemcpyDeviceToDevice, ctx->stream));

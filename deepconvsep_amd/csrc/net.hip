@@ -484,8 +484,8 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
     if (eps_mode != DCS_EPS_A && eps_mode != DCS_EPS_B) DCS_FAIL(DCS_EINVAL, "bad eps_mode");
     if (L < 1) DCS_FAIL(DCS_EINVAL, "dcs_separate: empty signal");
     if (n_clips < 1 || n_clips > 65535) DCS_FAIL(DCS_EINVAL, "dcs_separate_batch: %lld clips", (long long)n_clips);
-    if (n_clips > 1 && (m->arch != DCS_ARCH_DSD || sep_out || mag_out || phase_out || audio_stride < L))
-        DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_batch: DSD graph, PCM output and clip stride >= length only");
+    if (n_clips > 1 && (m->arch == DCS_ARCH_DSD_ILD || sep_out || mag_out || phase_out || audio_stride < L))
+        DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_batch: mono graphs, PCM output and clip stride >= length only");
     DCS_ON_DEVICE(m->ctx->device);
     const int tc = m->tc, F = m->F, st = tc - ov, S = m->d.S;
     int64_t T = dcs_frame_count(L, plan->hop);
@@ -583,7 +583,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         return DCS_OK;
     }
     return dcs_generic_separate(m->gen, plan, audio_d, L, ov, tiler, scale, eps_mode, tie_mode, pcm_d, sep_out, mag_out,
-                                phase_out, ld_out, &m->ws);
+                                phase_out, ld_out, &m->ws, n_clips, audio_stride);
 }
 
 static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,

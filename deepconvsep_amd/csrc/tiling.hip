@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kThreads) void overlap_add_kernel(const float* __re
                                                                int tc, int ov, int F,
                                                                const float* __restrict__ rise,
                                                                float* __restrict__ sep, int64_t sep_stride,
-                                                               int64_t ld) {
+                                                               int64_t ld, int64_t out_src_stride) {
     const int64_t t = blockIdx.x;
     const int s = blockIdx.y;
     const int st = tc - ov;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kThreads) void overlap_add_kernel(const float* __re
         for (int f = threadIdx.x; f < F; f += kThreads) dst[f] = 0.f;
         return;
     }
-    const float* src = out + (int64_t)s * n * tc * F;
+    const float* src = out + (int64_t)s * out_src_stride;
     for (int f = threadIdx.x; f < F; f += kThreads) {
         float acc = src[(k0 * tc + j0) * F + f];
         for (int64_t k = k0 + 1; k < n && k * st <= t; ++k) {
@@ -101,11 +101,12 @@ int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t l
 }
 
 int dcs_launch_overlap_add(dcs_ctx* ctx, const float* out, int64_t n, int S, int tc, int ov, int F,
-                           const float* rise_d, float* sep, int64_t sep_stride, int64_t ld) {
+                           const float* rise_d, float* sep, int64_t sep_stride, int64_t ld, int64_t out_src_stride) {
+    if (out_src_stride <= 0) out_src_stride = n * tc * (int64_t)F;   // dense [S][n][tc][F]
     const int64_t rows = n * (tc - ov) + tc;
     DcsTimer tm(ctx, DCS_TAG_OLA);
     hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)rows, (unsigned)S), dim3(kThreads), 0, ctx->stream, out,
-                       n, S, tc, ov, F, rise_d, sep, sep_stride, ld);
+                       n, S, tc, ov, F, rise_d, sep, sep_stride, ld, out_src_stride);
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;

@@ -122,7 +122,8 @@ int dcs_model_create(dcs_ctx* ctx, int arch, int in_channels, int time_context, 
 int dcs_model_destroy(dcs_model* m);
 int dcs_model_num_sources(const dcs_model* m);
 /* f16 = 1: conv2 and its transpose of the ikala / bach10 / score-informed graphs run with f16 inputs and
- * f32 accumulation on the matrix cores (BASELINE config 3, "fp16 MFMA conv path"); 0 (default): f32. */
+ * f32 accumulation on the matrix cores (BASELINE config 3, "fp16 MFMA conv path"); 0 (default): f32.  Graphs whose
+ * conv2 filter is wider than one column (ikala, 10 x 20) keep their f32 kernel, which is the faster one there. */
 int dcs_model_set_conv_precision(dcs_model* m, int f16);
 
 /* predict_function2 (separate_dsd.py:273,298): tiles_d [n, C, tc, F] -> out_d [S, n, tc, F]
@@ -148,8 +149,8 @@ int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_s
  * audio_d + c * clip_stride (clip_stride >= n_samples), pcm_d [n_clips][S][n_samples].  Every clip is processed
  * exactly as dcs_separate would process it alone (same tiles, same cross-fade) -- the clips only share kernel
  * launches; outputs agree with the single-clip call to fp32 rounding (the FFT / GEMM kernel variants are
- * chosen by the total amount of work).  DSD / hiphop graph only (DCS_EUNSUPPORTED otherwise: loop over
- * dcs_separate).  n_tiles_out / n_frames_out are per clip. */
+ * chosen by the total amount of work).  The ikala / bach10 graphs stack the tiles of all clips into one pass of the
+ * network (their dense-layer weights are then read once per group).  n_tiles_out / n_frames_out are per clip. */
 int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,
                        int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode, int tie_mode,
                        float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out);

@@ -612,13 +612,29 @@ def test_separate_batch_equals_clip_by_clip(N, seconds, clips, tiler, hop):
     assert np.array_equal(got2, got)
 
 
-def test_separate_batch_rejects_other_graphs():
-    import torch
-    params = synth_params("ikala", 30, 513, seed=1)
-    sep = dcs.Separator("ikala", params, 0.3, 30, 20, 32, 513, 1024, 512, np.hanning)
-    buf = sep.ctx.to_device(np.zeros((2, 30000), np.float32), np.float32)
-    with pytest.raises(NotImplementedError):                    # DCS_EUNSUPPORTED: loop over separate() instead
-        sep.net.separate_batch(sep.plan, buf, 20, sep.tiler, 0.3)
+@pytest.mark.parametrize("arch,N,ov,clips,seconds", [("ikala", 1024, 20, 3, 1.1), ("bach10", 1024, 25, 2, 0.9)])
+def test_separate_batch_of_the_generic_graphs_equals_clip_by_clip(arch, N, ov, clips, seconds):
+    """dcs_separate_batch for the ikala / bach10 graphs: equal-length clips share the launches -- one STFT / iSTFT
+    launch and one pass of all their tiles through the network; every clip equals its single-clip result and the
+    oracle.  The stereo (ILD) graph and the spectra outputs stay single-clip."""
+    F = N // 2 + 1
+    params = synth_params(arch, 30, F, seed=1)
+    sep = dcs.Separator(arch, params, 0.3, 30, ov, 32, F, N, 512, np.hanning)
+    L = int(44100 * seconds)
+    audio = np.stack([synth_audio(L, seed=140 + c) for c in range(clips)]).astype(np.float32)
+    buf = sep.ctx.to_device(audio, np.float32)
+    got = sep.ctx.to_host(sep.net.separate_batch(sep.plan, buf, ov, sep.tiler, 0.3))
+    assert got.shape == (clips, ARCHS[arch].S, L)
+    for c in range(clips):
+        alone = sep.ctx.to_host(sep.net.separate(sep.plan, buf[c], ov, sep.tiler, 0.3))
+        assert np.max(np.abs(got[c] - alone)) < 5e-6, "clip %d differs from the single-clip path" % c
+    want = pipeline.separate(arch, params, audio[1].astype(np.float64), 0.3, 30, ov, 32, N, 512, np.hanning)
+    assert np.max(np.abs(got[1] - want)) < 1e-4
+    many = sep.separate_many([a.astype(np.float64) for a in audio] + [synth_audio(L + 999, seed=5)])
+    assert np.max(np.abs(many[0] - got[0])) < 5e-6 and many[-1].shape == (ARCHS[arch].S, L + 999)
+    ild = dcs.Separator("dsd_ild", synth_params("dsd_ild", 30, 513, seed=1), 0.3, 30, 25, 32, 513, 1024, 512, np.hanning)
+    with pytest.raises(NotImplementedError):
+        ild.net.separate_batch(ild.plan, buf, 25, TILER_LIBRARY, 0.3)
 
 
 @pytest.mark.parametrize("arch,F,n", [("bach10", 257, 4), ("ikala", 513, 3)])
