@@ -77,6 +77,7 @@ def load():
     proto("dcs_model_num_sources", i32, vp)
     proto("dcs_model_set_conv_precision", i32, vp, i32)
     proto("dcs_model_out_channels", i32, vp)
+    proto("dcs_model_final_kernel", i32, vp, i64, i64, i32)
     proto("dcs_model_forward_masked", i32, vp, vp, i64, i32, i32, vp)
     proto("dcs_model_forward", i32, vp, vp, i64, i32, vp)
     proto("dcs_separate", i32, vp, vp, vp, i64, i32, i32, f32, i32, i32, vp, POINTER(i64), POINTER(i64))

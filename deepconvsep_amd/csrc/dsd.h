@@ -30,8 +30,8 @@ struct DsdFinalArgs {
     int bias_half;        // 0: bias[4] per source; > 0: two input channels side by side, bins >= bias_half use bias[2 s + 1]
     int n_clips;          // stacked clips of equal length (0 or 1: a single clip); clip c uses G + c*g_clip_stride,
     int64_t g_clip_stride, mix_clip_stride, out_clip_stride;  // mix + c*mix_clip_stride, out + c*out_clip_stride
-    // opt-in bf16x3 path (dsd_bf16x3.hip): G split into three bf16 planes [item][t][3][64] and the weights split and
-    // laid out per (bin, plane, K block, lane group); null = the f32 kernel
+    // bf16x3 path (dsd_bf16x3.hip): G split into three bf16 planes [item][channel group][t][3][8] and the weights split
+    // and laid out per (bin, plane, K block, lane group); null = the f32 kernel
     const void* Gs;
     const void* Bpk;
     int64_t gs_clip_stride;   // 16-byte units
@@ -41,11 +41,18 @@ struct DsdFinalArgs {
 
 // Bw:  [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]   (few tiles)
 // Bws: [ci][16 taps][CP] holds W2c[co, ci, dt], ci padded to whole groups of 8, tap 15 zero   (many tiles)
+// Gs != null: the outputs are (also, for few tiles) produced as three bf16 planes for the bf16x3 final kernel,
+// Gs[item][channel group][t][plane][8 channels] -- 16-byte pieces, dsd_gs_pitch() of them per (tile, branch)
 int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const float* Bws, float* G, int64_t n_ks,
-                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols);
+                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols, void* Gs = nullptr);
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold);
+// column blocks per wave the final kernel will use for this launch (2: 128-bin workgroups, 1: 64-bin ones for few rows)
+int dsd_final_cbw(const dcs_ctx* ctx, int64_t rows, int F, int64_t n_clips);
+// whether the fused (fold) launch of these dimensions runs the bf16x3 kernel -- the caller then has deconv2 produce the
+// split planes (DsdFinalArgs::Gs) instead of f32 G
+bool dsd_final_bf16x3(const dcs_ctx* ctx, int64_t rows, int F, int64_t n_clips, int CI, int mask_mode);
 
-// ---- opt-in bf16x3 variant of the fused final kernel (DCS_FINAL_BF16X3=1; dsd_bf16x3.hip)
-constexpr int kDsdSplitRowU4 = 24;   // 16-byte units per (item, t) row of the split G: 3 planes x 64 channels x bf16
-int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg, int ci);
+// ---- bf16x3 variant of the fused final kernel (dsd_bf16x3.hip; DCS_FINAL_BF16X3=0 switches it off)
+inline int dsd_gs_pitch(int CI, int tc) { return ((CI + kDsdGch - 1) / kDsdGch) * tc * 3; }  // 16-byte pieces per (tile, branch)
+int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg);
 int dcs_launch_dsd_final_bf16x3(dcs_ctx* ctx, const DsdFinalArgs& a, int n_colg, int64_t n_wg, unsigned n_clips);

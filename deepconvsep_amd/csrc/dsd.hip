@@ -126,6 +126,21 @@ constexpr int kD2PsStride = 20;  // floats per skewed row: 16 taps + 4 (16-byte 
 constexpr int kD2PsChan = 32 * kD2PsStride + 32;
 constexpr int kD2PsSize = 2 * kD2PsChan;
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + mid + lo exactly, each term a bf16 (truncation split: 8 + 8 + 8 significand bits); returned as the three
+// 32-bit patterns whose upper halves are the bf16 values
+__device__ __forceinline__ void bf16_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);     // exact
+    m = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m);    // exact, at most 8 significant bits left
+    l = __float_as_uint(r2) & 0xffff0000u;
+}
+
+// SPLIT: the outputs leave as three bf16 planes, Gs[item][channel group][t][plane][8 channels] (16 bytes per piece, the
+// operand layout of final_bf16x3_kernel), instead of f32 G[item][channel group][t][8].
+template <bool SPLIT>
 __global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* __restrict__ D,
                                                                   const float* __restrict__ Bws,
                                                                   float* __restrict__ G, int64_t n_ks, int H2,
@@ -233,9 +248,25 @@ __global__ __launch_bounds__(kThreads) void deconv2_stream_kernel(const float* _
                 Os[t * GS + 2 * cp + cc] = sum;
             }
         }
-        if (lane < tc * GS / 4) {
-            const f32x4 v = reinterpret_cast<const f32x4*>(Os)[lane];
-            reinterpret_cast<f32x4*>(G + (ks * ngg + g) * (int64_t)tc * GS)[lane] = v;
+        if constexpr (SPLIT) {
+            // lane -> (t, half of the 8 channels): 4 values, all three planes; a (t, plane) piece is 16 bytes, the two
+            // halves of a piece are written by neighbouring lanes
+            if (lane < 2 * tc) {
+                const int t = lane >> 1, half = lane & 1;
+                const f32x4 v = reinterpret_cast<const f32x4*>(Os)[lane];
+                unsigned h[4], md[4], lo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf16_split3(v[j], h[j], md[j], lo[j]);
+                u32x2* dst = reinterpret_cast<u32x2*>(G) + (((ks * ngg + g) * (int64_t)tc + t) * 3) * 2 + half;
+                dst[0] = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+                dst[2] = u32x2{(md[0] >> 16) | md[1], (md[2] >> 16) | md[3]};
+                dst[4] = u32x2{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]};
+            }
+        } else {
+            if (lane < tc * GS / 4) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(Os)[lane];
+                reinterpret_cast<f32x4*>(G + (ks * ngg + g) * (int64_t)tc * GS)[lane] = v;
+            }
         }
     }
 #undef DCS_LOAD_D
@@ -294,6 +325,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     __shared__ __attribute__((aligned(16))) float down_t[kMaxM * 16];  // weight kept of what is already there
     __shared__ int meta_k0[16];
     __shared__ int meta_j0[16];
+    __shared__ int meta_mlim[16];   // last covering tile (index m) that has a weight on the row; -1: a dead row
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -346,6 +378,12 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
         if (m == 0) {
             meta_k0[i] = (int)k0;
             meta_j0[i] = j0;
+            int lim = -1;
+            if (j0 >= 0) {
+                lim = j0 / st;
+                if (lim > n - 1 - k0) lim = (int)(n - 1 - k0);
+            }
+            meta_mlim[i] = lim;
         }
         const int j = j0 - m * st;
         const bool valid = j0 >= 0 && j >= 0 && k0 + m < n;
@@ -430,31 +468,40 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     // workgroup-uniform base; the per-slot offsets stay 32-bit
     const float* gbase = a.G + clip * a.g_clip_stride + (int64_t)kbase * NBR * NGG * tc * kDsdGch;
     constexpr int NSL = (slots + kThreads - 1) / kThreads;   // float4 slots per thread: 3 (NBR = 3) or 4
-    int goff[NSL], dst[NSL], srow[NSL];
+    // A slot is loaded for EVERY covering tile: where tile m has no weight on the slot's row (up = 0, down = 1: the
+    // row keeps what it has) the address is clamped to the last tile that does -- finite values that the epilogue
+    // multiplies by up = 0 -- so the loop body has no data-dependent branch and no LDS lookup in front of its loads.
+    int goff[NSL], dst[NSL], mlim[NSL];
+    bool in_slot[NSL];
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
         const int idx = tid + u * kThreads;
         const int s = idx / (16 * NQ);
         const int rem = idx - s * 16 * NQ;
         const int i = rem / NQ, c4 = rem - i * NQ;
-        const bool in = idx < slots;
-        const int j0 = in ? meta_j0[i] : -1;
-        srow[u] = in ? i : -1;
+        const bool in = (u + 1) * kThreads <= slots || idx < slots;   // compile-time true for all but the last slot
+        in_slot[u] = in;
+        const int lim = in ? meta_mlim[i] : -1;
+        const int j0 = lim >= 0 ? meta_j0[i] : 0;            // a dead row reads row 0 of the first tile
+        const int dk = lim >= 0 ? meta_k0[i] - kbase : 0;
+        mlim[u] = lim >= 0 ? lim : 0;
         dst[u] = (s * 16 + i) * AS + c4 * 4;
-        goff[u] = ((((in ? meta_k0[i] - kbase : 0) * NBR + s) * NGG + (c4 >> 1)) * tc + (j0 < 0 ? 0 : j0)) * kDsdGch +
-                  (c4 & 1) * 4;
+        goff[u] = (((dk * NBR + s) * NGG + (c4 >> 1)) * tc + j0) * kDsdGch + (c4 & 1) * 4;
     }
     f32x4 pre[NSL];
 #define DCS_LOAD_A(m_)                                                                          \
     _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                    \
-        if (srow[u] >= 0 && up_t[(m_) * 16 + srow[u]] != 0.f)                                   \
-            v = *reinterpret_cast<const f32x4*>(gbase + (goff[u] + (m_) * m_delta));            \
+        if ((u + 1) * kThreads <= slots || in_slot[u]) {                                        \
+            const int mm = (m_) < mlim[u] ? (m_) : mlim[u];                                     \
+            v = *reinterpret_cast<const f32x4*>(gbase + (goff[u] + mm * m_delta));              \
+        }                                                                                       \
         pre[u] = v;                                                                             \
     }
 #define DCS_STORE_A(buf_)                                                                       \
     _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
-        if (srow[u] >= 0) *reinterpret_cast<f32x4*>(As + (buf_) * kABuf + dst[u]) = pre[u];     \
+        if ((u + 1) * kThreads <= slots || in_slot[u])                                          \
+            *reinterpret_cast<f32x4*>(As + (buf_) * kABuf + dst[u]) = pre[u];                   \
     }
 
     DCS_LOAD_A(0)
@@ -587,7 +634,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
 }  // namespace
 
 int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const float* Bws, float* G, int64_t n_ks,
-                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols) {
+                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols, void* Gs) {
     if (n_ks <= 0) return DCS_OK;
     const int nrb = (H2 + 15) / 16;
     if (nrb > 2) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: conv2 output height %d > 32", H2);
@@ -610,19 +657,34 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const 
         int Xt = tail_ch ? slots - n_full * X : 0;
         if (tail_ch && Xt < 1) Xt = 1;
         const size_t lds2 = ((size_t)kDsdGch * 16 * CP + 4 * (kD2PsSize + 32 * kDsdGch)) * sizeof(float);
-        auto kern = deconv2_stream_kernel;
+        auto kern = Gs ? deconv2_stream_kernel<true> : deconv2_stream_kernel<false>;
         if (lds2 > 48 * 1024)
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds2));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(n_full * X + Xt)), dim3(kThreads), lds2, ctx->stream, D, Bws, G, n_ks,
-                           H2, kh, tc, ngg, n_full, X, tail_ch, Xt);
+        // Gs: the consumer is the bf16x3 final kernel -- the three bf16 planes are written directly, f32 G is not
+        hipLaunchKernelGGL(kern, dim3((unsigned)(n_full * X + Xt)), dim3(kThreads), lds2, ctx->stream, D, Bws,
+                           Gs ? reinterpret_cast<float*>(Gs) : G, n_ks, H2, kh, tc, ngg, n_full, X, tail_ch, Xt);
+        tm.done();
     } else {
         hipLaunchKernelGGL(deconv2_kernel<13>, dim3((unsigned)n_ks, (unsigned)NG), dim3(kThreads), lds, ctx->stream, D,
                            Bw, G, H2, CP, CI, kh, tc, GS, gcols);
+        tm.done();
+        if (Gs) DCS_CHECK(dcs_launch_dsd_gsplit(ctx, G, Gs, n_ks, tc, ngg));   // few tiles: one-shot kernel, then one pass that splits G
     }
-    tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
+}
+
+int dsd_final_cbw(const dcs_ctx* ctx, int64_t rows, int F, int64_t n_clips) {
+    static const int force = getenv("DCS_FINAL_CBW") ? atoi(getenv("DCS_FINAL_CBW")) : 0;
+    if (force) return force;
+    if (n_clips < 1) n_clips = 1;
+    return dcs_cdiv(rows, 16) * ((F + 127) / 128) * n_clips >= 3 * (int64_t)ctx->n_cu ? 2 : 1;
+}
+
+bool dsd_final_bf16x3(const dcs_ctx* ctx, int64_t rows, int F, int64_t n_clips, int CI, int mask_mode) {
+    static const bool on = !(getenv("DCS_FINAL_BF16X3") && atoi(getenv("DCS_FINAL_BF16X3")) == 0);
+    return on && CI == 52 && mask_mode < 2 && dsd_final_cbw(ctx, rows, F, n_clips) == 2;
 }
 
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
@@ -632,16 +694,15 @@ int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {
     // workgroup = 16 rows x 128 bins (two column blocks per wave); with few rows (the 32-tile step has 12 row
     // groups) 16 x 64 gives twice the workgroups and half the work in each: 32 tiles 17.8 vs 19.1 us
     const int64_t n_rg = dcs_cdiv(a.rows, 16);
-    static const int force = getenv("DCS_FINAL_CBW") ? atoi(getenv("DCS_FINAL_CBW")) : 0;
     const unsigned n_clips = a.n_clips > 0 ? (unsigned)a.n_clips : 1u;
-    const int cbw = force ? force : (n_rg * ((a.F + 127) / 128) * n_clips >= 3 * (int64_t)ctx->n_cu ? 2 : 1);
+    const int cbw = dsd_final_cbw(ctx, a.rows, a.F, n_clips);
     const int n_colg = (a.F + 64 * cbw - 1) / (64 * cbw);
     if (a.ldb < n_colg * 64 * cbw || (a.ldb & 1))
         DCS_FAIL(DCS_EINVAL, "final: weight pitch %d < %d", a.ldb, n_colg * 64 * cbw);
     const int64_t n_wg = n_rg * n_colg;
     if (n_wg > 0x7fffffff) DCS_FAIL(DCS_EUNSUPPORTED, "final: %lld workgroups", (long long)n_wg);
     DcsTimer tm(ctx, DCS_TAG_FINAL);
-    if (a.Gs && a.Bpk && fold && a.nbr != 4 && cbw == 2 && a.mask_mode < 2 && a.bias_half == 0) {   // opt-in bf16x3 path
+    if (a.Gs && a.Bpk && fold && a.nbr != 4 && cbw == 2 && a.mask_mode < 2 && a.bias_half == 0) {   // bf16x3 path (the caller asked dsd_final_bf16x3)
         const int rc = dcs_launch_dsd_final_bf16x3(ctx, a, n_colg, n_wg, n_clips);
         tm.done();
         return rc;

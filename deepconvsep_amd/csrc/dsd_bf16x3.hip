@@ -1,5 +1,5 @@
-// OPT-IN experiment (DCS_FINAL_BF16X3=1, off by default): the final kernel of dsd.hip on the 16-bit-input matrix pipe
-// with fp32-class results.
+// The fused final kernel of dsd.hip on the 16-bit-input matrix pipe with fp32-class results (the default for launches
+// large enough for 128-bin workgroups; DCS_FINAL_BF16X3=0 selects the f32 kernel).
 //
 // Why: scripts/ubench/mfma16_valu.hip (profiles/r01_d_ubench_mfma16_valu.txt) -- v_mfma_f32_16x16x32_bf16 takes 6.9 ns
 // per SIMD for 16 384 flop and runs BESIDE the VALU, while the f32 MFMA (13.9 ns for 2 048 flop) executes on the
@@ -10,8 +10,10 @@
 //     a.b ~= a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)          dropped: a1 b2 + a2 b1 + a2 b2 <= 3 * 2^-24 |a b|
 // Each pair is a K = 64 (50 channels, zero padded) bf16 MFMA chain with f32 accumulation: 12 MFMAs per (branch,
 // column block, covering tile) instead of 13 f32 ones.  bf16 products are exact in f32, so the only roundings are the
-// accumulator's -- the class of the f32 kernel.  G arrives already split (g_split_kernel: one pass over G, 4 -> 6
-// bytes per value), the transposed-conv1 weights are split when the model is packed.
+// accumulator's -- the class of the f32 kernel.  G arrives already split: the streaming deconv2 kernel writes the three
+// planes itself (Gs[item][channel group][t][plane][8 channels], 16-byte pieces; 6 instead of 4 bytes per value and no
+// f32 copy), the one-shot deconv2 kernel of small launches is followed by g_split_kernel; the transposed-conv1 weights
+// are split when the model is packed.
 //
 // Everything else -- row/tile bookkeeping, cross-fade tables, soft mask, fold, stores -- is final_kernel<true, MODE, 2, 3>.
 #include "dcs_internal.h"
@@ -28,31 +30,23 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
-constexpr int kRowU4 = kDsdSplitRowU4;  // 24 x 16 bytes per (item, t): 3 planes x 64 channels x bf16
+constexpr int kNgg = 7;                 // channel groups of 8 that carry data (50 filters -> 56); group 7 of the K = 64 axis is zero
 constexpr int kRowLds = 25;             // LDS row stride in 16-byte units: 100 words, fi * 100 mod 64 = 16 distinct bank quads
 
 __device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
 
-// G f32 [item][channel group][t][8]  ->  Gs bf16 [item][t][plane][64 channels], x = plane0 + plane1 + plane2 exactly
+// G f32 [item][channel group][t][8]  ->  Gs bf16 [item][channel group][t][plane][8], x = plane0 + plane1 + plane2 exactly
 __global__ __launch_bounds__(kThreads) void g_split_kernel(const float* __restrict__ G, u32x4* __restrict__ Gs,
-                                                           int64_t n_rows /* items * tc */, int tc, int ngg, int ci /* channels that carry data */) {
-    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    const int g8 = (int)(idx & 7);
-    const int64_t it = idx >> 3;
+                                                           int64_t n_rows /* items * channel groups * tc */) {
+    const int64_t it = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (it >= n_rows) return;
-    const int64_t item = it / tc;
-    const int t = (int)(it - item * tc);
+    const f32x4* p = reinterpret_cast<const f32x4*>(G + it * 8);
+    const f32x4 x0 = p[0], x1 = p[1];
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (g8 < ngg) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(G + ((item * ngg + g8) * tc + t) * 8);
-        const f32x4 x0 = p[0], x1 = p[1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = g8 * 8 + j < ci ? x0[j] : 0.f;
-            v[4 + j] = g8 * 8 + 4 + j < ci ? x1[j] : 0.f;
-        }
+    for (int j = 0; j < 4; ++j) {
+        v[j] = x0[j];
+        v[4 + j] = x1[j];
     }
     unsigned pl[3][8];
 #pragma unroll
@@ -66,11 +60,11 @@ __global__ __launch_bounds__(kThreads) void g_split_kernel(const float* __restri
         pl[2][j] = bf_trunc(r2);
     }
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int q3 = 0; q3 < 3; ++q3) {
         u32x4 w;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = (pl[p][2 * q] >> 16) | (pl[p][2 * q + 1] & 0xffff0000u);
-        Gs[it * kRowU4 + p * 8 + g8] = w;
+        for (int q = 0; q < 4; ++q) w[q] = (pl[q3][2 * q] >> 16) | (pl[q3][2 * q + 1] & 0xffff0000u);
+        Gs[it * 3 + q3] = w;
     }
 }
 
@@ -82,6 +76,10 @@ __device__ __forceinline__ f32x2 max2(f32x2 x, float lo) {
 }
 
 __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef DCS_EXP_NOMFMA
+    c[0] += __uint_as_float(a[0] ^ b[0]);
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -95,6 +93,7 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
     __shared__ __attribute__((aligned(16))) float down_t[kMaxM * 16];
     __shared__ int meta_k0[16];
     __shared__ int meta_j0[16];
+    __shared__ int meta_mlim[16];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -132,6 +131,12 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
         if (m == 0) {
             meta_k0[i] = (int)k0;
             meta_j0[i] = j0;
+            int lim = -1;
+            if (j0 >= 0) {
+                lim = j0 / st;
+                if (lim > n - 1 - k0) lim = (int)(n - 1 - k0);
+            }
+            meta_mlim[i] = lim;
         }
         const int j = j0 - m * st;
         const bool valid = j0 >= 0 && j >= 0 && k0 + m < n;
@@ -192,42 +197,76 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 
     __syncthreads();
 
-    // staging plan: NSL 16-byte slots of the [3 branches][16 rows][24] A set per thread
-    constexpr int slots = NBR * 16 * kRowU4;                 // 1152
-    constexpr int NSL = (slots + kThreads - 1) / kThreads;   // 5
-    const int m_delta = (NBR * tc - st) * kRowU4;            // 16-byte units from covering tile m to m + 1
+    // staging plan: the A set of a covering tile is [3 branches][16 rows][3 planes][7 channel groups] 16-byte pieces
+    // (1008; the 8th group of the K = 64 axis is zeroed once below).  Slot idx -> (branch s, piece pg = plane * 7 + g, row i)
+    // with the row fastest: 16 consecutive lanes fetch the same piece of 16 consecutive frames, 48 bytes apart.
+    constexpr int slots = NBR * 16 * 3 * kNgg;               // 1008
+    constexpr int NSL = (slots + kThreads - 1) / kThreads;   // 4
+    const int m_delta = (NBR * kNgg * tc - st) * 3;          // 16-byte units from covering tile m to m + 1
     const int kbase = meta_k0[0];
-    const u32x4* gbase = reinterpret_cast<const u32x4*>(a.Gs) + clip * a.gs_clip_stride + (int64_t)kbase * NBR * tc * kRowU4;
-    int goff[NSL], dst[NSL], srow[NSL];
+    const u32x4* gbase = reinterpret_cast<const u32x4*>(a.Gs) + clip * a.gs_clip_stride + (int64_t)kbase * NBR * kNgg * tc * 3;
+    // every slot is loaded for every covering tile, with the tile index clamped to the last one that has a weight on
+    // the slot's row (see final_kernel in dsd.hip): no data-dependent branch in front of the loads
+    int goff[NSL], dst[NSL], mlim[NSL];
+    bool in_slot[NSL];
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
         const int idx = tid + u * kThreads;
-        const int s = idx / (16 * kRowU4);
-        const int rem = idx - s * 16 * kRowU4;
-        const int i = rem / kRowU4, c = rem - i * kRowU4;
-        const bool in = idx < slots;
-        const int j0 = in ? meta_j0[i] : -1;
-        srow[u] = in ? i : -1;
-        dst[u] = (s * 16 + i) * kRowLds + c;
-        goff[u] = (((in ? meta_k0[i] - kbase : 0) * NBR + s) * tc + (j0 < 0 ? 0 : j0)) * kRowU4 + c;
+        const int i = idx & 15, sp = idx >> 4;               // sp = s * 21 + plane * 7 + g
+        const int s = sp / (3 * kNgg), pg = sp - s * (3 * kNgg);
+        const int plane = pg / kNgg, g = pg - plane * kNgg;
+        const bool in = (u + 1) * kThreads <= slots || idx < slots;   // compile-time true for all but the last slot
+        in_slot[u] = in;
+        const int lim = in ? meta_mlim[i] : -1;
+        const int j0 = lim >= 0 ? meta_j0[i] : 0;
+        const int dk = lim >= 0 ? meta_k0[i] - kbase : 0;
+        mlim[u] = lim >= 0 ? lim : 0;
+        dst[u] = (s * 16 + i) * kRowLds + plane * 8 + g;
+        goff[u] = (((dk * NBR + s) * kNgg + g) * tc + j0) * 3 + plane;
+    }
+    for (int idx = tid; idx < 2 * NBR * 16 * 3; idx += kThreads) {   // K channels 56..63: zero in both buffers
+        const int buf = idx / (NBR * 16 * 3), r = idx - buf * (NBR * 16 * 3);
+        As[buf * kABuf + (r / 3) * kRowLds + (r % 3) * 8 + 7] = u32x4{0u, 0u, 0u, 0u};
     }
     u32x4 pre[NSL];
-#define DCS_LOAD_A(m_)                                                                          \
+#define DCS_LOAD_A(m_, dst_)                                                                    \
     _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
         u32x4 v = u32x4{0u, 0u, 0u, 0u};                                                        \
-        if (srow[u] >= 0 && up_t[(m_) * 16 + srow[u]] != 0.f) v = gbase[goff[u] + (m_) * m_delta]; \
-        pre[u] = v;                                                                             \
+        if ((u + 1) * kThreads <= slots || in_slot[u]) {                                        \
+            const int mm = (m_) < mlim[u] ? (m_) : mlim[u];                                     \
+            v = gbase[goff[u] + mm * m_delta];                                                  \
+        }                                                                                       \
+        dst_[u] = v;                                                                            \
     }
 #define DCS_STORE_A(buf_)                                                                       \
     _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
-        if (srow[u] >= 0) As[(buf_) * kABuf + dst[u]] = pre[u];                                 \
+        if ((u + 1) * kThreads <= slots || in_slot[u]) As[(buf_) * kABuf + dst[u]] = pre[u];    \
     }
 
-    DCS_LOAD_A(0)
+#ifndef DCS_EXP_PF
+#define DCS_EXP_PF 1
+#endif
+    // the A set of covering tile m is requested DCS_EXP_PF iterations before it is stored to LDS (an iteration is
+    // ~1 us; a first touch of G comes from HBM / the infinity cache)
+    DCS_LOAD_A(0, pre)
+#if DCS_EXP_PF == 2
+    u32x4 nxt[NSL];
+    DCS_LOAD_A(1, nxt)      // clamped addressing makes this valid for mmax == 1 too
+#endif
     for (int m = 0; m < mmax; ++m) {
         DCS_STORE_A(m & 1)
+#ifndef DCS_EXP_NOBARRIER
         __syncthreads();
-        if (m + 1 < mmax) DCS_LOAD_A(m + 1)
+#endif
+#if DCS_EXP_PF == 2
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) pre[u] = nxt[u];
+        if (m + 2 < mmax) DCS_LOAD_A(m + 2, nxt)
+#else
+#ifndef DCS_EXP_NOLOAD
+        if (m + 1 < mmax) DCS_LOAD_A(m + 1, pre)
+#endif
+#endif
         if (!live) continue;
         const u32x4* Ab = As + (m & 1) * kABuf + fi * kRowLds + kq;
         f32x4 acc[NBR][CBW];
@@ -266,6 +305,13 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[0][kb], breg[cb][0][kb], acc[s][cb]);
         }
+#ifdef DCS_EXP_NOEPI
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int s = 0; s < NBR; ++s) res[cb][s] += acc[s][cb];
+        continue;
+#endif
         const f32x4 up4 = *reinterpret_cast<const f32x4*>(up_t + m * 16 + kq * 4);
         const f32x4 down4 = *reinterpret_cast<const f32x4*>(down_t + m * 16 + kq * 4);
 #pragma unroll
@@ -333,11 +379,12 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 
 }  // namespace
 
-int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg, int ci) {
+int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg) {
     if (n_items <= 0) return DCS_OK;
-    const int64_t n_rows = n_items * tc;
-    hipLaunchKernelGGL(g_split_kernel, dim3((unsigned)dcs_cdiv(n_rows * 8, kThreads)), dim3(kThreads), 0, ctx->stream, G,
-                       reinterpret_cast<u32x4*>(Gs), n_rows, tc, ngg, ci);
+    if (ngg != kNgg) DCS_FAIL(DCS_EUNSUPPORTED, "bf16x3 final kernel: built for 50 conv1 filters (7 channel groups), got %d", ngg);
+    const int64_t n_rows = n_items * ngg * tc;
+    hipLaunchKernelGGL(g_split_kernel, dim3((unsigned)dcs_cdiv(n_rows, kThreads)), dim3(kThreads), 0, ctx->stream, G,
+                       reinterpret_cast<u32x4*>(Gs), n_rows);
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }

@@ -88,9 +88,8 @@ struct dcs_model {
     DcsGenericNet* gen = nullptr;
     // ---- scratch
     DcsBuffer ws;
-    // opt-in bf16x3 final kernel (DCS_FINAL_BF16X3=1): split weights and the split copy of G
+    // bf16x3 final kernel: the transposed-conv1 weights split into three bf16 planes
     uint16_t* Bpk = nullptr;
-    DcsBuffer gs_buf;
     DcsBuffer clip_tab;   // {samples, frames, tiles} per clip of a batch of different lengths (dcs_separate_ragged)
     float* rise_d = nullptr;
     int rise_ov = -1;
@@ -263,6 +262,7 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
 
 struct DsdScratch {
     float *H1, *C2, *Z, *D, *G;
+    void* Gs;   // bf16 planes of G for the bf16x3 final kernel (null: f32 G only)
 };
 
 // Encoder + dense layers + transposed conv2 for n tiles whose frames are rows of `rows_src`.
@@ -316,21 +316,24 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
     // InverseLayer(., l_conv2) (separate_dsd.py:211,217,223)
     return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n * n_clips * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
-                                  m->d2_gcols);
+                                  m->d2_gcols, w.Gs);
 }
 
-size_t dsd_scratch_bytes(const dcs_model* m, int64_t n, int64_t rows1, int64_t rows2) {
+size_t dsd_scratch_bytes(const dcs_model* m, int64_t n, int64_t rows1, int64_t rows2, bool split = false) {
     return align256((size_t)rows1 * m->CI * 4) + align256((size_t)rows2 * m->CP * 4) +
            align256((size_t)n * m->hid64 * 4) + align256((size_t)n * m->nd * 4) +
-           align256((size_t)n * m->d.n_fc * dsd_g_pitch(m->CI, m->tc) * 4);
+           align256((size_t)n * m->d.n_fc * dsd_g_pitch(m->CI, m->tc) * 4) +
+           (split ? align256((size_t)n * m->d.n_fc * dsd_gs_pitch(m->CI, m->tc) * 16) : 0);
 }
 
-char* dsd_carve(const dcs_model* m, char* p, int64_t n, int64_t rows1, int64_t rows2, DsdScratch* w) {
+char* dsd_carve(const dcs_model* m, char* p, int64_t n, int64_t rows1, int64_t rows2, DsdScratch* w, bool split = false) {
     w->H1 = (float*)p; p += align256((size_t)rows1 * m->CI * 4);
     w->C2 = (float*)p; p += align256((size_t)rows2 * m->CP * 4);
     w->Z = (float*)p; p += align256((size_t)n * m->hid64 * 4);
     w->D = (float*)p; p += align256((size_t)n * m->nd * 4);
     w->G = (float*)p; p += align256((size_t)n * m->d.n_fc * dsd_g_pitch(m->CI, m->tc) * 4);
+    w->Gs = nullptr;
+    if (split) { w->Gs = p; p += align256((size_t)n * m->d.n_fc * dsd_gs_pitch(m->CI, m->tc) * 16); }
     return p;
 }
 
@@ -429,7 +432,6 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->ws.release();
     m->clip_tab.release();
-    m->gs_buf.release();
     if (m->Bpk) (void)hipFree(m->Bpk);
     delete m;
     return DCS_OK;
@@ -445,6 +447,13 @@ extern "C" int dcs_model_set_conv_precision(dcs_model* m, int f16) {
 
 extern "C" int dcs_model_num_sources(const dcs_model* m) { return m ? m->d.S : DCS_EINVAL; }
 extern "C" int dcs_model_out_channels(const dcs_model* m) { return m ? m->d.n_branch * m->C : DCS_EINVAL; }
+
+extern "C" int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips, int eps_mode) {
+    if (!m || n_frames < 1) return DCS_EINVAL;
+    if (m->arch != DCS_ARCH_DSD) return DCS_EUNSUPPORTED;
+    if (m->Bpk && dsd_final_bf16x3(m->ctx, n_frames, m->F, n_clips, m->CI, eps_mode)) return 2;
+    return dsd_final_cbw(m->ctx, n_frames, m->F, n_clips) == 2 ? 1 : 0;
+}
 
 static int forward_any(dcs_model* m, const float* tiles_d, int64_t n, int mask_mode, int tie_mode, float* out_d) {
     if (!m || !tiles_d || !out_d) DCS_FAIL(DCS_EINVAL, "dcs_model_forward: null argument");
@@ -533,14 +542,17 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         const int64_t rows1 = n_clips > 1 ? n_clips * Trows : Tcov;
         const int64_t rows2 = n_clips > 1 ? rows1 : (n - 1) * st + m->d.h2;
         const int64_t n_all = n * n_clips;
-        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + dsd_scratch_bytes(m, n_all, rows1, rows2)));
+        // large launches run the final kernel on the bf16 matrix pipe with three-way split operands (dsd_bf16x3.hip):
+        // deconv2 then writes the split planes of G itself
+        const bool split = m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode);
+        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + dsd_scratch_bytes(m, n_all, rows1, rows2, split)));
         char* p = (char*)m->ws.ptr;
         float* mag = (float*)p; p += b_mag;
         float2* unit = (float2*)p; p += b_unit;
         float* phase = phase_out ? (float*)p : nullptr; p += b_ph;
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
-        dsd_carve(m, p, n_all, rows1, rows2, &w);
+        dsd_carve(m, p, n_all, rows1, rows2, &w, split);
         DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,
                                                     false, clip_tab_d));
         DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows));
@@ -556,14 +568,10 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         a.mix_clip_stride = Trows * ld;
         a.out_clip_stride = (int64_t)S * T * ld;
         a.clip_tab = clip_tab_d;
-        static const bool bf16x3 = getenv("DCS_FINAL_BF16X3") && atoi(getenv("DCS_FINAL_BF16X3")) != 0;
-        if (bf16x3 && m->Bpk) {   // opt-in: split G once, then the final kernel on the bf16 matrix pipe (dsd_bf16x3.hip)
-            const int64_t items = n_all * m->d.n_fc;
-            DCS_CHECK(m->gs_buf.ensure((size_t)items * tc * kDsdSplitRowU4 * 16));
-            DCS_CHECK(dcs_launch_dsd_gsplit(m->ctx, w.G, m->gs_buf.ptr, items, tc, (m->CI + kDsdGch - 1) / kDsdGch, m->d.nf1));
-            a.Gs = m->gs_buf.ptr;
+        if (split) {
+            a.Gs = w.Gs;
             a.Bpk = m->Bpk;
-            a.gs_clip_stride = n * m->d.n_fc * (int64_t)tc * kDsdSplitRowU4;
+            a.gs_clip_stride = n * m->d.n_fc * (int64_t)dsd_gs_pitch(m->CI, tc);
         }
         DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
         if (pcm_d)
@@ -594,9 +602,7 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     DCS_ON_DEVICE(m->ctx->device);
     static const bool graphs_on = !(getenv("DCS_GRAPH") && atoi(getenv("DCS_GRAPH")) == 0);
     // graph replay needs a capturable (non-null) stream, no event timing, and an identical repeat call
-    static const bool bf16x3 = getenv("DCS_FINAL_BF16X3") && atoi(getenv("DCS_FINAL_BF16X3")) != 0;   // its buffer grows on demand
-    const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD &&
-                           !bf16x3;
+    const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD;
     auto eager = [&]() {
         return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr, nullptr,
                              nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);

@@ -236,6 +236,13 @@ class Network(object):
         self.S = int(ctx._lib.dcs_model_num_sources(h))
         self.out_channels = int(ctx._lib.dcs_model_out_channels(h))
 
+    def final_kernel(self, n_frames, n_clips=1, eps_mode=None):
+        """Which kernel the fused path runs for the last decoder stage on a launch of this size: ``'f32x64'``,
+        ``'f32x128'`` or ``'bf16x3'`` (``dcs_model_final_kernel``); None for graphs without a fused decoder."""
+        eps = self.arch.eps_mode if eps_mode is None else eps_mode
+        code = int(self.ctx._lib.dcs_model_final_kernel(self._h, int(n_frames), int(n_clips), int(eps)))
+        return {0: 'f32x64', 1: 'f32x128', 2: 'bf16x3'}.get(code)
+
     def set_conv_precision(self, dtype):
         """``'f16'``: conv2 and its transpose use f16-input / f32-accumulate MFMA (BASELINE config 3);
         ``'f32'`` (default): exact f32."""

@@ -133,6 +133,12 @@ int dcs_model_forward_masked(dcs_model* m, const float* tiles_d, int64_t n_tiles
 /* lasagne.layers.get_output(network2): p_d [n, channels_out, tc, F] before masking (testing aid) */
 int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n_tiles, int tie_mode, float* p_d);
 int dcs_model_out_channels(const dcs_model* m);
+/* Which kernel the fused path (dcs_separate*) runs for the decoder's last stage (transposed conv1 + bias + rectify + mask
+ * + cross-fade) on n_clips clips of n_frames frames each: 0 = f32 MFMA, 64-bin workgroups (small launches); 1 = f32
+ * MFMA, 128-bin workgroups; 2 = bf16 MFMA on operands split exactly into three bf16 terms (f32-class results, the
+ * default for launches that fill the chip; DSD / hiphop graph); negative: not a fused-kernel graph.  bench.py prices
+ * its roofline block with this. */
+int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips, int eps_mode);
 
 /* ------------------------------------------------------------------ fused file-level path */
 /* The separation block of train_auto (separate_dsd.py:289-306) for one mono signal already in
