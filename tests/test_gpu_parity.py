@@ -857,7 +857,7 @@ def test_bf16x3_final_kernel_meets_the_parity_bar(kind, tmp_path):
         fh.write("dsd fused path (bf16x3 final kernel), %s weights: %d bins of the separated spectrogram, outside 1e-4: %d, "
                  "max err %.2e; vs the f32 kernel max %.2e\n" % (kind, err[0].size, int((err.max(axis=0) > 1e-4).sum()),
                                                                   err.max(), np.abs(sep16 - sep32).max()))
-    assert (err.max(axis=0) > 1e-4).mean() < (0.0 if kind == "glorot" else 0.02)
+    assert (err.max(axis=0) > 1e-4).mean() <= (0.0 if kind == "glorot" else 0.02)
 
 
 # ------------------------------------------------------------------ score-informed path
