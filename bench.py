@@ -26,8 +26,9 @@ batch, so the launch shape does not depend on how K divides by 16.
 Timing: a *round* is EXACTLY K steps bracketed by a barrier + torch.cuda.synchronize() on both
 sides (max over ranks).  Rounds are repeated until `--min-time` (0.25 s) has been timed; `value`
 comes from the MEDIAN round, so it does not depend on K being large (`rounds`, `round_ms` in the
-line).  Every 4th round brackets the launches of the dominant kernel on stream 0 with HIP events
-(those rounds launch stream 0 kernel by kernel instead of replaying its hipGraph).
+line).  Every 4th round brackets the launches of the dominant kernel with HIP events; such a round
+issues its K steps on stream 0 alone (kernel by kernel instead of replaying the hipGraph), because
+with kernels of other streams sharing the CUs an event pair measures a time-sliced duration.
 
 Rank 0 prints ONE JSON line.  `roofline` refers to the dominant kernel of the headline workload
 (transposed conv1 + bias + rectify + soft mask + cross-fade); `cpu_baseline` is the CPU oracle
@@ -252,7 +253,9 @@ def main():
         if instrumented:
             ctx0.timing(["final"])
             before = lanes[0].launched_tiles
-        el = timed(groups, lanes)
+        # an event round issues its K steps on stream 0 alone: with other streams' kernels sharing the CUs an event pair
+        # would measure the kernel's time-sliced duration, not its own
+        el = timed(groups, lanes[:1] if instrumented else lanes)
         if instrumented:
             ctx0.timing(None)
             events_tiles += lanes[0].launched_tiles - before
@@ -368,8 +371,8 @@ def main():
     ev_tiles = events_tiles / float(final_launches) if final_launches else groups[0] * n_tiles
     roofline = roof(ev_tiles, final_ms, final_launches, frames=ev_tiles / n_tiles * frames_per_step,
                     key="final_kernel_%dx%d_tiles" % (groups[0], n_tiles), clips=max(1, int(round(ev_tiles / n_tiles))))
-    roofline["timed"] = ("HIP events around every launch of the kernel on stream 0 in %d of the %d timed rounds"
-                         % (events_rounds, len(round_s)))
+    roofline["timed"] = ("HIP events around every launch of the kernel in %d of the %d timed rounds; those rounds run "
+                         "their K steps on stream 0 alone" % (events_rounds, len(round_s)))
     single = {"ms_per_step": round(el1 * 1e3, 5), "value": round(world * frames_per_step / el1, 1),
               "steps_per_round": k1, "rounds": len(single_rounds),
               "roofline": roof(n_tiles, final_ms1, final_launches1), "kernels_ms": kernels_ms,

@@ -44,7 +44,8 @@ struct DsdFinalArgs {
 // Gs != null: the outputs are (also, for few tiles) produced as three bf16 planes for the bf16x3 final kernel,
 // Gs[item][channel group][t][plane][8 channels] -- 16-byte pieces, dsd_gs_pitch() of them per (tile, branch)
 int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const float* Bws, float* G, int64_t n_ks,
-                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols, void* Gs = nullptr);
+                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols, void* Gs = nullptr,
+                           const void* Bq = nullptr);
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold);
 // column blocks per wave the final kernel will use for this launch (2: 128-bin workgroups, 1: 64-bin ones for few rows)
 int dsd_final_cbw(const dcs_ctx* ctx, int64_t rows, int F, int64_t n_clips);
@@ -55,4 +56,10 @@ bool dsd_final_bf16x3(const dcs_ctx* ctx, int64_t rows, int F, int64_t n_clips, 
 // ---- bf16x3 variant of the fused final kernel (dsd_bf16x3.hip; DCS_FINAL_BF16X3=0 switches it off)
 inline int dsd_gs_pitch(int CI, int tc) { return ((CI + kDsdGch - 1) / kDsdGch) * tc * 3; }  // 16-byte pieces per (tile, branch)
 int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg);
+// streaming transposed conv2 on the bf16 matrix pipe (many items): D f32 in, the bf16 planes of G out.  Bq: the conv2
+// weights as bf16 planes, [channel group][8 channels][16 taps][25 pieces of 16 bytes] (dsd_d2q_bytes() per model)
+constexpr int kDsdD2qGroupBytes = kDsdGch * 16 * 25 * 16;
+inline size_t dsd_d2q_bytes(int CI) { return (size_t)((CI + kDsdGch - 1) / kDsdGch) * kDsdD2qGroupBytes; }
+int dcs_launch_dsd_deconv2_bf16(dcs_ctx* ctx, const float* D, const void* Bq, void* Gs, int64_t n_ks, int H2, int CP, int CI,
+                                int kh, int tc);
 int dcs_launch_dsd_final_bf16x3(dcs_ctx* ctx, const DsdFinalArgs& a, int n_colg, int64_t n_wg, unsigned n_clips);

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
 }  // namespace
 
 int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const float* Bws, float* G, int64_t n_ks,
-                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols, void* Gs) {
+                           int H2, int CP, int CI, int kh, int tc, int NG, int GS, int gcols, void* Gs, const void* Bq) {
     if (n_ks <= 0) return DCS_OK;
     const int nrb = (H2 + 15) / 16;
     if (nrb > 2) DCS_FAIL(DCS_EUNSUPPORTED, "deconv2: conv2 output height %d > 32", H2);
@@ -646,6 +646,14 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const 
     const int ngg = (CI + kDsdGch - 1) / kDsdGch;
     const bool can_stream = nrb == 1 && kh <= 16 && tc <= 32 && H2 + kh - 1 <= 32;
     const bool stream = can_stream && (force ? force == 2 : n_ks >= 4 * (int64_t)ctx->n_cu);
+    static const bool d2_bf16 = !(getenv("DCS_DECONV2_BF16") && atoi(getenv("DCS_DECONV2_BF16")) == 0);
+    if (stream && Gs && Bq && d2_bf16) {
+        // the consumer is the bf16x3 final kernel: the transposed conv2 runs on the bf16 matrix pipe too and writes the
+        // three planes of G (dsd_bf16x3.hip)
+        const int rc = dcs_launch_dsd_deconv2_bf16(ctx, D, Bq, Gs, n_ks, H2, CP, CI, kh, tc);
+        tm.done();
+        return rc;
+    }
     if (stream) {
         // 3 workgroups per CU (50.6 KB of LDS each), one round: X columns for each full channel group, and a
         // proportionally smaller share for the last, partial group

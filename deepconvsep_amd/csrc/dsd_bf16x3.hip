@@ -76,10 +76,6 @@ __device__ __forceinline__ f32x2 max2(f32x2 x, float lo) {
 }
 
 __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
-#ifdef DCS_EXP_NOMFMA
-    c[0] += __uint_as_float(a[0] ^ b[0]);
-    return c;
-#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -243,30 +239,13 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
         if ((u + 1) * kThreads <= slots || in_slot[u]) As[(buf_) * kABuf + dst[u]] = pre[u];    \
     }
 
-#ifndef DCS_EXP_PF
-#define DCS_EXP_PF 1
-#endif
-    // the A set of covering tile m is requested DCS_EXP_PF iterations before it is stored to LDS (an iteration is
-    // ~1 us; a first touch of G comes from HBM / the infinity cache)
+    // the A set of covering tile m + 1 is requested while tile m is multiplied (requesting it two tiles ahead costs 20
+    // more registers and measured slower: 0.360 vs 0.346 ms at 4096 tiles)
     DCS_LOAD_A(0, pre)
-#if DCS_EXP_PF == 2
-    u32x4 nxt[NSL];
-    DCS_LOAD_A(1, nxt)      // clamped addressing makes this valid for mmax == 1 too
-#endif
     for (int m = 0; m < mmax; ++m) {
         DCS_STORE_A(m & 1)
-#ifndef DCS_EXP_NOBARRIER
         __syncthreads();
-#endif
-#if DCS_EXP_PF == 2
-#pragma unroll
-        for (int u = 0; u < NSL; ++u) pre[u] = nxt[u];
-        if (m + 2 < mmax) DCS_LOAD_A(m + 2, nxt)
-#else
-#ifndef DCS_EXP_NOLOAD
         if (m + 1 < mmax) DCS_LOAD_A(m + 1, pre)
-#endif
-#endif
         if (!live) continue;
         const u32x4* Ab = As + (m & 1) * kABuf + fi * kRowLds + kq;
         f32x4 acc[NBR][CBW];
@@ -305,13 +284,6 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[0][kb], breg[cb][0][kb], acc[s][cb]);
         }
-#ifdef DCS_EXP_NOEPI
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-            for (int s = 0; s < NBR; ++s) res[cb][s] += acc[s][cb];
-        continue;
-#endif
         const f32x4 up4 = *reinterpret_cast<const f32x4*>(up_t + m * 16 + kq * 4);
         const f32x4 down4 = *reinterpret_cast<const f32x4*>(down_t + m * 16 + kq * 4);
 #pragma unroll
@@ -377,7 +349,190 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming transposed conv2 (deconv2_stream_kernel of dsd.hip) on the bf16 matrix pipe.  Same decomposition -- per
+// (tile, branch) item and input channel c the product P[t'][dt] = sum_co D[t'][co] W2[co, c, dt] (M = 16 positions,
+// N = 16 tap slots, K = 50 filters padded to 64), written skewed so that the col2im sum is a row sum, 8 channels per
+// workgroup, independent waves streaming over items -- but every operand is split exactly into three bf16 terms and
+// the six products above 2^-24 are accumulated in f32 (12 MFMAs of 16 cycles per channel instead of 13 of 32), and
+// the VALU work (splitting the item's D rows, skew / row sums, packing the outputs) runs beside the matrix pipe.
+//   A: lane (t' = fi, kq) holds filters 8 kq .. 8 kq + 7 (+ 32 for the second K block) of row t' of D, split in
+//      registers when the item is consumed; rows are fetched two items ahead.
+//   B: the group's weights as bf16 planes in LDS, Bq[channel][tap][plane][K piece] 16-byte pieces, tap stride 25 pieces
+//      (100 words: the 16 taps of a 16-lane pass start in 16 different bank quads), copied from the packed global array.
+//   Output: the three bf16 planes of G, Gs[item][channel group][t][plane][8] (what final_bf16x3_kernel stages).
+// ------------------------------------------------------------------------------------------------
+constexpr int kD2TapU4 = 25;                       // 16-byte pieces per (channel, tap): 3 planes x 8 K pieces + 1 pad
+constexpr int kD2ChanU4 = 16 * kD2TapU4;           // per channel
+constexpr int kD2GroupU4 = kDsdGch * kD2ChanU4;    // per channel group: 3200 pieces = 51 200 bytes
+constexpr int kD2PsStride = 20;                    // floats per skewed row: 16 taps + 4
+constexpr int kD2PsChan = 32 * kD2PsStride + 32;   // second channel of a pair starts 32 banks further
+constexpr int kD2PsSize = 2 * kD2PsChan;
+
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& mid, u32x4& lo) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? x0[j] : x1[j - 4];
+        h[j] = bf_trunc(x);
+        const float r1 = x - __uint_as_float(h[j]);
+        m[j] = bf_trunc(r1);
+        l[j] = bf_trunc(r1 - __uint_as_float(m[j]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hi[q] = (h[2 * q] >> 16) | h[2 * q + 1];
+        mid[q] = (m[2 * q] >> 16) | m[2 * q + 1];
+        lo[q] = (l[2 * q] >> 16) | l[2 * q + 1];
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void deconv2_stream_bf16_kernel(const float* __restrict__ D,
+                                                                          const u32x4* __restrict__ Bq,
+                                                                          u32x4* __restrict__ Gs, int64_t n_ks, int H2,
+                                                                          int kh, int tc, int ngg, int n_full, int X,
+                                                                          int tail_ch, int Xt) {
+    constexpr int CP = 52, GS = kDsdGch;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    u32x4* Bs = reinterpret_cast<u32x4*>(smem_raw);                 // [GS][16][25]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* Ps = reinterpret_cast<float*>(Bs + kD2GroupU4) + wave * (kD2PsSize + 32 * GS);  // [2][32][20] skewed products
+    float* Os = Ps + kD2PsSize;                                                             // [tc][8] outputs of the item
+    const int fi = lane & 15, kq = lane >> 4;
+
+    // block -> (channel group g, workgroup column x of nwx): as deconv2_stream_kernel
+    const int b = blockIdx.x;
+    int g, x, nwx, n_ch;
+    if (b < n_full * X) {
+        const int xl = b & 7, t = b >> 3;
+        g = t % n_full;
+        x = (t / n_full) * 8 + xl;
+        nwx = X;
+        n_ch = GS;
+    } else {
+        g = n_full;
+        x = b - n_full * X;
+        nwx = Xt;
+        n_ch = tail_ch;
+    }
+    {
+        const u32x4* src = Bq + (int64_t)g * kD2GroupU4;
+        for (int i = tid; i < kD2GroupU4; i += kThreads) Bs[i] = src[i];
+        for (int i = lane; i < kD2PsSize + 32 * GS; i += 64) Ps[i] = 0.f;
+    }
+    __syncthreads();
+
+    const int n_pairs = (n_ch + 1) >> 1;
+    // raw D rows of an item: filters 8 kq .. +7 (K block 0) and 32 + 8 kq .. +7 (K block 1; filters >= 52 do not exist)
+    f32x4 ra[4], rb[4];
+#define DCS_LOAD_D(ks_, r_)                                                                             \
+    {                                                                                                   \
+        const float* dp = D + ((ks_) * (int64_t)H2 + fi) * CP + 8 * kq;                                 \
+        const bool in = fi < H2;                                                                        \
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+        r_[0] = in ? *reinterpret_cast<const f32x4*>(dp) : z;                                           \
+        r_[1] = in ? *reinterpret_cast<const f32x4*>(dp + 4) : z;                                       \
+        r_[2] = (in && kq < 3) ? *reinterpret_cast<const f32x4*>(dp + 32) : z;                          \
+        r_[3] = (in && kq < 2) ? *reinterpret_cast<const f32x4*>(dp + 36) : z;                          \
+    }
+    const int64_t kstep = (int64_t)nwx * 4;
+    int64_t ks = (int64_t)x * 4 + wave;
+    if (ks < n_ks) DCS_LOAD_D(ks, ra)
+    if (ks + kstep < n_ks) DCS_LOAD_D(ks + kstep, rb)
+    const u32x4* bl = Bs + fi * kD2TapU4 + kq;      // this lane's tap and K piece
+    for (; ks < n_ks; ks += kstep) {
+        u32x4 ap[3][2];                              // A planes x K blocks
+        split8(ra[0], ra[1], ap[0][0], ap[1][0], ap[2][0]);
+        split8(ra[2], ra[3], ap[0][1], ap[1][1], ap[2][1]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ra[u] = rb[u];
+        if (ks + 2 * kstep < n_ks) DCS_LOAD_D(ks + 2 * kstep, rb)
+        for (int cp = 0; cp < n_pairs; ++cp) {
+            const u32x4* b0 = bl + (2 * cp) * kD2ChanU4;
+            const u32x4* b1 = b0 + kD2ChanU4;
+            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            // smallest terms first; the two channels alternate so that no MFMA waits for the one before it
+#define DCS_D2_TERM(pa_, pb_)                                                                           \
+            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                          \
+                acc0 = mma(ap[pa_][kb], b0[(pb_) * 8 + kb * 4], acc0);                                  \
+                acc1 = mma(ap[pa_][kb], b1[(pb_) * 8 + kb * 4], acc1);                                  \
+            }
+            DCS_D2_TERM(2, 0) DCS_D2_TERM(0, 2) DCS_D2_TERM(1, 1) DCS_D2_TERM(1, 0) DCS_D2_TERM(0, 1) DCS_D2_TERM(0, 0)
+#undef DCS_D2_TERM
+            // acc[e] = P[t' = 4 kq + e][dt = fi]  ->  Ps[c][t' + dt][dt]
+            if (fi < kh) {
+                float* w0 = Ps + (4 * kq + fi) * kD2PsStride + fi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * kq + e < H2) {
+                        w0[e * kD2PsStride] = acc0[e];
+                        w0[kD2PsChan + e * kD2PsStride] = acc1[e];
+                    }
+                }
+            }
+            if (lane < 2 * tc) {
+                const int cc = lane & 1, t = lane >> 1;
+                const f32x4* r = reinterpret_cast<const f32x4*>(Ps + cc * kD2PsChan + t * kD2PsStride);
+                const f32x4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                float sum = 0.f;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) sum += r0[d];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) sum += r1[d];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) sum += r2[d];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) sum += r3[d];
+                Os[t * GS + 2 * cp + cc] = sum;
+            }
+        }
+        // lane -> (t, half of the 8 channels): 4 values, all three planes; a (t, plane) piece is 16 bytes
+        if (lane < 2 * tc) {
+            const int t = lane >> 1, half = lane & 1;
+            const f32x4 v = reinterpret_cast<const f32x4*>(Os)[lane];
+            unsigned h[4], md[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[j] = bf_trunc(v[j]);
+                const float r1 = v[j] - __uint_as_float(h[j]);
+                md[j] = bf_trunc(r1);
+                lo[j] = bf_trunc(r1 - __uint_as_float(md[j]));
+            }
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2* dst = reinterpret_cast<u32x2*>(Gs) + (((ks * ngg + g) * (int64_t)tc + t) * 3) * 2 + half;
+            dst[0] = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+            dst[2] = u32x2{(md[0] >> 16) | md[1], (md[2] >> 16) | md[3]};
+            dst[4] = u32x2{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]};
+        }
+    }
+#undef DCS_LOAD_D
+}
+
 }  // namespace
+
+int dcs_launch_dsd_deconv2_bf16(dcs_ctx* ctx, const float* D, const void* Bq, void* Gs, int64_t n_ks, int H2, int CP,
+                                int CI, int kh, int tc) {
+    if (n_ks <= 0) return DCS_OK;
+    if (CP != 52 || H2 > 16 || kh > 16 || tc > 32 || H2 + kh - 1 > 32)
+        DCS_FAIL(DCS_EUNSUPPORTED, "bf16 deconv2: built for 50 conv2 filters and tc <= 32");
+    const int ngg = (CI + kDsdGch - 1) / kDsdGch;
+    const int n_full = CI / kDsdGch, tail_ch = CI - n_full * kDsdGch;
+    const int slots = 2 * ctx->n_cu;   // 2 workgroups per CU (77 KB of LDS each), one round
+    const double units = n_full + (tail_ch ? (double)((tail_ch + 1) / 2) / (kDsdGch / 2) : 0.0);
+    int X = (int)(slots / units) / 8 * 8;
+    if (X < 8) X = 8;
+    int Xt = tail_ch ? slots - n_full * X : 0;
+    if (tail_ch && Xt < 1) Xt = 1;
+    const size_t lds = (size_t)kD2GroupU4 * 16 + (size_t)4 * (kD2PsSize + 32 * kDsdGch) * sizeof(float);
+    auto kern = deconv2_stream_bf16_kernel;
+    DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_full * X + Xt)), dim3(kThreads), lds, ctx->stream, D,
+                       reinterpret_cast<const u32x4*>(Bq), reinterpret_cast<u32x4*>(Gs), n_ks, H2, kh, tc, ngg, n_full, X,
+                       tail_ch, Xt);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
 
 int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg) {
     if (n_items <= 0) return DCS_OK;

@@ -88,8 +88,9 @@ struct dcs_model {
     DcsGenericNet* gen = nullptr;
     // ---- scratch
     DcsBuffer ws;
-    // bf16x3 final kernel: the transposed-conv1 weights split into three bf16 planes
+    // bf16x3 kernels: the transposed-conv1 and conv2 weights split into three bf16 planes
     uint16_t* Bpk = nullptr;
+    uint16_t* Bw2q = nullptr;
     DcsBuffer clip_tab;   // {samples, frames, tiles} per clip of a batch of different lengths (dcs_separate_ragged)
     float* rise_d = nullptr;
     int rise_ov = -1;
@@ -256,6 +257,26 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
                 }
             }
         DCS_CHECK(upload(&m->Bpk, Bpk));
+        // streaming deconv2 on the bf16 pipe: Bw2q[group][channel 8][tap 16][25 pieces][8 bf16]; piece plane * 8 + kb * 4 +
+        // kq holds filters co = 32 kb + 8 kq + j of W2c[co, ci, dt]; x = plane0 + plane1 + plane2 exactly
+        std::vector<uint16_t> Bw2q(dsd_d2q_bytes(CI) / 2, 0);
+        if (kh <= 16)
+            for (int ci = 0; ci < d.nf1; ++ci)
+                for (int dt = 0; dt < kh; ++dt)
+                    for (int co = 0; co < d.nf2; ++co) {
+                        float r = Bw2s[((size_t)ci * 16 + dt) * CP + co];
+                        const int kb = co >> 5, kq = (co & 31) >> 3, j = co & 7;
+                        for (int pl = 0; pl < 3; ++pl) {
+                            uint32_t bits;
+                            memcpy(&bits, &r, 4);
+                            bits &= 0xffff0000u;
+                            float part;
+                            memcpy(&part, &bits, 4);
+                            r -= part;
+                            Bw2q[(((size_t)ci * 16 + dt) * 25 + pl * 8 + kb * 4 + kq) * 8 + j] = (uint16_t)(bits >> 16);
+                        }
+                    }
+        DCS_CHECK(upload(&m->Bw2q, Bw2q));
     }
     return DCS_OK;
 }
@@ -316,7 +337,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
     // InverseLayer(., l_conv2) (separate_dsd.py:211,217,223)
     return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n * n_clips * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
-                                  m->d2_gcols, w.Gs);
+                                  m->d2_gcols, w.Gs, m->Bw2q);
 }
 
 size_t dsd_scratch_bytes(const dcs_model* m, int64_t n, int64_t rows1, int64_t rows2, bool split = false) {
@@ -433,6 +454,7 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     m->ws.release();
     m->clip_tab.release();
     if (m->Bpk) (void)hipFree(m->Bpk);
+    if (m->Bw2q) (void)hipFree(m->Bw2q);
     delete m;
     return DCS_OK;
 }
