@@ -338,50 +338,49 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int64_t clip = blockIdx.y;  // stacked clips of equal length (dcs_separate_batch): same fold, shifted buffers
     const unsigned rg = swz / (unsigned)n_colg;
-    const int64_t row0 = (int64_t)rg * 16;
+    const int row0 = (int)rg * 16;    // rows, tiles and workgroups all fit 31 bits (checked by the launcher)
     // Which wave takes which 16*CBW bins rotates with the row group: F = 64k + 1 leaves the last column group one
     // live wave (the Nyquist bin), and a fixed choice would put all of those on the same SIMD of every CU
     // (45 instead of 40 waves' worth of MFMAs at F = 1025).
     const int colw = (int)(swz - rg * (unsigned)n_colg) * (64 * CBW) + ((wave + (int)rg) & 3) * (16 * CBW);
     const int col = colw + CBW * fi;  // this lane's bins: col (cb = 0), col + 1 (cb = 1)
     const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
-    int64_t n = a.n, rows = a.rows;
+    int n = (int)a.n, rows = (int)a.rows;
     if (a.clip_tab) {   // stacked clips of different lengths: this clip's own tile and frame counts
-        rows = a.clip_tab[3 * clip + 1];
-        n = a.clip_tab[3 * clip + 2];
+        rows = (int)a.clip_tab[3 * clip + 1];
+        n = (int)a.clip_tab[3 * clip + 2];
         if (row0 >= rows) return;   // workgroup-uniform, before any barrier
     }
 
     // ---- per-row state, once per workgroup: owner tile k0 / position j0 of each row, then the table of
     // cross-fade weights (util.py:321-325): the owner tile (m = 0) overwrites (up 1, down 0), a later
     // tile blends with up = rise[j], down = rise[ov-1-j], a tile that does not cover the row leaves it
-    // (up 0, down 1).
+    // (up 0, down 1).  32-bit arithmetic: a 64-bit division is ~100 instructions on this path's critical chain.
     if (tid < 16 * mmax) {
         const int i = tid & 15, m = tid >> 4;
-        const int64_t r = row0 + i;
-        int64_t k0 = 0;
-        int j0 = -1;
+        const int r = row0 + i;
+        int k0 = 0, j0 = -1;
         if (r < rows) {
             if (FOLD) {
-                int64_t kk = (r < ov) ? 0 : (int64_t)((uint64_t)(r - ov) / (unsigned)st);
+                int kk = (r < ov) ? 0 : (int)((unsigned)(r - ov) / (unsigned)st);
                 if (kk > n - 1) kk = n - 1;
-                const int64_t jj = r - kk * st;
+                const int jj = r - kk * st;
                 if (jj < tc) {
                     k0 = kk;
-                    j0 = (int)jj;
+                    j0 = jj;
                 }
             } else {
-                k0 = (int64_t)((uint64_t)r / (unsigned)tc);
-                j0 = (int)(r - k0 * tc);
+                k0 = (int)((unsigned)r / (unsigned)tc);
+                j0 = r - k0 * tc;
             }
         }
         if (m == 0) {
-            meta_k0[i] = (int)k0;
+            meta_k0[i] = k0;
             meta_j0[i] = j0;
             int lim = -1;
             if (j0 >= 0) {
-                lim = j0 / st;
-                if (lim > n - 1 - k0) lim = (int)(n - 1 - k0);
+                lim = (int)((unsigned)j0 / (unsigned)st);
+                if (lim > n - 1 - k0) lim = n - 1 - k0;
             }
             meta_mlim[i] = lim;
         }
@@ -417,8 +416,8 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     // mixture value of this lane's 4 rows x 2 bins
     const bool vec = CBW == 2 && ((a.mix_ld | a.out_ld) & 1) == 0;  // rows 8-byte aligned (the fused path pads F to 4)
     f32x4 mixv[CBW];
-    const float* mix0 = a.mix + clip * a.mix_clip_stride + row0 * a.mix_ld;   // workgroup-uniform
-    const int rows_here = rows - row0 < 16 ? (int)(rows - row0) : 16;
+    const float* mix0 = a.mix + clip * a.mix_clip_stride + (int64_t)row0 * a.mix_ld;   // workgroup-uniform
+    const int rows_here = rows - row0 < 16 ? rows - row0 : 16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int ri = kq * 4 + e;
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
             // CBW == 1 is the few-workgroups variant, where the duration is one workgroup's dependent chain: with the
             // full 64-bit address the compiler issues these loads ahead of the staging plan (15.3 -> 12.6 us at 32 tiles);
             // with many workgroups the cheaper 32-bit offset wins
-            const float* mp = CBW == 1 ? a.mix + clip * a.mix_clip_stride + (row0 + ri) * a.mix_ld + col
+            const float* mp = CBW == 1 ? a.mix + clip * a.mix_clip_stride + (int64_t)(row0 + ri) * a.mix_ld + col
                                        : mix0 + (ri * (int)a.mix_ld + col);
             if (vec && col + 1 < a.F) {
                 const f32x2 v = *reinterpret_cast<const f32x2*>(mp);
@@ -593,7 +592,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
 #undef DCS_STORE_A
 
     {
-        float* out0 = a.out + clip * a.out_clip_stride + row0 * a.out_ld;   // workgroup-uniform; offsets below are 32-bit
+        float* out0 = a.out + clip * a.out_clip_stride + (int64_t)row0 * a.out_ld;   // workgroup-uniform; offsets below are 32-bit
         // stereo trainer: source = mask * input + eps*r (trainCNN_ILD_DSD100.py:180); the cross-fade weights of a frame
         // sum to one, so the constant is added once, after the fold
         if (MODE == 3) {

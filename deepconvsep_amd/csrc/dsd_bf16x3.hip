@@ -99,38 +99,37 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
     const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int64_t clip = blockIdx.y;
     const unsigned rg = swz / (unsigned)n_colg;
-    const int64_t row0 = (int64_t)rg * 16;
+    const int row0 = (int)rg * 16;        // rows, tiles and workgroups all fit 31 bits (checked by the launcher)
     const int colw = (int)(swz - rg * (unsigned)n_colg) * (64 * CBW) + ((wave + (int)rg) & 3) * (16 * CBW);
     const int col = colw + CBW * fi;
     const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
-    int64_t n = a.n, rows = a.rows;
+    int n = (int)a.n, rows = (int)a.rows;
     if (a.clip_tab) {
-        rows = a.clip_tab[3 * clip + 1];
-        n = a.clip_tab[3 * clip + 2];
+        rows = (int)a.clip_tab[3 * clip + 1];
+        n = (int)a.clip_tab[3 * clip + 2];
         if (row0 >= rows) return;
     }
 
     if (tid < 16 * mmax) {
         const int i = tid & 15, m = tid >> 4;
-        const int64_t r = row0 + i;
-        int64_t k0 = 0;
-        int j0 = -1;
+        const int r = row0 + i;
+        int k0 = 0, j0 = -1;
         if (r < rows) {
-            int64_t kk = (r < ov) ? 0 : (int64_t)((uint64_t)(r - ov) / (unsigned)st);
+            int kk = (r < ov) ? 0 : (int)((unsigned)(r - ov) / (unsigned)st);
             if (kk > n - 1) kk = n - 1;
-            const int64_t jj = r - kk * st;
+            const int jj = r - kk * st;
             if (jj < tc) {
                 k0 = kk;
-                j0 = (int)jj;
+                j0 = jj;
             }
         }
         if (m == 0) {
-            meta_k0[i] = (int)k0;
+            meta_k0[i] = k0;
             meta_j0[i] = j0;
             int lim = -1;
             if (j0 >= 0) {
-                lim = j0 / st;
-                if (lim > n - 1 - k0) lim = (int)(n - 1 - k0);
+                lim = (int)((unsigned)j0 / (unsigned)st);
+                if (lim > n - 1 - k0) lim = n - 1 - k0;
             }
             meta_mlim[i] = lim;
         }
@@ -150,7 +149,8 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 
     const bool live = colw < a.F;
     // B fragments: the three planes of Bw[c][bin] for this lane's two bins and K-quarter, constant for the workgroup
-    const u32x4* Bpk = reinterpret_cast<const u32x4*>(a.Bpk);
+    // (one lane-dependent address; the 12 pieces of a lane are compile-time offsets from it)
+    const u32x4* Bpk = reinterpret_cast<const u32x4*>(a.Bpk) + (col * 24 + kq);
     u32x4 breg[CBW][3][2];
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb)
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
-                breg[cb][p][kb] = live ? Bpk[(((col + cb) * 3 + p) * 2 + kb) * 4 + kq] : u32x4{0u, 0u, 0u, 0u};
+                breg[cb][p][kb] = live ? Bpk[cb * 24 + (p * 2 + kb) * 4] : u32x4{0u, 0u, 0u, 0u};
 
     const bool vec = ((a.mix_ld | a.out_ld) & 1) == 0;
     f32x4 mixv[CBW];
-    const float* mix0 = a.mix + clip * a.mix_clip_stride + row0 * a.mix_ld;
-    const int rows_here = rows - row0 < 16 ? (int)(rows - row0) : 16;
+    const float* mix0 = a.mix + clip * a.mix_clip_stride + (int64_t)row0 * a.mix_ld;
+    const int rows_here = rows - row0 < 16 ? rows - row0 : 16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int ri = kq * 4 + e;
@@ -321,16 +321,19 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 #undef DCS_LOAD_A
 #undef DCS_STORE_A
 
-    float* out0 = a.out + clip * a.out_clip_stride + row0 * a.out_ld;
+    // per source a workgroup-uniform base (scalar registers) plus one 32-bit lane offset per row
+    float* out0 = a.out + clip * a.out_clip_stride + (int64_t)row0 * a.out_ld;
+    float* outc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) outc[c] = out0 + c * a.out_src_stride;
     if (vec && colw + 16 * CBW <= a.F) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int ri = kq * 4 + e;
             if (ri < rows_here) {
-                float* op = out0 + (ri * (int)a.out_ld + col);
+                const int off = ri * (int)a.out_ld + col;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    *reinterpret_cast<f32x2*>(op + c * a.out_src_stride) = f32x2{res[0][c][e], res[1][c][e]};
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x2*>(outc[c] + off) = f32x2{res[0][c][e], res[1][c][e]};
             }
         }
     } else if (col < a.F) {
@@ -338,11 +341,11 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
         for (int e = 0; e < 4; ++e) {
             const int ri = kq * 4 + e;
             if (ri < rows_here) {
-                float* op = out0 + (ri * (int)a.out_ld + col);
+                const int off = ri * (int)a.out_ld + col;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    op[c * a.out_src_stride] = res[0][c][e];
-                    if (col + 1 < a.F) op[c * a.out_src_stride + 1] = res[1][c][e];
+                    outc[c][off] = res[0][c][e];
+                    if (col + 1 < a.F) outc[c][off + 1] = res[1][c][e];
                 }
             }
         }
