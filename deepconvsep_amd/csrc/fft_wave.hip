@@ -603,6 +603,175 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
     flush(hb1, n_hi < n_lo ? -R : n_hi);  // a chunk no frame reaches: zeros
 }
 
+// ------------------------------------------------------------------------------------------------
+// inverse, barrier-free form (N <= 2048, hop | N with N / hop in {2, 4}, hop / 2 a multiple of 64): ONE WAVE walks C
+// consecutive hop-blocks of one source on its own.  It transforms the frames that touch its blocks in increasing
+// order (the R - 1 frames before the first block are transformed by this wave and by its left neighbour) and keeps the
+// R hop-blocks a frame can touch in REGISTERS -- a lane owns hop / 128 sample pairs of every block -- so the windowed
+// overlap-add (frame order = the reference's accumulation order, transform.py:381-389) is R packed multiply-adds per
+// owned pair, and a block is normalised by sum(w^2) and stored (8-byte stores, 512 contiguous bytes per instruction)
+// as soon as the frame of its own index has been added.  No ring in LDS, no workgroup barrier after the window table
+// is staged, no flush loop: the four waves of a workgroup (the four sources of one chunk, which share the phasor
+// rows) never wait for each other.  istft_wave_kernel above: 2 barriers per 4 frames, 16 LDS read-modify-writes per
+// thread and step, ~300 scalar instructions per frame of 64-bit flush bookkeeping.  Measured at 4096 tiles (N = 2048,
+// 4 sources): 0.302 -> 0.240 ms; a 16 x 32-tile launch group 56.7 -> 49.1 us.
+// ------------------------------------------------------------------------------------------------
+template <int LOG2M, bool UNIT, int R>
+__global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restrict__ mag, int64_t src_stride,
+                                                          const float* __restrict__ phase, const float2* __restrict__ unit,
+                                                          int64_t ld, const float* __restrict__ win,
+                                                          const float* __restrict__ wsq, const float2* __restrict__ tw,
+                                                          float* __restrict__ audio, int64_t n_out, int64_t T, int C,
+                                                          int64_t n_blocks, int n_chunks, int n_src, float pre_div,
+                                                          float sqrt_n, int64_t unit_clip_stride, int src_per_clip,
+                                                          const int64_t* __restrict__ clip_tab, int64_t out_stride) {
+    constexpr int M = 1 << LOG2M, N = 2 * M, P = M / 64, MP = M + M / 32;
+    constexpr int hop = N / R, hp = hop / 2, VPB = hp / 64;   // sample pairs a lane owns in one hop-block
+    constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
+    static_assert(WaveTw<LOG2M>::REG3 && VPB * R == P && VPB >= 1, "lean twiddles, whole pairs per lane");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* winl = reinterpret_cast<float2*>(smem);          // [M] window pairs times 1/M
+    float2* fbuf = winl + M;                                 // [4][MP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2* buf = fbuf + wave * MP;
+    const float inv_m = 1.f / (float)M;                      // a power of two: (z / M) * w == z * (w / M) exactly
+    {
+        const float2* w2g = reinterpret_cast<const float2*>(win);
+        for (int k = tid; k < M; k += 256) stc(winl + k, ldc(w2g + k) * inv_m);
+    }
+    __syncthreads();
+    // wave -> (chunk, source): the sources of a chunk are neighbouring waves and read the same phasor rows
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int s = (int)(gw % n_src);
+    const int64_t chunk = gw / n_src;
+    if (chunk >= n_chunks) return;
+    if (clip_tab) {   // clips of different lengths: this source's own sample / frame / hop-block counts
+        const int64_t c = s / src_per_clip;
+        n_out = clip_tab[3 * c];
+        T = clip_tab[3 * c + 1];
+        n_blocks = (n_out + M + hop - 1) / hop;
+    }
+    const int64_t hb0 = chunk * C;
+    if (hb0 >= n_blocks) return;
+    const int64_t hb1 = (hb0 + C < n_blocks) ? hb0 + C : n_blocks;
+    const int64_t n_first = (hb0 < R) ? 0 : hb0 - (R - 1);
+    const int64_t n_last = (hb1 - 1 < T - 1) ? hb1 - 1 : T - 1;
+    const float amp = 0.5f * (sqrt_n / pre_div);  // (mag / scale_factor) sqrt(N), and the 1/2 of the even/odd split
+    const float* msrc = mag + (int64_t)s * src_stride;
+    unit += (int64_t)(s / src_per_clip) * unit_clip_stride;
+    float* dst = audio + (int64_t)s * out_stride;
+    const bool dst_al = (reinterpret_cast<uintptr_t>(dst) & 7) == 0;   // sample pairs start at even offsets
+    WaveTw<LOG2M> wt;
+    wt.init(tw, lane);
+    const cx wl = ldc(tw + lane);
+    // steady-state normaliser of this lane's pairs: 1 / sum over the R frames that cover a block
+    cx nrm[VPB];
+#pragma unroll
+    for (int v = 0; v < VPB; ++v) {
+        const int q = 2 * (lane + 64 * v);
+        float nx = 0.f, ny = 0.f;
+#pragma unroll
+        for (int d = R - 1; d >= 0; --d) {   // frames in increasing order
+            nx += wsq[q + d * hop];
+            ny += wsq[q + 1 + d * hop];
+        }
+        nrm[v] = mk(nx == 0.f ? 1.f : 1.f / nx, ny == 0.f ? 1.f : 1.f / ny);
+    }
+    cx acc[R][VPB];
+#pragma unroll
+    for (int d = 0; d < R; ++d)
+#pragma unroll
+        for (int v = 0; v < VPB; ++v) acc[d][v] = mk(0.f, 0.f);
+
+    const float2* wlane = winl + lane;
+    const float2* blane = buf + pad(lane);
+    for (int64_t nb = (n_first / R) * R; nb < hb1; nb += R) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int64_t n = nb + j;
+            if (n >= n_first && n <= n_last) {       // wave-uniform
+                const float* mrow = msrc + n * ld;
+                const float2* urow = unit + n * ld;
+                const float* prow = phase + n * ld;
+                cx v[P];
+#pragma unroll
+                for (int b = 0; b < NB1; ++b)
+#pragma unroll
+                    for (int tt = 0; tt < R1; ++tt) {
+                        const int k = lane + 64 * b + tt * stride1;  // 0 <= k < M
+                        const int km = M - k;                         // 1..M
+                        const float a = mrow[k] * amp;
+                        const float b2 = mrow[km] * amp;
+                        cx xk, xm;
+                        if (UNIT) {
+                            xk = ldc(urow + k) * a;
+                            xm = ldc(urow + km) * b2;
+                        } else {
+                            float sn, cs;
+                            sincosf(prow[k], &sn, &cs);
+                            xk = mk(a * cs, a * sn);
+                            sincosf(prow[km], &sn, &cs);
+                            xm = mk(b2 * cs, b2 * sn);
+                        }
+                        if (b == 0 && tt == 0) {  // k == 0 only there: imaginary parts of DC / Nyquist are ignored (numpy irfft)
+                            if (lane == 0) {
+                                xk[1] = 0.f;
+                                xm[1] = 0.f;
+                            }
+                        }
+                        const cx e = c_add_conj(xk, xm), d = c_sub_conj(xk, xm);
+                        const int jj = (b + tt * NB1) * (1024 / M);   // k = lane + 64 j: w^k = w^lane * exp(-i pi 64 j / M)
+                        const cx wk = jj == 0 ? wl : c_mul(wl, w_pi16(jj));
+                        const cx o = c_mul_conj(d, wk);
+                        v[b * R1 + tt] = c_add_i(e, o);
+                    }
+                fft_wave<LOG2M, +1>(v, lane, wt, tw, buf);
+                // frame n covers the hop-blocks n .. n + R - 1: block n + d lives in register slot (j + d) % R
+#pragma unroll
+                for (int d = 0; d < R; ++d)
+#pragma unroll
+                    for (int vv = 0; vv < VPB; ++vv) {
+                        const int k = d * hp + 64 * vv;           // + lane; constant part a multiple of 64
+                        const cx z = ldc(blane + cpad(k));
+                        acc[(j + d) % R][vv] += z * ldc(wlane + k);
+                    }
+            }
+            // block g = n has now received every frame that touches it
+            const int64_t g = n;
+            if (g >= hb0 && g < hb1) {
+                const bool steady = g >= R - 1 && g <= T - 1;
+                const int64_t m0 = g * hop - M;                   // output index of the block's first sample
+                if (steady && dst_al && m0 >= 0 && m0 + hop <= n_out) {
+                    float* op = dst + m0 + 2 * lane;
+#pragma unroll
+                    for (int vv = 0; vv < VPB; ++vv) *reinterpret_cast<cx*>(op + 128 * vv) = acc[j][vv] * nrm[vv];
+                } else {
+                    const int64_t f_hi = g < T - 1 ? g : T - 1;
+                    const int64_t f_lo = g < R ? 0 : g - (R - 1);
+#pragma unroll
+                    for (int vv = 0; vv < VPB; ++vv) {
+                        const int q = 2 * (lane + 64 * vv);
+                        const int64_t m = m0 + q;
+                        if (m + 1 < 0 || m >= n_out) continue;
+                        float nx = 0.f, ny = 0.f;
+                        for (int64_t f = f_lo; f <= f_hi; ++f) {
+                            nx += wsq[(g - f) * hop + q];
+                            ny += wsq[(g - f) * hop + q + 1];
+                        }
+                        if (nx == 0.f) nx = 1.f;
+                        if (ny == 0.f) ny = 1.f;
+                        if (m >= 0) dst[m] = steady ? acc[j][vv][0] * nrm[vv][0] : acc[j][vv][0] / nx;
+                        if (m + 1 < n_out) dst[m + 1] = steady ? acc[j][vv][1] * nrm[vv][1] : acc[j][vv][1] / ny;
+                    }
+                }
+            }
+#pragma unroll
+            for (int vv = 0; vv < VPB; ++vv) acc[j][vv] = mk(0.f, 0.f);
+        }
+    }
+}
+
 template <int LOG2M>
 int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips, float* mag,
                float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave,
@@ -639,6 +808,38 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     const int wreg = (lean_env && hop / 2 <= 256 && (R_ == 2 || R_ == 4) && LOG2M <= 10) ? R_ : 0;
     const size_t lds = ((wreg ? 0 : (size_t)(M + 1)) + 4 * (size_t)MP + (wreg ? 0 : (size_t)M) +
                         (size_t)ring_slots * (hop / 2)) * sizeof(float2) + (size_t)hop * sizeof(float);
+    // barrier-free wave-sequential kernel: N <= 2048, frames of 2 or 4 hop-blocks, hop / 2 a multiple of 64
+    static const int seq_env = getenv("DCS_ISTFT_SEQ") ? atoi(getenv("DCS_ISTFT_SEQ")) : 1;
+    if constexpr (LOG2M <= 10) {
+        if (seq_env && (R_ == 2 || R_ == 4) && (hop / 2) % 64 == 0 && R_ * (hop / 2) == M) {
+            static const int c_seq = getenv("DCS_ISTFT_SEQ_HOPS") ? atoi(getenv("DCS_ISTFT_SEQ_HOPS")) : 0;
+            const int64_t total_s = n_blocks * n_src;
+            // 2 waves per SIMD: the kernel needs ~240 registers (the R blocks in flight, the pass twiddles, a frame's points);
+            // sized for 3 waves it spills 46 of them and runs 2.2x slower (0.52 vs 0.24 ms at 4096 tiles)
+            const int64_t resident_w = (int64_t)p->ctx->n_cu * 4 * 2;
+            int64_t Cs = (total_s + resident_w - 1) / resident_w;
+            if (Cs < 1) Cs = 1;
+            if (c_seq > 0) Cs = c_seq;
+            const int n_chunks_s = (int)((n_blocks + Cs - 1) / Cs);
+            const size_t lds_s = ((size_t)M + 4 * (size_t)MP) * sizeof(float2);
+            const dim3 grid_s((unsigned)(((int64_t)n_chunks_s * n_src + 3) / 4));
+#define DCS_SEQ(UNIT_, R__)                                                                                          \
+            {                                                                                                        \
+                auto kern = istft_seq_kernel<LOG2M, UNIT_, R__>;                                                     \
+                if (lds_s > 48 * 1024)                                                                               \
+                    DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));            \
+                hipLaunchKernelGGL(kern, grid_s, dim3(256), lds_s, p->ctx->stream, mag, src_stride, phase, unit, ld,  \
+                                   p->win_f, p->wsq_f, p->tw_f, audio, n_out, T, (int)Cs, n_blocks, n_chunks_s, n_src, \
+                                   pre_div, (float)sqrt((double)N), unit_clip_stride,                                \
+                                   src_per_clip > 0 ? src_per_clip : n_src, clip_tab, out_stride > 0 ? out_stride : n_out); \
+            }
+            if (unit) { if (R_ == 4) DCS_SEQ(true, 4) else DCS_SEQ(true, 2) }
+            else { if (R_ == 4) DCS_SEQ(false, 4) else DCS_SEQ(false, 2) }
+#undef DCS_SEQ
+            return DCS_OK;
+        }
+    }
     static const int pad_env = getenv("DCS_ISTFT_LDSPAD") ? atoi(getenv("DCS_ISTFT_LDSPAD")) : 0;  // occupancy experiments
     const size_t lds_req = lds + (size_t)pad_env;
     if (lds_req > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "wave iSTFT: %zu bytes of LDS", lds_req);

@@ -769,9 +769,11 @@ def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
     {"DCS_FINAL_CBW": "2", "DCS_FINAL_BF16X3": "0"},              # 128-bin workgroups, f32 kernel
     {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2"},                   # bf16x3 kernel fed by the streaming deconv2 (writes the planes)
     {"DCS_DECONV2": "2"}, {"DCS_DECONV2": "1"},                   # streaming / one-shot transposed conv2
-    {"DCS_ISTFT_HOPS": "1"}, {"DCS_ISTFT_HOPS": "7"}, {"DCS_ISTFT_HOPS": "64"},   # hop-blocks per iSTFT workgroup
+    {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "1"}, {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "7"},
+    {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "64"},              # ring iSTFT: hop-blocks per workgroup
     {"DCS_STFT_WAVE_MIN": "1"}, {"DCS_FFT_BLOCK": "1"},           # wave-per-frame / block-level FFT everywhere
-    {"DCS_ISTFT_LEAN": "0"},                                       # iSTFT with its twiddle / window tables in LDS
+    {"DCS_ISTFT_LEAN": "0", "DCS_ISTFT_SEQ": "0"},               # ring iSTFT with its twiddle / window tables in LDS
+    {"DCS_ISTFT_SEQ": "0"}, {"DCS_ISTFT_SEQ_HOPS": "1"}, {"DCS_ISTFT_SEQ_HOPS": "37"},   # ring iSTFT; blocks per wave of the sequential one
     {"DCS_GRAPH": "0"},
 ])
 @pytest.mark.parametrize("N", [1024, 2048])
