@@ -48,8 +48,14 @@ if [ "${DCS_PROFILE:-1}" = "1" ]; then
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- \
       python $GRAFT_REPO_ROOT/bench.py --steps 160 --warmup 32 --no-cpu-baseline --no-host-fed > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err)
   echo "rocprof exit $?"
-  for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -n 40 $f; done
-  python scripts/trace_by_grid.py $OUT/prof > $OUT/kernel_durations_by_grid.txt 2>&1; head -n 60 $OUT/kernel_durations_by_grid.txt
+  for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -n 14 $f; done
+  python scripts/trace_by_grid.py $OUT/prof > $OUT/kernel_durations_by_grid.txt 2>&1
+  # the same on ONE stream: kernel durations that are not time-sliced with another stream's kernels (what the HIP events of
+  # bench.py's event rounds measure)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof1 -o bench -- \
+      python $GRAFT_REPO_ROOT/bench.py --steps 160 --warmup 32 --streams 1 --no-cpu-baseline --no-host-fed --legs= > $GRAFT_REPO_ROOT/$OUT/prof1_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof1.err)
+  echo "rocprof (1 stream) exit $?"
+  python scripts/trace_by_grid.py $OUT/prof1 > $OUT/kernel_durations_by_grid_1stream.txt 2>&1; grep -E "final|istft|deconv2_stream|stft_forward_wave" $OUT/kernel_durations_by_grid_1stream.txt
 fi
 cat $OUT/mask_bins.txt 2>/dev/null | head -40
 cat $OUT/f16_stats.txt 2>/dev/null
