@@ -155,8 +155,14 @@ struct DcsGemm {
     // set by the launcher only: K split over workgroups (few rows, very long K -- the 166 650-wide dense layer of
     // the Bach10 graph): slice z covers [z*kchunk, (z+1)*kchunk) and writes raw sums to partial[z][M][n_cols]
     float* partial; int kchunk;
+    // optional: B split into three bf16 planes by dcs_gemm_pack_bq (gemm_bf16x3.hip); launches that fill the chip then
+    // run on the bf16 matrix pipe with f32-class results
+    const void* Bq;
 };
 int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag);
+size_t dcs_gemm_bq_bytes(int K, int n_cols);
+int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d);   // enqueued on the ctx stream
+bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g);
 
 // ---------------------------------------------------------------------------------- tiling kernels
 int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F,

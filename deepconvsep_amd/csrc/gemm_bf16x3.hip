@@ -1,0 +1,208 @@
+// GEMM over gathered rows on the bf16 matrix pipe with f32-class results (gfx950, v_mfma_f32_16x16x32_bf16).
+//
+// Same contract as gemm_rows_kernel (gemm.hip): C[row(r)][0..n_store) = act(a_scale * A[arow(r)][0..K) . B[K][n_cols] + bias).
+// Both operands are split exactly into three bf16 terms by truncation (x = hi + mid + lo, 8 + 8 + 8 significand bits)
+// and the six term products above 2^-24 are accumulated in f32:
+//     a.b ~= a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)        dropped: <= 3 * 2^-24 |a b|
+// bf16 x bf16 products are exact in f32, so the only roundings are the accumulator's -- the class of the f32-MFMA kernel --
+// at 6 MFMAs of 16 cycles per 16 x 16 x 32 block instead of 8 of 32, with the VALU (splitting A, address arithmetic)
+// running beside the matrix pipe.
+//   B is split once per model by gemm_pack_bq_kernel: Bq[k tile][plane][column][4 pieces], a 16-byte piece = the 8
+//     consecutive k of one column a lane multiplies, so a wave's B fragment of a (k tile, plane) is 1 KB contiguous and
+//     goes from L2 straight to registers (each element is used by one wave of the workgroup: no LDS for B).
+//   A rows are fetched as f32 (8 consecutive k per thread), scaled, split in registers and stored to LDS as planes
+//     [plane][row][4 pieces], double buffered, one barrier per k tile; the next tile's rows and B fragments are requested
+//     before the current tile is multiplied.
+// Workgroup = 4 waves = 4 column blocks of 16; RB row blocks of 16 per wave (B fragments reused RB times).
+#include "dcs_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kThreads = 256;
+constexpr int kRowU4 = 5;   // LDS row stride in 16-byte pieces: 4 pieces + 1 (20 words: 16 rows start in 16 different bank quads)
+
+__device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& mid, u32x4& lo) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? x0[j] : x1[j - 4];
+        h[j] = bf_trunc(x);
+        const float r1 = x - __uint_as_float(h[j]);      // exact
+        m[j] = bf_trunc(r1);
+        l[j] = bf_trunc(r1 - __uint_as_float(m[j]));     // exact difference, at most 8 significant bits left
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hi[q] = (h[2 * q] >> 16) | h[2 * q + 1];
+        mid[q] = (m[2 * q] >> 16) | m[2 * q + 1];
+        lo[q] = (l[2 * q] >> 16) | l[2 * q + 1];
+    }
+}
+
+__device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// B f32 [K rows][ldb] (rows past K are read as zero) -> Bq[kt][plane][n_cols][4] pieces
+__global__ __launch_bounds__(kThreads) void gemm_pack_bq_kernel(const float* __restrict__ B, int K, int ldb, int n_cols,
+                                                                u32x4* __restrict__ Bq, int64_t n_pieces /* kt * n_cols * 4 */) {
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;   // (kt, n, kq), n fastest within kq? -> kq fastest
+    if (idx >= n_pieces) return;
+    const int kq = (int)(idx & 3);
+    const int64_t t = idx >> 2;
+    const int n = (int)(t % n_cols);
+    const int64_t kt = t / n_cols;
+    f32x4 x0, x1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t k = kt * 32 + kq * 8 + j;
+        const float v = k < K ? B[k * ldb + n] : 0.f;
+        if (j < 4) x0[j] = v; else x1[j - 4] = v;
+    }
+    u32x4 p0, p1, p2;
+    split8(x0, x1, p0, p1, p2);
+    const int64_t base = (kt * 3 * n_cols + n) * 4 + kq;
+    Bq[base] = p0;
+    Bq[base + (int64_t)n_cols * 4] = p1;
+    Bq[base + (int64_t)n_cols * 8] = p2;
+}
+
+template <int RB>
+__global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g) {
+    constexpr int BM = 16 * RB;
+    constexpr int kPlane = BM * kRowU4;                 // pieces per plane
+    constexpr int kBuf = 3 * kPlane;
+    __shared__ u32x4 As[2 * kBuf];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * 64;
+    const int gK = g.K, n_cols = g.n_cols;
+    const int64_t gM = g.M;
+    const float gscale = g.a_scale;
+    // A staging: piece (row, kq) = 8 consecutive k of one row; BM * 4 pieces, one per thread for RB = 4
+    constexpr int A_PER = (BM * 4 + kThreads - 1) / kThreads;
+    const float* a_ptr[A_PER];
+    bool a_ok[A_PER];
+    int a_dst[A_PER], a_k0[A_PER];
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        const int idx = tid + u * kThreads;
+        const int row = idx >> 2, q = idx & 3;
+        const int64_t r = m0 + row;
+        a_ok[u] = idx < BM * 4 && r < gM;
+        const int64_t rr = a_ok[u] ? r : 0;
+        a_ptr[u] = g.A + ((rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda + q * 8;
+        a_k0[u] = q * 8;
+        a_dst[u] = row * kRowU4 + q;
+    }
+    const u32x4* Bq = reinterpret_cast<const u32x4*>(g.Bq) + ((int64_t)(n0 + wave * 16 + fi)) * 4 + kq;
+    const int64_t b_plane = (int64_t)n_cols * 4, b_kt = 3 * b_plane;
+
+    f32x4 ra[A_PER][2];
+    u32x4 rb[3];
+#define DCS_LOAD(kt_)                                                                                   \
+    {                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                             \
+            const int k = (kt_) * 32 + a_k0[u];                                                         \
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+            ra[u][0] = (a_ok[u] && k < gK) ? *reinterpret_cast<const f32x4*>(a_ptr[u] + (kt_) * 32) : z;      \
+            ra[u][1] = (a_ok[u] && k + 4 < gK) ? *reinterpret_cast<const f32x4*>(a_ptr[u] + (kt_) * 32 + 4) : z; \
+        }                                                                                               \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) rb[p] = Bq[(kt_) * b_kt + p * b_plane];           \
+    }
+#define DCS_STORE(buf_)                                                                                 \
+    {                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                             \
+            if (A_PER * kThreads == BM * 4 || tid + u * kThreads < BM * 4) {                            \
+                u32x4 p0, p1, p2;                                                                       \
+                split8(ra[u][0] * gscale, ra[u][1] * gscale, p0, p1, p2);                               \
+                As[(buf_) * kBuf + a_dst[u]] = p0;                                                      \
+                As[(buf_) * kBuf + kPlane + a_dst[u]] = p1;                                             \
+                As[(buf_) * kBuf + 2 * kPlane + a_dst[u]] = p2;                                         \
+            }                                                                                           \
+        }                                                                                               \
+    }
+
+    f32x4 acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkt = (gK + 31) / 32;
+    DCS_LOAD(0)
+    for (int kt = 0; kt < nkt; ++kt) {
+        // buffer kt & 1 was last read in iteration kt - 2; the barrier of iteration kt - 1 fences those reads
+        DCS_STORE(kt & 1)
+        u32x4 bcur[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bcur[p] = rb[p];
+        __syncthreads();
+        if (kt + 1 < nkt) DCS_LOAD(kt + 1)
+        const u32x4* Ab = As + (kt & 1) * kBuf + fi * kRowU4 + kq;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const u32x4 a0 = Ab[r * 16 * kRowU4], a1 = Ab[kPlane + r * 16 * kRowU4], a2 = Ab[2 * kPlane + r * 16 * kRowU4];
+            // smallest terms first
+            acc[r] = mma(a2, bcur[0], acc[r]);
+            acc[r] = mma(a0, bcur[2], acc[r]);
+            acc[r] = mma(a1, bcur[1], acc[r]);
+            acc[r] = mma(a1, bcur[0], acc[r]);
+            acc[r] = mma(a0, bcur[1], acc[r]);
+            acc[r] = mma(a0, bcur[0], acc[r]);
+        }
+    }
+#undef DCS_LOAD
+#undef DCS_STORE
+    // epilogue: C/D layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
+    const int col = n0 + wave * 16 + fi;
+    if (col < g.n_store) {
+        const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = m0 + r * 16 + kq * 4 + e;
+                if (row < g.M) {
+                    float v = acc[r][e] + bias;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t dcs_gemm_bq_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * 3 * (size_t)n_cols * 4 * 16; }
+
+int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d) {
+    const int64_t n_pieces = (int64_t)((K + 31) / 32) * n_cols * 4;
+    hipLaunchKernelGGL(gemm_pack_bq_kernel, dim3((unsigned)dcs_cdiv(n_pieces, kThreads)), dim3(kThreads), 0, ctx->stream, B_d, K,
+                       ldb, n_cols, reinterpret_cast<u32x4*>(Bq_d), n_pieces);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+// true when the launch was taken (the caller's DcsTimer brackets it)
+bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
+    static const bool on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
+    if (!on || !g.Bq || !g.a_vec || g.partial || (g.K & 3) || (g.lda & 3)) return false;
+    const int64_t groups16 = (g.M + 15) / 16, col_groups = g.n_cols / 64;
+    // launches that fill the chip only: with few workgroups a kernel's duration is one wave's dependent chain and the
+    // f32 split-K kernels of gemm.hip cut that chain instead
+    if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu) return false;
+    if (groups16 * col_groups <= 16 * (int64_t)ctx->n_cu)
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<2>), dim3((unsigned)dcs_cdiv(g.M, 32), (unsigned)col_groups), dim3(kThreads), 0,
+                           ctx->stream, g);
+    else
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<4>), dim3((unsigned)dcs_cdiv(g.M, 64), (unsigned)col_groups), dim3(kThreads), 0,
+                           ctx->stream, g);
+    return true;
+}

@@ -861,6 +861,8 @@ struct DcsGenericNet {
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
     float* Bd[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* Bfcq = nullptr;                                 // dense weights as bf16 planes (gemm_bf16x3.hip)
+    void* Bdq[4] = {nullptr, nullptr, nullptr, nullptr};
     float* biasd[4] = {nullptr, nullptr, nullptr, nullptr};
     float* bout = nullptr;
     DcsBuffer ws;
@@ -1001,6 +1003,15 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     std::vector<float> bout(P[8 + 2 * d.n_fc]);
     UP(g->bout, bout)
 #undef UP
+    if (rc == DCS_OK) {   // the dense weights once more as three bf16 planes each, split on the device
+        auto pack = [&](const float* B, int rows, int cols, void** q) -> int {
+            DCS_HIP(hipMalloc(q, dcs_gemm_bq_bytes(rows, cols)));
+            return dcs_gemm_pack_bq(ctx, B, rows, cols, cols, *q);
+        };
+        rc = pack(g->Bfc, (int)dcs_round_up(Kfc, 128), g->hid64, &g->Bfcq);
+        for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) rc = pack(g->Bd[s], (int)dcs_round_up(g->hid64, 128), g->flat64, &g->Bdq[s]);
+        if (rc == DCS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = DCS_EHIP;
+    }
     if (rc != DCS_OK) {
         dcs_generic_destroy(g);
         return rc;
@@ -1013,7 +1024,7 @@ void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
     void* ptrs[] = {g->Wslab, g->Wslab_t, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
-                    g->biasd[3], g->bout, g->rise_d};
+                    g->biasd[3], g->bout, g->rise_d, g->Bfcq, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1157,7 +1168,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     {
         DcsGemm q{};
         q.A = a2b; q.lda = g->flat_p; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
-        q.B = g->Bfc; q.ldb = g->hid64; q.bias = g->biasfc;
+        q.B = g->Bfc; q.ldb = g->hid64; q.bias = g->biasfc; q.Bq = g->Bfcq;
         q.C = Z; q.ldc = g->hid64; q.c_gdiv = 1 << 30; q.c_gmul = 0;
         q.M = n; q.n_cols = g->hid64; q.n_store = g->hid64; q.K = g->flat_p; q.relu = 1; q.a_vec = 1;
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC));
@@ -1168,7 +1179,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         const int s = d.branch_fc[b];
         DcsGemm q{};
         q.A = Z; q.lda = g->hid64; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
-        q.B = g->Bd[s]; q.ldb = g->flat64; q.bias = g->biasd[s];
+        q.B = g->Bd[s]; q.ldb = g->flat64; q.bias = g->biasd[s]; q.Bq = g->Bdq[s];
         q.C = D + (int64_t)b * g->flat_p; q.ldc = (int64_t)NB * g->flat_p; q.c_gdiv = 1 << 30; q.c_gmul = 0;
         q.M = n; q.n_cols = g->flat64; q.n_store = d.flat; q.K = g->hid64; q.relu = 1; q.a_vec = 1;
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC1X));
