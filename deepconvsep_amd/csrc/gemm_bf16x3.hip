@@ -196,8 +196,10 @@ bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
     if (!on || !g.Bq || !g.a_vec || g.partial || (g.K & 3) || (g.lda & 3)) return false;
     const int64_t groups16 = (g.M + 15) / 16, col_groups = g.n_cols / 64;
     // launches that fill the chip only: with few workgroups a kernel's duration is one wave's dependent chain and the
-    // f32 split-K kernels of gemm.hip cut that chain instead
-    if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu) return false;
+    // f32 split-K kernels of gemm.hip cut that chain instead.  And wide B only (the per-source dense layers): the
+    // A-streaming GEMMs of the encoder are bound by memory latency, not by the matrix pipe -- measured at 4096 tiles
+    // conv1 0.041 -> 0.047 ms, fc 0.020 -> 0.021, while fc1x 0.042 -> 0.036; Bach10 fc1x (167 x 256 x 666 600) 0.72 -> 0.58
+    if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu || g.n_cols < 1024 || g.M < 128) return false;
     if (groups16 * col_groups <= 16 * (int64_t)ctx->n_cu)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2>), dim3((unsigned)dcs_cdiv(g.M, 32), (unsigned)col_groups), dim3(kThreads), 0,
                            ctx->stream, g);

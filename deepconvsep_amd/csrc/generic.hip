@@ -617,6 +617,194 @@ __global__ __launch_bounds__(kColThreads) void slabconv_kernel(const SlabConvArg
 }
 
 // ------------------------------------------------------------------------------------------------
+// The slab convolution on the 16-bit matrix pipe.  One MFMA (16 x 16 x 32) covers a whole tap -- 32 input channels --
+// for 16 output channels x 16 columns:
+//   MODE 0 (default, f32-class results): both operands split exactly into three bf16 terms (x = hi + mid + lo by
+//           truncation), the six term products above 2^-24 accumulated in f32 -- 12 MFMAs of 16 cycles per (tap, block)
+//           instead of 16 of 32, with the VALU (splitting the slab values) running beside the matrix pipe;
+//   MODE 1 (dcs_model_set_conv_precision(f16)): operands rounded to f16, one product -- 2 MFMAs per (tap, block).
+// The slab stays f32 in LDS, channel-fastest [row][x][36] (32 channels + 4 words: a lane's 8 channels are two 16-byte
+// reads, 16 consecutive x start in 16 different bank quads); a lane converts its 8 values when it uses them.  The
+// weights are packed per model [tap][plane][32 co][4 pieces] (a 16-byte piece = the 8 input channels a lane multiplies)
+// and stream through LDS two taps at a time with a row stride of 5 pieces.  Bands, tap / block skipping and the
+// accumulator layout are those of slabconv_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kSlabCi = 36;                 // floats per (row, x) of the slab
+constexpr int kSlabWRow = 5;                // 16-byte pieces per (plane, co) weight row in LDS: 4 + 1 pad
+
+__device__ __forceinline__ unsigned bf_trunc_u(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+template <int MODE>
+__device__ __forceinline__ void slab_convert(const f32x4& x0, const f32x4& x1, u32x4 (&out)[MODE == 0 ? 3 : 1]) {
+    if constexpr (MODE == 0) {
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = j < 4 ? x0[j] : x1[j - 4];
+            h[j] = bf_trunc_u(x);
+            const float r1 = x - __uint_as_float(h[j]);
+            m[j] = bf_trunc_u(r1);
+            l[j] = bf_trunc_u(r1 - __uint_as_float(m[j]));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            out[0][q] = (h[2 * q] >> 16) | h[2 * q + 1];
+            out[1][q] = (m[2 * q] >> 16) | m[2 * q + 1];
+            out[2][q] = (l[2 * q] >> 16) | l[2 * q + 1];
+        }
+    } else {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)(j < 4 ? x0[j] : x1[j - 4]);
+        out[0] = __builtin_bit_cast(u32x4, v);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4 slab_mma(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (MODE == 0)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kColThreads) void slabconv_mx_kernel(const SlabConvArgs g, const u32x4* __restrict__ Wq) {
+    constexpr int NP = MODE == 0 ? 3 : 1;
+    constexpr int kTapLds = NP * 32 * kSlabWRow;          // pieces per tap in LDS
+    constexpr int kTapGlb = NP * 32 * 4;                  // pieces per tap in the packed array
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem);           // [2][tstage][NP][32][5]
+    const int wstage = g.tstage * kTapLds;                // pieces per weight stage
+    float* slab = smem + 2 * wstage * 4;                  // [rows_max][W][36]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t img = blockIdx.x / g.n_bands;
+    const int y0 = (int)(blockIdx.x - img * g.n_bands) * g.band;
+    const int yb = y0 + g.band < g.Ho ? y0 + g.band : g.Ho;   // rows [y0, yb)
+    const float* in = g.in + img * g.in_n_stride;
+    float* out = g.out + img * g.out_n_stride;
+    int rbase = y0 - g.ph, rtop = yb - 1 - g.ph + g.kh - 1;
+    if (rbase < 0) rbase = 0;
+    if (rtop > g.H - 1) rtop = g.H - 1;
+    const int rows = rtop - rbase + 1;
+    const int RW = g.rows_max * g.W;
+    // slab fill: element (ci, r, x) with x fastest (coalesced reads of the channel-major input); channels >= Cin and
+    // rows past the band's reach are zero
+    for (int i = tid; i < 32 * RW; i += kColThreads) {
+        const int ci = i / RW, rem = i - ci * RW;
+        const int r = rem / g.W;
+        slab[rem * kSlabCi + ci] = (ci < g.Cin && r < rows) ? in[((int64_t)ci * g.H + rbase + r) * g.W + (rem - r * g.W)] : 0.f;
+    }
+    const int nxb = (g.Wo + 15) >> 4, nblk = (yb - y0) * nxb;
+    int by[4], bx[4];
+    f32x4 acc0[4], acc1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = wave + 8 * i;
+        by[i] = b < nblk ? y0 + b / nxb : -1;
+        bx[i] = b < nblk ? (b % nxb) * 16 : 0;
+        acc0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nvs = (g.kw + g.tstage - 1) / g.tstage;
+    int u_lo = g.ph - (yb - 1), u_hi = g.ph - y0 + g.H - 1;
+    if (u_lo < 0) u_lo = 0;
+    if (u_hi > g.kh - 1) u_hi = g.kh - 1;
+    const int n_stage = (u_hi - u_lo + 1) * nvs;
+    // weight staging: a stage is tstage * NP * 128 pieces, at most 2 per thread (tstage <= 2 for NP = 3)
+    constexpr int WPRE = 2;
+    u32x4 wpre[WPRE];
+#define DCS_SLABQ_WFETCH(st_)                                                                           \
+    {                                                                                                   \
+        const int u_ = u_lo + (st_) / nvs, v_ = ((st_) % nvs) * g.tstage;                               \
+        const int nt_ = v_ + g.tstage <= g.kw ? g.tstage : g.kw - v_;                                    \
+        _Pragma("unroll") for (int q = 0; q < WPRE; ++q) {                                              \
+            const int e = tid + q * kColThreads;                                                        \
+            wpre[q] = e < nt_ * kTapGlb ? Wq[(int64_t)(u_ * g.kw + v_) * kTapGlb + e] : u32x4{0u, 0u, 0u, 0u}; \
+        }                                                                                               \
+    }
+    if (n_stage > 0) DCS_SLABQ_WFETCH(0)
+    for (int st = 0; st < n_stage; ++st) {
+        u32x4* Wb = Wl + (st & 1) * wstage;
+#pragma unroll
+        for (int q = 0; q < WPRE; ++q) {
+            const int e = tid + q * kColThreads;           // (tap, plane * 32 + co, kq) in the packed order
+            if (e < g.tstage * kTapGlb) Wb[(e >> 2) * kSlabWRow + (e & 3)] = wpre[q];
+        }
+        __syncthreads();       // also orders the slab fill before the first use; buffer st&1 was last read at st-2
+        if (st + 1 < n_stage) DCS_SLABQ_WFETCH(st + 1)
+        const int u = u_lo + st / nvs, v0 = (st % nvs) * g.tstage;
+        const int nt = v0 + g.tstage <= g.kw ? g.tstage : g.kw - v0;
+        for (int tv = 0; tv < nt; ++tv) {
+            const int v = v0 + tv;
+            const u32x4* wp = Wb + tv * kTapLds + fi * kSlabWRow + kq;
+            u32x4 a0[NP], a1[NP];
+            bool have = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (by[i] < 0) continue;
+                const int r = by[i] + u - g.ph;                      // input row (uniform per block)
+                const int xs = bx[i] + v - g.pw;                     // shifted column of lane 0
+                if (r < 0 || r >= g.H || xs + 15 < 0 || xs >= g.W) continue;
+                if (!have) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        a0[p] = wp[(p * 32) * kSlabWRow];
+                        a1[p] = wp[(p * 32 + 16) * kSlabWRow];
+                    }
+                    have = true;
+                }
+                const int xl = xs + fi;
+                const bool ok = xl >= 0 && xl < g.W;
+                const float* sp = slab + ((r - rbase) * g.W + (ok ? xl : 0)) * kSlabCi + 8 * kq;
+                f32x4 x0 = *reinterpret_cast<const f32x4*>(sp), x1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                if (!ok) {
+                    x0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    x1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                u32x4 b[NP];
+                slab_convert<MODE>(x0, x1, b);
+                if constexpr (MODE == 0) {   // smallest terms first
+                    acc0[i] = slab_mma<0>(a0[2], b[0], acc0[i]);
+                    acc1[i] = slab_mma<0>(a1[2], b[0], acc1[i]);
+                    acc0[i] = slab_mma<0>(a0[0], b[2], acc0[i]);
+                    acc1[i] = slab_mma<0>(a1[0], b[2], acc1[i]);
+                    acc0[i] = slab_mma<0>(a0[1], b[1], acc0[i]);
+                    acc1[i] = slab_mma<0>(a1[1], b[1], acc1[i]);
+                    acc0[i] = slab_mma<0>(a0[1], b[0], acc0[i]);
+                    acc1[i] = slab_mma<0>(a1[1], b[0], acc1[i]);
+                    acc0[i] = slab_mma<0>(a0[0], b[1], acc0[i]);
+                    acc1[i] = slab_mma<0>(a1[0], b[1], acc1[i]);
+                    acc0[i] = slab_mma<0>(a0[0], b[0], acc0[i]);
+                    acc1[i] = slab_mma<0>(a1[0], b[0], acc1[i]);
+                } else {
+                    acc0[i] = slab_mma<1>(a0[0], b[0], acc0[i]);
+                    acc1[i] = slab_mma<1>(a1[0], b[0], acc1[i]);
+                }
+            }
+        }
+    }
+#undef DCS_SLABQ_WFETCH
+    const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (by[i] < 0 || bx[i] + fi >= g.Wo) continue;
+        float* op = out + (int64_t)by[i] * g.Wo + bx[i] + fi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = 4 * kq + e;
+            if (co < g.Cout) op[(int64_t)co * HoWo] = acc0[i][e] + g.bias[co];
+            if (co + 16 < g.Cout) op[(int64_t)(co + 16) * HoWo] = acc1[i][e] + g.bias[co + 16];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The column convolution with f16 inputs and f32 accumulation (v_mfma_f32_16x16x32_f16): one MFMA covers a whole
 // tap (32 input channels) for a 16 co x 16 x block, 16x the f32 rate, so this variant is LDS- and store-bound.
 // Slab and weights are stored channel-fastest -- slab [row][x][ci], weights [u][co][ci], rows of 32 halves padded to
@@ -853,6 +1041,8 @@ struct DcsGenericNet {
     int conv_f16 = 0;
     // column convolution (kw2 == 1): weights [kh][32 ci][32 co swizzled] of conv2 and of its transpose
     float *Wslab = nullptr, *Wslab_t = nullptr;   // [kh][kw][32][32] conv2 / its transpose for slabconv_kernel
+    // the same for slabconv_mx_kernel: [tap][plane][32 co][4 pieces of 8 ci]; q3 = three bf16 planes, h = one f16 plane
+    uint16_t *Wslab_q3 = nullptr, *Wslab_t_q3 = nullptr, *Wslab_h = nullptr, *Wslab_t_h = nullptr;
     int use_slabconv = 0;
     float* W1p = nullptr;      // conv1 filters padded to sw1*ceil(kw1/sw1) taps (register-blocked transpose of conv1)
     float *Wcol = nullptr, *Wcol_t = nullptr;
@@ -861,8 +1051,7 @@ struct DcsGenericNet {
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
     float* Bd[4] = {nullptr, nullptr, nullptr, nullptr};
-    void* Bfcq = nullptr;                                 // dense weights as bf16 planes (gemm_bf16x3.hip)
-    void* Bdq[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* Bdq[4] = {nullptr, nullptr, nullptr, nullptr};  // per-source dense weights as bf16 planes (gemm_bf16x3.hip)
     float* biasd[4] = {nullptr, nullptr, nullptr, nullptr};
     float* bout = nullptr;
     DcsBuffer ws;
@@ -957,6 +1146,35 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
                             W2[(((size_t)co * nf1 + ci) * kh + u) * kw + v];
                     }
     }
+    // 16-bit packings of both slab weight sets: piece (tap, plane, co, kq) = input channels 8 kq .. 8 kq + 7
+    std::vector<uint16_t> Wslab_q3, Wslab_t_q3, Wslab_h, Wslab_t_h;
+    if (g->use_slabconv) {
+        auto pack = [&](const std::vector<float>& Wf, std::vector<uint16_t>& q3, std::vector<uint16_t>& h1) {
+            const int taps = kh * kw;
+            q3.assign((size_t)taps * 3 * 32 * 32, 0);
+            h1.assign((size_t)taps * 32 * 32, 0);
+            for (int t = 0; t < taps; ++t)
+                for (int co = 0; co < 32; ++co)
+                    for (int ci = 0; ci < 32; ++ci) {
+                        float r = Wf[(size_t)t * 1024 + colconv_wslot(0, ci, co)];
+                        const _Float16 hv = (_Float16)r;
+                        uint16_t hb;
+                        memcpy(&hb, &hv, 2);
+                        h1[((size_t)t * 32 + co) * 32 + ci] = hb;
+                        for (int pl = 0; pl < 3; ++pl) {
+                            uint32_t bits;
+                            memcpy(&bits, &r, 4);
+                            bits &= 0xffff0000u;
+                            float part;
+                            memcpy(&part, &bits, 4);
+                            r -= part;
+                            q3[(((size_t)t * 3 + pl) * 32 + co) * 32 + ci] = (uint16_t)(bits >> 16);
+                        }
+                    }
+        };
+        pack(Wslab, Wslab_q3, Wslab_h);
+        pack(Wslab_t, Wslab_t_q3, Wslab_t_h);
+    }
     // column convolution (kw == 1): Wcol[u][ci][co] = W2[co][ci][kh-1-u] (true convolution), transpose
     // Wcol_t[u][co][ci] = W2[co][ci][u]
     std::vector<float> Wcol, Wcol_t;
@@ -991,7 +1209,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
     if (!W1p.empty()) { UP(g->W1p, W1p) }
-    if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) }
+    if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) UP(g->Wslab_q3, Wslab_q3) UP(g->Wslab_t_q3, Wslab_t_q3) UP(g->Wslab_h, Wslab_h) UP(g->Wslab_t_h, Wslab_t_h) }
     if (g->use_colconv) { UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) }
     for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) {
         std::vector<float> Bd((size_t)dcs_round_up(g->hid64, 128) * g->flat64, 0.f), bd(g->flat64, 0.f);
@@ -1003,12 +1221,11 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     std::vector<float> bout(P[8 + 2 * d.n_fc]);
     UP(g->bout, bout)
 #undef UP
-    if (rc == DCS_OK) {   // the dense weights once more as three bf16 planes each, split on the device
+    if (rc == DCS_OK) {   // the per-source dense weights once more as three bf16 planes, split on the device
         auto pack = [&](const float* B, int rows, int cols, void** q) -> int {
             DCS_HIP(hipMalloc(q, dcs_gemm_bq_bytes(rows, cols)));
             return dcs_gemm_pack_bq(ctx, B, rows, cols, cols, *q);
         };
-        rc = pack(g->Bfc, (int)dcs_round_up(Kfc, 128), g->hid64, &g->Bfcq);
         for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) rc = pack(g->Bd[s], (int)dcs_round_up(g->hid64, 128), g->flat64, &g->Bdq[s]);
         if (rc == DCS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = DCS_EHIP;
     }
@@ -1022,9 +1239,9 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->Wslab, g->Wslab_t, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
-                    g->biasd[3], g->bout, g->rise_d, g->Bfcq, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
+                    g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1033,10 +1250,15 @@ void dcs_generic_destroy(DcsGenericNet* g) {
 
 namespace {
 
-// false: the shape does not fit (LDS); the caller falls back to the implicit GEMM
-bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images) {
+// false: the shape does not fit (LDS); the caller falls back to the implicit GEMM.
+// Wq: weights packed for the 16-bit matrix pipe (mode 0: three bf16 planes, f32-class results -- the default; mode 1: one
+// f16 plane); null: the f32-MFMA kernel (DCS_SLABCONV_MX=0).
+bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images, const uint16_t* Wq = nullptr, int mode = 0) {
     const int nxb = (a.Wo + 15) / 16;
-    a.tstage = a.kw < 4 ? a.kw : 4;
+    const int np = mode == 0 ? 3 : 1;
+    a.tstage = Wq ? (a.kw < 2 ? a.kw : 2) : (a.kw < 4 ? a.kw : 4);
+    const size_t w_bytes = Wq ? (size_t)2 * a.tstage * np * 32 * kSlabWRow * 16 : (size_t)2 * a.tstage * 1024 * sizeof(float);
+    const size_t row_bytes = Wq ? (size_t)a.W * kSlabCi * sizeof(float) : (size_t)32 * a.W * sizeof(float);
     int band = 32 / nxb;                                   // 4 blocks per wave at most
     if (band < 1) return false;
     if (band > a.Ho) band = a.Ho;
@@ -1047,17 +1269,26 @@ bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images) {
     size_t lds;
     for (;; --band) {
         if (band < 1) return false;
-        lds = ((size_t)2 * a.tstage * 1024 + (size_t)32 * (band + a.kh - 1) * a.W) * sizeof(float);
+        lds = w_bytes + row_bytes * (size_t)(band + a.kh - 1);
         if (lds <= 160 * 1024) break;
     }
     a.band = band;
     a.n_bands = (a.Ho + band - 1) / band;
     a.rows_max = band + a.kh - 1;
+    const dim3 grid((unsigned)(n_images * a.n_bands));
+    if (Wq) {
+        auto kern = mode == 0 ? slabconv_mx_kernel<0> : slabconv_mx_kernel<1>;
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return false;
+        hipLaunchKernelGGL(kern, grid, dim3(kColThreads), lds, ctx->stream, a, reinterpret_cast<const u32x4*>(Wq));
+        return true;
+    }
     auto kern = slabconv_kernel;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * a.n_bands)), dim3(kColThreads), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(kColThreads), lds, ctx->stream, a);
     return true;
 }
 
@@ -1093,6 +1324,7 @@ int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16
 }
 
 static const bool kF16Igemm = getenv("DCS_F16_IGEMM") && atoi(getenv("DCS_F16_IGEMM")) != 0;
+static const bool kSlabMx = !(getenv("DCS_SLABCONV_MX") && atoi(getenv("DCS_SLABCONV_MX")) == 0);   // 0: the f32-MFMA slab kernel
 
 // one chunk of tiles through the graph; scratch carved from `w`
 int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_total, int64_t k_first, int mask_mode,
@@ -1146,8 +1378,8 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.ph = 0; c.kh = d.kh2;
             DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr));
         } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
-            // general filters (iKala, 10 x 20): the f32 slab kernel beats the f16 implicit GEMM (10 s: 1.9 vs 2.4 ms), so the
-            // switch keeps it unless DCS_F16_IGEMM=1 asks for the f16 kernel
+            // general filters (iKala, 10 x 20) go through the slab kernel in either precision unless DCS_F16_IGEMM=1 asks
+            // for the f16 implicit GEMM
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2m_h);
         else {
@@ -1157,7 +1389,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                 c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
                 c.Wk = g->Wslab; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride;
                 c.Cout = a.Cout; c.Ho = a.Ho; c.Wo = a.Wo; c.kh = d.kh2; c.kw = d.kw2; c.ph = 0; c.pw = 0;
-                done = launch_slabconv(ctx, c, n);
+                done = launch_slabconv(ctx, c, n, kSlabMx ? (g->conv_f16 ? g->Wslab_h : g->Wslab_q3) : nullptr, g->conv_f16 ? 1 : 0);
             }
             if (!done)
                 hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
@@ -1168,7 +1400,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     {
         DcsGemm q{};
         q.A = a2b; q.lda = g->flat_p; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
-        q.B = g->Bfc; q.ldb = g->hid64; q.bias = g->biasfc; q.Bq = g->Bfcq;
+        q.B = g->Bfc; q.ldb = g->hid64; q.bias = g->biasfc;
         q.C = Z; q.ldc = g->hid64; q.c_gdiv = 1 << 30; q.c_gmul = 0;
         q.M = n; q.n_cols = g->hid64; q.n_store = g->hid64; q.K = g->flat_p; q.relu = 1; q.a_vec = 1;
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC));
@@ -1209,7 +1441,8 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                 c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
                 c.Wk = g->Wslab_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride;
                 c.Cout = a.Cout; c.Ho = a.Ho; c.Wo = a.Wo; c.kh = d.kh2; c.kw = d.kw2; c.ph = d.kh2 - 1; c.pw = d.kw2 - 1;
-                done = launch_slabconv(ctx, c, n * NB);
+                done = launch_slabconv(ctx, c, n * NB, kSlabMx ? (g->conv_f16 ? g->Wslab_t_h : g->Wslab_t_q3) : nullptr,
+                                       g->conv_f16 ? 1 : 0);
             }
             if (!done)
                 hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);

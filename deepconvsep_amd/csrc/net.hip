@@ -91,7 +91,7 @@ struct dcs_model {
     // bf16x3 kernels: the transposed-conv1 and conv2 weights split into three bf16 planes
     uint16_t* Bpk = nullptr;
     uint16_t* Bw2q = nullptr;
-    void *B1q = nullptr, *B2q = nullptr, *Bfcq = nullptr, *Bdq = nullptr;   // GEMM weights as bf16 planes (gemm_bf16x3.hip)
+    void* Bdq = nullptr;   // per-source dense weights as bf16 planes (gemm_bf16x3.hip)
     DcsBuffer clip_tab;   // {samples, frames, tiles} per clip of a batch of different lengths (dcs_separate_ragged)
     float* rise_d = nullptr;
     int rise_ov = -1;
@@ -239,14 +239,11 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     DCS_CHECK(upload(&m->Bfin, Bfin));
     DCS_CHECK(upload(&m->bout, bout));
     {
-        // the four GEMM weight matrices once more as three bf16 planes each, split on the device
-        struct { float* B; int rows, cols; void** q; } mats[4] = {
-            {m->B1, (int)dcs_round_up(m->K1, 128), 64, &m->B1q}, {m->B2, (int)dcs_round_up(kh * CI, 128), 64, &m->B2q},
-            {m->Bfc, (int)dcs_round_up(d.h2 * CP, 128), m->hid64, &m->Bfcq}, {m->Bd, (int)dcs_round_up(m->hid64, 128), m->nd64, &m->Bdq}};
-        for (auto& t : mats) {
-            DCS_HIP(hipMalloc(t.q, dcs_gemm_bq_bytes(t.rows, t.cols)));
-            DCS_CHECK(dcs_gemm_pack_bq(m->ctx, t.B, t.rows, t.cols, t.cols, *t.q));
-        }
+        // the per-source dense weights once more as three bf16 planes, split on the device (the wide-B GEMM of large
+        // launches runs on the bf16 matrix pipe; the encoder GEMMs are latency-bound and stay f32)
+        const int rows = (int)dcs_round_up(m->hid64, 128);
+        DCS_HIP(hipMalloc(&m->Bdq, dcs_gemm_bq_bytes(rows, m->nd64)));
+        DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->Bd, rows, m->nd64, m->nd64, m->Bdq));
     }
     if (C == 1) {
         // bf16x3 variant of the final kernel: Bpk[bin][plane 3][K block 2][lane group 4][8 channels], channel
@@ -316,7 +313,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     const int64_t n_rows1 = clips ? n_clips * clip_pitch : (shared_frames ? (n - 1) * tile_row_stride + tc : n * tc);
     DcsGemm g1{};
     g1.A = rows_src; g1.lda = lda; g1.a_gdiv = 1 << 30; g1.a_gmul = 0; g1.a_scale = a_scale;
-    g1.B = m->B1; g1.ldb = 64; g1.bias = m->bias1; g1.Bq = m->B1q;
+    g1.B = m->B1; g1.ldb = 64; g1.bias = m->bias1;
     g1.C = w.H1; g1.ldc = CI; g1.c_gdiv = 1 << 30; g1.c_gmul = 0;
     g1.M = n_rows1; g1.n_cols = 64; g1.n_store = CI; g1.K = a_vec ? m->K1 : m->F; g1.relu = 0; g1.a_vec = a_vec;
     (void)BIG;
@@ -327,7 +324,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     if (clips) { g2.a_gdiv = 1 << 30; g2.a_gmul = 0; g2.M = n_rows1 - (d.kh2 - 1); }
     else if (shared_frames) { g2.a_gdiv = 1 << 30; g2.a_gmul = 0; g2.M = (n - 1) * tile_row_stride + d.h2; }
     else { g2.a_gdiv = d.h2; g2.a_gmul = tc; g2.M = n * d.h2; }
-    g2.B = m->B2; g2.ldb = 64; g2.bias = m->bias2; g2.Bq = m->B2q;
+    g2.B = m->B2; g2.ldb = 64; g2.bias = m->bias2;
     g2.C = w.C2; g2.ldc = CP; g2.c_gdiv = 1 << 30; g2.c_gmul = 0;
     g2.n_cols = 64; g2.n_store = CP; g2.K = d.kh2 * CI; g2.relu = 0; g2.a_vec = 1;
     DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g2, DCS_TAG_CONV2));
@@ -335,7 +332,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     DcsGemm g3{};
     g3.A = w.C2; g3.lda = (shared_frames ? tile_row_stride : d.h2) * (int64_t)CP; g3.a_gdiv = 1 << 30; g3.a_gmul = 0;
     if (clips) { g3.a_gdiv = (int)n; g3.a_gmul = clip_pitch / tile_row_stride; }
-    g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc; g3.Bq = m->Bfcq;
+    g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc;
     g3.C = w.Z; g3.ldc = m->hid64; g3.c_gdiv = 1 << 30; g3.c_gmul = 0;
     g3.M = n * n_clips; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
     DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g3, DCS_TAG_FC));
@@ -466,8 +463,7 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     m->clip_tab.release();
     if (m->Bpk) (void)hipFree(m->Bpk);
     if (m->Bw2q) (void)hipFree(m->Bw2q);
-    for (void* q : {m->B1q, m->B2q, m->Bfcq, m->Bdq})
-        if (q) (void)hipFree(q);
+    if (m->Bdq) (void)hipFree(m->Bdq);
     delete m;
     return DCS_OK;
 }

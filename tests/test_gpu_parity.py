@@ -710,11 +710,12 @@ sys.exit(0 if err < 1e-4 else 3)
 """
 
 
-@pytest.mark.parametrize("env", [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}])
+@pytest.mark.parametrize("env", [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}, {"DCS_SLABCONV_MX": "0"}])
 @pytest.mark.parametrize("F,n", [(513, 9), (1025, 3)])
 def test_ikala_conv2_kernels_agree_with_the_oracle(env, F, n, tmp_path):
-    """conv2 of the iKala graph (10 x 20) and its transpose: slab kernel (default) and implicit-GEMM fallback, on batch
-    sizes that give several row bands per image."""
+    """conv2 of the iKala graph (10 x 20) and its transpose: slab kernel on the bf16 matrix pipe with three-way split
+    operands (default), the f32-MFMA slab kernel (DCS_SLABCONV_MX=0) and the implicit-GEMM fallback, on batch sizes that
+    give several row bands per image."""
     import subprocess
     x = _tiles("ikala", n, 30, F, seed=16)
     want = net_ref.forward("ikala", synth_params("ikala", 30, F, seed=4), x.astype(np.float64), inverse='explicit').numpy()
