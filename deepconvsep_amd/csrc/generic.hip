@@ -84,30 +84,44 @@ __global__ __launch_bounds__(kThreads) void pool_kernel(const float* __restrict_
 
 // VJP of the pool at the forward input `a` (rows of w1): position f receives g[f/pw] when a[f] equals
 // its window maximum -- every such position (tie_all, Theano 0.9 CPU MaxPoolGrad) or only the first.
-// g rows are indexed [n*S + s], a rows [n]: a_row = (g_row / (S*rows_per_n)) ... handled by the caller
-// through `S` (g has S branch copies per tile).
+// g rows are indexed [n*S + s], a rows [n] (g has S branch copies per tile).  One thread per pooling WINDOW: it reads
+// the window of `a` once, decides the routing and writes the pw outputs (one 16-byte store for pw = 4 and aligned
+// rows); the border columns past wp*pw are zeroed by the first threads of a row.  32-bit indexing (the launcher checks).
+template <int PW>
 __global__ __launch_bounds__(kThreads) void unpool_kernel(const float* __restrict__ g, const float* __restrict__ a,
-                                                          float* __restrict__ out, int64_t rows_g, int rows_per_tile,
-                                                          int S, int w1, int wp, int pw, int tie_first) {
-    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (idx >= rows_g * w1) return;
-    const int64_t rg = idx / w1;
-    const int f = (int)(idx - rg * w1);
-    float v = 0.f;
-    if (f < wp * pw) {
-        const int64_t tile_s = rg / rows_per_tile;          // n*S + s
-        const int64_t ra = (tile_s / S) * rows_per_tile + (rg - tile_s * rows_per_tile);
-        const int j = f / pw;
-        const float* p = a + ra * w1 + j * pw;
-        float m = p[0];
-        for (int q = 1; q < pw; ++q) m = fmaxf(m, p[q]);
-        const int q0 = f - j * pw;
-        bool hit = p[q0] == m;
-        if (hit && tie_first)
-            for (int q = 0; q < q0; ++q) hit = hit && !(p[q] == m);
-        if (hit) v = g[rg * wp + j];
+                                                          float* __restrict__ out, unsigned rows_g, unsigned rows_per_tile,
+                                                          unsigned S, int w1, int wp, int tie_first) {
+    const unsigned rg = blockIdx.x * 4u + (threadIdx.x >> 6);   // a wave per row of g / out
+    if (rg >= rows_g) return;
+    const unsigned tile_s = rg / rows_per_tile;             // n*S + s
+    const unsigned ra = (tile_s / S) * rows_per_tile + (rg - tile_s * rows_per_tile);
+    float* orow = out + (int64_t)rg * w1;
+    const int lane = threadIdx.x & 63;
+    for (int j = lane; j < w1 - wp * PW; j += 64) orow[wp * PW + j] = 0.f;   // columns the pool ignored
+    for (int j = lane; j < wp; j += 64) {
+    const float* p = a + (int64_t)ra * w1 + j * PW;
+    float win[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q) win[q] = p[q];
+    float m = win[0];
+#pragma unroll
+    for (int q = 1; q < PW; ++q) m = fmaxf(m, win[q]);
+    const float gv = g[(int64_t)rg * wp + j];
+    float v[PW];
+    bool seen = false;
+#pragma unroll
+    for (int q = 0; q < PW; ++q) {
+        const bool hit = win[q] == m && !(tie_first && seen);
+        seen = seen || win[q] == m;
+        v[q] = hit ? gv : 0.f;
     }
-    out[idx] = v;
+    if (PW == 4 && (w1 & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        *reinterpret_cast<f32x4*>(orow + j * PW) = f32x4{v[0], v[1], v[2], v[3 % PW]};
+    } else {
+#pragma unroll
+        for (int q = 0; q < PW; ++q) orow[j * PW + q] = v[q];
+    }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1452,8 +1466,10 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // InverseLayer(., pool)
     if (d.pool_w) {
         DcsTimer tm(ctx, DCS_TAG_UNPOOL);
-        hipLaunchKernelGGL(unpool_kernel, dim3((unsigned)dcs_cdiv(n * NB * d.nf1 * plane1, kThreads)), dim3(kThreads), 0,
-                           ctx->stream, g2, a1b, g1, n * NB * d.nf1 * tc, d.nf1 * tc, NB, d.w1, d.wp, d.pool_w,
+        const int64_t rows_g = n * NB * d.nf1 * tc;
+        if (d.pool_w != 4 || rows_g > 0x7fffffff) DCS_FAIL(DCS_EUNSUPPORTED, "un-pool: pool width %d, %lld rows", d.pool_w, (long long)rows_g);
+        hipLaunchKernelGGL((unpool_kernel<4>), dim3((unsigned)dcs_cdiv(rows_g, 4)), dim3(kThreads), 0,
+                           ctx->stream, g2, a1b, g1, (unsigned)rows_g, (unsigned)(d.nf1 * tc), (unsigned)NB, d.w1, d.wp,
                            tie_mode == DCS_TIE_FIRST ? 1 : 0);
         tm.done();
     }
