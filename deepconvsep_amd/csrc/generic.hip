@@ -685,9 +685,10 @@ __device__ __forceinline__ f32x4 slab_mma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kColThreads) void slabconv_mx_kernel(const SlabConvArgs g, const u32x4* __restrict__ Wq) {
+template <int MODE, int NW /* waves per workgroup: 8 or 16 */>
+__global__ __launch_bounds__(64 * NW) void slabconv_mx_kernel(const SlabConvArgs g, const u32x4* __restrict__ Wq) {
     constexpr int NP = MODE == 0 ? 3 : 1;
+    constexpr int NTH = 64 * NW, NBW = 32 / NW;          // threads; (row, 16-column) blocks per wave
     constexpr int kTapLds = NP * 32 * kSlabWRow;          // pieces per tap in LDS
     constexpr int kTapGlb = NP * 32 * 4;                  // pieces per tap in the packed array
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -709,17 +710,17 @@ __global__ __launch_bounds__(kColThreads) void slabconv_mx_kernel(const SlabConv
     const int RW = g.rows_max * g.W;
     // slab fill: element (ci, r, x) with x fastest (coalesced reads of the channel-major input); channels >= Cin and
     // rows past the band's reach are zero
-    for (int i = tid; i < 32 * RW; i += kColThreads) {
+    for (int i = tid; i < 32 * RW; i += NTH) {
         const int ci = i / RW, rem = i - ci * RW;
         const int r = rem / g.W;
         slab[rem * kSlabCi + ci] = (ci < g.Cin && r < rows) ? in[((int64_t)ci * g.H + rbase + r) * g.W + (rem - r * g.W)] : 0.f;
     }
     const int nxb = (g.Wo + 15) >> 4, nblk = (yb - y0) * nxb;
-    int by[4], bx[4];
-    f32x4 acc0[4], acc1[4];
+    int by[NBW], bx[NBW];
+    f32x4 acc0[NBW], acc1[NBW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int b = wave + 8 * i;
+    for (int i = 0; i < NBW; ++i) {
+        const int b = wave + NW * i;
         by[i] = b < nblk ? y0 + b / nxb : -1;
         bx[i] = b < nblk ? (b % nxb) * 16 : 0;
         acc0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -730,15 +731,15 @@ __global__ __launch_bounds__(kColThreads) void slabconv_mx_kernel(const SlabConv
     if (u_lo < 0) u_lo = 0;
     if (u_hi > g.kh - 1) u_hi = g.kh - 1;
     const int n_stage = (u_hi - u_lo + 1) * nvs;
-    // weight staging: a stage is tstage * NP * 128 pieces, at most 2 per thread (tstage <= 2 for NP = 3)
-    constexpr int WPRE = 2;
+    // weight staging: a stage is tstage * NP * 128 <= 768 pieces
+    constexpr int WPRE = NW == 8 ? 2 : 1;
     u32x4 wpre[WPRE];
 #define DCS_SLABQ_WFETCH(st_)                                                                           \
     {                                                                                                   \
         const int u_ = u_lo + (st_) / nvs, v_ = ((st_) % nvs) * g.tstage;                               \
         const int nt_ = v_ + g.tstage <= g.kw ? g.tstage : g.kw - v_;                                    \
         _Pragma("unroll") for (int q = 0; q < WPRE; ++q) {                                              \
-            const int e = tid + q * kColThreads;                                                        \
+            const int e = tid + q * NTH;                                                        \
             wpre[q] = e < nt_ * kTapGlb ? Wq[(int64_t)(u_ * g.kw + v_) * kTapGlb + e] : u32x4{0u, 0u, 0u, 0u}; \
         }                                                                                               \
     }
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(kColThreads) void slabconv_mx_kernel(const SlabConv
         u32x4* Wb = Wl + (st & 1) * wstage;
 #pragma unroll
         for (int q = 0; q < WPRE; ++q) {
-            const int e = tid + q * kColThreads;           // (tap, plane * 32 + co, kq) in the packed order
+            const int e = tid + q * NTH;           // (tap, plane * 32 + co, kq) in the packed order
             if (e < g.tstage * kTapGlb) Wb[(e >> 2) * kSlabWRow + (e & 3)] = wpre[q];
         }
         __syncthreads();       // also orders the slab fill before the first use; buffer st&1 was last read at st-2
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(kColThreads) void slabconv_mx_kernel(const SlabConv
             u32x4 a0[NP], a1[NP];
             bool have = false;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NBW; ++i) {
                 if (by[i] < 0) continue;
                 const int r = by[i] + u - g.ph;                      // input row (uniform per block)
                 const int xs = bx[i] + v - g.pw;                     // shifted column of lane 0
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(kColThreads) void slabconv_mx_kernel(const SlabConv
 #undef DCS_SLABQ_WFETCH
     const int HoWo = g.Ho * g.Wo;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NBW; ++i) {
         if (by[i] < 0 || bx[i] + fi >= g.Wo) continue;
         float* op = out + (int64_t)by[i] * g.Wo + bx[i] + fi;
 #pragma unroll
@@ -1291,11 +1292,15 @@ bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images, const uint1
     a.rows_max = band + a.kh - 1;
     const dim3 grid((unsigned)(n_images * a.n_bands));
     if (Wq) {
-        auto kern = mode == 0 ? slabconv_mx_kernel<0> : slabconv_mx_kernel<1>;
+        // 16 waves per workgroup: LDS allows one workgroup per CU, so the waves that hide each other's LDS latency have
+        // to come from inside it
+        static const int nw_env = getenv("DCS_SLABCONV_WAVES") ? atoi(getenv("DCS_SLABCONV_WAVES")) : 16;
+        auto kern = nw_env == 8 ? (mode == 0 ? slabconv_mx_kernel<0, 8> : slabconv_mx_kernel<1, 8>)
+                                : (mode == 0 ? slabconv_mx_kernel<0, 16> : slabconv_mx_kernel<1, 16>);
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return false;
-        hipLaunchKernelGGL(kern, grid, dim3(kColThreads), lds, ctx->stream, a, reinterpret_cast<const u32x4*>(Wq));
+        hipLaunchKernelGGL(kern, grid, dim3(nw_env == 8 ? 512 : 1024), lds, ctx->stream, a, reinterpret_cast<const u32x4*>(Wq));
         return true;
     }
     auto kern = slabconv_kernel;
