@@ -555,7 +555,7 @@ def arch_work(arch, tc, F, n, f16):
     """Per launch of n tiles: algorithmic FLOPs and HBM bytes of every kernel tag of the generic graphs
     (SURVEY 8a-4', 8d), the matrix peak that applies to it."""
     d = arch.dims(tc, F)
-    NB, C = len(arch.branch_fc), arch.C
+    NB, C = arch.live_branches(), arch.C      # the branches predict_function2 needs (score-informed: 1 of 4)
     conv1 = 2.0 * d['nf1'] * C * d['kw1'] * tc * d['w1']
     conv2 = 2.0 * d['nf2'] * d['nf1'] * d['kh2'] * d['kw2'] * d['h2'] * d['w2']
     fc = 2.0 * d['flat'] * arch.hidden
@@ -678,7 +678,7 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
     # batches: launches-per-clip launches of n / launches tiles each)
     work_tags = [t for t in ("conv1", "conv2", "fc", "fc1x", "deconv2", "final") if t in k_ms]
     dom = max(work_tags, key=lambda t: k_ms[t])
-    per_tag_launches = {"fc1x": len(arch.branch_fc)}          # one GEMM per branch
+    per_tag_launches = {"fc1x": arch.live_branches()}       # one GEMM per live branch
     calls = max(1, k_launch[dom] // per_tag_launches.get(dom, 1))   # network passes per clip
     tiles_per_pass = n / float(calls)
     work = arch_work(arch, TC, Fb, tiles_per_pass, f16)
@@ -692,7 +692,7 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
         r = kernel_roofline(t, k_ms[t] / max(1, k_launch[t] // per_tag_launches.get(t, 1)), fl, by, pk, KERNEL_NAMES[t])
         table[t] = {"ms_per_clip": k_ms[t], "bound": r["bound"], "frac": r["frac"]}
     frames = Tfr
-    total_flops = n * arch.flops_per_tile(TC, Fb)
+    total_flops = n * arch.flops_per_tile(TC, Fb, live_only=True)
     res = {"workload": what, "tiles": int(n), "frames": int(frames), "audio_seconds": round(Lc / float(SR), 2),
            "batch_size": batch, "ms_per_clip": round(sec * 1e3, 4), "rounds": len(per),
            "value": round(frames / sec, 1), "unit": "frames/s", "x_realtime": round(Lc / float(SR) / sec, 1),

@@ -57,14 +57,22 @@ class Arch(object):
         shapes.append((len(self.branch_fc) * self.C,))
         return shapes
 
-    def flops_per_tile(self, tc, F):
+    def live_branches(self):
+        """Decoder branches that reach the masks: the masks use the first S output channels
+        (``prediction2[:, 0:S]``) and a branch contributes C of them -- all branches for the single-channel graphs,
+        branch 0 alone for the score-informed graph (C = 4, S = 4; the other three are dead code for
+        ``predict_function2``, bach10_scoreinformed/separate_bach10.py:475-488)."""
+        return min(len(self.branch_fc), -(-self.S // self.C))
+
+    def flops_per_tile(self, tc, F, live_only=False):
         """Algorithmic multiply-add FLOPs of one tile through the reference graph
-        (every output branch computed, as Theano does for the aliased DSD branch only once)."""
+        (every output branch computed, as Theano does for the aliased DSD branch only once);
+        ``live_only``: only the branches ``predict_function2`` needs."""
         d = self.dims(tc, F)
         conv1 = 2 * d['nf1'] * self.C * d['kw1'] * tc * d['w1']
         conv2 = 2 * d['nf2'] * d['nf1'] * d['kh2'] * d['kw2'] * d['h2'] * d['w2']
         fc = 2 * d['flat'] * self.hidden
-        nb = self.n_fc
+        nb = min(self.n_fc, self.live_branches()) if live_only else self.n_fc
         return conv1 + conv2 + fc + nb * (fc + conv2 + conv1)
 
 

@@ -1350,7 +1350,13 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                   int tie_mode, float* out, char* w) {
     const DcsGenericDims& d = g->d;
     dcs_ctx* ctx = g->ctx;
-    const int C = g->C, tc = g->tc, F = g->F, NB = d.n_branch;
+    const int C = g->C, tc = g->tc, F = g->F;
+    // Branches that reach the requested output.  The masks use the first S output channels (prediction2[:, 0:S]); with C
+    // input channels per branch those belong to the first ceil(S / C) branches -- for the score-informed graph (C = 4,
+    // S = 4) branch 0 alone: the other three branches of its decoder are dead code for predict_function2
+    // (bach10_scoreinformed/separate_bach10.py:475-488; Theano prunes them from the compiled function as well).
+    // dcs_model_forward (mask_mode 2: the whole network output) evaluates all of them.
+    const int NB = mask_mode == 2 ? d.n_branch : (d.S + C - 1) / C < d.n_branch ? (d.S + C - 1) / C : d.n_branch;
     const int64_t plane1 = (int64_t)tc * d.w1, planep = (int64_t)tc * d.wp;
     float* a1b = (float*)w; w += align256((size_t)n * d.nf1 * plane1 * 4);
     float* p1 = a1b;
