@@ -67,6 +67,57 @@ __global__ __launch_bounds__(kThreads) void conv1_kernel(const float* __restrict
     for (int o = 0; o < NF; ++o) out[((n * NF + o) * tc + t) * (int64_t)w1 + j] = acc[o];
 }
 
+// conv1, register-blocked: a thread owns one output position j of a row and all NF filters; the kw inputs of the current
+// channel sit in registers (for a stride of 4 the window starts 16-byte aligned: eight 16-byte loads, shared with the
+// neighbouring threads through L1), the filter taps -- the same for every thread -- come through scalar loads from
+// Wt[c][u][32] (filters fastest), so the inner loop is NF multiply-adds per tap with one vector and one scalar operand.
+// The LDS kernel above does one (broadcast) LDS read per multiply-add and is bound by that.
+template <int NF, int SW>
+__global__ __launch_bounds__(kThreads) void conv1_reg_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int C, int tc, int F, int kw, int w1) {
+    constexpr int KW = 32;                  // taps held in registers (kw <= 32)
+    const int64_t nt = blockIdx.y;          // n*tc + t
+    const int64_t n = nt / tc;
+    const int t = (int)(nt - n * tc);
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= w1) return;
+    float acc[NF];
+#pragma unroll
+    for (int o = 0; o < NF; ++o) acc[o] = bias[o];
+    for (int c = 0; c < C; ++c) {
+        const float* xr = x + ((n * C + c) * tc + t) * (int64_t)F + (int64_t)j * SW;
+        float xv[KW];
+        const bool vec = SW == 4 && (F & 3) == 0 && j * SW + KW <= F && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < KW / 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[4 * q + e] = v[e];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < KW; ++u) xv[u] = (u < kw && j * SW + u < F) ? xr[u] : 0.f;
+        }
+        const float* wc = Wt + (int64_t)c * kw * 32;     // uniform: scalar loads
+#pragma unroll
+        for (int u = 0; u < KW; ++u) {
+            if (u < kw) {
+                // one v_fmac with a scalar-register operand per filter (written out: left to itself the compiler packs
+                // pairs into v_pk_fma_f32 and spends three moves per multiply-add bringing the scalar taps into vector pairs)
+#pragma unroll
+                for (int o = 0; o < NF; ++o) {
+                    const float w = wc[u * 32 + o];
+                    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[o]) : "s"(w), "v"(xv[u]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NF; ++o) out[((n * NF + o) * tc + t) * (int64_t)w1 + j] = acc[o];
+}
+
 // ------------------------------------------------------------------------------------------------
 // max-pool (1,pw), stride pw, ignore_border: rows of w1 -> rows of wp
 // ------------------------------------------------------------------------------------------------
@@ -1044,6 +1095,7 @@ struct DcsGenericNet {
     int flat_p = 0, flat64 = 0, hid64 = 0;
     // conv1 / deconv1
     float *W1c = nullptr, *bias1 = nullptr;
+    float* W1t = nullptr;      // conv1 filters [c][u][32] (filters fastest) for conv1_reg_kernel
     // conv2 as implicit GEMM
     float *W2m = nullptr, *bias2 = nullptr;
     int *k2off = nullptr, *k2uv = nullptr;
@@ -1097,6 +1149,10 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
             for (int u = 0; u < kw1; ++u) W1c[((size_t)o * C + c) * kw1 + u] = W1[((size_t)o * C + c) * kw1 + (kw1 - 1 - u)];
         bias1[o] = b1[o] + b1b[o];
     }
+    std::vector<float> W1t((size_t)C * kw1 * 32, 0.f);
+    for (int o = 0; o < nf1; ++o)
+        for (int c = 0; c < C; ++c)
+            for (int u = 0; u < kw1; ++u) W1t[((size_t)c * kw1 + u) * 32 + o] = W1c[((size_t)o * C + c) * kw1 + u];
     // the same filters with the tap axis zero-padded to a multiple of the stride (deconv1_reg_kernel)
     std::vector<float> W1p;
     if (16 % d.sw1 == 0) {
@@ -1220,7 +1276,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     int rc = DCS_OK;
 #define UP(dst, src)                                \
     if (rc == DCS_OK) rc = upload(&(dst), (src));
-    UP(g->W1c, W1c) UP(g->bias1, bias1) UP(g->W2m, W2m) UP(g->bias2, bias2) UP(g->k2off, k2off) UP(g->k2uv, k2uv)
+    UP(g->W1c, W1c) UP(g->W1t, W1t) UP(g->bias1, bias1) UP(g->W2m, W2m) UP(g->bias2, bias2) UP(g->k2off, k2off) UP(g->k2uv, k2uv)
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
     if (!W1p.empty()) { UP(g->W1p, W1p) }
@@ -1254,7 +1310,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
     for (void* p : ptrs)
@@ -1377,8 +1433,17 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
         DcsTimer tm(ctx, DCS_TAG_CONV1);
-        hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(d.w1, kThreads), (unsigned)(n * tc)), dim3(kThreads), lds,
-                           ctx->stream, tiles, g->W1c, g->bias1, a1b, C, tc, F, d.kw1, d.sw1, d.w1);
+        static const int reg1 = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
+        const dim3 grid1((unsigned)dcs_cdiv(d.w1, kThreads), (unsigned)(n * tc));
+        if (reg1 && d.kw1 <= 32 && d.sw1 == 4)
+            hipLaunchKernelGGL((conv1_reg_kernel<30, 4>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, a1b, C,
+                               tc, F, d.kw1, d.w1);
+        else if (reg1 && d.kw1 <= 32 && d.sw1 == 3)
+            hipLaunchKernelGGL((conv1_reg_kernel<30, 3>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, a1b, C,
+                               tc, F, d.kw1, d.w1);
+        else
+            hipLaunchKernelGGL(kern, grid1, dim3(kThreads), lds, ctx->stream, tiles, g->W1c, g->bias1, a1b, C, tc, F, d.kw1,
+                               d.sw1, d.w1);
         tm.done();
     }
     if (d.pool_w) {
