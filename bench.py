@@ -568,6 +568,8 @@ def arch_work(arch, tc, F, n, f16):
         "fc1x": (n * NB * fc, NB * d['flat'] * arch.hidden * 4.0 + n * NB * plane2, PEAK_F32_TFLOPS),
         "deconv2": (n * NB * conv2, n * NB * (plane2 + plane1), mfma16),
         "final": (n * NB * conv1, n * NB * (d['nf1'] * tc * d['w1'] * 4.0 + plane_in), PEAK_F32_TFLOPS),
+        # both InverseLayers in one kernel: the activations between them never reach HBM
+        "decoder": (n * NB * (conv2 + conv1), n * NB * (plane2 + plane_in), mfma16),
     }
 
 
@@ -590,6 +592,7 @@ KERNEL_NAMES = {
     "conv1": "conv1_kernel (strided conv1 + biases)", "conv2": "conv2 (slab / column convolution, MFMA)",
     "fc": "gemm_rows (bottleneck DenseLayer)", "fc1x": "gemm_rows (per-source DenseLayers)",
     "deconv2": "transposed conv2 (slab / column convolution, MFMA)", "final": "transposed conv1 (deconv1_reg / deconv1)",
+    "decoder": "colconv_deconv1_fused_kernel (transposed conv2 + transposed conv1, weights in registers)",
 }
 
 
@@ -676,7 +679,7 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
     ctx.timing_reset()
     # dominant kernel among the network's kernels; priced per launch (a clip may go through in several chunks /
     # batches: launches-per-clip launches of n / launches tiles each)
-    work_tags = [t for t in ("conv1", "conv2", "fc", "fc1x", "deconv2", "final") if t in k_ms]
+    work_tags = [t for t in ("conv1", "conv2", "fc", "fc1x", "deconv2", "final", "decoder") if t in k_ms]
     dom = max(work_tags, key=lambda t: k_ms[t])
     per_tag_launches = {"fc1x": arch.live_branches()}       # one GEMM per live branch
     calls = max(1, k_launch[dom] // per_tag_launches.get(dom, 1))   # network passes per clip

@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcs.h")
 DCS_OK, DCS_EINVAL, DCS_EUNSUPPORTED, DCS_EHIP, DCS_ENOMEM, DCS_ESHAPE = 0, -1, -2, -3, -4, -5
 
 TAGS = dict(stft=0, conv1=1, conv2=2, fc=3, fc1x=4, deconv2=5, final=6, istft=7, ola=8, tile=9, pool=10, unpool=11,
-            mask=12, score=13)
+            mask=12, score=13, decoder=14)
 
 
 class DcsError(RuntimeError):

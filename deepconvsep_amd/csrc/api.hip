@@ -44,7 +44,7 @@ void DcsBuffer::release() {
     bytes = 0;
 }
 
-DcsTimer::DcsTimer(dcs_ctx* c, int t) : ctx(c), tag(t), idx(0), on((c->timing_mask >> t) & 1u) {
+DcsTimer::DcsTimer(dcs_ctx* c, int t) : ctx(c), tag(t), idx(0), on(t >= 0 && ((c->timing_mask >> t) & 1u)) {   // t < 0: no-op
     if (!on) return;
     if ((c->timing_seen[t]++ % (uint64_t)c->timing_stride) != 0) {
         on = false;

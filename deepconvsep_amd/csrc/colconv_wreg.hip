@@ -1,0 +1,515 @@
+// Column convolution (kh x 1 filters: conv2 of the Bach10 / score-informed graphs, separate_bach10.py:196-200, and its
+// InverseLayer) with f16 operands, f32 accumulation and the WEIGHTS IN REGISTERS.
+//
+//   out[co][y][x] = bias[co] + sum_u sum_ci W[u][co][ci] * in[ci][y + u - ph][x]        (rows outside 0 <= . < H are zero)
+//
+// Every column x is an independent 1-D problem along y.  colconv_f16_kernel (generic.hip) keeps slab and weights in
+// LDS and reads three 16-byte operands per pair of MFMAs: with four SIMDs sharing 128 B/clk the LDS pipe is asked for
+// three times what it has, and the 512-thread workgroup pays two barriers per 16 columns.  Here a WAVE owns 16
+// columns of one image and nothing is shared, so there is no LDS and no barrier:
+//   * all kh x 2 weight fragments (B operand, 32 in-channels x 16 out-channels each) stay in 8 kh VGPRs for the whole
+//     launch (160 for kh = 20); the kernel runs one wave per SIMD with the 512-VGPR budget;
+//   * the slab goes global -> registers directly as the A operand (rows = x): lane (x = lane & 15, kg = lane >> 4) loads
+//     in[ci = 8 kg + j][row][x0 + x], 16 consecutive x per channel (64-byte segments), rounds to f16 in registers;
+//   * the accumulator then holds 4 consecutive x of one output channel per lane: one 16-byte store per (row, 16 channels).
+// Two forms, both fully unrolled so that every register index is static:
+//   gather  (transpose: H = 11 input rows, 30 output rows): all input rows resident as fragments, output rows two at
+//           a time (four independent MFMA chains); the next unit's rows are requested before the first MFMA;
+//   scatter (forward: 30 input rows, 11 output rows): all output rows accumulate in registers while the input rows
+//           stream through a ring of kAhead rows in flight.
+// MFMA work: 220 (row, tap) pairs x 2 per unit either way = 440 MFMAs of 16 cycles; 668 images x 32 units over 1024
+// SIMDs is 21 units per wave, 0.06 ms at the matrix pipe's rate against 0.93 (transpose) / 0.27 ms (forward) measured
+// for the LDS kernel on the Bach10 leg (profiles/r02_d_bench_legs.json).
+#include <string.h>
+
+#include "dcs_internal.h"
+#include "generic.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // 4-byte aligned: rows are W floats apart, W odd
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ f32x4 mma(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ h8 as_h8(u32x4 v) {
+    union { u32x4 u; h8 h; } x;
+    x.u = v;
+    return x.h;
+}
+
+__device__ __forceinline__ h8 round8(const float (&r)[8]) {
+    h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)r[j];
+    return v;
+}
+
+// Addresses are (uniform pointer)[32-bit lane index] throughout: one SGPR base per row + one VGPR offset per channel.
+// Nothing carries a column predicate: the last column block of an image starts at W - 16 and overlaps its neighbour
+// (the shared columns are computed twice, to the same bits, and stored twice).  A lane of a padded channel reads the
+// last real channel instead and meets zero weights.
+struct LaneIn {
+    int idx[8];
+};
+__device__ __forceinline__ int block_x(int block, int W) { return block * 16 + 16 <= W ? block * 16 : W - 16; }
+
+__device__ __forceinline__ LaneIn lane_in(const DcsColConv& g, int kg, int xc, int HW) {
+    LaneIn li;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = kg * 8 + j < g.Cin ? kg * 8 + j : g.Cin - 1;
+        li.idx[j] = c * HW + xc;
+    }
+    return li;
+}
+
+// ---- gather form: out row y takes input rows r = y + u - PH, PH = KH - 1 (InverseLayer of a 'valid' convolution)
+template <int KH, int H>
+__global__ __launch_bounds__(kThreads) void colconv_wreg_gather_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
+                                                                       int64_t n_units) {
+    constexpr int HO = H + KH - 1, PH = KH - 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fi = lane & 15, kg = lane >> 4;
+    h8 w[KH][2];
+#pragma unroll
+    for (int u = 0; u < KH; ++u) {
+        w[u][0] = as_h8(Wq[(u * 2) * 64 + lane]);
+        w[u][1] = as_h8(Wq[(u * 2 + 1) * 64 + lane]);
+    }
+    const float bias0 = g.bias[fi], bias1 = g.bias[16 + fi];
+    const bool c1_ok = fi + 16 < g.Cout;
+    const int W = g.W, n_xb = g.n_xb;
+    const int HW = H * W;
+    const int out_lane = fi * HO * W + kg * 4;          // + 16 HO W for the second channel half
+    // the four waves of a workgroup take four adjacent column blocks: their 64-byte row segments share cache lines
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+    float raw[H][8];
+#define DCS_FETCH(unit_)                                                                                \
+    {                                                                                                   \
+        const int64_t img_ = (unit_) / n_xb;                                                            \
+        const int xb_ = block_x((int)((unit_) - img_ * n_xb), W);                                       \
+        const LaneIn li_ = lane_in(g, kg, xb_ + fi, HW);                                                \
+        const float* ib_ = g.in + img_ * g.in_n_stride;                                                 \
+        _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                 \
+            const float* ir_ = ib_ + h * W;                                                             \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) raw[h][j] = ir_[li_.idx[j]];                  \
+        }                                                                                               \
+    }
+    if (unit < n_units) DCS_FETCH(unit)
+    for (; unit < n_units; unit += stride) {
+        h8 a[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) a[h] = round8(raw[h]);
+        {
+            const int64_t next = unit + stride < n_units ? unit + stride : unit;     // last round: a harmless re-read
+            DCS_FETCH(next)
+        }
+        const int64_t img = unit / n_xb;
+        const int xb = block_x((int)(unit - img * n_xb), W);
+        float* ob = g.out + img * g.out_n_stride + xb;
+#pragma unroll
+        for (int y = 0; y < HO; y += 2) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int u = h - (y + t) + PH;
+                    if (y + t < HO && u >= 0 && u < KH) {
+                        acc[t][0] = mma(a[h], w[u < 0 || u >= KH ? 0 : u][0], acc[t][0]);
+                        acc[t][1] = mma(a[h], w[u < 0 || u >= KH ? 0 : u][1], acc[t][1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc[t][0] += bias0;
+                acc[t][1] += bias1;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (y + t < HO) *reinterpret_cast<f32x4u*>(ob + (y + t) * W + out_lane) = acc[t][0];
+            if (c1_ok) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (y + t < HO) *reinterpret_cast<f32x4u*>(ob + (16 * HO + y + t) * W + out_lane) = acc[t][1];
+            }
+        }
+    }
+#undef DCS_FETCH
+}
+
+// ---- scatter form: 'valid' convolution, input row r feeds output rows y = r - u, HO = H - KH + 1
+template <int KH, int H, int AHEAD /* input rows in flight */>
+__global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
+                                                                        int64_t n_units) {
+    constexpr int HO = H - KH + 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fi = lane & 15, kg = lane >> 4;
+    h8 w[KH][2];
+#pragma unroll
+    for (int u = 0; u < KH; ++u) {
+        w[u][0] = as_h8(Wq[(u * 2) * 64 + lane]);
+        w[u][1] = as_h8(Wq[(u * 2 + 1) * 64 + lane]);
+    }
+    const float bias0 = g.bias[fi], bias1 = g.bias[16 + fi];
+    const bool c1_ok = fi + 16 < g.Cout;
+    const int W = g.W, n_xb = g.n_xb;
+    const int HW = H * W;
+    const int out_lane = fi * HO * W + kg * 4;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+    if (unit >= n_units) return;
+    // the first AHEAD rows of a unit are requested while the previous unit's last rows are multiplied
+    float pre[AHEAD][8];
+    int64_t img = unit / n_xb;
+    int xb = block_x((int)(unit - img * n_xb), W);
+    LaneIn li = lane_in(g, kg, xb + fi, HW);
+    const float* ib = g.in + img * g.in_n_stride;
+#pragma unroll
+    for (int r = 0; r < AHEAD; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre[r][j] = (ib + r * W)[li.idx[j]];
+    for (; unit < n_units; unit += stride) {
+        const int64_t next = unit + stride < n_units ? unit + stride : unit;         // last round: a harmless re-read
+        const int64_t img_n = next / n_xb;
+        const int xb_n = block_x((int)(next - img_n * n_xb), W);
+        const LaneIn li_n = lane_in(g, kg, xb_n + fi, HW);
+        const float* ib_n = g.in + img_n * g.in_n_stride;
+        float raw[H][8];                      // fully unrolled: only AHEAD + 1 rows are live at any point
+#pragma unroll
+        for (int r = 0; r < AHEAD; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[r][j] = pre[r][j];
+        f32x4 acc[HO][2];
+#pragma unroll
+        for (int y = 0; y < HO; ++y) acc[y][0] = acc[y][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            if (r + AHEAD < H) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[r + AHEAD][j] = (ib + (r + AHEAD) * W)[li.idx[j]];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pre[r + AHEAD - H][j] = (ib_n + (r + AHEAD - H) * W)[li_n.idx[j]];
+            }
+            const h8 a = round8(raw[r]);
+#pragma unroll
+            for (int y = 0; y < HO; ++y) {
+                const int u = r - y;
+                if (u >= 0 && u < KH) {
+                    acc[y][0] = mma(a, w[u < 0 || u >= KH ? 0 : u][0], acc[y][0]);
+                    acc[y][1] = mma(a, w[u < 0 || u >= KH ? 0 : u][1], acc[y][1]);
+                }
+            }
+        }
+        float* ob = g.out + img * g.out_n_stride + xb;
+#pragma unroll
+        for (int y = 0; y < HO; ++y) {
+            acc[y][0] += bias0;
+            acc[y][1] += bias1;
+        }
+#pragma unroll
+        for (int y = 0; y < HO; ++y) *reinterpret_cast<f32x4u*>(ob + y * W + out_lane) = acc[y][0];
+        if (c1_ok) {
+#pragma unroll
+            for (int y = 0; y < HO; ++y) *reinterpret_cast<f32x4u*>(ob + (16 * HO + y) * W + out_lane) = acc[y][1];
+        }
+        img = img_n; xb = xb_n; li = li_n; ib = ib_n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// InverseLayer(conv2) + InverseLayer(conv1) of the Bach10 graph in one kernel (separate_bach10.py:219-227; f16 switch on).
+//
+// Unfused, the 30 x 30 x 505 activations between the two layers are 1.2 GB per 10 s clip, written and read back in
+// 64-byte pieces that start on 4-byte boundaries (rows are 505 floats): both kernels ran at the rate the memory system
+// absorbs such pieces (0.73 + 0.54 ms), an order of magnitude above their arithmetic.  Here they never leave the wave:
+//   stage 1  the gather form above with the operands swapped (A = weights, B = slab), so that a lane ends up with
+//            G[ci = 4 kq + e (+16)][t][x = fi] -- eight input channels of ONE column, which is exactly a B-operand
+//            fragment of a second MFMA whose K axis is the channel (k slot j <-> ci = 4 kq + j | 16 + 4 kq + j - 4);
+//   stage 2  conv1^T with stride 4 and 30 (padded 32) taps is  y[4 q + r] = sum_mm sum_ci G[ci][q - mm] W1[ci][4 mm + r]:
+//            P^T[(mm, r)][x] = sum_ci W1[ci][4 mm + r] G[ci][x] is a 32 x 32 x 16 product per row (bf16 pipe, both
+//            operands split three ways, six products: f32-class), after which lane (x, kq) holds the float4
+//            P[x][mm = kq (+4)][r = 0..3] = a 16-byte piece of the output row at f = 4 (x + mm);
+//   shift-add  the eight pieces that meet at one q come from different lanes: they are added into a per-wave LDS ring
+//            y[t][32 q slots][4] with ds_add_f32 (no return value, nothing waits on it).  A wave walks consecutive
+//            column blocks of one image, so after block b the slots of q = 16 b .. 16 b + 15 are complete (their inputs
+//            are x = q - 7 .. q) and are flushed as 256 contiguous bytes per row, while q = 16 b + 16 .. + 22 carry over.
+// An image's blocks are cut into runs (one wave each); a run that does not start at x = 0 first recomputes the block to
+// its left and keeps only the carry.  HBM traffic: the dense-layer output once (445 MB) + the 164 MB result.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+// x = hi + mid + lo exactly (three bf16 by truncation); element j of a piece is k slot j
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = bf_trunc(x[j]);
+        const float r1 = x[j] - __uint_as_float(h[j]);
+        m[j] = bf_trunc(r1);
+        l[j] = bf_trunc(r1 - __uint_as_float(m[j]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hi[q] = (h[2 * q] >> 16) | h[2 * q + 1];
+        mid[q] = (m[2 * q] >> 16) | m[2 * q + 1];
+        lo[q] = (l[2 * q] >> 16) | l[2 * q + 1];
+    }
+}
+
+struct DcsDecoderFused {
+    const u32x4* Wq1;       // [3 planes][2 tap halves][64 lanes] pieces of the padded conv1 filter
+    float* out;             // [image][HO][F]
+    int F;
+    int runs_per_image;
+    int64_t n_runs;
+};
+
+template <int KH, int H>
+__global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
+                                                                         const DcsDecoderFused d) {
+    constexpr int HO = H + KH - 1, PH = KH - 1;
+    constexpr int kRing = HO * 32 * 4;                       // floats per wave
+    __shared__ __attribute__((aligned(16))) float Yall[4 * kRing];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fi = lane & 15, kq = lane >> 4;
+    float* Y = Yall + wave * kRing;
+    for (int i = lane; i < kRing / 4; i += 64) reinterpret_cast<f32x4*>(Y)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h8 w[KH][2];
+#pragma unroll
+    for (int u = 0; u < KH; ++u) {
+        w[u][0] = as_h8(Wq[(u * 2) * 64 + lane]);
+        w[u][1] = as_h8(Wq[(u * 2 + 1) * 64 + lane]);
+    }
+    u32x4 w1[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        w1[p][0] = d.Wq1[(p * 2) * 64 + lane];
+        w1[p][1] = d.Wq1[(p * 2 + 1) * 64 + lane];
+    }
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        bias[e] = g.bias[4 * kq + e];
+        bias[4 + e] = g.bias[16 + 4 * kq + e];
+    }
+    const int W = g.W, n_xb = g.n_xb, F = d.F;
+    const int HW = H * W;
+    const int rpi = d.runs_per_image;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    float raw[H][8];
+#define DCS_FETCH(img_, blk_)                                                                           \
+    {                                                                                                   \
+        const int xl_ = (blk_) * 16 + fi;                                                               \
+        const LaneIn li_ = lane_in(g, kq, xl_ < W ? xl_ : W - 1, HW);                                   \
+        const float* ib_ = g.in + (img_) * g.in_n_stride;                                               \
+        _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                 \
+            const float* ir_ = ib_ + h * W;                                                             \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) raw[h][j] = ir_[li_.idx[j]];                  \
+        }                                                                                               \
+    }
+    // slots (ro + q) & 31, q < 16, of every row: out (when `store`) and cleared; q0 = first output q of the slots
+#define DCS_FLUSH(store_, q0_)                                                                          \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < (HO + 3) / 4; ++i) {                                      \
+            const int t_ = kq + 4 * i;                                                                  \
+            if (t_ < HO) {                                                                              \
+                f32x4* yp_ = reinterpret_cast<f32x4*>(Y) + t_ * 32 + ((ro + fi) & 31);                  \
+                const f32x4 v_ = *yp_;                                                                  \
+                *yp_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                       \
+                const int f_ = 4 * ((q0_) + fi);                                                        \
+                if (store_) {                                                                           \
+                    float* op_ = d.out + (img * HO + t_) * (int64_t)F + f_;                             \
+                    if (f_ + 4 <= F) {                                                                  \
+                        *reinterpret_cast<f32x4u*>(op_) = v_;                                           \
+                    } else {                                                                            \
+                        _Pragma("unroll") for (int e = 0; e < 3; ++e)                                   \
+                            if (f_ + e < F) op_[e] = v_[e];                                             \
+                    }                                                                                   \
+                }                                                                                       \
+            }                                                                                           \
+        }                                                                                               \
+    }
+    for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < d.n_runs; run += stride) {
+        const int64_t img = run / rpi;
+        const int rr = (int)(run - img * rpi);
+        const int b_lo = (int)((int64_t)rr * n_xb / rpi), b_hi = (int)((int64_t)(rr + 1) * n_xb / rpi);
+        const int b_first = b_lo > 0 ? b_lo - 1 : 0;         // the block to the left is recomputed for its carry
+        int ro = 0;
+        DCS_FETCH(img, b_first)
+        for (int b = b_first; b < b_hi; ++b) {
+            h8 a[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) a[h] = round8(raw[h]);
+            {
+                const int nb = b + 1 < b_hi ? b + 1 : b;     // last block of the run: a harmless re-read
+                DCS_FETCH(img, nb)
+            }
+            const bool x_ok = b * 16 + fi < W;
+            float* y0 = Y + ((ro + fi + kq) & 31) * 4;       // taps mm = kq; mm = kq + 4 four slots further
+            float* y1 = Y + ((ro + fi + kq + 4) & 31) * 4;
+#pragma unroll
+            for (int y = 0; y < HO; y += 2) {
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int u = h - (y + t) + PH;
+                        if (y + t < HO && u >= 0 && u < KH) {
+                            acc[t][0] = mma(w[u < 0 || u >= KH ? 0 : u][0], a[h], acc[t][0]);
+                            acc[t][1] = mma(w[u < 0 || u >= KH ? 0 : u][1], a[h], acc[t][1]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (y + t < HO) {
+                        float gv[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gv[e] = acc[t][0][e] + bias[e];
+                            gv[4 + e] = acc[t][1][e] + bias[4 + e];
+                        }
+                        u32x4 g0, g1, g2;
+                        split8(gv, g0, g1, g2);
+                        f32x4 P[2];
+#pragma unroll
+                        for (int mh = 0; mh < 2; ++mh) {
+                            f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+                            p = mma_bf(w1[2][mh], g0, p);      // smallest products first
+                            p = mma_bf(w1[0][mh], g2, p);
+                            p = mma_bf(w1[1][mh], g1, p);
+                            p = mma_bf(w1[1][mh], g0, p);
+                            p = mma_bf(w1[0][mh], g1, p);
+                            p = mma_bf(w1[0][mh], g0, p);
+                            P[mh] = p;
+                        }
+                        // columns past W (last block only) must not reach the rows
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            __hip_atomic_fetch_add(y0 + (y + t) * 128 + e, x_ok ? P[0][e] : 0.f, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __hip_atomic_fetch_add(y1 + (y + t) * 128 + e, x_ok ? P[1][e] : 0.f, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+                }
+            }
+            const bool keep = b >= b_lo;                     // wave-uniform
+            DCS_FLUSH(keep, b * 16)
+            ro ^= 16;
+        }
+        // the carry: the tail of the image (and the zeros up to F) for the last run, otherwise the next run recomputes it
+        const bool last = b_hi == n_xb;
+        DCS_FLUSH(last, b_hi * 16)
+    }
+#undef DCS_FETCH
+#undef DCS_FLUSH
+}
+
+}  // namespace
+
+// Wh: [kh][32 out][40] halves, in-channel fastest (the LDS kernel's weights) -> [kh][2 halves][64 lanes] 16-byte pieces:
+// lane (fi, kg) of (u, half) = W[u][out = fi + 16 half][in = 8 kg .. 8 kg + 7]
+void dcs_colconv_wreg_pack(const _Float16* Wh, int kh, std::vector<_Float16>* out) {
+    out->assign((size_t)kh * 2 * 64 * 8, (_Float16)0.f);
+    for (int u = 0; u < kh; ++u)
+        for (int half = 0; half < 2; ++half)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j)
+                    (*out)[(((size_t)u * 2 + half) * 64 + lane) * 8 + j] =
+                        Wh[((size_t)u * 32 + (lane & 15) + 16 * half) * 40 + (lane >> 4) * 8 + j];
+}
+
+bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq) {
+    static const bool on = !(getenv("DCS_COLCONV_WREG") && atoi(getenv("DCS_COLCONV_WREG")) == 0);
+    if (!on || !Wq || a.Cin > 32 || a.Cout > 32 || a.kh != 20 || a.W < 16) return false;
+    const int64_t n_units = n_images * a.n_xb;
+    if (n_units <= 0) return true;
+    const unsigned grid = (unsigned)std::min<int64_t>(dcs_cdiv(n_units, 4), ctx->n_cu);
+    const u32x4* wq = reinterpret_cast<const u32x4*>(Wq);
+    if (a.ph == a.kh - 1 && a.H == 11 && a.Ho == 30) {
+        hipLaunchKernelGGL((colconv_wreg_gather_kernel<20, 11>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, n_units);
+        return true;
+    }
+    if (a.ph == 0 && a.H == 30 && a.Ho == 11) {
+        hipLaunchKernelGGL((colconv_wreg_scatter_kernel<20, 30, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, n_units);
+        return true;
+    }
+    return false;
+}
+
+// W1p: [nf1][C = 1][32 taps] (tap axis zero-padded) -> [3 planes][2 tap halves][64 lanes][8] bf16: lane (fi, kg) of tap
+// half mh holds, for row (mm = fi / 4 + 4 mh, r = fi % 4), the k slots j <-> ci = 4 kg + j (j < 4) | 16 + 4 kg + j - 4
+void dcs_decoder_fused_pack(const float* W1p, int nf1, std::vector<uint16_t>* out) {
+    out->assign((size_t)3 * 2 * 64 * 8, 0);
+    for (int mh = 0; mh < 2; ++mh)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int fi = lane & 15, kg = lane >> 4;
+                const int ci = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
+                const int tap = 4 * ((fi >> 2) + 4 * mh) + (fi & 3);
+                float r = ci < nf1 ? W1p[(size_t)ci * 32 + tap] : 0.f;
+                for (int p = 0; p < 3; ++p) {
+                    uint32_t bits;
+                    memcpy(&bits, &r, 4);
+                    bits &= 0xffff0000u;
+                    float part;
+                    memcpy(&part, &bits, 4);
+                    r -= part;
+                    (*out)[(((size_t)p * 2 + mh) * 64 + lane) * 8 + j] = (uint16_t)(bits >> 16);
+                }
+            }
+}
+
+bool dcs_decoder_fused_ok(const DcsColConv& a, int F) {
+    static const bool on = !(getenv("DCS_DECODER_FUSED") && atoi(getenv("DCS_DECODER_FUSED")) == 0);
+    return on && a.Cin <= 32 && a.Cout <= 32 && a.kh == 20 && a.ph == 19 && a.H == 11 && a.Ho == 30 && a.W >= 16 &&
+           F >= 4 * a.W + 26 && F <= 4 * a.W + 32;
+}
+
+bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out,
+                              int F) {
+    if (!Wq || !Wq1 || !dcs_decoder_fused_ok(a, F)) return false;
+    if (n_images <= 0) return true;
+    // runs per image: fewest (rounds of waves) x (blocks per run + the recomputed one)
+    const int64_t n_waves = (int64_t)ctx->n_cu * 4;
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int rpi = 1; rpi <= a.n_xb; ++rpi) {
+        const int64_t len = (a.n_xb + rpi - 1) / rpi + (rpi > 1 ? 1 : 0);
+        const int64_t cost = dcs_cdiv(n_images * rpi, n_waves) * len;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rpi; }
+    }
+    DcsDecoderFused d{};
+    d.Wq1 = reinterpret_cast<const u32x4*>(Wq1);
+    d.out = out;
+    d.F = F;
+    d.runs_per_image = best;
+    d.n_runs = n_images * best;
+    const unsigned grid = (unsigned)std::min<int64_t>(dcs_cdiv(d.n_runs, 4), ctx->n_cu);
+    hipLaunchKernelGGL((colconv_deconv1_fused_kernel<20, 11>), dim3(grid), dim3(kThreads), 0, ctx->stream, a,
+                       reinterpret_cast<const u32x4*>(Wq), d);
+    return true;
+}

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void gemm_pack_bq_kernel(const float* __r
 }
 
 template <int RB>
-__global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g) {
+__global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g, int xcd_map) {
     constexpr int BM = 16 * RB;
     constexpr int kPlane = BM * kRowU4;                 // pieces per plane
     constexpr int kBuf = 3 * kPlane;
@@ -82,8 +82,15 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g) 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * 64;
+    // Workgroups are dealt to the 8 XCDs round-robin by their linear id.  The row tiles that share a 64-column B slab
+    // (3 for Bach10: 167 rows, 1 GB of B planes) must run on ONE XCD, back to back, for the slab to be read from HBM
+    // once and from that XCD's L2 afterwards: XCD x takes a contiguous run of (column group, row tile) pairs.
+    const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = lin & 7, slot = lin >> 3, base = total >> 3, rem = total & 7;
+    const unsigned virt = xcd_map ? xcd * base + (xcd < rem ? xcd : rem) + slot : lin;   // XCD x owns base + (x < rem) ids
+    const unsigned bx = virt % gridDim.x, by = virt / gridDim.x;
+    const int64_t m0 = (int64_t)bx * BM;
+    const int n0 = by * 64;
     const int gK = g.K, n_cols = g.n_cols;
     const int64_t gM = g.M;
     const float gscale = g.a_scale;
@@ -178,93 +185,6 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g) 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Short-K, wide-N form (the per-source dense layers: K = 128 / 256, N = 2 496 ... 666 600): the A rows of a workgroup are
-// split ONCE and stay in LDS as planes for all of K; the workgroup then walks a run of 64-column groups, and per group
-// the only memory traffic is the B stream -- per k tile three 16-byte fragments per lane straight from the packed array,
-// requested one k tile ahead -- against RB x 6 MFMAs.  No barrier and no A staging inside the column loop (the general
-// kernel above re-fetches and re-splits its A tile for every 64 columns: 2 604 times for the Bach10 layers).
-// ------------------------------------------------------------------------------------------------
-template <int RB>
-__global__ __launch_bounds__(kThreads) void gemm_bf16x3_ares_kernel(const DcsGemm g, int nkt, int cg_per_wg) {
-    constexpr int BM = 16 * RB;
-    extern __shared__ u32x4 Aq[];                 // [3 planes][BM][nkt * 4 + 1] pieces
-    const int row_u4 = nkt * 4 + 1;               // odd piece count per row: 16 rows start in different bank quads
-    const int plane_u4 = BM * row_u4;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int fi = lane & 15, kq = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int gK = g.K, n_cols = g.n_cols;
-    const float gscale = g.a_scale;
-    // ---- A: every (row, 8-k piece) once
-    for (int idx = tid; idx < BM * nkt * 4; idx += kThreads) {
-        const int row = idx / (nkt * 4), pc = idx - row * (nkt * 4);
-        const int64_t r = m0 + row;
-        f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
-        if (r < g.M) {
-            const float* ap = g.A + ((r / g.a_gdiv) * g.a_gmul + (r % g.a_gdiv)) * g.lda + pc * 8;
-            if (pc * 8 < gK) x0 = *reinterpret_cast<const f32x4*>(ap);
-            if (pc * 8 + 4 < gK) x1 = *reinterpret_cast<const f32x4*>(ap + 4);
-        }
-        u32x4 p0, p1, p2;
-        split8(x0 * gscale, x1 * gscale, p0, p1, p2);
-        Aq[row * row_u4 + pc] = p0;
-        Aq[plane_u4 + row * row_u4 + pc] = p1;
-        Aq[2 * plane_u4 + row * row_u4 + pc] = p2;
-    }
-    __syncthreads();
-    const int cg0 = blockIdx.y * cg_per_wg;
-    const int cg1 = cg0 + cg_per_wg < n_cols / 64 ? cg0 + cg_per_wg : n_cols / 64;
-    const int64_t b_plane = (int64_t)n_cols * 4, b_kt = 3 * b_plane;
-    const u32x4* Ab = Aq + fi * row_u4 + kq;
-    for (int cg = cg0; cg < cg1; ++cg) {
-        const u32x4* Bq = reinterpret_cast<const u32x4*>(g.Bq) + ((int64_t)(cg * 64 + wave * 16 + fi)) * 4 + kq;
-        f32x4 acc[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 bn[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) bn[p] = Bq[p * b_plane];
-        for (int kt = 0; kt < nkt; ++kt) {
-            u32x4 bc[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bc[p] = bn[p];
-            if (kt + 1 < nkt) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) bn[p] = Bq[(kt + 1) * b_kt + p * b_plane];
-            }
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const u32x4* ar = Ab + r * 16 * row_u4 + kt * 4;
-                const u32x4 a0 = ar[0], a1 = ar[plane_u4], a2 = ar[2 * plane_u4];
-                acc[r] = mma(a2, bc[0], acc[r]);
-                acc[r] = mma(a0, bc[2], acc[r]);
-                acc[r] = mma(a1, bc[1], acc[r]);
-                acc[r] = mma(a1, bc[0], acc[r]);
-                acc[r] = mma(a0, bc[1], acc[r]);
-                acc[r] = mma(a0, bc[0], acc[r]);
-            }
-        }
-        const int col = cg * 64 + wave * 16 + fi;
-        if (col < g.n_store) {
-            const float bias = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int64_t row = m0 + r * 16 + kq * 4 + e;
-                    if (row < g.M) {
-                        float v = acc[r][e] + bias;
-                        if (g.relu) v = fmaxf(v, 0.f);
-                        g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
 }  // namespace
 
 size_t dcs_gemm_bq_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * 3 * (size_t)n_cols * 4 * 16; }
@@ -287,30 +207,12 @@ bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
     // A-streaming GEMMs of the encoder are bound by memory latency, not by the matrix pipe -- measured at 4096 tiles
     // conv1 0.041 -> 0.047 ms, fc 0.020 -> 0.021, while fc1x 0.042 -> 0.036; Bach10 fc1x (167 x 256 x 666 600) 0.72 -> 0.58
     if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu || g.n_cols < 1024 || g.M < 128) return false;
-    static const bool ares_on = !(getenv("DCS_GEMM_ARES") && atoi(getenv("DCS_GEMM_ARES")) == 0);
-    if (ares_on && g.K <= 256) {
-        // short K: A resident in LDS, a workgroup walks a run of column groups.  64-row tiles; the run length gives about
-        // three rounds of resident workgroups (LDS decides how many share a CU)
-        const int nkt = (g.K + 31) / 32;
-        const int64_t row_tiles = dcs_cdiv(g.M, 64);
-        const size_t lds = (size_t)3 * 64 * (nkt * 4 + 1) * 16;
-        const int64_t capacity = (int64_t)ctx->n_cu * (lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1));
-        int cg_per_wg = (int)((row_tiles * col_groups + 3 * capacity - 1) / (3 * capacity));
-        if (cg_per_wg < 1) cg_per_wg = 1;
-        auto kern = gemm_bf16x3_ares_kernel<4>;
-        if (lds <= 160 * 1024 &&
-            (lds <= 48 * 1024 || hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)lds) == hipSuccess)) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)row_tiles, (unsigned)dcs_cdiv(col_groups, cg_per_wg)), dim3(kThreads), lds,
-                               ctx->stream, g, nkt, cg_per_wg);
-            return true;
-        }
-    }
+    static const int xcd_map = !(getenv("DCS_GEMM_XCD") && atoi(getenv("DCS_GEMM_XCD")) == 0);
     if (groups16 * col_groups <= 16 * (int64_t)ctx->n_cu)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2>), dim3((unsigned)dcs_cdiv(g.M, 32), (unsigned)col_groups), dim3(kThreads), 0,
-                           ctx->stream, g);
+                           ctx->stream, g, xcd_map);
     else
         hipLaunchKernelGGL((gemm_bf16x3_kernel<4>), dim3((unsigned)dcs_cdiv(g.M, 64), (unsigned)col_groups), dim3(kThreads), 0,
-                           ctx->stream, g);
+                           ctx->stream, g, xcd_map);
     return true;
 }

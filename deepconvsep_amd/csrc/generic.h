@@ -12,6 +12,25 @@ struct DcsGenericDims {
 
 struct DcsGenericNet;
 
+// column convolution (kh x 1): see colconv_kernel in generic.hip for the operation
+struct DcsColConv {
+    const float* in; int64_t in_n_stride; int Cin, H, W;
+    const float* Wk;            // [kh][32][32] (ci, co swizzled: see colconv_wslot)
+    const float* bias;          // [32]
+    float* out; int64_t out_n_stride; int Cout, Ho;
+    int ph, kh;
+    int xb_per_wg;              // column blocks (16 x each) a workgroup walks
+    int n_xb;                   // column blocks per image
+};
+// weights-in-registers f16 variant (colconv_wreg.hip): false = shape not covered, nothing launched
+void dcs_colconv_wreg_pack(const _Float16* Wh, int kh, std::vector<_Float16>* out);
+bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq);
+// InverseLayer(conv2) + InverseLayer(conv1) in one kernel (Bach10 graph, f16 switch on): out [image][Ho][F]
+void dcs_decoder_fused_pack(const float* W1p, int nf1, std::vector<uint16_t>* out);
+bool dcs_decoder_fused_ok(const DcsColConv& a, int F);
+bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out,
+                              int F);
+
 int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int F,
                        const std::vector<std::vector<float>>& params, DcsGenericNet** out);
 void dcs_generic_destroy(DcsGenericNet* g);

@@ -344,15 +344,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const IgemmArgs g)
 // weights for several column blocks of the same image.  LDS strides / the co swizzle keep the two K-quarters of a
 // 32-lane half on disjoint banks.  Measured (Bach10, 10 s): transpose 5.2 -> see DESIGN.md, forward 0.95 -> idem.
 // ------------------------------------------------------------------------------------------------
-struct ColConvArgs {
-    const float* in; int64_t in_n_stride; int Cin, H, W;
-    const float* Wk;            // [kh][32][32] (ci, co swizzled: see colconv_wslot)
-    const float* bias;          // [32]
-    float* out; int64_t out_n_stride; int Cout, Ho;
-    int ph, kh;
-    int xb_per_wg;              // column blocks (16 x each) a workgroup walks
-    int n_xb;                   // column blocks per image
-};
+typedef DcsColConv ColConvArgs;
 
 __host__ __device__ __forceinline__ int colconv_wslot(int u, int ci, int co) {
     return (u * 32 + ci) * 32 + ((co + 16 * (ci & 1)) & 31);
@@ -1114,6 +1106,8 @@ struct DcsGenericNet {
     float* W1p = nullptr;      // conv1 filters padded to sw1*ceil(kw1/sw1) taps (register-blocked transpose of conv1)
     float *Wcol = nullptr, *Wcol_t = nullptr;
     _Float16 *Wcol_h = nullptr, *Wcol_t_h = nullptr;     // [kh][32 co][40] halves, channel-fastest
+    _Float16 *Wcol_r = nullptr, *Wcol_t_r = nullptr;     // the same weights as MFMA fragments (colconv_wreg.hip)
+    uint16_t* W1q = nullptr;                             // padded conv1 filter as bf16 x 3 fragments (fused decoder)
     int use_colconv = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
@@ -1281,7 +1275,17 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
     if (!W1p.empty()) { UP(g->W1p, W1p) }
     if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) UP(g->Wslab_q3, Wslab_q3) UP(g->Wslab_t_q3, Wslab_t_q3) UP(g->Wslab_h, Wslab_h) UP(g->Wslab_t_h, Wslab_t_h) }
-    if (g->use_colconv) { UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) }
+    if (g->use_colconv) {
+        std::vector<_Float16> Wcol_r, Wcol_t_r;
+        dcs_colconv_wreg_pack(Wcol_h.data(), kh, &Wcol_r);
+        dcs_colconv_wreg_pack(Wcol_t_h.data(), kh, &Wcol_t_r);
+        UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) UP(g->Wcol_r, Wcol_r) UP(g->Wcol_t_r, Wcol_t_r)
+        if (C == 1 && d.sw1 == 4 && kw1 > 28 && kw1 <= 32 && !d.pool_w && !W1p.empty()) {
+            std::vector<uint16_t> W1q;
+            dcs_decoder_fused_pack(W1p.data(), nf1, &W1q);
+            UP(g->W1q, W1q)
+        }
+    }
     for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) {
         std::vector<float> Bd((size_t)dcs_round_up(g->hid64, 128) * g->flat64, 0.f), bd(g->flat64, 0.f);
         for (int h = 0; h < d.hidden; ++h)
@@ -1310,7 +1314,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
     for (void* p : ptrs)
@@ -1367,8 +1371,9 @@ bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images, const uint1
     return true;
 }
 
-int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16* Wh = nullptr) {
+int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16* Wh = nullptr, const _Float16* Wr = nullptr) {
     a.n_xb = (a.W + 15) / 16;
+    if (Wh && Wr && dcs_launch_colconv_wreg(ctx, a, n_images, Wr)) return DCS_OK;
     if (Wh) {
         int per = 8;
         while (per > 1 && n_images * ((a.n_xb + per - 1) / per) < 4 * (int64_t)ctx->n_cu) per >>= 1;
@@ -1466,7 +1471,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = 0; c.kh = d.kh2;
-            DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr));
+            DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr, g->Wcol_r));
         } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
             // general filters (iKala, 10 x 20) go through the slab kernel in either precision unless DCS_F16_IGEMM=1 asks
             // for the f16 implicit GEMM
@@ -1507,6 +1512,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC1X));
     }
     // InverseLayer(., conv2): [n*NB, nf2, h2, w2] -> [n*NB, nf1, tc, wp]
+    bool decoder_fused = false;
     {
         IgemmArgs a{};
         a.in = D; a.in_n_stride = g->flat_p; a.Cin = d.nf2; a.H = d.h2; a.W = d.w2;
@@ -1514,13 +1520,22 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         a.out = g2; a.out_n_stride = (int64_t)d.nf1 * planep; a.Cout = d.nf1; a.Ho = tc; a.Wo = d.wp;
         a.ph = d.kh2 - 1; a.pw = d.kw2 - 1; a.K = g->K2; a.M = n * NB * planep;
         a.kh = d.kh2; a.k_per_u = d.nf2 * d.kw2;
-        DcsTimer tm(ctx, DCS_TAG_DECONV2);
+        ColConvArgs c{};
         if (g->use_colconv) {
-            ColConvArgs c{};
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
-            c.ph = d.kh2 - 1; c.kh = d.kh2;
-            DCS_CHECK(launch_colconv(ctx, c, n * NB, g->conv_f16 ? g->Wcol_t_h : nullptr));
+            c.ph = d.kh2 - 1; c.kh = d.kh2; c.n_xb = (c.W + 15) / 16;
+            decoder_fused = g->conv_f16 && g->W1q && g->Wcol_t_r && dcs_decoder_fused_ok(c, F);
+        }
+        if (decoder_fused) {                                 // both InverseLayers in one kernel: o directly
+            DcsTimer tmf(ctx, DCS_TAG_DECODER);
+            dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F);
+            tmf.done();
+        }
+        DcsTimer tm(ctx, decoder_fused ? -1 : DCS_TAG_DECONV2);
+        if (decoder_fused) {
+        } else if (g->use_colconv) {
+            DCS_CHECK(launch_colconv(ctx, c, n * NB, g->conv_f16 ? g->Wcol_t_h : nullptr, g->Wcol_t_r));
         } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2t_h);
@@ -1550,7 +1565,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         tm.done();
     }
     // InverseLayer(., conv1): [n*NB, nf1, tc, w1] -> [n*NB, C, tc, F] = [n, NB*C, tc, F]
-    {
+    if (!decoder_fused) {
         const int span = kThreads / d.sw1 + d.kw1 / d.sw1 + 3;
         const size_t lds = ((size_t)d.nf1 * C * d.kw1 + (size_t)d.nf1 * span) * 4;
         auto kern = deconv1_kernel<30>;

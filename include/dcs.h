@@ -212,7 +212,9 @@ int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_fram
  * 0 disables all. */
 enum { DCS_TAG_STFT = 0, DCS_TAG_CONV1 = 1, DCS_TAG_CONV2 = 2, DCS_TAG_FC = 3, DCS_TAG_FC1X = 4,
        DCS_TAG_DECONV2 = 5, DCS_TAG_FINAL = 6, DCS_TAG_ISTFT = 7, DCS_TAG_OLA = 8, DCS_TAG_TILE = 9, DCS_TAG_POOL = 10,
-       DCS_TAG_UNPOOL = 11, DCS_TAG_MASK = 12, DCS_TAG_SCORE = 13, DCS_TAG_COUNT = 14 };
+       DCS_TAG_UNPOOL = 11, DCS_TAG_MASK = 12, DCS_TAG_SCORE = 13,
+       DCS_TAG_DECODER = 14 /* transposed conv2 + transposed conv1 in one kernel (Bach10 graph, f16 switch) */,
+       DCS_TAG_COUNT = 15 };
 int dcs_timing_enable(dcs_ctx* ctx, unsigned tag_mask);
 /* bracket only every stride-th launch of an enabled tag (an event pair costs ~6 us of stream time each side) */
 int dcs_timing_stride(dcs_ctx* ctx, int stride);
