@@ -241,10 +241,13 @@ __global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const Dc
 //            P^T[(mm, r)][x] = sum_ci W1[ci][4 mm + r] G[ci][x] is a 32 x 32 x 16 product per row (bf16 pipe, both
 //            operands split three ways, six products: f32-class), after which lane (x, kq) holds the float4
 //            P[x][mm = kq (+4)][r = 0..3] = a 16-byte piece of the output row at f = 4 (x + mm);
-//   shift-add  the eight pieces that meet at one q come from different lanes: they are added into a per-wave LDS ring
-//            y[t][32 q slots][4] with ds_add_f32 (no return value, nothing waits on it).  A wave walks consecutive
-//            column blocks of one image, so after block b the slots of q = 16 b .. 16 b + 15 are complete (their inputs
-//            are x = q - 7 .. q) and are flushed as 256 contiguous bytes per row, while q = 16 b + 16 .. + 22 carry over.
+//   shift-add  the eight pieces that meet at one q come from different lanes.  Each lane writes its two pieces to a
+//            per-wave LDS array P[row][mm][slot 8 + x] (zero guard slots either side); then lane q of the first (second)
+//            half-wave adds the eight slots P[row 0 (1)][mm][8 + q - mm] of its q = 16 b .. 16 b + 22 -- plain
+//            ds_write_b128 / ds_read_b128, no conflicts, no atomics (ds_add_f32 costs ~150 cycles per wave instruction
+//            and made the first version 1.9 ms).  A wave walks consecutive column blocks of one image: q < 16 b + 16 is
+//            complete after block b (its inputs are x = q - 7 .. q) and goes out as 256 contiguous bytes per row, with the
+//            carry of block b - 1 added; q = 16 b + 16 .. + 22 are this block's carry (LDS, [row][8]).
 // An image's blocks are cut into runs (one wave each); a run that does not start at x = 0 first recomputes the block to
 // its left and keeps only the carry.  HBM traffic: the dense-layer output once (445 MB) + the 164 MB result.
 // ------------------------------------------------------------------------------------------------
@@ -286,13 +289,18 @@ template <int KH, int H>
 __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
                                                                          const DcsDecoderFused d) {
     constexpr int HO = H + KH - 1, PH = KH - 1;
-    constexpr int kRing = HO * 32 * 4;                       // floats per wave
-    __shared__ __attribute__((aligned(16))) float Yall[4 * kRing];
+    static_assert(HO % 2 == 0, "output rows are processed in pairs");
+    // per wave: Pb [2 rows][8 taps mm][32 slots] float4 -- slot 8 + x holds P[x][mm], slots 0..7 and 24..31 stay zero --
+    // and the carry Cb [HO][8] float4 (q = 16 b + 16 .. + 23 of the block just finished; the last one is always zero)
+    constexpr int kPb = 2 * 8 * 32 * 4, kCb = HO * 8 * 4;
+    __shared__ __attribute__((aligned(16))) float lds[4 * (kPb + kCb)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fi = lane & 15, kq = lane >> 4;
-    float* Y = Yall + wave * kRing;
-    for (int i = lane; i < kRing / 4; i += 64) reinterpret_cast<f32x4*>(Y)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4* Pb = reinterpret_cast<f32x4*>(lds + wave * (kPb + kCb));
+    f32x4* Cb = Pb + kPb / 4;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < kPb / 4; i += 64) Pb[i] = zero4;
     h8 w[KH][2];
 #pragma unroll
     for (int u = 0; u < KH; ++u) {
@@ -315,6 +323,11 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
     const int HW = H * W;
     const int rpi = d.runs_per_image;
     const int64_t stride = (int64_t)gridDim.x * 4;
+    // write side: lane (x = fi, kq) owns taps mm = kq and kq + 4 of column x
+    f32x4* pw = Pb + kq * 32 + 8 + fi;
+    // read side: lanes 0..31 sum row 0 of a pair, lanes 32..63 row 1; lane & 31 = q - 16 b (0..22 are real)
+    const int rt = lane >> 5, rq = lane & 31;
+    const f32x4* pr = Pb + rt * 256 + (rq < 23 ? rq : 22) + 8;
     float raw[H][8];
 #define DCS_FETCH(img_, blk_)                                                                           \
     {                                                                                                   \
@@ -326,34 +339,12 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
             _Pragma("unroll") for (int j = 0; j < 8; ++j) raw[h][j] = ir_[li_.idx[j]];                  \
         }                                                                                               \
     }
-    // slots (ro + q) & 31, q < 16, of every row: out (when `store`) and cleared; q0 = first output q of the slots
-#define DCS_FLUSH(store_, q0_)                                                                          \
-    {                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < (HO + 3) / 4; ++i) {                                      \
-            const int t_ = kq + 4 * i;                                                                  \
-            if (t_ < HO) {                                                                              \
-                f32x4* yp_ = reinterpret_cast<f32x4*>(Y) + t_ * 32 + ((ro + fi) & 31);                  \
-                const f32x4 v_ = *yp_;                                                                  \
-                *yp_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                       \
-                const int f_ = 4 * ((q0_) + fi);                                                        \
-                if (store_) {                                                                           \
-                    float* op_ = d.out + (img * HO + t_) * (int64_t)F + f_;                             \
-                    if (f_ + 4 <= F) {                                                                  \
-                        *reinterpret_cast<f32x4u*>(op_) = v_;                                           \
-                    } else {                                                                            \
-                        _Pragma("unroll") for (int e = 0; e < 3; ++e)                                   \
-                            if (f_ + e < F) op_[e] = v_[e];                                             \
-                    }                                                                                   \
-                }                                                                                       \
-            }                                                                                           \
-        }                                                                                               \
-    }
     for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < d.n_runs; run += stride) {
         const int64_t img = run / rpi;
         const int rr = (int)(run - img * rpi);
         const int b_lo = (int)((int64_t)rr * n_xb / rpi), b_hi = (int)((int64_t)(rr + 1) * n_xb / rpi);
         const int b_first = b_lo > 0 ? b_lo - 1 : 0;         // the block to the left is recomputed for its carry
-        int ro = 0;
+        for (int i = lane; i < kCb / 4; i += 64) Cb[i] = zero4;
         DCS_FETCH(img, b_first)
         for (int b = b_first; b < b_hi; ++b) {
             h8 a[H];
@@ -363,20 +354,21 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
                 const int nb = b + 1 < b_hi ? b + 1 : b;     // last block of the run: a harmless re-read
                 DCS_FETCH(img, nb)
             }
-            const bool x_ok = b * 16 + fi < W;
-            float* y0 = Y + ((ro + fi + kq) & 31) * 4;       // taps mm = kq; mm = kq + 4 four slots further
-            float* y1 = Y + ((ro + fi + kq + 4) & 31) * 4;
+            const bool x_ok = b * 16 + fi < W;               // columns past W (last block only) must not reach the rows
+            const bool keep = b >= b_lo;                     // wave-uniform: false for the recomputed block
+            const int f0 = 4 * (b * 16 + rq);
+            float* orow = d.out + (img * HO + rt) * (int64_t)F + f0;
 #pragma unroll
             for (int y = 0; y < HO; y += 2) {
                 f32x4 acc[2][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = zero4;
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int u = h - (y + t) + PH;
-                        if (y + t < HO && u >= 0 && u < KH) {
+                        if (u >= 0 && u < KH) {
                             acc[t][0] = mma(w[u < 0 || u >= KH ? 0 : u][0], a[h], acc[t][0]);
                             acc[t][1] = mma(w[u < 0 || u >= KH ? 0 : u][1], a[h], acc[t][1]);
                         }
@@ -384,48 +376,65 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    if (y + t < HO) {
-                        float gv[8];
+                    float gv[8];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            gv[e] = acc[t][0][e] + bias[e];
-                            gv[4 + e] = acc[t][1][e] + bias[4 + e];
-                        }
-                        u32x4 g0, g1, g2;
-                        split8(gv, g0, g1, g2);
-                        f32x4 P[2];
+                    for (int e = 0; e < 4; ++e) {
+                        gv[e] = acc[t][0][e] + bias[e];
+                        gv[4 + e] = acc[t][1][e] + bias[4 + e];
+                    }
+                    u32x4 g0, g1, g2;
+                    split8(gv, g0, g1, g2);
 #pragma unroll
-                        for (int mh = 0; mh < 2; ++mh) {
-                            f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
-                            p = mma_bf(w1[2][mh], g0, p);      // smallest products first
-                            p = mma_bf(w1[0][mh], g2, p);
-                            p = mma_bf(w1[1][mh], g1, p);
-                            p = mma_bf(w1[1][mh], g0, p);
-                            p = mma_bf(w1[0][mh], g1, p);
-                            p = mma_bf(w1[0][mh], g0, p);
-                            P[mh] = p;
-                        }
-                        // columns past W (last block only) must not reach the rows
+                    for (int mh = 0; mh < 2; ++mh) {
+                        f32x4 p = zero4;
+                        p = mma_bf(w1[2][mh], g0, p);          // smallest products first
+                        p = mma_bf(w1[0][mh], g2, p);
+                        p = mma_bf(w1[1][mh], g1, p);
+                        p = mma_bf(w1[1][mh], g0, p);
+                        p = mma_bf(w1[0][mh], g1, p);
+                        p = mma_bf(w1[0][mh], g0, p);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            __hip_atomic_fetch_add(y0 + (y + t) * 128 + e, x_ok ? P[0][e] : 0.f, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            __hip_atomic_fetch_add(y1 + (y + t) * 128 + e, x_ok ? P[1][e] : 0.f, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        }
+                        for (int e = 0; e < 4; ++e) p[e] = x_ok ? p[e] : 0.f;
+                        pw[t * 256 + mh * 128] = p;
                     }
                 }
+                asm volatile("" ::: "memory");               // the pieces of both rows are written (LDS is in order per wave)
+                f32x4 sum = zero4;
+#pragma unroll
+                for (int mm = 0; mm < 8; ++mm) sum += pr[mm * 32 - mm];
+                const f32x4 cin = Cb[(y + rt) * 8 + (rq & 7)];
+                if (rq < 8) sum += cin;
+                if (rq >= 16 && rq < 24) Cb[(y + rt) * 8 + rq - 16] = rq < 23 ? sum : zero4;
+                if (keep && rq < 16) {
+                    float* op = orow + (int64_t)y * F;
+                    if (f0 + 4 <= F) {
+                        *reinterpret_cast<f32x4u*>(op) = sum;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            if (f0 + e < F) op[e] = sum[e];
+                    }
+                }
+                asm volatile("" ::: "memory");
             }
-            const bool keep = b >= b_lo;                     // wave-uniform
-            DCS_FLUSH(keep, b * 16)
-            ro ^= 16;
         }
         // the carry: the tail of the image (and the zeros up to F) for the last run, otherwise the next run recomputes it
-        const bool last = b_hi == n_xb;
-        DCS_FLUSH(last, b_hi * 16)
+        if (b_hi == n_xb) {
+#pragma unroll
+            for (int i = 0; i < (HO + 7) / 8; ++i) {
+                const int t = (lane >> 3) + 8 * i, f = 4 * (16 * n_xb + (lane & 7));
+                if (t < HO) {
+                    const f32x4 v = Cb[t * 8 + (lane & 7)];
+                    float* op = d.out + (img * HO + t) * (int64_t)F + f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (f + e < F) op[e] = v[e];
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
     }
 #undef DCS_FETCH
-#undef DCS_FLUSH
 }
 
 }  // namespace
