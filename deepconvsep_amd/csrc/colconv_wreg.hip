@@ -355,6 +355,7 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
                 DCS_FETCH(img, nb)
             }
             const bool x_ok = b * 16 + fi < W;               // columns past W (last block only) must not reach the rows
+            const bool edge = b * 16 + 16 > W;
             const bool keep = b >= b_lo;                     // wave-uniform: false for the recomputed block
             const int f0 = 4 * (b * 16 + rq);
             float* orow = d.out + (img * HO + rt) * (int64_t)F + f0;
@@ -393,8 +394,10 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
                         p = mma_bf(w1[1][mh], g0, p);
                         p = mma_bf(w1[0][mh], g1, p);
                         p = mma_bf(w1[0][mh], g0, p);
+                        if (edge) {                            // wave-uniform: only the last block of an image
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) p[e] = x_ok ? p[e] : 0.f;
+                            for (int e = 0; e < 4; ++e) p[e] = x_ok ? p[e] : 0.f;
+                        }
                         pw[t * 256 + mh * 128] = p;
                     }
                 }

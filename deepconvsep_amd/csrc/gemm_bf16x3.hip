@@ -185,6 +185,139 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Few rows, very wide N (the per-source dense layers of the Bach10 / score-informed graphs: 167 x 256 x 666 600, a
+// gigabyte of B planes): ALL rows in one workgroup, so that every byte of B is read exactly once and meets 11 row blocks.
+// The product is taken transposed -- MFMA rows = 16 columns of C, MFMA columns = 16 rows of C -- and the four column
+// blocks of a wave are interleaved (block cb, MFMA row i  <->  column 16 (i / 4) + 4 cb + i % 4), so that a lane ends up
+// with 16 CONSECUTIVE columns of one row: four 16-byte stores, 256 contiguous bytes per row and wave (the 64 x 64 tiling
+// above writes 64-byte pieces, which this chip's store path moves at a fraction of the rate, and reads B once per row tile).
+// B fragments go global -> registers one k tile ahead; the A rows of a k tile are split once per workgroup into LDS planes
+// (double buffered, one barrier per k tile).  176 + 96 + ... VGPRs: one wave per SIMD, which is all the LDS allows anyway.
+// ------------------------------------------------------------------------------------------------
+template <int RBT /* row blocks of 16 */>
+__global__ __launch_bounds__(kThreads) void gemm_bf16x3_skinny_kernel(const DcsGemm g) {
+    constexpr int ROWS = RBT * 16;
+    constexpr int kPlane = ROWS * kRowU4, kBuf = 3 * kPlane;
+    extern __shared__ u32x4 As[];                         // [2][3 planes][ROWS][kRowU4]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int n_cols = g.n_cols, gK = g.K;
+    const int nkt = (gK + 31) / 32;
+    const float gscale = g.a_scale;
+    const int n0 = blockIdx.x * 256 + wave * 64;          // this wave's 64 columns
+    const bool live = n0 < n_cols;                        // n_cols is a multiple of 64
+    // A staging: piece idx = (row, kg): 8 consecutive k of one row
+    constexpr int A_PER = (ROWS * 4 + kThreads - 1) / kThreads;
+    const float* a_ptr[A_PER];
+    bool a_ok[A_PER];
+    int a_dst[A_PER], a_k0[A_PER];
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        const int idx = tid + u * kThreads;
+        const int row = idx >> 2, q = idx & 3;
+        a_ok[u] = idx < ROWS * 4 && row < g.M;
+        const int64_t rr = a_ok[u] ? row : 0;
+        a_ptr[u] = g.A + ((rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda + q * 8;
+        a_k0[u] = q * 8;
+        a_dst[u] = idx < ROWS * 4 ? row * kRowU4 + q : -1;
+    }
+    // B: piece (kt, plane, column, kg); the column of MFMA row fi in block cb
+    const int64_t b_plane = (int64_t)n_cols * 4, b_kt = 3 * b_plane;
+    const u32x4* Bl = reinterpret_cast<const u32x4*>(g.Bq) + ((int64_t)((live ? n0 : 0) + (fi >> 2) * 16 + (fi & 3))) * 4 + kq;
+    f32x4 ra[A_PER][2];
+    u32x4 bn[4][3], bc[4][3];
+#define DCS_LOAD_A(kt_)                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                                 \
+        const int k = (kt_) * 32 + a_k0[u];                                                             \
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+        ra[u][0] = (a_ok[u] && k < gK) ? *reinterpret_cast<const f32x4*>(a_ptr[u] + (kt_) * 32) : z;    \
+        ra[u][1] = (a_ok[u] && k + 4 < gK) ? *reinterpret_cast<const f32x4*>(a_ptr[u] + (kt_) * 32 + 4) : z; \
+    }
+#define DCS_LOAD_B(kt_)                                                                                 \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                    \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) bn[cb][p] = Bl[(kt_) * b_kt + p * b_plane + cb * 16];
+#define DCS_STORE_A(buf_)                                                                               \
+    _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                                 \
+        if (a_dst[u] >= 0) {                                                                            \
+            u32x4 p0, p1, p2;                                                                           \
+            split8(ra[u][0] * gscale, ra[u][1] * gscale, p0, p1, p2);                                   \
+            u32x4* dst = As + (buf_) * kBuf + a_dst[u];                                                 \
+            dst[0] = p0; dst[kPlane] = p1; dst[2 * kPlane] = p2;                                        \
+        }                                                                                               \
+    }
+    f32x4 acc[RBT][4];
+#pragma unroll
+    for (int r = 0; r < RBT; ++r)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[r][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    DCS_LOAD_A(0)
+    DCS_LOAD_B(0)
+    DCS_STORE_A(0)
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bc[cb][p] = bn[cb][p];
+        const int ktn = kt + 1 < nkt ? kt + 1 : kt;       // last tile: a harmless re-read
+        DCS_LOAD_A(ktn)
+        DCS_LOAD_B(ktn)
+        const u32x4* Ab = As + (kt & 1) * kBuf + fi * kRowU4 + kq;
+#pragma unroll
+        for (int r = 0; r < RBT; ++r) {
+            const u32x4 a0 = Ab[r * 16 * kRowU4], a1 = Ab[kPlane + r * 16 * kRowU4], a2 = Ab[2 * kPlane + r * 16 * kRowU4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x4 c = acc[r][cb];
+                c = mma(bc[cb][2], a0, c);                // smallest products first
+                c = mma(bc[cb][0], a2, c);
+                c = mma(bc[cb][1], a1, c);
+                c = mma(bc[cb][1], a0, c);
+                c = mma(bc[cb][0], a1, c);
+                c = mma(bc[cb][0], a0, c);
+                acc[r][cb] = c;
+            }
+        }
+        if (kt + 1 < nkt) DCS_STORE_A((kt + 1) & 1)
+        __syncthreads();
+    }
+#undef DCS_LOAD_A
+#undef DCS_LOAD_B
+#undef DCS_STORE_A
+    if (!live) return;
+    // lane (row fi of block r, kq): columns n0 + 16 kq + 4 cb + e
+    const int c0 = n0 + kq * 16;
+    f32x4 bias[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[cb][e] = (g.bias && c0 + cb * 4 + e < g.n_store) ? g.bias[c0 + cb * 4 + e] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RBT; ++r) {
+        const int64_t row = r * 16 + fi;
+        if (row < g.M) {
+            float* cp = g.C + ((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + c0;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x4 v = acc[r][cb] + bias[cb];
+                if (g.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (c0 + cb * 4 + 4 <= g.n_store) {
+                    *reinterpret_cast<f32x4*>(cp + cb * 4) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (c0 + cb * 4 + e < g.n_store) cp[cb * 4 + e] = v[e];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 size_t dcs_gemm_bq_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * 3 * (size_t)n_cols * 4 * 16; }
@@ -207,6 +340,18 @@ bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
     // A-streaming GEMMs of the encoder are bound by memory latency, not by the matrix pipe -- measured at 4096 tiles
     // conv1 0.041 -> 0.047 ms, fc 0.020 -> 0.021, while fc1x 0.042 -> 0.036; Bach10 fc1x (167 x 256 x 666 600) 0.72 -> 0.58
     if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu || g.n_cols < 1024 || g.M < 128) return false;
+    static const bool skinny_on = !(getenv("DCS_GEMM_SKINNY") && atoi(getenv("DCS_GEMM_SKINNY")) == 0);
+    // 16-byte stores need C rows and the column offset on 16-byte boundaries
+    if (skinny_on && g.M <= 176 && g.n_cols >= 8192 && (g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0) {
+        const int rbt = g.M <= 128 ? 8 : 11;
+        const size_t lds = (size_t)2 * 3 * rbt * 16 * kRowU4 * 16;
+        auto kern = rbt == 8 ? gemm_bf16x3_skinny_kernel<8> : gemm_bf16x3_skinny_kernel<11>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+            hipSuccess) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(g.n_cols, 256)), dim3(kThreads), lds, ctx->stream, g);
+            return true;
+        }
+    }
     static const int xcd_map = !(getenv("DCS_GEMM_XCD") && atoi(getenv("DCS_GEMM_XCD")) == 0);
     if (groups16 * col_groups <= 16 * (int64_t)ctx->n_cu)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2>), dim3((unsigned)dcs_cdiv(g.M, 32), (unsigned)col_groups), dim3(kThreads), 0,

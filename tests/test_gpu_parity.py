@@ -350,6 +350,31 @@ def test_generic_graphs_match_oracle(arch, F, n):
                    conv='A' if arch == 'ikala' else 'B', label="%s F=%d glorot" % (arch, F))
 
 
+@pytest.mark.parametrize("n", [150, 128])
+def test_dense_layers_with_all_rows_in_one_workgroup(n):
+    """128 ... 176 tiles in one launch: the per-source dense layers (256 x 18 810 here, 256 x 166 650 at F = 2049) run on
+    the bf16 pipe with three-way split operands and every row in one workgroup (gemm_bf16x3_skinny_kernel, 11 or 8 row
+    blocks).  f32 path against the oracle at 1e-4; with the f16 switch on (conv2 / conv2^T in f16, both InverseLayers in
+    the fused decoder kernel, one run per image here) against the f16 path's stated tolerance."""
+    arch, F, tc = "bach10", 257, 30
+    S = ARCHS[arch].S
+    params = synth_params(arch, tc, F, seed=3)
+    x = _tiles(arch, n, tc, F, seed=21)
+    ctx = default_context()
+    net = Network(ctx, arch, params, tc, F)
+    xd = ctx.to_device(x, np.float32)
+    want = net_ref.forward(arch, params, x.astype(np.float64), inverse='explicit').numpy()
+    p = net.forward_raw(xd).cpu().numpy()
+    assert np.max(np.abs(p - want)) < 1e-4
+    got = net.forward_masked(xd).cpu().numpy()
+    ref = net_ref.predict(arch, params, x.astype(np.float64), inverse='explicit')
+    _assert_masked(got, ref, want, x[:, 0].astype(np.float64), S, p_got=p, conv='B', label="bach10 F=257, %d tiles" % n)
+    net.set_conv_precision('f16')
+    p16 = net.forward_raw(xd).cpu().numpy()
+    net.set_conv_precision('f32')
+    assert np.max(np.abs(p16 - want)) < 2e-3
+
+
 def test_ikala_pool_tie_modes():
     """Digital-silence rows make every pooling window tie: Theano's CPU gradient feeds all tied positions
     (default), cuDNN only the first."""
