@@ -68,6 +68,13 @@ void DcsTimer::done() {
     if (on) (void)hipEventRecord(ctx->slots[tag].stop[idx], ctx->stream);
 }
 
+// nothing was launched after all: give the slot back (only valid while it is the tag's most recent one)
+void DcsTimer::cancel() {
+    if (!on) return;
+    ctx->slots[tag].used = idx;
+    on = false;
+}
+
 extern "C" int dcs_timing_enable(dcs_ctx* ctx, unsigned tag_mask) {
     if (!ctx) DCS_FAIL(DCS_EINVAL, "dcs_timing_enable: null ctx");
     ctx->timing_mask = tag_mask;

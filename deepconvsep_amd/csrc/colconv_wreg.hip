@@ -313,12 +313,7 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
         w1[p][0] = d.Wq1[(p * 2) * 64 + lane];
         w1[p][1] = d.Wq1[(p * 2 + 1) * 64 + lane];
     }
-    float bias[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        bias[e] = g.bias[4 * kq + e];
-        bias[4 + e] = g.bias[16 + 4 * kq + e];
-    }
+    // g.bias is not read: an InverseLayer has no bias (the generic path's vector for this layer is all zeros)
     const int W = g.W, n_xb = g.n_xb, F = d.F;
     const int HW = H * W;
     const int rpi = d.runs_per_image;
@@ -380,8 +375,8 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
                     float gv[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        gv[e] = acc[t][0][e] + bias[e];
-                        gv[4 + e] = acc[t][1][e] + bias[4 + e];
+                        gv[e] = acc[t][0][e];
+                        gv[4 + e] = acc[t][1][e];
                     }
                     u32x4 g0, g1, g2;
                     split8(gv, g0, g1, g2);

@@ -94,6 +94,7 @@ struct DcsTimer {
     bool on;
     DcsTimer(dcs_ctx* c, int t);
     void done();
+    void cancel();
 };
 
 static inline int64_t dcs_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -163,6 +164,13 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag);
 size_t dcs_gemm_bq_bytes(int K, int n_cols);
 int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d);   // enqueued on the ctx stream
 bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g);
+struct DcsGemmBranches {         // (B planes, bias, C) of up to 4 GEMMs that share A and shape
+    int n;
+    const void* Bq[4];
+    const float* bias[4];
+    float* C[4];
+};
+bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemmBranches* br);   // false: not taken
 
 // ---------------------------------------------------------------------------------- tiling kernels
 int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F,

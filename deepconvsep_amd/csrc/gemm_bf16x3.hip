@@ -193,20 +193,30 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g, 
 // with 16 CONSECUTIVE columns of one row: four 16-byte stores, 256 contiguous bytes per row and wave (the 64 x 64 tiling
 // above writes 64-byte pieces, which this chip's store path moves at a fraction of the rate, and reads B once per row tile).
 // B fragments go global -> registers one k tile ahead; the A rows of a k tile are split once per workgroup into LDS planes
-// (double buffered, one barrier per k tile).  176 + 96 + ... VGPRs: one wave per SIMD, which is all the LDS allows anyway.
+// (one buffer, two barriers per k tile: with two column blocks per wave two or three workgroups share a CU and fill each
+// other's barrier, prologue and store-tail gaps; four blocks per wave = one wave per SIMD measured slower than the 64 x 64
+// tiling: 0.56 vs 0.52 ms for the four Bach10 launches).
 // ------------------------------------------------------------------------------------------------
-template <int RBT /* row blocks of 16 */>
-__global__ __launch_bounds__(kThreads) void gemm_bf16x3_skinny_kernel(const DcsGemm g) {
+template <int RBT /* row blocks of 16 */, int CB /* 16-column blocks per wave */>
+__global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_kernel(const DcsGemm g0, const DcsGemmBranches br) {
+    // blockIdx.y = branch: the same A against another (B planes, bias, C) triple -- one launch for all sources
+    DcsGemm g = g0;
+    if (br.n > 0) {
+        g.Bq = br.Bq[blockIdx.y];
+        g.bias = br.bias[blockIdx.y];
+        g.C = br.C[blockIdx.y];
+    }
     constexpr int ROWS = RBT * 16;
-    constexpr int kPlane = ROWS * kRowU4, kBuf = 3 * kPlane;
-    extern __shared__ u32x4 As[];                         // [2][3 planes][ROWS][kRowU4]
+    constexpr int kPlane = ROWS * kRowU4;
+    constexpr int CW = CB * 16;                            // columns per wave
+    extern __shared__ u32x4 As[];                         // [3 planes][ROWS][kRowU4]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
     const int n_cols = g.n_cols, gK = g.K;
     const int nkt = (gK + 31) / 32;
     const float gscale = g.a_scale;
-    const int n0 = blockIdx.x * 256 + wave * 64;          // this wave's 64 columns
+    const int n0 = (blockIdx.x * 4 + wave) * CW;          // this wave's columns
     const bool live = n0 < n_cols;                        // n_cols is a multiple of 64
     // A staging: piece idx = (row, kg): 8 consecutive k of one row
     constexpr int A_PER = (ROWS * 4 + kThreads - 1) / kThreads;
@@ -223,11 +233,11 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_skinny_kernel(const DcsG
         a_k0[u] = q * 8;
         a_dst[u] = idx < ROWS * 4 ? row * kRowU4 + q : -1;
     }
-    // B: piece (kt, plane, column, kg); the column of MFMA row fi in block cb
+    // B: piece (kt, plane, column, kg); MFMA row fi of block cb is column n0 + 4 CB (fi / 4) + 4 cb + fi % 4
     const int64_t b_plane = (int64_t)n_cols * 4, b_kt = 3 * b_plane;
-    const u32x4* Bl = reinterpret_cast<const u32x4*>(g.Bq) + ((int64_t)((live ? n0 : 0) + (fi >> 2) * 16 + (fi & 3))) * 4 + kq;
+    const u32x4* Bl = reinterpret_cast<const u32x4*>(g.Bq) + ((int64_t)((live ? n0 : 0) + (fi >> 2) * (4 * CB) + (fi & 3))) * 4 + kq;
     f32x4 ra[A_PER][2];
-    u32x4 bn[4][3], bc[4][3];
+    u32x4 bn[CB][3], bc[CB][3];
 #define DCS_LOAD_A(kt_)                                                                                 \
     _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                                 \
         const int k = (kt_) * 32 + a_k0[u];                                                             \
@@ -236,40 +246,39 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_skinny_kernel(const DcsG
         ra[u][1] = (a_ok[u] && k + 4 < gK) ? *reinterpret_cast<const f32x4*>(a_ptr[u] + (kt_) * 32 + 4) : z; \
     }
 #define DCS_LOAD_B(kt_)                                                                                 \
-    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                    \
+    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                   \
         _Pragma("unroll") for (int p = 0; p < 3; ++p) bn[cb][p] = Bl[(kt_) * b_kt + p * b_plane + cb * 16];
-#define DCS_STORE_A(buf_)                                                                               \
-    _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                                 \
-        if (a_dst[u] >= 0) {                                                                            \
-            u32x4 p0, p1, p2;                                                                           \
-            split8(ra[u][0] * gscale, ra[u][1] * gscale, p0, p1, p2);                                   \
-            u32x4* dst = As + (buf_) * kBuf + a_dst[u];                                                 \
-            dst[0] = p0; dst[kPlane] = p1; dst[2 * kPlane] = p2;                                        \
-        }                                                                                               \
-    }
-    f32x4 acc[RBT][4];
+    f32x4 acc[RBT][CB];
 #pragma unroll
     for (int r = 0; r < RBT; ++r)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[r][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < CB; ++cb) acc[r][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     DCS_LOAD_A(0)
     DCS_LOAD_B(0)
-    DCS_STORE_A(0)
-    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int u = 0; u < A_PER; ++u) {
+            if (a_dst[u] >= 0) {
+                u32x4 p0, p1, p2;
+                split8(ra[u][0] * gscale, ra[u][1] * gscale, p0, p1, p2);
+                u32x4* dst = As + a_dst[u];
+                dst[0] = p0; dst[kPlane] = p1; dst[2 * kPlane] = p2;
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int p = 0; p < 3; ++p) bc[cb][p] = bn[cb][p];
+        __syncthreads();
         const int ktn = kt + 1 < nkt ? kt + 1 : kt;       // last tile: a harmless re-read
         DCS_LOAD_A(ktn)
         DCS_LOAD_B(ktn)
-        const u32x4* Ab = As + (kt & 1) * kBuf + fi * kRowU4 + kq;
+        const u32x4* Ab = As + fi * kRowU4 + kq;
 #pragma unroll
         for (int r = 0; r < RBT; ++r) {
             const u32x4 a0 = Ab[r * 16 * kRowU4], a1 = Ab[kPlane + r * 16 * kRowU4], a2 = Ab[2 * kPlane + r * 16 * kRowU4];
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
+            for (int cb = 0; cb < CB; ++cb) {
                 f32x4 c = acc[r][cb];
                 c = mma(bc[cb][2], a0, c);                // smallest products first
                 c = mma(bc[cb][0], a2, c);
@@ -280,18 +289,16 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_skinny_kernel(const DcsG
                 acc[r][cb] = c;
             }
         }
-        if (kt + 1 < nkt) DCS_STORE_A((kt + 1) & 1)
-        __syncthreads();
+        __syncthreads();                                  // every wave has read this k tile's planes
     }
 #undef DCS_LOAD_A
 #undef DCS_LOAD_B
-#undef DCS_STORE_A
     if (!live) return;
-    // lane (row fi of block r, kq): columns n0 + 16 kq + 4 cb + e
-    const int c0 = n0 + kq * 16;
-    f32x4 bias[4];
+    // lane (row fi of block r, kq): columns n0 + 4 CB kq + 4 cb + e
+    const int c0 = n0 + kq * (4 * CB);
+    f32x4 bias[CB];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias[cb][e] = (g.bias && c0 + cb * 4 + e < g.n_store) ? g.bias[c0 + cb * 4 + e] : 0.f;
 #pragma unroll
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_skinny_kernel(const DcsG
         if (row < g.M) {
             float* cp = g.C + ((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + c0;
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
+            for (int cb = 0; cb < CB; ++cb) {
                 f32x4 v = acc[r][cb] + bias[cb];
                 if (g.relu) {
 #pragma unroll
@@ -340,18 +347,7 @@ bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
     // A-streaming GEMMs of the encoder are bound by memory latency, not by the matrix pipe -- measured at 4096 tiles
     // conv1 0.041 -> 0.047 ms, fc 0.020 -> 0.021, while fc1x 0.042 -> 0.036; Bach10 fc1x (167 x 256 x 666 600) 0.72 -> 0.58
     if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu || g.n_cols < 1024 || g.M < 128) return false;
-    static const bool skinny_on = !(getenv("DCS_GEMM_SKINNY") && atoi(getenv("DCS_GEMM_SKINNY")) == 0);
-    // 16-byte stores need C rows and the column offset on 16-byte boundaries
-    if (skinny_on && g.M <= 176 && g.n_cols >= 8192 && (g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0) {
-        const int rbt = g.M <= 128 ? 8 : 11;
-        const size_t lds = (size_t)2 * 3 * rbt * 16 * kRowU4 * 16;
-        auto kern = rbt == 8 ? gemm_bf16x3_skinny_kernel<8> : gemm_bf16x3_skinny_kernel<11>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
-            hipSuccess) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(g.n_cols, 256)), dim3(kThreads), lds, ctx->stream, g);
-            return true;
-        }
-    }
+    if (dcs_launch_gemm_bf16x3_skinny(ctx, g, nullptr)) return true;
     static const int xcd_map = !(getenv("DCS_GEMM_XCD") && atoi(getenv("DCS_GEMM_XCD")) == 0);
     if (groups16 * col_groups <= 16 * (int64_t)ctx->n_cu)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2>), dim3((unsigned)dcs_cdiv(g.M, 32), (unsigned)col_groups), dim3(kThreads), 0,
@@ -359,5 +355,32 @@ bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
     else
         hipLaunchKernelGGL((gemm_bf16x3_kernel<4>), dim3((unsigned)dcs_cdiv(g.M, 64), (unsigned)col_groups), dim3(kThreads), 0,
                            ctx->stream, g, xcd_map);
+    return true;
+}
+
+// All rows in one workgroup (gemm_bf16x3_skinny_kernel): 128 <= M <= 176 rows against very wide B planes.  `br` (optional):
+// up to 4 (B planes, bias, C) triples that share g's A and shape -- one launch, blockIdx.y = branch.
+bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemmBranches* br) {
+    static const bool on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0) &&
+                           !(getenv("DCS_GEMM_SKINNY") && atoi(getenv("DCS_GEMM_SKINNY")) == 0);
+    DcsGemmBranches b{};
+    if (br) b = *br;
+    const void* bq0 = b.n > 0 ? b.Bq[0] : g.Bq;
+    if (!on || !bq0 || !g.a_vec || g.partial || (g.K & 3) || (g.lda & 3)) return false;
+    if (g.M < 128 || g.M > 176 || g.n_cols < 8192 || (g.ldc & 3)) return false;
+    // 16-byte stores need C rows and the column offset on 16-byte boundaries
+    for (int i = 0; i < (b.n > 0 ? b.n : 1); ++i)
+        if (((uintptr_t)(b.n > 0 ? b.C[i] : g.C) & 15) || (b.n > 0 && !b.Bq[i])) return false;
+    const int rbt = g.M <= 128 ? 8 : 11;
+    static const int cb_env = getenv("DCS_GEMM_SKINNY_CB") ? atoi(getenv("DCS_GEMM_SKINNY_CB")) : 2;
+    const int cb = cb_env == 4 ? 4 : 2;
+    const size_t lds = (size_t)3 * rbt * 16 * kRowU4 * 16;
+    auto kern = rbt == 8 ? (cb == 4 ? gemm_bf16x3_skinny_kernel<8, 4> : gemm_bf16x3_skinny_kernel<8, 2>)
+                         : (cb == 4 ? gemm_bf16x3_skinny_kernel<11, 4> : gemm_bf16x3_skinny_kernel<11, 2>);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+    hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(g.n_cols, 64 * cb), (unsigned)(b.n > 0 ? b.n : 1)), dim3(kThreads), lds,
+                       ctx->stream, g, b);
     return true;
 }

@@ -1502,7 +1502,24 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     }
     // per-source dense (rectify): D[n][branch][flat_p]; aliased branches (none in these graphs) would reuse a layer
     if (g->flat_p != d.flat) DCS_HIP(hipMemsetAsync(D, 0, (size_t)n * NB * g->flat_p * 4, ctx->stream));
-    for (int b = 0; b < NB; ++b) {
+    bool branches_done = false;
+    if (NB > 1) {                                        // every live branch in one launch when the shape allows it
+        DcsGemm q{};
+        q.A = Z; q.lda = g->hid64; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
+        q.ldb = g->flat64; q.ldc = (int64_t)NB * g->flat_p; q.c_gdiv = 1 << 30; q.c_gmul = 0;
+        q.M = n; q.n_cols = g->flat64; q.n_store = d.flat; q.K = g->hid64; q.relu = 1; q.a_vec = 1;
+        DcsGemmBranches br{};
+        br.n = NB;
+        for (int b = 0; b < NB; ++b) {
+            const int s = d.branch_fc[b];
+            br.Bq[b] = g->Bdq[s]; br.bias[b] = g->biasd[s]; br.C[b] = D + (int64_t)b * g->flat_p;
+        }
+        q.B = g->Bd[d.branch_fc[0]]; q.bias = br.bias[0]; q.Bq = br.Bq[0]; q.C = br.C[0];
+        DcsTimer tm(ctx, DCS_TAG_FC1X);
+        branches_done = dcs_launch_gemm_bf16x3_skinny(ctx, q, &br);
+        if (branches_done) tm.done(); else tm.cancel();
+    }
+    for (int b = 0; b < NB && !branches_done; ++b) {
         const int s = d.branch_fc[b];
         DcsGemm q{};
         q.A = Z; q.lda = g->hid64; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
