@@ -1,6 +1,8 @@
 // Generic build_ca path (strided conv1, optional max-pool, 2-D conv2, large dense layers):
 // iKala, Bach10 and score-informed graphs.  Implemented in generic.hip.
 #pragma once
+#include <stdint.h>
+
 #include <vector>
 
 #include "dcs_internal.h"
@@ -22,6 +24,21 @@ struct DcsColConv {
     int xb_per_wg;              // column blocks (16 x each) a workgroup walks
     int n_xb;                   // column blocks per image
 };
+// slab convolution (general kh x kw): see slabconv_kernel in generic.hip for the operation
+struct DcsSlabConv {
+    const float* in; int64_t in_n_stride; int Cin, H, W;
+    const float* Wk;            // [kh][kw][32][32] (ci, co swizzled: colconv_wslot(0, ci, co) within a tap)
+    const float* bias;          // [32]
+    float* out; int64_t out_n_stride; int Cout, Ho, Wo;
+    int kh, kw, ph, pw;
+    int band, n_bands;          // output rows per workgroup, workgroups per image
+    int rows_max;               // band + kh - 1 (slab rows allocated)
+    int tstage;                 // taps (along v) staged per step
+    int pstage;                 // tap pairs staged per step (slabconv_ps.hip)
+};
+// pre-split slab variant (slabconv_ps.hip): false = shape not covered, nothing launched
+void dcs_slabconv_ps_pack(const float* Wf, int kh, int kw, int (*wslot)(int, int), int mode, std::vector<uint16_t>* out);
+bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const void* Wq, int mode);
 // weights-in-registers f16 variant (colconv_wreg.hip): false = shape not covered, nothing launched
 void dcs_colconv_wreg_pack(const _Float16* Wh, int kh, std::vector<_Float16>* out);
 bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq);

@@ -549,16 +549,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f16_kernel(const IgemmArg
 // whose shifted columns all do, are skipped -- the implicit GEMM multiplies all of them (63 % of its K loop for the
 // iKala transpose) and re-gathers every operand from L2.
 // ------------------------------------------------------------------------------------------------
-struct SlabConvArgs {
-    const float* in; int64_t in_n_stride; int Cin, H, W;
-    const float* Wk;            // [kh][kw][32][32] (ci, co swizzled: colconv_wslot(0, ci, co) within a tap)
-    const float* bias;          // [32]
-    float* out; int64_t out_n_stride; int Cout, Ho, Wo;
-    int kh, kw, ph, pw;
-    int band, n_bands;          // output rows per workgroup, workgroups per image
-    int rows_max;               // band + kh - 1 (slab rows allocated)
-    int tstage;                 // taps (along v) staged per step
-};
+typedef DcsSlabConv SlabConvArgs;
 
 __global__ __launch_bounds__(kColThreads) void slabconv_kernel(const SlabConvArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1102,6 +1093,7 @@ struct DcsGenericNet {
     float *Wslab = nullptr, *Wslab_t = nullptr;   // [kh][kw][32][32] conv2 / its transpose for slabconv_kernel
     // the same for slabconv_mx_kernel: [tap][plane][32 co][4 pieces of 8 ci]; q3 = three bf16 planes, h = one f16 plane
     uint16_t *Wslab_q3 = nullptr, *Wslab_t_q3 = nullptr, *Wslab_h = nullptr, *Wslab_t_h = nullptr;
+    uint16_t *Wps_q3 = nullptr, *Wps_t_q3 = nullptr, *Wps_h = nullptr, *Wps_t_h = nullptr;   // slabconv_ps.hip orders
     int use_slabconv = 0;
     float* W1p = nullptr;      // conv1 filters padded to sw1*ceil(kw1/sw1) taps (register-blocked transpose of conv1)
     float *Wcol = nullptr, *Wcol_t = nullptr;
@@ -1240,6 +1232,14 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         pack(Wslab, Wslab_q3, Wslab_h);
         pack(Wslab_t, Wslab_t_q3, Wslab_t_h);
     }
+    std::vector<uint16_t> Wps_q3, Wps_t_q3, Wps_h, Wps_t_h;
+    if (g->use_slabconv) {
+        auto slot = +[](int ci, int co) { return colconv_wslot(0, ci, co); };
+        dcs_slabconv_ps_pack(Wslab.data(), kh, kw, slot, 0, &Wps_q3);
+        dcs_slabconv_ps_pack(Wslab.data(), kh, kw, slot, 1, &Wps_h);
+        dcs_slabconv_ps_pack(Wslab_t.data(), kh, kw, slot, 0, &Wps_t_q3);
+        dcs_slabconv_ps_pack(Wslab_t.data(), kh, kw, slot, 1, &Wps_t_h);
+    }
     // column convolution (kw == 1): Wcol[u][ci][co] = W2[co][ci][kh-1-u] (true convolution), transpose
     // Wcol_t[u][co][ci] = W2[co][ci][u]
     std::vector<float> Wcol, Wcol_t;
@@ -1274,7 +1274,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
     if (!W1p.empty()) { UP(g->W1p, W1p) }
-    if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) UP(g->Wslab_q3, Wslab_q3) UP(g->Wslab_t_q3, Wslab_t_q3) UP(g->Wslab_h, Wslab_h) UP(g->Wslab_t_h, Wslab_t_h) }
+    if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) UP(g->Wslab_q3, Wslab_q3) UP(g->Wslab_t_q3, Wslab_t_q3) UP(g->Wslab_h, Wslab_h) UP(g->Wslab_t_h, Wslab_t_h) UP(g->Wps_q3, Wps_q3) UP(g->Wps_t_q3, Wps_t_q3) UP(g->Wps_h, Wps_h) UP(g->Wps_t_h, Wps_t_h) }
     if (g->use_colconv) {
         std::vector<_Float16> Wcol_r, Wcol_t_r;
         dcs_colconv_wreg_pack(Wcol_h.data(), kh, &Wcol_r);
@@ -1314,7 +1314,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
     for (void* p : ptrs)
@@ -1328,7 +1328,9 @@ namespace {
 // false: the shape does not fit (LDS); the caller falls back to the implicit GEMM.
 // Wq: weights packed for the 16-bit matrix pipe (mode 0: three bf16 planes, f32-class results -- the default; mode 1: one
 // f16 plane); null: the f32-MFMA kernel (DCS_SLABCONV_MX=0).
-bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images, const uint16_t* Wq = nullptr, int mode = 0) {
+bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images, const uint16_t* Wq = nullptr, int mode = 0,
+                     const uint16_t* Wps = nullptr) {
+    if (Wq && Wps && dcs_launch_slabconv_ps(ctx, a, n_images, Wps, mode)) return true;
     const int nxb = (a.Wo + 15) / 16;
     const int np = mode == 0 ? 3 : 1;
     a.tstage = Wq ? (a.kw < 2 ? a.kw : 2) : (a.kw < 4 ? a.kw : 4);
@@ -1484,7 +1486,8 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                 c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
                 c.Wk = g->Wslab; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride;
                 c.Cout = a.Cout; c.Ho = a.Ho; c.Wo = a.Wo; c.kh = d.kh2; c.kw = d.kw2; c.ph = 0; c.pw = 0;
-                done = launch_slabconv(ctx, c, n, kSlabMx ? (g->conv_f16 ? g->Wslab_h : g->Wslab_q3) : nullptr, g->conv_f16 ? 1 : 0);
+                done = launch_slabconv(ctx, c, n, kSlabMx ? (g->conv_f16 ? g->Wslab_h : g->Wslab_q3) : nullptr, g->conv_f16 ? 1 : 0,
+                                       g->conv_f16 ? g->Wps_h : g->Wps_q3);
             }
             if (!done)
                 hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);
@@ -1564,7 +1567,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                 c.Wk = g->Wslab_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride;
                 c.Cout = a.Cout; c.Ho = a.Ho; c.Wo = a.Wo; c.kh = d.kh2; c.kw = d.kw2; c.ph = d.kh2 - 1; c.pw = d.kw2 - 1;
                 done = launch_slabconv(ctx, c, n * NB, kSlabMx ? (g->conv_f16 ? g->Wslab_t_h : g->Wslab_t_q3) : nullptr,
-                                       g->conv_f16 ? 1 : 0);
+                                       g->conv_f16 ? 1 : 0, g->conv_f16 ? g->Wps_t_h : g->Wps_t_q3);
             }
             if (!done)
                 hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a);

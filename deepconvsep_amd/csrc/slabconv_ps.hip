@@ -1,0 +1,294 @@
+// conv2 of the iKala graph (10 x 20 filters, 30 -> 30 channels, separate_ikala.py:181-183) and its InverseLayer on the
+// 16-bit matrix pipe with the SLAB ALREADY SPLIT in LDS.
+//
+//   out[co][y][x] = bias[co] + sum_{u,v,ci} W[u][v][co][ci] * in[ci][y + u - ph][x + v - pw]      (zero outside the input)
+//
+// slabconv_mx_kernel (generic.hip) keeps the input slab in LDS as f32 and splits a lane's eight channels into three bf16
+// terms every time a tap reads them: ~50 VALU instructions beside 12 MFMAs, 200 times per slab element, and the f32 slab
+// (144 bytes per position) leaves conv2 one output row per workgroup -- 4 of 16 waves busy.  Here
+//   * the slab holds 16 channels at a time as bf16 planes, record (row, x) = [plane][16 ci] + 16 bytes of padding
+//     (112 bytes: 16 consecutive x land on 16 different bank quads), written once per element when the slab is filled;
+//     the kernel makes two passes (channels 0-15, 16-31) over the same accumulators;
+//   * one MFMA K block (32) = TWO taps (v, v + 1) x 16 channels: lane (x = fi, kg) reads the 16 bytes of channels
+//     8 (kg & 1) .. + 7 of column x + v + (kg >> 1) -- a plain ds_read_b128 per plane, no VALU on the operand;
+//   * weights are packed on the host in the same k order, [half][u][tap pair][plane][32 co][4 kg] pieces, and streamed
+//     through a double-buffered LDS stage by the workgroup exactly as before.
+// A (tap pair, 16 x 16 block) step is 12 MFMAs (bf16 x 3: six products x two channel halves of the output) against
+// three operand reads + six weight reads shared by the wave's blocks.  MODE 1 (f16 switch): one plane, 2 MFMAs.
+#include <string.h>
+
+#include "dcs_internal.h"
+#include "generic.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWRow = 5;                     // 16-byte pieces per (plane, co) weight row in LDS: 4 + 1 pad
+
+__device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+template <int MODE>
+__device__ __forceinline__ void convert8(const float (&x)[8], u32x4 (&out)[MODE == 0 ? 3 : 1]) {
+    if constexpr (MODE == 0) {
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h[j] = bf_trunc(x[j]);
+            const float r1 = x[j] - __uint_as_float(h[j]);
+            m[j] = bf_trunc(r1);
+            l[j] = bf_trunc(r1 - __uint_as_float(m[j]));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            out[0][q] = (h[2 * q] >> 16) | h[2 * q + 1];
+            out[1][q] = (m[2 * q] >> 16) | m[2 * q + 1];
+            out[2][q] = (l[2 * q] >> 16) | l[2 * q + 1];
+        }
+    } else {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)x[j];
+        out[0] = __builtin_bit_cast(u32x4, v);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (MODE == 0)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int MODE, int NW /* waves per workgroup */>
+__global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv g, const u32x4* __restrict__ Wq) {
+    constexpr int NP = MODE == 0 ? 3 : 1;
+    constexpr int RP = NP * 2 + 1;                        // 16-byte pieces per slab record
+    constexpr int NTH = 64 * NW, NBW = 32 / NW;           // threads; blocks per wave
+    constexpr int kStage = NP * 32 * kWRow;               // LDS pieces per tap pair
+    constexpr int kStageGlb = NP * 128;                   // packed pieces per tap pair
+    extern __shared__ u32x4 smem[];
+    u32x4* Wl = smem;                                     // [2][pairs_per_stage][NP][32][5]
+    const int wstage = g.pstage * kStage;
+    u32x4* slab = smem + 2 * wstage;                      // [rows_max][W][RP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t img = blockIdx.x / g.n_bands;
+    const int y0 = (int)(blockIdx.x - img * g.n_bands) * g.band;
+    const int yb = y0 + g.band < g.Ho ? y0 + g.band : g.Ho;   // output rows [y0, yb)
+    const float* in = g.in + img * g.in_n_stride;
+    float* out = g.out + img * g.out_n_stride;
+    int rbase = y0 - g.ph, rtop = yb - 1 - g.ph + g.kh - 1;
+    if (rbase < 0) rbase = 0;
+    if (rtop > g.H - 1) rtop = g.H - 1;
+    const int rows = rtop - rbase + 1;
+    const int HW = g.H * g.W;
+    const int nxb = (g.Wo + 15) >> 4, nblk = (yb - y0) * nxb;
+    int by[NBW], bx[NBW];
+    f32x4 acc0[NBW], acc1[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int b = wave + NW * i;
+        by[i] = b < nblk ? y0 + b / nxb : -1;
+        bx[i] = b < nblk ? (b % nxb) * 16 : 0;
+        acc0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nvp = (g.kw + 1) >> 1;                      // tap pairs per filter row
+    const int nvs = (nvp + g.pstage - 1) / g.pstage;      // stages per filter row
+    int u_lo = g.ph - (yb - 1), u_hi = g.ph - y0 + g.H - 1;
+    if (u_lo < 0) u_lo = 0;
+    if (u_hi > g.kh - 1) u_hi = g.kh - 1;
+    const int n_stage = (u_hi - u_lo + 1) * nvs;
+    constexpr int WPRE = (2 * kStageGlb + NTH - 1) / NTH;  // pstage <= 2
+    u32x4 wpre[WPRE];
+    for (int hc = 0; hc < 2; ++hc) {
+        __syncthreads();                                  // every wave is done with the previous half's slab and weights
+        // slab fill: task = (row, x, channel octet); consecutive threads take consecutive x of one (octet, row)
+        const int n_task = 2 * rows * g.W;
+        for (int i = tid; i < n_task; i += NTH) {
+            const int o = i / (rows * g.W), rem = i - o * (rows * g.W);
+            const int r = rem / g.W, x = rem - r * g.W;
+            const int c0 = 16 * hc + 8 * o;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c0 + j < g.Cin ? in[(int64_t)(c0 + j) * HW + (rbase + r) * g.W + x] : 0.f;
+            u32x4 p[NP];
+            convert8<MODE>(v, p);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) slab[rem * RP + q * 2 + o] = p[q];
+        }
+        const u32x4* Wh = Wq + (int64_t)hc * g.kh * nvp * kStageGlb;
+#define DCS_PS_WFETCH(st_)                                                                              \
+        {                                                                                               \
+            const int u_ = u_lo + (st_) / nvs, vp_ = ((st_) % nvs) * g.pstage;                          \
+            const int np_ = vp_ + g.pstage <= nvp ? g.pstage : nvp - vp_;                               \
+            _Pragma("unroll") for (int q = 0; q < WPRE; ++q) {                                          \
+                const int e = tid + q * NTH;                                                            \
+                wpre[q] = e < np_ * kStageGlb ? Wh[(int64_t)(u_ * nvp + vp_) * kStageGlb + e] : u32x4{0u, 0u, 0u, 0u}; \
+            }                                                                                           \
+        }
+        if (n_stage > 0) DCS_PS_WFETCH(0)
+        for (int st = 0; st < n_stage; ++st) {
+            u32x4* Wb = Wl + (st & 1) * wstage;
+#pragma unroll
+            for (int q = 0; q < WPRE; ++q) {
+                const int e = tid + q * NTH;              // (pair, plane * 32 + co, kg) in the packed order
+                if (e < g.pstage * kStageGlb) Wb[(e >> 2) * kWRow + (e & 3)] = wpre[q];
+            }
+            __syncthreads();     // also orders the slab fill before its first use; buffer st & 1 was last read at st - 2
+            if (st + 1 < n_stage) DCS_PS_WFETCH(st + 1)
+            const int u = u_lo + st / nvs, vp0 = (st % nvs) * g.pstage;
+            const int np = vp0 + g.pstage <= nvp ? g.pstage : nvp - vp0;
+            for (int tp = 0; tp < np; ++tp) {
+                const int v = 2 * (vp0 + tp);
+                const u32x4* wp = Wb + tp * kStage + fi * kWRow + kq;
+                u32x4 a0[NP], a1[NP];
+                bool have = false;
+#pragma unroll
+                for (int i = 0; i < NBW; ++i) {
+                    if (by[i] < 0) continue;
+                    const int r = by[i] + u - g.ph;                  // input row (uniform per block)
+                    const int xs = bx[i] + v - g.pw;                 // column of lane 0, first tap of the pair
+                    if (r < 0 || r >= g.H || xs + 16 < 0 || xs >= g.W) continue;
+                    if (!have) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            a0[p] = wp[(p * 32) * kWRow];
+                            a1[p] = wp[(p * 32 + 16) * kWRow];
+                        }
+                        have = true;
+                    }
+                    const int xc = xs + fi + (kq >> 1);
+                    const bool ok = xc >= 0 && xc < g.W;
+                    const u32x4* sp = slab + ((r - rbase) * g.W + (ok ? xc : 0)) * RP + (kq & 1);
+                    u32x4 b[NP];
+                    if (xs >= 0 && xs + 17 <= g.W) {                 // every column of both taps inside: no select
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) b[p] = sp[p * 2];
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const u32x4 t = sp[p * 2];
+                            b[p] = ok ? t : u32x4{0u, 0u, 0u, 0u};
+                        }
+                    }
+                    if constexpr (MODE == 0) {   // smallest terms first
+                        acc0[i] = mma<0>(a0[2], b[0], acc0[i]);
+                        acc1[i] = mma<0>(a1[2], b[0], acc1[i]);
+                        acc0[i] = mma<0>(a0[0], b[2], acc0[i]);
+                        acc1[i] = mma<0>(a1[0], b[2], acc1[i]);
+                        acc0[i] = mma<0>(a0[1], b[1], acc0[i]);
+                        acc1[i] = mma<0>(a1[1], b[1], acc1[i]);
+                        acc0[i] = mma<0>(a0[1], b[0], acc0[i]);
+                        acc1[i] = mma<0>(a1[1], b[0], acc1[i]);
+                        acc0[i] = mma<0>(a0[0], b[1], acc0[i]);
+                        acc1[i] = mma<0>(a1[0], b[1], acc1[i]);
+                        acc0[i] = mma<0>(a0[0], b[0], acc0[i]);
+                        acc1[i] = mma<0>(a1[0], b[0], acc1[i]);
+                    } else {
+                        acc0[i] = mma<1>(a0[0], b[0], acc0[i]);
+                        acc1[i] = mma<1>(a1[0], b[0], acc1[i]);
+                    }
+                }
+            }
+        }
+#undef DCS_PS_WFETCH
+    }
+    const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        if (by[i] < 0 || bx[i] + fi >= g.Wo) continue;
+        float* op = out + (int64_t)by[i] * g.Wo + bx[i] + fi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = 4 * kq + e;
+            if (co < g.Cout) op[(int64_t)co * HoWo] = acc0[i][e] + g.bias[co];
+            if (co + 16 < g.Cout) op[(int64_t)(co + 16) * HoWo] = acc1[i][e] + g.bias[co + 16];
+        }
+    }
+}
+
+}  // namespace
+
+// Wf: [kh * kw taps][1024] f32 with element (ci, co) of a tap at wslot(ci, co) -> the kernel's order
+// [half hc][u][tap pair vp][plane][32 co][4 kg][8]: k slot (kg, j) = tap 2 vp + (kg >> 1), channel 16 hc + 8 (kg & 1) + j.
+// mode 0: three bf16 planes (truncation split, exact); mode 1: one f16 plane (round to nearest even).
+void dcs_slabconv_ps_pack(const float* Wf, int kh, int kw, int (*wslot)(int, int), int mode, std::vector<uint16_t>* out) {
+    const int np = mode == 0 ? 3 : 1, nvp = (kw + 1) / 2;
+    out->assign((size_t)2 * kh * nvp * np * 128 * 8, 0);
+    for (int hc = 0; hc < 2; ++hc)
+        for (int u = 0; u < kh; ++u)
+            for (int vp = 0; vp < nvp; ++vp)
+                for (int co = 0; co < 32; ++co)
+                    for (int kg = 0; kg < 4; ++kg)
+                        for (int j = 0; j < 8; ++j) {
+                            const int v = 2 * vp + (kg >> 1), ci = 16 * hc + 8 * (kg & 1) + j;
+                            float r = v < kw ? Wf[(size_t)(u * kw + v) * 1024 + wslot(ci, co)] : 0.f;
+                            const size_t base = ((((size_t)hc * kh + u) * nvp + vp) * np) * 128 * 8;
+                            const size_t idx = ((size_t)co * 4 + kg) * 8 + j;
+                            if (mode == 0) {
+                                for (int p = 0; p < 3; ++p) {
+                                    uint32_t bits;
+                                    memcpy(&bits, &r, 4);
+                                    bits &= 0xffff0000u;
+                                    float part;
+                                    memcpy(&part, &bits, 4);
+                                    r -= part;
+                                    (*out)[base + (size_t)p * 128 * 8 + idx] = (uint16_t)(bits >> 16);
+                                }
+                            } else {
+                                const _Float16 hv = (_Float16)r;
+                                uint16_t hb;
+                                memcpy(&hb, &hv, 2);
+                                (*out)[base + idx] = hb;
+                            }
+                        }
+}
+
+// false: the shape does not fit; nothing launched
+bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const void* Wq, int mode) {
+    static const bool on = !(getenv("DCS_SLABCONV_PS") && atoi(getenv("DCS_SLABCONV_PS")) == 0);
+    if (!on || !Wq || a.Cin > 32 || a.Cout > 32) return false;
+    const int np = mode == 0 ? 3 : 1;
+    const int nxb = (a.Wo + 15) / 16;
+    const size_t rec = (size_t)(np * 2 + 1) * 16;
+    const size_t row_bytes = (size_t)a.W * rec;
+    // rows per workgroup: a workgroup has 16 waves x 2 block slots and streams all the weights whatever its band, so the
+    // best band is the one that wastes the fewest (wave, slot) pairs -- counting the short last band and the CUs left
+    // without a workgroup -- among those whose slab fits; ties go to the taller band.  (iKala conv2, 21 x 64 outputs:
+    // bands of 4 rows = 16 blocks, one per wave, instead of 5 rows = 20 blocks on 16 waves.)
+    int band = 0;
+    size_t lds = 0;
+    double best = 0.0;
+    for (int cand = 1; cand <= a.Ho && cand * nxb <= 32; ++cand) {
+        int ps = 2;
+        size_t need = (size_t)2 * ps * np * 32 * kWRow * 16 + row_bytes * (size_t)(cand + a.kh - 1);
+        if (need > 160 * 1024) {
+            ps = 1;
+            need = (size_t)2 * ps * np * 32 * kWRow * 16 + row_bytes * (size_t)(cand + a.kh - 1);
+            if (need > 160 * 1024) break;
+        }
+        const int64_t n_wg = n_images * ((a.Ho + cand - 1) / cand);
+        const int rounds = (cand * nxb + 15) / 16;          // block slots used per wave
+        double eff = (double)n_images * a.Ho * nxb / ((double)n_wg * 16 * rounds);
+        if (n_wg < ctx->n_cu) eff *= (double)n_wg / ctx->n_cu;
+        if (eff >= best) { best = eff; band = cand; lds = need; a.pstage = ps; }
+    }
+    if (band < 1 || band * nxb < 8) return false;          // fewer than 8 blocks: the f32-slab kernel is no worse
+    a.band = band;
+    a.n_bands = (a.Ho + band - 1) / band;
+    a.rows_max = band + a.kh - 1;
+    auto kern = mode == 0 ? slabconv_ps_kernel<0, 16> : slabconv_ps_kernel<1, 16>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * a.n_bands)), dim3(1024), lds, ctx->stream, a,
+                       reinterpret_cast<const u32x4*>(Wq));
+    return true;
+}
