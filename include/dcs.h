@@ -122,8 +122,11 @@ int dcs_model_create(dcs_ctx* ctx, int arch, int in_channels, int time_context, 
 int dcs_model_destroy(dcs_model* m);
 int dcs_model_num_sources(const dcs_model* m);
 /* f16 = 1: conv2 and its transpose of the ikala / bach10 / score-informed graphs run with f16 inputs and
- * f32 accumulation on the matrix cores (BASELINE config 3, "fp16 MFMA conv path"); 0 (default): f32.  Graphs whose
- * conv2 filter is wider than one column (ikala, 10 x 20) keep their f32 kernel, which is the faster one there. */
+ * f32 accumulation on the matrix cores (BASELINE config 3, "fp16 MFMA conv path"); 0 (default): f32-class arithmetic
+ * everywhere (f32 MFMA, or the bf16 pipe with operands split exactly into three bf16 terms).  With the switch on, the
+ * single-channel bach10 graph runs both InverseLayers in one kernel (colconv_wreg.hip): conv2^T in f16, conv1^T on the
+ * bf16 pipe with three-way split operands (f32-class), the activations between them never rounded below f32.  The ikala
+ * graph (10 x 20 filters) takes the same slab kernel in either precision (one f16 plane instead of three bf16 planes). */
 int dcs_model_set_conv_precision(dcs_model* m, int f16);
 
 /* predict_function2 (separate_dsd.py:273,298): tiles_d [n, C, tc, F] -> out_d [S, n, tc, F]
