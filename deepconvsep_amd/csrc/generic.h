@@ -14,6 +14,12 @@ struct DcsGenericDims {
 
 struct DcsGenericNet;
 
+// expandMidi's note table on the host (see dcs_score_masks): the score-informed front-end of the whole-path entry
+struct DcsScoreNotes {
+    const double* notes_h;
+    int ninst, n_notes, width;
+};
+
 // column convolution (kh x 1): see colconv_kernel in generic.hip for the operation
 struct DcsColConv {
     const float* in; int64_t in_n_stride; int Cin, H, W;
@@ -58,4 +64,5 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
 // stacked into one batch for the network; pcm [n_clips][S][L].  The spectra outputs are single-clip only.
 int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm, float* sep_out, float* mag_out, float* phase_out,
-                         int64_t ld_out, DcsBuffer* ws, int64_t n_clips = 1, int64_t audio_stride = 0);
+                         int64_t ld_out, DcsBuffer* ws, int64_t n_clips = 1, int64_t audio_stride = 0,
+                         const DcsScoreNotes* notes = nullptr);

@@ -1062,6 +1062,54 @@ __global__ __launch_bounds__(kThreads) void mask_kernel(const float* __restrict_
     for (int s = 0; s < S; ++s) out[((int64_t)s * n + k) * plane + r] = (p[s] / den) * mix;
 }
 
+// ------------------------------------------------------------------------------------------------
+// mask_kernel + overlap_add_kernel (tiling.hip) in one pass for the whole-path entry point: the masked tiles
+// [S][n][tc][F] (164 MB per 10 s of Bach10, written once and read once) never exist.  Output frame t is owned by the last
+// tile k0 whose copy region contains it and blended with the later tiles that reach it, in increasing k -- the operands
+// and the order of overlap_add_kernel -- and every tile value is computed where it is consumed with the expressions of
+// mask_kernel: the result is bit-identical to the two kernels.  Each (tile, frame, bin) of o is read exactly once.
+// o: [n_all][CH][tc][F] raw decoder output, x: the tiles [n_all][C][tc][F]; this clip's tiles start at k_off.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void mask_ola_kernel(const float* __restrict__ o, const float* __restrict__ bias,
+                                                            const float* __restrict__ x, int64_t n, int64_t k_off, int CH,
+                                                            int S, int C, int tc, int ov, int F,
+                                                            const float* __restrict__ rise, float* __restrict__ sep,
+                                                            int64_t sep_stride, int64_t ld, int mode) {
+    const int64_t t = blockIdx.x;
+    const int st = tc - ov;
+    const int64_t plane = (int64_t)tc * F;
+    int64_t k0 = (t < ov) ? 0 : (t - ov) / st;
+    if (k0 > n - 1) k0 = n - 1;
+    const int64_t j0 = (n > 0) ? t - k0 * st : tc;
+    const float eps_r = 5e-19f;
+    const int f = blockIdx.y * kThreads + threadIdx.x;   // one (frame, bin) per thread: enough waves to cover the latency
+    if (f < F) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (j0 < tc) {                                   // else: past the last tile, the zeros of util.py:313
+            for (int64_t k = k0; k < n && k * st <= t; ++k) {
+                const int j = (int)(t - k * st);
+                const int64_t r = (int64_t)j * F + f;
+                float p[4];
+                float den = 0.f;
+                for (int s = 0; s < S; ++s) {
+                    p[s] = fmaxf(o[((k_off + k) * CH + s) * plane + r] + bias[s], 0.f);
+                    if (mode == 0) p[s] += eps_r;
+                    den = (s == 0) ? p[s] : den + p[s];
+                }
+                if (mode == 1) den += eps_r;
+                const float mix = x[((k_off + k) * C) * plane + r];
+                if (k == k0) {
+                    for (int s = 0; s < S; ++s) acc[s] = (p[s] / den) * mix;
+                } else {
+                    const float down = rise[ov - 1 - j], up = rise[j];
+                    for (int s = 0; s < S; ++s) acc[s] = down * acc[s] + up * ((p[s] / den) * mix);
+                }
+            }
+        }
+        for (int s = 0; s < S; ++s) sep[s * sep_stride + t * ld + f] = acc[s];
+    }
+}
+
 template <typename T>
 int upload(T** dst, const std::vector<T>& src) {
     DCS_HIP(hipMalloc((void**)dst, src.size() * sizeof(T)));
@@ -1110,6 +1158,8 @@ struct DcsGenericNet {
     DcsBuffer ws;
     float* rise_d = nullptr;
     int rise_ov = -1;
+    const float* raw_o = nullptr;        // decoder output of the last deferred-mask pass (scratch of ws), its channel count
+    int raw_ch = 0;
 };
 
 int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int F,
@@ -1605,7 +1655,10 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         tm.done();
     }
     // concat + bias + rectify + mask.  out is [S or CH][n_total][tc][F]; this chunk starts at tile k_first.
-    {
+    if (mask_mode < 0) {                                 // deferred to mask_ola_kernel (single chunk): o stays in scratch
+        g->raw_o = o;
+        g->raw_ch = NB * C;
+    } else {
         const int64_t plane = (int64_t)tc * F;
         const int CH = NB * C;
         DcsTimer tm(ctx, DCS_TAG_MASK);
@@ -1658,6 +1711,7 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
     static const int64_t chunk_env = getenv("DCS_GENERIC_CHUNK") ? atoll(getenv("DCS_GENERIC_CHUNK")) : 0;
     int64_t chunk = chunk_env > 0 ? chunk_env : (int64_t)(((size_t)4 << 30) / (chunk_bytes(g, 64) / 64 + 1));
     if (chunk < 64 && chunk_env <= 0) chunk = 64;
+    if (mask_mode < 0 && n > chunk) return DCS_EUNSUPPORTED;   // deferred mask: one chunk only (quiet: the caller falls back)
     const int64_t per = n < chunk ? n : chunk;
     DCS_CHECK(g->ws.ensure(chunk_bytes(g, per)));
     const int64_t tile_elems = (int64_t)g->C * g->tc * g->F;
@@ -1670,7 +1724,7 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
 
 int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm, float* sep_out, float* mag_out, float* phase_out,
-                         int64_t ld_out, DcsBuffer* ws, int64_t n_clips, int64_t audio_stride) {
+                         int64_t ld_out, DcsBuffer* ws, int64_t n_clips, int64_t audio_stride, const DcsScoreNotes* notes) {
     // The un-fused composition of the public operators: STFT -> tiles -> network -> cross-fade -> iSTFT.  Equal-length
     // clips share the launches: one STFT / iSTFT launch over all clips and ONE pass of all their tiles through the
     // network (the dense layers' weights -- 853 MB for Bach10 -- are then read once for the whole group).
@@ -1682,9 +1736,12 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
     const int64_t rows = n * st + tc;  // rows of the stitched spectrogram (>= T)
     const int64_t n_all = n * n_clips;
     const size_t b_mag = align256((size_t)n_clips * T * ld * 4), b_unit = 2 * b_mag, b_ph = phase_out ? b_mag : 0;
-    const size_t b_tiles = align256((size_t)n_all * tc * F * 4), b_out = align256((size_t)S * n_all * tc * F * 4);
+    const size_t b_tiles = align256((size_t)n_all * g->C * tc * F * 4), b_out = align256((size_t)S * n_all * tc * F * 4);
     const size_t b_sep = align256((size_t)n_clips * S * rows * ld * 4);
-    DCS_CHECK(ws->ensure(b_mag + b_unit + b_ph + b_tiles + b_out + b_sep));
+    const size_t b_inp = notes ? align256((size_t)g->C * T * F * 4) : 0;   // score-informed network input [C][T][F]
+    if (notes && (n_clips != 1 || notes->ninst != g->C))
+        DCS_FAIL(DCS_EINVAL, "score-informed path: one clip, %d score channels (got %d)", g->C, notes->ninst);
+    DCS_CHECK(ws->ensure(b_mag + b_unit + b_ph + b_tiles + b_out + b_sep + b_inp));
     char* p = (char*)ws->ptr;
     float* mag = (float*)p; p += b_mag;
     float2* unit = (float2*)p; p += b_unit;
@@ -1692,10 +1749,27 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
     float* tiles = (float*)p; p += b_tiles;
     float* outm = (float*)p; p += b_out;
     float* sep = (float*)p; p += b_sep;
+    float* inp = (float*)p; p += b_inp;
     DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio, L, audio_stride, n_clips, mag, phase, unit, ld, T, T));
-    for (int64_t c = 0; c < n_clips; ++c)
-        DCS_CHECK(dcs_launch_tile(ctx, mag + c * T * ld, 0, ld, 1, T, F, tc, ov, tiler, scale, tiles + c * n * tc * F, n));
-    DCS_CHECK(dcs_generic_forward(g, tiles, n_all, eps_mode, tie_mode, outm));
+    if (notes) {
+        // separate_bach10.py (score-informed) :503-527: scaled magnitudes x filterSpec masks, one channel per instrument,
+        // then the C-channel tiles (the masks multiply channel 0 of a tile, as in the script)
+        DCS_CHECK(dcs_score_masks_scaled(ctx, mag, ld, T, F, notes->notes_h, notes->ninst, notes->n_notes, notes->width, 0, T,
+                                         scale, inp, nullptr));
+        DCS_CHECK(dcs_launch_tile(ctx, inp, T * (int64_t)F, F, g->C, T, F, tc, ov, tiler, 1.0f, tiles, n));
+    } else {
+        for (int64_t c = 0; c < n_clips; ++c)
+            DCS_CHECK(dcs_launch_tile(ctx, mag + c * T * ld, 0, ld, 1, T, F, tc, ov, tiler, scale, tiles + c * n * tc * F, n));
+    }
+    // mask + cross-fade in one kernel when all tiles go through the graph in one chunk (the masked tiles then never exist)
+    static const bool fuse_env = !(getenv("DCS_MASK_OLA") && atoi(getenv("DCS_MASK_OLA")) == 0);
+    bool mask_fused = false;
+    if (fuse_env && S <= 4) {
+        const int rc = dcs_generic_forward(g, tiles, n_all, -1, tie_mode, outm);
+        if (rc == DCS_OK) mask_fused = true;
+        else if (rc != DCS_EUNSUPPORTED) return rc;
+    }
+    if (!mask_fused) DCS_CHECK(dcs_generic_forward(g, tiles, n_all, eps_mode, tie_mode, outm));
     if (g->rise_ov != ov) {
         std::vector<float> r(ov > 0 ? ov : 1, 0.f);
         if (ov > 1) {
@@ -1713,9 +1787,17 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
         g->rise_ov = ov;
     }
     // outm is [S][n_all][tc][F]: clip c's tiles of source s start at (s * n_all + c * n) tiles
-    for (int64_t c = 0; c < n_clips; ++c)
-        DCS_CHECK(dcs_launch_overlap_add(ctx, outm + c * n * tc * F, n, S, tc, ov, F, g->rise_d, sep + c * S * rows * ld,
-                                         rows * ld, ld, n_all * tc * (int64_t)F));
+    if (mask_fused) {
+        DcsTimer tm(ctx, DCS_TAG_MASK);
+        for (int64_t c = 0; c < n_clips; ++c)
+            hipLaunchKernelGGL(mask_ola_kernel, dim3((unsigned)rows, (unsigned)dcs_cdiv(F, kThreads)), dim3(kThreads), 0, ctx->stream, g->raw_o, g->bout, tiles, n,
+                               c * n, g->raw_ch, S, g->C, tc, ov, F, g->rise_d, sep + c * S * rows * ld, rows * ld, ld, eps_mode);
+        tm.done();
+    } else {
+        for (int64_t c = 0; c < n_clips; ++c)
+            DCS_CHECK(dcs_launch_overlap_add(ctx, outm + c * n * tc * F, n, S, tc, ov, F, g->rise_d, sep + c * S * rows * ld,
+                                             rows * ld, ld, n_all * tc * (int64_t)F));
+    }
     // pad columns of sep (F..ld) are never written by the stitch; the iSTFT only reads bins < F
     if (pcm)
         DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, rows * ld, unit, T * ld, ld, T, S, n_clips, scale, pcm, L));

@@ -512,13 +512,19 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm_d, float* sep_out, float* mag_out, float* phase_out,
                          int64_t ld_out, int64_t* n_tiles_out, int64_t* n_frames_out, int64_t n_clips = 1,
-                         int64_t audio_stride = 0, const int64_t* lens_h = nullptr, int64_t pcm_stride = 0) {
+                         int64_t audio_stride = 0, const int64_t* lens_h = nullptr, int64_t pcm_stride = 0,
+                         const DcsScoreNotes* notes = nullptr) {
     if (!m || !plan || !audio_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: null argument");
     if (plan->ctx != m->ctx) DCS_FAIL(DCS_EINVAL, "dcs_separate: plan and model belong to different contexts");
     if (plan->frame / 2 + 1 != m->F)
         DCS_FAIL(DCS_EINVAL, "dcs_separate: frameSize %d gives %d bins, network was built for %d", plan->frame,
                  plan->frame / 2 + 1, m->F);
-    if (m->C != 1) DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate: multi-channel (score-informed) input needs the host front-end");
+    if (notes) {
+        if (!m->gen || m->C != notes->ninst || n_clips != 1 || lens_h)
+            DCS_FAIL(DCS_EINVAL, "dcs_separate_scoreinformed: the model takes %d score channels, the note table has %d", m->C,
+                     notes->ninst);
+    } else if (m->C != 1)
+        DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate: multi-channel (score-informed) input goes through dcs_separate_scoreinformed");
     if (ov < 1 || ov >= m->tc) DCS_FAIL(DCS_EINVAL, "dcs_separate: overlap %d not in [1, %d)", ov, m->tc);
     if (scale == 0.f) DCS_FAIL(DCS_EINVAL, "dcs_separate: scale_factor is zero");
     if (eps_mode != DCS_EPS_A && eps_mode != DCS_EPS_B) DCS_FAIL(DCS_EINVAL, "bad eps_mode");
@@ -622,7 +628,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         return DCS_OK;
     }
     return dcs_generic_separate(m->gen, plan, audio_d, L, ov, tiler, scale, eps_mode, tie_mode, pcm_d, sep_out, mag_out,
-                                phase_out, ld_out, &m->ws, n_clips, audio_stride);
+                                phase_out, ld_out, &m->ws, n_clips, audio_stride, notes);
 }
 
 static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,
@@ -720,6 +726,16 @@ extern "C" int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, 
                             int64_t* n_frames_out) {
     return separate_graphed(m, plan, audio_d, n_samples, 1, 0, overlap, tiler, scale, eps_mode, tie_mode, pcm_d,
                             n_tiles_out, n_frames_out);
+}
+
+extern "C" int dcs_separate_scoreinformed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples,
+                                          const double* notes_h, int ninst, int n_notes, int width, int overlap, float scale,
+                                          int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
+                                          int64_t* n_frames_out) {
+    if (!pcm_d || !notes_h) DCS_FAIL(DCS_EINVAL, "dcs_separate_scoreinformed: null argument");
+    const DcsScoreNotes notes{notes_h, ninst, n_notes, width};
+    return separate_impl(m, plan, audio_d, n_samples, overlap, DCS_TILER_LIBRARY, scale, eps_mode, tie_mode, pcm_d, nullptr,
+                         nullptr, nullptr, 0, n_tiles_out, n_frames_out, 1, 0, nullptr, 0, &notes);
 }
 
 extern "C" int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples,

@@ -18,13 +18,14 @@ struct ScoreRect {
 
 __global__ __launch_bounds__(256) void score_floor_kernel(const float* __restrict__ mag, int64_t ld, int64_t T, int F,
                                                           int ninst, const float* __restrict__ lo /* [ninst] */,
-                                                          float* __restrict__ out, float* __restrict__ mask) {
+                                                          float* __restrict__ out, float* __restrict__ mask,
+                                                          float mag_scale) {
     const int64_t t = blockIdx.x;
     const int j = blockIdx.y;
     const float v = lo[j];
     const float* mrow = mag + t * ld;
     for (int f = threadIdx.x; f < F; f += 256) {
-        if (out) out[((int64_t)j * T + t) * F + f] = v * mrow[f];
+        if (out) out[((int64_t)j * T + t) * F + f] = v * (mag_scale * mrow[f]);
         if (mask) mask[t * ((int64_t)ninst * F) + (int64_t)j * F + f] = v;
     }
 }
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(256) void score_floor_kernel(const float* __restric
 __global__ __launch_bounds__(256) void score_rect_kernel(const float* __restrict__ mag, int64_t ld, int64_t T, int F,
                                                          int ninst, const ScoreRect* __restrict__ rects,
                                                          const float* __restrict__ hi /* [ninst] */,
-                                                         float* __restrict__ out, float* __restrict__ mask) {
+                                                         float* __restrict__ out, float* __restrict__ mask,
+                                                         float mag_scale) {
     const ScoreRect r = rects[blockIdx.x];
     const float v = hi[r.inst];
     const int w = r.f1 - r.f0;
@@ -40,16 +42,17 @@ __global__ __launch_bounds__(256) void score_rect_kernel(const float* __restrict
     for (int64_t c = threadIdx.x; c < cells; c += 256) {
         const int64_t t = r.t0 + c / w;
         const int f = r.f0 + (int)(c % w);
-        if (out) out[((int64_t)r.inst * T + t) * F + f] = v * mag[t * ld + f];
+        if (out) out[((int64_t)r.inst * T + t) * F + f] = v * (mag_scale * mag[t * ld + f]);
         if (mask) mask[t * ((int64_t)ninst * F) + (int64_t)r.inst * F + f] = v;
     }
 }
 
 }  // namespace
 
-extern "C" int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F,
-                               const double* notes_h, int ninst, int n_notes, int width, int64_t start, int64_t stop,
-                               float* out_d, float* mask_d) {
+// mag_scale: the spectrogram is multiplied by it first (the scripts' scale_factor, separate_bach10.py:503; 1 = already scaled)
+int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
+                           int ninst, int n_notes, int width, int64_t start, int64_t stop, float mag_scale, float* out_d,
+                           float* mask_d) {
     if (!ctx || !mag_d || !notes_h) DCS_FAIL(DCS_EINVAL, "dcs_score_masks: null argument");
     if (!out_d && !mask_d) DCS_FAIL(DCS_EINVAL, "dcs_score_masks: nothing to write");
     if (ninst < 1 || ninst > 65535 || n_notes < 0 || width < 5 || ((width - 3) & 1) || F < 1 || ld < F || n_frames < 0)
@@ -99,14 +102,20 @@ extern "C" int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int
     DCS_HIP(hipMemcpyAsync(base + off_hi, hi.data(), b_val, hipMemcpyHostToDevice, ctx->stream));
     DcsTimer tm(ctx, DCS_TAG_SCORE);
     hipLaunchKernelGGL(score_floor_kernel, dim3((unsigned)n_frames, (unsigned)ninst), dim3(256), 0, ctx->stream, mag_d, ld,
-                       n_frames, F, ninst, (const float*)(base + off_lo), out_d, mask_d);
+                       n_frames, F, ninst, (const float*)(base + off_lo), out_d, mask_d, mag_scale);
     if (!rects.empty())
         hipLaunchKernelGGL(score_rect_kernel, dim3((unsigned)rects.size()), dim3(256), 0, ctx->stream, mag_d, ld, n_frames,
-                           F, ninst, (const ScoreRect*)base, (const float*)(base + off_hi), out_d, mask_d);
+                           F, ninst, (const ScoreRect*)base, (const float*)(base + off_hi), out_d, mask_d, mag_scale);
     tm.done();
     DCS_HIP(hipGetLastError());
     // the staging buffer and the host vectors must outlive the copies and the kernels
     DCS_HIP(hipStreamSynchronize(ctx->stream));
     buf.release();
     return DCS_OK;
+}
+
+extern "C" int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F,
+                               const double* notes_h, int ninst, int n_notes, int width, int64_t start, int64_t stop,
+                               float* out_d, float* mask_d) {
+    return dcs_score_masks_scaled(ctx, mag_d, ld, n_frames, F, notes_h, ninst, n_notes, width, start, stop, 1.0f, out_d, mask_d);
 }

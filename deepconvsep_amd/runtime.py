@@ -291,6 +291,26 @@ class Network(object):
         return out
 
     @_on_ctx_stream
+    def separate_scoreinformed(self, plan, audio_t, notes, overlap, scale=0.3, eps_mode=None, tie_mode=TIE_ALL, out=None):
+        """``dcs_separate_scoreinformed``: 1-D float32 device tensor + the note table ``[C, P, W]`` of
+        :func:`deepconvsep_amd.score` (``expandMidi``'s layout) -> ``[S, L]`` float32 PCM, one call."""
+        torch = _torch()
+        notes = np.ascontiguousarray(notes, dtype=np.float64)
+        if notes.ndim != 3:
+            raise ValueError("notes must be [instruments, notes, 2*nharmonics+3]")
+        L = int(audio_t.numel())
+        if out is None:
+            out = torch.empty((self.S, L), dtype=torch.float32, device=audio_t.device)
+        eps = self.arch.eps_mode if eps_mode is None else eps_mode
+        nt, nf = c_int64(), c_int64()
+        _lib.check(self.ctx._lib.dcs_separate_scoreinformed(
+            self._h, plan._h, _ptr(audio_t), L, notes.ctypes.data_as(POINTER(c_double)), int(notes.shape[0]),
+            int(notes.shape[1]), int(notes.shape[2]), int(overlap), float(scale), int(eps), int(tie_mode), _ptr(out),
+            byref(nt), byref(nf)))
+        self.last_tiles, self.last_frames = nt.value, nf.value
+        return out
+
+    @_on_ctx_stream
     def separate_batch(self, plan, audio_t, overlap, tiler=TILER_SCRIPT, scale=0.3, eps_mode=None, tie_mode=TIE_ALL,
                        out=None):
         """Fused path for equal-length clips sharing one set of launches: ``[B, L]`` float32 device tensor

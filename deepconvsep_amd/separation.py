@@ -287,15 +287,24 @@ class Separator(object):
         a = self.ctx.to_device(np.asarray(audio), np.float32)
         return self.ctx.to_host(self.separate_scoreinformed_device(a, melody)).astype(np.float64)
 
-    @_on_ctx_stream
-    def separate_scoreinformed_device(self, a, melody):
+    def separate_scoreinformed_device(self, a, melody, staged=False):
         """:meth:`separate_scoreinformed` on a float32 device tensor ``[L]``; returns the float32 PCM ``[S, L]`` on the
-        device.  The network runs ``batch_size`` tiles at a time, like ``predict_function2`` in the script's loop."""
-        import torch
-        from .score import score_masks
+        device.  One ``dcs_separate_scoreinformed`` call (all tiles in one pass of the network; the script's
+        ``batch_size`` loop gives the same values tile by tile).  ``staged=True``: the same path composed from the
+        stage-level operators, ``batch_size`` tiles at a time (what the reference's control flow looks like when each
+        helper is swapped for its ``dcs_*`` counterpart)."""
         if self.arch.C != np.asarray(melody).shape[0]:
             raise ValueError("the network takes %d score channels, the note table has %d"
                              % (self.arch.C, np.asarray(melody).shape[0]))
+        if staged:
+            return self._separate_scoreinformed_staged(a, melody)
+        return self.net.separate_scoreinformed(self.plan, a, melody, self.overlap, self.scale_factor,
+                                               tie_mode=self.tie_mode)
+
+    @_on_ctx_stream
+    def _separate_scoreinformed_staged(self, a, melody):
+        import torch
+        from .score import score_masks
         mag, ph = self.plan.forward(a, phase=True)
         T = int(mag.shape[0])
         mag = mag * np.float32(self.scale_factor)                       # :503

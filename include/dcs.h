@@ -153,6 +153,16 @@ int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_s
                  float scale, int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
                  int64_t* n_frames_out);
 
+/* The separation block of the score-informed script (examples/bach10_scoreinformed/separate_bach10.py:497-571) in one
+ * call: STFT -> x scale -> filterSpec masks of the note table (notes_h exactly as for dcs_score_masks, frame window
+ * (0, n_frames)) -> ninst-channel tiles of the library tiler -> network -> masks (applied to input channel 0) -> cross-fade
+ * -> / scale -> iSTFT.  The model must have ninst input channels.  pcm_d [S, n_samples] float32.  All tiles go through the
+ * network in one pass (the script's batch loop gives the same values tile by tile).  Synchronises the ctx stream once (the
+ * note rectangles are staged from the host). */
+int dcs_separate_scoreinformed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, const double* notes_h,
+                               int ninst, int n_notes, int width, int overlap, float scale, int eps_mode, int tie_mode,
+                               float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out);
+
 /* The same pipeline for n_clips mono signals of EQUAL length in one set of launches (the batch-of-files
  * driver of SURVEY 8f.1 / separate_multiple.ipynb; equal-length segments of one long file): clip c starts at
  * audio_d + c * clip_stride (clip_stride >= n_samples), pcm_d [n_clips][S][n_samples].  Every clip is processed
