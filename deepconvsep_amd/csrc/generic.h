@@ -45,6 +45,10 @@ struct DcsSlabConv {
 // pre-split slab variant (slabconv_ps.hip): false = shape not covered, nothing launched
 void dcs_slabconv_ps_pack(const float* Wf, int kh, int kw, int (*wslot)(int, int), int mode, std::vector<uint16_t>* out);
 bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const void* Wq, int mode);
+// conv1 with a frequency stride of 4 on the bf16 matrix pipe (conv1_mfma.hip): false = shape not covered, nothing launched
+void dcs_conv1_mfma_pack(const float* Wc, int NF, int C, int kw, std::vector<uint16_t>* out);
+bool dcs_launch_conv1_mfma(dcs_ctx* ctx, const float* x, const void* Wq, const float* bias, float* out, int64_t n, int C,
+                           int NF, int tc, int F, int kw, int sw, int w1);
 // weights-in-registers f16 variant (colconv_wreg.hip): false = shape not covered, nothing launched
 void dcs_colconv_wreg_pack(const _Float16* Wh, int kh, std::vector<_Float16>* out);
 bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq);

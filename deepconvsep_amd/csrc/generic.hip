@@ -1148,6 +1148,7 @@ struct DcsGenericNet {
     _Float16 *Wcol_h = nullptr, *Wcol_t_h = nullptr;     // [kh][32 co][40] halves, channel-fastest
     _Float16 *Wcol_r = nullptr, *Wcol_t_r = nullptr;     // the same weights as MFMA fragments (colconv_wreg.hip)
     uint16_t* W1q = nullptr;                             // padded conv1 filter as bf16 x 3 fragments (fused decoder)
+    uint16_t* W1m = nullptr;                             // conv1 filter as bf16 x 3 fragments (conv1_mfma.hip)
     int use_colconv = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
@@ -1324,6 +1325,11 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     UP(g->W2t, W2t) UP(g->bias0, bias0) UP(g->kt_off, kt_off) UP(g->kt_uv, kt_uv) UP(g->Bfc, Bfc) UP(g->biasfc, biasfc)
     UP(g->W2m_h, W2m_h) UP(g->W2t_h, W2t_h)
     if (!W1p.empty()) { UP(g->W1p, W1p) }
+    if (d.sw1 == 4 && kw1 <= 32 && (C == 1 || C == 4)) {
+        std::vector<uint16_t> W1m;
+        dcs_conv1_mfma_pack(W1c.data(), nf1, C, kw1, &W1m);
+        UP(g->W1m, W1m)
+    }
     if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) UP(g->Wslab_q3, Wslab_q3) UP(g->Wslab_t_q3, Wslab_t_q3) UP(g->Wslab_h, Wslab_h) UP(g->Wslab_t_h, Wslab_t_h) UP(g->Wps_q3, Wps_q3) UP(g->Wps_t_q3, Wps_t_q3) UP(g->Wps_h, Wps_h) UP(g->Wps_t_h, Wps_t_h) }
     if (g->use_colconv) {
         std::vector<_Float16> Wcol_r, Wcol_t_r;
@@ -1364,7 +1370,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
     for (void* p : ptrs)
@@ -1492,7 +1498,8 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         DcsTimer tm(ctx, DCS_TAG_CONV1);
         static const int reg1 = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
         const dim3 grid1((unsigned)dcs_cdiv(d.w1, kThreads), (unsigned)(n * tc));
-        if (reg1 && d.kw1 <= 32 && d.sw1 == 4)
+        if (g->W1m && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1)) {
+        } else if (reg1 && d.kw1 <= 32 && d.sw1 == 4)
             hipLaunchKernelGGL((conv1_reg_kernel<30, 4>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, a1b, C,
                                tc, F, d.kw1, d.w1);
         else if (reg1 && d.kw1 <= 32 && d.sw1 == 3)
