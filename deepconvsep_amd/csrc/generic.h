@@ -49,6 +49,10 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
 void dcs_conv1_mfma_pack(const float* Wc, int NF, int C, int kw, std::vector<uint16_t>* out);
 bool dcs_launch_conv1_mfma(dcs_ctx* ctx, const float* x, const void* Wq, const float* bias, float* out, int64_t n, int C,
                            int NF, int tc, int F, int kw, int sw, int w1);
+// InverseLayer(conv1) with a frequency stride of 4 on the bf16 matrix pipe (deconv1_mfma.hip)
+void dcs_deconv1_mfma_pack(const float* W1p, int nf1, int C, std::vector<uint16_t>* out);
+bool dcs_launch_deconv1_mfma(dcs_ctx* ctx, const float* g, const void* Wq, float* out, int64_t n_images, int NF, int C, int tc,
+                             int F, int w1);
 // weights-in-registers f16 variant (colconv_wreg.hip): false = shape not covered, nothing launched
 void dcs_colconv_wreg_pack(const _Float16* Wh, int kh, std::vector<_Float16>* out);
 bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq);

@@ -1149,6 +1149,7 @@ struct DcsGenericNet {
     _Float16 *Wcol_r = nullptr, *Wcol_t_r = nullptr;     // the same weights as MFMA fragments (colconv_wreg.hip)
     uint16_t* W1q = nullptr;                             // padded conv1 filter as bf16 x 3 fragments (fused decoder)
     uint16_t* W1m = nullptr;                             // conv1 filter as bf16 x 3 fragments (conv1_mfma.hip)
+    uint16_t* W1dq = nullptr;                            // the same for its InverseLayer (deconv1_mfma.hip)
     int use_colconv = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
@@ -1329,6 +1330,11 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         std::vector<uint16_t> W1m;
         dcs_conv1_mfma_pack(W1c.data(), nf1, C, kw1, &W1m);
         UP(g->W1m, W1m)
+        if (kw1 > 28 && !W1p.empty()) {                  // the padded tap axis is 32 long
+            std::vector<uint16_t> W1dq;
+            dcs_deconv1_mfma_pack(W1p.data(), nf1, C, &W1dq);
+            UP(g->W1dq, W1dq)
+        }
     }
     if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) UP(g->Wslab_q3, Wslab_q3) UP(g->Wslab_t_q3, Wslab_t_q3) UP(g->Wslab_h, Wslab_h) UP(g->Wslab_t_h, Wslab_t_h) UP(g->Wps_q3, Wps_q3) UP(g->Wps_t_q3, Wps_t_q3) UP(g->Wps_h, Wps_h) UP(g->Wps_t_h, Wps_t_h) }
     if (g->use_colconv) {
@@ -1370,7 +1376,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W1dq, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
     for (void* p : ptrs)
@@ -1651,7 +1657,8 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                                         (int)lds));
         DcsTimer tm(ctx, DCS_TAG_FINAL);
         static const int reg_env = getenv("DCS_DECONV1_REG") ? atoi(getenv("DCS_DECONV1_REG")) : 1;
-        if (g->W1p && reg_env && d.sw1 == 4 && (d.kw1 + 3) / 4 == 8) {
+        if (g->W1dq && dcs_launch_deconv1_mfma(ctx, g1, g->W1dq, o, n * NB, d.nf1, C, tc, F, d.w1)) {
+        } else if (g->W1p && reg_env && d.sw1 == 4 && (d.kw1 + 3) / 4 == 8) {
             const int nqb = (F + 15) / 16;
             hipLaunchKernelGGL((deconv1_reg_kernel<4, 8>), dim3((unsigned)dcs_cdiv((int64_t)tc * nqb, kThreads), (unsigned)(n * NB)),
                                dim3(kThreads), 0, ctx->stream, g1, g->W1p, o, d.nf1, C, tc, F, d.w1, nqb);
