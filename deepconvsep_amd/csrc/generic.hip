@@ -945,7 +945,9 @@ template <int SW, int NT /* taps per residue = ceil(kw / SW) */>
 __global__ __launch_bounds__(kThreads) void deconv1_reg_kernel(const float* __restrict__ g, const float* __restrict__ Wp,
                                                                float* __restrict__ out, int NF, int C, int tc, int F,
                                                                int w1, int nqb) {
-    constexpr int QB = 16 / SW, XI = QB + NT - 1;
+    // a thread owns QB values of q and all SW residues: FB = SW * QB consecutive bins (16 for a stride of 4, 12 for the
+    // iKala stride of 3, whose 30 taps are exactly 10 per residue)
+    constexpr int QB = 4, FB = SW * QB, XI = QB + NT - 1;
     const int64_t m = blockIdx.y;
     const int idx = blockIdx.x * kThreads + threadIdx.x;
     if (idx >= tc * nqb) return;
@@ -953,17 +955,19 @@ __global__ __launch_bounds__(kThreads) void deconv1_reg_kernel(const float* __re
     const int q0 = qb * QB, j0 = q0 - (NT - 1);            // inputs j0 .. j0 + XI - 1
     const float* grow = g + (m * NF * tc + t) * (int64_t)w1;
     for (int c = 0; c < C; ++c) {
-        float acc[16];
+        float acc[FB];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int i = 0; i < FB; ++i) acc[i] = 0.f;
         for (int o = 0; o < NF; ++o) {
             const float* gp = grow + (int64_t)o * tc * w1;
             float gw[XI];
-            if (XI <= 12 && j0 >= 0 && j0 + 12 <= w1) {   // interior: three (unaligned) 16-byte loads
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(gp + j0), v1 = *reinterpret_cast<const f32x4*>(gp + j0 + 4),
-                            v2 = *reinterpret_cast<const f32x4*>(gp + j0 + 8);
+            constexpr int NV = (XI + 3) / 4;
+            if (j0 >= 0 && j0 + 4 * NV <= w1) {           // interior: three or four (unaligned) 16-byte loads
+                f32x4 v[NV];
 #pragma unroll
-                for (int x = 0; x < XI; ++x) gw[x] = x < 4 ? v0[x & 3] : (x < 8 ? v1[x & 3] : v2[x & 3]);
+                for (int q = 0; q < NV; ++q) v[q] = *reinterpret_cast<const f32x4*>(gp + j0 + 4 * q);
+#pragma unroll
+                for (int x = 0; x < XI; ++x) gw[x] = v[x >> 2][x & 3];
             } else {
 #pragma unroll
                 for (int x = 0; x < XI; ++x) {
@@ -983,7 +987,7 @@ __global__ __launch_bounds__(kThreads) void deconv1_reg_kernel(const float* __re
         }
         float* op = out + ((m * C + c) * tc + t) * (int64_t)F + (int64_t)q0 * SW;
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < FB; ++i)
             if (q0 * SW + i < F) op[i] = acc[i];
     }
 }
@@ -1193,7 +1197,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
             for (int u = 0; u < kw1; ++u) W1t[((size_t)c * kw1 + u) * 32 + o] = W1c[((size_t)o * C + c) * kw1 + u];
     // the same filters with the tap axis zero-padded to a multiple of the stride (deconv1_reg_kernel)
     std::vector<float> W1p;
-    if (16 % d.sw1 == 0) {
+    if (16 % d.sw1 == 0 || d.sw1 == 3) {
         const int ntap = d.sw1 * ((kw1 + d.sw1 - 1) / d.sw1);
         W1p.assign((size_t)nf1 * C * ntap, 0.f);
         for (int o = 0; o < nf1; ++o)
@@ -1658,6 +1662,10 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         DcsTimer tm(ctx, DCS_TAG_FINAL);
         static const int reg_env = getenv("DCS_DECONV1_REG") ? atoi(getenv("DCS_DECONV1_REG")) : 1;
         if (g->W1dq && dcs_launch_deconv1_mfma(ctx, g1, g->W1dq, o, n * NB, d.nf1, C, tc, F, d.w1)) {
+        } else if (g->W1p && reg_env && d.sw1 == 3 && (d.kw1 + 2) / 3 == 10) {
+            const int nqb = (F + 11) / 12;
+            hipLaunchKernelGGL((deconv1_reg_kernel<3, 10>), dim3((unsigned)dcs_cdiv((int64_t)tc * nqb, kThreads), (unsigned)(n * NB)),
+                               dim3(kThreads), 0, ctx->stream, g1, g->W1p, o, d.nf1, C, tc, F, d.w1, nqb);
         } else if (g->W1p && reg_env && d.sw1 == 4 && (d.kw1 + 3) / 4 == 8) {
             const int nqb = (F + 15) / 16;
             hipLaunchKernelGGL((deconv1_reg_kernel<4, 8>), dim3((unsigned)dcs_cdiv((int64_t)tc * nqb, kThreads), (unsigned)(n * NB)),
