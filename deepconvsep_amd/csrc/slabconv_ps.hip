@@ -107,7 +107,8 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
     if (u_lo < 0) u_lo = 0;
     if (u_hi > g.kh - 1) u_hi = g.kh - 1;
     const int n_stage = (u_hi - u_lo + 1) * nvs;
-    constexpr int WPRE = (2 * kStageGlb + NTH - 1) / NTH;  // pstage <= 2
+    constexpr int kMaxPairs = 5;                          // tap pairs per weight stage (launcher: as many as fit)
+    constexpr int WPRE = (kMaxPairs * kStageGlb + NTH - 1) / NTH;
     u32x4 wpre[WPRE];
     for (int hc = 0; hc < 2; ++hc) {
         __syncthreads();                                  // every wave is done with the previous half's slab and weights
@@ -270,13 +271,15 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
     size_t lds = 0;
     double best = 0.0;
     for (int cand = 1; cand <= a.Ho && cand * nxb <= 32; ++cand) {
-        int ps = 2;
-        size_t need = (size_t)2 * ps * np * 128 * 16 + row_bytes * (size_t)(cand + a.kh - 1);
-        if (need > 160 * 1024) {
-            ps = 1;
+        // weight stage: as many tap pairs as fit beside the slab (a barrier per stage: the fewer the better), at most 5
+        int ps = 5;
+        size_t need = 0;
+        for (;; --ps) {
+            if (ps < 1) break;
             need = (size_t)2 * ps * np * 128 * 16 + row_bytes * (size_t)(cand + a.kh - 1);
-            if (need > 160 * 1024) break;
+            if (need <= 160 * 1024) break;
         }
+        if (ps < 1) break;
         const int64_t n_wg = n_images * ((a.Ho + cand - 1) / cand);
         const int rounds = (cand * nxb + 15) / 16;          // block slots used per wave
         double eff = (double)n_images * a.Ho * nxb / ((double)n_wg * 16 * rounds);
