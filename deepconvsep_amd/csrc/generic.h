@@ -41,6 +41,7 @@ struct DcsSlabConv {
     int rows_max;               // band + kh - 1 (slab rows allocated)
     int tstage;                 // taps (along v) staged per step
     int pstage;                 // tap pairs staged per step (slabconv_ps.hip)
+    int xt, n_xt;               // output columns per workgroup (multiple of 16), column tiles per band (slabconv_ps.hip)
 };
 // pre-split slab variant (slabconv_ps.hip): false = shape not covered, nothing launched
 void dcs_slabconv_ps_pack(const float* Wf, int kh, int kw, int (*wslot)(int, int), int mode, std::vector<uint16_t>* out);

@@ -1146,6 +1146,7 @@ struct DcsGenericNet {
     // the same for slabconv_mx_kernel: [tap][plane][32 co][4 pieces of 8 ci]; q3 = three bf16 planes, h = one f16 plane
     uint16_t *Wslab_q3 = nullptr, *Wslab_t_q3 = nullptr, *Wslab_h = nullptr, *Wslab_t_h = nullptr;
     uint16_t *Wps_q3 = nullptr, *Wps_t_q3 = nullptr, *Wps_h = nullptr, *Wps_t_h = nullptr;   // slabconv_ps.hip orders
+    uint16_t *Wpc_q3 = nullptr, *Wpc_t_q3 = nullptr;     // the kh x 1 filters in the same orders (bf16 x 3)
     int use_slabconv = 0;
     float* W1p = nullptr;      // conv1 filters padded to sw1*ceil(kw1/sw1) taps (register-blocked transpose of conv1)
     float *Wcol = nullptr, *Wcol_t = nullptr;
@@ -1345,6 +1346,12 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         std::vector<_Float16> Wcol_r, Wcol_t_r;
         dcs_colconv_wreg_pack(Wcol_h.data(), kh, &Wcol_r);
         dcs_colconv_wreg_pack(Wcol_t_h.data(), kh, &Wcol_t_r);
+        // Wcol is [u][1024] with (ci, co) at colconv_wslot(0, ci, co): the slab kernel's source format with kw = 1
+        std::vector<uint16_t> Wpc_q3, Wpc_t_q3;
+        auto slot = +[](int ci, int co) { return colconv_wslot(0, ci, co); };
+        dcs_slabconv_ps_pack(Wcol.data(), kh, 1, slot, 0, &Wpc_q3);
+        dcs_slabconv_ps_pack(Wcol_t.data(), kh, 1, slot, 0, &Wpc_t_q3);
+        UP(g->Wpc_q3, Wpc_q3) UP(g->Wpc_t_q3, Wpc_t_q3)
         UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) UP(g->Wcol_r, Wcol_r) UP(g->Wcol_t_r, Wcol_t_r)
         if (C == 1 && d.sw1 == 4 && kw1 > 28 && kw1 <= 32 && !d.pool_w && !W1p.empty()) {
             std::vector<uint16_t> W1q;
@@ -1380,7 +1387,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
 
 void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
-    void* ptrs[] = {g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W1dq, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
+    void* ptrs[] = {g->Wpc_q3, g->Wpc_t_q3, g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W1dq, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
     for (void* p : ptrs)
@@ -1439,9 +1446,21 @@ bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images, const uint1
     return true;
 }
 
-int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16* Wh = nullptr, const _Float16* Wr = nullptr) {
+int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16* Wh = nullptr, const _Float16* Wr = nullptr,
+                   const uint16_t* Wps = nullptr) {
     a.n_xb = (a.W + 15) / 16;
     if (Wh && Wr && dcs_launch_colconv_wreg(ctx, a, n_images, Wr)) return DCS_OK;
+    static const bool ps_col = !(getenv("DCS_COLCONV_PS") && atoi(getenv("DCS_COLCONV_PS")) == 0);
+    // f32-class forward conv2: bf16 x 3 with the slab pre-split in LDS (0.41 -> 0.25 ms on the score-informed batch).  The
+    // transpose stays with the f32 column kernel: 7 of 20 taps are valid on average there and that kernel walks only
+    // those (0.34 against 0.38 ms)
+    if (!Wh && Wps && ps_col && a.ph == 0) {
+        SlabConvArgs c{};
+        c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
+        c.Wk = a.Wk; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride;
+        c.Cout = a.Cout; c.Ho = a.Ho; c.Wo = a.W; c.kh = a.kh; c.kw = 1; c.ph = a.ph; c.pw = 0;
+        if (dcs_launch_slabconv_ps(ctx, c, n_images, Wps, 0)) return DCS_OK;
+    }
     if (Wh) {
         int per = 8;
         while (per > 1 && n_images * ((a.n_xb + per - 1) / per) < 4 * (int64_t)ctx->n_cu) per >>= 1;
@@ -1540,7 +1559,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = 0; c.kh = d.kh2;
-            DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr, g->Wcol_r));
+            DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr, g->Wcol_r, g->Wpc_q3));
         } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
             // general filters (iKala, 10 x 20) go through the slab kernel in either precision unless DCS_F16_IGEMM=1 asks
             // for the f16 implicit GEMM
@@ -1622,7 +1641,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         DcsTimer tm(ctx, decoder_fused ? -1 : DCS_TAG_DECONV2);
         if (decoder_fused) {
         } else if (g->use_colconv) {
-            DCS_CHECK(launch_colconv(ctx, c, n * NB, g->conv_f16 ? g->Wcol_t_h : nullptr, g->Wcol_t_r));
+            DCS_CHECK(launch_colconv(ctx, c, n * NB, g->conv_f16 ? g->Wcol_t_h : nullptr, g->Wcol_t_r, g->Wpc_t_q3));
         } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
             hipLaunchKernelGGL(conv_igemm_f16_kernel, dim3((unsigned)dcs_cdiv(a.M, 128)), dim3(kThreads), 0, ctx->stream, a,
                                g->W2t_h);

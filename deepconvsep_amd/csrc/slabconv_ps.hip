@@ -66,7 +66,10 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int MODE, int NW /* waves per workgroup */>
+// PU = false: a K block pairs the taps (u, v) and (u, v + 1) (filters wider than one column: iKala);
+// PU = true:  kw == 1 (Bach10 / score-informed in f32): a K block pairs the taps u = 2 up and 2 up + 1 of the one column,
+//             and a workgroup owns a tile of output columns (a 505-column row does not fit in LDS).
+template <int MODE, int NW /* waves per workgroup */, bool PU>
 __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv g, const u32x4* __restrict__ Wq) {
     constexpr int NP = MODE == 0 ? 3 : 1;
     constexpr int RP = NP * 2;                            // 16-byte pieces per slab record
@@ -76,13 +79,19 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
     extern __shared__ u32x4 smem[];
     u32x4* Wl = smem;                                     // [2][pairs_per_stage][NP][2][64]
     const int wstage = g.pstage * kStage;
-    u32x4* slab = smem + 2 * wstage;                      // [rows_max][W][RP]
+    u32x4* slab = smem + 2 * wstage;                      // [rows_max][columns of the tile][RP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, kq = lane >> 4;
-    const int64_t img = blockIdx.x / g.n_bands;
-    const int y0 = (int)(blockIdx.x - img * g.n_bands) * g.band;
+    // workgroup = (image, band of output rows, tile of output columns)
+    // (wide filters keep whole rows: n_xt == 1, and the tile arithmetic below folds to constants)
+    const int xtile = PU ? blockIdx.x % g.n_xt : 0;
+    const int bb = PU ? blockIdx.x / g.n_xt : blockIdx.x;
+    const int64_t img = bb / g.n_bands;
+    const int y0 = (int)(bb - img * g.n_bands) * g.band;
     const int yb = y0 + g.band < g.Ho ? y0 + g.band : g.Ho;   // output rows [y0, yb)
+    const int xt0 = PU ? xtile * g.xt : 0;
+    const int xt1 = PU ? (xt0 + g.xt < g.Wo ? xt0 + g.xt : g.Wo) : g.Wo;   // output columns [xt0, xt1)
     const float* in = g.in + img * g.in_n_stride;
     float* out = g.out + img * g.out_n_stride;
     int rbase = y0 - g.ph, rtop = yb - 1 - g.ph + g.kh - 1;
@@ -90,50 +99,66 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
     if (rtop > g.H - 1) rtop = g.H - 1;
     const int rows = rtop - rbase + 1;
     const int HW = g.H * g.W;
-    const int nxb = (g.Wo + 15) >> 4, nblk = (yb - y0) * nxb;
+    const int nxb = (xt1 - xt0 + 15) >> 4, nblk = (yb - y0) * nxb;
+    const int nvp = PU ? 1 : (g.kw + 1) >> 1;             // tap pairs per filter row
+    // input columns the tile can touch: [cx0, cx1)
+    int cx0 = 0, cx1 = g.W;
+    if (PU) {
+        cx0 = xt0 - g.pw;
+        cx1 = xt0 - g.pw + nxb * 16;
+        if (cx0 < 0) cx0 = 0;
+        if (cx1 > g.W) cx1 = g.W;
+    }
+    const int SW = cx1 > cx0 ? cx1 - cx0 : 0;
     int by[NBW], bx[NBW];
     f32x4 acc0[NBW], acc1[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
         const int b = wave + NW * i;
         by[i] = b < nblk ? y0 + b / nxb : -1;
-        bx[i] = b < nblk ? (b % nxb) * 16 : 0;
+        bx[i] = b < nblk ? xt0 + (b % nxb) * 16 : 0;
         acc0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int nvp = (g.kw + 1) >> 1;                      // tap pairs per filter row
-    const int nvs = (nvp + g.pstage - 1) / g.pstage;      // stages per filter row
     int u_lo = g.ph - (yb - 1), u_hi = g.ph - y0 + g.H - 1;
     if (u_lo < 0) u_lo = 0;
     if (u_hi > g.kh - 1) u_hi = g.kh - 1;
-    const int n_stage = (u_hi - u_lo + 1) * nvs;
+    // pairs of this band as (outer, inner): PU: one outer step, inner = up in [u_lo / 2, u_hi / 2];
+    // otherwise outer = u in [u_lo, u_hi], inner = vp in [0, nvp)
+    const int in_lo = PU ? u_lo >> 1 : 0;
+    const int n_in = PU ? (u_hi >> 1) - in_lo + 1 : nvp;
+    const int n_out = PU ? (u_hi >= u_lo ? 1 : 0) : u_hi - u_lo + 1;
+    const int nvs = (n_in + g.pstage - 1) / g.pstage;     // stages per outer step
+    const int n_stage = n_out * nvs;
+    const int pairs_per_half = PU ? (g.kh + 1) >> 1 : g.kh * nvp;
     constexpr int kMaxPairs = 5;                          // tap pairs per weight stage (launcher: as many as fit)
     constexpr int WPRE = (kMaxPairs * kStageGlb + NTH - 1) / NTH;
     u32x4 wpre[WPRE];
     for (int hc = 0; hc < 2; ++hc) {
         __syncthreads();                                  // every wave is done with the previous half's slab and weights
         // slab fill: task = (row, x, channel octet); consecutive threads take consecutive x of one (octet, row)
-        const int n_task = 2 * rows * g.W;
+        const int n_task = 2 * rows * SW;
         for (int i = tid; i < n_task; i += NTH) {
-            const int o = i / (rows * g.W), rem = i - o * (rows * g.W);
-            const int r = rem / g.W, x = rem - r * g.W;
+            const int o = i / (rows * SW), rem = i - o * (rows * SW);
+            const int r = rem / SW, x = rem - r * SW;
             const int c0 = 16 * hc + 8 * o;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = c0 + j < g.Cin ? in[(int64_t)(c0 + j) * HW + (rbase + r) * g.W + x] : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = c0 + j < g.Cin ? in[(int64_t)(c0 + j) * HW + (rbase + r) * g.W + cx0 + x] : 0.f;
             u32x4 p[NP];
             convert8<MODE>(v, p);
 #pragma unroll
             for (int q = 0; q < NP; ++q) slab[rem * RP + q * 2 + o] = p[q];
         }
-        const u32x4* Wh = Wq + (int64_t)hc * g.kh * nvp * kStageGlb;
+        const u32x4* Wh = Wq + (int64_t)hc * pairs_per_half * kStageGlb;
 #define DCS_PS_WFETCH(st_)                                                                              \
         {                                                                                               \
-            const int u_ = u_lo + (st_) / nvs, vp_ = ((st_) % nvs) * g.pstage;                          \
-            const int np_ = vp_ + g.pstage <= nvp ? g.pstage : nvp - vp_;                               \
+            const int o_ = (st_) / nvs, i0_ = ((st_) - o_ * nvs) * g.pstage;                            \
+            const int np_ = i0_ + g.pstage <= n_in ? g.pstage : n_in - i0_;                             \
+            const int pair_ = PU ? in_lo + i0_ : (u_lo + o_) * nvp + i0_;                               \
             _Pragma("unroll") for (int q = 0; q < WPRE; ++q) {                                          \
                 const int e = tid + q * NTH;                                                            \
-                wpre[q] = e < np_ * kStageGlb ? Wh[(int64_t)(u_ * nvp + vp_) * kStageGlb + e] : u32x4{0u, 0u, 0u, 0u}; \
+                wpre[q] = e < np_ * kStageGlb ? Wh[(int64_t)pair_ * kStageGlb + e] : u32x4{0u, 0u, 0u, 0u};    \
             }                                                                                           \
         }
         if (n_stage > 0) DCS_PS_WFETCH(0)
@@ -146,19 +171,27 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
             }
             __syncthreads();     // also orders the slab fill before its first use; buffer st & 1 was last read at st - 2
             if (st + 1 < n_stage) DCS_PS_WFETCH(st + 1)
-            const int u = u_lo + st / nvs, vp0 = (st % nvs) * g.pstage;
-            const int np = vp0 + g.pstage <= nvp ? g.pstage : nvp - vp0;
+            const int so = st / nvs, i0 = (st - so * nvs) * g.pstage;
+            const int np = i0 + g.pstage <= n_in ? g.pstage : n_in - i0;
             for (int tp = 0; tp < np; ++tp) {
-                const int v = 2 * (vp0 + tp);
+                const int u = PU ? 2 * (in_lo + i0 + tp) : u_lo + so;      // first tap of the pair
+                const int v = PU ? 0 : 2 * (i0 + tp);
                 const u32x4* wp = Wb + tp * kStage + lane;
                 u32x4 a0[NP], a1[NP];
                 bool have = false;
 #pragma unroll
                 for (int i = 0; i < NBW; ++i) {
                     if (by[i] < 0) continue;
-                    const int r = by[i] + u - g.ph;                  // input row (uniform per block)
-                    const int xs = bx[i] + v - g.pw;                 // column of lane 0, first tap of the pair
-                    if (r < 0 || r >= g.H || xs + 16 < 0 || xs >= g.W) continue;
+                    const int r = by[i] + u - g.ph;                  // input row of the first tap (uniform per block)
+                    const int xs = bx[i] + v - g.pw;                 // input column of lane 0, first tap
+                    bool inner;                                      // every row / column of both taps inside: no select
+                    if (PU) {
+                        if (r + 1 < 0 || r >= g.H || xs + 15 < 0 || xs >= g.W) continue;
+                        inner = r >= 0 && r + 1 < g.H && u + 1 < g.kh && xs >= 0 && xs + 16 <= g.W;
+                    } else {
+                        if (r < 0 || r >= g.H || xs + 16 < 0 || xs >= g.W) continue;
+                        inner = xs >= 0 && xs + 17 <= g.W;
+                    }
                     if (!have) {
 #pragma unroll
                         for (int p = 0; p < NP; ++p) {
@@ -167,11 +200,13 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
                         }
                         have = true;
                     }
-                    const int xc = xs + fi + (kq >> 1);
-                    const bool ok = xc >= 0 && xc < g.W;
-                    const u32x4* sp = slab + ((r - rbase) * g.W + (ok ? xc : 0)) * RP + (kq & 1);
+                    const int rr = PU ? r + (kq >> 1) : r;
+                    const int xc = PU ? xs + fi : xs + fi + (kq >> 1);
+                    // (a second tap past the filter has zero weights, but its row may lie outside the slab: no read)
+                    const bool ok = xc >= 0 && xc < g.W && rr >= 0 && rr < g.H && (!PU || u + (kq >> 1) < g.kh);
+                    const u32x4* sp = slab + (ok ? (rr - rbase) * SW + xc - cx0 : 0) * RP + (kq & 1);
                     u32x4 b[NP];
-                    if (xs >= 0 && xs + 17 <= g.W) {                 // every column of both taps inside: no select
+                    if (inner) {
 #pragma unroll
                         for (int p = 0; p < NP; ++p) b[p] = sp[p * 2];
                     } else {
@@ -220,81 +255,101 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
 }  // namespace
 
 // Wf: [kh * kw taps][1024] f32 with element (ci, co) of a tap at wslot(ci, co) -> the kernel's order
-// [half hc][u][tap pair vp][plane][co half][lane = 16 kg + (co & 15)][8]: k slot (kg, j) = tap 2 vp + (kg >> 1), channel
-// 16 hc + 8 (kg & 1) + j.
+// [half hc][pair][plane][co half][lane = 16 kg + (co & 15)][8], channel of k slot (kg, j) = 16 hc + 8 (kg & 1) + j and
+//   kw > 1:  pair = u * ceil(kw / 2) + vp, tap (u, 2 vp + (kg >> 1));     kw == 1:  pair = up, tap (2 up + (kg >> 1), 0).
 // mode 0: three bf16 planes (truncation split, exact); mode 1: one f16 plane (round to nearest even).
 void dcs_slabconv_ps_pack(const float* Wf, int kh, int kw, int (*wslot)(int, int), int mode, std::vector<uint16_t>* out) {
+    const bool pu = kw == 1;
     const int np = mode == 0 ? 3 : 1, nvp = (kw + 1) / 2;
-    out->assign((size_t)2 * kh * nvp * np * 128 * 8, 0);
+    const int pairs = pu ? (kh + 1) / 2 : kh * nvp;
+    out->assign((size_t)2 * pairs * np * 128 * 8, 0);
     for (int hc = 0; hc < 2; ++hc)
-        for (int u = 0; u < kh; ++u)
-            for (int vp = 0; vp < nvp; ++vp)
-                for (int co = 0; co < 32; ++co)
-                    for (int kg = 0; kg < 4; ++kg)
-                        for (int j = 0; j < 8; ++j) {
-                            const int v = 2 * vp + (kg >> 1), ci = 16 * hc + 8 * (kg & 1) + j;
-                            float r = v < kw ? Wf[(size_t)(u * kw + v) * 1024 + wslot(ci, co)] : 0.f;
-                            const size_t base = ((((size_t)hc * kh + u) * nvp + vp) * np) * 128 * 8;
-                            const size_t idx = (((size_t)(co >> 4) * 64) + kg * 16 + (co & 15)) * 8 + j;
-                            if (mode == 0) {
-                                for (int p = 0; p < 3; ++p) {
-                                    uint32_t bits;
-                                    memcpy(&bits, &r, 4);
-                                    bits &= 0xffff0000u;
-                                    float part;
-                                    memcpy(&part, &bits, 4);
-                                    r -= part;
-                                    (*out)[base + (size_t)p * 128 * 8 + idx] = (uint16_t)(bits >> 16);
-                                }
-                            } else {
-                                const _Float16 hv = (_Float16)r;
-                                uint16_t hb;
-                                memcpy(&hb, &hv, 2);
-                                (*out)[base + idx] = hb;
+        for (int pr = 0; pr < pairs; ++pr)
+            for (int co = 0; co < 32; ++co)
+                for (int kg = 0; kg < 4; ++kg)
+                    for (int j = 0; j < 8; ++j) {
+                        const int u = pu ? 2 * pr + (kg >> 1) : pr / nvp;
+                        const int v = pu ? 0 : 2 * (pr % nvp) + (kg >> 1);
+                        const int ci = 16 * hc + 8 * (kg & 1) + j;
+                        float r = (u < kh && v < kw) ? Wf[(size_t)(u * kw + v) * 1024 + wslot(ci, co)] : 0.f;
+                        const size_t base = (((size_t)hc * pairs + pr) * np) * 128 * 8;
+                        const size_t idx = (((size_t)(co >> 4) * 64) + kg * 16 + (co & 15)) * 8 + j;
+                        if (mode == 0) {
+                            for (int p = 0; p < 3; ++p) {
+                                uint32_t bits;
+                                memcpy(&bits, &r, 4);
+                                bits &= 0xffff0000u;
+                                float part;
+                                memcpy(&part, &bits, 4);
+                                r -= part;
+                                (*out)[base + (size_t)p * 128 * 8 + idx] = (uint16_t)(bits >> 16);
                             }
+                        } else {
+                            const _Float16 hv = (_Float16)r;
+                            uint16_t hb;
+                            memcpy(&hb, &hv, 2);
+                            (*out)[base + idx] = hb;
                         }
+                    }
 }
 
 // false: the shape does not fit; nothing launched
 bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const void* Wq, int mode) {
     static const bool on = !(getenv("DCS_SLABCONV_PS") && atoi(getenv("DCS_SLABCONV_PS")) == 0);
     if (!on || !Wq || a.Cin > 32 || a.Cout > 32) return false;
+    const bool pu = a.kw == 1;
     const int np = mode == 0 ? 3 : 1;
-    const int nxb = (a.Wo + 15) / 16;
+    const int nvp = (a.kw + 1) / 2;
+    const int nxb_all = (a.Wo + 15) / 16;
     const size_t rec = (size_t)np * 2 * 16;
-    const size_t row_bytes = (size_t)a.W * rec;
-    // rows per workgroup: a workgroup has 16 waves x 2 block slots and streams all the weights whatever its band, so the
-    // best band is the one that wastes the fewest (wave, slot) pairs -- counting the short last band and the CUs left
-    // without a workgroup -- among those whose slab fits; ties go to the taller band.  (iKala conv2, 21 x 64 outputs:
-    // bands of 4 rows = 16 blocks, one per wave, instead of 5 rows = 20 blocks on 16 waves.)
-    int band = 0;
+    // (rows, columns) of outputs per workgroup: a workgroup has 16 waves x 2 block slots and streams all the weights
+    // whatever its share, so the best split is the one that wastes the fewest (wave, slot) pairs -- counting short last
+    // bands / tiles and CUs left without a workgroup -- among those whose slab fits, discounted by the number of weight
+    // stages (barriers) the leftover LDS forces; ties go to the larger weight stage, then to the larger share.  Wide filters keep whole rows (the halo of a column tile would be kw - 1 columns).
+    int band = 0, xt = 0, ps_best = 1;
     size_t lds = 0;
     double best = 0.0;
-    for (int cand = 1; cand <= a.Ho && cand * nxb <= 32; ++cand) {
-        // weight stage: as many tap pairs as fit beside the slab (a barrier per stage: the fewer the better), at most 5
-        int ps = 5;
-        size_t need = 0;
-        for (;; --ps) {
+    for (int cxt = pu ? 1 : nxb_all; cxt <= nxb_all && cxt <= 32; ++cxt) {     // 16-column blocks per tile
+        const int n_xt = (nxb_all + cxt - 1) / cxt;
+        int sw = cxt * 16 + (pu ? 0 : 2 * nvp - 1);
+        if (sw > a.W) sw = a.W;
+        for (int cand = 1; cand <= a.Ho && cand * cxt <= 32; ++cand) {
+            int rows = cand + a.kh - 1;
+            if (rows > a.H) rows = a.H;
+            // weight stage: as many tap pairs as fit beside the slab (a barrier per stage: the fewer the better), at most 5
+            int ps = 5;
+            size_t need = 0;
+            for (;; --ps) {
+                if (ps < 1) break;
+                need = (size_t)2 * ps * np * 128 * 16 + (size_t)rows * sw * rec;
+                if (need <= 160 * 1024) break;
+            }
             if (ps < 1) break;
-            need = (size_t)2 * ps * np * 128 * 16 + row_bytes * (size_t)(cand + a.kh - 1);
-            if (need <= 160 * 1024) break;
+            const int64_t n_wg = n_images * ((a.Ho + cand - 1) / cand) * n_xt;
+            const int rounds = (cand * cxt + 15) / 16;                // block slots used per wave
+            double eff = (double)n_images * a.Ho * nxb_all / ((double)n_wg * 16 * rounds);
+            if (n_wg < ctx->n_cu) eff *= (double)n_wg / ctx->n_cu;
+            eff /= 1.0 + 0.6 / ps;                                    // a barrier per stage: measured, iKala 0.83 -> 0.67 ms
+            const bool tie = eff > best - 1e-9;
+            if (eff > best + 1e-9 || (tie && (ps > ps_best || (ps == ps_best && cand * cxt >= band * (xt / 16))))) {
+                best = eff; band = cand; xt = cxt * 16; lds = need; ps_best = ps;
+            }
         }
-        if (ps < 1) break;
-        const int64_t n_wg = n_images * ((a.Ho + cand - 1) / cand);
-        const int rounds = (cand * nxb + 15) / 16;          // block slots used per wave
-        double eff = (double)n_images * a.Ho * nxb / ((double)n_wg * 16 * rounds);
-        if (n_wg < ctx->n_cu) eff *= (double)n_wg / ctx->n_cu;
-        if (eff >= best) { best = eff; band = cand; lds = need; a.pstage = ps; }
     }
-    if (band < 1 || band * nxb < 8) return false;          // fewer than 8 blocks: the f32-slab kernel is no worse
+    if (band < 1 || band * (xt / 16) < 8) return false;    // fewer than 8 blocks: the f32-slab kernels are no worse
+    a.pstage = ps_best;
     a.band = band;
     a.n_bands = (a.Ho + band - 1) / band;
     a.rows_max = band + a.kh - 1;
-    auto kern = mode == 0 ? slabconv_ps_kernel<0, 16> : slabconv_ps_kernel<1, 16>;
+    a.xt = xt;
+    a.n_xt = (nxb_all * 16 + xt - 1) / xt;
+    typedef void (*kern_t)(const DcsSlabConv, const u32x4*);
+    kern_t kern = pu ? (mode == 0 ? (kern_t)slabconv_ps_kernel<0, 16, true> : (kern_t)slabconv_ps_kernel<1, 16, true>)
+                     : (mode == 0 ? (kern_t)slabconv_ps_kernel<0, 16, false> : (kern_t)slabconv_ps_kernel<1, 16, false>);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * a.n_bands)), dim3(1024), lds, ctx->stream, a,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * a.n_bands * a.n_xt)), dim3(1024), lds, ctx->stream, a,
                        reinterpret_cast<const u32x4*>(Wq));
     return true;
 }
