@@ -250,6 +250,7 @@ __global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const Dc
 //            carry of block b - 1 added; q = 16 b + 16 .. + 22 are this block's carry (LDS, [row][8]).
 // An image's blocks are cut into runs (one wave each); a run that does not start at x = 0 first recomputes the block to
 // its left and keeps only the carry.  HBM traffic: the dense-layer output once (445 MB) + the 164 MB result.
+// (scripts/emu_fused_decoder.py: the same index arithmetic lane by lane in NumPy against the direct formula.)
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 

@@ -10,7 +10,7 @@
 // -- after which lane (x, kq) holds the 16-byte piece of the output row at f = 4 (x + mm), mm = kq (+4).  The eight pieces
 // that meet at one q are summed through a per-wave LDS array (plain 16-byte writes, shifted reads), a wave walks the column
 // blocks of its two rows left to right, finished q leave as 256 contiguous bytes per row and 7 carry over.  See the fused
-// kernel for the derivation and the lane-level emulation the index arithmetic was checked with.
+// kernel for the derivation; scripts/emu_fused_decoder.py is the lane-level emulation the index arithmetic was checked with.
 #include <string.h>
 
 #include "dcs_internal.h"
