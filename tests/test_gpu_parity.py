@@ -637,6 +637,39 @@ def test_separate_batch_equals_clip_by_clip(N, seconds, clips, tiler, hop):
     assert np.array_equal(got2, got)
 
 
+_WHOLE_PATH_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepconvsep_amd as dcs
+from deepconvsep_amd.synth import synth_audio, synth_params
+arch, N, ov = sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+F = N // 2 + 1
+sep = dcs.Separator(arch, synth_params(arch, 30, F, seed=7), 0.3, 30, ov, 32, F, N, 512, np.hanning)
+np.save(sys.argv[2], sep.separate(synth_audio(int(3.2 * 44100), seed=33)))
+"""
+
+
+@pytest.mark.parametrize("arch,ov", [("bach10", 25), ("ikala", 20)])
+def test_whole_path_fallbacks_of_the_generic_graphs_agree(arch, ov, tmp_path):
+    """dcs_separate on the generic graphs: the one-chunk path with mask + cross-fade in one kernel (default), the same
+    with the two kernels (DCS_MASK_OLA=0) and the several-chunk path, which cannot defer the mask (DCS_GENERIC_CHUNK=8:
+    46 tiles in 6 chunks), must give the same PCM: the fused kernel is bit-compatible by construction, chunking only
+    changes which GEMM variants the sizes select."""
+    import subprocess
+    res = {}
+    for name, env in (("default", {}), ("two_kernels", {"DCS_MASK_OLA": "0"}), ("chunks", {"DCS_GENERIC_CHUNK": "8"})):
+        f = str(tmp_path / (name + ".npy"))
+        child_env = dict(os.environ)
+        child_env.update(env)
+        r = subprocess.run([sys.executable, "-c", _WHOLE_PATH_CHILD, ROOT, f, arch, "1024", str(ov)], env=child_env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-800:])
+        res[name] = np.load(f)
+    assert np.max(np.abs(res["default"])) > 1e-3
+    assert np.array_equal(res["default"], res["two_kernels"])
+    assert np.max(np.abs(res["default"] - res["chunks"])) < 5e-6
+
+
 @pytest.mark.parametrize("arch,N,ov,clips,seconds", [("ikala", 1024, 20, 3, 1.1), ("bach10", 1024, 25, 2, 0.9)])
 def test_separate_batch_of_the_generic_graphs_equals_clip_by_clip(arch, N, ov, clips, seconds):
     """dcs_separate_batch for the ikala / bach10 graphs: equal-length clips share the launches -- one STFT / iSTFT
