@@ -10,7 +10,10 @@ import os
 import re
 import sys
 
-KEYS = ("final_bf16x3_kernel", "deconv2_stream_bf16_kernel", "g_split_kernel", "final_kernel", "deconv2_stream_kernel",
+KEYS = ("final_bf16x3_kernel", "deconv2_stream_bf16_kernel", "g_split_kernel", "istft_seq_kernel", "gemm_bf16x3_skinny_kernel",
+        "gemm_bf16x3_kernel", "gemm_pack_bq_kernel", "slabconv_ps_kernel", "slabconv_mx_kernel", "colconv_deconv1_fused_kernel",
+        "colconv_wreg_gather_kernel", "colconv_wreg_scatter_kernel", "conv1_mfma_kernel", "deconv1_mfma_kernel",
+        "conv1_reg_kernel", "mask_ola_kernel", "final_kernel", "deconv2_stream_kernel",
         "deconv2_kernel", "istft_wave_kernel", "istft_fused_kernel", "gemm_rows_splitk_kernel", "gemm_ksplit_reduce_kernel",
         "gemm_rows_kernel", "stft_forward_wave_kernel", "stft_forward_kernel", "slabconv_kernel", "colconv_f16_kernel",
         "colconv_kernel", "deconv1_reg_kernel", "deconv1_kernel", "conv1_kernel", "unpool_kernel", "pool_kernel",
