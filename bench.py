@@ -16,12 +16,14 @@ the PCM of all ranks is all-gathered over RCCL inside the timed region.
 A 32-tile batch holds 0.57 GFLOP -- 3.6 us of the chip's f32 peak -- spread over dependent
 kernels, so one batch at a time leaves the GPU mostly idle (`single_stream` reports that regime:
 one batch per launch, one stream).  Steps are independent, therefore the K steps of a round are
-cut into launch groups of about `--clips-per-launch` (16) batches that share one set of kernel
+cut into launch groups of about `--clips-per-launch` (32) batches that share one set of kernel
 launches (dcs_separate_batch: every batch is tiled, cross-faded and inverted exactly as if it
 were alone) and `--streams S` (default 3) such groups are in flight on S HIP streams, each with
 its own libdcs context, plan, model handle and buffers -- the way a batch-of-files server overlaps
 requests.  K steps are always K batches; the groups of a round differ in size by at most one
-batch, so the launch shape does not depend on how K divides by 16.
+batch, so the launch shape does not depend on how K divides by the group size.  (Group size, 3 streams, MI355X,
+profiles/r02_g_group_size_sweep.txt: 14 -> 20.2 M frames/s, 16 -> 20.7, 24 -> 21.9, 32 -> 23.2, 48 -> 23.8, 64 -> 24.6;
+32 batches = 1024 tiles = a 68 s clip's worth per launch.)
 
 Timing: a *round* is EXACTLY K steps bracketed by a barrier + torch.cuda.synchronize() on both
 sides (max over ranks).  Rounds are repeated until `--min-time` (0.25 s) has been timed; `value`
@@ -107,7 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--tiles", type=int, default=32, help="tiles per GPU per step (BASELINE configs[1]: 32)")
     ap.add_argument("--frame-size", type=int, default=2048)
-    ap.add_argument("--clips-per-launch", type=int, default=16,
+    ap.add_argument("--clips-per-launch", type=int, default=32,
                     help="target number of independent 32-tile batches that share one set of kernel launches "
                          "(dcs_separate_batch); every batch still counts as one step")
     ap.add_argument("--streams", type=int, default=3, help="launch groups in flight per GPU (HIP streams)")
