@@ -105,7 +105,7 @@ def time_cpu(fn, min_seconds, max_reps=1000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=384)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--tiles", type=int, default=32, help="tiles per GPU per step (BASELINE configs[1]: 32)")
     ap.add_argument("--frame-size", type=int, default=2048)

@@ -74,7 +74,13 @@ def main():
     if fin:
         doc["final_kernel_4096_tiles"] = traffic["final_bf16x3_kernel@grid_threads=%d" % fin[-1]]
         if len(fin) >= 2:
-            doc["final_kernel_16x32_tiles"] = traffic["final_bf16x3_kernel@grid_threads=%d" % fin[0]]
+            # the launch group of the counters run: bench.py looks the record up as final_kernel_<batches>x<tiles>_tiles
+            g0 = 16
+            try:
+                g0 = int(cfg["config"]["launch_groups_per_round"][0])
+            except Exception:
+                pass
+            doc["final_kernel_%dx32_tiles" % g0] = traffic["final_bf16x3_kernel@grid_threads=%d" % fin[0]]
     small = sorted(g for (kk, g) in fetch if kk == "final_kernel")
     if small:
         doc["final_kernel_32_tiles"] = traffic["final_kernel@grid_threads=%d" % small[0]]
