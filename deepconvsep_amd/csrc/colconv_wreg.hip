@@ -18,8 +18,10 @@
 //   scatter (forward: 30 input rows, 11 output rows): all output rows accumulate in registers while the input rows
 //           stream through a ring of kAhead rows in flight.
 // MFMA work: 220 (row, tap) pairs x 2 per unit either way = 440 MFMAs of 16 cycles; 668 images x 32 units over 1024
-// SIMDs is 21 units per wave, 0.06 ms at the matrix pipe's rate against 0.93 (transpose) / 0.27 ms (forward) measured
-// for the LDS kernel on the Bach10 leg (profiles/r02_d_bench_legs.json).
+// SIMDs is 21 units per wave, 0.06 ms at the matrix pipe's rate.  Measured on the Bach10 leg: the LDS kernel 0.93
+// (transpose) / 0.27 ms (forward), these two 0.73 / 0.15 ms -- the transpose cannot ISSUE its 1.2 GB of 4-byte-aligned
+// 16-byte stores any faster (profiles/r02_e_pmc_legs.txt), which is why the default for the single-channel graph is the
+// fused kernel at the end of this file; the gather form remains for the 4-channel graph with the f16 switch on.
 #include <string.h>
 
 #include "dcs_internal.h"
