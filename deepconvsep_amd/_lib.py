@@ -76,6 +76,9 @@ def load():
     proto("dcs_model_destroy", i32, vp)
     proto("dcs_model_num_sources", i32, vp)
     proto("dcs_model_set_conv_precision", i32, vp, i32)
+    proto("dcs_model_set_latency_stages", i32, vp, i32)
+    proto("dcs_lat_pack_b_host", i64, vp, i32, i32, i32, i32, i32, vp, i64)
+    proto("dcs_lat_pack_deconv2_host", i64, vp, i32, vp, i64)
     proto("dcs_model_out_channels", i32, vp)
     proto("dcs_model_final_kernel", i32, vp, i64, i64, i32)
     proto("dcs_model_forward_masked", i32, vp, vp, i64, i32, i32, vp)

@@ -1,0 +1,796 @@
+// One-batch ("latency") kernels of the DSD separation path for gfx950 -- see dsd_lat.h.
+//
+// The reference runs its network once per batch of 32 tiles (examples/dsd100/separate_dsd.py:296-298).  One such batch
+// is ~190 STFT frames: every layer is a few MFLOP, the whole step 0.57 GFLOP.  The throughput kernels (gemm.hip, dsd.hip,
+// dsd_bf16x3.hip, fft_wave.hip) loop over K tiles / covering tiles / frames inside a wave; at this size each of those
+// loops is a chain of dependent memory latencies and the eight launches took 70 us.  Here every kernel is one round of
+// global loads, one short burst of arithmetic, one round of stores:
+//
+//   lat_stft_kernel     one workgroup per frame: window, N/2-point complex FFT in LDS, |X|/sqrt(N) and X/|X|
+//                       (compute_file, transform.py:224-252,277-335)
+//   lat_gemm_kernel     conv1 / conv2 / bottleneck / per-source dense layers (separate_dsd.py:198-221): one 16 x 16 output
+//                       block per workgroup, K split over up to 16 waves, B pre-packed in MFMA fragment order so that a
+//                       wave's whole B operand is a few 1 KB loads
+//   lat_deconv2_kernel  InverseLayer(., l_conv2) (:211,217,223): (tile, branch, 8 channels) per workgroup, GEMM + col2im,
+//                       writes the f32 G and / or the three bf16 planes the final kernel multiplies
+//   lat_final_kernel    InverseLayer(., l_conv1) + bias + rectify + soft mask (:212-271) + overlapadd_multi
+//                       (util.py:297-327): 16 frames x 64 bins per workgroup, ALL covering tiles staged in LDS at once
+//                       (115 KB), bf16 MFMA on three-way split operands (dsd_bf16x3.hip's arithmetic)
+//   lat_istft_kernel    compute_inverse + istft_norm (transform.py:254-274,337-396): one workgroup per (source, hop
+//                       block), the N/hop frames that overlap the block are transformed by N/hop thread groups in
+//                       parallel and added in frame order
+#include "dsd_lat.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------ sliced-K GEMM
+template <int J>
+__global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
+    __shared__ float red[16 * 4 * 64];
+    const int tid = threadIdx.x;
+    const int s = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 16, cb = blockIdx.y;
+    const int row = m0 + fi;
+    const bool row_ok = row < g.M;
+    const int slice_len = g.slice_len;
+    const float* a_ptr = g.A + (int64_t)(row_ok ? row : 0) * g.a_row_stride + s * slice_len + 4 * kq;
+    const f32x4* b_ptr = reinterpret_cast<const f32x4*>(g.Bp) + ((int64_t)(s * g.n_cb + cb) * J) * 64 + lane;
+    f32x4 a[J], b[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int kl = 16 * j + 4 * kq;
+        const bool ok = row_ok && kl < slice_len && s * slice_len + kl < g.K;
+        a[j] = ok ? *reinterpret_cast<const f32x4*>(a_ptr + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b[j] = b_ptr[j * 64];
+    }
+    const float sc = g.a_scale;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * a[j][0], b[j][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * a[j][1], b[j][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * a[j][2], b[j][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * a[j][3], b[j][3], acc1, 0, 0, 0);
+    }
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(s * 4 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    if (tid < 256) {
+        const int l = tid & 63, e = tid >> 6;
+        const int nw = (int)(blockDim.x >> 6);
+        float sum = 0.f;
+        for (int w = 0; w < nw; ++w) sum += red[(w * 4 + e) * 64 + l];   // slice order: deterministic
+        const int col = cb * 16 + (l & 15);
+        const int r = m0 + (l >> 4) * 4 + e;
+        if (r < g.M && col < g.n_store) {
+            float v = sum + g.bias[col];
+            if (g.relu) v = fmaxf(v, 0.f);
+            g.C[(int64_t)r * g.ldc + col] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ transposed conv2
+constexpr int kPsStride = 20;                     // floats per skewed row: 16 taps + 4 (rows stay 16-byte aligned)
+constexpr int kPsChan = 32 * kPsStride;           // 31 rows t' + dt used
+__device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+// P[t'][dt] = sum_co D[t'][co] W2c[co][ci][dt]  (one 16 x 16 block per channel ci: row = t', column = tap),
+// G[t][ci] = sum_dt P[t - dt][dt]: the block is written skewed, Ps[t' + dt][dt], so the col2im sum is a row sum in tap
+// order (the order of deconv2_kernel in dsd.hip).
+__global__ __launch_bounds__(256) void lat_deconv2_kernel(const float* __restrict__ D, const float* __restrict__ Wp,
+                                                          float* __restrict__ G, u32x4* __restrict__ Gs) {
+    __shared__ __attribute__((aligned(16))) float Ps[4 * 2 * kPsChan];
+    __shared__ __attribute__((aligned(16))) float Gl[30 * 8];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int64_t item = blockIdx.x;
+    const int grp = blockIdx.y;
+    const float* Dp = D + item * (16 * 52) + fi * 52 + 4 * kq;
+    f32x4 a[4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[j] = *reinterpret_cast<const f32x4*>(Dp + 16 * j);
+    a[3] = kq == 0 ? *reinterpret_cast<const f32x4*>(Dp + 48) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 b[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ci = grp * 8 + wave * 2 + c;
+        const f32x4* bp = reinterpret_cast<const f32x4*>(Wp) + (int64_t)ci * 4 * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[c][j] = bp[j * 64];
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][e], b[c][j][e], acc[c], 0, 0, 0);
+    float* Pw = Ps + wave * 2 * kPsChan;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Pw[c * kPsChan + (kq * 4 + e + fi) * kPsStride + fi] = acc[c][e];
+    __syncthreads();
+    {
+        const int c = lane >> 5, t = lane & 31;
+        if (t < 30) {
+            const f32x4* rowp = reinterpret_cast<const f32x4*>(Pw + c * kPsChan + t * kPsStride);
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 x = rowp[q];
+                v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 15; ++dt) {
+                const int tp = t - dt;
+                sum += (tp >= 0 && tp < 16) ? v[dt] : 0.f;   // entries no (t', dt) maps to were never written: selected away
+            }
+            Gl[t * 8 + wave * 2 + c] = sum;
+        }
+    }
+    __syncthreads();
+    if (tid < 30) {
+        const int t = tid;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(Gl + t * 8), x1 = *reinterpret_cast<const f32x4*>(Gl + t * 8 + 4);
+        const int64_t rowi = (item * 7 + grp) * 30 + t;
+        if (G) {
+            *reinterpret_cast<f32x4*>(G + rowi * 8) = x0;
+            *reinterpret_cast<f32x4*>(G + rowi * 8 + 4) = x1;
+        }
+        if (Gs) {
+            // x = plane0 + plane1 + plane2 exactly (truncation split), as g_split_kernel in dsd_bf16x3.hip
+            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            unsigned pl[3][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned h = bf_trunc(v[j]);
+                const float r1 = v[j] - __uint_as_float(h);
+                const unsigned m = bf_trunc(r1);
+                const float r2 = r1 - __uint_as_float(m);
+                pl[0][j] = h; pl[1][j] = m; pl[2][j] = bf_trunc(r2);
+            }
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) {
+                u32x4 w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = (pl[q3][2 * q] >> 16) | (pl[q3][2 * q + 1] & 0xffff0000u);
+                Gs[rowi * 3 + q3] = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ final kernel
+constexpr int kRowLds = 25;      // LDS row stride in 16-byte units (as final_bf16x3_kernel)
+constexpr int kNgg = 7;
+constexpr int kLatMaxM = 8;      // covering tiles per frame the LDS holds at once (6 for overlap 25 / stride 5)
+constexpr int kFinNbr = 3;
+constexpr int kFinABuf = kFinNbr * 16 * kRowLds;   // 16-byte pieces per covering tile
+
+__device__ __forceinline__ f32x4 mma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float imaxf(float x, float lo) {   // max on the bit patterns: no canonicalising v_max
+    const int xi = __float_as_int(x), li = __float_as_int(lo);
+    return __int_as_float(xi > li ? xi : li);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NBR = kFinNbr, NSL = 4, slots = NBR * 16 * 3 * kNgg;   // 1008 pieces per covering tile
+    const int mmax = a.mmax;
+    u32x4* As = reinterpret_cast<u32x4*>(smem);
+    float* up_t = reinterpret_cast<float*>(As + mmax * kFinABuf);
+    float* down_t = up_t + kLatMaxM * 16;
+    int* meta_k0 = reinterpret_cast<int*>(down_t + kLatMaxM * 16);
+    int* meta_j0 = meta_k0 + 16;
+    int* meta_mlim = meta_j0 + 16;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int row0 = (int)blockIdx.y * 16;
+    const int colw = (int)blockIdx.x * 64 + wave * 16;
+    const int col = colw + fi;
+    const int tc = a.tc, st = a.st, ov = a.ov;
+    const int n = (int)a.n, rows = (int)a.rows;
+
+    // rows of this group: owner tile k0 (the first one the reference's sequential loop writes the frame from), its row
+    // j0 there, the later tiles k0 + m blend in at row j0 - m * st  (util.py:311-326; same bookkeeping as dsd.hip)
+    if (tid < 16 * mmax) {
+        const int i = tid & 15, m = tid >> 4;
+        const int r = row0 + i;
+        int k0 = 0, j0 = -1;
+        if (r < rows) {
+            int kk = (r < ov) ? 0 : (int)((unsigned)(r - ov) / (unsigned)st);
+            if (kk > n - 1) kk = n - 1;
+            const int jj = r - kk * st;
+            if (jj < tc) {
+                k0 = kk;
+                j0 = jj;
+            }
+        }
+        if (m == 0) {
+            meta_k0[i] = k0;
+            meta_j0[i] = j0;
+            int lim = -1;
+            if (j0 >= 0) {
+                lim = (int)((unsigned)j0 / (unsigned)st);
+                if (lim > n - 1 - k0) lim = n - 1 - k0;
+            }
+            meta_mlim[i] = lim;
+        }
+        const int j = j0 - m * st;
+        const bool valid = j0 >= 0 && j >= 0 && k0 + m < n;
+        float up = 0.f, down = 1.f;
+        if (m == 0) {
+            up = valid ? 1.f : 0.f;
+            down = 0.f;
+        } else if (valid) {
+            up = a.rise[j];
+            down = a.rise[ov - 1 - j];
+        }
+        up_t[m * 16 + i] = up;
+        down_t[m * 16 + i] = down;
+    }
+
+    const bool live = colw < a.F;
+    const u32x4* Bpk = reinterpret_cast<const u32x4*>(a.Bpk) + (col * 24 + kq);
+    u32x4 breg[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) breg[p][kb] = live ? Bpk[(p * 2 + kb) * 4] : u32x4{0u, 0u, 0u, 0u};
+
+    const int rows_here = rows - row0 < 16 ? rows - row0 : 16;
+    const float* mix0 = a.mix + (int64_t)row0 * a.mix_ld;
+    f32x4 mixv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ri = kq * 4 + e;
+        float mv = 0.f;
+        if (ri < rows_here && col < a.F) mv = mix0[ri * (int)a.mix_ld + col];
+        mixv[e] = a.mix_scale * mv;
+    }
+    const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
+    const float eps_r = 5e-19f;
+
+    __syncthreads();
+
+    // staging plan (final_bf16x3_kernel's): the A set of a covering tile is [3 branches][16 rows][3 planes][7 channel
+    // groups] 16-byte pieces; every slot is loaded for every covering tile with the tile index clamped to the last one
+    // that has a weight on the slot's row (finite values the epilogue multiplies by up = 0)
+    const int m_delta = (NBR * kNgg * tc - st) * 3;
+    const int kbase = meta_k0[0];
+    const u32x4* gbase = reinterpret_cast<const u32x4*>(a.Gs) + (int64_t)kbase * NBR * kNgg * tc * 3;
+    int goff[NSL], dst[NSL], mlim[NSL];
+    bool in_slot[NSL];
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+        const int idx = tid + u * 256;
+        const int i = idx & 15, sp = idx >> 4;
+        const int s = sp / (3 * kNgg), pg = sp - s * (3 * kNgg);
+        const int plane = pg / kNgg, g = pg - plane * kNgg;
+        const bool in = idx < slots;
+        in_slot[u] = in;
+        const int lim = in ? meta_mlim[i] : -1;
+        const int j0 = lim >= 0 ? meta_j0[i] : 0;
+        const int dk = lim >= 0 ? meta_k0[i] - kbase : 0;
+        mlim[u] = lim >= 0 ? lim : 0;
+        dst[u] = (s * 16 + i) * kRowLds + plane * 8 + g;
+        goff[u] = (((dk * NBR + s) * kNgg + g) * tc + j0) * 3 + plane;
+    }
+    u32x4 pre[kLatMaxM][NSL];
+#pragma unroll
+    for (int mm = 0; mm < kLatMaxM; ++mm) {
+        if (mm < mmax) {
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (in_slot[u]) {
+                    const int q = mm < mlim[u] ? mm : mlim[u];
+                    v = gbase[goff[u] + q * m_delta];
+                }
+                pre[mm][u] = v;
+            }
+        }
+    }
+    for (int idx = tid; idx < mmax * NBR * 16 * 3; idx += 256) {   // K channels 56..63 of every row: zero
+        const int buf = idx / (NBR * 16 * 3), r = idx - buf * (NBR * 16 * 3);
+        As[buf * kFinABuf + (r / 3) * kRowLds + (r % 3) * 8 + 7] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int mm = 0; mm < kLatMaxM; ++mm) {
+        if (mm < mmax) {
+#pragma unroll
+            for (int u = 0; u < NSL; ++u)
+                if (in_slot[u]) As[mm * kFinABuf + dst[u]] = pre[mm][u];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    f32x4 res[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) res[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < mmax; ++m) {
+        const u32x4* Ab = As + m * kFinABuf + fi * kRowLds + kq;
+        u32x4 af[NBR][3][2];
+#pragma unroll
+        for (int s = 0; s < NBR; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) af[s][p][kb] = Ab[s * 16 * kRowLds + p * 8 + kb * 4];
+        f32x4 acc[NBR];
+        acc[0] = f32x4{bias0, bias0, bias0, bias0};
+        acc[1] = f32x4{bias1, bias1, bias1, bias1};
+        acc[2] = f32x4{bias2, bias2, bias2, bias2};
+        // smallest terms first (the order of final_bf16x3_kernel); the three branches alternate so that no MFMA waits
+        // for the one before it
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < NBR; ++s) acc[s] = mma_bf(af[s][2][kb], breg[0][kb], acc[s]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < NBR; ++s) acc[s] = mma_bf(af[s][0][kb], breg[2][kb], acc[s]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < NBR; ++s) acc[s] = mma_bf(af[s][1][kb], breg[1][kb], acc[s]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < NBR; ++s) acc[s] = mma_bf(af[s][1][kb], breg[0][kb], acc[s]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < NBR; ++s) acc[s] = mma_bf(af[s][0][kb], breg[1][kb], acc[s]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < NBR; ++s) acc[s] = mma_bf(af[s][0][kb], breg[0][kb], acc[s]);
+        const f32x4 up4 = *reinterpret_cast<const f32x4*>(up_t + m * 16 + kq * 4);
+        const f32x4 down4 = *reinterpret_cast<const f32x4*>(down_t + m * 16 + kq * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = acc[0][e], x1 = acc[1][e], x2 = acc[2][e];
+            const float x3 = x1 + (bias3 - bias1);      // the 4th output re-uses the 2nd dense layer (separate_dsd.py:228)
+            const float lo = MODE == 0 ? eps_r : 0.f;
+            const float p0 = imaxf(x0, lo), p1 = imaxf(x1, lo), p2 = imaxf(x2, lo), p3 = imaxf(x3, lo);
+            const float mu = mixv[e] * up4[e];
+            float den = ((p0 + p1) + p2) + p3;
+            if (MODE != 0) den += eps_r;
+            const float w = __builtin_amdgcn_rcpf(den) * mu;
+            res[0][e] = fmaf(down4[e], res[0][e], p0 * w);
+            res[1][e] = fmaf(down4[e], res[1][e], p1 * w);
+            res[2][e] = fmaf(down4[e], res[2][e], p2 * w);
+            res[3][e] = fmaf(down4[e], res[3][e], p3 * w);
+        }
+    }
+    if (col < a.F) {
+        float* out0 = a.out + (int64_t)row0 * a.out_ld + col;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ri = kq * 4 + e;
+                if (ri < rows_here) out0[c * a.out_src_stride + ri * a.out_ld] = res[c][e];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ FFT in LDS
+// w(j) = exp(DIR * 2 pi i j / N), 0 <= j < N, from the half-circle table tw[0..M] (forward sign), N = 2 M
+template <int DIR>
+__device__ __forceinline__ float2 tw_at(const float2* tw, int j, int M) {
+    float2 w;
+    if (j <= M) {
+        w = tw[j];
+    } else {
+        w = tw[j - M];
+        w.x = -w.x;
+        w.y = -w.y;
+    }
+    if (DIR > 0) w.y = -w.y;
+    return w;
+}
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// complex FFT of length M = 2^LOG2M by one group of 256 threads (gt = index in the group), Stockham radix 4 (+ one
+// radix-2 pass when LOG2M is odd), unscaled, natural order.  EVERY thread of the workgroup calls it (barriers inside);
+// returns the buffer that holds the result.
+template <int LOG2M, int DIR>
+__device__ __forceinline__ float2* lat_fft(float2* a, float2* b, const float2* tw, int gt) {
+    constexpr int M = 1 << LOG2M;
+    int Ns = 1;
+#pragma unroll
+    for (int lg = 0; lg + 2 <= LOG2M; lg += 2) {
+        constexpr int quarter = M >> 2;
+        const int step = (2 * M) / (4 * Ns);
+        for (int j = gt; j < quarter; j += 256) {
+            const int k = j & (Ns - 1);
+            float2 v0 = a[j], v1 = a[j + quarter], v2 = a[j + 2 * quarter], v3 = a[j + 3 * quarter];
+            if (Ns > 1) {
+                v1 = cmul(v1, tw_at<DIR>(tw, k * step, M));
+                v2 = cmul(v2, tw_at<DIR>(tw, 2 * k * step, M));
+                v3 = cmul(v3, tw_at<DIR>(tw, 3 * k * step, M));
+            }
+            const float2 a02 = make_float2(v0.x + v2.x, v0.y + v2.y), s02 = make_float2(v0.x - v2.x, v0.y - v2.y);
+            const float2 a13 = make_float2(v1.x + v3.x, v1.y + v3.y), s13 = make_float2(v1.x - v3.x, v1.y - v3.y);
+            const float2 ym = make_float2(s02.x + s13.y, s02.y - s13.x);   // s02 - i s13
+            const float2 yp = make_float2(s02.x - s13.y, s02.y + s13.x);   // s02 + i s13
+            const int d = ((j - k) << 2) + k;
+            b[d] = make_float2(a02.x + a13.x, a02.y + a13.y);
+            b[d + Ns] = (DIR < 0) ? ym : yp;
+            b[d + 2 * Ns] = make_float2(a02.x - a13.x, a02.y - a13.y);
+            b[d + 3 * Ns] = (DIR < 0) ? yp : ym;
+        }
+        __syncthreads();
+        float2* t = a;
+        a = b;
+        b = t;
+        Ns <<= 2;
+    }
+    if (LOG2M & 1) {
+        constexpr int half = M >> 1;
+        const int step = (2 * M) / (2 * Ns);
+        for (int j = gt; j < half; j += 256) {
+            const int k = j & (Ns - 1);
+            const float2 v0 = a[j];
+            float2 v1 = a[j + half];
+            if (Ns > 1) v1 = cmul(v1, tw_at<DIR>(tw, k * step, M));
+            const int d = ((j - k) << 1) + k;
+            b[d] = make_float2(v0.x + v1.x, v0.y + v1.y);
+            b[d + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+        }
+        __syncthreads();
+        float2* t = a;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// forward: frame t = window * padded[t*hop : t*hop+N], padded = [N/2 zeros | audio | zeros] (transform.py:309-333);
+// mag = |X| / sqrt(N) (:244-245); unit = X / |X| = exp(j angle(X)), (1, 0) where X == 0 (np.angle(0) = 0)
+template <int LOG2M>
+__global__ __launch_bounds__(256) void lat_stft_kernel(const float* __restrict__ audio, int64_t L,
+                                                       const float* __restrict__ win, const float2* __restrict__ tw,
+                                                       float* __restrict__ mag, float* __restrict__ phase,
+                                                       float2* __restrict__ unit, int64_t ld, int hop, int64_t T,
+                                                       float sqrt_n, int vec) {
+    constexpr int M = 1 << LOG2M;
+    __shared__ float2 buf0[M];
+    __shared__ float2 buf1[M];
+    __shared__ float2 twl[M + 2];
+    const int tid = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    float* mrow = mag + t * ld;
+    float* prow = phase ? phase + t * ld : nullptr;   // angle(X) for the transform-API outputs only (transform.py:247)
+    float2* urow = unit + t * ld;
+    if (t >= T) {   // rows past the last frame: zeros (zero-padding tiler, util.py:233)
+        for (int k = tid; k < ld; k += 256) {
+            mrow[k] = 0.f;
+            if (prow) prow[k] = 0.f;
+            urow[k] = make_float2(1.f, 0.f);
+        }
+        return;
+    }
+    for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
+    const int64_t base = t * (int64_t)hop - M;
+    const float2* w2 = reinterpret_cast<const float2*>(win);
+    for (int m = tid; m < M; m += 256) {
+        const int64_t p = base + 2 * m;
+        float x0 = 0.f, x1 = 0.f;
+        if (vec && p >= 0 && p + 1 < L) {
+            const float2 x = *reinterpret_cast<const float2*>(audio + p);
+            x0 = x.x;
+            x1 = x.y;
+        } else {
+            if (p >= 0 && p < L) x0 = audio[p];
+            if (p + 1 >= 0 && p + 1 < L) x1 = audio[p + 1];
+        }
+        const float2 w = w2[m];
+        buf0[m] = make_float2(x0 * w.x, x1 * w.y);
+    }
+    __syncthreads();
+    const float2* Z = lat_fft<LOG2M, -1>(buf0, buf1, twl, tid);
+    for (int k = tid; k <= M; k += 256) {
+        const float2 zk = Z[k & (M - 1)];
+        const float2 zm = Z[(M - k) & (M - 1)];
+        // E = (zk + conj(zm))/2 ; O = -i (zk - conj(zm))/2 ; X = E + w^k O
+        const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+        const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+        const float2 w = twl[k];
+        const float xr = er + (w.x * orr - w.y * oi);
+        const float xi = ei + (w.x * oi + w.y * orr);
+        const float ax = sqrtf(xr * xr + xi * xi);
+        mrow[k] = ax / sqrt_n;
+        if (prow) prow[k] = atan2f(xi, xr);
+        urow[k] = (ax > 0.f) ? make_float2(xr / ax, xi / ax) : make_float2(1.f, 0.f);
+    }
+    for (int k = M + 1 + tid; k < ld; k += 256) {   // row padding
+        mrow[k] = 0.f;
+        if (prow) prow[k] = 0.f;
+        urow[k] = make_float2(1.f, 0.f);
+    }
+}
+
+// inverse + overlap-add.  Workgroup (b, s): output samples [b*hop, (b+1)*hop) of source s = padded positions of hop block
+// h = b + R/2; the R = N/hop frames t = h-R+1 .. h overlap it.  Thread group q transforms frame h-R+1+q
+// (X = mag/pre_div * sqrt(N) * unit, irfft through the packed N/2-point complex transform) and contributes its segment
+// R-1-q; the segments are added in frame order (the reference's accumulation order, transform.py:385-389), divided by
+// the sum of window^2 of the same frames (zeros -> 1, :392-394).
+template <int LOG2M, int R>
+__global__ __launch_bounds__(R * 256) void lat_istft_kernel(const float* __restrict__ sep, int64_t src_stride,
+                                                           const float2* __restrict__ unit, int64_t ld,
+                                                           const float* __restrict__ win, const float* __restrict__ wsq,
+                                                           const float2* __restrict__ tw, float* __restrict__ audio,
+                                                           int64_t n_out, int hop, int64_t T, float pre_div,
+                                                           float sqrt_n) {
+    constexpr int M = 1 << LOG2M;
+    constexpr int SEG = M / R;              // complex values (sample pairs) per hop block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* twl = reinterpret_cast<float2*>(smem);            // [M + 2]; the segments are collected here after the FFT
+    const int tid = threadIdx.x;
+    const int q = tid >> 8, gt = tid & 255;
+    float2* b0 = twl + (M + 2) + q * (2 * M + 2);
+    float2* b1 = b0 + M;                                      // [M + 2]: holds X[0..M] first
+    const int s = blockIdx.y;
+    const int64_t b = blockIdx.x;
+    const int64_t h = b + R / 2;
+    const int64_t t = h - (R - 1) + q;
+    const bool valid = t >= 0 && t < T;
+    for (int k = tid; k <= M; k += R * 256) twl[k] = tw[k];
+    {
+        const float* mrow = sep + (int64_t)s * src_stride + t * ld;
+        const float2* urow = unit + t * ld;
+        for (int k = gt; k <= M; k += 256) {
+            float2 x = make_float2(0.f, 0.f);
+            if (valid) {
+                const float am = (mrow[k] / pre_div) * sqrt_n;
+                const float2 u = urow[k];
+                x = make_float2(am * u.x, am * u.y);
+                if (k == 0 || k == M) x.y = 0.f;
+            }
+            b1[k] = x;
+        }
+    }
+    __syncthreads();
+    for (int k = gt; k < M; k += 256) {
+        const float2 xk = b1[k];
+        const float2 xm = b1[M - k];
+        // E = (xk + conj(xm))/2 ; D = (xk - conj(xm))/2 ; O = D * conj(w^k) ; Z = E + i O
+        const float er = 0.5f * (xk.x + xm.x), ei = 0.5f * (xk.y - xm.y);
+        const float dr = 0.5f * (xk.x - xm.x), di = 0.5f * (xk.y + xm.y);
+        const float2 w = twl[k];
+        const float orr = dr * w.x + di * w.y;
+        const float oi = di * w.x - dr * w.y;
+        b0[k] = make_float2(er - oi, ei + orr);
+    }
+    __syncthreads();
+    const float2* z = lat_fft<LOG2M, +1>(b0, b1, twl, gt);
+    const float inv_m = 1.f / (float)M;
+    float2* ola = twl;                                        // [R][SEG]: the twiddles are not read any more
+    {
+        const int seg = R - 1 - q;
+        const float2* w2 = reinterpret_cast<const float2*>(win);
+        for (int i = gt; i < SEG; i += 256) {
+            const float2 v = z[seg * SEG + i];
+            const float2 w = w2[seg * SEG + i];
+            ola[q * SEG + i] = make_float2((v.x * inv_m) * w.x, (v.y * inv_m) * w.y);
+        }
+    }
+    __syncthreads();
+    if (q == 0) {
+        const float2* wsq2 = reinterpret_cast<const float2*>(wsq);
+        float* dst = audio + (int64_t)s * n_out;
+        for (int i = gt; i < SEG; i += 256) {
+            float2 acc = make_float2(0.f, 0.f), norm = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int qq = 0; qq < R; ++qq) {
+                const int64_t tq = h - (R - 1) + qq;
+                if (tq >= 0 && tq < T) {
+                    const float2 f = ola[qq * SEG + i];
+                    const float2 ws = wsq2[(R - 1 - qq) * SEG + i];
+                    acc.x += f.x;
+                    acc.y += f.y;
+                    norm.x += ws.x;
+                    norm.y += ws.y;
+                }
+            }
+            if (norm.x == 0.f) norm.x = 1.f;
+            if (norm.y == 0.f) norm.y = 1.f;
+            const int64_t m0 = b * hop + 2 * i;
+            if (m0 < n_out) dst[m0] = acc.x / norm.x;
+            if (m0 + 1 < n_out) dst[m0 + 1] = acc.y / norm.y;
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side
+void dcs_lat_pack_b(const float* B, int ldb, int K, int n_cb, int slice_len, int n_slices, std::vector<float>* out) {
+    const int J = dcs_lat_j(slice_len);
+    out->assign((size_t)n_slices * n_cb * J * 64 * 4, 0.f);
+    for (int s = 0; s < n_slices; ++s)
+        for (int cb = 0; cb < n_cb; ++cb)
+            for (int j = 0; j < J; ++j)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int fi = lane & 15, kq = lane >> 4;
+                        const int kl = 16 * j + 4 * kq + e, k = s * slice_len + kl;
+                        if (kl < slice_len && k < K)
+                            (*out)[((((size_t)s * n_cb + cb) * J + j) * 64 + lane) * 4 + e] = B[(size_t)k * ldb + cb * 16 + fi];
+                    }
+}
+
+void dcs_lat_pack_deconv2(const float* Bw2s, int n_ci8, std::vector<float>* out) {
+    // B[k = co][column = tap dt] of channel ci = Bw2s[ci][dt][co]; k order 16 j + 4 kq + e, co < 52
+    out->assign((size_t)n_ci8 * 4 * 64 * 4, 0.f);
+    for (int ci = 0; ci < n_ci8; ++ci)
+        for (int j = 0; j < 4; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int fi = lane & 15, kq = lane >> 4;
+                    const int co = 16 * j + 4 * kq + e;
+                    if (co < 52) (*out)[(((size_t)ci * 4 + j) * 64 + lane) * 4 + e] = Bw2s[((size_t)ci * 16 + fi) * 52 + co];
+                }
+}
+
+// host-only views of the two packers for the CPU tests (tests/test_lat_cpu.py emulates the kernels' lane arithmetic
+// on their output)
+extern "C" int64_t dcs_lat_pack_b_host(const float* B, int ldb, int K, int n_cb, int slice_len, int n_slices, float* out,
+                                       int64_t out_len) {
+    if (!B || n_cb < 1 || slice_len < 4 || (slice_len & 3) || n_slices < 1) return DCS_EINVAL;
+    std::vector<float> v;
+    dcs_lat_pack_b(B, ldb, K, n_cb, slice_len, n_slices, &v);
+    if (out && out_len >= (int64_t)v.size()) memcpy(out, v.data(), v.size() * sizeof(float));
+    return (int64_t)v.size();
+}
+extern "C" int64_t dcs_lat_pack_deconv2_host(const float* Bw2s, int n_ci8, float* out, int64_t out_len) {
+    if (!Bw2s || n_ci8 < 1) return DCS_EINVAL;
+    std::vector<float> v;
+    dcs_lat_pack_deconv2(Bw2s, n_ci8, &v);
+    if (out && out_len >= (int64_t)v.size()) memcpy(out, v.data(), v.size() * sizeof(float));
+    return (int64_t)v.size();
+}
+
+int dcs_launch_lat_gemm(dcs_ctx* ctx, const DcsLatGemm& g, int tag) {
+    if (g.M <= 0) return DCS_OK;
+    const int J = dcs_lat_j(g.slice_len);
+    if (g.n_slices < 4 || g.n_slices > 16 || (g.slice_len & 3) || (g.K & 3) || (g.a_row_stride & 3) || J < 1 || J > 5)
+        DCS_FAIL(DCS_EINVAL, "lat_gemm: %d slices of %d", g.n_slices, g.slice_len);
+    const dim3 grid((unsigned)dcs_cdiv(g.M, 16), (unsigned)g.n_cb), block((unsigned)g.n_slices * 64);
+    DcsTimer tm(ctx, tag);
+    switch (J) {
+        case 1: hipLaunchKernelGGL(lat_gemm_kernel<1>, grid, block, 0, ctx->stream, g); break;
+        case 2: hipLaunchKernelGGL(lat_gemm_kernel<2>, grid, block, 0, ctx->stream, g); break;
+        case 3: hipLaunchKernelGGL(lat_gemm_kernel<3>, grid, block, 0, ctx->stream, g); break;
+        case 4: hipLaunchKernelGGL(lat_gemm_kernel<4>, grid, block, 0, ctx->stream, g); break;
+        default: hipLaunchKernelGGL(lat_gemm_kernel<5>, grid, block, 0, ctx->stream, g); break;
+    }
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+int dcs_launch_lat_deconv2(dcs_ctx* ctx, const float* D, const float* Wp, float* G, void* Gs, int64_t n_items) {
+    if (n_items <= 0) return DCS_OK;
+    DcsTimer tm(ctx, DCS_TAG_DECONV2);
+    hipLaunchKernelGGL(lat_deconv2_kernel, dim3((unsigned)n_items, 7), dim3(256), 0, ctx->stream, D, Wp, G,
+                       reinterpret_cast<u32x4*>(Gs));
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+bool dcs_lat_final_supported(const DsdFinalArgs& a) {
+    return a.Gs && a.Bpk && a.CI == 52 && a.tc == 30 && a.mmax >= 1 && a.mmax <= kLatMaxM && a.mask_mode < 2 &&
+           a.n_clips <= 1 && !a.clip_tab && (a.nbr == 0 || a.nbr == 3) && a.bias_half == 0 && a.rows < (1 << 24) &&
+           a.n < (1 << 24);
+}
+
+int dcs_launch_lat_final(dcs_ctx* ctx, const DsdFinalArgs& a) {
+    if (!dcs_lat_final_supported(a)) DCS_FAIL(DCS_EINVAL, "lat_final: unsupported launch");
+    if (a.rows <= 0) return DCS_OK;
+    const size_t lds = (size_t)a.mmax * kFinABuf * 16 + (2 * kLatMaxM * 16 + 48) * 4;
+    auto k0 = lat_final_kernel<0>;
+    auto k1 = lat_final_kernel<1>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)dcs_cdiv(a.F, 64), (unsigned)dcs_cdiv(a.rows, 16));
+    DcsTimer tm(ctx, DCS_TAG_FINAL);
+    if (a.mask_mode == 0)
+        hipLaunchKernelGGL(k0, grid, dim3(256), lds, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k1, grid, dim3(256), lds, ctx->stream, a);
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+bool dcs_lat_stft_supported(const dcs_stft* p) {
+    if (!p || (p->frame != 1024 && p->frame != 2048) || p->hop <= 0) return false;
+    const int R = p->frame / p->hop;
+    return R * p->hop == p->frame && (R == 2 || R == 4);
+}
+
+int dcs_launch_lat_stft(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
+                        int64_t rows_out, int64_t T) {
+    if (rows_out <= 0) return DCS_OK;
+    if (!dcs_lat_stft_supported(p)) DCS_FAIL(DCS_EINVAL, "lat_stft: frameSize %d / hop %d", p->frame, p->hop);
+    const int vec = (((uintptr_t)audio & 7) == 0 && (p->hop & 1) == 0) ? 1 : 0;   // sample pairs 8-byte aligned
+    const float sq = (float)sqrt((double)p->frame);
+    DcsTimer tm(p->ctx, DCS_TAG_STFT);
+    if (p->frame == 2048)
+        hipLaunchKernelGGL(lat_stft_kernel<10>, dim3((unsigned)rows_out), dim3(256), 0, p->ctx->stream, audio, L, p->win_f,
+                           p->tw_f, mag, phase, unit, ld, p->hop, T, sq, vec);
+    else
+        hipLaunchKernelGGL(lat_stft_kernel<9>, dim3((unsigned)rows_out), dim3(256), 0, p->ctx->stream, audio, L, p->win_f,
+                           p->tw_f, mag, phase, unit, ld, p->hop, T, sq, vec);
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+namespace {
+template <int LOG2M, int R>
+int launch_istft(dcs_stft* p, const float* sep, int64_t src_stride, const float2* unit, int64_t ld, int64_t T, int n_src,
+                 float pre_div, float* audio, int64_t n_out) {
+    constexpr int M = 1 << LOG2M;
+    const size_t lds = ((size_t)(M + 2) + (size_t)R * (2 * M + 2)) * sizeof(float2);
+    auto kern = lat_istft_kernel<LOG2M, R>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)dcs_cdiv(n_out, p->hop), (unsigned)n_src);
+    hipLaunchKernelGGL(kern, grid, dim3(R * 256), lds, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->wsq_f, p->tw_f,
+                       audio, n_out, p->hop, T, pre_div, (float)sqrt((double)p->frame));
+    return DCS_OK;
+}
+}  // namespace
+
+int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, const float2* unit, int64_t ld, int64_t T,
+                         int n_src, float pre_div, float* audio, int64_t n_out) {
+    if (T <= 0 || n_src <= 0 || n_out <= 0) return DCS_OK;
+    if (!dcs_lat_stft_supported(p)) DCS_FAIL(DCS_EINVAL, "lat_istft: frameSize %d / hop %d", p->frame, p->hop);
+    const int R = p->frame / p->hop;
+    DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
+    int rc;
+    if (p->frame == 2048)
+        rc = R == 4 ? launch_istft<10, 4>(p, sep, src_stride, unit, ld, T, n_src, pre_div, audio, n_out)
+                    : launch_istft<10, 2>(p, sep, src_stride, unit, ld, T, n_src, pre_div, audio, n_out);
+    else
+        rc = R == 4 ? launch_istft<9, 4>(p, sep, src_stride, unit, ld, T, n_src, pre_div, audio, n_out)
+                    : launch_istft<9, 2>(p, sep, src_stride, unit, ld, T, n_src, pre_div, audio, n_out);
+    tm.done();
+    DCS_CHECK(rc);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}

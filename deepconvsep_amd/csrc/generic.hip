@@ -1528,10 +1528,10 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         static const int reg1 = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
         const dim3 grid1((unsigned)dcs_cdiv(d.w1, kThreads), (unsigned)(n * tc));
         if (g->W1m && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1)) {
-        } else if (reg1 && d.kw1 <= 32 && d.sw1 == 4)
+        } else if (reg1 && d.nf1 == 30 && d.kw1 <= 32 && d.sw1 == 4)   // the register kernel is built for 30 filters
             hipLaunchKernelGGL((conv1_reg_kernel<30, 4>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, a1b, C,
                                tc, F, d.kw1, d.w1);
-        else if (reg1 && d.kw1 <= 32 && d.sw1 == 3)
+        else if (reg1 && d.nf1 == 30 && d.kw1 <= 32 && d.sw1 == 3)
             hipLaunchKernelGGL((conv1_reg_kernel<30, 3>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, a1b, C,
                                tc, F, d.kw1, d.w1);
         else

@@ -4,10 +4,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "dcs_internal.h"
 #include "dsd.h"
+#include "dsd_lat.h"
 #include "generic.h"
 
 namespace {
@@ -92,16 +94,24 @@ struct dcs_model {
     uint16_t* Bpk = nullptr;
     uint16_t* Bw2q = nullptr;
     void* Bdq = nullptr;   // per-source dense weights as bf16 planes (gemm_bf16x3.hip)
+    // one-batch ("latency") kernels, dsd_lat.hip: the GEMM B operands in MFMA fragment order, the transposed-conv2
+    // weights likewise; lat_stages = -1: automatic (all stages for one clip of at most lat_max_frames frames)
+    float *L1p = nullptr, *L2p = nullptr, *Lfcp = nullptr, *Ldp = nullptr, *Lw2p = nullptr;
+    int lat_slice1 = 0;
+    bool lat_ok = false;
+    int lat_stages = -1;
     DcsBuffer clip_tab;   // {samples, frames, tiles} per clip of a batch of different lengths (dcs_separate_ragged)
-    float* rise_d = nullptr;
-    int rise_ov = -1;
+    // cross-fade ramps np.linspace(0, 1, ov), one device table per overlap ever asked for; a table is never freed or
+    // re-allocated while the model lives (captured graphs of other call shapes keep pointing at theirs)
+    std::vector<std::pair<int, float*>> rise_tabs;
+    float* rise_d = nullptr;   // the table of the current call (set by ensure_rise)
     // ---- hipGraph of the fused step (dcs_separate): the 8 launches of one call replayed as one launch.
     // A graph is captured the second time the same call (same buffers, sizes, options) arrives.
     struct StepKey {
         const void* plan = nullptr; const void* audio = nullptr; const void* pcm = nullptr; const void* ws = nullptr;
-        int64_t L = -1, n_clips = 1, audio_stride = 0; int ov = 0, tiler = 0, eps = 0, tie = 0; float scale = 0.f;
+        int64_t L = -1, n_clips = 1, audio_stride = 0; int ov = 0, tiler = 0, eps = 0, tie = 0, lat = -1; float scale = 0.f;
         bool operator==(const StepKey& o) const {
-            return plan == o.plan && audio == o.audio && pcm == o.pcm && ws == o.ws && L == o.L && ov == o.ov &&
+            return lat == o.lat && plan == o.plan && audio == o.audio && pcm == o.pcm && ws == o.ws && L == o.L && ov == o.ov &&
                    tiler == o.tiler && eps == o.eps && tie == o.tie && scale == o.scale && n_clips == o.n_clips &&
                    audio_stride == o.audio_stride;
         }
@@ -125,7 +135,14 @@ struct dcs_model {
 namespace {
 
 int ensure_rise(dcs_model* m, int ov) {
-    if (m->rise_ov == ov) return DCS_OK;
+    for (const auto& t : m->rise_tabs)
+        if (t.first == ov) {
+            m->rise_d = t.second;
+            return DCS_OK;
+        }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (m->ctx->stream && hipStreamIsCapturing(m->ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        DCS_FAIL(DCS_EHIP, "ensure_rise: new overlap %d during a stream capture", ov);   // callers create it before capturing
     std::vector<float> r(ov > 0 ? ov : 1, 0.f);
     // np.linspace(0., 1.0, num=overlap)  (util.py:306): arange * (1/(ov-1)), last element = 1.0
     if (ov > 1) {
@@ -133,14 +150,11 @@ int ensure_rise(dcs_model* m, int ov) {
         for (int i = 0; i < ov; ++i) r[i] = (float)((double)i * step);
         r[ov - 1] = 1.0f;
     }
-    if (m->rise_d) {
-        DCS_HIP(hipStreamSynchronize(m->ctx->stream));
-        (void)hipFree(m->rise_d);
-        m->rise_d = nullptr;
-    }
-    DCS_HIP(hipMalloc((void**)&m->rise_d, r.size() * sizeof(float)));
-    DCS_HIP(hipMemcpy(m->rise_d, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
-    m->rise_ov = ov;
+    float* d = nullptr;
+    DCS_HIP(hipMalloc((void**)&d, r.size() * sizeof(float)));
+    DCS_HIP(hipMemcpy(d, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
+    m->rise_tabs.emplace_back(ov, d);
+    m->rise_d = d;
     return DCS_OK;
 }
 
@@ -286,6 +300,22 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
                     }
         DCS_CHECK(upload(&m->Bw2q, Bw2q));
     }
+    // one-batch kernels (dsd_lat.hip): built for the reference's DSD shapes (50 + 50 filters, time_context 30, 128 hidden units)
+    if (C == 1 && CI == 52 && CP == 52 && d.h2 == 16 && kh == 15 && m->tc == 30 && m->hid64 == 128 && d.n_fc == 3 && m->Bpk) {
+        std::vector<float> pk;
+        m->lat_slice1 = (int)dcs_round_up((m->K1 + 15) / 16, 4);
+        dcs_lat_pack_b(B1.data(), 64, m->K1, 4, m->lat_slice1, 16, &pk);
+        DCS_CHECK(upload(&m->L1p, pk));
+        dcs_lat_pack_b(B2.data(), 64, kh * CI, 4, CI, kh, &pk);
+        DCS_CHECK(upload(&m->L2p, pk));
+        dcs_lat_pack_b(Bfc.data(), m->hid64, d.h2 * CP, m->hid64 / 16, CP, d.h2, &pk);
+        DCS_CHECK(upload(&m->Lfcp, pk));
+        dcs_lat_pack_b(Bd.data(), m->nd64, m->hid64, m->nd64 / 16, 32, 4, &pk);
+        DCS_CHECK(upload(&m->Ldp, pk));
+        dcs_lat_pack_deconv2(Bw2s.data(), (int)dcs_round_up(CI, kDsdGch), &pk);
+        DCS_CHECK(upload(&m->Lw2p, pk));
+        m->lat_ok = true;
+    }
     return DCS_OK;
 }
 
@@ -300,15 +330,17 @@ struct DsdScratch {
 //   clips   : n_clips > 1 stacked clips of n tiles each (fused only); clip c's frames start at row c * clip_pitch
 //             (a multiple of st).  conv1 / conv2 simply run over all rows -- positions that straddle two clips are
 //             computed and never read -- and the bottleneck's A row of tile (c, k) is row c*clip_pitch + k*st.
+//   lat     : stage bits (dsd_lat.h) whose layer runs on the one-batch kernels of dsd_lat.hip (one clip, shared frames)
 int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, float a_scale, int64_t n,
                int64_t tile_row_stride /* st or tc */, bool shared_frames, const DsdScratch& w, int64_t n_clips = 1,
-               int64_t clip_pitch = 0) {
+               int64_t clip_pitch = 0, unsigned lat = 0) {
     const Dims& d = m->d;
     const int tc = m->tc, CI = m->CI, CP = m->CP;
     const int64_t BIG = (int64_t)1 << 40;
     const bool clips = n_clips > 1;
     if (clips && (!shared_frames || clip_pitch % tile_row_stride != 0 || n > 0x7fffffff))
         DCS_FAIL(DCS_EINVAL, "dsd_encode: bad clip batch");
+    if (lat && (clips || !shared_frames || !a_vec || !m->lat_ok)) DCS_FAIL(DCS_EINVAL, "dsd_encode: latency kernels need one clip");
     // conv1 + both biases  (separate_dsd.py:198-199)
     const int64_t n_rows1 = clips ? n_clips * clip_pitch : (shared_frames ? (n - 1) * tile_row_stride + tc : n * tc);
     DcsGemm g1{};
@@ -317,7 +349,14 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g1.C = w.H1; g1.ldc = CI; g1.c_gdiv = 1 << 30; g1.c_gmul = 0;
     g1.M = n_rows1; g1.n_cols = 64; g1.n_store = CI; g1.K = a_vec ? m->K1 : m->F; g1.relu = 0; g1.a_vec = a_vec;
     (void)BIG;
-    DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g1, DCS_TAG_CONV1));
+    if (lat & DCS_LAT_CONV1) {
+        DcsLatGemm q{};
+        q.A = rows_src; q.a_row_stride = lda; q.a_scale = a_scale; q.Bp = m->L1p; q.bias = m->bias1;
+        q.C = w.H1; q.ldc = CI; q.M = (int)n_rows1; q.n_store = CI; q.K = m->K1; q.slice_len = m->lat_slice1;
+        q.n_slices = 16; q.n_cb = 4; q.relu = 0;
+        DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_CONV1));
+    } else
+        DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g1, DCS_TAG_CONV1));
     // conv2 + both biases (separate_dsd.py:202-203): output row = position; its A row is kh consecutive H1 rows
     DcsGemm g2{};
     g2.A = w.H1; g2.lda = CI; g2.a_scale = 1.f;
@@ -327,7 +366,14 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g2.B = m->B2; g2.ldb = 64; g2.bias = m->bias2;
     g2.C = w.C2; g2.ldc = CP; g2.c_gdiv = 1 << 30; g2.c_gmul = 0;
     g2.n_cols = 64; g2.n_store = CP; g2.K = d.kh2 * CI; g2.relu = 0; g2.a_vec = 1;
-    DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g2, DCS_TAG_CONV2));
+    if (lat & DCS_LAT_CONV2) {
+        DcsLatGemm q{};   // the A row of position p is kh consecutive H1 rows = kh * CI contiguous floats: one slice per tap
+        q.A = w.H1; q.a_row_stride = CI; q.a_scale = 1.f; q.Bp = m->L2p; q.bias = m->bias2;
+        q.C = w.C2; q.ldc = CP; q.M = (int)g2.M; q.n_store = CP; q.K = d.kh2 * CI; q.slice_len = CI;
+        q.n_slices = d.kh2; q.n_cb = 4; q.relu = 0;
+        DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_CONV2));
+    } else
+        DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g2, DCS_TAG_CONV2));
     // bottleneck DenseLayer, rectify (separate_dsd.py:206): A row of tile k = h2 consecutive C2 rows
     DcsGemm g3{};
     g3.A = w.C2; g3.lda = (shared_frames ? tile_row_stride : d.h2) * (int64_t)CP; g3.a_gdiv = 1 << 30; g3.a_gmul = 0;
@@ -335,15 +381,31 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc;
     g3.C = w.Z; g3.ldc = m->hid64; g3.c_gdiv = 1 << 30; g3.c_gmul = 0;
     g3.M = n * n_clips; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
-    DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g3, DCS_TAG_FC));
+    if (lat & DCS_LAT_FC) {
+        DcsLatGemm q{};   // the A row of tile k is h2 consecutive C2 rows from row k * st: one slice per row
+        q.A = w.C2; q.a_row_stride = tile_row_stride * (int64_t)CP; q.a_scale = 1.f; q.Bp = m->Lfcp; q.bias = m->biasfc;
+        q.C = w.Z; q.ldc = m->hid64; q.M = (int)n; q.n_store = m->hid64; q.K = d.h2 * CP; q.slice_len = CP;
+        q.n_slices = d.h2; q.n_cb = m->hid64 / 16; q.relu = 1;
+        DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_FC));
+    } else
+        DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g3, DCS_TAG_FC));
     // per-source DenseLayers, rectify (separate_dsd.py:209,215,221)
     DcsGemm g4{};
     g4.A = w.Z; g4.lda = m->hid64; g4.a_gdiv = 1 << 30; g4.a_gmul = 0; g4.a_scale = 1.f;
     g4.B = m->Bd; g4.ldb = m->nd64; g4.bias = m->biasd; g4.Bq = m->Bdq;
     g4.C = w.D; g4.ldc = m->nd; g4.c_gdiv = 1 << 30; g4.c_gmul = 0;
     g4.M = n * n_clips; g4.n_cols = m->nd64; g4.n_store = m->nd; g4.K = m->hid64; g4.relu = 1; g4.a_vec = 1;
-    DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
+    if (lat & DCS_LAT_FC1X) {
+        DcsLatGemm q{};
+        q.A = w.Z; q.a_row_stride = m->hid64; q.a_scale = 1.f; q.Bp = m->Ldp; q.bias = m->biasd;
+        q.C = w.D; q.ldc = m->nd; q.M = (int)n; q.n_store = m->nd; q.K = m->hid64; q.slice_len = 32;
+        q.n_slices = 4; q.n_cb = m->nd64 / 16; q.relu = 1;
+        DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_FC1X));
+    } else
+        DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
     // InverseLayer(., l_conv2) (separate_dsd.py:211,217,223)
+    if (lat & DCS_LAT_DECONV2)   // f32 G only when a consumer reads it (the one-batch final kernel multiplies the planes)
+        return dcs_launch_lat_deconv2(m->ctx, w.D, m->Lw2p, ((lat & DCS_LAT_FINAL) && w.Gs) ? nullptr : w.G, w.Gs, n * d.n_fc);
     return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n * n_clips * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
                                   m->d2_gcols, w.Gs, m->Bw2q);
 }
@@ -452,9 +514,13 @@ extern "C" int dcs_model_create(dcs_ctx* ctx, int arch, int C, int tc, int F, co
 extern "C" int dcs_model_destroy(dcs_model* m) {
     if (!m) return DCS_OK;
     DCS_ON_DEVICE(m->ctx->device);
-    float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bw2s, m->Bfin, m->bout,
-                     m->rise_d};
+    float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bw2s, m->Bfin, m->bout};
     for (float* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& t : m->rise_tabs)
+        if (t.second) (void)hipFree(t.second);
+    float* lat[] = {m->L1p, m->L2p, m->Lfcp, m->Ldp, m->Lw2p};
+    for (float* p : lat)
         if (p) (void)hipFree(p);
     if (m->gen) dcs_generic_destroy(m->gen);
     for (auto& g : m->graphs)
@@ -473,6 +539,15 @@ extern "C" int dcs_model_set_conv_precision(dcs_model* m, int f16) {
     if (f16 && !m->gen)
         DCS_FAIL(DCS_EUNSUPPORTED, "the f16 MFMA conv path exists for the ikala / bach10 / score-informed graphs");
     if (m->gen) return dcs_generic_set_conv_f16(m->gen, f16);
+    return DCS_OK;
+}
+
+extern "C" int dcs_model_set_latency_stages(dcs_model* m, int stages) {
+    if (!m) DCS_FAIL(DCS_EINVAL, "dcs_model_set_latency_stages: null model");
+    if (stages < -1 || stages > DCS_LAT_ALL) DCS_FAIL(DCS_EINVAL, "dcs_model_set_latency_stages: %d", stages);
+    if (stages > 0 && !m->lat_ok)
+        DCS_FAIL(DCS_EUNSUPPORTED, "the one-batch kernels exist for the DSD graph (50 + 50 filters, time_context 30)");
+    m->lat_stages = stages;
     return DCS_OK;
 }
 
@@ -581,7 +656,18 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         const int64_t n_all = n * n_clips;
         // large launches run the final kernel on the bf16 matrix pipe with three-way split operands (dsd_bf16x3.hip):
         // deconv2 then writes the split planes of G itself
-        const bool split = m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode);
+        // one batch per call (the reference's predict_function2 shape): every stage on the short-chain kernels of
+        // dsd_lat.hip.  DCS_LAT=<stage bits> / dcs_model_set_latency_stages force a selection (A/B tests, profiling).
+        unsigned lat = 0;
+        if (m->lat_ok && n_clips == 1 && !clip_tab_d && dcs_lat_stft_supported(plan)) {
+            static const int env_mask = getenv("DCS_LAT") ? atoi(getenv("DCS_LAT")) : -1;
+            static const int64_t env_max = getenv("DCS_LAT_MAX_FRAMES") ? atoll(getenv("DCS_LAT_MAX_FRAMES")) : 640;
+            const int want = m->lat_stages >= 0 ? m->lat_stages : (env_mask >= 0 ? env_mask : (T <= env_max ? DCS_LAT_ALL : 0));
+            lat = (unsigned)want & DCS_LAT_ALL;
+            if ((ov + st - 1) / st + 1 > 8 || eps_mode > 1) lat &= ~(unsigned)DCS_LAT_FINAL;   // more covering tiles than the LDS holds
+            if (T >= (1 << 24)) lat = 0;
+        }
+        const bool split = (lat & DCS_LAT_FINAL) || (m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode));
         DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + dsd_scratch_bytes(m, n_all, rows1, rows2, split)));
         char* p = (char*)m->ws.ptr;
         float* mag = (float*)p; p += b_mag;
@@ -590,9 +676,12 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
         dsd_carve(m, p, n_all, rows1, rows2, &w, split);
-        DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,
-                                                    false, clip_tab_d));
-        DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows));
+        if (lat & DCS_LAT_STFT)
+            DCS_CHECK(dcs_launch_lat_stft(plan, audio_d, L, mag, phase, unit, ld, Trows, T));
+        else
+            DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,
+                                                        false, clip_tab_d));
+        DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows, lat));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
         a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
@@ -610,8 +699,13 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
             a.Bpk = m->Bpk;
             a.gs_clip_stride = n * m->d.n_fc * (int64_t)dsd_gs_pitch(m->CI, tc);
         }
-        DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
-        if (pcm_d)
+        if (lat & DCS_LAT_FINAL)
+            DCS_CHECK(dcs_launch_lat_final(m->ctx, a));
+        else
+            DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
+        if (pcm_d && (lat & DCS_LAT_ISTFT))
+            DCS_CHECK(dcs_launch_lat_istft(plan, sep, T * ld, unit, ld, T, S, scale, pcm_d, L));
+        else if (pcm_d)
             DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, T * ld, unit, Trows * ld, ld, T, S, n_clips, scale, pcm_d, L,
                                                         clip_tab_d, lens_h ? pcm_stride : 0));
         if (sep_out || mag_out || phase_out) {
@@ -648,7 +742,7 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     dcs_model::StepKey key;
     key.plan = plan; key.audio = audio_d; key.pcm = pcm_d; key.ws = m->ws.ptr; key.L = n_samples; key.ov = overlap;
     key.tiler = tiler; key.eps = eps_mode; key.tie = tie_mode; key.scale = scale;
-    key.n_clips = n_clips; key.audio_stride = audio_stride;
+    key.n_clips = n_clips; key.audio_stride = audio_stride; key.lat = m->lat_stages;
     const uint64_t now = ++m->step_clock;
     // graphs recorded against a workspace that has since been re-allocated point at freed memory: drop them
     for (auto& g : m->graphs)
@@ -683,6 +777,7 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     m->seen_stamp[seen_at] = 0;
     hipGraph_t graph = nullptr;
     int64_t nt = 0, nf = 0;
+    DCS_CHECK(ensure_rise(m, overlap));   // anything that may allocate or synchronise happens before the capture
     DCS_HIP(hipStreamBeginCapture(m->ctx->stream, hipStreamCaptureModeRelaxed));
     const int rc = separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr,
                                  nullptr, nullptr, 0, &nt, &nf, n_clips, audio_stride);
@@ -690,8 +785,8 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     if (rc != DCS_OK || ce != hipSuccess || !graph || m->ws.ptr != key.ws) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        if (rc != DCS_OK) return rc;
-        return eager();   // capture failed: run this call eagerly
+        return eager();   // capture failed (or the captured run reported an error): run this call eagerly; an error
+                          // the eager run hits as well is the one the caller gets
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

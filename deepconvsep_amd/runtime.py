@@ -243,6 +243,12 @@ class Network(object):
         code = int(self.ctx._lib.dcs_model_final_kernel(self._h, int(n_frames), int(n_clips), int(eps)))
         return {0: 'f32x64', 1: 'f32x128', 2: 'bf16x3'}.get(code)
 
+    def set_latency_stages(self, stages):
+        """Stages of the fused path that run on the one-batch kernels (``dcs_model_set_latency_stages``): -1 automatic,
+        0 none, else bits 1 STFT, 2 conv1, 4 conv2, 8 bottleneck, 16 per-source dense, 32 transposed conv2, 64 final,
+        128 iSTFT."""
+        _lib.check(self.ctx._lib.dcs_model_set_latency_stages(self._h, int(stages)))
+
     def set_conv_precision(self, dtype):
         """``'f16'``: conv2 and its transpose use f16-input / f32-accumulate MFMA (BASELINE config 3);
         ``'f32'`` (default): exact f32."""

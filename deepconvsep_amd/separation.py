@@ -201,10 +201,14 @@ class Separator(object):
         (empty, or too short for one tile) never join a shared launch; ``on_error='return'`` puts the exception the
         single-clip path raises for them into their slot of the result instead of raising it."""
         audios = [np.asarray(a) for a in audios]
-        for a in audios:
+        for i, a in enumerate(audios):
             if a.ndim != 1:
-                # reshape(-1) would interleave the channels of a [L, 2] array; mix down first (to_mono)
-                raise ValueError("separate_many takes mono clips ([L] arrays), got shape %r" % (a.shape,))
+                # [L, 1] / [1, L] mono arrays are flattened; reshape(-1) of a real [L, 2] array would interleave its
+                # channels: mix down first (to_mono)
+                if a.size == max(a.shape + (0,)):
+                    audios[i] = a.reshape(-1)
+                else:
+                    raise ValueError("separate_many takes mono clips ([L] arrays), got shape %r" % (a.shape,))
         out = [None] * len(audios)
         ragged_ok = (self.arch_name in ("dsd", "hiphop") and self.frameSize in (1024, 2048, 4096)
                      and self.frameSize % self.hopSize == 0 and self.hopSize % 2 == 0)
@@ -235,14 +239,26 @@ class Separator(object):
             stack = np.zeros((len(idx), max(lens)), dtype=np.float32)
             for b, i in enumerate(idx):
                 stack[b, :lens[b]] = audios[i]
-            dev = self.ctx.to_device(stack, np.float32)                                              # [B, Lmax]
-            if min(lens) == max(lens):
-                pcm = self.net.separate_batch(self.plan, dev, self.overlap, self.tiler, self.scale_factor, None,
-                                              self.tie_mode)
-            else:
-                pcm = self.net.separate_ragged(self.plan, dev, lens, self.overlap, self.tiler, self.scale_factor, None,
-                                               self.tie_mode)
-            pcm = self.ctx.to_host(pcm)
+            try:
+                dev = self.ctx.to_device(stack, np.float32)                                          # [B, Lmax]
+                if min(lens) == max(lens):
+                    pcm = self.net.separate_batch(self.plan, dev, self.overlap, self.tiler, self.scale_factor, None,
+                                                  self.tie_mode)
+                else:
+                    pcm = self.net.separate_ragged(self.plan, dev, lens, self.overlap, self.tiler, self.scale_factor,
+                                                   None, self.tie_mode)
+                pcm = self.ctx.to_host(pcm)
+            except Exception:
+                if on_error == 'raise':
+                    raise
+                # a failure of the shared launch (e.g. out of memory on a large group) must not discard the clips
+                # already separated: its members go through the single-clip path, each with its own outcome
+                for i in idx:
+                    try:
+                        out[i] = self.separate(audios[i])
+                    except Exception as exc:
+                        out[i] = exc
+                continue
             for b, i in enumerate(idx):
                 out[i] = pcm[b, :, :lens[b]].astype(np.float64)
         return out

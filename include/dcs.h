@@ -128,6 +128,21 @@ int dcs_model_num_sources(const dcs_model* m);
  * bf16 pipe with three-way split operands (f32-class), the activations between them never rounded below f32.  The ikala
  * graph (10 x 20 filters) takes the same slab kernel in either precision (one f16 plane instead of three bf16 planes). */
 int dcs_model_set_conv_precision(dcs_model* m, int f16);
+/* Which stages of dcs_separate run on the one-batch ("latency") kernels of csrc/dsd_lat.hip -- the shape of the
+ * reference's own call, predict_function2 on ONE batch of 32 tiles (separate_dsd.py:296-298), where a kernel's duration
+ * is its chain of dependent memory latencies.  stages = -1 (default): automatic, all of them for one clip of at most
+ * DCS_LAT_MAX_FRAMES (640) frames; 0: the throughput kernels; else a bit set: 1 STFT, 2 conv1, 4 conv2, 8 bottleneck,
+ * 16 per-source dense, 32 transposed conv2, 64 final (transposed conv1 + mask + cross-fade), 128 iSTFT.  Both families
+ * read and write the same buffers, so any mix is valid (tests compare each stage against the other family).  DSD graph
+ * only (DCS_EUNSUPPORTED otherwise). */
+int dcs_model_set_latency_stages(dcs_model* m, int stages);
+/* Testing aids (host only, no GPU): the weight re-layouts of the one-batch kernels.  dcs_lat_pack_b_host: B[K][ldb]
+ * (k-major) -> [slice][column block][j][lane][4], the order in which lane (fi = lane & 15, kq = lane >> 4) of wave
+ * `slice` feeds v_mfma_f32_16x16x4_f32: element e of piece j is B[slice * slice_len + 16 j + 4 kq + e][16 cb + fi].
+ * dcs_lat_pack_deconv2_host: Bw2s[ci][16 taps][52] -> [ci][j][lane][4] with column fi = tap.  Both return the number of
+ * floats of the packed array (and fill `out` when out_len is large enough) or a negative status. */
+int64_t dcs_lat_pack_b_host(const float* B, int ldb, int K, int n_cb, int slice_len, int n_slices, float* out, int64_t out_len);
+int64_t dcs_lat_pack_deconv2_host(const float* Bw2s, int n_ci8, float* out, int64_t out_len);
 
 /* predict_function2 (separate_dsd.py:273,298): tiles_d [n, C, tc, F] -> out_d [S, n, tc, F]
  * = soft-masked magnitudes of the S sources. */
