@@ -45,5 +45,8 @@ int dcs_launch_lat_final(dcs_ctx* ctx, const DsdFinalArgs& a);
 bool dcs_lat_stft_supported(const dcs_stft* p);
 int dcs_launch_lat_stft(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase /* nullable */, float2* unit,
                         int64_t ld, int64_t rows_out, int64_t T);
+// the inverse is two launches (every frame transformed once, then the overlap-add); frames: scratch of
+// dcs_lat_istft_scratch_bytes() bytes, [source][frame][frameSize] float32
+size_t dcs_lat_istft_scratch_bytes(const dcs_stft* p, int64_t T, int n_src);
 int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, const float2* unit, int64_t ld, int64_t T,
-                         int n_src, float pre_div, float* audio, int64_t n_out);
+                         int n_src, float pre_div, float* audio, int64_t n_out, float* frames);

@@ -15,10 +15,11 @@
 //                       writes the f32 G and / or the three bf16 planes the final kernel multiplies
 //   lat_final_kernel    InverseLayer(., l_conv1) + bias + rectify + soft mask (:212-271) + overlapadd_multi
 //                       (util.py:297-327): 16 frames x 64 bins per workgroup, ALL covering tiles staged in LDS at once
-//                       (115 KB), bf16 MFMA on three-way split operands (dsd_bf16x3.hip's arithmetic)
-//   lat_istft_kernel    compute_inverse + istft_norm (transform.py:254-274,337-396): one workgroup per (source, hop
-//                       block), the N/hop frames that overlap the block are transformed by N/hop thread groups in
-//                       parallel and added in frame order
+//                       (115 KB), bf16 MFMA on three-way split operands (dsd_bf16x3.hip's arithmetic), the covering
+//                       tiles of a frame folded in two halves by two waves
+//   lat_ifft_kernel     compute_inverse + istft_norm (transform.py:254-274,337-396), first half: one workgroup per
+//                       (source, frame), windowed time frames to a scratch buffer
+//   lat_ola_kernel      second half: the frames that cover a sample added in frame order, / sum of window^2
 #include "dsd_lat.h"
 
 #include <math.h>
@@ -31,10 +32,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// -DDCS_LAT_TRACE (scripts/build_exp.sh): thread 0 of the first and of the last workgroup of every launch stamps the
+// shader clock (s_memtime) at the marked points into a device buffer (lat_trace_dump); LAT_DRAIN waits for every
+// outstanding memory operation first, so that the stamp behind it dates the data's arrival, not the request.
+#ifdef DCS_LAT_TRACE
+__device__ unsigned long long lat_trace_buf[16 * 64];
+#define LAT_STAMP(kid, slot)                                                                              \
+    do {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        if (threadIdx.x == 0) {                                                                           \
+            const bool first_ = blockIdx.x == 0 && blockIdx.y == 0;                                       \
+            const bool last_ = blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;                \
+            if (first_) lat_trace_buf[(kid) * 64 + (slot)] = __builtin_amdgcn_s_memtime();               \
+            if (last_) lat_trace_buf[(kid) * 64 + 32 + (slot)] = __builtin_amdgcn_s_memtime();           \
+            if ((slot) == 0 && first_) lat_trace_buf[(kid) * 64 + 30] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    } while (0)
+#define LAT_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#define LAT_STAMP_END(kid, slot)                                                                          \
+    do {                                                                                                  \
+        LAT_STAMP(kid, slot);                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)                                       \
+            lat_trace_buf[(kid) * 64 + 31] = __builtin_amdgcn_s_memrealtime();                            \
+    } while (0)
+#else
+#define LAT_STAMP(kid, slot)
+#define LAT_DRAIN()
+#define LAT_STAMP_END(kid, slot)
+#endif
+
 // ------------------------------------------------------------------------------------------------ sliced-K GEMM
 template <int J>
 __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
     __shared__ float red[16 * 4 * 64];
+#ifdef DCS_LAT_TRACE
+    const int kid = g.n_slices == 15 ? 1 : (g.n_cb == 8 ? 2 : (J == 2 ? 3 : 0));
+#endif
+    LAT_STAMP(kid, 0);
     const int tid = threadIdx.x;
     const int s = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
@@ -52,6 +87,11 @@ __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
         a[j] = ok ? *reinterpret_cast<const f32x4*>(a_ptr + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
         b[j] = b_ptr[j * 64];
     }
+    // requested with the operands: a load behind the LDS reduction would put one more memory latency on the chain
+    const float biasv = tid < 256 ? g.bias[cb * 16 + (tid & 15)] : 0.f;
+    LAT_STAMP(kid, 1);   // kernel arguments read, every load requested
+    LAT_DRAIN();
+    LAT_STAMP(kid, 2);   // operands arrived
     const float sc = g.a_scale;
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -64,20 +104,30 @@ __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
     const f32x4 acc = acc0 + acc1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[(s * 4 + e) * 64 + lane] = acc[e];
+    LAT_DRAIN();
+    LAT_STAMP(kid, 3);   // products done, partial sums in LDS
     __syncthreads();
+    LAT_STAMP(kid, 4);   // every slice arrived
     if (tid < 256) {
         const int l = tid & 63, e = tid >> 6;
         const int nw = (int)(blockDim.x >> 6);
+        float part[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) part[w] = w < nw ? red[(w * 4 + e) * 64 + l] : 0.f;   // all reads in flight at once
         float sum = 0.f;
-        for (int w = 0; w < nw; ++w) sum += red[(w * 4 + e) * 64 + l];   // slice order: deterministic
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += part[w];                                       // slice order: deterministic
         const int col = cb * 16 + (l & 15);
         const int r = m0 + (l >> 4) * 4 + e;
         if (r < g.M && col < g.n_store) {
-            float v = sum + g.bias[col];
+            float v = sum + biasv;
             if (g.relu) v = fmaxf(v, 0.f);
             g.C[(int64_t)r * g.ldc + col] = v;
         }
     }
+    LAT_STAMP(kid, 5);   // stores issued
+    LAT_DRAIN();
+    LAT_STAMP_END(kid, 6);   // stores acknowledged
 }
 
 // ------------------------------------------------------------------------------------------------ transposed conv2
@@ -189,10 +239,21 @@ __device__ __forceinline__ float imaxf(float x, float lo) {   // max on the bit 
     return __int_as_float(xi > li ? xi : li);
 }
 
+// np.linspace(0., 1., ov)[j] as ensure_rise() tabulates it (util.py:306): arange * (1 / (ov - 1)) in float64, last = 1
+__device__ __forceinline__ float ramp(int j, int ov) {
+    if (ov < 2) return 0.f;
+    if (j == ov - 1) return 1.f;
+    return (float)((double)j * (1.0 / (double)(ov - 1)));
+}
+
+// 8 waves: wave & 3 = 16-bin column block, wave >> 2 = which half of the covering tiles it folds.  The cross-fade
+// res <- down * res + up * v is linear in res, so the fold over tiles m0 .. m1-1 started from 0 (r1) together with the
+// product of their `down` weights (dprod) continues any earlier fold: res = dprod * r0 + r1.  Half 0 folds the owner tile
+// and the first blends, half 1 the rest; they swap partial results through LDS and each stores two of the four sources.
 template <int MODE>
-__global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
+__global__ __launch_bounds__(512) void lat_final_kernel(const DsdFinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NBR = kFinNbr, NSL = 4, slots = NBR * 16 * 3 * kNgg;   // 1008 pieces per covering tile
+    constexpr int NBR = kFinNbr, NSL = 2, slots = NBR * 16 * 3 * kNgg;   // 1008 pieces per covering tile
     const int mmax = a.mmax;
     u32x4* As = reinterpret_cast<u32x4*>(smem);
     float* up_t = reinterpret_cast<float*>(As + mmax * kFinABuf);
@@ -200,12 +261,15 @@ __global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
     int* meta_k0 = reinterpret_cast<int*>(down_t + kLatMaxM * 16);
     int* meta_j0 = meta_k0 + 16;
     int* meta_mlim = meta_j0 + 16;
+    float* xch = reinterpret_cast<float*>(meta_mlim + 16);              // [8 waves][12][64 lanes]
+    LAT_STAMP(5, 0);
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
+    const int half = wave >> 2;
     const int row0 = (int)blockIdx.y * 16;
-    const int colw = (int)blockIdx.x * 64 + wave * 16;
+    const int colw = (int)blockIdx.x * 64 + (wave & 3) * 16;
     const int col = colw + fi;
     const int tc = a.tc, st = a.st, ov = a.ov;
     const int n = (int)a.n, rows = (int)a.rows;
@@ -241,9 +305,9 @@ __global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
         if (m == 0) {
             up = valid ? 1.f : 0.f;
             down = 0.f;
-        } else if (valid) {
-            up = a.rise[j];
-            down = a.rise[ov - 1 - j];
+        } else if (valid) {   // computed, not loaded: a table in global memory would be one more latency on the chain
+            up = ramp(j, ov);
+            down = ramp(ov - 1 - j, ov);
         }
         up_t[m * 16 + i] = up;
         down_t[m * 16 + i] = down;
@@ -269,8 +333,10 @@ __global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
     }
     const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
     const float eps_r = 5e-19f;
+    LAT_STAMP(5, 1);    // tables written, weight / mixture / bias loads requested
 
     __syncthreads();
+    LAT_STAMP(5, 2);
 
     // staging plan (final_bf16x3_kernel's): the A set of a covering tile is [3 branches][16 rows][3 planes][7 channel
     // groups] 16-byte pieces; every slot is loaded for every covering tile with the tile index clamped to the last one
@@ -282,7 +348,7 @@ __global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
     bool in_slot[NSL];
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
-        const int idx = tid + u * 256;
+        const int idx = tid + u * 512;
         const int i = idx & 15, sp = idx >> 4;
         const int s = sp / (3 * kNgg), pg = sp - s * (3 * kNgg);
         const int plane = pg / kNgg, g = pg - plane * kNgg;
@@ -310,7 +376,10 @@ __global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
             }
         }
     }
-    for (int idx = tid; idx < mmax * NBR * 16 * 3; idx += 256) {   // K channels 56..63 of every row: zero
+    LAT_STAMP(5, 3);    // A pieces requested
+    LAT_DRAIN();
+    LAT_STAMP(5, 4);    // ... arrived (and the weights, mixture, bias)
+    for (int idx = tid; idx < mmax * NBR * 16 * 3; idx += 512) {   // K channels 56..63 of every row: zero
         const int buf = idx / (NBR * 16 * 3), r = idx - buf * (NBR * 16 * 3);
         As[buf * kFinABuf + (r / 3) * kRowLds + (r % 3) * 8 + 7] = u32x4{0u, 0u, 0u, 0u};
     }
@@ -323,12 +392,16 @@ __global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
         }
     }
     __syncthreads();
-    if (!live) return;
+    LAT_STAMP(5, 5);    // A set in LDS
 
     f32x4 res[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) res[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int m = 0; m < mmax; ++m) {
+    f32x4 dprod = f32x4{1.f, 1.f, 1.f, 1.f};
+    const int mh = (mmax + 1) >> 1;
+    const int m_lo = half ? mh : 0, m_hi = half ? mmax : mh;
+    if (live)
+    for (int m = m_lo; m < m_hi; ++m) {
         const u32x4* Ab = As + m * kFinABuf + fi * kRowLds + kq;
         u32x4 af[NBR][3][2];
 #pragma unroll
@@ -383,18 +456,45 @@ __global__ __launch_bounds__(256) void lat_final_kernel(const DsdFinalArgs a) {
             res[1][e] = fmaf(down4[e], res[1][e], p1 * w);
             res[2][e] = fmaf(down4[e], res[2][e], p2 * w);
             res[3][e] = fmaf(down4[e], res[3][e], p3 * w);
+            dprod[e] *= down4[e];
         }
     }
+    LAT_STAMP(5, 6);    // covering tiles folded
+    // swap: half 0 hands over its sources 2, 3; half 1 its sources 0, 1 and the product of its `down` weights
+    {
+        float* mine = xch + wave * 12 * 64 + lane;
+        const int c0 = half ? 0 : 2;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine[(c * 4 + e) * 64] = res[c0 + c][e];
+        if (half) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine[(8 + e) * 64] = dprod[e];
+        }
+    }
+    __syncthreads();
     if (col < a.F) {
+        const float* theirs = xch + (wave ^ 4) * 12 * 64 + lane;
+        const int c0 = half ? 2 : 0;                       // the sources this wave finishes and stores
         float* out0 = a.out + (int64_t)row0 * a.out_ld + col;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                const float other = theirs[(c * 4 + e) * 64];
+                // half 0: res = first fold, other = second fold from 0; half 1: the other way round
+                const float dp = half ? dprod[e] : theirs[(8 + e) * 64];
+                const float first = half ? other : res[c0 + c][e];
+                const float second = half ? res[c0 + c][e] : other;
+                const float v = fmaf(dp, first, second);
                 const int ri = kq * 4 + e;
-                if (ri < rows_here) out0[c * a.out_src_stride + ri * a.out_ld] = res[c][e];
+                if (ri < rows_here) out0[(c0 + c) * a.out_src_stride + ri * a.out_ld] = v;
             }
     }
+    LAT_STAMP(5, 7);    // stores issued
+    LAT_DRAIN();
+    LAT_STAMP_END(5, 8);
 }
 
 // ------------------------------------------------------------------------------------------------ FFT in LDS
@@ -476,11 +576,12 @@ __global__ __launch_bounds__(256) void lat_stft_kernel(const float* __restrict__
                                                        const float* __restrict__ win, const float2* __restrict__ tw,
                                                        float* __restrict__ mag, float* __restrict__ phase,
                                                        float2* __restrict__ unit, int64_t ld, int hop, int64_t T,
-                                                       float sqrt_n, int vec) {
+                                                       float inv_sqrt_n, int vec) {
     constexpr int M = 1 << LOG2M;
     __shared__ float2 buf0[M];
     __shared__ float2 buf1[M];
     __shared__ float2 twl[M + 2];
+    LAT_STAMP(6, 0);
     const int tid = threadIdx.x;
     const int64_t t = blockIdx.x;
     float* mrow = mag + t * ld;
@@ -511,8 +612,11 @@ __global__ __launch_bounds__(256) void lat_stft_kernel(const float* __restrict__
         const float2 w = w2[m];
         buf0[m] = make_float2(x0 * w.x, x1 * w.y);
     }
+    LAT_STAMP(6, 1);    // table + frame requested and written to LDS (the LDS writes wait for the loads)
     __syncthreads();
+    LAT_STAMP(6, 2);
     const float2* Z = lat_fft<LOG2M, -1>(buf0, buf1, twl, tid);
+    LAT_STAMP(6, 3);    // FFT done
     for (int k = tid; k <= M; k += 256) {
         const float2 zk = Z[k & (M - 1)];
         const float2 zm = Z[(M - k) & (M - 1)];
@@ -522,60 +626,61 @@ __global__ __launch_bounds__(256) void lat_stft_kernel(const float* __restrict__
         const float2 w = twl[k];
         const float xr = er + (w.x * orr - w.y * oi);
         const float xi = ei + (w.x * oi + w.y * orr);
-        const float ax = sqrtf(xr * xr + xi * xi);
-        mrow[k] = ax / sqrt_n;
+        // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences: ~40 instructions less per bin on
+        // the kernel's critical chain; magnitudes stay within 2e-7 relative of the float64 reference
+        const float ax = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+        const float rx = __builtin_amdgcn_rcpf(ax);
+        mrow[k] = ax * inv_sqrt_n;
         if (prow) prow[k] = atan2f(xi, xr);
-        urow[k] = (ax > 0.f) ? make_float2(xr / ax, xi / ax) : make_float2(1.f, 0.f);
+        urow[k] = (ax > 0.f) ? make_float2(xr * rx, xi * rx) : make_float2(1.f, 0.f);
     }
     for (int k = M + 1 + tid; k < ld; k += 256) {   // row padding
         mrow[k] = 0.f;
         if (prow) prow[k] = 0.f;
         urow[k] = make_float2(1.f, 0.f);
     }
+    LAT_STAMP(6, 4);    // stores issued
+    LAT_DRAIN();
+    LAT_STAMP_END(6, 5);
 }
 
-// inverse + overlap-add.  Workgroup (b, s): output samples [b*hop, (b+1)*hop) of source s = padded positions of hop block
-// h = b + R/2; the R = N/hop frames t = h-R+1 .. h overlap it.  Thread group q transforms frame h-R+1+q
-// (X = mag/pre_div * sqrt(N) * unit, irfft through the packed N/2-point complex transform) and contributes its segment
-// R-1-q; the segments are added in frame order (the reference's accumulation order, transform.py:385-389), divided by
-// the sum of window^2 of the same frames (zeros -> 1, :392-394).
-template <int LOG2M, int R>
-__global__ __launch_bounds__(R * 256) void lat_istft_kernel(const float* __restrict__ sep, int64_t src_stride,
-                                                           const float2* __restrict__ unit, int64_t ld,
-                                                           const float* __restrict__ win, const float* __restrict__ wsq,
-                                                           const float2* __restrict__ tw, float* __restrict__ audio,
-                                                           int64_t n_out, int hop, int64_t T, float pre_div,
-                                                           float sqrt_n) {
+// inverse, two kernels.  (The first version did both in one: a workgroup per (source, hop block) transformed the N/hop
+// frames that overlap its block with N/hop thread groups -- N/hop times the FFT work, and at ~500 VALU instructions per
+// wave and frame that is 10 us of the whole chip's vector time for one batch: 18 us measured.  Every frame is now
+// transformed once.)
+//   lat_ifft_kernel: workgroup (t, s): X = mag/pre_div * sqrt(N) * unit (transform.py:271), irfft through the packed
+//                    N/2-point complex transform, frame * window -> fr[s][t][N]      (istft_norm, transform.py:382-388)
+//   lat_ola_kernel : out[s][m] = sum over the frames t that cover padded position m + N/2, in increasing t (the
+//                    reference's accumulation order, :385-389), / sum of window^2 of the same frames, zeros -> 1 (:392-394)
+template <int LOG2M>
+__global__ __launch_bounds__(256) void lat_ifft_kernel(const float* __restrict__ sep, int64_t src_stride,
+                                                       const float2* __restrict__ unit, int64_t ld,
+                                                       const float* __restrict__ win, const float2* __restrict__ tw,
+                                                       float2* __restrict__ fr, int64_t T, float pre_mul, float sqrt_n) {
     constexpr int M = 1 << LOG2M;
-    constexpr int SEG = M / R;              // complex values (sample pairs) per hop block
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* twl = reinterpret_cast<float2*>(smem);            // [M + 2]; the segments are collected here after the FFT
+    __shared__ float2 b0[M];
+    __shared__ float2 b1[M + 2];
+    __shared__ float2 twl[M + 2];
+    LAT_STAMP(7, 0);
     const int tid = threadIdx.x;
-    const int q = tid >> 8, gt = tid & 255;
-    float2* b0 = twl + (M + 2) + q * (2 * M + 2);
-    float2* b1 = b0 + M;                                      // [M + 2]: holds X[0..M] first
+    const int64_t t = blockIdx.x;
     const int s = blockIdx.y;
-    const int64_t b = blockIdx.x;
-    const int64_t h = b + R / 2;
-    const int64_t t = h - (R - 1) + q;
-    const bool valid = t >= 0 && t < T;
-    for (int k = tid; k <= M; k += R * 256) twl[k] = tw[k];
+    for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
     {
         const float* mrow = sep + (int64_t)s * src_stride + t * ld;
         const float2* urow = unit + t * ld;
-        for (int k = gt; k <= M; k += 256) {
-            float2 x = make_float2(0.f, 0.f);
-            if (valid) {
-                const float am = (mrow[k] / pre_div) * sqrt_n;
-                const float2 u = urow[k];
-                x = make_float2(am * u.x, am * u.y);
-                if (k == 0 || k == M) x.y = 0.f;
-            }
+        for (int k = tid; k <= M; k += 256) {
+            const float am = (mrow[k] * pre_mul) * sqrt_n;
+            const float2 u = urow[k];
+            float2 x = make_float2(am * u.x, am * u.y);
+            if (k == 0 || k == M) x.y = 0.f;     // numpy's irfft ignores the imaginary parts of DC and Nyquist
             b1[k] = x;
         }
     }
+    LAT_STAMP(7, 1);
     __syncthreads();
-    for (int k = gt; k < M; k += 256) {
+    LAT_STAMP(7, 2);
+    for (int k = tid; k < M; k += 256) {
         const float2 xk = b1[k];
         const float2 xm = b1[M - k];
         // E = (xk + conj(xm))/2 ; D = (xk - conj(xm))/2 ; O = D * conj(w^k) ; Z = E + i O
@@ -587,43 +692,56 @@ __global__ __launch_bounds__(R * 256) void lat_istft_kernel(const float* __restr
         b0[k] = make_float2(er - oi, ei + orr);
     }
     __syncthreads();
-    const float2* z = lat_fft<LOG2M, +1>(b0, b1, twl, gt);
+    const float2* z = lat_fft<LOG2M, +1>(b0, b1, twl, tid);
+    LAT_STAMP(7, 3);
     const float inv_m = 1.f / (float)M;
-    float2* ola = twl;                                        // [R][SEG]: the twiddles are not read any more
-    {
-        const int seg = R - 1 - q;
-        const float2* w2 = reinterpret_cast<const float2*>(win);
-        for (int i = gt; i < SEG; i += 256) {
-            const float2 v = z[seg * SEG + i];
-            const float2 w = w2[seg * SEG + i];
-            ola[q * SEG + i] = make_float2((v.x * inv_m) * w.x, (v.y * inv_m) * w.y);
-        }
+    const float2* w2 = reinterpret_cast<const float2*>(win);
+    float2* dst = fr + ((int64_t)s * T + t) * M;
+    for (int m = tid; m < M; m += 256) {
+        const float2 v = z[m];
+        const float2 w = w2[m];
+        dst[m] = make_float2((v.x * inv_m) * w.x, (v.y * inv_m) * w.y);
     }
-    __syncthreads();
-    if (q == 0) {
-        const float2* wsq2 = reinterpret_cast<const float2*>(wsq);
-        float* dst = audio + (int64_t)s * n_out;
-        for (int i = gt; i < SEG; i += 256) {
-            float2 acc = make_float2(0.f, 0.f), norm = make_float2(0.f, 0.f);
+    LAT_STAMP(7, 4);
+    LAT_DRAIN();
+    LAT_STAMP_END(7, 5);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void lat_ola_kernel(const float2* __restrict__ fr, const float* __restrict__ wsq,
+                                                      float* __restrict__ audio, int64_t n_out, int log2hop, int M,
+                                                      int64_t T) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // sample pair
+    const int64_t m0 = 2 * i;
+    if (m0 >= n_out) return;
+    const int s = blockIdx.y;
+    const int64_t p = m0 + M;                                       // padded position (the first N/2 samples are dropped)
+    const int64_t h = p >> log2hop;
+    const float2* wsq2 = reinterpret_cast<const float2*>(wsq);
+    float2 acc = make_float2(0.f, 0.f), norm = make_float2(0.f, 0.f);
+    float2 f[R], ws[R];
+    bool ok[R];
 #pragma unroll
-            for (int qq = 0; qq < R; ++qq) {
-                const int64_t tq = h - (R - 1) + qq;
-                if (tq >= 0 && tq < T) {
-                    const float2 f = ola[qq * SEG + i];
-                    const float2 ws = wsq2[(R - 1 - qq) * SEG + i];
-                    acc.x += f.x;
-                    acc.y += f.y;
-                    norm.x += ws.x;
-                    norm.y += ws.y;
-                }
-            }
-            if (norm.x == 0.f) norm.x = 1.f;
-            if (norm.y == 0.f) norm.y = 1.f;
-            const int64_t m0 = b * hop + 2 * i;
-            if (m0 < n_out) dst[m0] = acc.x / norm.x;
-            if (m0 + 1 < n_out) dst[m0 + 1] = acc.y / norm.y;
-        }
+    for (int q = 0; q < R; ++q) {
+        const int64_t t = h - (R - 1) + q;
+        ok[q] = t >= 0 && t < T;
+        const int pos2 = (int)((p - (t << log2hop)) >> 1);          // sample pair inside frame t
+        f[q] = ok[q] ? fr[((int64_t)s * T + t) * M + pos2] : make_float2(0.f, 0.f);
+        ws[q] = ok[q] ? wsq2[pos2] : make_float2(0.f, 0.f);
     }
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+        if (ok[q]) {
+            acc.x += f[q].x;
+            acc.y += f[q].y;
+            norm.x += ws[q].x;
+            norm.y += ws[q].y;
+        }
+    if (norm.x == 0.f) norm.x = 1.f;
+    if (norm.y == 0.f) norm.y = 1.f;
+    float* dst = audio + (int64_t)s * n_out;
+    dst[m0] = acc.x / norm.x;
+    if (m0 + 1 < n_out) dst[m0 + 1] = acc.y / norm.y;
 }
 
 }  // namespace
@@ -655,6 +773,17 @@ void dcs_lat_pack_deconv2(const float* Bw2s, int n_ci8, std::vector<float>* out)
                     const int co = 16 * j + 4 * kq + e;
                     if (co < 52) (*out)[(((size_t)ci * 4 + j) * 64 + lane) * 4 + e] = Bw2s[((size_t)ci * 16 + fi) * 52 + co];
                 }
+}
+
+// experiment builds only (-DDCS_LAT_TRACE): the stamps of the last launches, [kernel][64] shader-clock values
+extern "C" int lat_trace_dump(unsigned long long* out, int n) {
+#ifdef DCS_LAT_TRACE
+    if (!out || n < 16 * 64) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lat_trace_buf), 16 * 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+#else
+    (void)out; (void)n;
+    return -2;
+#endif
 }
 
 // host-only views of the two packers for the CPU tests (tests/test_lat_cpu.py emulates the kernels' lane arithmetic
@@ -713,7 +842,7 @@ bool dcs_lat_final_supported(const DsdFinalArgs& a) {
 int dcs_launch_lat_final(dcs_ctx* ctx, const DsdFinalArgs& a) {
     if (!dcs_lat_final_supported(a)) DCS_FAIL(DCS_EINVAL, "lat_final: unsupported launch");
     if (a.rows <= 0) return DCS_OK;
-    const size_t lds = (size_t)a.mmax * kFinABuf * 16 + (2 * kLatMaxM * 16 + 48) * 4;
+    const size_t lds = (size_t)a.mmax * kFinABuf * 16 + (2 * kLatMaxM * 16 + 48 + 8 * 12 * 64) * 4;
     auto k0 = lat_final_kernel<0>;
     auto k1 = lat_final_kernel<1>;
     static bool attr_done = false;
@@ -725,9 +854,9 @@ int dcs_launch_lat_final(dcs_ctx* ctx, const DsdFinalArgs& a) {
     const dim3 grid((unsigned)dcs_cdiv(a.F, 64), (unsigned)dcs_cdiv(a.rows, 16));
     DcsTimer tm(ctx, DCS_TAG_FINAL);
     if (a.mask_mode == 0)
-        hipLaunchKernelGGL(k0, grid, dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL(k0, grid, dim3(512), lds, ctx->stream, a);
     else
-        hipLaunchKernelGGL(k1, grid, dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL(k1, grid, dim3(512), lds, ctx->stream, a);
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
@@ -744,7 +873,7 @@ int dcs_launch_lat_stft(dcs_stft* p, const float* audio, int64_t L, float* mag, 
     if (rows_out <= 0) return DCS_OK;
     if (!dcs_lat_stft_supported(p)) DCS_FAIL(DCS_EINVAL, "lat_stft: frameSize %d / hop %d", p->frame, p->hop);
     const int vec = (((uintptr_t)audio & 7) == 0 && (p->hop & 1) == 0) ? 1 : 0;   // sample pairs 8-byte aligned
-    const float sq = (float)sqrt((double)p->frame);
+    const float sq = (float)(1.0 / sqrt((double)p->frame));
     DcsTimer tm(p->ctx, DCS_TAG_STFT);
     if (p->frame == 2048)
         hipLaunchKernelGGL(lat_stft_kernel<10>, dim3((unsigned)rows_out), dim3(256), 0, p->ctx->stream, audio, L, p->win_f,
@@ -757,40 +886,34 @@ int dcs_launch_lat_stft(dcs_stft* p, const float* audio, int64_t L, float* mag, 
     return DCS_OK;
 }
 
-namespace {
-template <int LOG2M, int R>
-int launch_istft(dcs_stft* p, const float* sep, int64_t src_stride, const float2* unit, int64_t ld, int64_t T, int n_src,
-                 float pre_div, float* audio, int64_t n_out) {
-    constexpr int M = 1 << LOG2M;
-    const size_t lds = ((size_t)(M + 2) + (size_t)R * (2 * M + 2)) * sizeof(float2);
-    auto kern = lat_istft_kernel<LOG2M, R>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    const dim3 grid((unsigned)dcs_cdiv(n_out, p->hop), (unsigned)n_src);
-    hipLaunchKernelGGL(kern, grid, dim3(R * 256), lds, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->wsq_f, p->tw_f,
-                       audio, n_out, p->hop, T, pre_div, (float)sqrt((double)p->frame));
-    return DCS_OK;
+size_t dcs_lat_istft_scratch_bytes(const dcs_stft* p, int64_t T, int n_src) {
+    return (size_t)n_src * (size_t)T * (size_t)p->frame * sizeof(float);
 }
-}  // namespace
 
 int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, const float2* unit, int64_t ld, int64_t T,
-                         int n_src, float pre_div, float* audio, int64_t n_out) {
+                         int n_src, float pre_div, float* audio, int64_t n_out, float* frames) {
     if (T <= 0 || n_src <= 0 || n_out <= 0) return DCS_OK;
-    if (!dcs_lat_stft_supported(p)) DCS_FAIL(DCS_EINVAL, "lat_istft: frameSize %d / hop %d", p->frame, p->hop);
-    const int R = p->frame / p->hop;
+    if (!dcs_lat_stft_supported(p) || !frames) DCS_FAIL(DCS_EINVAL, "lat_istft: frameSize %d / hop %d", p->frame, p->hop);
+    const int R = p->frame / p->hop, M = p->frame / 2;
+    int log2hop = 0;
+    while ((1 << log2hop) < p->hop) ++log2hop;
+    if ((1 << log2hop) != p->hop) DCS_FAIL(DCS_EINVAL, "lat_istft: hop %d is not a power of two", p->hop);
+    const float pre_mul = 1.f / pre_div, sq = (float)sqrt((double)p->frame);
+    float2* fr = reinterpret_cast<float2*>(frames);
     DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
-    int rc;
+    const dim3 g1((unsigned)T, (unsigned)n_src);
     if (p->frame == 2048)
-        rc = R == 4 ? launch_istft<10, 4>(p, sep, src_stride, unit, ld, T, n_src, pre_div, audio, n_out)
-                    : launch_istft<10, 2>(p, sep, src_stride, unit, ld, T, n_src, pre_div, audio, n_out);
+        hipLaunchKernelGGL(lat_ifft_kernel<10>, g1, dim3(256), 0, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f,
+                           fr, T, pre_mul, sq);
     else
-        rc = R == 4 ? launch_istft<9, 4>(p, sep, src_stride, unit, ld, T, n_src, pre_div, audio, n_out)
-                    : launch_istft<9, 2>(p, sep, src_stride, unit, ld, T, n_src, pre_div, audio, n_out);
-    tm.done();
-    DCS_CHECK(rc);
+        hipLaunchKernelGGL(lat_ifft_kernel<9>, g1, dim3(256), 0, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f,
+                           fr, T, pre_mul, sq);
+    const dim3 g2((unsigned)dcs_cdiv((n_out + 1) / 2, 256), (unsigned)n_src);
+    if (R == 4)
+        hipLaunchKernelGGL(lat_ola_kernel<4>, g2, dim3(256), 0, p->ctx->stream, fr, p->wsq_f, audio, n_out, log2hop, M, T);
+    else
+        hipLaunchKernelGGL(lat_ola_kernel<2>, g2, dim3(256), 0, p->ctx->stream, fr, p->wsq_f, audio, n_out, log2hop, M, T);
+    tm.done();   // both launches under the iSTFT tag
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }

@@ -668,8 +668,10 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
             if (T >= (1 << 24)) lat = 0;
         }
         const bool split = (lat & DCS_LAT_FINAL) || (m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode));
-        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + dsd_scratch_bytes(m, n_all, rows1, rows2, split)));
+        const size_t b_fr = (lat & DCS_LAT_ISTFT) && pcm_d ? align256(dcs_lat_istft_scratch_bytes(plan, T, S)) : 0;
+        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + b_fr + dsd_scratch_bytes(m, n_all, rows1, rows2, split)));
         char* p = (char*)m->ws.ptr;
+        float* frames = (float*)p; p += b_fr;
         float* mag = (float*)p; p += b_mag;
         float2* unit = (float2*)p; p += b_unit;
         float* phase = phase_out ? (float*)p : nullptr; p += b_ph;
@@ -704,7 +706,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         else
             DCS_CHECK(dcs_launch_dsd_final(m->ctx, a, true));
         if (pcm_d && (lat & DCS_LAT_ISTFT))
-            DCS_CHECK(dcs_launch_lat_istft(plan, sep, T * ld, unit, ld, T, S, scale, pcm_d, L));
+            DCS_CHECK(dcs_launch_lat_istft(plan, sep, T * ld, unit, ld, T, S, scale, pcm_d, L, frames));
         else if (pcm_d)
             DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, T * ld, unit, Trows * ld, ld, T, S, n_clips, scale, pcm_d, L,
                                                         clip_tab_d, lens_h ? pcm_stride : 0));

@@ -29,8 +29,15 @@ echo "== launch floor"
 (cd scripts/ubench && hipcc --offload-arch=gfx950 -O3 launch_floor.hip -o launch_floor 2>/dev/null && timeout 120 ./launch_floor) 2>&1 | tee $OUT/launch_floor.txt
 echo "== rocprofv3 kernel trace, one batch per call"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_lat -o lat -- \
-   python $GRAFT_REPO_ROOT/scripts/gpu_lat_exp.py > $GRAFT_REPO_ROOT/$OUT/prof_lat.log 2>&1)
+   env DCS_LAT_EXP_STAGES=0,255 python $GRAFT_REPO_ROOT/scripts/gpu_lat_exp.py > $GRAFT_REPO_ROOT/$OUT/prof_lat.log 2>&1)
 echo "rocprof exit $?"
 python scripts/trace_by_grid.py $OUT/prof_lat > $OUT/lat_kernel_durations_by_grid.txt 2>&1
 cat $OUT/lat_kernel_durations_by_grid.txt | head -60
+python scripts/trace_timeline.py $OUT/prof_lat > $OUT/lat_timeline.txt 2>&1
+cat $OUT/lat_timeline.txt
+find $OUT/prof_lat -name "*kernel_trace.csv" -delete; find $OUT/prof_lat -name "*.db" -delete
+if [ -f deepconvsep_amd/_exp_lattrace.so ]; then
+  echo "== in-kernel timeline (s_memtime stamps, experiment build)"
+  DCS_LIB=$PWD/deepconvsep_amd/_exp_lattrace.so timeout 300 python scripts/gpu_lat_trace.py 2>&1 | tee $OUT/lat_trace.txt
+fi
 cat $OUT/mask_bins.txt 2>/dev/null
