@@ -12,18 +12,26 @@
 // stage bits of the latency path
 enum {
     DCS_LAT_STFT = 1, DCS_LAT_CONV1 = 2, DCS_LAT_CONV2 = 4, DCS_LAT_FC = 8, DCS_LAT_FC1X = 16, DCS_LAT_DECONV2 = 32,
-    DCS_LAT_FINAL = 64, DCS_LAT_ISTFT = 128, DCS_LAT_ALL = 255
+    DCS_LAT_FINAL = 64, DCS_LAT_ISTFT = 128,
+    DCS_LAT_MID = 256,    // with CONV2 | FC | FC1X | DECONV2 all set: those four as ONE launch (lat_mid_kernel)
+    DCS_LAT_ALL = 511
 };
+constexpr int kDcsLatMidMaxTiles = 256;
 
 // C[r][0..n_store) = act(a_scale * A_r[0..K) . B + bias),  A_r = A + r * a_row_stride (K contiguous floats, 16-byte
 // aligned).  K is cut into n_slices slices of slice_len (multiple of 4); wave s of a workgroup multiplies slice s of one
 // 16 x 16 output block, the slices are added through LDS in slice order.  Bp is B in fragment order
 // (dcs_lat_pack_b): [slice][column block][j][lane][4].
+// Split over workgroups: nz > 1 cuts the slices into nz groups, one workgroup each (4 waves -- one per matrix pipe --
+// instead of 16 on one CU); group z writes its partial sum to C + z * c_part_stride (bias in part 0, no rectifier), and
+// the NEXT layer adds the parts while it loads its operand: a_parts = 4, a_part_stride, relu_in.
 struct DcsLatGemm {
     const float* A; int64_t a_row_stride; float a_scale;
     const float* Bp; const float* bias;
     float* C; int64_t ldc;
     int M, n_store, K, slice_len, n_slices, n_cb, relu;
+    int nz; int64_t c_part_stride;                 // output split (0 / 1: none)
+    int a_parts; int64_t a_part_stride; int relu_in;   // operand = sum of a_parts arrays (1 or 4), then rectified if relu_in
 };
 inline int dcs_lat_j(int slice_len) { return (slice_len + 15) / 16; }
 // host: B[k][ldb] (k-major, n_cb*16 <= ldb columns) -> fragment order
@@ -36,8 +44,24 @@ int dcs_launch_lat_gemm(dcs_ctx* ctx, const DcsLatGemm& g, int tag);
 void dcs_lat_pack_deconv2(const float* Bw2s, int n_ci8, std::vector<float>* out);
 int dcs_launch_lat_deconv2(dcs_ctx* ctx, const float* D, const float* Wp, float* G, void* Gs, int64_t n_items);
 
+// conv2 -> bottleneck -> per-source dense -> transposed conv2 in ONE launch: clusters of 8 workgroups per tile, the
+// exchanges inside a cluster through tagged 8-byte granules (lat_mid_kernel).  state: dcs_lat_mid_state_bytes(max_tiles)
+// bytes of device memory owned by the model, initialised once by dcs_lat_mid_state_init.
+struct DcsLatMidArgs {
+    const float *H1, *W2p, *bias2, *Wfc, *biasfc, *Wd, *biasd, *Wdc;
+    void* state;
+    float* G;      // nullable
+    void* Gs;      // nullable
+    int n_tiles, st;
+};
+void dcs_lat_pack_mid(const float* Bfc, int ld_fc, const float* Bd, int ld_d, std::vector<float>* wfc, std::vector<float>* wd);
+size_t dcs_lat_mid_state_bytes(int max_tiles);
+int dcs_lat_mid_state_init(void* state_d, int max_tiles);
+int dcs_launch_lat_mid(dcs_ctx* ctx, const DcsLatMidArgs& a);
+
 // fused transposed conv1 + bias + rectify + soft mask + cross-fade (final_bf16x3_kernel's arithmetic) with 16 rows x 64
 // bins per workgroup and every covering tile's A set staged at once; needs a.Gs / a.Bpk, one clip, mask_mode 0 / 1
+int dcs_lat_final_max_covers();   // ceil(overlap / stride) + 1 must not exceed this (6)
 bool dcs_lat_final_supported(const DsdFinalArgs& a);
 int dcs_launch_lat_final(dcs_ctx* ctx, const DsdFinalArgs& a);
 

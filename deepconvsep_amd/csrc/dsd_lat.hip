@@ -63,7 +63,13 @@ __device__ unsigned long long lat_trace_buf[16 * 64];
 #endif
 
 // ------------------------------------------------------------------------------------------------ sliced-K GEMM
-template <int J>
+// NA = 1: A is one array.  NA = 4: A is the sum of 4 partial arrays a_part_stride apart (the producer split its K over 4
+// workgroups per output block, see below), optionally rectified -- the consumer finishes the producer's reduction while it
+// loads its operand, so the producer needs neither 16 waves on one CU's four matrix pipes (0.8 us of MFMA issue per
+// workgroup in the in-kernel timeline) nor a second pass.
+// Grid (row blocks, column blocks, NZ): workgroup z multiplies slices z * waves .. z * waves + waves - 1 and writes its sum
+// to C + z * c_part_stride (NZ = 1: the complete result with bias / rectifier; NZ > 1: bias in part 0, no rectifier).
+template <int J, int NA>
 __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
     __shared__ float red[16 * 4 * 64];
 #ifdef DCS_LAT_TRACE
@@ -71,24 +77,28 @@ __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
 #endif
     LAT_STAMP(kid, 0);
     const int tid = threadIdx.x;
-    const int s = tid >> 6, lane = tid & 63;
+    const int nw = (int)(blockDim.x >> 6);
+    const int wv = tid >> 6, lane = tid & 63;
+    const int s = (int)blockIdx.z * nw + wv;
     const int fi = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * 16, cb = blockIdx.y;
     const int row = m0 + fi;
-    const bool row_ok = row < g.M;
     const int slice_len = g.slice_len;
-    const float* a_ptr = g.A + (int64_t)(row_ok ? row : 0) * g.a_row_stride + s * slice_len + 4 * kq;
-    const f32x4* b_ptr = reinterpret_cast<const f32x4*>(g.Bp) + ((int64_t)(s * g.n_cb + cb) * J) * 64 + lane;
-    f32x4 a[J], b[J];
+    const bool row_ok = row < g.M && s < g.n_slices;
+    const float* a_ptr = g.A + (int64_t)(row_ok ? row : 0) * g.a_row_stride + (row_ok ? s : 0) * slice_len + 4 * kq;
+    const f32x4* b_ptr = reinterpret_cast<const f32x4*>(g.Bp) + ((int64_t)((s < g.n_slices ? s : 0) * g.n_cb + cb) * J) * 64 + lane;
+    f32x4 a[NA][J], b[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int kl = 16 * j + 4 * kq;
         const bool ok = row_ok && kl < slice_len && s * slice_len + kl < g.K;
-        a[j] = ok ? *reinterpret_cast<const f32x4*>(a_ptr + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int z = 0; z < NA; ++z)
+            a[z][j] = ok ? *reinterpret_cast<const f32x4*>(a_ptr + z * g.a_part_stride + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
         b[j] = b_ptr[j * 64];
     }
     // requested with the operands: a load behind the LDS reduction would put one more memory latency on the chain
-    const float biasv = tid < 256 ? g.bias[cb * 16 + (tid & 15)] : 0.f;
+    const float biasv = (tid < 256 && blockIdx.z == 0) ? g.bias[cb * 16 + (tid & 15)] : 0.f;
     LAT_STAMP(kid, 1);   // kernel arguments read, every load requested
     LAT_DRAIN();
     LAT_STAMP(kid, 2);   // operands arrived
@@ -96,21 +106,28 @@ __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * a[j][0], b[j][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * a[j][1], b[j][1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * a[j][2], b[j][2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * a[j][3], b[j][3], acc1, 0, 0, 0);
+        f32x4 av = a[0][j];
+        if (NA > 1) {
+            av = (a[0][j] + a[1][j]) + (a[2][j] + a[3][j]);
+            if (g.relu_in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = fmaxf(av[e], 0.f);
+            }
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * av[0], b[j][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * av[1], b[j][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * av[2], b[j][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc * av[3], b[j][3], acc1, 0, 0, 0);
     }
     const f32x4 acc = acc0 + acc1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[(s * 4 + e) * 64 + lane] = acc[e];
+    for (int e = 0; e < 4; ++e) red[(wv * 4 + e) * 64 + lane] = acc[e];
     LAT_DRAIN();
     LAT_STAMP(kid, 3);   // products done, partial sums in LDS
     __syncthreads();
     LAT_STAMP(kid, 4);   // every slice arrived
     if (tid < 256) {
         const int l = tid & 63, e = tid >> 6;
-        const int nw = (int)(blockDim.x >> 6);
         float part[16];
 #pragma unroll
         for (int w = 0; w < 16; ++w) part[w] = w < nw ? red[(w * 4 + e) * 64 + l] : 0.f;   // all reads in flight at once
@@ -121,8 +138,8 @@ __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
         const int r = m0 + (l >> 4) * 4 + e;
         if (r < g.M && col < g.n_store) {
             float v = sum + biasv;
-            if (g.relu) v = fmaxf(v, 0.f);
-            g.C[(int64_t)r * g.ldc + col] = v;
+            if (g.relu && gridDim.z == 1) v = fmaxf(v, 0.f);
+            g.C[(int64_t)blockIdx.z * g.c_part_stride + (int64_t)r * g.ldc + col] = v;
         }
     }
     LAT_STAMP(kid, 5);   // stores issued
@@ -225,7 +242,12 @@ __global__ __launch_bounds__(256) void lat_deconv2_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ final kernel
-constexpr int kRowLds = 25;      // LDS row stride in 16-byte units (as final_bf16x3_kernel)
+// LDS row of the A set, in 16-byte pieces: plane p at 9 p, channel group g behind it (8 per plane, the 8th zero), rows 27
+// apart.  With the staging lanes ordered (plane, row) -- the order of the pieces in memory -- consecutive lanes then
+// write to piece offsets that are consecutive modulo 8: the eight lanes a ds_write_b128 serves per cycle hit eight
+// different bank quads.
+constexpr int kRowLds = 27;
+constexpr int kPlaneLds = 9;
 constexpr int kNgg = 7;
 constexpr int kLatMaxM = 8;      // covering tiles per frame the LDS holds at once (6 for overlap 25 / stride 5)
 constexpr int kFinNbr = 3;
@@ -261,7 +283,8 @@ __global__ __launch_bounds__(512) void lat_final_kernel(const DsdFinalArgs a) {
     int* meta_k0 = reinterpret_cast<int*>(down_t + kLatMaxM * 16);
     int* meta_j0 = meta_k0 + 16;
     int* meta_mlim = meta_j0 + 16;
-    float* xch = reinterpret_cast<float*>(meta_mlim + 16);              // [8 waves][12][64 lanes]
+    float* dp_t = reinterpret_cast<float*>(meta_mlim + 16);             // [16] product of the second half's `down` weights
+    float* xch = dp_t + 16;                                             // [2 halves][4 sources][16 rows][64 bins]
     LAT_STAMP(5, 0);
 
     const int tid = threadIdx.x;
@@ -344,21 +367,25 @@ __global__ __launch_bounds__(512) void lat_final_kernel(const DsdFinalArgs a) {
     const int m_delta = (NBR * kNgg * tc - st) * 3;
     const int kbase = meta_k0[0];
     const u32x4* gbase = reinterpret_cast<const u32x4*>(a.Gs) + (int64_t)kbase * NBR * kNgg * tc * 3;
+    // slot idx -> (plane, row i, channel group g, branch s) with the plane fastest, then the row: that is the order of the
+    // pieces in memory ([item][g][t][plane], the rows of one tile are consecutive t), so 48 consecutive lanes read four
+    // runs of <= 240 contiguous bytes.  (Rows fastest -- final_bf16x3_kernel's order -- made every load instruction touch
+    // 48 cache lines for 1 KB: 1.1 us of address-unit time per workgroup in the in-kernel timeline.)
     int goff[NSL], dst[NSL], mlim[NSL];
     bool in_slot[NSL];
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
         const int idx = tid + u * 512;
-        const int i = idx & 15, sp = idx >> 4;
-        const int s = sp / (3 * kNgg), pg = sp - s * (3 * kNgg);
-        const int plane = pg / kNgg, g = pg - plane * kNgg;
+        const int t3 = idx / 3, plane = idx - 3 * t3;
+        const int i = t3 & 15, gs = t3 >> 4;
+        const int s = gs / kNgg, g = gs - s * kNgg;
         const bool in = idx < slots;
         in_slot[u] = in;
         const int lim = in ? meta_mlim[i] : -1;
         const int j0 = lim >= 0 ? meta_j0[i] : 0;
         const int dk = lim >= 0 ? meta_k0[i] - kbase : 0;
         mlim[u] = lim >= 0 ? lim : 0;
-        dst[u] = (s * 16 + i) * kRowLds + plane * 8 + g;
+        dst[u] = (s * 16 + i) * kRowLds + plane * kPlaneLds + g;
         goff[u] = (((dk * NBR + s) * kNgg + g) * tc + j0) * 3 + plane;
     }
     u32x4 pre[kLatMaxM][NSL];
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(512) void lat_final_kernel(const DsdFinalArgs a) {
     LAT_STAMP(5, 4);    // ... arrived (and the weights, mixture, bias)
     for (int idx = tid; idx < mmax * NBR * 16 * 3; idx += 512) {   // K channels 56..63 of every row: zero
         const int buf = idx / (NBR * 16 * 3), r = idx - buf * (NBR * 16 * 3);
-        As[buf * kFinABuf + (r / 3) * kRowLds + (r % 3) * 8 + 7] = u32x4{0u, 0u, 0u, 0u};
+        As[buf * kFinABuf + (r / 3) * kRowLds + (r % 3) * kPlaneLds + 7] = u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int mm = 0; mm < kLatMaxM; ++mm) {
@@ -409,7 +436,7 @@ __global__ __launch_bounds__(512) void lat_final_kernel(const DsdFinalArgs a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) af[s][p][kb] = Ab[s * 16 * kRowLds + p * 8 + kb * 4];
+                for (int kb = 0; kb < 2; ++kb) af[s][p][kb] = Ab[s * 16 * kRowLds + p * kPlaneLds + kb * 4];
         f32x4 acc[NBR];
         acc[0] = f32x4{bias0, bias0, bias0, bias0};
         acc[1] = f32x4{bias1, bias1, bias1, bias1};
@@ -460,41 +487,394 @@ __global__ __launch_bounds__(512) void lat_final_kernel(const DsdFinalArgs a) {
         }
     }
     LAT_STAMP(5, 6);    // covering tiles folded
-    // swap: half 0 hands over its sources 2, 3; half 1 its sources 0, 1 and the product of its `down` weights
+    // Both halves put their folds into an LDS tile [half][source][row][64 bins]; then every thread finishes two 16-byte
+    // pieces of the output, res = dprod * first + second, and stores them: 16 lanes write 256 contiguous bytes of a row.
+    // (Storing from the accumulator layout -- a lane holds 4 rows x 1 bin -- was 8 dword stores per lane in 64-byte
+    // segments: 2 us of the workgroup's 8.1 in the in-kernel timeline.)
     {
-        float* mine = xch + wave * 12 * 64 + lane;
-        const int c0 = half ? 0 : 2;
+        float* mine = xch + (half * 4 * 16) * 64 + (wave & 3) * 16 + fi;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mine[(c * 4 + e) * 64] = res[c0 + c][e];
-        if (half) {
+            for (int e = 0; e < 4; ++e) mine[(c * 16 + kq * 4 + e) * 64] = res[c][e];
+        if (wave == 4 && fi == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mine[(8 + e) * 64] = dprod[e];
+            for (int e = 0; e < 4; ++e) dp_t[kq * 4 + e] = dprod[e];
         }
     }
     __syncthreads();
-    if (col < a.F) {
-        const float* theirs = xch + (wave ^ 4) * 12 * 64 + lane;
-        const int c0 = half ? 2 : 0;                       // the sources this wave finishes and stores
-        float* out0 = a.out + (int64_t)row0 * a.out_ld + col;
+    {
+        const int64_t ld4 = a.out_ld;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 512;
+            const int q4 = idx & 15, ri = (idx >> 4) & 15, c = idx >> 8;
+            const int col4 = (int)blockIdx.x * 64 + q4 * 4;
+            if (ri < rows_here && col4 + 3 < ld4) {
+                const f32x4 first = *reinterpret_cast<const f32x4*>(xch + ((0 * 4 + c) * 16 + ri) * 64 + q4 * 4);
+                const f32x4 second = *reinterpret_cast<const f32x4*>(xch + ((1 * 4 + c) * 16 + ri) * 64 + q4 * 4);
+                const float dp = dp_t[ri];
+                f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float other = theirs[(c * 4 + e) * 64];
-                // half 0: res = first fold, other = second fold from 0; half 1: the other way round
-                const float dp = half ? dprod[e] : theirs[(8 + e) * 64];
-                const float first = half ? other : res[c0 + c][e];
-                const float second = half ? res[c0 + c][e] : other;
-                const float v = fmaf(dp, first, second);
-                const int ri = kq * 4 + e;
-                if (ri < rows_here) out0[(c0 + c) * a.out_src_stride + ri * a.out_ld] = v;
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(dp, first[e], second[e]);
+                *reinterpret_cast<f32x4*>(a.out + c * a.out_src_stride + (int64_t)(row0 + ri) * ld4 + col4) = v;
             }
+        }
     }
     LAT_STAMP(5, 7);    // stores issued
     LAT_DRAIN();
     LAT_STAMP_END(5, 8);
+}
+
+// ------------------------------------------------------------------------------------------------ the middle, one launch
+// conv2 -> bottleneck -> per-source dense -> transposed conv2 of one TILE touch 1.9 MB of weights and a few KB of data, and
+// as four launches they cost 4 x (2.4 us of dispatch + ~1 us of cold start + 2-3 us of dependent loads) = 20 us for
+// 57 MFLOP.  Here a CLUSTER of 8 workgroups (8 consecutive block ids: the dispatcher hands them out in order, so at most
+// one cluster per launch is ever partially resident) owns one tile; every workgroup streams an eighth of every layer's
+// weights into REGISTERS at kernel start (they do not depend on data), and the three exchanges inside the cluster go
+// through 8-byte {tag, value} granules (MI355X guide, recipe R2): the data is the flag, one relaxed agent-scope store per
+// value, consumers re-read their granules until every tag is this launch's -- no fences, no flag words, no grid barrier.
+//   phase 1  conv2 (separate_dsd.py:202-203): members 0..3 = the four 16-column blocks, 16 positions x 780 on the f32 MFMA,
+//            K split by taps over the 4 waves                                              -> 832 granules
+//   phase 2  bottleneck + rectify (:206): member c = hidden units 16c..16c+15, vector ALU     -> 128 granules
+//   phase 3  per-source dense + rectify (:209,215,221): member c = columns 312c..312c+311     -> 2496 granules
+//   phase 4  InverseLayer(., l_conv2) (:211,217,223): the 21 (branch, 8-channel group) units dealt round-robin, GEMM +
+//            col2im as lat_deconv2_kernel                                                     -> G / Gs in HBM
+// Tags are launch epoch * 4 + phase; the epoch lives in device memory and is advanced by the last workgroup to finish (a
+// kernel argument would be frozen in a replayed hipGraph), so nothing has to be zeroed between launches.
+typedef unsigned long long u64;
+constexpr int kMidC2 = 832, kMidZ = 128, kMidD = 2496;
+constexpr int kMidTileGranules = 1024 + 128 + 2560;     // per tile: conv2 output, bottleneck, dense outputs (padded)
+constexpr unsigned kMidSpinLimit = 1u << 22;
+
+__device__ __forceinline__ void granule_store(u64* g, unsigned tag, float v) {
+    __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// re-reads this thread's granules idx = first + 256 u (clamped to count - 1: every load is issued, none sits behind a
+// branch -- with one exec-masked branch and one wait per granule a sweep was NU serial round trips) until all carry `tag`;
+// false on give-up (state[2] is set)
+template <int NU>
+__device__ __forceinline__ bool granule_sweep(const u64* g, int first, int count, unsigned tag, float (&v)[NU], unsigned* state) {
+    const u64* p[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int idx = first + 256 * u;
+        p[u] = g + (idx < count ? idx : count - 1);
+    }
+    for (unsigned spins = 0;; ++spins) {
+        u64 x[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) x[u] = __hip_atomic_load(p[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            ok = ok & ((unsigned)(x[u] >> 32) == tag);
+            v[u] = __uint_as_float((unsigned)x[u]);
+        }
+        if (ok) return true;
+        if (spins > kMidSpinLimit) {
+            __hip_atomic_store(state + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+struct DcsLatMid {
+    const float* H1;       // [rows][52] conv1 output (+ biases), tile k starts at row k * st
+    const float* W2p;      // conv2 weights, fragment order [tap 15][column block 4][4][64][4]   (dcs_lat_pack_b)
+    const float* bias2;    // [64]
+    const float* Wfc;      // [member 8][832][16]
+    const float* biasfc;   // [128]
+    const float* Wd;       // [member 8][129][312], row 128 zero
+    const float* biasd;    // [2496]
+    const float* Wdc;      // transposed-conv2 fragments [56 channels][4][64][4]   (dcs_lat_pack_deconv2)
+    u64* gran;             // [tiles][kMidTileGranules]
+    unsigned* state;       // [0] launch epoch (>= 1), [1] workgroups finished (ever), [2] tag a sweep gave up on (0: none)
+    float* G;              // nullable
+    u32x4* Gs;             // nullable
+    int n_tiles, st;
+};
+
+__global__ __launch_bounds__(256) void lat_mid_kernel(const DcsLatMid a) {
+    __shared__ __attribute__((aligned(16))) float H1l[30 * 52 + 16];
+    __shared__ __attribute__((aligned(16))) float C2l[kMidC2];
+    __shared__ __attribute__((aligned(16))) float Zl[kMidZ];
+    __shared__ __attribute__((aligned(16))) float Dl[3 * kMidC2];
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64];          // conv2: [wave][e][lane]; fc: [64][16]; fc1x: [3][312]
+    __shared__ __attribute__((aligned(16))) float Ps[4 * 2 * kPsChan];
+    __shared__ __attribute__((aligned(16))) float Gl[30 * 8];
+    LAT_STAMP(4, 0);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int c = (int)(blockIdx.x & 7);                  // member
+    const int cl = (int)(blockIdx.x >> 3), ncl = (int)(gridDim.x >> 3);
+    const unsigned epoch = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- weights -> registers.  A wave's loads return in order, so the order of the requests is the order in which the
+    // phases can start: the first tile's conv1 rows and the conv2 / bottleneck weights first (187 KB per workgroup at
+    // most); the dense and transposed-conv2 weights (184 KB) are requested once the conv2 products have been issued
+    // (LAT_PIN keeps the compiler from hoisting them) and arrive while the cluster exchanges the conv2 output.
+#define LAT_PIN(off_) asm volatile("" : "+s"(off_))   // an opaque zero offset: the loads behind it cannot be hoisted above it
+    f32x4 h1pre[2];
+    {
+        const float* src = a.H1 + (int64_t)cl * a.st * 52;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u;
+            h1pre[u] = (c < 4 && cl < a.n_tiles && i < 30 * 13) ? *reinterpret_cast<const f32x4*>(src + 4 * i)
+                                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 w2[4][4];                                        // conv2: taps wave, wave+4, wave+8, wave+12 of column block c
+    if (c < 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = wave + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w2[q][j] = reinterpret_cast<const f32x4*>(a.W2p)[((int64_t)(u * 4 + c) * 4 + j) * 64 + lane];   // tap 15: zeros
+        }
+    }
+    const float b2 = c < 4 ? a.bias2[c * 16 + (tid & 15)] : 0.f;
+    const int h4 = tid & 3, ks = tid >> 2;                 // bottleneck: 4 hidden units x slice ks of 13 inputs
+    f32x4 wfc[13];
+#pragma unroll
+    for (int j = 0; j < 13; ++j)
+        wfc[j] = *reinterpret_cast<const f32x4*>(a.Wfc + ((int64_t)(c * kMidC2 + ks * 13 + j) * 16 + 4 * h4));
+    const float bfc = tid < 16 ? a.biasfc[c * 16 + tid] : 0.f;
+    const int cq = tid % 78, ksd = tid / 78;               // dense: 4 columns x slice ksd of 43 hidden units (tid < 234)
+    const int n_units = c < 5 ? 3 : 2;                     // transposed conv2: units c, c + 8, c + 16 of the 21
+    f32x4 wd[43];
+    f32x4 wdc[3][2][4];
+    f32x4 bd = f32x4{0.f, 0.f, 0.f, 0.f};
+    LAT_STAMP(4, 1);    // first requests out
+    // conv2 products of one tile (members 0..3): conv1 rows -> LDS, 4 taps x 16 MFMAs per wave, partial sums -> red
+#define LAT_MID_CONV2(tile_, first_)                                                                                  \
+    if (c < 4) {                                                                                                      \
+        if (first_) {                                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                             \
+                if (tid + 256 * u < 30 * 13) *reinterpret_cast<f32x4*>(H1l + 4 * (tid + 256 * u)) = h1pre[u];        \
+        } else {                                                                                                      \
+            const float* src = a.H1 + (int64_t)(tile_) * a.st * 52;                                                   \
+            for (int i = tid; i < 30 * 13; i += 256)                                                                  \
+                *reinterpret_cast<f32x4*>(H1l + 4 * i) = *reinterpret_cast<const f32x4*>(src + 4 * i);                \
+        }                                                                                                             \
+        __syncthreads();                                                                                              \
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                               \
+            const int u = wave + 4 * q;                                                                               \
+            if (u < 15) {                                                                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
+                    const f32x4 av = (j < 3 || kq == 0)                                                               \
+                                         ? *reinterpret_cast<const f32x4*>(H1l + (fi + u) * 52 + 16 * j + 4 * kq)     \
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w2[q][j][0], acc0, 0, 0, 0);                   \
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], w2[q][j][1], acc1, 0, 0, 0);                   \
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], w2[q][j][2], acc0, 0, 0, 0);                   \
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w2[q][j][3], acc1, 0, 0, 0);                   \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+        const f32x4 acc = acc0 + acc1;                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) red[(wave * 4 + e) * 64 + lane] = acc[e];                       \
+    }
+
+    if (cl < a.n_tiles) { LAT_MID_CONV2(cl, true) }
+    // the weights of phases 3 and 4, requested behind the first tile's conv2 products
+    {
+        int zero = 0;
+        LAT_PIN(zero);
+        const float* Wd = a.Wd + zero;
+        const float* Wdc = a.Wdc + zero;
+        const float* bdp = a.biasd + zero;
+        // unconditional loads (a branch per load otherwise): idle threads read slice 0, the packed array has a zero row 128
+        const int cqc = tid < 234 ? cq : 0, ksc = tid < 234 ? ksd : 0;
+#pragma unroll
+        for (int j = 0; j < 43; ++j)
+            wd[j] = *reinterpret_cast<const f32x4*>(Wd + ((int64_t)(c * 129 + ksc * 43 + j) * 312 + 4 * cqc));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int v = q < n_units ? c + 8 * q : c, g = v % 7;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    wdc[q][cc][j] = reinterpret_cast<const f32x4*>(Wdc)[((int64_t)(g * 8 + wave * 2 + cc) * 4 + j) * 64 + lane];
+        }
+        bd = *reinterpret_cast<const f32x4*>(bdp + c * 312 + 4 * (tid < 78 ? tid : 0));
+    }
+
+    for (int tile = cl; tile < a.n_tiles; tile += ncl) {
+        u64* gC2 = a.gran + (int64_t)tile * kMidTileGranules;
+        u64* gZ = gC2 + 1024;
+        u64* gD = gZ + 128;
+        const unsigned tag1 = epoch * 4 + 1, tag2 = epoch * 4 + 2, tag3 = epoch * 4 + 3;
+        // ---- phase 1: conv2 of the tile's 16 positions
+        if (tile != cl) { LAT_MID_CONV2(tile, false) }
+        if (c < 4) {
+            __syncthreads();
+            {
+                const int l = tid & 63, e = tid >> 6;
+                const float sum = ((red[(0 * 4 + e) * 64 + l] + red[(1 * 4 + e) * 64 + l]) + red[(2 * 4 + e) * 64 + l]) +
+                                  red[(3 * 4 + e) * 64 + l];
+                const int col = c * 16 + (l & 15), pos = (l >> 4) * 4 + e;
+                if (col < 52) granule_store(gC2 + pos * 52 + col, tag1, sum + b2);
+            }
+        }
+        LAT_STAMP(4, 2);    // conv2 done and published (members 0..3)
+        // ---- phase 2: bottleneck
+        {
+            float v[4];
+            granule_sweep<4>(gC2, tid, kMidC2, tag1, v, a.state);
+            LAT_STAMP(4, 3);    // conv2 output of the whole cluster seen
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (tid + 256 * u < kMidC2) C2l[tid + 256 * u] = v[u];
+            __syncthreads();
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 13; ++j) acc += C2l[ks * 13 + j] * wfc[j];
+            *reinterpret_cast<f32x4*>(red + ks * 16 + 4 * h4) = acc;
+            __syncthreads();
+            {   // 64 slices -> 16 partial sums per hidden unit -> 1
+                const int h = tid & 15, part = tid >> 4;
+                const float s4 = ((red[(4 * part) * 16 + h] + red[(4 * part + 1) * 16 + h]) + red[(4 * part + 2) * 16 + h]) +
+                                 red[(4 * part + 3) * 16 + h];
+                __syncthreads();
+                red[part * 16 + h] = s4;
+            }
+            __syncthreads();
+            if (tid < 16) {
+                float s = 0.f;
+#pragma unroll
+                for (int part = 0; part < 16; ++part) s += red[part * 16 + tid];
+                granule_store(gZ + c * 16 + tid, tag2, fmaxf(s + bfc, 0.f));
+            }
+        }
+        LAT_STAMP(4, 4);    // bottleneck slice published
+        // ---- phase 3: per-source dense layers
+        {
+            float v[1];
+            granule_sweep<1>(gZ, tid, kMidZ, tag2, v, a.state);
+            LAT_STAMP(4, 5);    // bottleneck seen
+            __syncthreads();                                  // red is free again
+            if (tid < kMidZ) Zl[tid] = v[0];
+            __syncthreads();
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 43; ++j) {
+                const int h = ksd * 43 + j;
+                acc += Zl[h < kMidZ ? h : 0] * wd[j];         // wd is zero past the last hidden unit
+            }
+            if (tid < 234) *reinterpret_cast<f32x4*>(red + ksd * 312 + 4 * cq) = acc;
+            __syncthreads();
+            if (tid < 78) {
+                const f32x4 s = (*reinterpret_cast<const f32x4*>(red + 4 * tid) + *reinterpret_cast<const f32x4*>(red + 312 + 4 * tid)) +
+                                *reinterpret_cast<const f32x4*>(red + 624 + 4 * tid) + bd;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) granule_store(gD + c * 312 + 4 * tid + e, tag3, fmaxf(s[e], 0.f));
+            }
+        }
+        LAT_STAMP(4, 6);    // dense slice published
+        // ---- phase 4: transposed conv2 of this member's units
+        {
+            float v[10];
+            granule_sweep<10>(gD, tid, kMidD, tag3, v, a.state);
+            LAT_STAMP(4, 7);    // dense outputs seen
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 10; ++u)
+                if (tid + 256 * u < kMidD) Dl[tid + 256 * u] = v[u];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q < n_units) {                            // uniform per workgroup
+                    const int vu = c + 8 * q, br = vu / 7, grp = vu - 7 * br;
+                    const float* Dp = Dl + br * kMidC2 + fi * 52 + 4 * kq;
+                    f32x4 av[4];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) av[j] = *reinterpret_cast<const f32x4*>(Dp + 16 * j);
+                    av[3] = kq == 0 ? *reinterpret_cast<const f32x4*>(Dp + 48) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int cc = 0; cc < 2; ++cc)
+                                acc[cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], wdc[q][cc][j][e], acc[cc], 0, 0, 0);
+                    float* Pw = Ps + wave * 2 * kPsChan;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Pw[cc * kPsChan + (kq * 4 + e + fi) * kPsStride + fi] = acc[cc][e];
+                    __syncthreads();
+                    {
+                        const int cc = lane >> 5, t = lane & 31;
+                        if (t < 30) {
+                            const f32x4* rowp = reinterpret_cast<const f32x4*>(Pw + cc * kPsChan + t * kPsStride);
+                            float x[16];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const f32x4 y = rowp[r];
+                                x[4 * r] = y[0]; x[4 * r + 1] = y[1]; x[4 * r + 2] = y[2]; x[4 * r + 3] = y[3];
+                            }
+                            float sum = 0.f;
+#pragma unroll
+                            for (int dt = 0; dt < 15; ++dt) {
+                                const int tp = t - dt;
+                                sum += (tp >= 0 && tp < 16) ? x[dt] : 0.f;
+                            }
+                            Gl[t * 8 + wave * 2 + cc] = sum;
+                        }
+                    }
+                    __syncthreads();
+                    if (tid < 30) {
+                        const int t = tid;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(Gl + t * 8), x1 = *reinterpret_cast<const f32x4*>(Gl + t * 8 + 4);
+                        const int64_t rowi = (((int64_t)tile * 3 + br) * 7 + grp) * 30 + t;
+                        if (a.G) {
+                            *reinterpret_cast<f32x4*>(a.G + rowi * 8) = x0;
+                            *reinterpret_cast<f32x4*>(a.G + rowi * 8 + 4) = x1;
+                        }
+                        if (a.Gs) {
+                            float y[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                            unsigned pl[3][8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const unsigned hh = bf_trunc(y[j]);
+                                const float r1 = y[j] - __uint_as_float(hh);
+                                const unsigned mm = bf_trunc(r1);
+                                const float r2 = r1 - __uint_as_float(mm);
+                                pl[0][j] = hh; pl[1][j] = mm; pl[2][j] = bf_trunc(r2);
+                            }
+#pragma unroll
+                            for (int q3 = 0; q3 < 3; ++q3) {
+                                u32x4 w;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) w[r] = (pl[q3][2 * r] >> 16) | (pl[q3][2 * r + 1] & 0xffff0000u);
+                                a.Gs[rowi * 3 + q3] = w;
+                            }
+                        }
+                    }
+                    __syncthreads();                          // Gl / Ps are rewritten by the next unit
+                }
+            }
+        }
+    }
+    LAT_STAMP(4, 8);        // transposed conv2 done, stores issued
+    LAT_DRAIN();
+    LAT_STAMP_END(4, 9);
+    // ---- the last workgroup of the launch advances the epoch for the next one
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned total = gridDim.x;
+        const unsigned old = __hip_atomic_fetch_add(a.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old + 1) % total == 0)
+            __hip_atomic_store(a.state, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ FFT in LDS
@@ -652,24 +1032,30 @@ __global__ __launch_bounds__(256) void lat_stft_kernel(const float* __restrict__
 //                    N/2-point complex transform, frame * window -> fr[s][t][N]      (istft_norm, transform.py:382-388)
 //   lat_ola_kernel : out[s][m] = sum over the frames t that cover padded position m + N/2, in increasing t (the
 //                    reference's accumulation order, :385-389), / sum of window^2 of the same frames, zeros -> 1 (:392-394)
-template <int LOG2M>
-__global__ __launch_bounds__(256) void lat_ifft_kernel(const float* __restrict__ sep, int64_t src_stride,
-                                                       const float2* __restrict__ unit, int64_t ld,
-                                                       const float* __restrict__ win, const float2* __restrict__ tw,
-                                                       float2* __restrict__ fr, int64_t T, float pre_mul, float sqrt_n) {
+// NG thread groups of 256 = NG sources of ONE frame per workgroup: they share the twiddle table in LDS and the frame's
+// unit-phasor row (the 2nd .. NGth group's loads of it hit the CU's L1) -- 32 KB of loads per frame instead of 4 x 20.
+template <int LOG2M, int NG>
+__global__ __launch_bounds__(NG * 256) void lat_ifft_kernel(const float* __restrict__ sep, int64_t src_stride,
+                                                            const float2* __restrict__ unit, int64_t ld,
+                                                            const float* __restrict__ win, const float2* __restrict__ tw,
+                                                            float2* __restrict__ fr, int64_t T, int n_src, float pre_mul,
+                                                            float sqrt_n) {
     constexpr int M = 1 << LOG2M;
-    __shared__ float2 b0[M];
-    __shared__ float2 b1[M + 2];
-    __shared__ float2 twl[M + 2];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* twl = reinterpret_cast<float2*>(smem);            // [M + 2]
     LAT_STAMP(7, 0);
     const int tid = threadIdx.x;
+    const int q = tid >> 8, gt = tid & 255;
+    float2* b0 = twl + (M + 2) + q * (2 * M + 2);
+    float2* b1 = b0 + M;                                      // [M + 2]
     const int64_t t = blockIdx.x;
-    const int s = blockIdx.y;
-    for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
+    const int s = (int)blockIdx.y * NG + q;
+    const bool live = s < n_src;
+    for (int k = tid; k <= M; k += NG * 256) twl[k] = tw[k];
     {
-        const float* mrow = sep + (int64_t)s * src_stride + t * ld;
+        const float* mrow = sep + (int64_t)(live ? s : 0) * src_stride + t * ld;
         const float2* urow = unit + t * ld;
-        for (int k = tid; k <= M; k += 256) {
+        for (int k = gt; k <= M; k += 256) {
             const float am = (mrow[k] * pre_mul) * sqrt_n;
             const float2 u = urow[k];
             float2 x = make_float2(am * u.x, am * u.y);
@@ -680,7 +1066,7 @@ __global__ __launch_bounds__(256) void lat_ifft_kernel(const float* __restrict__
     LAT_STAMP(7, 1);
     __syncthreads();
     LAT_STAMP(7, 2);
-    for (int k = tid; k < M; k += 256) {
+    for (int k = gt; k < M; k += 256) {
         const float2 xk = b1[k];
         const float2 xm = b1[M - k];
         // E = (xk + conj(xm))/2 ; D = (xk - conj(xm))/2 ; O = D * conj(w^k) ; Z = E + i O
@@ -692,16 +1078,17 @@ __global__ __launch_bounds__(256) void lat_ifft_kernel(const float* __restrict__
         b0[k] = make_float2(er - oi, ei + orr);
     }
     __syncthreads();
-    const float2* z = lat_fft<LOG2M, +1>(b0, b1, twl, tid);
+    const float2* z = lat_fft<LOG2M, +1>(b0, b1, twl, gt);
     LAT_STAMP(7, 3);
     const float inv_m = 1.f / (float)M;
     const float2* w2 = reinterpret_cast<const float2*>(win);
-    float2* dst = fr + ((int64_t)s * T + t) * M;
-    for (int m = tid; m < M; m += 256) {
-        const float2 v = z[m];
-        const float2 w = w2[m];
-        dst[m] = make_float2((v.x * inv_m) * w.x, (v.y * inv_m) * w.y);
-    }
+    float2* dst = fr + ((int64_t)(live ? s : 0) * T + t) * M;
+    if (live)
+        for (int m = gt; m < M; m += 256) {
+            const float2 v = z[m];
+            const float2 w = w2[m];
+            dst[m] = make_float2((v.x * inv_m) * w.x, (v.y * inv_m) * w.y);
+        }
     LAT_STAMP(7, 4);
     LAT_DRAIN();
     LAT_STAMP_END(7, 5);
@@ -807,17 +1194,58 @@ extern "C" int64_t dcs_lat_pack_deconv2_host(const float* Bw2s, int n_ci8, float
 int dcs_launch_lat_gemm(dcs_ctx* ctx, const DcsLatGemm& g, int tag) {
     if (g.M <= 0) return DCS_OK;
     const int J = dcs_lat_j(g.slice_len);
-    if (g.n_slices < 4 || g.n_slices > 16 || (g.slice_len & 3) || (g.K & 3) || (g.a_row_stride & 3) || J < 1 || J > 5)
-        DCS_FAIL(DCS_EINVAL, "lat_gemm: %d slices of %d", g.n_slices, g.slice_len);
-    const dim3 grid((unsigned)dcs_cdiv(g.M, 16), (unsigned)g.n_cb), block((unsigned)g.n_slices * 64);
+    const int nz = g.nz > 1 ? g.nz : 1;
+    const int waves = (g.n_slices + nz - 1) / nz;
+    if (g.n_slices < 1 || waves < 4 || waves > 16 || (g.slice_len & 3) || (g.K & 3) || (g.a_row_stride & 3) || J < 1 || J > 5 ||
+        (g.a_parts != 1 && g.a_parts != 4) || (g.a_part_stride & 3))
+        DCS_FAIL(DCS_EINVAL, "lat_gemm: %d slices of %d over %d workgroups, %d operand parts", g.n_slices, g.slice_len, nz, g.a_parts);
+    const dim3 grid((unsigned)dcs_cdiv(g.M, 16), (unsigned)g.n_cb, (unsigned)nz), block((unsigned)waves * 64);
     DcsTimer tm(ctx, tag);
+#define DCS_LAT_GEMM(J_)                                                                                       \
+    if (g.a_parts == 4) hipLaunchKernelGGL((lat_gemm_kernel<J_, 4>), grid, block, 0, ctx->stream, g);          \
+    else hipLaunchKernelGGL((lat_gemm_kernel<J_, 1>), grid, block, 0, ctx->stream, g);
     switch (J) {
-        case 1: hipLaunchKernelGGL(lat_gemm_kernel<1>, grid, block, 0, ctx->stream, g); break;
-        case 2: hipLaunchKernelGGL(lat_gemm_kernel<2>, grid, block, 0, ctx->stream, g); break;
-        case 3: hipLaunchKernelGGL(lat_gemm_kernel<3>, grid, block, 0, ctx->stream, g); break;
-        case 4: hipLaunchKernelGGL(lat_gemm_kernel<4>, grid, block, 0, ctx->stream, g); break;
-        default: hipLaunchKernelGGL(lat_gemm_kernel<5>, grid, block, 0, ctx->stream, g); break;
+        case 1: DCS_LAT_GEMM(1) break;
+        case 2: DCS_LAT_GEMM(2) break;
+        case 3: DCS_LAT_GEMM(3) break;
+        case 4: DCS_LAT_GEMM(4) break;
+        default: DCS_LAT_GEMM(5) break;
     }
+#undef DCS_LAT_GEMM
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
+
+// ---- the middle in one launch (lat_mid_kernel)
+void dcs_lat_pack_mid(const float* Bfc, int ld_fc, const float* Bd, int ld_d, std::vector<float>* wfc, std::vector<float>* wd) {
+    wfc->assign((size_t)8 * kMidC2 * 16, 0.f);     // [member][input kk][16 hidden units of the member]
+    for (int c = 0; c < 8; ++c)
+        for (int kk = 0; kk < kMidC2; ++kk)
+            for (int h = 0; h < 16; ++h) (*wfc)[((size_t)c * kMidC2 + kk) * 16 + h] = Bfc[(size_t)kk * ld_fc + 16 * c + h];
+    wd->assign((size_t)8 * 129 * 312, 0.f);        // [member][hidden unit, 3 slices of 43 = 129 rows, the last zero][312 columns]
+    for (int c = 0; c < 8; ++c)
+        for (int h = 0; h < kMidZ; ++h)
+            for (int j = 0; j < 312; ++j) (*wd)[((size_t)c * 129 + h) * 312 + j] = Bd[(size_t)h * ld_d + 312 * c + j];
+}
+size_t dcs_lat_mid_state_bytes(int max_tiles) { return 256 + (size_t)max_tiles * kMidTileGranules * sizeof(u64); }
+int dcs_lat_mid_state_init(void* state_d, int max_tiles) {   // once per model: granules zero (no launch has tag 0), epoch 1
+    DCS_HIP(hipMemset(state_d, 0, dcs_lat_mid_state_bytes(max_tiles)));
+    const unsigned one = 1;
+    DCS_HIP(hipMemcpy(state_d, &one, sizeof(one), hipMemcpyHostToDevice));
+    return DCS_OK;
+}
+int dcs_launch_lat_mid(dcs_ctx* ctx, const DcsLatMidArgs& h) {
+    if (h.n_tiles <= 0) return DCS_OK;
+    DcsLatMid a{};
+    a.H1 = h.H1; a.W2p = h.W2p; a.bias2 = h.bias2; a.Wfc = h.Wfc; a.biasfc = h.biasfc; a.Wd = h.Wd; a.biasd = h.biasd;
+    a.Wdc = h.Wdc; a.state = reinterpret_cast<unsigned*>(h.state);
+    a.gran = reinterpret_cast<u64*>(reinterpret_cast<char*>(h.state) + 256);
+    a.G = h.G; a.Gs = reinterpret_cast<u32x4*>(h.Gs); a.n_tiles = h.n_tiles; a.st = h.st;
+    // ALWAYS 32 clusters of 8 workgroups: the epoch hand-over counts workgroups modulo the grid size, and one workgroup
+    // per CU is what the register budget (512 per lane: all weights of a member live in registers) admits anyway
+    DcsTimer tm(ctx, DCS_TAG_CONV2);
+    hipLaunchKernelGGL(lat_mid_kernel, dim3(256), dim3(256), 0, ctx->stream, a);
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
@@ -833,7 +1261,15 @@ int dcs_launch_lat_deconv2(dcs_ctx* ctx, const float* D, const float* Wp, float*
     return DCS_OK;
 }
 
+int dcs_lat_final_max_covers() {   // covering tiles per frame whose A sets fit the 160 KB of LDS beside the output tile
+    int m = 0;
+    while (m < kLatMaxM && (size_t)(m + 1) * kFinABuf * 16 + (2 * kLatMaxM * 16 + 48 + 16 + 2 * 4 * 16 * 64) * 4 <= 160 * 1024) ++m;
+    return m;
+}
+
 bool dcs_lat_final_supported(const DsdFinalArgs& a) {
+    if (a.mmax > dcs_lat_final_max_covers()) return false;
+    if ((a.out_ld & 3) || ((uintptr_t)a.out & 15) || (a.out_src_stride & 3)) return false;   // 16-byte output pieces
     return a.Gs && a.Bpk && a.CI == 52 && a.tc == 30 && a.mmax >= 1 && a.mmax <= kLatMaxM && a.mask_mode < 2 &&
            a.n_clips <= 1 && !a.clip_tab && (a.nbr == 0 || a.nbr == 3) && a.bias_half == 0 && a.rows < (1 << 24) &&
            a.n < (1 << 24);
@@ -842,7 +1278,7 @@ bool dcs_lat_final_supported(const DsdFinalArgs& a) {
 int dcs_launch_lat_final(dcs_ctx* ctx, const DsdFinalArgs& a) {
     if (!dcs_lat_final_supported(a)) DCS_FAIL(DCS_EINVAL, "lat_final: unsupported launch");
     if (a.rows <= 0) return DCS_OK;
-    const size_t lds = (size_t)a.mmax * kFinABuf * 16 + (2 * kLatMaxM * 16 + 48 + 8 * 12 * 64) * 4;
+    const size_t lds = (size_t)a.mmax * kFinABuf * 16 + (2 * kLatMaxM * 16 + 48 + 16 + 2 * 4 * 16 * 64) * 4;
     auto k0 = lat_final_kernel<0>;
     auto k1 = lat_final_kernel<1>;
     static bool attr_done = false;
@@ -901,13 +1337,25 @@ int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, cons
     const float pre_mul = 1.f / pre_div, sq = (float)sqrt((double)p->frame);
     float2* fr = reinterpret_cast<float2*>(frames);
     DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
-    const dim3 g1((unsigned)T, (unsigned)n_src);
-    if (p->frame == 2048)
-        hipLaunchKernelGGL(lat_ifft_kernel<10>, g1, dim3(256), 0, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f,
-                           fr, T, pre_mul, sq);
-    else
-        hipLaunchKernelGGL(lat_ifft_kernel<9>, g1, dim3(256), 0, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f,
-                           fr, T, pre_mul, sq);
+    {
+        constexpr int NG = 4;
+        const dim3 g1((unsigned)T, (unsigned)dcs_cdiv(n_src, NG));
+        const size_t lds = ((size_t)(M + 2) + (size_t)NG * (2 * M + 2)) * sizeof(float2);
+        auto k10 = lat_ifft_kernel<10, NG>;
+        auto k9 = lat_ifft_kernel<9, NG>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k10), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_done = true;
+        }
+        if (p->frame == 2048)
+            hipLaunchKernelGGL(k10, g1, dim3(NG * 256), lds, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f, fr, T,
+                               n_src, pre_mul, sq);
+        else
+            hipLaunchKernelGGL(k9, g1, dim3(NG * 256), lds, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f, fr, T,
+                               n_src, pre_mul, sq);
+    }
     const dim3 g2((unsigned)dcs_cdiv((n_out + 1) / 2, 256), (unsigned)n_src);
     if (R == 4)
         hipLaunchKernelGGL(lat_ola_kernel<4>, g2, dim3(256), 0, p->ctx->stream, fr, p->wsq_f, audio, n_out, log2hop, M, T);

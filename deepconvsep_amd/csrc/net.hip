@@ -97,6 +97,8 @@ struct dcs_model {
     // one-batch ("latency") kernels, dsd_lat.hip: the GEMM B operands in MFMA fragment order, the transposed-conv2
     // weights likewise; lat_stages = -1: automatic (all stages for one clip of at most lat_max_frames frames)
     float *L1p = nullptr, *L2p = nullptr, *Lfcp = nullptr, *Ldp = nullptr, *Lw2p = nullptr;
+    float *Lmfc = nullptr, *Lmd = nullptr;   // bottleneck / dense weights per cluster member (lat_mid_kernel)
+    void* lat_mid_state = nullptr;           // epoch, counters and granules of lat_mid_kernel
     int lat_slice1 = 0;
     bool lat_ok = false;
     int lat_stages = -1;
@@ -306,7 +308,7 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
         m->lat_slice1 = (int)dcs_round_up((m->K1 + 15) / 16, 4);
         dcs_lat_pack_b(B1.data(), 64, m->K1, 4, m->lat_slice1, 16, &pk);
         DCS_CHECK(upload(&m->L1p, pk));
-        dcs_lat_pack_b(B2.data(), 64, kh * CI, 4, CI, kh, &pk);
+        dcs_lat_pack_b(B2.data(), 64, kh * CI, 4, CI, kh + 1, &pk);   // one more (zero) tap: lat_mid_kernel loads 16 unconditionally
         DCS_CHECK(upload(&m->L2p, pk));
         dcs_lat_pack_b(Bfc.data(), m->hid64, d.h2 * CP, m->hid64 / 16, CP, d.h2, &pk);
         DCS_CHECK(upload(&m->Lfcp, pk));
@@ -314,6 +316,12 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
         DCS_CHECK(upload(&m->Ldp, pk));
         dcs_lat_pack_deconv2(Bw2s.data(), (int)dcs_round_up(CI, kDsdGch), &pk);
         DCS_CHECK(upload(&m->Lw2p, pk));
+        std::vector<float> wfc, wd;
+        dcs_lat_pack_mid(Bfc.data(), m->hid64, Bd.data(), m->nd64, &wfc, &wd);
+        DCS_CHECK(upload(&m->Lmfc, wfc));
+        DCS_CHECK(upload(&m->Lmd, wd));
+        DCS_HIP(hipMalloc(&m->lat_mid_state, dcs_lat_mid_state_bytes(kDcsLatMidMaxTiles)));
+        DCS_CHECK(dcs_lat_mid_state_init(m->lat_mid_state, kDcsLatMidMaxTiles));
         m->lat_ok = true;
     }
     return DCS_OK;
@@ -341,6 +349,13 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     if (clips && (!shared_frames || clip_pitch % tile_row_stride != 0 || n > 0x7fffffff))
         DCS_FAIL(DCS_EINVAL, "dsd_encode: bad clip batch");
     if (lat && (clips || !shared_frames || !a_vec || !m->lat_ok)) DCS_FAIL(DCS_EINVAL, "dsd_encode: latency kernels need one clip");
+    constexpr unsigned kMidAll = DCS_LAT_CONV2 | DCS_LAT_FC | DCS_LAT_FC1X | DCS_LAT_DECONV2 | DCS_LAT_MID;
+    const bool mid = (lat & kMidAll) == kMidAll && n <= kDcsLatMidMaxTiles && m->lat_mid_state;
+    // two consecutive one-batch GEMMs: the first leaves its K reduction as 4 partial arrays (4 workgroups of 4 waves per
+    // output block instead of one of 16), the second adds them while it loads its operand (DESIGN.md "one batch")
+    const bool split1 = (lat & DCS_LAT_CONV1) && (lat & DCS_LAT_CONV2) && !mid;
+    const bool split2 = (lat & DCS_LAT_CONV2) && (lat & DCS_LAT_FC) && !mid;
+    const bool split3 = (lat & DCS_LAT_FC) && (lat & DCS_LAT_FC1X) && !mid;
     // conv1 + both biases  (separate_dsd.py:198-199)
     const int64_t n_rows1 = clips ? n_clips * clip_pitch : (shared_frames ? (n - 1) * tile_row_stride + tc : n * tc);
     DcsGemm g1{};
@@ -353,10 +368,19 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
         DcsLatGemm q{};
         q.A = rows_src; q.a_row_stride = lda; q.a_scale = a_scale; q.Bp = m->L1p; q.bias = m->bias1;
         q.C = w.H1; q.ldc = CI; q.M = (int)n_rows1; q.n_store = CI; q.K = m->K1; q.slice_len = m->lat_slice1;
-        q.n_slices = 16; q.n_cb = 4; q.relu = 0;
+        q.n_slices = 16; q.n_cb = 4; q.relu = 0; q.a_parts = 1;
+        q.nz = split1 ? 4 : 1; q.c_part_stride = n_rows1 * CI;
         DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_CONV1));
     } else
         DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g1, DCS_TAG_CONV1));
+    if (mid) {
+        // conv2 -> bottleneck -> dense -> transposed conv2 of every tile in one launch (clusters of 8 workgroups)
+        DcsLatMidArgs q{};
+        q.H1 = w.H1; q.W2p = m->L2p; q.bias2 = m->bias2; q.Wfc = m->Lmfc; q.biasfc = m->biasfc; q.Wd = m->Lmd;
+        q.biasd = m->biasd; q.Wdc = m->Lw2p; q.state = m->lat_mid_state;
+        q.G = ((lat & DCS_LAT_FINAL) && w.Gs) ? nullptr : w.G; q.Gs = w.Gs; q.n_tiles = (int)n; q.st = (int)tile_row_stride;
+        return dcs_launch_lat_mid(m->ctx, q);
+    }
     // conv2 + both biases (separate_dsd.py:202-203): output row = position; its A row is kh consecutive H1 rows
     DcsGemm g2{};
     g2.A = w.H1; g2.lda = CI; g2.a_scale = 1.f;
@@ -371,6 +395,8 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
         q.A = w.H1; q.a_row_stride = CI; q.a_scale = 1.f; q.Bp = m->L2p; q.bias = m->bias2;
         q.C = w.C2; q.ldc = CP; q.M = (int)g2.M; q.n_store = CP; q.K = d.kh2 * CI; q.slice_len = CI;
         q.n_slices = d.kh2; q.n_cb = 4; q.relu = 0;
+        q.a_parts = split1 ? 4 : 1; q.a_part_stride = n_rows1 * CI;
+        q.nz = split2 ? 4 : 1; q.c_part_stride = g2.M * CP;
         DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_CONV2));
     } else
         DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g2, DCS_TAG_CONV2));
@@ -386,6 +412,8 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
         q.A = w.C2; q.a_row_stride = tile_row_stride * (int64_t)CP; q.a_scale = 1.f; q.Bp = m->Lfcp; q.bias = m->biasfc;
         q.C = w.Z; q.ldc = m->hid64; q.M = (int)n; q.n_store = m->hid64; q.K = d.h2 * CP; q.slice_len = CP;
         q.n_slices = d.h2; q.n_cb = m->hid64 / 16; q.relu = 1;
+        q.a_parts = split2 ? 4 : 1; q.a_part_stride = g2.M * CP;
+        q.nz = split3 ? 4 : 1; q.c_part_stride = n * (int64_t)m->hid64;      // split: the rectifier is the consumer's
         DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_FC));
     } else
         DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g3, DCS_TAG_FC));
@@ -400,6 +428,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
         q.A = w.Z; q.a_row_stride = m->hid64; q.a_scale = 1.f; q.Bp = m->Ldp; q.bias = m->biasd;
         q.C = w.D; q.ldc = m->nd; q.M = (int)n; q.n_store = m->nd; q.K = m->hid64; q.slice_len = 32;
         q.n_slices = 4; q.n_cb = m->nd64 / 16; q.relu = 1;
+        q.a_parts = split3 ? 4 : 1; q.a_part_stride = n * (int64_t)m->hid64; q.relu_in = split3 ? 1 : 0;
         DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_FC1X));
     } else
         DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
@@ -410,17 +439,19 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
                                   m->d2_gcols, w.Gs, m->Bw2q);
 }
 
-size_t dsd_scratch_bytes(const dcs_model* m, int64_t n, int64_t rows1, int64_t rows2, bool split = false) {
-    return align256((size_t)rows1 * m->CI * 4) + align256((size_t)rows2 * m->CP * 4) +
-           align256((size_t)n * m->hid64 * 4) + align256((size_t)n * m->nd * 4) +
+// parts: copies of H1 / C2 / Z (the one-batch GEMMs leave their K reduction as 4 partial arrays for the next layer to add)
+size_t dsd_scratch_bytes(const dcs_model* m, int64_t n, int64_t rows1, int64_t rows2, bool split = false, int parts = 1) {
+    return align256((size_t)parts * rows1 * m->CI * 4) + align256((size_t)parts * rows2 * m->CP * 4) +
+           align256((size_t)parts * n * m->hid64 * 4) + align256((size_t)n * m->nd * 4) +
            align256((size_t)n * m->d.n_fc * dsd_g_pitch(m->CI, m->tc) * 4) +
            (split ? align256((size_t)n * m->d.n_fc * dsd_gs_pitch(m->CI, m->tc) * 16) : 0);
 }
 
-char* dsd_carve(const dcs_model* m, char* p, int64_t n, int64_t rows1, int64_t rows2, DsdScratch* w, bool split = false) {
-    w->H1 = (float*)p; p += align256((size_t)rows1 * m->CI * 4);
-    w->C2 = (float*)p; p += align256((size_t)rows2 * m->CP * 4);
-    w->Z = (float*)p; p += align256((size_t)n * m->hid64 * 4);
+char* dsd_carve(const dcs_model* m, char* p, int64_t n, int64_t rows1, int64_t rows2, DsdScratch* w, bool split = false,
+                int parts = 1) {
+    w->H1 = (float*)p; p += align256((size_t)parts * rows1 * m->CI * 4);
+    w->C2 = (float*)p; p += align256((size_t)parts * rows2 * m->CP * 4);
+    w->Z = (float*)p; p += align256((size_t)parts * n * m->hid64 * 4);
     w->D = (float*)p; p += align256((size_t)n * m->nd * 4);
     w->G = (float*)p; p += align256((size_t)n * m->d.n_fc * dsd_g_pitch(m->CI, m->tc) * 4);
     w->Gs = nullptr;
@@ -519,7 +550,8 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
         if (p) (void)hipFree(p);
     for (auto& t : m->rise_tabs)
         if (t.second) (void)hipFree(t.second);
-    float* lat[] = {m->L1p, m->L2p, m->Lfcp, m->Ldp, m->Lw2p};
+    if (m->lat_mid_state) (void)hipFree(m->lat_mid_state);
+    float* lat[] = {m->L1p, m->L2p, m->Lfcp, m->Ldp, m->Lw2p, m->Lmfc, m->Lmd};
     for (float* p : lat)
         if (p) (void)hipFree(p);
     if (m->gen) dcs_generic_destroy(m->gen);
@@ -584,6 +616,15 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------ fused path
+// one clip of at most this many frames takes the one-batch kernels (DCS_LAT_MAX_FRAMES)
+static int64_t dcs_lat_max_frames() {
+    static const int64_t v = getenv("DCS_LAT_MAX_FRAMES") ? atoll(getenv("DCS_LAT_MAX_FRAMES")) : 640;
+    return v;
+}
+// the automatic selection: one launch per layer.  The 8-workgroup-cluster launch of the middle (DCS_LAT_MID) is built and
+// tested but measured slower (a cluster per tile re-reads the 1.9 MB of weights per tile: 77 MB per batch through L2)
+constexpr int kLatDefault = DCS_LAT_ALL & ~DCS_LAT_MID;
+
 static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm_d, float* sep_out, float* mag_out, float* phase_out,
                          int64_t ld_out, int64_t* n_tiles_out, int64_t* n_frames_out, int64_t n_clips = 1,
@@ -661,15 +702,16 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         unsigned lat = 0;
         if (m->lat_ok && n_clips == 1 && !clip_tab_d && dcs_lat_stft_supported(plan)) {
             static const int env_mask = getenv("DCS_LAT") ? atoi(getenv("DCS_LAT")) : -1;
-            static const int64_t env_max = getenv("DCS_LAT_MAX_FRAMES") ? atoll(getenv("DCS_LAT_MAX_FRAMES")) : 640;
-            const int want = m->lat_stages >= 0 ? m->lat_stages : (env_mask >= 0 ? env_mask : (T <= env_max ? DCS_LAT_ALL : 0));
+            const int64_t env_max = dcs_lat_max_frames();
+            const int want = m->lat_stages >= 0 ? m->lat_stages : (env_mask >= 0 ? env_mask : (T <= env_max ? kLatDefault : 0));
             lat = (unsigned)want & DCS_LAT_ALL;
-            if ((ov + st - 1) / st + 1 > 8 || eps_mode > 1) lat &= ~(unsigned)DCS_LAT_FINAL;   // more covering tiles than the LDS holds
+            if ((ov + st - 1) / st + 1 > dcs_lat_final_max_covers() || eps_mode > 1) lat &= ~(unsigned)DCS_LAT_FINAL;   // more covering tiles than the LDS holds
             if (T >= (1 << 24)) lat = 0;
         }
         const bool split = (lat & DCS_LAT_FINAL) || (m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode));
         const size_t b_fr = (lat & DCS_LAT_ISTFT) && pcm_d ? align256(dcs_lat_istft_scratch_bytes(plan, T, S)) : 0;
-        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + b_fr + dsd_scratch_bytes(m, n_all, rows1, rows2, split)));
+        const int parts = lat ? 4 : 1;
+        DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + b_fr + dsd_scratch_bytes(m, n_all, rows1, rows2, split, parts)));
         char* p = (char*)m->ws.ptr;
         float* frames = (float*)p; p += b_fr;
         float* mag = (float*)p; p += b_mag;
@@ -677,7 +719,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         float* phase = phase_out ? (float*)p : nullptr; p += b_ph;
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
-        dsd_carve(m, p, n_all, rows1, rows2, &w, split);
+        dsd_carve(m, p, n_all, rows1, rows2, &w, split, parts);
         if (lat & DCS_LAT_STFT)
             DCS_CHECK(dcs_launch_lat_stft(plan, audio_d, L, mag, phase, unit, ld, Trows, T));
         else
@@ -735,7 +777,15 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     DCS_ON_DEVICE(m->ctx->device);
     static const bool graphs_on = !(getenv("DCS_GRAPH") && atoi(getenv("DCS_GRAPH")) == 0);
     // graph replay needs a capturable (non-null) stream, no event timing, and an identical repeat call
-    const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD;
+    // A replayed hipGraph costs ~4 us more per call than the same launches issued eagerly from a host that keeps ahead of
+    // the GPU (measured on MI355X / ROCm 7.2, one 32-tile batch per call: 55.2 vs 51.3 us; profiles/r03_*): graphs pay off
+    // when several streams compete for the host (launch groups), not for one short call after another.  DCS_LAT_GRAPH=1
+    // replays the one-batch path as a graph anyway.
+    static const bool lat_graph = getenv("DCS_LAT_GRAPH") && atoi(getenv("DCS_LAT_GRAPH")) != 0;
+    const bool lat_call = m->lat_ok && n_clips == 1 && m->lat_stages != 0 &&
+                          (m->lat_stages > 0 || dcs_frame_count(n_samples, plan ? plan->hop : 1) <= dcs_lat_max_frames());
+    const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD &&
+                           (!lat_call || lat_graph);
     auto eager = [&]() {
         return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr, nullptr,
                              nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);

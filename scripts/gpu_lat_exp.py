@@ -64,7 +64,7 @@ def main():
 
     res = {"N": N, "tiles": TILES, "us_per_step": {}}
     ref = None
-    sweep = [0, 255] + [255 ^ (1 << b) for b in range(8)] + [1 << b for b in range(8)]
+    sweep = [0, 511, 255] + [511 ^ (1 << b) for b in (0, 1, 6, 7)] + [255 ^ (1 << b) for b in range(2, 6)]
     if os.environ.get("DCS_LAT_EXP_STAGES"):
         sweep = [int(x, 0) for x in os.environ["DCS_LAT_EXP_STAGES"].split(",")]
     for stages in sweep:
@@ -95,7 +95,7 @@ def main():
         ctx.timing(None)
         ctx.timing_reset()
         return out
-    res["events_us"] = {"throughput": breakdown(0), "one_batch": breakdown(255)}
+    res["events_us"] = {"throughput": breakdown(0), "one_batch": breakdown(511)}
     print("HIP-event us per kernel, throughput kernels:", res["events_us"]["throughput"])
     print("HIP-event us per kernel, one-batch kernels :", res["events_us"]["one_batch"])
     # no graph: eager launches (what a first call costs)

@@ -25,6 +25,8 @@ MARKS = {
     1: ("conv2", ["args+request", "operands arrive", "mfma+lds write", "barrier", "reduce+store issue", "store ack"]),
     2: ("fc", ["args+request", "operands arrive", "mfma+lds write", "barrier", "reduce+store issue", "store ack"]),
     3: ("fc1x", ["args+request", "operands arrive", "mfma+lds write", "barrier", "reduce+store issue", "store ack"]),
+    4: ("mid", ["weights requested", "conv2+publish", "sweep C2", "fc+publish", "sweep Z", "dense+publish", "sweep D",
+                "deconv2+store issue", "store ack"]),
     5: ("final", ["tables+request B/mix", "barrier", "plan+request A", "A arrives", "LDS fill+barrier", "fold", "swap+store issue",
                   "store ack"]),
     6: ("stft", ["request+LDS fill", "barrier", "fft", "post+store issue", "store ack"]),
@@ -41,7 +43,7 @@ def main():
         sep = dcs.Separator("dsd", params, 0.3, TC, OV, 32, F, N, HOP, np.hanning, ctx=ctx)
         audio = ctx.to_device(synth_audio(L, seed=100), np.float32)
         pcm = torch.empty((4, L), dtype=torch.float32, device=audio.device)
-    sep.net.set_latency_stages(255)
+    sep.net.set_latency_stages(int(os.environ.get('DCS_LAT_TRACE_STAGES', '511')))
     fn = ctx._lib.dcs_separate_batch
     args = (sep.net._h, sep.plan._h, ctypes.c_void_p(audio.data_ptr()), L, 1, L, OV, TILER_SCRIPT, ctypes.c_float(0.3),
             sep.net.arch.eps_mode, 0, ctypes.c_void_p(pcm.data_ptr()), None, None)
