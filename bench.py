@@ -56,12 +56,45 @@ if ROOT not in sys.path:
 HOP, TC, OV, SCALE, SR = 512, 30, 25, 0.3, 44100
 PEAK_F32_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_F16_TFLOPS = 2500.0   # dense f16 / bf16 MFMA
-FINAL_NAMES = {"f32x64": "final_kernel<fold, 64-bin workgroups> (deconv1+bias+relu+mask+crossfade, f32 MFMA)",
+FINAL_NAMES = {"one_batch": "lat_final_kernel (deconv1+bias+relu+mask+crossfade of ONE batch per call: 16 frames x 64 bins per "
+                            "workgroup, every covering tile staged in LDS, bf16 MFMA on three-way split operands)",
+               "f32x64": "final_kernel<fold, 64-bin workgroups> (deconv1+bias+relu+mask+crossfade, f32 MFMA)",
                "f32x128": "final_kernel<fold> (deconv1+bias+relu+mask+crossfade, f32 MFMA)",
                "bf16x3": "final_bf16x3_kernel (deconv1+bias+relu+mask+crossfade; bf16 MFMA on operands split into "
                          "three bf16 terms, six products kept, f32 accumulation: f32-class results)"}
 PEAK_HBM_GBPS = 8000.0
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+# which kernel carries a timing tag in each leg (substring of the kernel name in the rocprofv3 counter files); used to look
+# up the HBM traffic record of a leg's kernels in TRAFFIC_FILE["legs"][leg]
+LEG_KERNELS = {
+    "ikala": {"conv1": "conv1_reg_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "slabconv_ps_kernel", "fc": "gemm_rows",
+              "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_reg_kernel"},
+    "bach10_f16": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_wreg_scatter_kernel", "decoder": "colconv_deconv1_fused_kernel",
+                   "fc": "gemm_rows", "fc1x": "gemm_bf16x3_skinny_kernel"},
+    "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
+                       "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel"},
+}
+# kernels that execute on the 16-bit matrix pipe: (products issued per f32 product, K padding factor)
+LEG_ISSUED = {
+    "ikala": {"conv2": (6, 32.0 / 30.0), "deconv2": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
+    "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc1x": (6, 1.0)},
+    "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
+}
+
+
+def load_traffic():
+    try:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
+            return json.load(fh)
+    except Exception:
+        return {}
+
+
+def traffic_bytes(rec):
+    """2*FETCH + WRITE (gfx950: FETCH_SIZE counts half the bytes of wide coalesced reads, MI355X_MICROARCH.md)."""
+    if not rec or "FETCH_SIZE_KiB" not in rec or "WRITE_SIZE_KiB" not in rec:
+        return None
+    return int((2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024)
 
 
 def samples_for_tiles(n_tiles, tc=TC, ov=OV, hop=HOP, library=False):
@@ -120,6 +153,14 @@ def main():
                     help="comma list of extra BASELINE configs to measure on rank 0 at N=1 ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive extra leg")
+    ap.add_argument("--no-cli", action="store_true", help="skip the command-line leg (separate_dsd.py on one wav, separate_batch.py on 50)")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the timed launches' output")
+    ap.add_argument("--gather", choices=["allgather", "root", "none"], default="allgather",
+                    help="N > 1: the collective that carries every launch group's int16 PCM inside the timed region: "
+                         "all_gather_into_tensor (every rank gets everything), gather to rank 0 (north_star: 'final gather'), "
+                         "or none (replicas: every rank keeps its own output)")
+    ap.add_argument("--only-legs", action="store_true",
+                    help="(counter passes) skip the headline timing: run only the legs given by --legs")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +192,13 @@ def main():
     from deepconvsep_amd.runtime import Context
     from deepconvsep_amd.synth import synth_audio, synth_params, synth_score_text
 
+    if args.only_legs:
+        legs = {}
+        for name in [x for x in args.legs.split(",") if x]:
+            legs[name] = run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_audio, synth_params,
+                                 synth_score_text, not args.no_cpu_baseline, cpu_model(), os.cpu_count() or 1)
+        print(json.dumps({"legs": legs}))
+        return
     N = args.frame_size
     F = N // 2 + 1
     K = max(1, args.steps)
@@ -163,6 +211,8 @@ def main():
     NS = max(1, args.streams)
     groups = split_groups(K, max(1, args.clips_per_launch), NS)
     CPL = max(groups)                                        # buffers are sized for the largest group
+
+    gather_mode = [args.gather]                              # a list: the gather split below switches it off and on again
 
     class Lane(object):                                      # one HIP stream with everything it needs
         def __init__(self, idx):
@@ -200,15 +250,25 @@ def main():
             if rc:
                 _lib.check(rc)
             self.launched_tiles += nclips * n_tiles
-            if world > 1:
+            if world > 1 and gather_mode[0] != "none":
                 rc = self._to16(self.ctx._h, ctypes.c_void_p(self.pcm.data_ptr()), nclips * 4 * L,
                                 ctypes.c_void_p(self.pcm16.data_ptr()))
                 if rc:
                     _lib.check(rc)
-                with torch.cuda.stream(self.stream):
-                    # RCCL over xGMI: the final gather of the separated PCM
-                    dist.all_gather_into_tensor(self.gathered[: world * nclips * 4].view(torch.uint8),
-                                                self.pcm16[: nclips * 4].view(torch.uint8))
+                self.gather(nclips)
+
+        def gather(self, nclips):
+            """RCCL over xGMI: the final gather of one launch group's separated PCM (int16, as bytes)."""
+            with torch.cuda.stream(self.stream):
+                src = self.pcm16[: nclips * 4].view(torch.uint8)
+                if gather_mode[0] == "root":
+                    dst = None
+                    if rank == 0:
+                        full = self.gathered[: world * nclips * 4].view(torch.uint8)
+                        dst = list(full.chunk(world, dim=0))
+                    dist.gather(src, dst, dst=0)
+                else:
+                    dist.all_gather_into_tensor(self.gathered[: world * nclips * 4].view(torch.uint8), src)
 
     lanes = [Lane(i) for i in range(NS)]
     ctx0 = lanes[0].ctx
@@ -270,6 +330,37 @@ def main():
     value = world * frames_per_step * K / med
     clean = [t for i, t in enumerate(round_s) if i % 4 != 3] or round_s
 
+    # ---- N > 1: what the collective costs -- the same rounds with the gather switched off, and the collective alone (one
+    # launch group's payload per call, back to back on lane 0), so that a scaling curve can be read: compute vs exchange
+    gather_split = None
+    if world > 1:
+        saved = gather_mode[0]
+        gather_mode[0] = "none"
+        for _ in range(2):
+            timed(groups, lanes)
+        no_g = statistics.median([timed(groups, lanes) for _ in range(5)])
+        gather_mode[0] = saved
+        alone = None
+        if saved != "none":
+            g0 = groups[0]
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps_g = 20
+            for _ in range(reps_g):
+                lanes[0].gather(g0)
+            torch.cuda.synchronize()
+            barrier()
+            alone = (time.perf_counter() - t0) / reps_g
+            tt = torch.tensor([alone], dtype=torch.float64, device=lanes[0].audio.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            alone = float(tt.item())
+        gather_split = {"mode": saved, "payload_bytes_per_rank_per_group": int(groups[0] * 4 * L * 2),
+                        "round_ms_without_gather": round(no_g * 1e3, 4), "round_ms_with_gather": round(med * 1e3, 4),
+                        "ms_per_group_collective_alone": round(alone * 1e3, 4) if alone is not None else None,
+                        "note": "rounds of the same K steps with the collective switched off, and the collective alone for one "
+                                "launch group's int16 PCM; no scaling curve is implied by one run"}
+
     # ---- optional self-check of the gather (tests): every rank's slice of the gathered buffer must be that rank's own
     # int16 PCM, bit for bit (digests exchanged out of band)
     gather_check = None
@@ -285,6 +376,8 @@ def main():
         ok = all(hashlib.sha1(got[r * g0 * 4:(r + 1) * g0 * 4].tobytes()).hexdigest() == digests[r] for r in range(world))
         # ranks separate different audio: equal digests would mean the check compares a buffer with itself
         ok = ok and len(set(digests)) == world and bool(np.any(got))
+        if gather_mode[0] == "root" and rank != 0:
+            ok = True                                       # only the root holds the gathered buffer
         flags = [None] * world
         dist.all_gather_object(flags, bool(ok))
         gather_check = "ok" if all(flags) else "MISMATCH"
@@ -331,41 +424,46 @@ def main():
     # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
     # WRITE_SIZE need their own rocprofv3 runs, scripts/gpu_traffic.sh); 2*FETCH + WRITE per the gfx950
     # correction of MI355X_MICROARCH.md.  None when the workload has no matching record.
-    traffic_rec = {}
-    try:
-        with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
-            traffic_rec = json.load(fh)
-    except Exception:
-        pass
+    traffic_all = load_traffic().get("all", {})
 
     net0 = lanes[0].sep.net
 
     def roof(tiles_per_launch, ms, launches, frames=None, key=None, clips=1):
         """Roofline block of the dominant kernel for launches of `tiles_per_launch` tiles in `clips` clips.  `achieved`
         is ALGORITHMIC f32 work (the reference's count for the layers the kernel replaces) over the measured duration,
-        priced against the f32 peak -- the arithmetic the path computes in.  When the launch runs the bf16x3 kernel the
-        work is issued as six bf16 products per f32 product on K padded 50 -> 64 and bins padded to whole 128-bin
-        workgroups; `issued` prices that against the dense bf16 MFMA peak."""
+        priced against the f32 peak -- the arithmetic the path computes in.  When the launch runs a bf16x3 kernel the
+        work is issued as six bf16 products per f32 product on K padded 50 -> 64 and bins padded to whole workgroups;
+        `issued` prices that against the dense bf16 MFMA peak.  `traffic` = 2*FETCH + WRITE of the same kernel at the same
+        grid size from the committed rocprofv3 --pmc passes (TRAFFIC_FILE), `traffic_ratio` = traffic / algorithmic bytes."""
         frames = (tiles_per_launch - 1) * (TC - OV) + TC if frames is None else frames
         ach = tiles_per_launch * final_flops_tile / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        rec = traffic_rec.get(key or "final_kernel_%d_tiles" % int(tiles_per_launch)) if N == 2048 else None
-        traffic = int((2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024) if rec else None
-        variant = net0.final_kernel(int(round(frames / float(clips))), clips)
+        clip_frames = int(round(frames / float(clips)))
+        variant = net0.final_kernel(clip_frames, clips)
+        rows16 = (clip_frames + 2 + 15) // 16          # the kernels run over all T frames of a clip (the tiles cover T - 2 or T - 3)
+        binpad = {"bf16x3": 128, "f32x128": 128, "f32x64": 64, "one_batch": 64}.get(variant, 128)
+        colg = (F + binpad - 1) // binpad
+        kname = {"bf16x3": "final_bf16x3_kernel", "one_batch": "lat_final_kernel"}.get(variant, "final_kernel")
+        grid_threads = (512 if variant == "one_batch" else 256) * rows16 * colg * clips
+        rec = traffic_all.get("%s@grid_threads=%d" % (kname, grid_threads)) if N == 2048 else None
+        traffic = traffic_bytes(rec)
+        g_bytes = 6 if variant in ("bf16x3", "one_batch") else 4
+        alg_bytes = int(tiles_per_launch * (3 * TC * 56 * g_bytes) + frames * F * 4 * 5)
         r = {"bound": "mfma", "kernel": FINAL_NAMES.get(variant, variant), "variant": variant,
              "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
              "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
-             "traffic_source": (TRAFFIC_FILE + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                "command, 2*FETCH+WRITE; not measured in this run)") if rec else None,
+             "traffic_ratio": round(traffic / float(alg_bytes), 3) if traffic else None,
+             "traffic_source": ("%s, record %s@grid_threads=%d (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                "this launch shape, 2*FETCH+WRITE; not measured in this run)"
+                                % (TRAFFIC_FILE, kname, grid_threads)) if rec else None,
              # G rows read once (3 branches x tc x 56 stored channels) + mixture read + 4 sources written
-             "algorithmic_bytes": int(tiles_per_launch * (3 * TC * 56 * (6 if variant == "bf16x3" else 4))
-                                      + frames * F * 4 * 5),
+             "algorithmic_bytes": alg_bytes,
              "avg_kernel_ms": round(ms, 5), "launches": int(launches),
              "tiles_per_launch": round(float(tiles_per_launch), 2)}
-        if variant == "bf16x3":
-            issued = ach * 6.0 * (64.0 / 50.0) * (((F + 127) // 128) * 128.0 / F)
+        if variant in ("bf16x3", "one_batch"):
+            issued = ach * 6.0 * (64.0 / 50.0) * (colg * binpad / float(F))
             r["issued"] = {"achieved": round(issued, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s (bf16 MFMA)",
                            "frac": round(issued / PEAK_F16_TFLOPS, 4),
-                           "note": "6 bf16 products per f32 product, K 50->64, bins padded to 128-bin workgroups"}
+                           "note": "6 bf16 products per f32 product, K 50->64, bins padded to %d-bin workgroups" % binpad}
             r["note"] = ("frac prices f32-equivalent algorithmic work against the 157.3 TFLOP/s f32 peak; the kernel "
                          "executes on the bf16 matrix pipe (see issued), so frac may exceed what an f32 kernel can reach")
         return r
@@ -376,6 +474,9 @@ def main():
     roofline["timed"] = ("HIP events around every launch of the kernel in %d of the %d timed rounds; those rounds run "
                          "their K steps on stream 0 alone" % (events_rounds, len(round_s)))
     single = {"ms_per_step": round(el1 * 1e3, 5), "value": round(world * frames_per_step / el1, 1),
+              "whole_path_frac_of_f32_peak": round(n_tiles * ARCHS["dsd"].flops_per_tile(TC, F) / el1 / 1e12 / PEAK_F32_TFLOPS, 4),
+              "kernels": "one-batch kernels (csrc/dsd_lat.hip), one launch per layer, issued eagerly" if net0.final_kernel(T, 1) == "one_batch"
+                         else "throughput kernels",
               "steps_per_round": k1, "rounds": len(single_rounds),
               "roofline": roof(n_tiles, final_ms1, final_launches1), "kernels_ms": kernels_ms,
               "kernels_ms_sum": round(sum(kernels_ms.values()), 5)}
@@ -519,12 +620,54 @@ def main():
             except Exception as exc:     # a leg must not take the headline line down with it
                 legs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
+    # ---- the timed launches did the work: PCM of one clip of the last timed launch group (and of the last one-batch
+    # call) against the CPU oracle on the same audio (outside every timed region; the oracle only checks here)
+    parity_check = None
+    if not args.no_parity_check:
+        from oracle import pipeline
+        ln = lanes[0]
+        g_last = groups[0]
+        ln.step(g_last)                                     # the launch shape of the timed rounds, same buffers
+        torch.cuda.synchronize()
+        clip = g_last - 1
+        got = ln.pcm[clip].cpu().numpy().astype(np.float64)
+        want = pipeline.separate("dsd", params, ln.audio_h[clip], SCALE, TC, OV, 32, N, HOP, np.hanning)
+        err_group = float(np.max(np.abs(got - want)))
+        ln.step(1)                                          # one batch per call (single_stream)
+        torch.cuda.synchronize()
+        got1 = ln.pcm[0].cpu().numpy().astype(np.float64)
+        want1 = pipeline.separate("dsd", params, ln.audio_h[0], SCALE, TC, OV, 32, N, HOP, np.hanning)
+        err_single = float(np.max(np.abs(got1 - want1)))
+        worst = max(err_group, err_single)
+        if world > 1:
+            tt = torch.tensor([worst], dtype=torch.float64, device=lanes[0].audio.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            worst = float(tt.item())
+        parity_check = {"max_abs_pcm_err": worst, "tolerance": 1e-4, "ok": bool(worst < 1e-4 and np.isfinite(worst)),
+                        "vs": "oracle.pipeline.separate (reference NumPy STFT / tiling / overlap-add + float64 network) on the same audio",
+                        "launch_group": {"clips": int(g_last), "clip_checked": int(clip), "tiles": int(n_tiles),
+                                         "max_abs_pcm_err": err_group, "final_kernel": net0.final_kernel(T, g_last)},
+                        "single_stream": {"tiles": int(n_tiles), "max_abs_pcm_err": err_single,
+                                          "final_kernel": net0.final_kernel(T, 1)},
+                        "ranks": int(world)}
+
+    whole_flops_step = n_tiles * ARCHS["dsd"].flops_per_tile(TC, F)
+    cli = None
+    if rank == 0 and world == 1 and not args.no_cli:
+        try:
+            cli = run_cli(torch, dcs, synth_audio, synth_params)
+        except Exception as exc:
+            cli = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     if rank == 0:
         line = {
             "metric": "spectrogram-frames/s", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": args.warmup, "ms_per_step": round(med / K * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "x_realtime": round(value * HOP / SR, 1),
+            "whole_path_algorithmic_tflops": round(world * whole_flops_step * K / med / 1e12, 2),
+            "whole_path_frac_of_f32_peak": round(whole_flops_step * K / med / 1e12 / PEAK_F32_TFLOPS, 4),
+            "parity_check": parity_check,
             "rounds": len(round_s), "timed_region_s": round(total, 4),
             "round_ms": {"median": round(med * 1e3, 4), "min": round(min(round_s) * 1e3, 4),
                          "max": round(max(round_s) * 1e3, 4),
@@ -543,13 +686,80 @@ def main():
                        "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",
                        "parallelism": "tiles sharded by rank (dp%d)" % world},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_stream": single, "launch_group": launch_group,
-            "saturating": saturating, "host_fed": host_fed, "legs": legs,
+            "saturating": saturating, "host_fed": host_fed, "legs": legs, "cli": cli,
         }
         if gather_check is not None:
             line["gather_check"] = gather_check
+        if gather_split is not None:
+            line["gather"] = gather_split
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ the command lines
+def run_cli(torch, dcs, synth_audio, synth_params):
+    """What a user of the reference gets (separate_dsd.py -i -o -m; separate_multiple.ipynb loops it over a folder):
+    the drop-in command on one 10 s stereo wav as a process (wall clock incl. interpreter + torch import + model upload)
+    and stage by stage in this process, and examples/separate_batch.py over 50 wavs with the model resident."""
+    import subprocess
+    from deepconvsep_amd import separation as sp
+    tmp = tempfile.mkdtemp(prefix="dcs_cli_")
+    F = 513                                                  # the as-shipped DSD config: frameSize 1024, hop 512
+    params = synth_params("dsd", TC, F, seed=2)
+    model = os.path.join(tmp, "model.pkl")
+    dcs.save_model(model, params)
+    Lc = 441000
+    wavs = []
+    for i in range(50):
+        w = os.path.join(tmp, "clip%02d.wav" % i)
+        sp.write_wav(w, synth_audio(Lc, seed=500 + i, channels=2), SR)
+        wavs.append(w)
+    out1 = os.path.join(tmp, "out1")
+    os.makedirs(out1)
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "dsd100", "separate_dsd.py"), "-i", wavs[0], "-o", out1,
+                        "-m", model], capture_output=True, text=True, timeout=600)
+    t_proc = time.perf_counter() - t0
+    if r.returncode != 0 or not os.path.isfile(os.path.join(out1, "vocals.wav")):
+        raise RuntimeError("separate_dsd.py failed: " + (r.stderr or r.stdout)[-300:])
+    # the same steps in this process (libraries already loaded), timed one by one
+    st = {}
+    t0 = time.perf_counter(); p2 = sp.load_model(model); st["load_model_pkl"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); sr, audio = sp.read_wav(wavs[0]); mono = sp.to_mono(audio, "dsd"); st["read_wav_to_mono"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sep = sp.Separator("dsd", p2, SCALE, TC, 25, 32, F, 1024, HOP, np.hanning)
+    torch.cuda.synchronize(); st["model_upload_and_plan"] = time.perf_counter() - t0
+    sep.separate(mono); torch.cuda.synchronize()            # first call: workspace allocation
+    ctx = sep.ctx
+    t0 = time.perf_counter(); a = ctx.to_device(mono, np.float32); torch.cuda.synchronize(); st["h2d_float32_audio"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); pcm_d = sep.net.separate(sep.plan, a, 25, sep.tiler, SCALE); torch.cuda.synchronize(); st["kernels"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); pcm = ctx.to_host(pcm_d).astype(np.float64); st["d2h_and_float64"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for path, sig in zip(sp.output_paths("dsd", wavs[0], out1), pcm):
+        sp.write_wav(path, sig, sr)
+    st["write_4_wavs"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); sep.separate(mono); st["Separator.separate_total"] = time.perf_counter() - t0
+    out50 = os.path.join(tmp, "out50")
+    os.makedirs(out50)
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "separate_batch.py"), "-a", "dsd", "-m", model, "-o", out50]
+                       + wavs, capture_output=True, text=True, timeout=900)
+    t_batch = time.perf_counter() - t0
+    if r.returncode != 0 or not os.path.isfile(os.path.join(out50, "clip49", "vocals.wav")):
+        raise RuntimeError("separate_batch.py failed: " + (r.stderr or r.stdout)[-300:])
+    frames = int(np.ceil(Lc / float(HOP))) + 2
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {"workload": "DSD as shipped (frameSize 1024, hop 512, 513 bins), 10 s stereo 44.1 kHz int16 wavs, synthetic weights",
+            "separate_dsd_py_process_s": round(t_proc, 3),
+            "separate_dsd_py_note": "python separate_dsd.py -i clip.wav -o out -m model.pkl as a process: interpreter start, torch / "
+                                    "libdcs import, model upload, one file, 4 wavs written",
+            "in_process_ms": {k: round(v * 1e3, 3) for k, v in st.items()},
+            "separate_batch_py_50_files_s": round(t_batch, 3),
+            "separate_batch_py_ms_per_file": round(t_batch / 50.0 * 1e3, 2),
+            "separate_batch_py_x_realtime": round(50 * Lc / float(SR) / t_batch, 1),
+            "separate_batch_py_frames_per_s": round(50 * frames / t_batch, 1)}
 
 
 # ------------------------------------------------------------------------------------------------ other configs
@@ -691,11 +901,53 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
     roofline = kernel_roofline(dom, k_ms[dom] / calls, flops, nbytes, peak, KERNEL_NAMES[dom])
     roofline["tiles_per_launch"] = round(tiles_per_pass, 1)
     roofline["timed"] = "HIP events around every kernel of %d instrumented whole-path passes (separate from the timed passes)" % reps
+    leg_traffic = load_traffic().get("legs", {}).get(name, {})
+
+    def leg_record(tag):
+        """Counter record (per launch) of the kernel that carries `tag` in this leg: the matching kernel with the most bytes."""
+        sub = LEG_KERNELS.get(name, {}).get(tag)
+        best = None
+        for kname, rec in leg_traffic.items():
+            if sub and sub in kname:
+                b = traffic_bytes(rec)
+                if b and (best is None or b > best[0]):
+                    best = (b, kname)
+        return best
+
+    def issued_block(tag, ach_tf):
+        if tag not in LEG_ISSUED.get(name, {}):
+            return None
+        prod, pad = LEG_ISSUED[name][tag]
+        iss = ach_tf * prod * pad
+        return {"achieved": round(iss, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s (16-bit MFMA)",
+                "frac": round(iss / PEAK_F16_TFLOPS, 4),
+                "note": "%d 16-bit products per f32 product, K padded x%.3f" % (prod, pad)}
+
+    def finish(r, tag):
+        tr = leg_record(tag)
+        if tr:
+            r["traffic"] = tr[0]
+            r["traffic_ratio"] = round(tr[0] / float(r["algorithmic_bytes"]), 3)
+            r["traffic_source"] = "%s legs/%s/%s (rocprofv3 --pmc passes of this leg, 2*FETCH+WRITE per launch)" % (TRAFFIC_FILE, name, tr[1])
+        if r["bound"] == "mfma":
+            ach_f32 = r["algorithmic_flops"] / (r["avg_kernel_ms"] * 1e-3) / 1e12 if r["avg_kernel_ms"] > 0 else 0.0
+            ib = issued_block(tag, ach_f32)
+            if ib:
+                r["issued"] = ib
+                r["note"] = ("runs on the 16-bit matrix pipe (operands split into three bf16 terms, or f16 inputs): `frac` prices "
+                             "the reference's f32 flop count against `peak`, `issued` the products actually issued against 2.5 PFLOP/s")
+        return r
+
+    roofline = finish(roofline, dom)
     table = {}
     for t in work_tags:
         fl, by, pk = arch_work(arch, TC, Fb, n / float(max(1, k_launch[t] // per_tag_launches.get(t, 1))), f16)[t]
-        r = kernel_roofline(t, k_ms[t] / max(1, k_launch[t] // per_tag_launches.get(t, 1)), fl, by, pk, KERNEL_NAMES[t])
-        table[t] = {"ms_per_clip": k_ms[t], "bound": r["bound"], "frac": r["frac"]}
+        r = finish(kernel_roofline(t, k_ms[t] / max(1, k_launch[t] // per_tag_launches.get(t, 1)), fl, by, pk, KERNEL_NAMES[t]), t)
+        table[t] = {"ms_per_clip": k_ms[t], "bound": r["bound"], "frac": r["frac"], "peak": r["peak"], "unit": r["unit"]}
+        if r.get("issued"):
+            table[t]["issued_frac_of_16bit_peak"] = r["issued"]["frac"]
+        if r.get("traffic"):
+            table[t]["traffic_ratio"] = r["traffic_ratio"]
     frames = Tfr
     total_flops = n * arch.flops_per_tile(TC, Fb, live_only=True)
     res = {"workload": what, "tiles": int(n), "frames": int(frames), "audio_seconds": round(Lc / float(SR), 2),
@@ -705,11 +957,22 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
            "kernels_ms": k_ms, "kernels_ms_sum": round(sum(k_ms.values()), 5), "kernel_rooflines": table,
            "whole_path_algorithmic_tflops": round(total_flops / sec / 1e12, 2),
            "roofline": roofline}
+    wp = total_flops / sec / 1e12
+    if wp <= PEAK_F32_TFLOPS and not f16:
+        res["whole_path_frac_of_f32_peak"] = round(wp / PEAK_F32_TFLOPS, 4)
+    else:
+        # part of this path runs on the 16-bit matrix pipe: the f32 peak is not the governing one for the whole path
+        res["whole_path_frac_of_16bit_peak"] = round(wp / PEAK_F16_TFLOPS, 4)
+        res["whole_path_note"] = ("reference-counted f32 flops; conv2 / conv2^T (and the dense layers' bf16x3 GEMMs) execute on the "
+                                  "16-bit matrix pipe, so the 157.3 TFLOP/s f32 peak does not bound this path -- per-kernel fractions "
+                                  "are in kernel_rooflines")
     if with_cpu:
         from oracle import pipeline, tiling_np
         # bounded sample of the same input: the first ~32 tiles (the reference's batch), about 10 s of CPU work
         n_s = min(int(n), 32)
         Ls = min(Lc, samples_for_tiles(n_s, ov=ov, library=library))
+        if name == "ikala":        # BASELINE configs[0] IS the CPU reference on the whole 10 s wav: no sampling
+            n_s, Ls = int(n), Lc
         audio_s = np.asarray(audio[:Ls], dtype=np.float64)
         T_s = int(np.ceil(Ls / float(HOP))) + 2
         if melody is not None:
@@ -725,13 +988,14 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
         torch.set_num_threads(nt)
         sec_c, reps_c, el_c = time_cpu(run_cpu, 6.0, 50)
         torch.set_num_threads(1)
-        sec_1, reps_1, el_1 = time_cpu(run_cpu, 4.0, 50)
+        sec_1, reps_1, el_1 = time_cpu(run_cpu, 4.0 if name != "ikala" else 0.5, 50)
         torch.set_num_threads(nt)
         res["cpu_baseline"] = {"value": round(T_s / sec_c, 1), "unit": "frames/s", "cores": int(nt), "kind": "port",
                                "single_thread": {"value": round(T_s / sec_1, 1), "cores": 1},
                                "cpu_model": cpu_name, "host_cpu_count": int(ncpu),
                                "label": "reference-equivalent CPU path (Theano unavailable)",
-                               "sample": "the first %.2f s (%d tiles, %d frames) of the same clip through the oracle "
+                               "sample": ("the WHOLE clip: " if Ls == Lc else "a bounded sample: ") +
+                                         "the first %.2f s (%d tiles, %d frames) of the same clip through the oracle "
                                          "(reference NumPy loops + torch-CPU float64 network), %d x at %d threads "
                                          "(%.1f s) and %d x at 1 thread (%.1f s)"
                                          % (Ls / float(SR), n_s, T_s, reps_c, nt, el_c, reps_1, el_1)}

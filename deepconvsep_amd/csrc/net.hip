@@ -574,6 +574,11 @@ extern "C" int dcs_model_set_conv_precision(dcs_model* m, int f16) {
     return DCS_OK;
 }
 
+// one clip of at most this many frames takes the one-batch kernels (DCS_LAT_MAX_FRAMES)
+static int64_t dcs_lat_max_frames() {
+    static const int64_t v = getenv("DCS_LAT_MAX_FRAMES") ? atoll(getenv("DCS_LAT_MAX_FRAMES")) : 640;
+    return v;
+}
 extern "C" int dcs_model_set_latency_stages(dcs_model* m, int stages) {
     if (!m) DCS_FAIL(DCS_EINVAL, "dcs_model_set_latency_stages: null model");
     if (stages < -1 || stages > DCS_LAT_ALL) DCS_FAIL(DCS_EINVAL, "dcs_model_set_latency_stages: %d", stages);
@@ -589,6 +594,11 @@ extern "C" int dcs_model_out_channels(const dcs_model* m) { return m ? m->d.n_br
 extern "C" int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips, int eps_mode) {
     if (!m || n_frames < 1) return DCS_EINVAL;
     if (m->arch != DCS_ARCH_DSD) return DCS_EUNSUPPORTED;
+    if (m->lat_ok && n_clips <= 1 && eps_mode < 2) {   // the one-batch kernels (dsd_lat.hip): as separate_impl selects them
+        static const int env_mask = getenv("DCS_LAT") ? atoi(getenv("DCS_LAT")) : -1;
+        const int want = m->lat_stages >= 0 ? m->lat_stages : (env_mask >= 0 ? env_mask : (n_frames <= dcs_lat_max_frames() ? DCS_LAT_ALL : 0));
+        if (want & DCS_LAT_FINAL) return 3;
+    }
     if (m->Bpk && dsd_final_bf16x3(m->ctx, n_frames, m->F, n_clips, m->CI, eps_mode)) return 2;
     return dsd_final_cbw(m->ctx, n_frames, m->F, n_clips) == 2 ? 1 : 0;
 }
@@ -616,11 +626,6 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------ fused path
-// one clip of at most this many frames takes the one-batch kernels (DCS_LAT_MAX_FRAMES)
-static int64_t dcs_lat_max_frames() {
-    static const int64_t v = getenv("DCS_LAT_MAX_FRAMES") ? atoll(getenv("DCS_LAT_MAX_FRAMES")) : 640;
-    return v;
-}
 // the automatic selection: one launch per layer.  The 8-workgroup-cluster launch of the middle (DCS_LAT_MID) is built and
 // tested but measured slower (a cluster per tile re-reads the 1.9 MB of weights per tile: 77 MB per batch through L2)
 constexpr int kLatDefault = DCS_LAT_ALL & ~DCS_LAT_MID;

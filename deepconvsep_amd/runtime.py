@@ -238,10 +238,11 @@ class Network(object):
 
     def final_kernel(self, n_frames, n_clips=1, eps_mode=None):
         """Which kernel the fused path runs for the last decoder stage on a launch of this size: ``'f32x64'``,
-        ``'f32x128'`` or ``'bf16x3'`` (``dcs_model_final_kernel``); None for graphs without a fused decoder."""
+        ``'f32x128'``, ``'bf16x3'`` or ``'one_batch'`` (the kernel of csrc/dsd_lat.hip a single short clip takes) -- ``dcs_model_final_kernel``; None for graphs
+        without a fused decoder."""
         eps = self.arch.eps_mode if eps_mode is None else eps_mode
         code = int(self.ctx._lib.dcs_model_final_kernel(self._h, int(n_frames), int(n_clips), int(eps)))
-        return {0: 'f32x64', 1: 'f32x128', 2: 'bf16x3'}.get(code)
+        return {0: 'f32x64', 1: 'f32x128', 2: 'bf16x3', 3: 'one_batch'}.get(code)
 
     def set_latency_stages(self, stages):
         """Stages of the fused path that run on the one-batch kernels (``dcs_model_set_latency_stages``): -1 automatic,

@@ -155,8 +155,9 @@ int dcs_model_out_channels(const dcs_model* m);
 /* Which kernel the fused path (dcs_separate*) runs for the decoder's last stage (transposed conv1 + bias + rectify + mask
  * + cross-fade) on n_clips clips of n_frames frames each: 0 = f32 MFMA, 64-bin workgroups (small launches); 1 = f32
  * MFMA, 128-bin workgroups; 2 = bf16 MFMA on operands split exactly into three bf16 terms (f32-class results, the
- * default for launches that fill the chip; DSD / hiphop graph); negative: not a fused-kernel graph.  bench.py prices
- * its roofline block with this. */
+ * default for launches that fill the chip; DSD / hiphop graph); 3 = the one-batch kernel of csrc/dsd_lat.hip (one clip of
+ * at most DCS_LAT_MAX_FRAMES frames, see dcs_model_set_latency_stages; the same bf16x3 arithmetic, 16 x 64 workgroups);
+ * negative: not a fused-kernel graph.  bench.py prices its roofline block with this. */
 int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips, int eps_mode);
 
 /* ------------------------------------------------------------------ fused file-level path */

@@ -103,3 +103,42 @@ NET_CASES = [
     ("net_bach10si_f129_sparse", "bach10_si", 129, 1, 40, "sparse"),
     ("net_dsdild_f33_glorot", "dsd_ild", 33, 1, 41, "glorot"),
 ]
+
+
+# ---- randomised draws (tests/test_oracle_net.py on the CPU against the reference's executed graph, tests/test_gpu_random.py
+# on the GPU against net_ref): beyond the committed fixtures.  A draw = (graph, small F, batch, weights, input), all from one
+# integer seed: weight gain 0.5 .. 2.2, dense biases of either sign, output biases from strongly negative (most outputs cut
+# to exact zeros) to positive, inputs from dense noise to few-level / silent rows (max-pool ties in the iKala graph).
+RANDOM_GRAPHS = (("dsd", 65), ("dsd", 129), ("ikala", 270), ("ikala", 303), ("bach10", 129), ("bach10_si", 129))
+
+
+def random_draw(seed):
+    rs = np.random.RandomState(10_000 + int(seed))
+    arch, F = RANDOM_GRAPHS[int(seed) % len(RANDOM_GRAPHS)]
+    tc, B = 30, int(rs.randint(1, 4))
+    gain = float(rs.uniform(0.5, 2.2))
+    params = synth_params(arch, tc, F, seed=int(rs.randint(1 << 30)), gain=gain)
+    n_fc = ARCHS[arch].n_fc
+    lo, hi = sorted(rs.uniform(-0.6, 0.3, 2))
+    for i in [7] + [9 + 2 * k for k in range(n_fc)]:
+        params[i] = rs.uniform(lo, hi, params[i].shape).astype(np.float32)
+    for i in (1, 2, 4, 5):                                      # the conv / BiasLayer biases
+        params[i] = rs.uniform(-0.2, 0.2, params[i].shape).astype(np.float32)
+    C = ARCHS[arch].C
+    style = int(rs.randint(3))
+    if style == 0:
+        x = 0.3 * rs.uniform(0, 3, (B, C, tc, F))
+    elif style == 1:                                             # few levels: equal neighbours -> ties in the max-pool
+        x = 0.3 * rs.randint(0, 3, (B, C, tc, F)).astype(np.float64)
+    else:                                                        # sparse input with silent rows and a silent tile
+        x = 0.3 * rs.uniform(0, 3, (B, C, tc, F)) * (rs.uniform(size=(B, C, tc, F)) < 0.3)
+        x[0, :, int(rs.randint(0, tc - 6)):][:, :5] = 0.0
+        if B > 1:
+            x[B - 1] = 0.0
+    x = x.astype(np.float32)
+    y = pre_bias_output(arch, params, x)
+    q = float(rs.choice([0.1, 0.5, 0.9, 0.97]))                  # share of the outputs the rectifier cuts to zero
+    bias = np.array([-np.quantile(y[:, c], q) for c in range(y.shape[1])])
+    bias += rs.uniform(-0.02, 0.02, bias.shape)
+    params[-1] = bias.astype(np.float32)
+    return arch, F, params, x

@@ -224,6 +224,8 @@ def test_bench_two_ranks_on_this_gpu_gather_is_exact():
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
     assert line["gather_check"] == "ok"
     assert line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert line["gather"]["mode"] == "allgather" and line["gather"]["ms_per_group_collective_alone"] > 0
+    assert line["parity_check"]["ok"] is True
 
 
 def _long_file_worker(rank, world, port, audio, params, ret):
@@ -239,6 +241,72 @@ def _long_file_worker(rank, world, port, audio, params, ret):
     if rank == 0:
         ret["pcm"] = out.numpy()
     dist.destroy_process_group()
+
+
+def _long_file_device_worker(rank, world, port, audio, params, ret):
+    """As _long_file_worker, but the per-rank separation is Network.separate on DEVICE tensors and the collective runs on
+    them -- the branch RCCL takes on a multi-GPU node (dist.py: torch tensors in, all_gather of device buffers)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from deepconvsep_amd.dist import separate_long_file
+    from deepconvsep_amd.runtime import default_context
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, 513, 1024, 512, np.hanning)
+    ctx = default_context()
+    dev = ctx.to_device(audio, np.float32)
+
+    def fn(seg):                                        # seg: a device slice of the signal
+        return sep.net.separate(sep.plan, seg.contiguous(), 25, sep.tiler, 0.3)
+    try:
+        out = separate_long_file(fn, dev, 1024, 512, 30, 25)
+        ret["device"] = bool(out.is_cuda)
+        if rank == 0:
+            ret["pcm"] = out.cpu().numpy()
+    except RuntimeError as exc:                          # a gloo build without device-tensor collectives
+        ret["error"] = str(exc)
+    dist.destroy_process_group()
+
+
+def test_long_file_sharded_over_two_ranks_on_device_tensors():
+    import torch.multiprocessing as mp
+    params = synth_params("dsd", 30, 513, seed=2)
+    audio = synth_audio(6 * 44100, seed=8)
+    whole = dcs.Separator("dsd", params, 0.3, 30, 25, 32, 513, 1024, 512, np.hanning).separate(audio)
+    ctxm = mp.get_context("spawn")
+    mgr = ctxm.Manager()
+    ret = mgr.dict()
+    mp.spawn(_long_file_device_worker, args=(2, _free_port(), audio, params, ret), nprocs=2, join=True)
+    if "error" in ret:
+        pytest.skip("gloo cannot gather device tensors here: %s" % ret["error"][:200])
+    assert ret["device"] is True
+    got = ret["pcm"]
+    assert got.shape == whole.shape
+    assert np.max(np.abs(got - whole)) < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["root", "none"])
+def test_bench_two_ranks_gather_modes(mode):
+    """bench.py --gpus 2 --gather root / none: the root gather of the north-star ("final gather") and the replica mode,
+    with the per-launch-group split of compute and collective in the line."""
+    env = dict(os.environ, DCS_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    if mode == "root":
+        env["DCS_BENCH_CHECK_GATHER"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--sat-tiles", "0", "--min-time", "0.02", "--legs", "", "--gather", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    if r.returncode != 0 and mode == "root" and "gloo" in (r.stderr + r.stdout).lower() and "gather" in (r.stderr + r.stdout).lower():
+        pytest.skip("gloo cannot gather device tensors to a root here")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["gather"]["mode"] == mode and line["gather"]["round_ms_without_gather"] > 0
+    if mode == "root":
+        assert line["gather_check"] == "ok" and line["gather"]["ms_per_group_collective_alone"] > 0
+    assert line["parity_check"]["ok"] is True and line["parity_check"]["ranks"] == 2
 
 
 def test_long_file_sharded_over_two_ranks_with_the_hip_separator():

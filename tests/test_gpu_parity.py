@@ -637,6 +637,29 @@ def test_separate_batch_equals_clip_by_clip(N, seconds, clips, tiler, hop):
     assert np.array_equal(got2, got)
 
 
+@pytest.mark.parametrize("clips", [20, 32])
+def test_bench_launch_shapes_match_oracle(clips):
+    """The launch groups bench.py times -- 20 (the driver's --steps 20) and 32 (the default) independent 32-tile batches
+    of N = 2048 in ONE set of launches (dcs_separate_batch), the bf16x3 final kernel selected by size, not by an
+    environment switch -- against the oracle, clip by clip: PCM within 1e-4 on every sample of every clip."""
+    N, F, hop, tc, ov = 2048, 1025, 512, 30, 25
+    params = synth_params("dsd", tc, F, seed=2)
+    L = (tc + 1 + 31 * (tc - ov) - 2) * hop
+    audio = np.stack([synth_audio(L, seed=300 + c) for c in range(clips)])
+    audio[3, 20000:30000] = 0.0
+    sep = dcs.Separator("dsd", params, 0.3, tc, ov, 32, F, N, hop, np.hanning)
+    T = _lib.frame_count(L, hop)
+    assert sep.net.final_kernel(T, clips) == "bf16x3"
+    ctx = default_context()
+    pcm = sep.net.separate_batch(sep.plan, ctx.to_device(audio, np.float32), ov, sep.tiler, 0.3).cpu().numpy()
+    assert pcm.shape == (clips, 4, L) and sep.net.last_tiles == 32
+    worst = 0.0
+    for c in range(clips):
+        want = pipeline.separate("dsd", params, audio[c], 0.3, tc, ov, 32, N, hop, np.hanning)
+        worst = max(worst, float(np.max(np.abs(pcm[c] - want))))
+    assert worst < 1e-4
+
+
 _WHOLE_PATH_CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
@@ -930,7 +953,12 @@ def test_bf16x3_final_kernel_meets_the_parity_bar(kind, tmp_path):
         fh.write("dsd fused path (bf16x3 final kernel), %s weights: %d bins of the separated spectrogram, outside 1e-4: %d, "
                  "max err %.2e; vs the f32 kernel max %.2e\n" % (kind, err[0].size, int((err.max(axis=0) > 1e-4).sum()),
                                                                   err.max(), np.abs(sep16 - sep32).max()))
-    assert (err.max(axis=0) > 1e-4).mean() <= (0.0 if kind == "glorot" else 0.02)
+    # what is measured: 0 bins outside 1e-4 (glorot, sparse), 1 of 267 525 (tiny).  Allowed: 0 / at most 2, and only where the
+    # reference itself has (nearly) nothing in every source -- there the mask is discontinuous
+    bad = err.max(axis=0) > 1e-4
+    assert int(bad.sum()) <= (0 if kind == "glorot" else 2)
+    if bad.any():
+        assert float(np.max(np.abs(mm[:, bad]))) < 1e-5
 
 
 # ------------------------------------------------------------------ score-informed path

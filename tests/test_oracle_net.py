@@ -219,3 +219,24 @@ def test_lasagne_standin_layer_order_and_alias():
     with pytest.raises(ValueError):
         L.set_all_param_values(out, [np.zeros(1)])
     assert L.get_output(out).shape == (2, 2, 6, 8)
+
+
+@pytest.mark.skipif(not ref_exec.available(), reason="needs /root/reference (build container only)")
+@pytest.mark.parametrize("seed", range(24))
+def test_random_draws_net_ref_equals_the_executed_reference_graph(seed):
+    """24 seeded draws (graph, weights of either bias sign and gain 0.5 .. 2.2, dense / few-level / sparse inputs,
+    10 .. 97 % of the outputs cut to exact zeros): the torch oracle against the reference's own build_ca source executed on
+    the Lasagne stand-in -- network output, both tie routings of the iKala graph, masked sources."""
+    arch, F, params, x = cases.random_draw(seed)
+    p_ref = ref_exec.network_output(arch, params, x)
+    p = net_ref.forward(arch, params, x.astype(np.float64), inverse='explicit').numpy()
+    assert p.shape == p_ref.shape
+    assert np.max(np.abs(p - p_ref)) < 1e-11
+    if arch == "ikala":
+        p1 = net_ref.forward(arch, params, x.astype(np.float64), tie_mode='first', inverse='explicit').numpy()
+        assert np.max(np.abs(p1 - ref_exec.network_output(arch, params, x, tie_mode="first"))) < 1e-11
+    m_ref = ref_exec.mask_sources(arch, p_ref, x)
+    m = net_ref.predict(arch, params, x.astype(np.float64), inverse='explicit')
+    assert len(m) == len(m_ref)
+    for a, b in zip(m, m_ref):
+        assert np.max(np.abs(a - b)) < 1e-11
