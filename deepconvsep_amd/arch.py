@@ -5,6 +5,8 @@ script; the HIP model (``csrc/``) is instantiated from it.
 
   dsd / hiphop  examples/dsd100/separate_dsd.py:172-236  (hiphopss/separate_hhds.py:171-235)
   ikala         examples/ikala/separate_ikala.py:172-192   (max-pool variant)
+  ikala_nopool  examples/ikala/trainCNN.py:87-118         (the trainer's graph: no pooling layer; a .pkl written by that
+                trainer has 90 090 rows in fc.W instead of 13 230 -- `resolve` picks the graph from the shapes)
   bach10        examples/bach10/separate_bach10.py:172-229
   bach10_si     examples/bach10_scoreinformed/separate_bach10.py:388-447
   dsd_ild       examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115   (stereo input, 4 branches x 2 channels)
@@ -12,7 +14,7 @@ script; the HIP model (``csrc/``) is instantiated from it.
 import numpy as np
 
 # enum values shared with include/dcs.h
-ARCH_DSD, ARCH_IKALA, ARCH_BACH10, ARCH_BACH10_SI, ARCH_DSD_ILD = 0, 1, 2, 3, 4
+ARCH_DSD, ARCH_IKALA, ARCH_BACH10, ARCH_BACH10_SI, ARCH_DSD_ILD, ARCH_IKALA_NOPOOL = 0, 1, 2, 3, 4, 5
 EPS_A, EPS_B = 0, 1
 EPS_ILD = 3   # per input channel, p / (sum + 1e-12 r), + 1e-12 r (trainCNN_ILD_DSD100.py:176-180); dcs_separate_stereo only
 TIE_ALL, TIE_FIRST = 0, 1
@@ -90,6 +92,20 @@ ARCHS = {
                     [0, 1, 2, 3], 4, EPS_ILD, ['vocals', 'bass', 'drums', 'other']),
 }
 ARCHS['hiphop'] = ARCHS['dsd']
+ARCHS['ikala_nopool'] = Arch('ikala_nopool', ARCH_IKALA_NOPOOL, 1, (30, 30, 3), 0, (30, lambda tc: 10, 20), 256,
+                             [0, 1], 2, EPS_A, ['voice', 'music'])
+
+
+def resolve(arch, params, tc, F):
+    """The graph a parameter list belongs to.  'ikala' is two graphs in the reference: separate_ikala.py builds it with a
+    (1, 4) max-pool (separate_ikala.py:176), ikala/trainCNN.py:92-100 without; the trainer's .pkl files therefore only load
+    into the no-pool graph.  The bottleneck's input size tells them apart (fc.W rows 13 230 vs 90 090 at 513 bins)."""
+    a = ARCHS[arch] if isinstance(arch, str) else arch
+    if a.name == 'ikala' and len(params) > 6 and np.ndim(params[6]) == 2:
+        rows = int(np.shape(params[6])[0])
+        if rows != a.dims(tc, F)['flat'] and rows == ARCHS['ikala_nopool'].dims(tc, F)['flat']:
+            return ARCHS['ikala_nopool']
+    return a
 
 
 def check_params(arch, params, tc, F):

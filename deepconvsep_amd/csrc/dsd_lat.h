@@ -32,6 +32,7 @@ struct DcsLatGemm {
     int M, n_store, K, slice_len, n_slices, n_cb, relu;
     int nz; int64_t c_part_stride;                 // output split (0 / 1: none)
     int a_parts; int64_t a_part_stride; int relu_in;   // operand = sum of a_parts arrays (1 or 4), then rectified if relu_in
+    int a_gdiv; int64_t a_gmul;                    // stacked clips: operand row of output row r = (r / a_gdiv) * a_gmul + r % a_gdiv
 };
 inline int dcs_lat_j(int slice_len) { return (slice_len + 15) / 16; }
 // host: B[k][ldb] (k-major, n_cb*16 <= ldb columns) -> fragment order

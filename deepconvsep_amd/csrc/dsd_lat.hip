@@ -85,7 +85,10 @@ __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
     const int row = m0 + fi;
     const int slice_len = g.slice_len;
     const bool row_ok = row < g.M && s < g.n_slices;
-    const float* a_ptr = g.A + (int64_t)(row_ok ? row : 0) * g.a_row_stride + (row_ok ? s : 0) * slice_len + 4 * kq;
+    // stacked clips: output row r = (clip, tile) reads operand row (r / a_gdiv) * a_gmul + r % a_gdiv  (a_gdiv = 0: r itself)
+    const int rr = row_ok ? row : 0;
+    const int64_t arow = g.a_gdiv > 0 ? (int64_t)(rr / g.a_gdiv) * g.a_gmul + rr % g.a_gdiv : rr;
+    const float* a_ptr = g.A + arow * g.a_row_stride + (row_ok ? s : 0) * slice_len + 4 * kq;
     const f32x4* b_ptr = reinterpret_cast<const f32x4*>(g.Bp) + ((int64_t)((s < g.n_slices ? s : 0) * g.n_cb + cb) * J) * 64 + lane;
     f32x4 a[NA][J], b[J];
 #pragma unroll

@@ -74,4 +74,7 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
 int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm, float* sep_out, float* mag_out, float* phase_out,
                          int64_t ld_out, DcsBuffer* ws, int64_t n_clips = 1, int64_t audio_stride = 0,
-                         const DcsScoreNotes* notes = nullptr);
+                         const DcsScoreNotes* notes = nullptr,
+                         const int64_t* lens_h = nullptr /* host: samples per clip (clips of different lengths) */,
+                         const int64_t* clip_tab_d = nullptr /* device {samples, frames, tiles} per clip */,
+                         int64_t pcm_stride = 0);

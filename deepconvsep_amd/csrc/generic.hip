@@ -1765,23 +1765,36 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
 
 int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm, float* sep_out, float* mag_out, float* phase_out,
-                         int64_t ld_out, DcsBuffer* ws, int64_t n_clips, int64_t audio_stride, const DcsScoreNotes* notes) {
-    // The un-fused composition of the public operators: STFT -> tiles -> network -> cross-fade -> iSTFT.  Equal-length
-    // clips share the launches: one STFT / iSTFT launch over all clips and ONE pass of all their tiles through the
-    // network (the dense layers' weights -- 853 MB for Bach10 -- are then read once for the whole group).
+                         int64_t ld_out, DcsBuffer* ws, int64_t n_clips, int64_t audio_stride, const DcsScoreNotes* notes,
+                         const int64_t* lens_h, const int64_t* clip_tab_d, int64_t pcm_stride) {
+    // The un-fused composition of the public operators: STFT -> tiles -> network -> cross-fade -> iSTFT.  Clips share the
+    // launches: one STFT / iSTFT launch over all clips and ONE pass of all their tiles through the network (the dense
+    // layers' weights -- 853 MB for Bach10 -- are then read once for the whole group).  lens_h: clips of different lengths
+    // (dcs_separate_ragged): L is then the longest, every clip is framed, tiled and cross-faded with its own counts (its
+    // tiles sit behind those of the clips before it), the STFT / iSTFT kernels read them from the device table.
     dcs_ctx* ctx = g->ctx;
     const int tc = g->tc, F = g->F, st = tc - ov, S = g->d.S;
     const int64_t T = dcs_frame_count(L, plan->hop);
     const int64_t n = dcs_tile_count(T, tc, ov, tiler);
     const int64_t ld = dcs_round_up(F, 4);
-    const int64_t rows = n * st + tc;  // rows of the stitched spectrogram (>= T)
-    const int64_t n_all = n * n_clips;
+    const int64_t rows = n * st + tc;  // rows of the stitched spectrogram (>= T), of the longest clip
+    std::vector<int64_t> Tc((size_t)n_clips, T), nc((size_t)n_clips, n), off((size_t)n_clips + 1, 0);
+    for (int64_t c = 0; c < n_clips; ++c) {
+        if (lens_h) {
+            Tc[c] = dcs_frame_count(lens_h[c], plan->hop);
+            nc[c] = dcs_tile_count(Tc[c], tc, ov, tiler);
+        }
+        off[c + 1] = off[c] + nc[c];
+    }
+    const int64_t n_all = off[n_clips];
     const size_t b_mag = align256((size_t)n_clips * T * ld * 4), b_unit = 2 * b_mag, b_ph = phase_out ? b_mag : 0;
     const size_t b_tiles = align256((size_t)n_all * g->C * tc * F * 4), b_out = align256((size_t)S * n_all * tc * F * 4);
     const size_t b_sep = align256((size_t)n_clips * S * rows * ld * 4);
     const size_t b_inp = notes ? align256((size_t)g->C * T * F * 4) : 0;   // score-informed network input [C][T][F]
     if (notes && (n_clips != 1 || notes->ninst != g->C))
         DCS_FAIL(DCS_EINVAL, "score-informed path: one clip, %d score channels (got %d)", g->C, notes->ninst);
+    if (lens_h && (notes || g->C != 1 || !clip_tab_d || phase_out || sep_out || mag_out))
+        DCS_FAIL(DCS_EUNSUPPORTED, "clips of different lengths: single-channel graphs, PCM output");
     DCS_CHECK(ws->ensure(b_mag + b_unit + b_ph + b_tiles + b_out + b_sep + b_inp));
     char* p = (char*)ws->ptr;
     float* mag = (float*)p; p += b_mag;
@@ -1791,7 +1804,7 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
     float* outm = (float*)p; p += b_out;
     float* sep = (float*)p; p += b_sep;
     float* inp = (float*)p; p += b_inp;
-    DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio, L, audio_stride, n_clips, mag, phase, unit, ld, T, T));
+    DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio, L, audio_stride, n_clips, mag, phase, unit, ld, T, T, false, clip_tab_d));
     if (notes) {
         // separate_bach10.py (score-informed) :503-527: scaled magnitudes x filterSpec masks, one channel per instrument,
         // then the C-channel tiles (the masks multiply channel 0 of a tile, as in the script)
@@ -1800,7 +1813,7 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
         DCS_CHECK(dcs_launch_tile(ctx, inp, T * (int64_t)F, F, g->C, T, F, tc, ov, tiler, 1.0f, tiles, n));
     } else {
         for (int64_t c = 0; c < n_clips; ++c)
-            DCS_CHECK(dcs_launch_tile(ctx, mag + c * T * ld, 0, ld, 1, T, F, tc, ov, tiler, scale, tiles + c * n * tc * F, n));
+            DCS_CHECK(dcs_launch_tile(ctx, mag + c * T * ld, 0, ld, 1, Tc[c], F, tc, ov, tiler, scale, tiles + off[c] * tc * F, nc[c]));
     }
     // mask + cross-fade in one kernel when all tiles go through the graph in one chunk (the masked tiles then never exist)
     static const bool fuse_env = !(getenv("DCS_MASK_OLA") && atoi(getenv("DCS_MASK_OLA")) == 0);
@@ -1827,21 +1840,23 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
         DCS_HIP(hipMemcpy(g->rise_d, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
         g->rise_ov = ov;
     }
-    // outm is [S][n_all][tc][F]: clip c's tiles of source s start at (s * n_all + c * n) tiles
+    // outm is [S][n_all][tc][F]: clip c's tiles of source s start at (s * n_all + off[c]) tiles.  A clip's stitched rows
+    // past its own n_c * st + tc stay unwritten (the iSTFT only reads its own T_c frames)
     if (mask_fused) {
         DcsTimer tm(ctx, DCS_TAG_MASK);
         for (int64_t c = 0; c < n_clips; ++c)
-            hipLaunchKernelGGL(mask_ola_kernel, dim3((unsigned)rows, (unsigned)dcs_cdiv(F, kThreads)), dim3(kThreads), 0, ctx->stream, g->raw_o, g->bout, tiles, n,
-                               c * n, g->raw_ch, S, g->C, tc, ov, F, g->rise_d, sep + c * S * rows * ld, rows * ld, ld, eps_mode);
+            hipLaunchKernelGGL(mask_ola_kernel, dim3((unsigned)(nc[c] * st + tc), (unsigned)dcs_cdiv(F, kThreads)), dim3(kThreads), 0, ctx->stream, g->raw_o, g->bout, tiles, nc[c],
+                               off[c], g->raw_ch, S, g->C, tc, ov, F, g->rise_d, sep + c * S * rows * ld, rows * ld, ld, eps_mode);
         tm.done();
     } else {
         for (int64_t c = 0; c < n_clips; ++c)
-            DCS_CHECK(dcs_launch_overlap_add(ctx, outm + c * n * tc * F, n, S, tc, ov, F, g->rise_d, sep + c * S * rows * ld,
+            DCS_CHECK(dcs_launch_overlap_add(ctx, outm + off[c] * tc * F, nc[c], S, tc, ov, F, g->rise_d, sep + c * S * rows * ld,
                                              rows * ld, ld, n_all * tc * (int64_t)F));
     }
     // pad columns of sep (F..ld) are never written by the stitch; the iSTFT only reads bins < F
     if (pcm)
-        DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, rows * ld, unit, T * ld, ld, T, S, n_clips, scale, pcm, L));
+        DCS_CHECK(dcs_launch_stft_inverse_f32_clips(plan, sep, rows * ld, unit, T * ld, ld, T, S, n_clips, scale, pcm, L, clip_tab_d,
+                                                    lens_h ? pcm_stride : 0));
     for (int s = 0; s < S && sep_out; ++s)
         DCS_HIP(hipMemcpy2DAsync(sep_out + (int64_t)s * T * ld_out, ld_out * 4, sep + (int64_t)s * rows * ld, ld * 4,
                                  (size_t)F * 4, (size_t)T, hipMemcpyDeviceToDevice, ctx->stream));

@@ -36,8 +36,9 @@ int arch_dims(int arch, int C, int tc, int F, Dims* d) {
             for (int i = 0; i < 4; ++i) d->branch_fc[i] = i;
             if (C != 2) DCS_FAIL(DCS_EINVAL, "the stereo (ILD) network takes 2 input channels");
             break;
-        case DCS_ARCH_IKALA:  // separate_ikala.py:173-191
-            d->nf1 = 30; d->kw1 = 30; d->sw1 = 3; d->pool_w = 4;
+        case DCS_ARCH_IKALA:         // separate_ikala.py:173-191
+        case DCS_ARCH_IKALA_NOPOOL:  // ikala/trainCNN.py:87-118: the same graph without the MaxPool2DLayer
+            d->nf1 = 30; d->kw1 = 30; d->sw1 = 3; d->pool_w = arch == DCS_ARCH_IKALA ? 4 : 0;
             d->nf2 = 30; d->kh2 = 10; d->kw2 = 20; d->hidden = 256;
             d->n_fc = 2; d->n_branch = 2; d->S = 2;
             d->branch_fc[0] = 0; d->branch_fc[1] = 1;
@@ -348,9 +349,9 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     const bool clips = n_clips > 1;
     if (clips && (!shared_frames || clip_pitch % tile_row_stride != 0 || n > 0x7fffffff))
         DCS_FAIL(DCS_EINVAL, "dsd_encode: bad clip batch");
-    if (lat && (clips || !shared_frames || !a_vec || !m->lat_ok)) DCS_FAIL(DCS_EINVAL, "dsd_encode: latency kernels need one clip");
+    if (lat && (!shared_frames || !a_vec || !m->lat_ok)) DCS_FAIL(DCS_EINVAL, "dsd_encode: the one-batch kernels need shared frames");
     constexpr unsigned kMidAll = DCS_LAT_CONV2 | DCS_LAT_FC | DCS_LAT_FC1X | DCS_LAT_DECONV2 | DCS_LAT_MID;
-    const bool mid = (lat & kMidAll) == kMidAll && n <= kDcsLatMidMaxTiles && m->lat_mid_state;
+    const bool mid = (lat & kMidAll) == kMidAll && n <= kDcsLatMidMaxTiles && m->lat_mid_state && !clips;
     // two consecutive one-batch GEMMs: the first leaves its K reduction as 4 partial arrays (4 workgroups of 4 waves per
     // output block instead of one of 16), the second adds them while it loads its operand (DESIGN.md "one batch")
     const bool split1 = (lat & DCS_LAT_CONV1) && (lat & DCS_LAT_CONV2) && !mid;
@@ -410,10 +411,11 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     if (lat & DCS_LAT_FC) {
         DcsLatGemm q{};   // the A row of tile k is h2 consecutive C2 rows from row k * st: one slice per row
         q.A = w.C2; q.a_row_stride = tile_row_stride * (int64_t)CP; q.a_scale = 1.f; q.Bp = m->Lfcp; q.bias = m->biasfc;
-        q.C = w.Z; q.ldc = m->hid64; q.M = (int)n; q.n_store = m->hid64; q.K = d.h2 * CP; q.slice_len = CP;
+        q.C = w.Z; q.ldc = m->hid64; q.M = (int)(n * n_clips); q.n_store = m->hid64; q.K = d.h2 * CP; q.slice_len = CP;
         q.n_slices = d.h2; q.n_cb = m->hid64 / 16; q.relu = 1;
+        if (clips) { q.a_gdiv = (int)n; q.a_gmul = clip_pitch / tile_row_stride; }   // tile (c, k) starts at row c * pitch + k * st
         q.a_parts = split2 ? 4 : 1; q.a_part_stride = g2.M * CP;
-        q.nz = split3 ? 4 : 1; q.c_part_stride = n * (int64_t)m->hid64;      // split: the rectifier is the consumer's
+        q.nz = split3 ? 4 : 1; q.c_part_stride = n * n_clips * (int64_t)m->hid64;      // split: the rectifier is the consumer's
         DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_FC));
     } else
         DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g3, DCS_TAG_FC));
@@ -426,15 +428,16 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     if (lat & DCS_LAT_FC1X) {
         DcsLatGemm q{};
         q.A = w.Z; q.a_row_stride = m->hid64; q.a_scale = 1.f; q.Bp = m->Ldp; q.bias = m->biasd;
-        q.C = w.D; q.ldc = m->nd; q.M = (int)n; q.n_store = m->nd; q.K = m->hid64; q.slice_len = 32;
+        q.C = w.D; q.ldc = m->nd; q.M = (int)(n * n_clips); q.n_store = m->nd; q.K = m->hid64; q.slice_len = 32;
         q.n_slices = 4; q.n_cb = m->nd64 / 16; q.relu = 1;
-        q.a_parts = split3 ? 4 : 1; q.a_part_stride = n * (int64_t)m->hid64; q.relu_in = split3 ? 1 : 0;
+        q.a_parts = split3 ? 4 : 1; q.a_part_stride = n * n_clips * (int64_t)m->hid64; q.relu_in = split3 ? 1 : 0;
         DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_FC1X));
     } else
         DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g4, DCS_TAG_FC1X));
     // InverseLayer(., l_conv2) (separate_dsd.py:211,217,223)
     if (lat & DCS_LAT_DECONV2)   // f32 G only when a consumer reads it (the one-batch final kernel multiplies the planes)
-        return dcs_launch_lat_deconv2(m->ctx, w.D, m->Lw2p, ((lat & DCS_LAT_FINAL) && w.Gs) ? nullptr : w.G, w.Gs, n * d.n_fc);
+        return dcs_launch_lat_deconv2(m->ctx, w.D, m->Lw2p, (w.Gs && ((lat & DCS_LAT_FINAL) || clips)) ? nullptr : w.G, w.Gs,
+                                      n * n_clips * d.n_fc);
     return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n * n_clips * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
                                   m->d2_gcols, w.Gs, m->Bw2q);
 }
@@ -629,6 +632,10 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 // the automatic selection: one launch per layer.  The 8-workgroup-cluster launch of the middle (DCS_LAT_MID) is built and
 // tested but measured slower (a cluster per tile re-reads the 1.9 MB of weights per tile: 77 MB per batch through L2)
 constexpr int kLatDefault = DCS_LAT_ALL & ~DCS_LAT_MID;
+constexpr int kLatBatchDefault = 0;
+static inline int64_t rows1_of(int64_t n, int64_t n_clips, int64_t Trows, int st, int tc) {
+    return n_clips > 1 ? n_clips * Trows : (n - 1) * st + tc;
+}
 
 static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm_d, float* sep_out, float* mag_out, float* phase_out,
@@ -661,8 +668,8 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
     if (lens_h) {
         // clips of different lengths in one set of launches: strides and grids are sized by the longest clip (L on
         // entry), every kernel that depends on a clip's own length reads {samples, frames, tiles} from a device table
-        if (m->arch != DCS_ARCH_DSD || !pcm_d || pcm_stride < L || n_clips < 2)
-            DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_ragged: DSD graph with PCM output and pcm_stride >= longest clip only");
+        if (m->arch == DCS_ARCH_DSD_ILD || m->C != 1 || !pcm_d || pcm_stride < L || n_clips < 2)
+            DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_ragged: single-channel graphs with PCM output and pcm_stride >= longest clip only");
         std::vector<int64_t> tab((size_t)n_clips * 3);
         T = 0;
         n = 0;
@@ -712,6 +719,13 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
             lat = (unsigned)want & DCS_LAT_ALL;
             if ((ov + st - 1) / st + 1 > dcs_lat_final_max_covers() || eps_mode > 1) lat &= ~(unsigned)DCS_LAT_FINAL;   // more covering tiles than the LDS holds
             if (T >= (1 << 24)) lat = 0;
+        }
+        if (lat == 0 && m->lat_ok) {
+            // launches of many tiles: the encoder layers (and the transposed conv2) may still take the sliced-K kernels of
+            // dsd_lat.hip -- DCS_LAT_BATCH=<stage bits 2 | 4 | 8 | 16 | 32>, measured per shape in profiles/r03_*
+            static const int batch_mask = getenv("DCS_LAT_BATCH") ? atoi(getenv("DCS_LAT_BATCH")) : kLatBatchDefault;
+            lat = (unsigned)batch_mask & (DCS_LAT_CONV1 | DCS_LAT_CONV2 | DCS_LAT_FC | DCS_LAT_FC1X | DCS_LAT_DECONV2);
+            if ((int64_t)n * n_clips * 3 > 0x7fffffff / 8 || rows1_of(n, n_clips, Trows, st, tc) > 0x7fffffff / 64) lat = 0;
         }
         const bool split = (lat & DCS_LAT_FINAL) || (m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode));
         const size_t b_fr = (lat & DCS_LAT_ISTFT) && pcm_d ? align256(dcs_lat_istft_scratch_bytes(plan, T, S)) : 0;
@@ -771,7 +785,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         return DCS_OK;
     }
     return dcs_generic_separate(m->gen, plan, audio_d, L, ov, tiler, scale, eps_mode, tie_mode, pcm_d, sep_out, mag_out,
-                                phase_out, ld_out, &m->ws, n_clips, audio_stride, notes);
+                                phase_out, ld_out, &m->ws, n_clips, audio_stride, notes, lens_h, clip_tab_d, pcm_stride);
 }
 
 static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,

@@ -10,7 +10,7 @@ from ctypes import POINTER, byref, c_double, c_int64, c_void_p
 import numpy as np
 
 from . import _lib
-from .arch import ARCHS, EPS_A, EPS_B, TIE_ALL, TIE_FIRST, TILER_LIBRARY, TILER_SCRIPT, check_params
+from .arch import ARCHS, EPS_A, EPS_B, TIE_ALL, TIE_FIRST, TILER_LIBRARY, TILER_SCRIPT, check_params, resolve as resolve_arch
 
 
 def _torch():
@@ -216,9 +216,9 @@ class Network(object):
 
     def __init__(self, ctx, arch, params, time_context=30, feat_size=513):
         self.ctx = ctx
-        self.arch = ARCHS[arch] if isinstance(arch, str) else arch
         self.tc, self.F = int(time_context), int(feat_size)
         params = [np.asarray(p) for p in params]
+        self.arch = resolve_arch(arch, params, self.tc, self.F)     # 'ikala': pooled or trainer (no-pool) graph by fc.W
         check_params(self.arch, params, self.tc, self.F)
         # weight tensors hosted by torch (float32, as the pickles store them)
         self._params = [ctx.to_device(p, np.float32) for p in params]
@@ -342,8 +342,8 @@ class Network(object):
                         tie_mode=TIE_ALL, out=None):
         """Clips of different lengths sharing one set of launches: ``audio_t [B, Lmax]`` float32 device tensor (row c
         holds ``lengths[c]`` samples), returns ``[B, S, Lmax]`` float32 PCM of which ``[c, :, :lengths[c]]`` is valid.
-        Every clip gets the frames, tiles and cross-fade :meth:`separate` would give it alone (DSD / hiphop graph,
-        frameSize 1024 / 2048 / 4096)."""
+        Every clip gets the frames, tiles and cross-fade :meth:`separate` would give it alone (every single-channel
+        graph; frameSize 1024 / 2048 / 4096)."""
         torch = _torch()
         if audio_t.dim() != 2 or audio_t.stride(1) != 1:
             raise ValueError("separate_ragged expects a [clips, samples] tensor with contiguous rows")

@@ -195,9 +195,9 @@ class Separator(object):
         sorted by length, they are cut into groups of at most ``max_group`` clips whose longest is at most
         ``max_ratio`` times the shortest (a group costs what its longest clip costs, times its size); a group goes
         through ``dcs_separate_ragged`` (``dcs_separate_batch`` when its lengths are equal).  Every clip gets exactly
-        the frames, the tiles and the cross-fade :meth:`separate` gives it alone.  The ikala / bach10 graphs and frame
-        sizes the wave STFT kernels do not cover share launches between clips of equal length only
-        (``dcs_separate_batch``); groups of one go through :meth:`separate`.  Clips that cannot be separated
+        the frames, the tiles and the cross-fade :meth:`separate` gives it alone.  Frame sizes the wave STFT kernels do
+        not cover share launches between clips of equal length only (``dcs_separate_batch``); groups of one go through
+        :meth:`separate`.  Clips that cannot be separated
         (empty, or too short for one tile) never join a shared launch; ``on_error='return'`` puts the exception the
         single-clip path raises for them into their slot of the result instead of raising it."""
         audios = [np.asarray(a) for a in audios]
@@ -210,7 +210,10 @@ class Separator(object):
                 else:
                     raise ValueError("separate_many takes mono clips ([L] arrays), got shape %r" % (a.shape,))
         out = [None] * len(audios)
-        ragged_ok = (self.arch_name in ("dsd", "hiphop") and self.frameSize in (1024, 2048, 4096)
+        # clips of different lengths share launches on every single-channel graph (dcs_separate_ragged: DSD fused path;
+        # ikala / bach10: every clip framed, tiled and cross-faded with its own counts, one pass of all tiles through the
+        # network) when the wave STFT kernels cover the frame size
+        ragged_ok = (self.arch.C == 1 and self.arch_name != "dsd_ild" and self.frameSize in (1024, 2048, 4096)
                      and self.frameSize % self.hopSize == 0 and self.hopSize % 2 == 0)
         # ikala / bach10: clips of EQUAL length share the launches (their tiles go through the network as one batch)
         equal_ok = self.arch.C == 1 and self.arch_name != "dsd_ild"

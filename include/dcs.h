@@ -48,7 +48,9 @@ typedef enum {
 
 /* build_ca variants (examples/<x>/separate_<x>.py) */
 enum { DCS_ARCH_DSD = 0, DCS_ARCH_IKALA = 1, DCS_ARCH_BACH10 = 2, DCS_ARCH_BACH10_SI = 3,
-       DCS_ARCH_DSD_ILD = 4 /* stereo DSD100 graph of examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115 */ };
+       DCS_ARCH_DSD_ILD = 4 /* stereo DSD100 graph of examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115 */,
+       DCS_ARCH_IKALA_NOPOOL = 5 /* the iKala TRAINER's graph (examples/ikala/trainCNN.py:87-118): as DCS_ARCH_IKALA without
+                                    the (1, 4) max-pool, fc.W has 30 * 21 * 143 = 90 090 rows at 513 bins */ };
 /* soft-mask epsilon convention: A = separate_dsd.py:258-266, B = separate_bach10.py:251-259 */
 enum { DCS_EPS_A = 0, DCS_EPS_B = 1 };
 /* max-pool gradient tie routing: ALL = Theano 0.9 CPU MaxPoolGrad, FIRST = cuDNN */
@@ -197,6 +199,8 @@ int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64
  * written).  Strides and grids are sized by the longest clip; the STFT, the cross-fade fold and the iSTFT read
  * every clip's own sample / frame / tile counts from a small device table, so each clip gets exactly the frames,
  * the tiles and the cross-fade dcs_separate gives it alone (shorter clips cost the launch the work of the longest).
+ * Every single-channel graph: DSD / hiphop through the fused path; ikala / bach10 with one STFT / iSTFT launch over all
+ * clips and one pass of all their tiles through the network (a clip's tiles sit behind those of the clips before it).
  * Needs the wave STFT kernels (frameSize 1024 / 2048 / 4096 with hop | frameSize, DCS_EUNSUPPORTED otherwise).
  * n_tiles_out / n_frames_out: [n_clips] or NULL.  Equal lengths with pcm_stride == length take the
  * dcs_separate_batch path. */

@@ -102,6 +102,8 @@ NET_CASES = [
     ("net_bach10_f129_tiny", "bach10", 129, 1, 39, "tiny"),
     ("net_bach10si_f129_sparse", "bach10_si", 129, 1, 40, "sparse"),
     ("net_dsdild_f33_glorot", "dsd_ild", 33, 1, 41, "glorot"),
+    ("net_ikalanp_f150_glorot", "ikala_nopool", 150, 1, 42, "glorot"),     # the iKala trainer's graph (no max-pool)
+    ("net_ikalanp_f150_sparse", "ikala_nopool", 150, 1, 43, "sparse"),
 ]
 
 
@@ -109,7 +111,8 @@ NET_CASES = [
 # on the GPU against net_ref): beyond the committed fixtures.  A draw = (graph, small F, batch, weights, input), all from one
 # integer seed: weight gain 0.5 .. 2.2, dense biases of either sign, output biases from strongly negative (most outputs cut
 # to exact zeros) to positive, inputs from dense noise to few-level / silent rows (max-pool ties in the iKala graph).
-RANDOM_GRAPHS = (("dsd", 65), ("dsd", 129), ("ikala", 270), ("ikala", 303), ("bach10", 129), ("bach10_si", 129))
+RANDOM_GRAPHS = (("dsd", 65), ("dsd", 129), ("ikala", 270), ("ikala", 303), ("bach10", 129), ("bach10_si", 129),
+                 ("ikala_nopool", 150))
 
 
 def random_draw(seed):

@@ -86,6 +86,7 @@ SPECS = {
     'dsd': NetSpec('dsd', 1, (50, 'F', 1), None, (50, lambda tc: int(tc / 2), 1), 128,
                    [0, 1, 2, 1], 4, 'A'),
     'ikala': NetSpec('ikala', 1, (30, 30, 3), 4, (30, 10, 20), 256, [0, 1], 2, 'A'),
+    'ikala_nopool': NetSpec('ikala_nopool', 1, (30, 30, 3), None, (30, 10, 20), 256, [0, 1], 2, 'A'),   # ikala/trainCNN.py:87-118
     'bach10': NetSpec('bach10', 1, (30, 30, 4), None, (30, lambda tc: int(2 * tc / 3), 1), 256,
                       [0, 1, 2, 3], 4, 'B'),
     'bach10_si': NetSpec('bach10_si', 4, (30, 30, 4), None, (30, lambda tc: int(2 * tc / 3), 1),

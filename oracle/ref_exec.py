@@ -127,6 +127,7 @@ _NET_FILES = {
     "dsd": "examples/dsd100/separate_dsd.py",
     "hiphop": "examples/hiphopss/separate_hhds.py",
     "ikala": "examples/ikala/separate_ikala.py",
+    "ikala_nopool": "examples/ikala/trainCNN.py",                      # the trainer's graph: no MaxPool2DLayer
     "bach10": "examples/bach10/separate_bach10.py",
     "bach10_si": "examples/bach10_scoreinformed/separate_bach10.py",
     "dsd_ild": "examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py",     # a trainer: build_ca only, returns a dict of layers

@@ -160,7 +160,11 @@ def networks():
                  n_params=len(params), zero_fraction=float((p == 0).mean()))
         if arch == "ikala":
             d["p_tie_first"] = ref_exec.network_output(arch, params, x, tie_mode="first")
-        if arch != "dsd_ild":
+        if arch == "ikala_nopool":
+            # the masks of the separate script (separate_ikala.py:211-216, eps 1e-18): the drop-in surface is that script fed
+            # a .pkl the trainer wrote; the trainer's own block uses its training epsilon 1e-8 (ikala/trainCNN.py:155)
+            d["masked"] = np.stack(ref_exec.mask_sources("ikala", p, x))
+        elif arch != "dsd_ild":
             d["masked"] = np.stack(ref_exec.mask_sources(arch, p, x))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         print(name, p.shape, "zeros %.3f" % d["zero_fraction"], "max %.3f" % p.max())

@@ -56,6 +56,45 @@ def test_hip_network_matches_the_reference_graph_fixtures(golden, name):
         assert rec["bins_outside_1e4"] == 0
 
 
+def test_ikala_trainer_pkl_selects_the_no_pool_graph(tmp_path):
+    """a .pkl written by examples/ikala/trainCNN.py (no MaxPool2DLayer, fc.W with 30*21*143 = 90 090 rows at 513
+    bins) loads into the no-pool graph, chosen from the shapes; whole path against the oracle through Separator('ikala', ...)
+    and through the separate_ikala.py command line, and a pooled .pkl still takes the pooled graph."""
+    import subprocess
+    import scipy.io.wavfile
+    F, N, ov = 513, 1024, 20
+    # gain 1.8: with a plain Glorot draw of this 90 090-wide graph both sources come out around 1e-4 in places, and a mask
+    # p_i / sum(p) there turns a 1e-7 float32 difference of p into 5e-4 of the mixture (tests/maskcheck.py's bound)
+    params = synth_params("ikala_nopool", 30, F, seed=6, gain=1.8)
+    assert params[6].shape == (90090, 256)
+    sep = dcs.Separator("ikala", params, 0.3, 30, ov, 32, F, N, 512, np.hanning)
+    assert sep.net.arch.name == "ikala_nopool"
+    audio = synth_audio(66150, seed=9)
+    got = sep.separate(audio)
+    want = pipeline.separate("ikala_nopool", params, audio, 0.3, 30, ov, 32, N, 512, np.hanning)
+    assert got.shape == want.shape == (2, audio.size)
+    assert np.max(np.abs(got - want)) < 1e-4
+    pooled = dcs.Separator("ikala", synth_params("ikala", 30, F, seed=6), 0.3, 30, ov, 32, F, N, 512, np.hanning)
+    assert pooled.net.arch.name == "ikala"
+    with pytest.raises(ValueError):                         # neither graph: set_all_param_values' failure
+        bad = [np.array(p) for p in params]
+        bad[6] = bad[6][:-1]
+        dcs.Separator("ikala", bad, 0.3, 30, ov, 32, F, N, 512, np.hanning)
+    # the command line
+    model = str(tmp_path / "trainer.pkl")
+    dcs.save_model(model, params)
+    st = synth_audio(44100, seed=3, channels=2)
+    wav = str(tmp_path / "mix.wav")
+    scipy.io.wavfile.write(wav, 44100, (st * 32767).astype('int16'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "ikala", "separate_ikala.py"), "-i", wav, "-o",
+                        str(tmp_path), "-m", model], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    sr, voice = scipy.io.wavfile.read(str(tmp_path / "mix-voice.wav"))
+    mono = (st * 32767).astype('int16').astype('float') / 32767
+    want2 = pipeline.separate("ikala_nopool", params, mono[:, 0] + mono[:, 1], 0.3, 30, ov, 32, N, 512, np.hanning)
+    assert sr == 44100 and np.max(np.abs(voice.astype(int) - (want2[0] * 32767).astype('int16').astype(int))) <= 2
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE configs
 def test_ikala_frame2048_ten_seconds_stereo_matches_oracle():
     """BASELINE configs[0] as worded: iKala 2-source, frameSize=2048 hop=512, time_context=30, overlap 20

@@ -560,6 +560,37 @@ def test_separate_ragged_equals_clip_by_clip(N, hop, tiler, lengths):
         assert many[b].shape == (4, a.size) and np.max(np.abs(many[b] - sep.separate(a))) < 5e-6
 
 
+@pytest.mark.parametrize("arch,N,ov,lengths", [("ikala", 1024, 20, [40000, 31000, 52000, 40000, 26011]),
+                                                ("bach10", 4096, 25, [60000, 45001, 60000, 38000])])
+def test_separate_ragged_of_the_generic_graphs_equals_clip_by_clip(arch, N, ov, lengths):
+    """dcs_separate_ragged on the ikala / bach10 graphs: one STFT / iSTFT launch over all clips and ONE pass of all their
+    tiles through the network, every clip framed, tiled and cross-faded with its own counts (its tiles sit behind those of
+    the clips before it): equal to the single-clip call to fp32 rounding, to the oracle within 1e-4, nothing written past a
+    clip's own length; separate_many takes this path for mixed lengths."""
+    F = N // 2 + 1
+    window = dcs.blackmanharris if arch == "bach10" else np.hanning
+    params = synth_params(arch, 30, F, seed=4)
+    sep = dcs.Separator(arch, params, 0.3, 30, ov, 32, F, N, 512, window)
+    clips = [synth_audio(n, seed=80 + i) for i, n in enumerate(lengths)]
+    Lmax = max(lengths)
+    stack = np.zeros((len(clips), Lmax + 5), dtype=np.float32)
+    for b, a in enumerate(clips):
+        stack[b, :a.size] = a
+    dev = sep.ctx.to_device(stack, np.float32)
+    got = sep.net.separate_ragged(sep.plan, dev[:, :Lmax], lengths, ov, sep.tiler, 0.3).cpu().numpy()
+    assert list(sep.net.last_frames) == [stft_np.frame_count(n, 512) for n in lengths]
+    S = ARCHS[arch].S
+    for b, a in enumerate(clips):
+        alone = sep.separate(a)
+        assert got[b].shape[0] == S and np.max(np.abs(got[b, :, :a.size] - alone)) < 5e-6
+        assert not got[b, :, a.size:].any()
+    want = pipeline.separate(arch, params, clips[1], 0.3, 30, ov, 32, N, 512, window)
+    assert np.max(np.abs(got[1, :, :clips[1].size] - want)) < 1e-4
+    many = sep.separate_many(clips)
+    for b, a in enumerate(clips):
+        assert many[b].shape == (S, a.size) and np.max(np.abs(many[b] - got[b, :, :a.size])) < 5e-6
+
+
 def test_separate_ragged_rejects_what_it_cannot_do():
     import torch
     params = synth_params("dsd", 30, 257, seed=2)

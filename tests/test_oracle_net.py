@@ -38,6 +38,12 @@ def test_param_counts_match_survey():
     assert ARCHS["bach10_si"].param_shapes(30, 2049)[-1] == (16,)
     assert ARCHS["dsd"].param_shapes(30, 513)[6] == (800, 128)
     assert ARCHS["ikala"].param_shapes(30, 513)[6] == (13230, 256)
+    assert ARCHS["ikala_nopool"].param_shapes(30, 513)[6] == (90090, 256)      # the trainer's graph
+    from deepconvsep_amd.arch import resolve
+    shapes = ARCHS["ikala_nopool"].param_shapes(30, 150)
+    fake = [np.zeros(s_, dtype=np.float32) for s_ in shapes]
+    assert resolve("ikala", fake, 30, 150).name == "ikala_nopool"           # picked from fc.W's rows
+    assert resolve("ikala", [np.zeros(s_, dtype=np.float32) for s_ in ARCHS["ikala"].param_shapes(30, 270)], 30, 270).name == "ikala"
     assert ARCHS["bach10"].param_shapes(30, 2049)[6] == (166650, 256)
     # SURVEY 8a-4': 11.78 MFLOP per DSD tile (aliased branch computed once)
     assert abs(ARCHS["dsd"].flops_per_tile(30, 513) / 1e6 - 11.78) < 0.02
@@ -176,7 +182,7 @@ def test_net_ref_matches_the_reference_graph_fixtures(golden, name):
 
 @pytest.mark.skipif(not ref_exec.available(), reason="needs /root/reference (build container only)")
 @pytest.mark.parametrize("arch,C,F", [("dsd", 1, 513), ("dsd", 1, 1025), ("hiphop", 1, 513), ("ikala", 1, 513),
-                                      ("ikala", 1, 1025), ("bach10", 1, 2049), ("bach10_si", 4, 2049),
+                                      ("ikala", 1, 1025), ("ikala_nopool", 1, 513), ("bach10", 1, 2049), ("bach10_si", 4, 2049),
                                       ("dsd_ild", 2, 513)])
 def test_parameter_order_comes_from_the_reference_graph(arch, C, F):
     """``get_all_params`` of the reference's own build_ca at the real sizes == the shape list the HIP model checks
@@ -235,7 +241,7 @@ def test_random_draws_net_ref_equals_the_executed_reference_graph(seed):
     if arch == "ikala":
         p1 = net_ref.forward(arch, params, x.astype(np.float64), tie_mode='first', inverse='explicit').numpy()
         assert np.max(np.abs(p1 - ref_exec.network_output(arch, params, x, tie_mode="first"))) < 1e-11
-    m_ref = ref_exec.mask_sources(arch, p_ref, x)
+    m_ref = ref_exec.mask_sources("ikala" if arch == "ikala_nopool" else arch, p_ref, x)   # the separate script's masks
     m = net_ref.predict(arch, params, x.astype(np.float64), inverse='explicit')
     assert len(m) == len(m_ref)
     for a, b in zip(m, m_ref):
