@@ -31,7 +31,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
 constexpr int kNgg = 7;                 // channel groups of 8 that carry data (50 filters -> 56); group 7 of the K = 64 axis is zero
+#ifndef DCS_FINAL_STAGE_MEMORY_ORDER
 constexpr int kRowLds = 25;             // LDS row stride in 16-byte units: 100 words, fi * 100 mod 64 = 16 distinct bank quads
+constexpr int kPlaneLds = 8;
+#else
+// Round-3 experiment (scripts/build_exp.sh ... -DDCS_FINAL_STAGE_MEMORY_ORDER): staging lanes in the order of the pieces in
+// memory (plane, then row; plane p of a row at 9 p, rows 27 apart so that consecutive lanes write consecutive piece offsets
+// modulo 8) -- what the one-batch kernel of dsd_lat.hip does.  Measured on this kernel: SLOWER, 109.3 vs 103.6 us per 1024
+// tiles, 303 vs 300 us at 4096 (the 27-piece row stride is 2-way conflicted for the MFMA fragment reads).
+constexpr int kRowLds = 27;
+constexpr int kPlaneLds = 9;
+#endif
 
 __device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
 
@@ -208,21 +218,29 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
         const int idx = tid + u * kThreads;
+#ifndef DCS_FINAL_STAGE_MEMORY_ORDER
         const int i = idx & 15, sp = idx >> 4;               // sp = s * 21 + plane * 7 + g
         const int s = sp / (3 * kNgg), pg = sp - s * (3 * kNgg);
         const int plane = pg / kNgg, g = pg - plane * kNgg;
+#else
+        // plane fastest, then the row: the order of the pieces in memory ([item][g][t][plane], the rows of one tile are
+        // consecutive t) -- 48 consecutive lanes read runs of up to 240 contiguous bytes instead of 16 bytes out of every 48
+        const int t3 = idx / 3, plane = idx - 3 * t3;
+        const int i = t3 & 15, gs = t3 >> 4;
+        const int s = gs / kNgg, g = gs - s * kNgg;
+#endif
         const bool in = (u + 1) * kThreads <= slots || idx < slots;   // compile-time true for all but the last slot
         in_slot[u] = in;
         const int lim = in ? meta_mlim[i] : -1;
         const int j0 = lim >= 0 ? meta_j0[i] : 0;
         const int dk = lim >= 0 ? meta_k0[i] - kbase : 0;
         mlim[u] = lim >= 0 ? lim : 0;
-        dst[u] = (s * 16 + i) * kRowLds + plane * 8 + g;
+        dst[u] = (s * 16 + i) * kRowLds + plane * kPlaneLds + g;
         goff[u] = (((dk * NBR + s) * kNgg + g) * tc + j0) * 3 + plane;
     }
     for (int idx = tid; idx < 2 * NBR * 16 * 3; idx += kThreads) {   // K channels 56..63: zero in both buffers
         const int buf = idx / (NBR * 16 * 3), r = idx - buf * (NBR * 16 * 3);
-        As[buf * kABuf + (r / 3) * kRowLds + (r % 3) * 8 + 7] = u32x4{0u, 0u, 0u, 0u};
+        As[buf * kABuf + (r / 3) * kRowLds + (r % 3) * kPlaneLds + 7] = u32x4{0u, 0u, 0u, 0u};
     }
     u32x4 pre[NSL];
 #define DCS_LOAD_A(m_, dst_)                                                                    \
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) af[p][kb] = Ab[s * 16 * kRowLds + p * 8 + kb * 4];
+                for (int kb = 0; kb < 2; ++kb) af[p][kb] = Ab[s * 16 * kRowLds + p * kPlaneLds + kb * 4];
             // smallest terms first; the two column blocks alternate so that no MFMA waits for the one before it
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {

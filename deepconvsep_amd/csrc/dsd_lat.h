@@ -14,7 +14,8 @@ enum {
     DCS_LAT_STFT = 1, DCS_LAT_CONV1 = 2, DCS_LAT_CONV2 = 4, DCS_LAT_FC = 8, DCS_LAT_FC1X = 16, DCS_LAT_DECONV2 = 32,
     DCS_LAT_FINAL = 64, DCS_LAT_ISTFT = 128,
     DCS_LAT_MID = 256,    // with CONV2 | FC | FC1X | DECONV2 all set: those four as ONE launch (lat_mid_kernel)
-    DCS_LAT_ALL = 511
+    DCS_LAT_FUSE1 = 512,  // with STFT | CONV1 set: those two as ONE launch (lat_stft_conv1_kernel)
+    DCS_LAT_ALL = 1023
 };
 constexpr int kDcsLatMidMaxTiles = 256;
 
@@ -73,5 +74,9 @@ int dcs_launch_lat_stft(dcs_stft* p, const float* audio, int64_t L, float* mag, 
 // the inverse is two launches (every frame transformed once, then the overlap-add); frames: scratch of
 // dcs_lat_istft_scratch_bytes() bytes, [source][frame][frameSize] float32
 size_t dcs_lat_istft_scratch_bytes(const dcs_stft* p, int64_t T, int n_src);
+// STFT and conv1 (+ both biases) in one launch, four frames per workgroup; B1 [K1][64] as pack_dsd lays it out
+int dcs_launch_lat_stft_conv1(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase /* nullable */, float2* unit,
+                              int64_t ld, int64_t rows_out, int64_t T, const float* B1, const float* bias1, float* H1,
+                              int64_t h1_rows /* rows of H1 to write */, int CI, float scale);
 int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, const float2* unit, int64_t ld, int64_t T,
                          int n_src, float pre_div, float* audio, int64_t n_out, float* frames);

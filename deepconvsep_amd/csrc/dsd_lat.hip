@@ -249,8 +249,13 @@ __global__ __launch_bounds__(256) void lat_deconv2_kernel(const float* __restric
 // apart.  With the staging lanes ordered (plane, row) -- the order of the pieces in memory -- consecutive lanes then
 // write to piece offsets that are consecutive modulo 8: the eight lanes a ds_write_b128 serves per cycle hit eight
 // different bank quads.
+#ifdef DCS_LAT_FINAL_ROWS_FIRST
+constexpr int kRowLds = 25;
+constexpr int kPlaneLds = 8;
+#else
 constexpr int kRowLds = 27;
 constexpr int kPlaneLds = 9;
+#endif
 constexpr int kNgg = 7;
 constexpr int kLatMaxM = 8;      // covering tiles per frame the LDS holds at once (6 for overlap 25 / stride 5)
 constexpr int kFinNbr = 3;
@@ -379,9 +384,15 @@ __global__ __launch_bounds__(512) void lat_final_kernel(const DsdFinalArgs a) {
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
         const int idx = tid + u * 512;
+#ifdef DCS_LAT_FINAL_ROWS_FIRST
+        const int i = idx & 15, sp = idx >> 4;
+        const int s = sp / (3 * kNgg), pg = sp - s * (3 * kNgg);
+        const int plane = pg / kNgg, g = pg - plane * kNgg;
+#else
         const int t3 = idx / 3, plane = idx - 3 * t3;
         const int i = t3 & 15, gs = t3 >> 4;
         const int s = gs / kNgg, g = gs - s * kNgg;
+#endif
         const bool in = idx < slots;
         in_slot[u] = in;
         const int lim = in ? meta_mlim[i] : -1;
@@ -1027,6 +1038,141 @@ __global__ __launch_bounds__(256) void lat_stft_kernel(const float* __restrict__
     LAT_STAMP_END(6, 5);
 }
 
+// STFT + conv1 in one launch (one launch fewer on the one-batch chain: ~1.5 us of dispatch + ~1 us of cold start + a round
+// trip of the magnitudes through HBM).  conv1's weights are 263 KB: a workgroup per frame would stream them 188 times through
+// the CUs' L1s (measured rate with every CU streaming: ~34 B/clk/CU, 3 us per workgroup), so a workgroup takes FOUR frames
+// (four thread groups of 256, one FFT each, as lat_stft_kernel) and every thread holds 1/1024 of the weights -- 16 loads of
+// 16 bytes, requested first and landing while the FFTs run.  conv1 itself is 4 x 51 k multiply-adds per workgroup on the
+// vector ALU: thread (wave w, f_sub = lane >> 4, 4 columns) multiplies rows f = 64 w + 4 j + f_sub of B1[f][64] with the
+// scaled magnitudes xs[f][4 frames] from LDS; the 64 partial sums per (frame, column) are added by two lane shuffles and
+// one LDS pass.   H1[t][c] = sum_f (scale * mag[t][f]) * W1[c, 0, 0, F-1-f] + b1[c] + b1b[c]   (separate_dsd.py:198-199)
+template <int LOG2M>
+__global__ __launch_bounds__(1024) void lat_stft_conv1_kernel(const float* __restrict__ audio, int64_t L,
+                                                              const float* __restrict__ win, const float2* __restrict__ tw,
+                                                              float* __restrict__ mag, float* __restrict__ phase,
+                                                              float2* __restrict__ unit, int64_t ld, int hop, int64_t T,
+                                                              int64_t rows_out, float inv_sqrt_n, int vec,
+                                                              const float* __restrict__ B1 /* [K1][64] */,
+                                                              const float* __restrict__ bias1, float* __restrict__ H1,
+                                                              int64_t h1_rows, int CI, float scale) {
+    constexpr int M = 1 << LOG2M;
+    constexpr int RPW = M / 16;                // rows of B1 per wave (K1 = M + 4: the last 4 rows are wave 0's extra load)
+    constexpr int NL = RPW / 4;                // 16-byte loads per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* twl = reinterpret_cast<float2*>(smem);                      // [M + 2]
+    const int tid = threadIdx.x;
+    const int q = tid >> 8, gt = tid & 255;
+    float2* buf0 = twl + (M + 2) + q * (2 * M);
+    float2* buf1 = buf0 + M;
+    f32x4* xs = reinterpret_cast<f32x4*>(twl + (M + 2) + 4 * (2 * M));   // [M + 4] rows x 4 frames
+    float* red = reinterpret_cast<float*>(xs + (M + 4));                // [16 waves][4 frames][64 columns]
+    const int wave = tid >> 6, lane = tid & 63;
+    const int f_sub = lane >> 4, c4 = (lane & 15) * 4;
+
+    // conv1 weights first: they do not depend on anything
+    f32x4 breg[NL], btail = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NL; ++j) breg[j] = *reinterpret_cast<const f32x4*>(B1 + (int64_t)(wave * RPW + 4 * j + f_sub) * 64 + c4);
+    if (wave == 0) btail = *reinterpret_cast<const f32x4*>(B1 + (int64_t)(M + f_sub) * 64 + c4);
+    const float b1 = tid < 256 ? bias1[tid & 63] : 0.f;
+
+    const int64_t t = (int64_t)blockIdx.x * 4 + q;
+    const bool in_grid = t < rows_out, live = in_grid && t < T;
+    float* mrow = mag + (in_grid ? t : 0) * ld;
+    float* prow = phase ? phase + (in_grid ? t : 0) * ld : nullptr;
+    float2* urow = unit + (in_grid ? t : 0) * ld;
+    for (int k = tid; k <= M; k += 1024) twl[k] = tw[k];
+    {
+        const int64_t base = t * (int64_t)hop - M;
+        const float2* w2 = reinterpret_cast<const float2*>(win);
+        for (int m = gt; m < M; m += 256) {
+            const int64_t p = base + 2 * m;
+            float x0 = 0.f, x1 = 0.f;
+            if (live) {
+                if (vec && p >= 0 && p + 1 < L) {
+                    const float2 x = *reinterpret_cast<const float2*>(audio + p);
+                    x0 = x.x;
+                    x1 = x.y;
+                } else {
+                    if (p >= 0 && p < L) x0 = audio[p];
+                    if (p + 1 >= 0 && p + 1 < L) x1 = audio[p + 1];
+                }
+            }
+            const float2 w = w2[m];
+            buf0[m] = make_float2(x0 * w.x, x1 * w.y);
+        }
+    }
+    __syncthreads();
+    const float2* Z = lat_fft<LOG2M, -1>(buf0, buf1, twl, gt);
+    float* xsf = reinterpret_cast<float*>(xs);
+    for (int k = gt; k <= M; k += 256) {
+        const float2 zk = Z[k & (M - 1)];
+        const float2 zm = Z[(M - k) & (M - 1)];
+        const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+        const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+        const float2 w = twl[k];
+        const float xr = er + (w.x * orr - w.y * oi);
+        const float xi = ei + (w.x * oi + w.y * orr);
+        const float ax = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+        const float rx = __builtin_amdgcn_rcpf(ax);
+        const float mg = live ? ax * inv_sqrt_n : 0.f;          // rows past the last frame: zeros (zero-padding tiler)
+        xsf[k * 4 + q] = scale * mg;
+        if (in_grid) {
+            mrow[k] = mg;
+            if (prow) prow[k] = live ? atan2f(xi, xr) : 0.f;
+            urow[k] = (live && ax > 0.f) ? make_float2(xr * rx, xi * rx) : make_float2(1.f, 0.f);
+        }
+    }
+    for (int k = M + 1 + gt; k < M + 4; k += 256) {             // row padding (ld = M + 4 for these frame sizes)
+        xsf[k * 4 + q] = 0.f;
+        if (in_grid && k < ld) {
+            mrow[k] = 0.f;
+            if (prow) prow[k] = 0.f;
+            urow[k] = make_float2(1.f, 0.f);
+        }
+    }
+    __syncthreads();
+    // conv1 partial sums: 4 frames x 4 columns per thread
+    f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const f32x4 xv = xs[wave * RPW + 4 * j + f_sub];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] += xv[g] * breg[j];
+    }
+    if (wave == 0) {
+        const f32x4 xv = xs[M + f_sub];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] += xv[g] * btail;
+    }
+    // the 4 row phases of a wave sit 16 lanes apart
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[g][e];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            acc[g][e] = v;
+        }
+    if (f_sub == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(red + (wave * 4 + g) * 64 + c4) = acc[g];
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int g = tid >> 6, col = tid & 63;
+        float part[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) part[w] = red[(w * 4 + g) * 64 + col];
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += part[w];
+        const int64_t tt = (int64_t)blockIdx.x * 4 + g;
+        if (tt < h1_rows && col < CI) H1[tt * CI + col] = sum + b1;
+    }
+}
+
 // inverse, two kernels.  (The first version did both in one: a workgroup per (source, hop block) transformed the N/hop
 // frames that overlap its block with N/hop thread groups -- N/hop times the FFT work, and at ~500 VALU instructions per
 // wave and frame that is 10 us of the whole chip's vector time for one batch: 18 us measured.  Every frame is now
@@ -1305,6 +1451,36 @@ bool dcs_lat_stft_supported(const dcs_stft* p) {
     if (!p || (p->frame != 1024 && p->frame != 2048) || p->hop <= 0) return false;
     const int R = p->frame / p->hop;
     return R * p->hop == p->frame && (R == 2 || R == 4);
+}
+
+int dcs_launch_lat_stft_conv1(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
+                              int64_t rows_out, int64_t T, const float* B1, const float* bias1, float* H1, int64_t h1_rows, int CI,
+                              float scale) {
+    if (rows_out <= 0) return DCS_OK;
+    const int M = p->frame / 2;
+    if (!dcs_lat_stft_supported(p) || ld != M + 4) DCS_FAIL(DCS_EINVAL, "lat_stft_conv1: frameSize %d, row pitch %lld", p->frame, (long long)ld);
+    const int vec = (((uintptr_t)audio & 7) == 0 && (p->hop & 1) == 0) ? 1 : 0;
+    const float sq = (float)(1.0 / sqrt((double)p->frame));
+    const size_t lds = ((size_t)(M + 2) + 4 * (size_t)(2 * M)) * sizeof(float2) + (size_t)(M + 4) * 16 + 16 * 4 * 64 * 4;
+    auto k10 = lat_stft_conv1_kernel<10>;
+    auto k9 = lat_stft_conv1_kernel<9>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k10), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)dcs_cdiv(rows_out, 4));
+    DcsTimer tm(p->ctx, DCS_TAG_STFT);
+    if (p->frame == 2048)
+        hipLaunchKernelGGL(k10, grid, dim3(1024), lds, p->ctx->stream, audio, L, p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T,
+                           rows_out, sq, vec, B1, bias1, H1, h1_rows < rows_out ? h1_rows : rows_out, CI, scale);
+    else
+        hipLaunchKernelGGL(k9, grid, dim3(1024), lds, p->ctx->stream, audio, L, p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T,
+                           rows_out, sq, vec, B1, bias1, H1, h1_rows < rows_out ? h1_rows : rows_out, CI, scale);
+    tm.done();
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
 }
 
 int dcs_launch_lat_stft(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,

@@ -354,7 +354,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     const bool mid = (lat & kMidAll) == kMidAll && n <= kDcsLatMidMaxTiles && m->lat_mid_state && !clips;
     // two consecutive one-batch GEMMs: the first leaves its K reduction as 4 partial arrays (4 workgroups of 4 waves per
     // output block instead of one of 16), the second adds them while it loads its operand (DESIGN.md "one batch")
-    const bool split1 = (lat & DCS_LAT_CONV1) && (lat & DCS_LAT_CONV2) && !mid;
+    const bool split1 = (lat & DCS_LAT_CONV1) && (lat & DCS_LAT_CONV2) && !mid && (lat & (DCS_LAT_STFT | DCS_LAT_FUSE1)) != (DCS_LAT_STFT | DCS_LAT_FUSE1);
     const bool split2 = (lat & DCS_LAT_CONV2) && (lat & DCS_LAT_FC) && !mid;
     const bool split3 = (lat & DCS_LAT_FC) && (lat & DCS_LAT_FC1X) && !mid;
     // conv1 + both biases  (separate_dsd.py:198-199)
@@ -365,7 +365,10 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g1.C = w.H1; g1.ldc = CI; g1.c_gdiv = 1 << 30; g1.c_gmul = 0;
     g1.M = n_rows1; g1.n_cols = 64; g1.n_store = CI; g1.K = a_vec ? m->K1 : m->F; g1.relu = 0; g1.a_vec = a_vec;
     (void)BIG;
-    if (lat & DCS_LAT_CONV1) {
+    constexpr unsigned kFuse1 = DCS_LAT_STFT | DCS_LAT_CONV1 | DCS_LAT_FUSE1;
+    if ((lat & kFuse1) == kFuse1) {
+        // conv1 was computed by the STFT launch (lat_stft_conv1_kernel)
+    } else if (lat & DCS_LAT_CONV1) {
         DcsLatGemm q{};
         q.A = rows_src; q.a_row_stride = lda; q.a_scale = a_scale; q.Bp = m->L1p; q.bias = m->bias1;
         q.C = w.H1; q.ldc = CI; q.M = (int)n_rows1; q.n_store = CI; q.K = m->K1; q.slice_len = m->lat_slice1;
@@ -631,7 +634,7 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 // ------------------------------------------------------------------------------------------------ fused path
 // the automatic selection: one launch per layer.  The 8-workgroup-cluster launch of the middle (DCS_LAT_MID) is built and
 // tested but measured slower (a cluster per tile re-reads the 1.9 MB of weights per tile: 77 MB per batch through L2)
-constexpr int kLatDefault = DCS_LAT_ALL & ~DCS_LAT_MID;
+constexpr int kLatDefault = DCS_LAT_ALL & ~DCS_LAT_MID & ~DCS_LAT_FUSE1;
 constexpr int kLatBatchDefault = 0;
 static inline int64_t rows1_of(int64_t n, int64_t n_clips, int64_t Trows, int st, int tc) {
     return n_clips > 1 ? n_clips * Trows : (n - 1) * st + tc;
@@ -739,7 +742,11 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
         dsd_carve(m, p, n_all, rows1, rows2, &w, split, parts);
-        if (lat & DCS_LAT_STFT)
+        constexpr unsigned kFuse1 = DCS_LAT_STFT | DCS_LAT_CONV1 | DCS_LAT_FUSE1;
+        if ((lat & kFuse1) == kFuse1 && ld != plan->frame / 2 + 4) lat &= ~(unsigned)DCS_LAT_FUSE1;
+        if ((lat & kFuse1) == kFuse1)     // STFT + conv1 of the frames the tiles cover: H1 rows 0 .. Tcov-1 (Trows >= Tcov)
+            DCS_CHECK(dcs_launch_lat_stft_conv1(plan, audio_d, L, mag, phase, unit, ld, Trows, T, m->B1, m->bias1, w.H1, rows1, m->CI, scale));
+        else if (lat & DCS_LAT_STFT)
             DCS_CHECK(dcs_launch_lat_stft(plan, audio_d, L, mag, phase, unit, ld, Trows, T));
         else
             DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,

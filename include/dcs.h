@@ -135,7 +135,8 @@ int dcs_model_set_conv_precision(dcs_model* m, int f16);
  * is its chain of dependent memory latencies.  stages = -1 (default): automatic, all of them for one clip of at most
  * DCS_LAT_MAX_FRAMES (640) frames; 0: the throughput kernels; else a bit set: 1 STFT, 2 conv1, 4 conv2, 8 bottleneck,
  * 16 per-source dense, 32 transposed conv2, 64 final (transposed conv1 + mask + cross-fade), 128 iSTFT, 256 (with 4 .. 32
- * all set) conv2 .. transposed conv2 as ONE launch of 8-workgroup clusters that exchange through tagged granules.  Both families
+ * all set) conv2 .. transposed conv2 as ONE launch of 8-workgroup clusters that exchange through tagged granules, 512 (with
+ * 1 and 2 set) STFT and conv1 as ONE launch (four frames per workgroup).  Both families
  * read and write the same buffers, so any mix is valid (tests compare each stage against the other family).  DSD graph
  * only (DCS_EUNSUPPORTED otherwise). */
 int dcs_model_set_latency_stages(dcs_model* m, int stages);

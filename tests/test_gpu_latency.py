@@ -23,7 +23,7 @@ from deepconvsep_amd.synth import synth_audio, synth_params  # noqa: E402
 from oracle import pipeline, stft_np, tiling_np  # noqa: E402
 
 STAGES = dict(stft=1, conv1=2, conv2=4, fc=8, fc1x=16, deconv2=32, final=64, istft=128, mid=4 | 8 | 16 | 32 | 256,
-              separate_launches=255, all=511)
+              stft_conv1=1 | 2 | 512, separate_launches=255, all=1023)
 HOP, TC = 512, 30
 
 
@@ -64,7 +64,7 @@ def test_each_stage_matches_the_throughput_kernel(N, stage):
     assert np.max(np.abs(got - ref)) < 5e-6, stage
 
 
-@pytest.mark.parametrize("stages", [255, 511])
+@pytest.mark.parametrize("stages", [255, 511, 255 | 512])
 @pytest.mark.parametrize("N,tiler,ov,tiles", [(2048, 'script', 25, 32), (1024, 'script', 25, 32), (1024, 'library', 25, 13),
                                                (2048, 'library', 20, 9), (1024, 'script', 20, 7), (2048, 'script', 25, 1),
                                                (1024, 'script', 25, 2), (1024, 'script', 25, 45), (2048, 'script', 25, 70)])
@@ -186,4 +186,4 @@ def test_latency_stage_selection_errors():
     net.set_latency_stages(0)
     _, sep = _sep(1024)
     with pytest.raises(Exception):
-        sep.net.set_latency_stages(512)
+        sep.net.set_latency_stages(1024)
