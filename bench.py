@@ -67,7 +67,8 @@ TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 # which kernel carries a timing tag in each leg (substring of the kernel name in the rocprofv3 counter files); used to look
 # up the HBM traffic record of a leg's kernels in TRAFFIC_FILE["legs"][leg]
 LEG_KERNELS = {
-    "ikala": {"conv1": "conv1_reg_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "slabconv_ps_kernel", "fc": "gemm_rows",
+    # (substring, 'max' | 'min'): conv2 and its transpose are the same kernel at two grids -- the transpose (2 branches) moves more
+    "ikala": {"conv1": "conv1_reg_kernel", "conv2": ("slabconv_ps_kernel", "min"), "deconv2": "slabconv_ps_kernel", "fc": "gemm_rows",
               "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_reg_kernel"},
     "bach10_f16": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_wreg_scatter_kernel", "decoder": "colconv_deconv1_fused_kernel",
                    "fc": "gemm_rows", "fc1x": "gemm_bf16x3_skinny_kernel"},
@@ -906,11 +907,14 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
     def leg_record(tag):
         """Counter record (per launch) of the kernel that carries `tag` in this leg: the matching kernel with the most bytes."""
         sub = LEG_KERNELS.get(name, {}).get(tag)
+        pick = "max"
+        if isinstance(sub, tuple):
+            sub, pick = sub
         best = None
         for kname, rec in leg_traffic.items():
             if sub and sub in kname:
                 b = traffic_bytes(rec)
-                if b and (best is None or b > best[0]):
+                if b and (best is None or (b > best[0] if pick == "max" else b < best[0])):
                     best = (b, kname)
         return best
 

@@ -58,7 +58,14 @@ inline int dsd_gs_pitch(int CI, int tc) { return ((CI + kDsdGch - 1) / kDsdGch) 
 int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_items, int tc, int ngg);
 // streaming transposed conv2 on the bf16 matrix pipe (many items): D f32 in, the bf16 planes of G out.  Bq: the conv2
 // weights as bf16 planes, [channel group][8 channels][16 taps][25 pieces of 16 bytes] (dsd_d2q_bytes() per model)
-constexpr int kDsdD2qGroupBytes = kDsdGch * 16 * 25 * 16;
+// 16-byte pieces per (channel, tap) of the packed conv2 weights: 3 planes x 8 K pieces = 24 used, the rest padding.  26: the
+// 16 taps of a ds_read_b128 lane group then start in 16 different bank quads (scripts/lds_bank_model.py; 25 is 2-way for the real
+// lane groups -- profiles/r03_b_pmc_summary.txt: 1.48 conflict cycles per LDS-active cycle in deconv2_stream_bf16_kernel)
+#ifndef DCS_D2Q_TAP_U4
+#define DCS_D2Q_TAP_U4 26
+#endif
+constexpr int kDsdD2qTapU4 = DCS_D2Q_TAP_U4;
+constexpr int kDsdD2qGroupBytes = kDsdGch * 16 * kDsdD2qTapU4 * 16;
 inline size_t dsd_d2q_bytes(int CI) { return (size_t)((CI + kDsdGch - 1) / kDsdGch) * kDsdD2qGroupBytes; }
 int dcs_launch_dsd_deconv2_bf16(dcs_ctx* ctx, const float* D, const void* Bq, void* Gs, int64_t n_ks, int H2, int CP, int CI,
                                 int kh, int tc);

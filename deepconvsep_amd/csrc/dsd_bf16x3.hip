@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 //      (100 words: the 16 taps of a 16-lane pass start in 16 different bank quads), copied from the packed global array.
 //   Output: the three bf16 planes of G, Gs[item][channel group][t][plane][8] (what final_bf16x3_kernel stages).
 // ------------------------------------------------------------------------------------------------
-constexpr int kD2TapU4 = 25;                       // 16-byte pieces per (channel, tap): 3 planes x 8 K pieces + 1 pad
+constexpr int kD2TapU4 = kDsdD2qTapU4;              // 16-byte pieces per (channel, tap): 3 planes x 8 K pieces + padding (dsd.h)
 constexpr int kD2ChanU4 = 16 * kD2TapU4;           // per channel
 constexpr int kD2GroupU4 = kDsdGch * kD2ChanU4;    // per channel group: 3200 pieces = 51 200 bytes
 constexpr int kD2PsStride = 20;                    // floats per skewed row: 16 taps + 4

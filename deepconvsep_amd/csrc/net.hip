@@ -298,7 +298,7 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
                             float part;
                             memcpy(&part, &bits, 4);
                             r -= part;
-                            Bw2q[(((size_t)ci * 16 + dt) * 25 + pl * 8 + kb * 4 + kq) * 8 + j] = (uint16_t)(bits >> 16);
+                            Bw2q[(((size_t)ci * 16 + dt) * kDsdD2qTapU4 + pl * 8 + kb * 4 + kq) * 8 + j] = (uint16_t)(bits >> 16);
                         }
                     }
         DCS_CHECK(upload(&m->Bw2q, Bw2q));

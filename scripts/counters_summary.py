@@ -10,7 +10,8 @@ import os
 import re
 import sys
 
-KEYS = ("final_bf16x3_kernel", "deconv2_stream_bf16_kernel", "g_split_kernel", "istft_seq_kernel", "gemm_bf16x3_skinny_kernel",
+KEYS = ("lat_final_kernel", "lat_gemm_kernel", "lat_deconv2_kernel", "lat_stft_kernel", "lat_ifft_kernel", "lat_ola_kernel",
+        "lat_mid_kernel", "lat_stft_conv1_kernel", "final_bf16x3_kernel", "deconv2_stream_bf16_kernel", "g_split_kernel", "istft_seq_kernel", "gemm_bf16x3_skinny_kernel",
         "gemm_bf16x3_kernel", "gemm_pack_bq_kernel", "slabconv_ps_kernel", "slabconv_mx_kernel", "colconv_deconv1_fused_kernel",
         "colconv_wreg_gather_kernel", "colconv_wreg_scatter_kernel", "conv1_mfma_kernel", "deconv1_mfma_kernel",
         "conv1_reg_kernel", "mask_ola_kernel", "final_kernel", "deconv2_stream_kernel",

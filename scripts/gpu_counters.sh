@@ -7,7 +7,7 @@
 set -u
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 16 --streams 1 --no-cpu-baseline --no-host-fed --legs=${DCS_COUNTER_LEGS:-} --sat-tiles 4096 --min-time 0.02"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 16 --streams 1 --no-cpu-baseline --no-host-fed --no-cli --no-parity-check --legs=${DCS_COUNTER_LEGS:-} --sat-tiles 4096 --min-time 0.02 --max-rounds 6"
 cd /tmp
 run() { name=$1; shift
   rm -rf $OUT/pmc_$name
