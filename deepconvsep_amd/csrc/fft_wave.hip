@@ -26,6 +26,21 @@
 #include <math.h>
 #include <stdlib.h>
 
+#ifdef DCS_FFTW_TRACE
+// experiment build: shader-clock stamps of wave 0 of the middle workgroup of the forward kernel (fftw_trace_dump)
+__device__ unsigned long long fftw_trace_buf[64];
+#define FW_STAMP(slot)                                                                                   \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) fftw_trace_buf[slot] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#define FW_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define FW_STAMP(slot)
+#define FW_DRAIN()
+#endif
+
 namespace {
 
 typedef float cx __attribute__((ext_vector_type(2)));  // (re, im) in an aligned VGPR pair
@@ -223,10 +238,12 @@ __device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, c
 #pragma unroll
             for (int t = 0; t < R1; ++t) stc(bs + cpad(R1 * 64 * b + t), v[b * R1 + permR<R1>(t)]);
     }
+    if (DIR < 0) FW_STAMP(4);   // pass 1 done, stores issued
 #pragma unroll
     for (int b = 0; b < NB2; ++b)
 #pragma unroll
         for (int t = 0; t < R2; ++t) v[b * R2 + t] = ldc(bl + cpad(64 * b + t * 64 * NB2));
+    if (DIR < 0) { FW_DRAIN(); FW_STAMP(5); }   // exchange 1 complete
     // ---- pass 2 (Ns = R1): k = lane % R1, index (lane - k) R2 + k + 64 b R2 + t R1; lane part & 31 = k < R1,
     // constant part & 31 is a multiple of R1 below 32
     {
@@ -243,10 +260,12 @@ __device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, c
 #pragma unroll
             for (int t = 0; t < R2; ++t) stc(bs + cpad(64 * b * R2 + t * R1), v[b * R2 + permR<R2>(t)]);
     }
+    if (DIR < 0) FW_STAMP(6);   // pass 2 done
 #pragma unroll
     for (int b = 0; b < NB3; ++b)
 #pragma unroll
         for (int t = 0; t < R3; ++t) v[b * R3 + t] = ldc(bl + cpad(64 * b + t * 64 * NB3));
+    if (DIR < 0) { FW_DRAIN(); FW_STAMP(7); }   // exchange 2 complete
     // ---- pass 3 (Ns = R1 R2 = M / R3 >= 64 NB3): k = j, index lane + 64 b + t Ns
     {
         constexpr int Ns = R1 * R2;
@@ -272,6 +291,16 @@ __device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, c
 // ------------------------------------------------------------------------------------------------
 // forward (compute_file): FPW frames per workgroup, one per wave
 // ------------------------------------------------------------------------------------------------
+#ifndef DCS_STFT_TW_GLOBAL
+#define DCS_STFT_TW_GLOBAL 0   // measured: the 18 per-lane twiddle gathers from global memory cost more than the table fill (0.099 vs 0.089 ms)
+#endif
+__host__ __device__ constexpr bool stft_fwd_tw_global(int log2m) { return DCS_STFT_TW_GLOBAL && log2m <= 10; }
+// per-wave staging of the forward kernel's outputs: 256 magnitudes (1 KB) + 128 phasors (1 KB), see the wide store path
+constexpr int kStftStageF2 = 256;
+#ifndef DCS_STFT_WIDE_STORES
+#define DCS_STFT_WIDE_STORES 1
+#endif
+
 template <int LOG2M>
 __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
                                          const float2* __restrict__ tw, float* __restrict__ mag,
@@ -281,12 +310,22 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     constexpr int M = 1 << LOG2M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* twl = reinterpret_cast<float2*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row pointers stay in SGPRs
-    float2* buf = twl + (M + 1) + wave * MP;
-    for (int k = tid; k <= M; k += blockDim.x) twl[k] = tw[k];
-    __syncthreads();
+    // M <= 1024: the passes take their twiddles from registers (WaveTw), so the table is only read by WaveTw::init and by
+    // the even / odd split -- both straight from global memory (8 KB, L1 / L2 resident), requested together with the samples:
+    // no table fill, no workgroup barrier in front of the first load, 8 KB less LDS (4 workgroups per CU instead of 3)
+    FW_STAMP(0);
+    constexpr bool kTwGlobal = stft_fwd_tw_global(LOG2M);
+    // [waves][kStageF2] output staging (16-byte aligned: first in the segment), then the table, then the waves' exchange buffers
+    float2* stage = reinterpret_cast<float2*>(smem) + wave * kStftStageF2;
+    float2* lds0 = reinterpret_cast<float2*>(smem) + (blockDim.x >> 6) * kStftStageF2;
+    const float2* twl = kTwGlobal ? tw : lds0;
+    float2* buf = lds0 + (kTwGlobal ? 0 : (M + 1)) + wave * MP;
+    if (!kTwGlobal) {
+        for (int k = tid; k <= M; k += blockDim.x) lds0[k] = tw[k];
+        __syncthreads();
+    }
     // output row -> (clip, frame): clips of equal length are stacked with a pitch of rows_pc rows
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (row >= rows_pc * n_clips) return;
@@ -309,6 +348,7 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
         }
         return;
     }
+    FW_STAMP(1);   // table filled, barrier passed
     WaveTw<LOG2M> wt;
     wt.init(twl, lane);
     cx v[P];
@@ -330,45 +370,116 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
             const int r = 2 * i;
             const cx w = ldc(w2 + i);
             cx x = mk(0.f, 0.f);
+#ifdef DCS_STFT_ABL_NOLOAD
+            if (inside) {
+                x = mk((float)r, 1.f);
+            } else {
+#else
             if (inside) {
                 x = *reinterpret_cast<const cx*>(ap + r);
             } else {
+#endif
                 if (r >= r_lo && r < r_hi) x[0] = ap[r];
                 if (r + 1 >= r_lo && r + 1 < r_hi) x[1] = ap[r + 1];
             }
             v[b * R1 + tt] = x * w;
         }
+    FW_STAMP(2);   // pass twiddles read, samples and window requested
+    FW_DRAIN();
+    FW_STAMP(3);   // arrived
+#ifdef DCS_STFT_ABL_NOFFT
+    for (int i = 0; i < P; ++i) stc(buf + pad(lane) + cpad(64 * i), v[i]);
+#else
     fft_wave<LOG2M, -1>(v, lane, wt, twl, buf);
+#endif
+    FW_STAMP(8);   // pass 3 done, stores issued
     // even/odd split: X[k] = E + w^k O with E = (Z[k] + conj Z[M-k])/2, O = -i (Z[k] - conj Z[M-k])/2.
     // k = lane + 64 u; M - k = (64 - lane) + (M - 64 (u + 1)): constant parts are multiples of 64.
     const float2* bk = buf + pad(lane);
     const float2* bm = buf + pad(64 - lane);
-#pragma unroll
-    for (int u = 0; u <= P; ++u) {
+    // bin k = lane + 64 u (u == P: k = M, lane 0 only) -> magnitude before the 1 / sqrt(N) scale, and X[k]
+    auto bin = [&](int u, float& ax, float& xr, float& xi) {
         const int k = lane + 64 * u;
-        if (u == P && lane > 0) break;  // k <= M
         const cx zk = u < P ? ldc(bk + cpad(64 * u)) : ldc(buf);                      // Z[k mod M]
         const cx zm = (u == P || (u == 0 && lane == 0)) ? ldc(buf) : ldc(bm + cpad(M - 64 * (u + 1)));  // Z[(M-k) mod M]
         const cx e2 = c_add_conj(zk, zm);  // 2 E
         const cx d2 = c_sub_conj(zk, zm);  // 2 i O  ->  O = -i d2 / 2
         const cx o2 = c_sub_i(mk(0.f, 0.f), d2);
         const cx x2 = e2 + c_mul(o2, ldc(twl + k));
-        const float xr = 0.5f * x2[0], xi = 0.5f * x2[1];
+        xr = 0.5f * x2[0];
+        xi = 0.5f * x2[1];
         // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded sequences (~8 and ~10 instructions per bin):
         // far inside the float32 FFT's own rounding error
-        const float ax = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
-        mrow[k] = ax * inv_sqrt_n;
-        if (prow) prow[k] = atan2f(xi, xr);
-        if (urow) {
-            const float ra = __builtin_amdgcn_rcpf(ax);  // one reciprocal for both components
-            stc(urow + k, (ax > 0.f) ? mk(xr * ra, xi * ra) : mk(1.f, 0.f));
+        ax = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+    };
+    auto phasor = [](float ax, float xr, float xi) {
+        const float ra = __builtin_amdgcn_rcpf(ax);  // one reciprocal for both components
+        return (ax > 0.f) ? mk(xr * ra, xi * ra) : mk(1.f, 0.f);
+    };
+    // Wide stores (measured: the kernel is bound by ISSUING its 34 four- and eight-byte store instructions per frame, not by
+    // their bytes -- without stores 0.062 instead of 0.088 ms at 4096 tiles): four 64-bin blocks of magnitudes / two of
+    // phasors go through a wave-private 2 KB staging area and leave as ONE 16-byte store per lane (1 KB per instruction):
+    // 4 + 8 + 3 store instructions per frame.  Needs rows of exactly M + 4 bins on 16-byte boundaries and no phase output.
+    const bool wide = DCS_STFT_WIDE_STORES && (P % 4 == 0) && ld == M + 4 && !prow && urow &&
+                      ((reinterpret_cast<uintptr_t>(mag) | reinterpret_cast<uintptr_t>(unit)) & 15) == 0;
+    if (wide) {
+        float* sm = reinterpret_cast<float*>(stage);          // [256] magnitudes of bins 256 g .. 256 g + 255
+        float2* su = stage + 128;                             // [128] phasors of bins 128 h .. 128 h + 127
+        typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int g = 0; g < P / 4; ++g) {
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                float ax, xr, xi;
+                bin(4 * g + uu, ax, xr, xi);
+                sm[64 * uu + lane] = ax * inv_sqrt_n;
+                stc(su + 64 * (uu & 1) + lane, phasor(ax, xr, xi));
+                if (uu & 1) {
+                    // a wave's LDS instructions execute in order, so the other lanes' writes above are complete when this
+                    // read executes; the empty asm keeps the COMPILER from moving accesses of different types across it
+                    asm volatile("" ::: "memory");
+                    const f4 q = *reinterpret_cast<const f4*>(su + 2 * lane);
+                    asm volatile("" ::: "memory");
+                    *reinterpret_cast<f4*>(urow + 128 * (2 * g + (uu >> 1)) + 2 * lane) = q;
+                }
+            }
+            asm volatile("" ::: "memory");
+            const f4 q = *reinterpret_cast<const f4*>(sm + 4 * lane);
+            asm volatile("" ::: "memory");
+            *reinterpret_cast<f4*>(mrow + 256 * g + 4 * lane) = q;
+        }
+        if (lane == 0) {   // bin M and the three padding bins of the row
+            float ax, xr, xi;
+            bin(P, ax, xr, xi);
+            const cx ph = phasor(ax, xr, xi);
+            *reinterpret_cast<f4*>(mrow + M) = f4{ax * inv_sqrt_n, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f4*>(urow + M) = f4{ph[0], ph[1], 1.f, 0.f};
+            *reinterpret_cast<f4*>(urow + M + 2) = f4{1.f, 0.f, 1.f, 0.f};
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u <= P; ++u) {
+            const int k = lane + 64 * u;
+            if (u == P && lane > 0) break;  // k <= M
+            float ax, xr, xi;
+            bin(u, ax, xr, xi);
+#ifdef DCS_STFT_ABL_NOSTORE
+            if (ax == 12345.678f) mrow[k] = ax;    // never true: keeps the arithmetic alive
+#else
+            mrow[k] = ax * inv_sqrt_n;
+            if (prow) prow[k] = atan2f(xi, xr);
+            if (urow) stc(urow + k, phasor(ax, xr, xi));
+#endif
+        }
+        for (int k = M + 1 + lane; k < ld; k += 64) {
+            mrow[k] = 0.f;
+            if (prow) prow[k] = 0.f;
+            if (urow) stc(urow + k, mk(1.f, 0.f));
         }
     }
-    for (int k = M + 1 + lane; k < ld; k += 64) {
-        mrow[k] = 0.f;
-        if (prow) prow[k] = 0.f;
-        if (urow) stc(urow + k, mk(1.f, 0.f));
-    }
+    FW_STAMP(9);    // split + magnitude / phasor done, every store issued
+    FW_DRAIN();
+    FW_STAMP(10);   // stores acknowledged
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -782,7 +893,7 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride,
     const int64_t rows_all = rows_out * n_clips;
     int fpw = rows_all >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
     if (fpw_env) fpw = fpw_env;
-    const size_t lds = ((size_t)(M + 1) + (size_t)fpw * MP) * sizeof(float2);
+    const size_t lds = ((stft_fwd_tw_global(LOG2M) ? 0 : (size_t)(M + 1)) + (size_t)fpw * (MP + kStftStageF2)) * sizeof(float2);
     auto kern = stft_forward_wave_kernel<LOG2M>;
     if (lds > 48 * 1024)
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -906,4 +1017,14 @@ int dcs_fft_wave_inverse(dcs_stft* p, const float* mag, int64_t src_stride, cons
         case 11: return launch_inv<11>(p, mag, src_stride, phase, unit, unit_clip_stride, src_per_clip, ld, T, n_src, pre_div, audio, n_out, clip_tab, out_stride);
     }
     DCS_FAIL(DCS_EUNSUPPORTED, "wave FFT: frame size");
+}
+
+extern "C" int fftw_trace_dump(unsigned long long* out, int n) {
+#ifdef DCS_FFTW_TRACE
+    if (!out || n < 64) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fftw_trace_buf), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+#else
+    (void)out; (void)n;
+    return -2;
+#endif
 }
