@@ -204,7 +204,8 @@ int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64
  * clips and one pass of all their tiles through the network (a clip's tiles sit behind those of the clips before it).
  * Needs the wave STFT kernels (frameSize 1024 / 2048 / 4096 with hop | frameSize, DCS_EUNSUPPORTED otherwise).
  * n_tiles_out / n_frames_out: [n_clips] or NULL.  Equal lengths with pcm_stride == length take the
- * dcs_separate_batch path. */
+ * dcs_separate_batch path.  Asynchronous like every other call: the clip table goes out through a pinned staging ring owned
+ * by the model (n_samples_h may be reused as soon as the call returns). */
 int dcs_separate_ragged(dcs_model* m, dcs_stft* plan, const float* audio_d, const int64_t* n_samples_h,
                         int64_t n_clips, int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode,
                         int tie_mode, float* pcm_d, int64_t pcm_stride, int64_t* n_tiles_out, int64_t* n_frames_out);
