@@ -44,6 +44,44 @@ void DcsBuffer::release() {
     bytes = 0;
 }
 
+int DcsUploadRing::begin(size_t bytes, void** host_out, void** dev_out) {
+    if (bytes == 0) bytes = 16;
+    const int slot = (int)(next++ % kSlots);
+    if (ev[slot]) DCS_HIP(hipEventSynchronize(ev[slot]));   // the upload that last used this slot has run (long ago, normally)
+    else DCS_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+    if (cap[slot] < bytes) {
+        if (host[slot]) DCS_HIP(hipHostFree(host[slot]));
+        host[slot] = nullptr;
+        cap[slot] = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        DCS_HIP(hipHostMalloc(&host[slot], want, hipHostMallocDefault));
+        cap[slot] = want;
+    }
+    DCS_CHECK(dev.ensure(bytes));   // synchronises the device when (and only when) the block has to grow
+    cur = slot;
+    *host_out = host[slot];
+    *dev_out = dev.ptr;
+    return DCS_OK;
+}
+
+int DcsUploadRing::commit(size_t bytes, hipStream_t stream) {
+    if (cur < 0) DCS_FAIL(DCS_EINVAL, "upload ring: commit without begin");
+    if (bytes) DCS_HIP(hipMemcpyAsync(dev.ptr, host[cur], bytes, hipMemcpyHostToDevice, stream));
+    DCS_HIP(hipEventRecord(ev[cur], stream));
+    cur = -1;
+    return DCS_OK;
+}
+
+void DcsUploadRing::release() {
+    for (int i = 0; i < kSlots; ++i) {
+        if (ev[i]) { (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); }
+        if (host[i]) (void)hipHostFree(host[i]);
+        ev[i] = nullptr; host[i] = nullptr; cap[i] = 0;
+    }
+    dev.release();
+    cur = -1;
+}
+
 DcsTimer::DcsTimer(dcs_ctx* c, int t) : ctx(c), tag(t), idx(0), on(t >= 0 && ((c->timing_mask >> t) & 1u)) {   // t < 0: no-op
     if (!on) return;
     if ((c->timing_seen[t]++ % (uint64_t)c->timing_stride) != 0) {
@@ -138,6 +176,7 @@ extern "C" int dcs_destroy(dcs_ctx* ctx) {
         for (auto e : s.stop) (void)hipEventDestroy(e);
     }
     ctx->gemm_ws.release();
+    ctx->score_ring.release();
     if (ctx->ola_rise_d) (void)hipFree(ctx->ola_rise_d);
     delete ctx;
     return DCS_OK;

@@ -66,6 +66,23 @@ struct DcsBuffer {
     void release();
 };
 
+// Small host tables (clip lengths, note rectangles) on their way to the device without a stream synchronisation in the
+// call: begin() hands out a pinned host slot of a ring (waiting, if ever, for the upload that used the slot kSlots calls
+// ago) and the device block, commit() enqueues ONE copy of the block and records the slot's event.  The device block is
+// shared by consecutive calls -- stream order protects it, so every user must be on the same stream.
+struct DcsUploadRing {
+    static constexpr int kSlots = 4;
+    void* host[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[kSlots] = {0, 0, 0, 0};
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned next = 0;
+    int cur = -1;
+    DcsBuffer dev;
+    int begin(size_t bytes, void** host_out, void** dev_out);
+    int commit(size_t bytes, hipStream_t stream);
+    void release();
+};
+
 struct DcsTimingSlot {
     std::vector<hipEvent_t> start, stop;
     size_t used = 0;
@@ -84,6 +101,7 @@ struct dcs_ctx {
     // their own per model)
     float* ola_rise_d = nullptr;
     std::vector<float> ola_rise_h;
+    DcsUploadRing score_ring;  // note rectangles and floor values of dcs_score_masks
 };
 
 // RAII-ish helper: records a start event on construction and a stop event in done().

@@ -103,15 +103,7 @@ struct dcs_model {
     int lat_slice1 = 0;
     bool lat_ok = false;
     int lat_stages = -1;
-    DcsBuffer clip_tab;   // {samples, frames, tiles} per clip of a batch of different lengths (dcs_separate_ragged)
-    // its host side: a ring of pinned staging slots, each guarded by an event recorded behind its upload, so that the call
-    // returns without waiting for the copy (the table of call i is not overwritten before call i + kClipTabSlots has seen
-    // the event of call i complete -- normally long past)
-    static constexpr int kClipTabSlots = 4;
-    int64_t* clip_tab_h[kClipTabSlots] = {nullptr, nullptr, nullptr, nullptr};
-    size_t clip_tab_h_cap[kClipTabSlots] = {0, 0, 0, 0};
-    hipEvent_t clip_tab_ev[kClipTabSlots] = {nullptr, nullptr, nullptr, nullptr};
-    unsigned clip_tab_next = 0;
+    DcsUploadRing clip_ring;   // {samples, frames, tiles} per clip of a batch of different lengths (dcs_separate_ragged)
     // cross-fade ramps np.linspace(0, 1, ov), one device table per overlap ever asked for; a table is never freed or
     // re-allocated while the model lives (captured graphs of other call shapes keep pointing at theirs)
     std::vector<std::pair<int, float*>> rise_tabs;
@@ -572,11 +564,7 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     for (auto& g : m->graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->ws.release();
-    m->clip_tab.release();
-    for (int i = 0; i < dcs_model::kClipTabSlots; ++i) {
-        if (m->clip_tab_ev[i]) { (void)hipEventSynchronize(m->clip_tab_ev[i]); (void)hipEventDestroy(m->clip_tab_ev[i]); }
-        if (m->clip_tab_h[i]) (void)hipHostFree(m->clip_tab_h[i]);
-    }
+    m->clip_ring.release();
     if (m->Bpk) (void)hipFree(m->Bpk);
     if (m->Bw2q) (void)hipFree(m->Bw2q);
     if (m->Bdq) (void)hipFree(m->Bdq);
@@ -685,18 +673,10 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         // entry), every kernel that depends on a clip's own length reads {samples, frames, tiles} from a device table
         if (m->arch == DCS_ARCH_DSD_ILD || m->C != 1 || !pcm_d || pcm_stride < L || n_clips < 2)
             DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_ragged: single-channel graphs with PCM output and pcm_stride >= longest clip only");
-        const int slot = (int)(m->clip_tab_next++ % dcs_model::kClipTabSlots);
         const size_t tab_n = (size_t)n_clips * 3;
-        if (m->clip_tab_ev[slot]) DCS_HIP(hipEventSynchronize(m->clip_tab_ev[slot]));   // the slot's previous upload is done
-        else DCS_HIP(hipEventCreateWithFlags(&m->clip_tab_ev[slot], hipEventDisableTiming));
-        if (m->clip_tab_h_cap[slot] < tab_n) {
-            if (m->clip_tab_h[slot]) DCS_HIP(hipHostFree(m->clip_tab_h[slot]));
-            m->clip_tab_h[slot] = nullptr;
-            m->clip_tab_h_cap[slot] = 0;
-            DCS_HIP(hipHostMalloc((void**)&m->clip_tab_h[slot], tab_n * sizeof(int64_t), hipHostMallocDefault));
-            m->clip_tab_h_cap[slot] = tab_n;
-        }
-        int64_t* tab = m->clip_tab_h[slot];
+        void *tab_h = nullptr, *tab_d = nullptr;
+        DCS_CHECK(m->clip_ring.begin(tab_n * sizeof(int64_t), &tab_h, &tab_d));
+        int64_t* tab = (int64_t*)tab_h;
         T = 0;
         n = 0;
         for (int64_t c = 0; c < n_clips; ++c) {
@@ -710,15 +690,8 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
             if (Tc > T) T = Tc;
             if (nc > n) n = nc;
         }
-        // the device table is shared by consecutive calls: stream order protects it (the upload of call i + 1 is behind the
-        // kernels of call i on the same stream); ensure() only reallocates when the table grows, behind a synchronisation
-        if (m->clip_tab.bytes < tab_n * sizeof(int64_t)) {
-            DCS_HIP(hipStreamSynchronize(m->ctx->stream));
-            DCS_CHECK(m->clip_tab.ensure(std::max<size_t>(tab_n * sizeof(int64_t), 3 * 64 * sizeof(int64_t))));
-        }
-        DCS_HIP(hipMemcpyAsync(m->clip_tab.ptr, tab, tab_n * sizeof(int64_t), hipMemcpyHostToDevice, m->ctx->stream));
-        DCS_HIP(hipEventRecord(m->clip_tab_ev[slot], m->ctx->stream));
-        clip_tab_d = (const int64_t*)m->clip_tab.ptr;
+        DCS_CHECK(m->clip_ring.commit(tab_n * sizeof(int64_t), m->ctx->stream));   // no synchronisation: DcsUploadRing
+        clip_tab_d = (const int64_t*)tab_d;
     } else {
         if (n_tiles_out) *n_tiles_out = n;
         if (n_frames_out) *n_frames_out = T;

@@ -8,6 +8,8 @@
 // HBM-bound: ninst * T * F * 4 B written (+ T * F * 4 read), 33.6 MB for a 10 s Bach10 file.
 #include "dcs_internal.h"
 
+#include <string.h>
+
 #include <vector>
 
 namespace {
@@ -92,14 +94,16 @@ int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t
         lo[j] = floor_v / maxv;
         hi[j] = 1.0f / maxv;
     }
-    DcsBuffer buf;
+    // rectangles + the two value rows travel as one block through the context's upload ring (no synchronisation here)
     const size_t b_rect = rects.size() * sizeof(ScoreRect), b_val = (size_t)ninst * sizeof(float);
     const size_t off_lo = (b_rect + 255) / 256 * 256, off_hi = off_lo + (b_val + 255) / 256 * 256;
-    DCS_CHECK(buf.ensure(off_hi + b_val));
-    char* base = (char*)buf.ptr;
-    if (b_rect) DCS_HIP(hipMemcpyAsync(base, rects.data(), b_rect, hipMemcpyHostToDevice, ctx->stream));
-    DCS_HIP(hipMemcpyAsync(base + off_lo, lo.data(), b_val, hipMemcpyHostToDevice, ctx->stream));
-    DCS_HIP(hipMemcpyAsync(base + off_hi, hi.data(), b_val, hipMemcpyHostToDevice, ctx->stream));
+    void *host = nullptr, *dev = nullptr;
+    DCS_CHECK(ctx->score_ring.begin(off_hi + b_val, &host, &dev));
+    if (b_rect) memcpy(host, rects.data(), b_rect);
+    memcpy((char*)host + off_lo, lo.data(), b_val);
+    memcpy((char*)host + off_hi, hi.data(), b_val);
+    DCS_CHECK(ctx->score_ring.commit(off_hi + b_val, ctx->stream));
+    char* base = (char*)dev;
     DcsTimer tm(ctx, DCS_TAG_SCORE);
     hipLaunchKernelGGL(score_floor_kernel, dim3((unsigned)n_frames, (unsigned)ninst), dim3(256), 0, ctx->stream, mag_d, ld,
                        n_frames, F, ninst, (const float*)(base + off_lo), out_d, mask_d, mag_scale);
@@ -108,9 +112,6 @@ int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t
                            F, ninst, (const ScoreRect*)base, (const float*)(base + off_hi), out_d, mask_d, mag_scale);
     tm.done();
     DCS_HIP(hipGetLastError());
-    // the staging buffer and the host vectors must outlive the copies and the kernels
-    DCS_HIP(hipStreamSynchronize(ctx->stream));
-    buf.release();
     return DCS_OK;
 }
 

@@ -177,8 +177,8 @@ int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_s
  * call: STFT -> x scale -> filterSpec masks of the note table (notes_h exactly as for dcs_score_masks, frame window
  * (0, n_frames)) -> ninst-channel tiles of the library tiler -> network -> masks (applied to input channel 0) -> cross-fade
  * -> / scale -> iSTFT.  The model must have ninst input channels.  pcm_d [S, n_samples] float32.  All tiles go through the
- * network in one pass (the script's batch loop gives the same values tile by tile).  Synchronises the ctx stream once (the
- * note rectangles are staged from the host). */
+ * network in one pass (the script's batch loop gives the same values tile by tile).  Asynchronous (the note rectangles are
+ * staged through the context's pinned upload ring; notes_h may be reused when the call returns). */
 int dcs_separate_scoreinformed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, const double* notes_h,
                                int ninst, int n_notes, int width, int overlap, float scale, int eps_mode, int tie_mode,
                                float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out);
@@ -238,7 +238,8 @@ int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d
  * the note rectangles and 1e-18 elsewhere, divided by its maximum (so an instrument without notes gets an all-ones
  * mask, as in the reference).  out_d [ninst][n_frames][F] = mask_j * mag_d (mag_d [n_frames, ld], already scaled by
  * the caller like :503); mask_d [n_frames][ninst*F] = filterSpec's return value.  Either output may be NULL.
- * A bin range outside [0, F) is DCS_ESHAPE (NumPy raises IndexError there).  Synchronises the ctx stream. */
+ * A bin range outside [0, F) is DCS_ESHAPE (NumPy raises IndexError there).  Asynchronous: the note rectangles go out through
+ * a pinned staging ring owned by the context. */
 int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
                     int ninst, int n_notes, int width, int64_t start, int64_t stop, float* out_d, float* mask_d);
 
