@@ -100,3 +100,83 @@ def gather_batches(pcm, group=None):
     out = torch.empty((world * pcm.shape[0], pcm.shape[1]), dtype=pcm.dtype, device=pcm.device)
     dist.all_gather_into_tensor(out, pcm.contiguous(), group=group)
     return out
+
+
+class RcclComm:
+    """An RCCL communicator of this process's own -- what ``dcs_gather`` (include/dcs.h) takes.  One rank per GPU; the
+    unique id is made by rank 0 and handed to the others by whatever side channel the launcher has
+    (``from_process_group`` uses ``torch.distributed``).  libdcs dlopens the same ``librccl.so.1``, so the communicator and
+    the collective calls live in one library instance."""
+
+    _rccl = None
+
+    @classmethod
+    def _lib(cls):
+        import ctypes
+        if cls._rccl is None:
+            lib = None
+            for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+                try:
+                    lib = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                    break
+                except OSError:
+                    continue
+            if lib is None:
+                raise NotImplementedError("librccl.so not found")
+            cls._rccl = lib
+        return cls._rccl
+
+    @classmethod
+    def unique_id(cls):
+        import ctypes
+        buf = (ctypes.c_char * 128)()
+        rc = cls._lib().ncclGetUniqueId(ctypes.byref(buf))
+        if rc != 0:
+            raise RuntimeError("ncclGetUniqueId: %d" % rc)
+        return bytes(buf)
+
+    def __init__(self, n_ranks, rank, uid):
+        import ctypes
+
+        class _Uid(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_char * 128)]
+        lib = self._lib()
+        u = _Uid()
+        ctypes.memmove(ctypes.byref(u), uid, 128)
+        self._h = ctypes.c_void_p()
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _Uid, ctypes.c_int]
+        rc = lib.ncclCommInitRank(ctypes.byref(self._h), int(n_ranks), u, int(rank))
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank: %d" % rc)
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(world, rank, box[0])
+
+    def gather(self, ctx, shard, full=None, root=-1):
+        """``shard``: this rank's contiguous device tensor; ``full``: ``[n_ranks, *shard.shape]`` of the same dtype on the
+        receiving rank(s) (allocated if omitted); ``root`` < 0: every rank receives.  Enqueued on the context's stream."""
+        import ctypes
+        import torch
+        from ._lib import check
+        if not shard.is_contiguous():
+            shard = shard.contiguous()
+        receives = root < 0 or root == self.rank
+        if full is None and receives:
+            with torch.cuda.stream(ctx.torch_stream):
+                full = torch.empty((self.n_ranks,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
+        nbytes = shard.numel() * shard.element_size()
+        check(ctx._lib.dcs_gather(ctx._h, self._h, ctypes.c_void_p(shard.data_ptr()), nbytes,
+                                  ctypes.c_void_p(full.data_ptr()) if full is not None else None, int(root)))
+        return full if receives else None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib().ncclCommDestroy.argtypes = [__import__("ctypes").c_void_p]
+            self._lib().ncclCommDestroy(self._h)
+            self._h = None

@@ -230,6 +230,15 @@ int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int
  * clipping (separate_dsd.py:307-309).  Halves the bytes of the multi-GPU PCM gather. */
 int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d);
 
+/* The one exchange of the multi-GPU path (tiles / clips are sharded over one process per GPU and nothing else is shared;
+ * SURVEY 8b `dcs_gather(h, ncclComm_t, shard, count, full, root)`, counted in BYTES here so that the scripts' int16 PCM of
+ * dcs_pcm_to_int16 travels as it is).  nccl_comm is the caller's ncclComm_t (RCCL: ncclCommInitRank, one rank per GPU);
+ * librccl is dlopen'ed on first use -- libdcs has no link-time dependency on it (DCS_EUNSUPPORTED if it cannot be loaded).
+ * root < 0: all-gather, every rank's full_d [n_ranks][bytes] in rank order.  root >= 0: only that rank receives (grouped
+ * ncclSend / ncclRecv: what a single writer process needs, 1 / n_ranks of the all-gather's traffic per link); full_d may be
+ * NULL elsewhere.  Enqueued on the ctx stream like every other call; shard_d may be the rank's own slot of full_d. */
+int dcs_gather(dcs_ctx* ctx, void* nccl_comm, const void* shard_d, int64_t bytes, void* full_d, int root);
+
 /* ------------------------------------------------------------------ score-informed front-end */
 /* filterSpec (examples/bach10_scoreinformed/separate_bach10.py:172-200) and the network input of :520-527.
  * notes_h: HOST table [ninst][n_notes][width] of doubles exactly as expandMidi returns it (util.py:424-512),

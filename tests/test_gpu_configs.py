@@ -10,6 +10,7 @@
   per-rank worker (gloo);
 * contexts on a side stream used without an enclosing ``torch.cuda.stream`` block (copy / kernel ordering).
 """
+import ctypes
 import json
 import os
 import socket
@@ -362,3 +363,37 @@ def test_long_file_sharded_over_two_ranks_with_the_hip_separator():
     got = ret["pcm"]
     assert got.shape == whole.shape
     assert np.max(np.abs(got - whole)) < 2e-6
+
+
+def test_dcs_gather_through_the_c_abi_with_a_one_rank_rccl_communicator():
+    """dcs_gather (include/dcs.h) on a communicator of ONE rank -- all this box can host (RCCL refuses two ranks
+    on one device): librccl is dlopen'ed by libdcs, the all-gather and the root form both deliver the shard bit for bit,
+    int16 PCM travels as bytes, and the argument checks hold.  N > 1 ranks stay unmeasured."""
+    import torch
+    from deepconvsep_amd import _lib
+    from deepconvsep_amd.dist import RcclComm
+    from deepconvsep_amd.runtime import default_context
+    ctx = default_context()
+    try:
+        comm = RcclComm(1, 0, RcclComm.unique_id())
+    except (NotImplementedError, RuntimeError, OSError) as e:
+        pytest.skip("no usable librccl here: %s" % e)
+    try:
+        pcm = torch.rand((4, 70001), device="cuda") * 2 - 1
+        pcm16 = torch.empty(pcm.shape, dtype=torch.int16, device="cuda")
+        _lib.check(ctx._lib.dcs_pcm_to_int16(ctx._h, ctypes.c_void_p(pcm.data_ptr()), pcm.numel(), ctypes.c_void_p(pcm16.data_ptr())))
+        full = comm.gather(ctx, pcm16, root=-1)
+        torch.cuda.synchronize()
+        assert tuple(full.shape) == (1, 4, 70001) and torch.equal(full[0], pcm16)
+        full2 = torch.zeros_like(full)
+        assert comm.gather(ctx, pcm16, full2, root=0) is full2
+        torch.cuda.synchronize()
+        assert torch.equal(full2[0], pcm16)
+        want = (pcm.cpu().numpy() * 32767).astype(np.int16)           # the scripts' truncation (separate_dsd.py:307-309)
+        assert np.array_equal(full2[0].cpu().numpy(), want)
+        with pytest.raises(ValueError):
+            comm.gather(ctx, pcm16, full2, root=3)                      # no such rank
+        with pytest.raises(ValueError):
+            _lib.check(ctx._lib.dcs_gather(ctx._h, None, ctypes.c_void_p(pcm16.data_ptr()), 16, ctypes.c_void_p(full2.data_ptr()), -1))
+    finally:
+        comm.close()
