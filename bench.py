@@ -74,12 +74,15 @@ LEG_KERNELS = {
                    "fc": "gemm_rows", "fc1x": "gemm_bf16x3_skinny_kernel"},
     "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
                        "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel"},
+    "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
+                   "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel"},
 }
 # kernels that execute on the 16-bit matrix pipe: (products issued per f32 product, K padding factor)
 LEG_ISSUED = {
     "ikala": {"conv2": (6, 32.0 / 30.0), "deconv2": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
     "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc1x": (6, 1.0)},
     "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
+    "bach10_f32": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
 }
 
 
@@ -150,7 +153,7 @@ def main():
     ap.add_argument("--min-time", type=float, default=0.25, help="seconds of timed rounds to accumulate")
     ap.add_argument("--max-rounds", type=int, default=4000)
     ap.add_argument("--sat-tiles", type=int, default=4096, help="tiles of the saturating extra run (0 = skip)")
-    ap.add_argument("--legs", default="ikala,bach10_f16,score_informed",
+    ap.add_argument("--legs", default="ikala,bach10_f16,bach10_f32,score_informed",
                     help="comma list of extra BASELINE configs to measure on rank 0 at N=1 ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive extra leg")
@@ -829,6 +832,15 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
         audio = synth_audio(Lc, seed=0)
         library, melody = False, None
         what = "Bach10 4-instrument separate_bach10 path (BASELINE configs[3]): frameSize=4096 hop=512 blackmanharris, overlap 25, 10 s mono, conv2 / conv2^T with f16 inputs + f32 accumulation (MFMA), everything else f32"
+    elif name == "bach10_f32":
+        # the same Bach10 clip with every layer f32-class (no f16 switch): the 1e-4 result of that graph; its CPU baseline is
+        # the bach10_f16 leg's (same clip, same float64 oracle)
+        arch_name, Nf, ov, window, f16, batch, seed = "bach10", 4096, 25, dcs.blackmanharris, False, 32, 3
+        Lc = 441000
+        audio = synth_audio(Lc, seed=0)
+        library, melody = False, None
+        with_cpu = False
+        what = "Bach10 4-instrument separate_bach10 path, f32-class arithmetic throughout (the 1e-4 variant of configs[3]): frameSize=4096 hop=512 blackmanharris, overlap 25, 10 s mono"
     elif name == "score_informed":
         # BASELINE configs[4]: score-conditioned masks, batch=128 (4-channel input [128,4,30,2049])
         arch_name, Nf, ov, window, f16, batch, seed = "bach10_si", 4096, 25, dcs.blackmanharris, False, 128, 5

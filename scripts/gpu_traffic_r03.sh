@@ -14,9 +14,12 @@ run() { tag=$1; shift
     timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${n}_$tag -o p -- "$@" > $OUT/pmc_${n}_$tag.json 2> $OUT/pmc_${n}_$tag.err
     echo "pmc $n $tag exit $?"
   done; }
+# DCS_TRAFFIC_LEGS="leg ..." restricts the visit to those legs (merge the result with scripts/traffic_merge.py)
+if [ -z "${DCS_TRAFFIC_LEGS:-}" ]; then
 run k20 $B --steps 20 --warmup 5 --legs= --sat-tiles 0
 run g32 $B --steps 32 --warmup 8 --streams 1 --legs= --sat-tiles 4096
-for leg in ikala bach10_f16 score_informed; do
+fi
+for leg in ${DCS_TRAFFIC_LEGS:-ikala bach10_f16 bach10_f32 score_informed}; do
   run leg_$leg $B --only-legs --legs $leg
 done
 cd $GRAFT_REPO_ROOT
