@@ -72,10 +72,17 @@ __global__ __launch_bounds__(kThreads) void conv1_kernel(const float* __restrict
 // neighbouring threads through L1), the filter taps -- the same for every thread -- come through scalar loads from
 // Wt[c][u][32] (filters fastest), so the inner loop is NF multiply-adds per tap with one vector and one scalar operand.
 // The LDS kernel above does one (broadcast) LDS read per multiply-add and is bound by that.
-template <int NF, int SW>
+// POOL: MaxPool2DLayer((1, 4)) fused in (iKala): the four lanes of a pooling window take the window maximum with two
+// quad permutes, the workgroup writes the POOLED rows [n][NF][tc][wp] and -- instead of the full-resolution activations,
+// which only the un-pooling VJP would read again -- the routing of that VJP as 4 bits per window (the positions that equal
+// the maximum: all of them, Theano 0.9's CPU MaxPoolGrad, or only the first with tie_first), 8 windows per 32-bit word,
+// mw words per row: a wave's ballot IS its two words.  deconv1_reg_kernel<., ., true> consumes the pair.
+template <int NF, int SW, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void conv1_reg_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int C, int tc, int F, int kw, int w1) {
+                                                             int C, int tc, int F, int kw, int w1,
+                                                             unsigned* __restrict__ maskw = nullptr, int wp = 0, int mw = 0,
+                                                             int tie_first = 0) {
     constexpr int KW = 32;                  // taps held in registers (kw <= 32)
     const int64_t nt = blockIdx.y;          // n*tc + t
     const int64_t n = nt / tc;
@@ -113,6 +120,23 @@ __global__ __launch_bounds__(kThreads) void conv1_reg_kernel(const float* __rest
                 }
             }
         }
+    }
+    if (POOL) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int o = 0; o < NF; ++o) {
+            const int ai = __builtin_bit_cast(int, acc[o]);
+            const float m1 = fmaxf(acc[o], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ai, ai, 0xB1, 0xf, 0xf, false)));
+            const int mi = __builtin_bit_cast(int, m1);
+            const float m = fmaxf(m1, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(mi, mi, 0x4E, 0xf, 0xf, false)));
+            unsigned long long b = __builtin_amdgcn_ballot_w64(acc[o] == m);
+            if (tie_first)   // keep the lowest set bit of every nibble
+                b &= ~(((b << 1) & 0xEEEEEEEEEEEEEEEEull) | ((b << 2) & 0xCCCCCCCCCCCCCCCCull) | ((b << 3) & 0x8888888888888888ull));
+            const int64_t row = (n * NF + o) * tc + t;
+            if ((lane & 3) == 0 && (j >> 2) < wp) out[row * wp + (j >> 2)] = m;
+            if ((lane & 31) == 0) maskw[row * mw + (j >> 5)] = lane ? (unsigned)(b >> 32) : (unsigned)b;
+        }
+        return;
     }
 #pragma unroll
     for (int o = 0; o < NF; ++o) out[((n * NF + o) * tc + t) * (int64_t)w1 + j] = acc[o];
@@ -941,10 +965,16 @@ __global__ __launch_bounds__(kColThreads) void colconv_f16_kernel(const ColConvA
 // per 11 vector loads for the Bach10 shape; the direct kernel below does one LDS read per operand (2 per
 // multiply-add) and is LDS-bandwidth bound: 1.3 ms -> see DESIGN.md for 167 tiles.
 // ------------------------------------------------------------------------------------------------
-template <int SW, int NT /* taps per residue = ceil(kw / SW) */>
+// POOLED (SW = 3, NT = 10: iKala): the un-pooling VJP fused in.  g is the POOLED gradient [m][NF][tc][wp] and maskw the routing
+// bits conv1_reg_kernel<., ., true> left (rows [m / nb][NF][tc][mw]): a thread's 13 inputs j0 .. j0 + 12 start at position 3
+// of window k = qb - 3 and cover windows k + 1 .. k + 3 whole, so it loads 4 pooled values (16 bytes) and 16 routing bits (one
+// 8-byte load) per channel instead of 13 un-pooled values -- and the un-pooled tensor (4x the bytes, written and read once) and
+// its kernel do not exist.
+template <int SW, int NT /* taps per residue = ceil(kw / SW) */, bool POOLED = false>
 __global__ __launch_bounds__(kThreads) void deconv1_reg_kernel(const float* __restrict__ g, const float* __restrict__ Wp,
                                                                float* __restrict__ out, int NF, int C, int tc, int F,
-                                                               int w1, int nqb) {
+                                                               int w1, int nqb, const unsigned* __restrict__ maskw = nullptr,
+                                                               int wp = 0, int mw = 0, int nb = 1) {
     // a thread owns QB values of q and all SW residues: FB = SW * QB consecutive bins (16 for a stride of 4, 12 for the
     // iKala stride of 3, whose 30 taps are exactly 10 per residue)
     constexpr int QB = 4, FB = SW * QB, XI = QB + NT - 1;
@@ -953,16 +983,42 @@ __global__ __launch_bounds__(kThreads) void deconv1_reg_kernel(const float* __re
     if (idx >= tc * nqb) return;
     const int t = idx / nqb, qb = idx - t * nqb;
     const int q0 = qb * QB, j0 = q0 - (NT - 1);            // inputs j0 .. j0 + XI - 1
-    const float* grow = g + (m * NF * tc + t) * (int64_t)w1;
+    static_assert(!POOLED || (QB == 4 && (NT - 1) % 4 == 1), "pooled input: j0 = 4 (qb - (NT + 2) / 4) + 3");
+    const float* grow = g + (m * NF * tc + t) * (int64_t)(POOLED ? wp : w1);
+    const unsigned* mrow = POOLED ? maskw + ((m / nb) * NF * tc + t) * (int64_t)mw : nullptr;
+    const int k = qb - (NT + 2) / 4;                       // POOLED: first window touched (position 3 of it only)
     for (int c = 0; c < C; ++c) {
         float acc[FB];
 #pragma unroll
         for (int i = 0; i < FB; ++i) acc[i] = 0.f;
         for (int o = 0; o < NF; ++o) {
-            const float* gp = grow + (int64_t)o * tc * w1;
+            const float* gp = grow + (int64_t)o * tc * (POOLED ? wp : w1);
             float gw[XI];
             constexpr int NV = (XI + 3) / 4;
-            if (j0 >= 0 && j0 + 4 * NV <= w1) {           // interior: three or four (unaligned) 16-byte loads
+            if (POOLED) {
+                const unsigned* mp = mrow + (int64_t)o * tc * mw;
+                float gv[4];
+                unsigned bits;
+                if (k >= 0 && k + 3 < wp) {               // interior: one 16-byte and one 8-byte load
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(gp + k);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[i] = v[i];
+                    const unsigned long long w64 = *reinterpret_cast<const unsigned long long*>(mp + (k >> 3));
+                    bits = (unsigned)(w64 >> (4 * (k & 7))) & 0xffffu;
+                } else {
+                    bits = 0u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int w = k + i;
+                        const bool in = w >= 0 && w < wp;
+                        gv[i] = in ? gp[w] : 0.f;
+                        if (in) bits |= ((mp[w >> 3] >> (4 * (w & 7))) & 15u) << (4 * i);
+                    }
+                }
+                // input x of the thread = position (x + 3) & 3 of window (x + 3) >> 2 (relative to k)
+#pragma unroll
+                for (int x = 0; x < XI; ++x) gw[x] = ((bits >> (x + 3)) & 1u) ? gv[(x + 3) >> 2] : 0.f;
+            } else if (j0 >= 0 && j0 + 4 * NV <= w1) {           // interior: three or four (unaligned) 16-byte loads
                 f32x4 v[NV];
 #pragma unroll
                 for (int q = 0; q < NV; ++q) v[q] = *reinterpret_cast<const f32x4*>(gp + j0 + 4 * q);
@@ -1516,6 +1572,17 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     float* g1 = g2;
     if (d.pool_w) { g1 = (float*)w; w += align256((size_t)n * NB * d.nf1 * plane1 * 4); }
     float* o = (float*)w; w += align256((size_t)n * NB * C * tc * F * 4);
+    // iKala: max-pool fused into conv1 and its VJP into conv1^T (register kernels, 30 filters of 30 taps at a stride of 3, pool
+    // width 4).  The full-resolution activations a1b then never exist; their region holds the routing words instead
+    // (pool_mw + 1 <= w1 words per row).  DCS_POOL_FUSED=0: the four separate kernels.
+    static const int pool_fused_env = getenv("DCS_POOL_FUSED") ? atoi(getenv("DCS_POOL_FUSED")) : 1;
+    static const int reg1_env = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
+    static const int dreg_env = getenv("DCS_DECONV1_REG") ? atoi(getenv("DCS_DECONV1_REG")) : 1;
+    const int pool_mw = (int)dcs_cdiv(d.w1, 64) * 2;
+    const bool pool_fused = pool_fused_env && reg1_env && dreg_env && d.pool_w == 4 && d.nf1 == 30 && d.sw1 == 3 && d.kw1 <= 32 &&
+                            (d.kw1 + 2) / 3 == 10 && g->W1t && g->W1p && !g->W1m && !g->W1dq &&
+                            pool_mw + 1 <= d.w1 && d.wp * 4 <= d.w1;
+    unsigned* pool_bits = reinterpret_cast<unsigned*>(a1b);
 
     // conv1 + both biases
     {
@@ -1527,7 +1594,10 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         DcsTimer tm(ctx, DCS_TAG_CONV1);
         static const int reg1 = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
         const dim3 grid1((unsigned)dcs_cdiv(d.w1, kThreads), (unsigned)(n * tc));
-        if (g->W1m && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1)) {
+        if (pool_fused) {   // conv1 + max-pool: pooled rows to p1, the un-pooling routing bits where the activations would go
+            hipLaunchKernelGGL((conv1_reg_kernel<30, 3, true>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, p1, C,
+                               tc, F, d.kw1, d.w1, pool_bits, d.wp, pool_mw, tie_mode == DCS_TIE_FIRST ? 1 : 0);
+        } else if (g->W1m && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1)) {
         } else if (reg1 && d.nf1 == 30 && d.kw1 <= 32 && d.sw1 == 4)   // the register kernel is built for 30 filters
             hipLaunchKernelGGL((conv1_reg_kernel<30, 4>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, a1b, C,
                                tc, F, d.kw1, d.w1);
@@ -1539,7 +1609,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                                d.sw1, d.w1);
         tm.done();
     }
-    if (d.pool_w) {
+    if (d.pool_w && !pool_fused) {
         DcsTimer tm(ctx, DCS_TAG_POOL);
         hipLaunchKernelGGL(pool_kernel, dim3((unsigned)dcs_cdiv(n * d.nf1 * tc * d.wp, kThreads)), dim3(kThreads), 0,
                            ctx->stream, a1b, p1, n * d.nf1 * tc, d.w1, d.wp, d.pool_w);
@@ -1661,7 +1731,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         tm.done();
     }
     // InverseLayer(., pool)
-    if (d.pool_w) {
+    if (d.pool_w && !pool_fused) {
         DcsTimer tm(ctx, DCS_TAG_UNPOOL);
         const int64_t rows_g = n * NB * d.nf1 * tc;
         if (d.pool_w != 4 || rows_g > 0x7fffffff) DCS_FAIL(DCS_EUNSUPPORTED, "un-pool: pool width %d, %lld rows", d.pool_w, (long long)rows_g);
@@ -1680,7 +1750,11 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                                         (int)lds));
         DcsTimer tm(ctx, DCS_TAG_FINAL);
         static const int reg_env = getenv("DCS_DECONV1_REG") ? atoi(getenv("DCS_DECONV1_REG")) : 1;
-        if (g->W1dq && dcs_launch_deconv1_mfma(ctx, g1, g->W1dq, o, n * NB, d.nf1, C, tc, F, d.w1)) {
+        if (pool_fused) {   // un-pool + conv1^T: reads the pooled gradient and the routing bits
+            const int nqb = (F + 11) / 12;
+            hipLaunchKernelGGL((deconv1_reg_kernel<3, 10, true>), dim3((unsigned)dcs_cdiv((int64_t)tc * nqb, kThreads), (unsigned)(n * NB)),
+                               dim3(kThreads), 0, ctx->stream, g2, g->W1p, o, d.nf1, C, tc, F, d.w1, nqb, pool_bits, d.wp, pool_mw, NB);
+        } else if (g->W1dq && dcs_launch_deconv1_mfma(ctx, g1, g->W1dq, o, n * NB, d.nf1, C, tc, F, d.w1)) {
         } else if (g->W1p && reg_env && d.sw1 == 3 && (d.kw1 + 2) / 3 == 10) {
             const int nqb = (F + 11) / 12;
             hipLaunchKernelGGL((deconv1_reg_kernel<3, 10>), dim3((unsigned)dcs_cdiv((int64_t)tc * nqb, kThreads), (unsigned)(n * NB)),

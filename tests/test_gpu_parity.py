@@ -395,6 +395,54 @@ def test_ikala_pool_tie_modes():
     assert np.abs(a - b).max() > 1e-5
 
 
+_IKALA_POOL_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from deepconvsep_amd.arch import TIE_ALL, TIE_FIRST
+from deepconvsep_amd.runtime import Network, default_context
+from deepconvsep_amd.synth import synth_params
+z = np.load(sys.argv[2])
+ctx = default_context()
+F = int(z['F'])
+net = Network(ctx, 'ikala', synth_params('ikala', 30, F, seed=9), 30, F)
+xd = ctx.to_device(z['x'], np.float32)
+worst = 0.0
+for mode, key in ((TIE_ALL, 'want_all'), (TIE_FIRST, 'want_first')):
+    p = net.forward_raw(xd, tie_mode=mode).cpu().numpy()
+    worst = max(worst, float(np.max(np.abs(p - z[key]))))
+print('max err %.3e' % worst)
+sys.exit(0 if worst < 1e-4 else 3)
+"""
+
+
+@pytest.mark.parametrize("F", [513, 1025, 271])
+@pytest.mark.parametrize("env", [{}, {"DCS_POOL_FUSED": "0"}, {"DCS_POOL_FUSED": "0", "DCS_CONV1_REG": "0"},
+                                 {"DCS_DECONV1_REG": "0"}])
+def test_ikala_pool_fused_and_separate_kernels_agree_with_the_oracle(env, F, tmp_path):
+    """The iKala graph's max-pool runs inside conv1 and its VJP inside conv1^T by default (routing bits instead of the
+    full-resolution activations); DCS_POOL_FUSED=0 (or either register kernel switched off) takes the four separate
+    kernels.  Both against the oracle for both tie routings, on tiles with digital-silence rows and a silent band (every
+    window over them ties exactly: the bias alone), and F = 271 / 513 (w1 = 81 / 162: rows that do not end on a window)."""
+    import subprocess
+    # max-pool routing is discontinuous: two conv1 outputs of a window closer than float32 rounding route the gradient
+    # differently in float64 -- seed 30 is the draw (of seeds 30..79, three tiles) with the widest smallest margin at all three
+    # sizes: 2.6e-6 of the largest activation, ~10x the rounding error of a 30-tap float32 dot product
+    n = 3
+    x = _tiles("ikala", n, 30, F, seed=30)
+    x[0, 0, 10:14] = 0.0
+    x[2, 0, :, 40:90] = 0.0
+    params = synth_params("ikala", 30, F, seed=9)
+    want_all = net_ref.forward("ikala", params, x.astype(np.float64), tie_mode='all', inverse='explicit').numpy()
+    want_first = net_ref.forward("ikala", params, x.astype(np.float64), tie_mode='first', inverse='explicit').numpy()
+    f = tmp_path / "case.npz"
+    np.savez(f, x=x, want_all=want_all, want_first=want_first, F=F)
+    child_env = dict(os.environ)
+    child_env.update(env)
+    r = subprocess.run([sys.executable, "-c", _IKALA_POOL_CHILD, ROOT, str(f)], env=child_env, capture_output=True, text=True,
+                       timeout=200)
+    assert r.returncode == 0, (env, F, r.stdout[-400:], r.stderr[-800:])
+
+
 def test_generic_chunked_batch_equals_small_batches():
     """More tiles than one scratch chunk: the chunked batch equals evaluation in small batches (the chunk is sized
     from a 4 GiB scratch budget; DCS_GENERIC_CHUNK forces small chunks in the variant test below)."""
