@@ -727,7 +727,14 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
 // thread and step, ~300 scalar instructions per frame of 64-bit flush bookkeeping.  Measured at 4096 tiles (N = 2048,
 // 4 sources): 0.302 -> 0.240 ms; a 16 x 32-tile launch group 56.7 -> 49.1 us.
 // ------------------------------------------------------------------------------------------------
-template <int LOG2M, bool UNIT, int R>
+// STAGE (four sources per clip, phasor input, rows of M + 4 bins on 16-byte boundaries): the spectra come in through LDS.
+// Measured on the plain form (profiles/r03_e_istft_ablation.txt): of 0.224 ms at 4096 tiles 0.090 are its 64 four- and
+// eight-byte global loads per frame and source (0.134 with none of them), 0.057 the phasor loads alone.  Here a wave requests
+// the NEXT frame's magnitude row (its own source) and its quarter of the phasor row (shared by the four sources = the four
+// waves of the workgroup) as 16-byte-per-lane global_load_lds transfers -- 8 instead of 64 vector-memory instructions per
+// frame, no registers, a whole FFT ahead of their use -- and reads them back lane by lane from LDS.  Costs one workgroup
+// barrier per frame: the four waves walk the same frames, which they do anyway (same chunk, same clip).
+template <int LOG2M, bool UNIT, int R, int STAGE = 0 /* 1: magnitudes and phasors through LDS, 2: magnitudes only (no barrier) */>
 __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restrict__ mag, int64_t src_stride,
                                                           const float* __restrict__ phase, const float2* __restrict__ unit,
                                                           int64_t ld, const float* __restrict__ win,
@@ -746,6 +753,9 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float2* buf = fbuf + wave * MP;
+    // STAGE: [2][M + 4] phasor rows (frame parity), then [4][M + 4] magnitude rows (one per wave); all 16-byte aligned
+    float2* sunit = fbuf + 4 * MP;
+    float* smag = reinterpret_cast<float*>(sunit + 2 * (M + 4)) + wave * (M + 4);
     const float inv_m = 1.f / (float)M;                      // a power of two: (z / M) * w == z * (w / M) exactly
     {
         const float2* w2g = reinterpret_cast<const float2*>(win);
@@ -797,6 +807,26 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
 
     const float2* wlane = winl + lane;
     const float2* blane = buf + pad(lane);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    // frame n's rows -> LDS: this wave's magnitude row (M + 4 floats = 4 full transfers + one 16-byte piece) and pieces
+    // 128 wave .. 128 wave + 127 of the phasor row (2 transfers; wave 3 also the last two pieces)
+    auto request = [&](int64_t n) {
+        const f4* m4 = reinterpret_cast<const f4*>(msrc + n * ld);
+        f4* sm4 = reinterpret_cast<f4*>(smag);
+#pragma unroll
+        for (int c = 0; c < M / 256; ++c) __builtin_amdgcn_global_load_lds(m4 + 64 * c + lane, sm4 + 64 * c, 16, 0, 0);
+        if (lane == 0) __builtin_amdgcn_global_load_lds(m4 + M / 4, sm4 + M / 4, 16, 0, 0);
+        if (STAGE == 2) return;
+        const f4* u4 = reinterpret_cast<const f4*>(unit + n * ld);
+        f4* su4 = reinterpret_cast<f4*>(sunit + (int)(n & 1) * (M + 4));
+        constexpr int UQ = M / 2 / 4;                         // 16-byte pieces per wave: M / 2 of the M / 2 * 4 + 2
+#pragma unroll
+        for (int c = 0; c < UQ / 64; ++c)
+            __builtin_amdgcn_global_load_lds(u4 + wave * UQ + 64 * c + lane, su4 + wave * UQ + 64 * c, 16, 0, 0);
+        if (wave == 3 && lane < 2) __builtin_amdgcn_global_load_lds(u4 + 4 * UQ + lane, su4 + 4 * UQ, 16, 0, 0);
+    };
+    int pend = 0;                                            // vector stores issued behind the last request (wave-uniform)
+    if (STAGE && n_first <= n_last) request(n_first);
     for (int64_t nb = (n_first / R) * R; nb < hb1; nb += R) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -805,6 +835,15 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
                 const float* mrow = msrc + n * ld;
                 const float2* urow = unit + n * ld;
                 const float* prow = phase + n * ld;
+                if (STAGE) {
+                    // the rows requested one frame ago have landed (the block stores issued after the request may still be in
+                    // flight: vector memory operations complete in order), here and -- behind the barrier -- in the other
+                    // three waves; the barrier also says that everybody is done reading frame n - 1's phasors
+                    if (pend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VPB) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (STAGE == 1) __syncthreads();
+                }
+                const float2* su = sunit + (int)(n & 1) * (M + 4);
                 cx v[P];
 #pragma unroll
                 for (int b = 0; b < NB1; ++b)
@@ -812,12 +851,21 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
                     for (int tt = 0; tt < R1; ++tt) {
                         const int k = lane + 64 * b + tt * stride1;  // 0 <= k < M
                         const int km = M - k;                         // 1..M
-                        const float a = mrow[k] * amp;
-                        const float b2 = mrow[km] * amp;
+#ifdef DCS_ISTFT_ABL_NOMAG
+                        const float a = (float)(k + 1) * amp, b2 = (float)(km + 1) * amp;
+#else
+                        const float a = (STAGE ? smag[k] : mrow[k]) * amp;
+                        const float b2 = (STAGE ? smag[km] : mrow[km]) * amp;
+#endif
                         cx xk, xm;
                         if (UNIT) {
-                            xk = ldc(urow + k) * a;
-                            xm = ldc(urow + km) * b2;
+#ifdef DCS_ISTFT_ABL_NOUNIT
+                            xk = mk(0.6f, 0.8f) * a;
+                            xm = mk(0.8f, -0.6f) * b2;
+#else
+                            xk = (STAGE == 1 ? ldc(su + k) : ldc(urow + k)) * a;
+                            xm = (STAGE == 1 ? ldc(su + km) : ldc(urow + km)) * b2;
+#endif
                         } else {
                             float sn, cs;
                             sincosf(prow[k], &sn, &cs);
@@ -837,6 +885,13 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
                         const cx o = c_mul_conj(d, wk);
                         v[b * R1 + tt] = c_add_i(e, o);
                     }
+                if (STAGE) {
+                    pend = 0;
+                    if (n + 1 <= n_last) {   // this wave's reads of its magnitude row are complete before it is overwritten
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        request(n + 1);
+                    }
+                }
                 fft_wave<LOG2M, +1>(v, lane, wt, tw, buf);
                 // frame n covers the hop-blocks n .. n + R - 1: block n + d lives in register slot (j + d) % R
 #pragma unroll
@@ -857,7 +912,9 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
                     float* op = dst + m0 + 2 * lane;
 #pragma unroll
                     for (int vv = 0; vv < VPB; ++vv) *reinterpret_cast<cx*>(op + 128 * vv) = acc[j][vv] * nrm[vv];
+                    pend = VPB;
                 } else {
+                    pend = 0;   // an edge block: the count of stores is data dependent, the next frame waits for all of them
                     const int64_t f_hi = g < T - 1 ? g : T - 1;
                     const int64_t f_lo = g < R ? 0 : g - (R - 1);
 #pragma unroll
@@ -934,6 +991,33 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
             const int n_chunks_s = (int)((n_blocks + Cs - 1) / Cs);
             const size_t lds_s = ((size_t)M + 4 * (size_t)MP) * sizeof(float2);
             const dim3 grid_s((unsigned)(((int64_t)n_chunks_s * n_src + 3) / 4));
+            // spectra through LDS (istft_seq_kernel<..., true>): four sources per clip in one workgroup, phasor input, rows of
+            // M + 4 bins whose starts are 16-byte aligned; DCS_ISTFT_STAGE=0 switches it off
+            static const int stage_env = getenv("DCS_ISTFT_STAGE") ? atoi(getenv("DCS_ISTFT_STAGE")) : 1;   // 2: magnitudes only
+            const int spc = src_per_clip > 0 ? src_per_clip : n_src;
+            // measured (profiles/r03_e_istft_stage_sweep.txt): 4096 tiles 0.229 -> 0.198 ms, 2048 tiles 0.129 -> 0.113, but 1024
+            // tiles 0.063 -> 0.069 and 640 tiles 0.048 -> 0.052 -- with few hop-blocks per wave the chip's memory system is not
+            // loaded and the plain loads cost less than the LDS round trip: staged from 16 hop-blocks per wave on
+            static const int stage_min = getenv("DCS_ISTFT_STAGE_MIN") ? atoi(getenv("DCS_ISTFT_STAGE_MIN")) : 16;
+            const bool stage = stage_env && Cs >= stage_min && unit && ld == M + 4 && n_src % 4 == 0 && spc % 4 == 0 && (src_stride & 3) == 0 &&
+                               (unit_clip_stride & 1) == 0 &&
+                               ((reinterpret_cast<uintptr_t>(mag) | reinterpret_cast<uintptr_t>(unit)) & 15) == 0;
+            const size_t lds_stage = lds_s + (2 * (size_t)(M + 4)) * sizeof(float2) + 4 * (size_t)(M + 4) * sizeof(float);
+#define DCS_SEQ_STAGE(R__)                                                                                           \
+            {                                                                                                        \
+                auto kern = stage_env == 2 ? istft_seq_kernel<LOG2M, true, R__, 2> : istft_seq_kernel<LOG2M, true, R__, 1>; \
+                DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage));            \
+                hipLaunchKernelGGL(kern, grid_s, dim3(256), lds_stage, p->ctx->stream, mag, src_stride, phase, unit, ld, \
+                                   p->win_f, p->wsq_f, p->tw_f, audio, n_out, T, (int)Cs, n_blocks, n_chunks_s, n_src, \
+                                   pre_div, (float)sqrt((double)N), unit_clip_stride, spc, clip_tab,                 \
+                                   out_stride > 0 ? out_stride : n_out);                                             \
+            }
+            if (stage) {
+                if (R_ == 4) DCS_SEQ_STAGE(4) else DCS_SEQ_STAGE(2)
+                return DCS_OK;
+            }
+#undef DCS_SEQ_STAGE
 #define DCS_SEQ(UNIT_, R__)                                                                                          \
             {                                                                                                        \
                 auto kern = istft_seq_kernel<LOG2M, UNIT_, R__>;                                                     \

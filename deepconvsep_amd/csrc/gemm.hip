@@ -255,8 +255,20 @@ __global__ __launch_bounds__(kThreads) void gemm_ksplit_reduce_kernel(const DcsG
     const int64_t row = idx / g.n_cols;
     const int col = (int)(idx - row * g.n_cols);
     if (col >= g.n_store) return;
+    // eight slices requested at a time (the additions stay in slice order): one thread per output with one load in flight
+    // was a chain of ksplit memory latencies -- 14.6 us for 53 slices of 84 x 256
     float v = 0.f;
-    for (int z = 0; z < ksplit; ++z) v += g.partial[(int64_t)z * g.M * g.n_cols + idx];
+    const int64_t zs = g.M * (int64_t)g.n_cols;
+    const float* p = g.partial + idx;
+    int z = 0;
+    for (; z + 8 <= ksplit; z += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(z + u) * zs];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; z < ksplit; ++z) v += p[z * zs];
     v += g.bias ? g.bias[col] : 0.f;
     if (g.relu) v = fmaxf(v, 0.f);
     g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
