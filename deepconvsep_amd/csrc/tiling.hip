@@ -52,7 +52,9 @@ __global__ __launch_bounds__(kThreads) void overlap_add_kernel(const float* __re
         float acc = src[(k0 * tc + j0) * F + f];
         for (int64_t k = k0 + 1; k < n && k * st <= t; ++k) {
             const int j = (int)(t - k * st);
-            acc = rise[ov - 1 - j] * acc + rise[j] * src[(k * tc + j) * F + f];
+            // written out (a product rounded on its own, then one fused multiply-add) so that this kernel and mask_ola_kernel,
+            // which blends the same operands, round identically whatever the compiler would contract
+            acc = fmaf(rise[ov - 1 - j], acc, __fmul_rn(rise[j], src[(k * tc + j) * F + f]));
         }
         dst[f] = acc;
     }
