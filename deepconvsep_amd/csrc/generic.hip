@@ -1474,14 +1474,8 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     std::vector<float> bout(P[8 + 2 * d.n_fc]);
     UP(g->bout, bout)
 #undef UP
-    if (rc == DCS_OK) {   // the per-source dense weights once more as three bf16 planes, split on the device
-        auto pack = [&](const float* B, int rows, int cols, void** q) -> int {
-            DCS_HIP(hipMalloc(q, dcs_gemm_bq_bytes(rows, cols)));
-            return dcs_gemm_pack_bq(ctx, B, rows, cols, cols, *q);
-        };
-        for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) rc = pack(g->Bd[s], (int)dcs_round_up(g->hid64, 128), g->flat64, &g->Bdq[s]);
-        if (rc == DCS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = DCS_EHIP;
-    }
+    // (the per-source dense weights as three bf16 planes -- 1.5x their f32 size, a gigabyte for Bach10 -- are made by the
+    // first forward pass large enough to run on the bf16 matrix pipe: ensure_bdq)
     if (rc != DCS_OK) {
         dcs_generic_destroy(g);
         return rc;
@@ -1710,6 +1704,17 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     }
     // per-source dense (rectify): D[n][branch][flat_p]; aliased branches (none in these graphs) would reuse a layer
     if (g->flat_p != d.flat) DCS_HIP(hipMemsetAsync(D, 0, (size_t)n * NB * g->flat_p * 4, ctx->stream));
+    // the bf16 planes of the dense weights, on first need: a launch of >= 128 rows against >= 1024 columns (smaller ones stay
+    // on the f32 kernels whatever is packed, dcs_launch_gemm_bf16x3); same stream, so no synchronisation
+    static const bool bf16_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
+    if (bf16_on && n >= 128 && g->flat64 >= 1024) {
+        for (int s2 = 0; s2 < d.n_fc; ++s2) {
+            if (g->Bdq[s2]) continue;
+            const int rows = (int)dcs_round_up(g->hid64, 128);
+            DCS_HIP(hipMalloc(&g->Bdq[s2], dcs_gemm_bq_bytes(rows, g->flat64)));
+            DCS_CHECK(dcs_gemm_pack_bq(ctx, g->Bd[s2], rows, g->flat64, g->flat64, g->Bdq[s2]));
+        }
+    }
     bool branches_done = false;
     if (NB > 1) {                                        // every live branch in one launch when the shape allows it
         DcsGemm q{};
