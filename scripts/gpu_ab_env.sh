@@ -1,10 +1,10 @@
 #!/bin/bash
 # A/B of environment switches on the DSD bench shapes without legs / CLI / CPU baseline:
-#   DCS_AB_TESTS="-k stft" (pytest selection, empty = skip)   DCS_AB_VARIANTS="default NAME=VAL ..."
+#   DCS_AB_K="stft or istft" (pytest -k expression, empty = skip)   DCS_AB_VARIANTS="default NAME=VAL ..."
 set -u
 OUT=gpurun_out; mkdir -p $OUT
-if [ -n "${DCS_AB_TESTS:-}" ]; then
-  timeout 900 python -m pytest tests -m gpu -q -x --timeout=240 -p no:cacheprovider $DCS_AB_TESTS > $OUT/ab_pytest.log 2>&1; echo "pytest exit $?"; tail -n 6 $OUT/ab_pytest.log
+if [ -n "${DCS_AB_K:-}" ]; then
+  timeout 1200 python -m pytest tests -m gpu -q -x --timeout=240 -p no:cacheprovider -k "$DCS_AB_K" > $OUT/ab_pytest.log 2>&1; echo "pytest exit $?"; tail -n 6 $OUT/ab_pytest.log
 fi
 for v in ${DCS_AB_VARIANTS:-default}; do
   envs=""; [ "$v" != "default" ] && envs="$v"
