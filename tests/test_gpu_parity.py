@@ -846,6 +846,7 @@ from deepconvsep_amd.synth import synth_params
 z = np.load(sys.argv[2])
 N = int(z['N']); F = N // 2 + 1
 sep = dcs.Separator('dsd', synth_params('dsd', 30, F, seed=2), 0.3, 30, 25, 32, F, N, 512, np.hanning)
+sep.net.set_latency_stages(0)             # the throughput kernels these switches select among (a 3 s clip would take the one-batch family)
 for rep in range(3):                      # eager, graph capture, graph replay
     got = sep.separate(z['audio'])
 err = float(np.max(np.abs(got - z['want'])))
@@ -948,6 +949,8 @@ def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
     {"DCS_ISTFT_LEAN": "0", "DCS_ISTFT_SEQ": "0"},               # ring iSTFT with its twiddle / window tables in LDS
     {"DCS_ISTFT_SEQ": "0"}, {"DCS_ISTFT_SEQ_HOPS": "1"}, {"DCS_ISTFT_SEQ_HOPS": "37"},   # ring iSTFT; blocks per wave of the sequential one
     {"DCS_GRAPH": "0"},
+    {"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE_MIN": "1", "DCS_ISTFT_STAGE": "2"},   # spectra through LDS (long clips' iSTFT) on a short clip
+    {"DCS_ISTFT_STAGE": "0"},
 ])
 @pytest.mark.parametrize("N", [1024, 2048])
 def test_kernel_variants_selected_by_size_agree_with_the_oracle(env, N, tmp_path):
@@ -984,6 +987,45 @@ np.save(sys.argv[3], ctx.to_host(s_d))
 pcm = sep.separate(z['audio'])
 np.save(sys.argv[4], pcm)
 """
+
+
+_STAGED_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepconvsep_amd as dcs
+from deepconvsep_amd.synth import synth_audio, synth_params
+z = np.load(sys.argv[2])
+N = int(z['N']); F = N // 2 + 1
+sep = dcs.Separator('dsd', synth_params('dsd', 30, F, seed=2), 0.3, 30, 25, 32, F, N, 512, np.hanning)
+sep.net.set_latency_stages(0)
+clips = [z['a0'], z['a1'], z['a2'], z['a0'][:len(z['a0']) - 4111]]
+many = sep.separate_many(clips)                      # sorted by length, one ragged group: per-clip frame counts in one launch
+alone = [sep.separate(c) for c in clips]
+same = sep.ctx.to_host(sep.net.separate_batch(sep.plan, sep.ctx.to_device(np.stack([z['a1'], z['a1'][::-1].copy()]), np.float32), 25, sep.tiler, 0.3))
+e_many = max(float(np.max(np.abs(m - a))) for m, a in zip(many, alone))
+e_same = float(np.max(np.abs(same[0] - alone[1])))
+e_ref = float(np.max(np.abs(alone[2] - z['want2'])))
+print('ragged vs alone %.2e, batch vs alone %.2e, vs oracle %.2e' % (e_many, e_same, e_ref))
+sys.exit(0 if (e_many < 5e-6 and e_same < 5e-6 and e_ref < 1e-4) else 3)
+"""
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+@pytest.mark.parametrize("env", [{"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE": "0"}])
+def test_staged_istft_on_ragged_groups_and_batches(env, N, tmp_path):
+    """The LDS-staged inverse STFT (normally long clips only) forced onto short ones: a ragged group (per-clip frame counts
+    from the device table: the four waves of a workgroup must still walk the same frames), an equal-length batch and single
+    clips agree with each other, and a single clip with the oracle.  DCS_ISTFT_STAGE=0: the same with the plain loads."""
+    import subprocess
+    a = [synth_audio(int(44100 * sec) + odd, seed=60 + i) for i, (sec, odd) in enumerate(((1.9, 0), (1.5, 0), (1.7, 313)))]
+    want2 = pipeline.separate("dsd", synth_params("dsd", 30, N // 2 + 1, seed=2), a[2], 0.3, 30, 25, 32, N, 512, np.hanning)
+    f = tmp_path / "case.npz"
+    np.savez(f, a0=a[0], a1=a[1], a2=a[2], want2=want2, N=N)
+    child_env = dict(os.environ)
+    child_env.update(env)
+    r = subprocess.run([sys.executable, "-c", _STAGED_CHILD, ROOT, str(f)], env=child_env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, (env, N, r.stdout[-400:], r.stderr[-800:])
 
 
 @pytest.mark.parametrize("kind", ["glorot", "sparse", "tiny"])
