@@ -408,7 +408,11 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& 
     }
 }
 
-__global__ __launch_bounds__(kThreads, 2) void deconv2_stream_bf16_kernel(const float* __restrict__ D,
+// NW waves per workgroup share one copy of the group's weights (53 KB); a wave's own skew / output buffers are 6.4 KB.  NW = 4:
+// two workgroups per CU = 2 waves per SIMD; NW = 16: one workgroup per CU (152 KB) = 4 waves per SIMD -- the kernel has no
+// barrier after the weight copy, so the only price of the big workgroup is that copy's barrier.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void deconv2_stream_bf16_kernel(const float* __restrict__ D,
                                                                           const u32x4* __restrict__ Bq,
                                                                           u32x4* __restrict__ Gs, int64_t n_ks, int H2,
                                                                           int kh, int tc, int ngg, int n_full, int X,
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(kThreads, 2) void deconv2_stream_bf16_kernel(const 
     }
     {
         const u32x4* src = Bq + (int64_t)g * kD2GroupU4;
-        for (int i = tid; i < kD2GroupU4; i += kThreads) Bs[i] = src[i];
+        for (int i = tid; i < kD2GroupU4; i += 64 * NW) Bs[i] = src[i];
         for (int i = lane; i < kD2PsSize + 32 * GS; i += 64) Ps[i] = 0.f;
     }
     __syncthreads();
@@ -457,8 +461,8 @@ __global__ __launch_bounds__(kThreads, 2) void deconv2_stream_bf16_kernel(const 
         r_[2] = (in && kq < 3) ? *reinterpret_cast<const f32x4*>(dp + 32) : z;                          \
         r_[3] = (in && kq < 2) ? *reinterpret_cast<const f32x4*>(dp + 36) : z;                          \
     }
-    const int64_t kstep = (int64_t)nwx * 4;
-    int64_t ks = (int64_t)x * 4 + wave;
+    const int64_t kstep = (int64_t)nwx * NW;
+    int64_t ks = (int64_t)x * NW + wave;
     if (ks < n_ks) DCS_LOAD_D(ks, ra)
     if (ks + kstep < n_ks) DCS_LOAD_D(ks + kstep, rb)
     const u32x4* bl = Bs + fi * kD2TapU4 + kq;      // this lane's tap and K piece
@@ -539,16 +543,21 @@ int dcs_launch_dsd_deconv2_bf16(dcs_ctx* ctx, const float* D, const void* Bq, vo
         DCS_FAIL(DCS_EUNSUPPORTED, "bf16 deconv2: built for 50 conv2 filters and tc <= 32");
     const int ngg = (CI + kDsdGch - 1) / kDsdGch;
     const int n_full = CI / kDsdGch, tail_ch = CI - n_full * kDsdGch;
-    const int slots = 2 * ctx->n_cu;   // 2 workgroups per CU (77 KB of LDS each), one round
+    // waves per workgroup: 4; DCS_DECONV2_WAVES=16 (one workgroup per CU, 4 waves per SIMD) makes THIS kernel 10-13 % faster
+    // (4096 tiles 0.135 -> 0.122 ms, 1024 tiles 43.5 -> 37.9 us) and the final kernel behind it 4-8 % slower (304 -> 315,
+    // 79.8 -> 86.0 us), for no gain on the path (profiles/r03_g_deconv2_waves.txt): measured, not the default
+    static const int nw_env = getenv("DCS_DECONV2_WAVES") ? atoi(getenv("DCS_DECONV2_WAVES")) : 0;
+    const int nw = nw_env == 16 ? 16 : 4;
+    const int slots = (nw == 16 ? 1 : 2) * ctx->n_cu;   // workgroups resident at once (77 / 152 KB of LDS each), one round
     const double units = n_full + (tail_ch ? (double)((tail_ch + 1) / 2) / (kDsdGch / 2) : 0.0);
     int X = (int)(slots / units) / 8 * 8;
     if (X < 8) X = 8;
     int Xt = tail_ch ? slots - n_full * X : 0;
     if (tail_ch && Xt < 1) Xt = 1;
-    const size_t lds = (size_t)kD2GroupU4 * 16 + (size_t)4 * (kD2PsSize + 32 * kDsdGch) * sizeof(float);
-    auto kern = deconv2_stream_bf16_kernel;
+    const size_t lds = (size_t)kD2GroupU4 * 16 + (size_t)nw * (kD2PsSize + 32 * kDsdGch) * sizeof(float);
+    auto kern = nw == 16 ? deconv2_stream_bf16_kernel<16> : deconv2_stream_bf16_kernel<4>;
     DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_full * X + Xt)), dim3(kThreads), lds, ctx->stream, D,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_full * X + Xt)), dim3(64 * nw), lds, ctx->stream, D,
                        reinterpret_cast<const u32x4*>(Bq), reinterpret_cast<u32x4*>(Gs), n_ks, H2, kh, tc, ngg, n_full, X,
                        tail_ch, Xt);
     DCS_HIP(hipGetLastError());
