@@ -924,7 +924,7 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
             sub, pick = sub
         best = None
         for kname, rec in leg_traffic.items():
-            if sub and sub in kname:
+            if sub and kname.startswith(sub):          # a prefix, not a substring: 'deconv1_mfma_kernel' contains 'conv1_mfma_kernel'
                 b = traffic_bytes(rec)
                 if b and (best is None or (b > best[0] if pick == "max" else b < best[0])):
                     best = (b, kname)
