@@ -68,8 +68,9 @@ TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 # up the HBM traffic record of a leg's kernels in TRAFFIC_FILE["legs"][leg]
 LEG_KERNELS = {
     # (substring, 'max' | 'min'): conv2 and its transpose are the same kernel at two grids -- the transpose (2 branches) moves more
-    "ikala": {"conv1": "conv1_reg_kernel", "conv2": ("slabconv_ps_kernel", "min"), "deconv2": "slabconv_ps_kernel", "fc": "gemm_rows",
-              "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_reg_kernel"},
+    # (84 tiles: both dense layers run on gemm_rows_kernel -- the bottleneck K-split over 424 workgroups, the per-source layer 1890)
+    "ikala": {"conv1": "conv1_reg_kernel", "conv2": ("slabconv_ps_kernel", "min"), "deconv2": "slabconv_ps_kernel",
+              "fc": "gemm_rows_kernel@grid_threads=108544", "fc1x": "gemm_rows_kernel@grid_threads=483840", "final": "deconv1_reg_kernel"},
     "bach10_f16": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_wreg_scatter_kernel", "decoder": "colconv_deconv1_fused_kernel",
                    "fc": "gemm_rows", "fc1x": "gemm_bf16x3_skinny_kernel"},
     "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
