@@ -376,11 +376,15 @@ __host__ __device__ __forceinline__ int colconv_wslot(int u, int ci, int co) {
 
 constexpr int kColThreads = 512;
 
+// LDS layouts (round 3): a lane's eight K values of a tap (channels kq, kq + 4, ..., kq + 28) are TWO 16-byte reads for
+// each operand instead of eight 4-byte ones -- weights Wl[u][kq][half][co 32][4], slab[kq][row][half][x 16][4]: within a
+// (u / row, kq, half) the 16 lanes of a fragment read 256 contiguous bytes, and the kq planes are whole multiples of 256
+// bytes apart, so the reads are conflict-free for the lane groups a ds_read_b128 is served in.  6 LDS reads per tap and
+// wave instead of 24 (the f32 MFMAs wait for their operands: Bach10 f32 conv2^T 1.73 ms, 0.48 of the f32 MFMA peak before).
 __global__ __launch_bounds__(kColThreads) void colconv_kernel(const ColConvArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wl = smem;                         // [kh*32*32]
-    const int PS = g.H * 16 + ((g.H & 1) ? 0 : 16);  // plane stride = 16 (mod 32): K-quarters kq, kq+1 land 16 banks apart
-    float* slab = smem + g.kh * 1024;         // [32][PS]
+    float* Wl = smem;                         // [kh][4 kq][2][32 co][4]
+    float* slab = smem + g.kh * 1024;         // [4 kq][H][2][16 x][4]   (512 H floats; the launcher reserves 32 (16 H + 16))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, kq = lane >> 4;
@@ -390,10 +394,16 @@ __global__ __launch_bounds__(kColThreads) void colconv_kernel(const ColConvArgs 
     const float* in = g.in + img * g.in_n_stride;
     float* out = g.out + img * g.out_n_stride;
     const int HoW = g.Ho * g.W;
+    const int H = g.H;
 
-    for (int i = tid; i < g.kh * 256; i += kColThreads)
-        reinterpret_cast<f32x4*>(Wl)[i] = reinterpret_cast<const f32x4*>(g.Wk)[i];
-    for (int i = tid; i < (32 - g.Cin) * PS; i += kColThreads) slab[g.Cin * PS + i] = 0.f;   // unused K planes
+    // weights: global [u][ci][co swizzled] (colconv_wslot) -> fragment order
+    for (int i = tid; i < g.kh * 1024; i += kColThreads) {
+        const int u = i >> 10, ci = (i >> 5) & 31, slot = i & 31;
+        const int co = (slot - 16 * (ci & 1)) & 31;
+        const int kk = ci >> 2;
+        Wl[((((u * 4 + (ci & 3)) * 2 + (kk >> 2)) * 32 + co) << 2) + (kk & 3)] = g.Wk[i];
+    }
+    for (int i = tid; i < 512 * H; i += kColThreads) slab[i] = 0.f;   // channels >= Cin stay zero
     const float bias_lo[4] = {g.bias[4 * kq], g.bias[4 * kq + 1], g.bias[4 * kq + 2], g.bias[4 * kq + 3]};
     const float bias_hi[4] = {g.bias[16 + 4 * kq], g.bias[17 + 4 * kq], g.bias[18 + 4 * kq], g.bias[19 + 4 * kq]};
 
@@ -401,14 +411,14 @@ __global__ __launch_bounds__(kColThreads) void colconv_kernel(const ColConvArgs 
     // elements are fetched into registers while the current one is multiplied (one workgroup per CU: nothing else
     // would hide the loads)
     constexpr int kPre = 32;
-    const int n_el = g.Cin * g.H * 16;
+    const int n_el = g.Cin * H * 16;
     int soff[kPre];
     float pre[kPre];
 #pragma unroll
     for (int i = 0; i < kPre; ++i) {
         const int e = tid + i * kColThreads;
-        const int cr = e >> 4, ci = cr / g.H;
-        soff[i] = e < n_el ? ci * PS + (cr - ci * g.H) * 16 + (e & 15) : -1;
+        const int cr = e >> 4, ci = cr / H, r = cr - ci * H, kk = ci >> 2;
+        soff[i] = e < n_el ? (((((ci & 3) * H + r) * 2 + (kk >> 2)) * 16 + (e & 15)) << 2) + (kk & 3) : -1;
     }
 #define DCS_COL_FETCH(x0_)                                                                               \
     _Pragma("unroll") for (int i = 0; i < kPre; ++i) {                                                   \
@@ -417,6 +427,8 @@ __global__ __launch_bounds__(kColThreads) void colconv_kernel(const ColConvArgs 
     }
     const int xb_end = xb0 + g.xb_per_wg < g.n_xb ? xb0 + g.xb_per_wg : g.n_xb;
     if (xb0 < xb_end) DCS_COL_FETCH(xb0 * 16)
+    const f32x4* sl4 = reinterpret_cast<const f32x4*>(slab) + kq * H * 32 + fi;      // + (row * 2 + half) * 16
+    const f32x4* wl4 = reinterpret_cast<const f32x4*>(Wl) + kq * 64 + fi;            // + u * 256 + half * 32 (+ 16: co + 16)
     for (int xb = xb0; xb < xb_end; ++xb) {
         const int x0 = xb * 16;
         __syncthreads();                      // previous slab fully read (and, first time, the weights staged)
@@ -426,20 +438,24 @@ __global__ __launch_bounds__(kColThreads) void colconv_kernel(const ColConvArgs 
         __syncthreads();
         if (xb + 1 < xb_end) DCS_COL_FETCH((xb + 1) * 16)
         for (int y = wave; y < g.Ho; y += kColThreads / 64) {
-            int u_lo = g.ph - y, u_hi = g.ph - y + g.H - 1;            // 0 <= y + u - ph < H
+            int u_lo = g.ph - y, u_hi = g.ph - y + H - 1;            // 0 <= y + u - ph < H
             if (u_lo < 0) u_lo = 0;
             if (u_hi > g.kh - 1) u_hi = g.kh - 1;
             f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int u = u_lo; u <= u_hi; ++u) {
-                const float* sp = slab + kq * PS + (y + u - g.ph) * 16 + fi;
-                const float* wp = Wl + (u * 32 + kq) * 32;
-                const int c0 = (fi + 16 * (kq & 1)) & 31, c1 = (fi + 16 + 16 * (kq & 1)) & 31;
+                const f32x4* sp = sl4 + (y + u - g.ph) * 32;
+                const f32x4* wp = wl4 + u * 256;
+                const f32x4 b0 = sp[0], b1 = sp[16];
+                const f32x4 a00 = wp[0], a01 = wp[32], a10 = wp[16], a11 = wp[48];
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const float b = sp[4 * kk * PS];
-                    const float a0 = wp[4 * kk * 32 + c0], a1 = wp[4 * kk * 32 + c1];
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a00[kk], b0[kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[kk], b0[kk], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[kk], b1[kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[kk], b1[kk], acc1, 0, 0, 0);
                 }
             }
             if (x0 + fi < g.W) {
