@@ -80,7 +80,7 @@ LEG_KERNELS = {
 }
 # kernels that execute on the 16-bit matrix pipe: (products issued per f32 product, K padding factor)
 LEG_ISSUED = {
-    "ikala": {"conv2": (6, 32.0 / 30.0), "deconv2": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
+    "ikala": {"conv2": (6, 32.0 / 30.0), "deconv2": (6, 32.0 / 30.0)},   # 84 tiles: the dense layers stay on the f32 MFMA (M < 128)
     "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc1x": (6, 1.0)},
     "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
     "bach10_f32": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
