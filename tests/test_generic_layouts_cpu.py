@@ -1,0 +1,139 @@
+"""CPU checks of index arithmetic in csrc/generic.hip (round 3; the second test covers the column convolution's LDS layouts).
+The iKala graph's fused max-pool: conv1_reg_kernel<30, 3, true>
+leaves, instead of the full-resolution activations, 4 routing bits per pooling window -- a wave's 64-bit ballot of "this
+position equals its window's maximum" is stored as two 32-bit words, 8 windows per word -- and deconv1_reg_kernel<3, 10, true>
+rebuilds the 13 un-pooled inputs of a thread (positions 4 qb - 9 .. 4 qb + 3) from 4 pooled gradients and 16 of those bits.
+The kernels' arithmetic is restated lane by lane in NumPy and compared with the plain un-pooling VJP (position f receives
+g[f // 4] when a[f] equals its window maximum: every such position, or only the first).  No GPU."""
+import numpy as np
+import pytest
+
+PW, NT, QB = 4, 10, 4          # pool width; taps per residue of the stride-3 conv1^T; q values per thread
+
+
+def _routing_words(a, w1, wp, mw, tie_first):
+    """conv1_reg_kernel<., ., true>: positions j = 64 wave + lane; quad maximum; ballot; nibble-wise first bit; two words per wave."""
+    words = np.zeros(mw, dtype=np.uint64)
+    for wave in range((w1 + 63) // 64):
+        b = 0
+        for lane in range(64):
+            j = 64 * wave + lane
+            if j >= w1:
+                continue                                   # the lane returned early: contributes 0 to the ballot
+            q0 = j & ~3
+            win = [a[q] for q in range(q0, q0 + 4) if q < w1]       # an incomplete border window: only its active lanes
+            if a[j] == max(win):
+                b |= 1 << lane
+        if tie_first:
+            E, C, S8 = 0xEEEEEEEEEEEEEEEE, 0xCCCCCCCCCCCCCCCC, 0x8888888888888888
+            b &= ~(((b << 1) & E) | ((b << 2) & C) | ((b << 3) & S8)) & 0xFFFFFFFFFFFFFFFF
+        if 64 * wave < w1:                                 # lane 0 active
+            words[2 * wave] = b & 0xFFFFFFFF
+        if 64 * wave + 32 < w1:                            # lane 32 active
+            words[2 * wave + 1] = b >> 32
+    return words
+
+
+def _thread_inputs(gp, words, wp, qb):
+    """deconv1_reg_kernel<3, 10, true>: the 13 inputs of thread qb from 4 pooled values and 16 routing bits."""
+    k = qb - (NT + 2) // 4
+    gv = np.zeros(4)
+    bits = 0
+    if k >= 0 and k + 3 < wp:                              # interior: one 16-byte and one 8-byte load
+        gv[:] = gp[k:k + 4]
+        w64 = int(words[k >> 3]) | (int(words[(k >> 3) + 1]) << 32 if (k >> 3) + 1 < len(words) else 0)
+        bits = (w64 >> (4 * (k & 7))) & 0xFFFF
+    else:
+        for i in range(4):
+            w = k + i
+            if 0 <= w < wp:
+                gv[i] = gp[w]
+                bits |= ((int(words[w >> 3]) >> (4 * (w & 7))) & 15) << (4 * i)
+    return np.array([gv[(x + 3) >> 2] if (bits >> (x + 3)) & 1 else 0.0 for x in range(QB + NT - 1)])
+
+
+@pytest.mark.parametrize("tie_first", [False, True])
+@pytest.mark.parametrize("w1", [81, 92, 162, 332, 64, 65])
+def test_routing_bits_rebuild_the_unpooled_gradient(w1, tie_first):
+    rng = np.random.RandomState(w1 + 7 * tie_first)
+    wp, mw = w1 // PW, ((w1 + 63) // 64) * 2
+    a = rng.randn(w1)
+    a[8:16] = 0.25                                          # two windows of exact ties
+    a[21] = a[22]                                           # a tie inside a window
+    if w1 > 70:
+        a[64:68] = -1.0                                     # a tied window at a wave boundary
+    gp = rng.randn(wp)
+    # the plain VJP of the pool at a
+    want = np.zeros(w1)
+    for w in range(wp):
+        win = a[4 * w:4 * w + 4]
+        hits = np.flatnonzero(win == win.max())
+        if tie_first:
+            hits = hits[:1]
+        want[4 * w + hits] = gp[w]
+    words = _routing_words(a, w1, wp, mw, tie_first)
+    nqb = (3 * (w1 - 1) + 30 + 11) // 12                    # threads per row: F = 3 (w1 - 1) + 30 bins, 12 per thread
+    for qb in range(nqb + 1):
+        got = _thread_inputs(gp, words, wp, qb)
+        j0 = 4 * qb - (NT - 1)
+        for x in range(QB + NT - 1):
+            j = j0 + x
+            ref = want[j] if 0 <= j < w1 else 0.0
+            assert got[x] == ref, (w1, tie_first, qb, x, j)
+
+
+def test_column_convolution_fragment_layouts():
+    """colconv_kernel (csrc/generic.hip, round 3): the weights go from the global order [u][ci][co swizzled] (colconv_wslot) to
+    LDS as Wl[u][kq][half][co 32][4] and the input slab as slab[kq][row][half][x 16][4], so that lane (fi, kq) reads its
+    eight K values of a tap -- channels kq, kq + 4, ..., kq + 28 -- as two 16-byte pieces per operand.  The index arithmetic
+    of the copy loops and of the fragment reads, lane by lane with v_mfma_f32_16x16x4_f32 semantics (A[i = lane & 15][k =
+    lane >> 4], B[k][j = lane & 15], D[4 (lane >> 4) + e][lane & 15]), against the direct 'full' correlation."""
+    rng = np.random.RandomState(11)
+    kh, H, Cin, Cout, W = 20, 11, 30, 30, 16
+    ph, Ho = kh - 1, H + kh - 1
+    Wk = rng.randn(kh, 32, 32)
+    Wk[:, Cin:, :] = 0.0
+    Wk[:, :, Cout:] = 0.0
+    x = rng.randn(Cin, H, W)
+    # global weight order of the model: slot (u, ci, co) -> (u * 32 + ci) * 32 + ((co + 16 (ci & 1)) & 31)
+    Wg = np.zeros(kh * 1024)
+    for u in range(kh):
+        for ci in range(32):
+            for co in range(32):
+                Wg[(u * 32 + ci) * 32 + ((co + 16 * (ci & 1)) & 31)] = Wk[u, ci, co]
+    # the kernel's copy into LDS
+    Wl = np.zeros(kh * 1024)
+    for i in range(kh * 1024):
+        u, ci, slot = i >> 10, (i >> 5) & 31, i & 31
+        co = (slot - 16 * (ci & 1)) & 31
+        kk = ci >> 2
+        Wl[((((u * 4 + (ci & 3)) * 2 + (kk >> 2)) * 32 + co) << 2) + (kk & 3)] = Wg[i]
+    slab = np.zeros(512 * H)
+    for ci in range(Cin):
+        for r in range(H):
+            for xx in range(16):
+                kk = ci >> 2
+                slab[((((ci & 3) * H + r) * 2 + (kk >> 2)) * 16 + xx) * 4 + (kk & 3)] = x[ci, r, xx]
+    Wl4, sl4 = Wl.reshape(-1, 4), slab.reshape(-1, 4)
+    lanes = np.arange(64)
+    fi, kq = lanes & 15, lanes >> 4
+    for y in (0, 5, 10, 19, 29):
+        u_lo, u_hi = max(0, ph - y), min(kh - 1, ph - y + H - 1)
+        acc = np.zeros((2, 16, 16))                       # [co block][co in block][x]
+        for u in range(u_lo, u_hi + 1):
+            row = y + u - ph
+            for half in range(2):
+                b = sl4[kq * H * 32 + fi + row * 32 + half * 16]               # [lane][4]
+                for blk in range(2):
+                    a = Wl4[kq * 64 + fi + u * 256 + half * 32 + blk * 16]     # [lane][4]
+                    for j in range(4):
+                        A = np.zeros((16, 4)); B = np.zeros((4, 16))
+                        A[fi, kq] = a[:, j]
+                        B[kq, fi] = b[:, j]
+                        acc[blk] += A @ B
+        want = np.zeros((32, 16))
+        for u in range(kh):
+            row = y + u - ph
+            if 0 <= row < H:
+                want += Wk[u, :Cin, :].T @ x[:, row, :]
+        np.testing.assert_allclose(acc.reshape(32, 16), want, rtol=0, atol=1e-11)
