@@ -89,10 +89,24 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFinalArgs a, int n_colg) {
+#ifndef DCS_FINAL_WGS_PER_CU
+#define DCS_FINAL_WGS_PER_CU 2       // workgroups per CU = waves per SIMD the register budget of the staged form is sized for
+#endif
+// DIRECT (round 4, the default; DCS_FINAL_DIRECT=0 selects the register-staged form): the A set of a covering tile goes
+// from HBM straight into LDS (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l, scripts/ubench/lds_async.hip)
+// in PIECE-major order -- unit (sp, i) = piece column sp = branch * 21 + plane * 7 + group of row i at sp * 16 + i:
+//   * no prefetch registers (16) and no LDS destination registers (4): 168 registers = THREE workgroups per CU (the staged
+//     form needs 188 and spills 21 when sized for three);
+//   * no ds_write of the staged pieces, no second pass over them in registers;
+//   * an MFMA A fragment (row fi, K piece kq) of (branch, plane, K block 0) is unit (..)*16 + 16 kq + fi = a constant + the
+//     LANE index: every ds_read_b128 of the kernel reads 1 KB of consecutive LDS -- conflict-free by construction (the
+//     staged form's row stride of 25 units measured an LDS bank-conflict ratio of 1.53);
+//   * K channels 56..63 (K block 1, kq = 3) do not exist in G: their B rows are zero (Bpk, net.hip), so those lanes read
+//     K piece 3 of the SAME row again -- finite numbers times zero -- and no LDS is zero-filled.
+template <int MODE, bool DIRECT>
+__global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void final_bf16x3_kernel(const DsdFinalArgs a, int n_colg) {
     constexpr int CBW = 2, NBR = 3;
-    constexpr int kABuf = NBR * 16 * kRowLds;
+    constexpr int kABuf = DIRECT ? 1024 : NBR * 16 * kRowLds;
     constexpr int kMaxM = 16;
     __shared__ u32x4 As[2 * kABuf];
     __shared__ __attribute__((aligned(16))) float up_t[kMaxM * 16];
@@ -238,11 +252,24 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
         dst[u] = (s * 16 + i) * kRowLds + plane * kPlaneLds + g;
         goff[u] = (((dk * NBR + s) * kNgg + g) * tc + j0) * 3 + plane;
     }
-    for (int idx = tid; idx < 2 * NBR * 16 * 3; idx += kThreads) {   // K channels 56..63: zero in both buffers
-        const int buf = idx / (NBR * 16 * 3), r = idx - buf * (NBR * 16 * 3);
-        As[buf * kABuf + (r / 3) * kRowLds + (r % 3) * kPlaneLds + 7] = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (!DIRECT) {
+        for (int idx = tid; idx < 2 * NBR * 16 * 3; idx += kThreads) {   // K channels 56..63: zero in both buffers
+            const int buf = idx / (NBR * 16 * 3), r = idx - buf * (NBR * 16 * 3);
+            As[buf * kABuf + (r / 3) * kRowLds + (r % 3) * kPlaneLds + 7] = u32x4{0u, 0u, 0u, 0u};
+        }
     }
-    u32x4 pre[NSL];
+    u32x4 pre[DIRECT ? 1 : NSL];
+    // DIRECT: slot idx = tid + 256 u IS LDS unit idx (row fastest, then the piece column): wave w's transfer u covers units
+    // 256 u + 64 w .. + 63, a wave-uniform LDS base
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define DCS_LOAD_A_DIRECT(m_, buf_)                                                             \
+    _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
+        if ((u + 1) * kThreads <= slots || in_slot[u]) {                                        \
+            const int mm = (m_) < mlim[u] ? (m_) : mlim[u];                                     \
+            __builtin_amdgcn_global_load_lds(gbase + (goff[u] + mm * m_delta),                  \
+                                             As + ((buf_) * kABuf + u * kThreads + wave_u * 64), 16, 0, 0); \
+        }                                                                                       \
+    }
 #define DCS_LOAD_A(m_, dst_)                                                                    \
     _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
         u32x4 v = u32x4{0u, 0u, 0u, 0u};                                                        \
@@ -259,11 +286,26 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 
     // the A set of covering tile m + 1 is requested while tile m is multiplied (requesting it two tiles ahead costs 20
     // more registers and measured slower: 0.360 vs 0.346 ms at 4096 tiles)
-    DCS_LOAD_A(0, pre)
+    // DIRECT fragment bases: K block 0 -> unit lane (= 16 kq + fi), K block 1 -> group 4 + kq, or group 3 again for kq = 3
+    const u32x4* Ad0 = As + lane;
+    const u32x4* Ad1 = As + (kq < 3 ? lane + 64 : lane);
+    if constexpr (DIRECT) {
+        DCS_LOAD_A_DIRECT(0, 0)
+    } else {
+        DCS_LOAD_A(0, pre)
+    }
     for (int m = 0; m < mmax; ++m) {
-        DCS_STORE_A(m & 1)
-        __syncthreads();
-        if (m + 1 < mmax) DCS_LOAD_A(m + 1, pre)
+        if constexpr (DIRECT) {
+            // tile m's transfers (issued one compute phase ago) have landed -- here, and behind the barrier in the other
+            // waves; the barrier also says that everybody is done with tile m - 1, whose buffer tile m + 1 now overwrites
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (m + 1 < mmax) DCS_LOAD_A_DIRECT(m + 1, (m + 1) & 1)
+        } else {
+            DCS_STORE_A(m & 1)
+            __syncthreads();
+            if (m + 1 < mmax) DCS_LOAD_A(m + 1, pre)
+        }
         if (!live) continue;
         const u32x4* Ab = As + (m & 1) * kABuf + fi * kRowLds + kq;
         f32x4 acc[NBR][CBW];
@@ -279,7 +321,12 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) af[p][kb] = Ab[s * 16 * kRowLds + p * kPlaneLds + kb * 4];
+                for (int kb = 0; kb < 2; ++kb) {
+                    if constexpr (DIRECT)
+                        af[p][kb] = (kb ? Ad1 : Ad0)[(m & 1) * kABuf + (s * 3 * kNgg + p * kNgg) * 16];
+                    else
+                        af[p][kb] = Ab[s * 16 * kRowLds + p * kPlaneLds + kb * 4];
+                }
             // smallest terms first; the two column blocks alternate so that no MFMA waits for the one before it
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -338,6 +385,7 @@ __global__ __launch_bounds__(kThreads, 2) void final_bf16x3_kernel(const DsdFina
     }
 #undef DCS_LOAD_A
 #undef DCS_STORE_A
+#undef DCS_LOAD_A_DIRECT
 
     // per source a workgroup-uniform base (scalar registers) plus one 32-bit lane offset per row
     float* out0 = a.out + clip * a.out_clip_stride + (int64_t)row0 * a.out_ld;
@@ -575,10 +623,16 @@ int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_item
 }
 
 int dcs_launch_dsd_final_bf16x3(dcs_ctx* ctx, const DsdFinalArgs& a, int n_colg, int64_t n_wg, unsigned n_clips) {
-    if (a.mask_mode == 0)
-        hipLaunchKernelGGL((final_bf16x3_kernel<0>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0, ctx->stream, a, n_colg);
-    else
-        hipLaunchKernelGGL((final_bf16x3_kernel<1>), dim3((unsigned)n_wg, n_clips), dim3(kThreads), 0, ctx->stream, a, n_colg);
+    // DCS_FINAL_DIRECT=0: the register-staged form (two workgroups per CU)
+    static const bool direct = !(getenv("DCS_FINAL_DIRECT") && atoi(getenv("DCS_FINAL_DIRECT")) == 0);
+    const dim3 grid((unsigned)n_wg, n_clips), block(kThreads);
+    if (direct) {
+        if (a.mask_mode == 0) hipLaunchKernelGGL((final_bf16x3_kernel<0, true>), grid, block, 0, ctx->stream, a, n_colg);
+        else hipLaunchKernelGGL((final_bf16x3_kernel<1, true>), grid, block, 0, ctx->stream, a, n_colg);
+    } else {
+        if (a.mask_mode == 0) hipLaunchKernelGGL((final_bf16x3_kernel<0, false>), grid, block, 0, ctx->stream, a, n_colg);
+        else hipLaunchKernelGGL((final_bf16x3_kernel<1, false>), grid, block, 0, ctx->stream, a, n_colg);
+    }
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }
