@@ -57,6 +57,19 @@ struct DcsDeviceGuard {
     if (dcs_guard__.err != hipSuccess)                                                              \
         DCS_FAIL(DCS_EHIP, "cannot select device %d: %s", (int)(dev_), hipGetErrorString(dcs_guard__.err))
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the CURRENT device's function object: a launcher that wants to
+// pay for it once (the one-batch kernels: the host call is on the latency path) must remember it per device, thread-safely.
+// `static DcsOncePerDevice once; if (once.first(ctx->device)) { set the attributes }` -- a second thread that loses the race sets
+// them again, which is harmless.
+struct DcsOncePerDevice {
+    unsigned long long mask = 0;   // devices 0..63; higher ordinals always report `first`
+    bool first(int device) {
+        if (device < 0 || device >= 64) return true;
+        const unsigned long long bit = 1ull << device;
+        return (__atomic_fetch_or(&mask, bit, __ATOMIC_ACQ_REL) & bit) == 0;
+    }
+};
+
 // A grow-only device scratch buffer.  Regions handed out keep their address until the
 // buffer has to grow (then `generation` changes and zero-initialised regions are re-zeroed).
 struct DcsBuffer {

@@ -85,6 +85,10 @@ __device__ __forceinline__ f32x2 max2(f32x2 x, float lo) {
     return __builtin_bit_cast(f32x2, r);
 }
 
+// 16 bytes per lane from global memory straight into LDS (lane l lands at lds + 16 l; lds is wave-uniform).  A __device__
+// function of its own: called from a __global__ template the builtin silently suppresses the HOST stub of the kernel.
+__device__ __forceinline__ void lds_dma16(const u32x4* src, u32x4* lds) { __builtin_amdgcn_global_load_lds(src, lds, 16, 0, 0); }
+
 __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -108,7 +112,11 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
     constexpr int CBW = 2, NBR = 3;
     constexpr int kABuf = DIRECT ? 1024 : NBR * 16 * kRowLds;
     constexpr int kMaxM = 16;
-    __shared__ u32x4 As[2 * kABuf];
+    // DIRECT: the two buffers are two ARRAYS and the loop over the covering tiles is unrolled by two, so that the compiler
+    // sees transfers into one array and fragment reads from the other -- with one array and a buffer index it must assume
+    // that an LDS read may alias a transfer in flight and waits for vmcnt(0) in front of the first ds_read of every tile
+    __shared__ u32x4 As[DIRECT ? kABuf : 2 * kABuf];
+    __shared__ u32x4 As1[DIRECT ? kABuf : 1];
     __shared__ __attribute__((aligned(16))) float up_t[kMaxM * 16];
     __shared__ __attribute__((aligned(16))) float down_t[kMaxM * 16];
     __shared__ int meta_k0[16];
@@ -266,8 +274,7 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
     _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
         if ((u + 1) * kThreads <= slots || in_slot[u]) {                                        \
             const int mm = (m_) < mlim[u] ? (m_) : mlim[u];                                     \
-            __builtin_amdgcn_global_load_lds(gbase + (goff[u] + mm * m_delta),                  \
-                                             As + ((buf_) * kABuf + u * kThreads + wave_u * 64), 16, 0, 0); \
+            lds_dma16(gbase + (goff[u] + mm * m_delta), (buf_) + (u * kThreads + wave_u * 64)); \
         }                                                                                       \
     }
 #define DCS_LOAD_A(m_, dst_)                                                                    \
@@ -284,30 +291,10 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
         if ((u + 1) * kThreads <= slots || in_slot[u]) As[(buf_) * kABuf + dst[u]] = pre[u];    \
     }
 
-    // the A set of covering tile m + 1 is requested while tile m is multiplied (requesting it two tiles ahead costs 20
-    // more registers and measured slower: 0.360 vs 0.346 ms at 4096 tiles)
     // DIRECT fragment bases: K block 0 -> unit lane (= 16 kq + fi), K block 1 -> group 4 + kq, or group 3 again for kq = 3
-    const u32x4* Ad0 = As + lane;
-    const u32x4* Ad1 = As + (kq < 3 ? lane + 64 : lane);
-    if constexpr (DIRECT) {
-        DCS_LOAD_A_DIRECT(0, 0)
-    } else {
-        DCS_LOAD_A(0, pre)
-    }
-    for (int m = 0; m < mmax; ++m) {
-        if constexpr (DIRECT) {
-            // tile m's transfers (issued one compute phase ago) have landed -- here, and behind the barrier in the other
-            // waves; the barrier also says that everybody is done with tile m - 1, whose buffer tile m + 1 now overwrites
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (m + 1 < mmax) DCS_LOAD_A_DIRECT(m + 1, (m + 1) & 1)
-        } else {
-            DCS_STORE_A(m & 1)
-            __syncthreads();
-            if (m + 1 < mmax) DCS_LOAD_A(m + 1, pre)
-        }
-        if (!live) continue;
-        const u32x4* Ab = As + (m & 1) * kABuf + fi * kRowLds + kq;
+    const int lane1 = kq < 3 ? lane + 64 : lane;
+    // one covering tile: fragments from a0 (K block 0) / a1 (K block 1), 72 MFMAs, mask + fold in registers
+    auto compute = [&](const int m, const u32x4* a0, const u32x4* a1) {
         f32x4 acc[NBR][CBW];
 #pragma unroll
         for (int cb = 0; cb < CBW; ++cb) {
@@ -323,9 +310,9 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     if constexpr (DIRECT)
-                        af[p][kb] = (kb ? Ad1 : Ad0)[(m & 1) * kABuf + (s * 3 * kNgg + p * kNgg) * 16];
+                        af[p][kb] = (kb ? a1 : a0)[(s * 3 * kNgg + p * kNgg) * 16];
                     else
-                        af[p][kb] = Ab[s * 16 * kRowLds + p * kPlaneLds + kb * 4];
+                        af[p][kb] = a0[s * 16 * kRowLds + p * kPlaneLds + kb * 4];
                 }
             // smallest terms first; the two column blocks alternate so that no MFMA waits for the one before it
 #pragma unroll
@@ -381,6 +368,32 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
                 res[cb][2][2 * h] = o2[0]; res[cb][2][2 * h + 1] = o2[1];
                 res[cb][3][2 * h] = o3[0]; res[cb][3][2 * h + 1] = o3[1];
             }
+        }
+    };
+    // the A set of covering tile m + 1 is requested while tile m is multiplied (requesting it two tiles ahead costs 20
+    // more registers and measured slower: 0.360 vs 0.346 ms at 4096 tiles)
+    if constexpr (DIRECT) {
+        DCS_LOAD_A_DIRECT(0, As)
+        for (int m = 0; m < mmax; m += 2) {
+            // tile m's transfers (issued one compute phase ago) have landed -- here, and behind the barrier in the other
+            // waves; the barrier also says that everybody is done with tile m - 1, whose buffer tile m + 1 now overwrites
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (m + 1 < mmax) DCS_LOAD_A_DIRECT(m + 1, As1)
+            if (live) compute(m, As + lane, As + lane1);
+            if (m + 1 >= mmax) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (m + 2 < mmax) DCS_LOAD_A_DIRECT(m + 2, As)
+            if (live) compute(m + 1, As1 + lane, As1 + lane1);
+        }
+    } else {
+        DCS_LOAD_A(0, pre)
+        for (int m = 0; m < mmax; ++m) {
+            DCS_STORE_A(m & 1)
+            __syncthreads();
+            if (m + 1 < mmax) DCS_LOAD_A(m + 1, pre)
+            if (live) compute(m, As + (m & 1) * kABuf + fi * kRowLds + kq, nullptr);
         }
     }
 #undef DCS_LOAD_A
@@ -591,11 +604,13 @@ int dcs_launch_dsd_deconv2_bf16(dcs_ctx* ctx, const float* D, const void* Bq, vo
         DCS_FAIL(DCS_EUNSUPPORTED, "bf16 deconv2: built for 50 conv2 filters and tc <= 32");
     const int ngg = (CI + kDsdGch - 1) / kDsdGch;
     const int n_full = CI / kDsdGch, tail_ch = CI - n_full * kDsdGch;
-    // waves per workgroup: 4; DCS_DECONV2_WAVES=16 (one workgroup per CU, 4 waves per SIMD) makes THIS kernel 10-13 % faster
-    // (4096 tiles 0.135 -> 0.122 ms, 1024 tiles 43.5 -> 37.9 us) and the final kernel behind it 4-8 % slower (304 -> 315,
-    // 79.8 -> 86.0 us), for no gain on the path (profiles/r03_g_deconv2_waves.txt): measured, not the default
+    // waves per workgroup: 16 (one workgroup per CU, 4 waves per SIMD) from 1024 (tile, branch) items on, else 4 (two
+    // workgroups per CU).  Round 3 measured the big workgroup 10-13 % faster for THIS kernel but the register-staged final
+    // kernel behind it 4-8 % slower, a wash; with the direct-to-LDS final kernel of round 4 the step gains: 20 x 32 tiles
+    // deconv2 33.2 -> 29.6 us with the final kernel unchanged (63.1 / 63.3), 4096 tiles 0.8526 -> 0.8449 ms per clip
+    // (profiles/r04_b_*).  DCS_DECONV2_WAVES=4 | 16 forces one.
     static const int nw_env = getenv("DCS_DECONV2_WAVES") ? atoi(getenv("DCS_DECONV2_WAVES")) : 0;
-    const int nw = nw_env == 16 ? 16 : 4;
+    const int nw = nw_env == 16 ? 16 : (nw_env == 4 ? 4 : (n_ks >= 1024 ? 16 : 4));
     const int slots = (nw == 16 ? 1 : 2) * ctx->n_cu;   // workgroups resident at once (77 / 152 KB of LDS each), one round
     const double units = n_full + (tail_ch ? (double)((tail_ch + 1) / 2) / (kDsdGch / 2) : 0.0);
     int X = (int)(slots / units) / 8 * 8;

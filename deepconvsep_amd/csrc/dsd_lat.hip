@@ -566,7 +566,9 @@ __device__ __forceinline__ void granule_store(u64* g, unsigned tag, float v) {
 }
 // re-reads this thread's granules idx = first + 256 u (clamped to count - 1: every load is issued, none sits behind a
 // branch -- with one exec-masked branch and one wait per granule a sweep was NU serial round trips) until all carry `tag`;
-// false on give-up (state[2] is set)
+// false on give-up: state[2] is set AND every value of the sweep is returned as NaN, so a timed-out exchange (a cluster
+// that was pre-empted, only partially resident, stopped by a debugger) poisons this tile's G, the separated spectrogram
+// and the PCM -- the caller sees NaNs, never stale granules that look like audio (round-3 advisor finding)
 template <int NU>
 __device__ __forceinline__ bool granule_sweep(const u64* g, int first, int count, unsigned tag, float (&v)[NU], unsigned* state) {
     const u64* p[NU];
@@ -588,6 +590,8 @@ __device__ __forceinline__ bool granule_sweep(const u64* g, int first, int count
         if (ok) return true;
         if (spins > kMidSpinLimit) {
             __hip_atomic_store(state + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) v[u] = __uint_as_float(0x7fc00000u);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -1312,7 +1316,7 @@ void dcs_lat_pack_deconv2(const float* Bw2s, int n_ci8, std::vector<float>* out)
 }
 
 // experiment builds only (-DDCS_LAT_TRACE): the stamps of the last launches, [kernel][64] shader-clock values
-extern "C" int lat_trace_dump(unsigned long long* out, int n) {
+extern "C" DCS_API int lat_trace_dump(unsigned long long* out, int n) {
 #ifdef DCS_LAT_TRACE
     if (!out || n < 16 * 64) return -1;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(lat_trace_buf), 16 * 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
@@ -1386,6 +1390,9 @@ int dcs_lat_mid_state_init(void* state_d, int max_tiles) {   // once per model: 
 }
 int dcs_launch_lat_mid(dcs_ctx* ctx, const DcsLatMidArgs& h) {
     if (h.n_tiles <= 0) return DCS_OK;
+    // 32 clusters of 8 workgroups, one workgroup per CU, must all be resident: a device (or partition) with fewer CUs
+    // would leave clusters waiting for members that cannot start
+    if (ctx->n_cu < 256) DCS_FAIL(DCS_EUNSUPPORTED, "lat_mid: the cluster launch needs 256 CUs, this device has %d", ctx->n_cu);
     DcsLatMid a{};
     a.H1 = h.H1; a.W2p = h.W2p; a.bias2 = h.bias2; a.Wfc = h.Wfc; a.biasfc = h.biasfc; a.Wd = h.Wd; a.biasd = h.biasd;
     a.Wdc = h.Wdc; a.state = reinterpret_cast<unsigned*>(h.state);
@@ -1430,11 +1437,10 @@ int dcs_launch_lat_final(dcs_ctx* ctx, const DsdFinalArgs& a) {
     const size_t lds = (size_t)a.mmax * kFinABuf * 16 + (2 * kLatMaxM * 16 + 48 + 16 + 2 * 4 * 16 * 64) * 4;
     auto k0 = lat_final_kernel<0>;
     auto k1 = lat_final_kernel<1>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DcsOncePerDevice attr_once;   // the attribute belongs to the device's function object (round-3 advisor finding)
+    if (attr_once.first(ctx->device)) {
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
     }
     const dim3 grid((unsigned)dcs_cdiv(a.F, 64), (unsigned)dcs_cdiv(a.rows, 16));
     DcsTimer tm(ctx, DCS_TAG_FINAL);
@@ -1464,11 +1470,10 @@ int dcs_launch_lat_stft_conv1(dcs_stft* p, const float* audio, int64_t L, float*
     const size_t lds = ((size_t)(M + 2) + 4 * (size_t)(2 * M)) * sizeof(float2) + (size_t)(M + 4) * 16 + 16 * 4 * 64 * 4;
     auto k10 = lat_stft_conv1_kernel<10>;
     auto k9 = lat_stft_conv1_kernel<9>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DcsOncePerDevice attr_once;
+    if (attr_once.first(p->ctx->device)) {
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k10), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_done = true;
     }
     const dim3 grid((unsigned)dcs_cdiv(rows_out, 4));
     DcsTimer tm(p->ctx, DCS_TAG_STFT);
@@ -1522,11 +1527,10 @@ int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, cons
         const size_t lds = ((size_t)(M + 2) + (size_t)NG * (2 * M + 2)) * sizeof(float2);
         auto k10 = lat_ifft_kernel<10, NG>;
         auto k9 = lat_ifft_kernel<9, NG>;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static DcsOncePerDevice attr_once;
+        if (attr_once.first(p->ctx->device)) {
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k10), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_done = true;
         }
         if (p->frame == 2048)
             hipLaunchKernelGGL(k10, g1, dim3(NG * 256), lds, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f, fr, T,

@@ -1098,7 +1098,7 @@ int dcs_fft_wave_inverse(dcs_stft* p, const float* mag, int64_t src_stride, cons
     DCS_FAIL(DCS_EUNSUPPORTED, "wave FFT: frame size");
 }
 
-extern "C" int fftw_trace_dump(unsigned long long* out, int n) {
+extern "C" DCS_API int fftw_trace_dump(unsigned long long* out, int n) {
 #ifdef DCS_FFTW_TRACE
     if (!out || n < 64) return -1;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(fftw_trace_buf), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;

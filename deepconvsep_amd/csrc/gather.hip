@@ -26,6 +26,7 @@ struct Rccl {
     fn_comm_int count = nullptr, user_rank = nullptr;
     fn_errstr errstr = nullptr;
     bool ok = false;
+    char why[256] = "";      // why RCCL is unusable, captured at load time
 };
 
 Rccl* rccl() {
@@ -36,7 +37,11 @@ Rccl* rccl() {
             x.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (x.lib) break;
         }
-        if (!x.lib) return x;
+        if (!x.lib) {
+            const char* e = dlerror();               // read ONCE: dlerror() clears the error state it returns
+            snprintf(x.why, sizeof(x.why), "%s", e ? e : "librccl.so not found");
+            return x;
+        }
         x.all_gather = (fn_all_gather)dlsym(x.lib, "ncclAllGather");
         x.send = (fn_send)dlsym(x.lib, "ncclSend");
         x.recv = (fn_recv)dlsym(x.lib, "ncclRecv");
@@ -46,6 +51,8 @@ Rccl* rccl() {
         x.user_rank = (fn_comm_int)dlsym(x.lib, "ncclCommUserRank");
         x.errstr = (fn_errstr)dlsym(x.lib, "ncclGetErrorString");
         x.ok = x.all_gather && x.send && x.recv && x.group_start && x.group_end && x.count && x.user_rank;
+        if (!x.ok) snprintf(x.why, sizeof(x.why), "librccl.so lacks one of ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / "
+                                                  "ncclGroupEnd / ncclCommCount / ncclCommUserRank");
         return x;
     }();
     return &r;
@@ -63,7 +70,7 @@ extern "C" int dcs_gather(dcs_ctx* ctx, void* nccl_comm, const void* shard_d, in
     if (!ctx || !nccl_comm || !shard_d) DCS_FAIL(DCS_EINVAL, "dcs_gather: null argument");
     if (bytes < 0) DCS_FAIL(DCS_EINVAL, "dcs_gather: %lld bytes", (long long)bytes);
     Rccl* R = rccl();
-    if (!R->ok) DCS_FAIL(DCS_EUNSUPPORTED, "dcs_gather: librccl.so not found or incomplete (%s)", dlerror() ? dlerror() : "symbols");
+    if (!R->ok) DCS_FAIL(DCS_EUNSUPPORTED, "dcs_gather: RCCL unavailable (%s)", R->why);
     DCS_ON_DEVICE(ctx->device);
     int n = 0, rank = -1;
     DCS_RCCL(R->count(nccl_comm, &n));

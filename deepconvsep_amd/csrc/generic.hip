@@ -1281,6 +1281,7 @@ struct DcsGenericNet {
     float *Bfc = nullptr, *biasfc = nullptr;
     float* Bd[4] = {nullptr, nullptr, nullptr, nullptr};
     void* Bdq[4] = {nullptr, nullptr, nullptr, nullptr};  // per-source dense weights as bf16 planes (gemm_bf16x3.hip)
+    bool bdq_failed = false;                              // the planes did not fit in memory: the dense layers stay on the f32 GEMM
     float* biasd[4] = {nullptr, nullptr, nullptr, nullptr};
     float* bout = nullptr;
     DcsBuffer ws;
@@ -1724,11 +1725,24 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // on the f32 kernels whatever is packed, dcs_launch_gemm_bf16x3); same stream, so no synchronisation
     static const bool bf16_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
     if (bf16_on && n >= 128 && g->flat64 >= 1024) {
-        for (int s2 = 0; s2 < d.n_fc; ++s2) {
+        for (int s2 = 0; s2 < d.n_fc && !g->bdq_failed; ++s2) {
             if (g->Bdq[s2]) continue;
+            // published only when packed: a failed pack must not leave a non-null, unpacked plane set behind (later calls
+            // would multiply by uninitialised memory).  Out of memory here (~1 GB for Bach10, outside the chunk budget) is
+            // not an error of the forward pass: the layer stays on the f32 GEMM (q.Bq == nullptr) for the model's lifetime.
             const int rows = (int)dcs_round_up(g->hid64, 128);
-            DCS_HIP(hipMalloc(&g->Bdq[s2], dcs_gemm_bq_bytes(rows, g->flat64)));
-            DCS_CHECK(dcs_gemm_pack_bq(ctx, g->Bd[s2], rows, g->flat64, g->flat64, g->Bdq[s2]));
+            void* planes = nullptr;
+            if (hipMalloc(&planes, dcs_gemm_bq_bytes(rows, g->flat64)) != hipSuccess) {
+                (void)hipGetLastError();
+                g->bdq_failed = true;
+                break;
+            }
+            const int rc = dcs_gemm_pack_bq(ctx, g->Bd[s2], rows, g->flat64, g->flat64, planes);
+            if (rc != DCS_OK) {
+                (void)hipFree(planes);
+                return rc;
+            }
+            g->Bdq[s2] = planes;
         }
     }
     bool branches_done = false;

@@ -597,14 +597,29 @@ extern "C" int dcs_model_set_latency_stages(dcs_model* m, int stages) {
 extern "C" int dcs_model_num_sources(const dcs_model* m) { return m ? m->d.S : DCS_EINVAL; }
 extern "C" int dcs_model_out_channels(const dcs_model* m) { return m ? m->d.n_branch * m->C : DCS_EINVAL; }
 
+// ONE place decides which one-batch stages (dsd_lat.hip) a call takes: separate_impl (what runs), separate_graphed (whether
+// the call is replayed from a hipGraph) and dcs_model_final_kernel (what bench.py prices) all ask here.  plan == nullptr /
+// ov < 0: the caller does not know them (dcs_model_final_kernel) -- the frame-size and covering-tile conditions are then
+// taken as met, which holds for every configuration the reference ships (frame 1024 / 2048, hop 512, overlap <= 25).
+constexpr int kLatDefault = DCS_LAT_ALL & ~DCS_LAT_MID & ~DCS_LAT_FUSE1;
+static unsigned dsd_lat_mask(const dcs_model* m, const dcs_stft* plan, int64_t T, int64_t n_clips, bool ragged, int ov,
+                             int eps_mode) {
+    if (!m->lat_ok || n_clips != 1 || ragged) return 0;
+    if (plan && !dcs_lat_stft_supported(plan)) return 0;
+    static const int env_mask = getenv("DCS_LAT") ? atoi(getenv("DCS_LAT")) : -1;
+    const int want = m->lat_stages >= 0 ? m->lat_stages : (env_mask >= 0 ? env_mask : (T <= dcs_lat_max_frames() ? kLatDefault : 0));
+    unsigned lat = (unsigned)want & DCS_LAT_ALL;
+    const int st = ov >= 0 ? m->tc - ov : 0;
+    if ((st > 0 && (ov + st - 1) / st + 1 > dcs_lat_final_max_covers()) || eps_mode > 1)
+        lat &= ~(unsigned)DCS_LAT_FINAL;   // more covering tiles than the LDS holds
+    if (T >= (1 << 24)) lat = 0;
+    return lat;
+}
+
 extern "C" int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips, int eps_mode) {
     if (!m || n_frames < 1) return DCS_EINVAL;
     if (m->arch != DCS_ARCH_DSD) return DCS_EUNSUPPORTED;
-    if (m->lat_ok && n_clips <= 1 && eps_mode < 2) {   // the one-batch kernels (dsd_lat.hip): as separate_impl selects them
-        static const int env_mask = getenv("DCS_LAT") ? atoi(getenv("DCS_LAT")) : -1;
-        const int want = m->lat_stages >= 0 ? m->lat_stages : (env_mask >= 0 ? env_mask : (n_frames <= dcs_lat_max_frames() ? DCS_LAT_ALL : 0));
-        if (want & DCS_LAT_FINAL) return 3;
-    }
+    if (dsd_lat_mask(m, nullptr, n_frames, n_clips < 1 ? 1 : n_clips, false, -1, eps_mode) & DCS_LAT_FINAL) return 3;
     if (m->Bpk && dsd_final_bf16x3(m->ctx, n_frames, m->F, n_clips, m->CI, eps_mode)) return 2;
     return dsd_final_cbw(m->ctx, n_frames, m->F, n_clips) == 2 ? 1 : 0;
 }
@@ -634,7 +649,6 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 // ------------------------------------------------------------------------------------------------ fused path
 // the automatic selection: one launch per layer.  The 8-workgroup-cluster launch of the middle (DCS_LAT_MID) is built and
 // tested but measured slower (a cluster per tile re-reads the 1.9 MB of weights per tile: 77 MB per batch through L2)
-constexpr int kLatDefault = DCS_LAT_ALL & ~DCS_LAT_MID & ~DCS_LAT_FUSE1;
 constexpr int kLatBatchDefault = 0;
 static inline int64_t rows1_of(int64_t n, int64_t n_clips, int64_t Trows, int st, int tc) {
     return n_clips > 1 ? n_clips * Trows : (n - 1) * st + tc;
@@ -715,15 +729,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         // deconv2 then writes the split planes of G itself
         // one batch per call (the reference's predict_function2 shape): every stage on the short-chain kernels of
         // dsd_lat.hip.  DCS_LAT=<stage bits> / dcs_model_set_latency_stages force a selection (A/B tests, profiling).
-        unsigned lat = 0;
-        if (m->lat_ok && n_clips == 1 && !clip_tab_d && dcs_lat_stft_supported(plan)) {
-            static const int env_mask = getenv("DCS_LAT") ? atoi(getenv("DCS_LAT")) : -1;
-            const int64_t env_max = dcs_lat_max_frames();
-            const int want = m->lat_stages >= 0 ? m->lat_stages : (env_mask >= 0 ? env_mask : (T <= env_max ? kLatDefault : 0));
-            lat = (unsigned)want & DCS_LAT_ALL;
-            if ((ov + st - 1) / st + 1 > dcs_lat_final_max_covers() || eps_mode > 1) lat &= ~(unsigned)DCS_LAT_FINAL;   // more covering tiles than the LDS holds
-            if (T >= (1 << 24)) lat = 0;
-        }
+        unsigned lat = dsd_lat_mask(m, plan, T, n_clips, clip_tab_d != nullptr, ov, eps_mode);
         if (lat == 0 && m->lat_ok) {
             // launches of many tiles: the encoder layers (and the transposed conv2) may still take the sliced-K kernels of
             // dsd_lat.hip -- DCS_LAT_BATCH=<stage bits 2 | 4 | 8 | 16 | 32>, measured per shape in profiles/r03_*
@@ -809,8 +815,8 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     // when several streams compete for the host (launch groups), not for one short call after another.  DCS_LAT_GRAPH=1
     // replays the one-batch path as a graph anyway.
     static const bool lat_graph = getenv("DCS_LAT_GRAPH") && atoi(getenv("DCS_LAT_GRAPH")) != 0;
-    const bool lat_call = m->lat_ok && n_clips == 1 && m->lat_stages != 0 &&
-                          (m->lat_stages > 0 || dcs_frame_count(n_samples, plan ? plan->hop : 1) <= dcs_lat_max_frames());
+    const bool lat_call = plan && m->arch == DCS_ARCH_DSD &&
+                          dsd_lat_mask(m, plan, dcs_frame_count(n_samples, plan->hop), n_clips, false, overlap, eps_mode) != 0;
     const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD &&
                            (!lat_call || lat_graph);
     auto eager = [&]() {

@@ -135,8 +135,20 @@ class RcclComm:
             raise RuntimeError("ncclGetUniqueId: %d" % rc)
         return bytes(buf)
 
-    def __init__(self, n_ranks, rank, uid):
+    def __init__(self, n_ranks, rank, uid, device=None):
+        """``device``: the GPU ordinal this rank's libdcs context lives on (a ``Context``, a ``torch.device`` or an int;
+        default: torch's current device).  ``ncclCommInitRank`` binds the communicator to the CURRENT HIP device and
+        ``dcs_gather`` later selects ``ctx->device``: the two must be the same GPU, so the device is made current here."""
         import ctypes
+        import torch
+        if device is None:
+            device = torch.cuda.current_device()
+        elif hasattr(device, "device_index"):            # a deepconvsep_amd.runtime.Context
+            device = device.device_index
+        elif isinstance(device, torch.device):
+            device = device.index if device.index is not None else torch.cuda.current_device()
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
 
         class _Uid(ctypes.Structure):
             _fields_ = [("internal", ctypes.c_char * 128)]
@@ -151,12 +163,12 @@ class RcclComm:
         self.n_ranks, self.rank = int(n_ranks), int(rank)
 
     @classmethod
-    def from_process_group(cls, group=None):
+    def from_process_group(cls, group=None, device=None):
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         box = [cls.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls(world, rank, box[0])
+        return cls(world, rank, box[0], device=device)
 
     def gather(self, ctx, shard, full=None, root=-1):
         """``shard``: this rank's contiguous device tensor; ``full``: ``[n_ranks, *shard.shape]`` of the same dtype on the

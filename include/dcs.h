@@ -29,6 +29,9 @@
 
 #include <stdint.h>
 
+/* libdcs.so is built with -fvisibility=hidden: the entry points below are the ONLY dynamic symbols it exports. */
+#define DCS_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -59,35 +62,35 @@ enum { DCS_TIE_ALL = 0, DCS_TIE_FIRST = 1 };
 enum { DCS_TILER_SCRIPT = 0, DCS_TILER_LIBRARY = 1 };
 
 /* ------------------------------------------------------------------ library / context */
-int dcs_version(void);
-const char* dcs_last_error(void);
+DCS_API int dcs_version(void);
+DCS_API const char* dcs_last_error(void);
 
 /* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the
  * device's default stream. */
-int dcs_create(int device, void* hip_stream, dcs_ctx** out);
-int dcs_destroy(dcs_ctx* ctx);
-int dcs_synchronize(dcs_ctx* ctx);
+DCS_API int dcs_create(int device, void* hip_stream, dcs_ctx** out);
+DCS_API int dcs_destroy(dcs_ctx* ctx);
+DCS_API int dcs_synchronize(dcs_ctx* ctx);
 
 /* ------------------------------------------------------------------ framing integers (host) */
 /* numberFrames of stft_norm: int(ceil(L/hop) + 2)                      transform.py:309 */
-int64_t dcs_frame_count(int64_t n_samples, int hop);
+DCS_API int64_t dcs_frame_count(int64_t n_samples, int hop);
 /* len(istft_norm(...)) = hop*(T-1) + N - N/2                            transform.py:373,390 */
-int64_t dcs_inverse_length(int64_t n_frames, int hop, int frame);
+DCS_API int64_t dcs_inverse_length(int64_t n_frames, int hop, int frame);
 /* number of tiles the reference tilers cut from T frames                separate_dsd.py:121-125, util.py:228-232 */
-int64_t dcs_tile_count(int64_t n_frames, int time_context, int overlap, int tiler);
+DCS_API int64_t dcs_tile_count(int64_t n_frames, int time_context, int overlap, int tiler);
 
 /* ------------------------------------------------------------------ STFT  (transform.py:224-396) */
 /* frame must be a power of two in [64, 8192]; window_h = window(frame) as the reference
  * materialises it in Transforms.__init__ (transform.py:78). */
-int dcs_stft_plan(dcs_ctx* ctx, int frame, int hop, const double* window_h, dcs_stft** out);
-int dcs_stft_plan_destroy(dcs_stft* plan);
+DCS_API int dcs_stft_plan(dcs_ctx* ctx, int frame, int hop, const double* window_h, dcs_stft** out);
+DCS_API int dcs_stft_plan_destroy(dcs_stft* plan);
 
 /* compute_file: mag = |rfft(w * frame)| / sqrt(N), phase = angle(.)     transform.py:243-247
  * audio_d [n_samples]; mag_d / phase_d [rows_out, ld] with rows >= dcs_frame_count() written
  * as zero rows (used by the zero-padding tiler); phase_d may be NULL (phase=False). */
-int dcs_stft_forward_f32(dcs_stft* plan, const float* audio_d, int64_t n_samples, float* mag_d,
+DCS_API int dcs_stft_forward_f32(dcs_stft* plan, const float* audio_d, int64_t n_samples, float* mag_d,
                          float* phase_d, int64_t ld, int64_t rows_out);
-int dcs_stft_forward_f64(dcs_stft* plan, const double* audio_d, int64_t n_samples, double* mag_d,
+DCS_API int dcs_stft_forward_f64(dcs_stft* plan, const double* audio_d, int64_t n_samples, double* mag_d,
                          double* phase_d, int64_t ld, int64_t rows_out);
 
 /* compute_inverse for n_src magnitude matrices sharing one phase:       transform.py:271-273, 337-396
@@ -96,40 +99,40 @@ int dcs_stft_forward_f64(dcs_stft* plan, const double* audio_d, int64_t n_sample
  * audio_d [n_src][n_out] with n_out <= dcs_inverse_length() (the caller's truncation,
  * separate_dsd.py:305-306).  pre_div is the scale_factor division of separate_dsd.py:304 (1.0 for
  * the plain transform API). */
-int dcs_stft_inverse_f32(dcs_stft* plan, const float* mag_d, int64_t src_stride, const float* phase_d,
+DCS_API int dcs_stft_inverse_f32(dcs_stft* plan, const float* mag_d, int64_t src_stride, const float* phase_d,
                          int64_t ld, int64_t n_frames, int n_src, float pre_div, float* audio_d,
                          int64_t n_out);
-int dcs_stft_inverse_f64(dcs_stft* plan, const double* mag_d, int64_t src_stride, const double* phase_d,
+DCS_API int dcs_stft_inverse_f64(dcs_stft* plan, const double* mag_d, int64_t src_stride, const double* phase_d,
                          int64_t ld, int64_t n_frames, int n_src, double pre_div, double* audio_d,
                          int64_t n_out);
 
 /* ------------------------------------------------------------------ tiling (separate_dsd.py:114-169, util.py:220-327) */
 /* generate_overlapadd: tiles_d [n, C, tc, F] = scale * mag_d[C][T, ld] windows; n = dcs_tile_count().
  * (the reference multiplies by scale_factor before tiling, separate_dsd.py:290) */
-int dcs_tile(dcs_ctx* ctx, const float* mag_d, int64_t ch_stride, int64_t ld, int C, int64_t n_frames, int F,
+DCS_API int dcs_tile(dcs_ctx* ctx, const float* mag_d, int64_t ch_stride, int64_t ld, int C, int64_t n_frames, int F,
              int time_context, int overlap, int tiler, float scale, float* tiles_d, int64_t n_tiles);
 
 /* overlapadd_multi / overlapadd: cross-fade stitch of out_d [S, n, tc, F] into
  * sep_d [S][n*(tc-ov)+tc, ld] (source stride sep_stride).  rise_h = np.linspace(0,1,overlap) as
  * float64 (util.py:306); the fall ramp is its reverse (util.py:307). */
-int dcs_overlap_add(dcs_ctx* ctx, const float* out_d, int64_t n_tiles, int S, int time_context, int overlap,
+DCS_API int dcs_overlap_add(dcs_ctx* ctx, const float* out_d, int64_t n_tiles, int S, int time_context, int overlap,
                     int F, const double* rise_h, float* sep_d, int64_t sep_stride, int64_t ld);
 
 /* ------------------------------------------------------------------ network (build_ca + mask) */
 /* params_d: device float32 arrays in lasagne.layers.get_all_params order (= the .pkl order),
  * shapes: nparams x 4 int64 (unused trailing dims = 1).  Fails with DCS_ESHAPE exactly where
  * lasagne.layers.set_all_param_values would raise (separate_dsd.py:250). */
-int dcs_model_create(dcs_ctx* ctx, int arch, int in_channels, int time_context, int F,
+DCS_API int dcs_model_create(dcs_ctx* ctx, int arch, int in_channels, int time_context, int F,
                      const float* const* params_d, const int64_t* shapes, int nparams, dcs_model** out);
-int dcs_model_destroy(dcs_model* m);
-int dcs_model_num_sources(const dcs_model* m);
+DCS_API int dcs_model_destroy(dcs_model* m);
+DCS_API int dcs_model_num_sources(const dcs_model* m);
 /* f16 = 1: conv2 and its transpose of the ikala / bach10 / score-informed graphs run with f16 inputs and
  * f32 accumulation on the matrix cores (BASELINE config 3, "fp16 MFMA conv path"); 0 (default): f32-class arithmetic
  * everywhere (f32 MFMA, or the bf16 pipe with operands split exactly into three bf16 terms).  With the switch on, the
  * single-channel bach10 graph runs both InverseLayers in one kernel (colconv_wreg.hip): conv2^T in f16, conv1^T on the
  * bf16 pipe with three-way split operands (f32-class), the activations between them never rounded below f32.  The ikala
  * graph (10 x 20 filters) takes the same slab kernel in either precision (one f16 plane instead of three bf16 planes). */
-int dcs_model_set_conv_precision(dcs_model* m, int f16);
+DCS_API int dcs_model_set_conv_precision(dcs_model* m, int f16);
 /* Which stages of dcs_separate run on the one-batch ("latency") kernels of csrc/dsd_lat.hip -- the shape of the
  * reference's own call, predict_function2 on ONE batch of 32 tiles (separate_dsd.py:296-298), where a kernel's duration
  * is its chain of dependent memory latencies.  stages = -1 (default): automatic, all of them for one clip of at most
@@ -139,29 +142,29 @@ int dcs_model_set_conv_precision(dcs_model* m, int f16);
  * 1 and 2 set) STFT and conv1 as ONE launch (four frames per workgroup).  Both families
  * read and write the same buffers, so any mix is valid (tests compare each stage against the other family).  DSD graph
  * only (DCS_EUNSUPPORTED otherwise). */
-int dcs_model_set_latency_stages(dcs_model* m, int stages);
+DCS_API int dcs_model_set_latency_stages(dcs_model* m, int stages);
 /* Testing aids (host only, no GPU): the weight re-layouts of the one-batch kernels.  dcs_lat_pack_b_host: B[K][ldb]
  * (k-major) -> [slice][column block][j][lane][4], the order in which lane (fi = lane & 15, kq = lane >> 4) of wave
  * `slice` feeds v_mfma_f32_16x16x4_f32: element e of piece j is B[slice * slice_len + 16 j + 4 kq + e][16 cb + fi].
  * dcs_lat_pack_deconv2_host: Bw2s[ci][16 taps][52] -> [ci][j][lane][4] with column fi = tap.  Both return the number of
  * floats of the packed array (and fill `out` when out_len is large enough) or a negative status. */
-int64_t dcs_lat_pack_b_host(const float* B, int ldb, int K, int n_cb, int slice_len, int n_slices, float* out, int64_t out_len);
-int64_t dcs_lat_pack_deconv2_host(const float* Bw2s, int n_ci8, float* out, int64_t out_len);
+DCS_API int64_t dcs_lat_pack_b_host(const float* B, int ldb, int K, int n_cb, int slice_len, int n_slices, float* out, int64_t out_len);
+DCS_API int64_t dcs_lat_pack_deconv2_host(const float* Bw2s, int n_ci8, float* out, int64_t out_len);
 
 /* predict_function2 (separate_dsd.py:273,298): tiles_d [n, C, tc, F] -> out_d [S, n, tc, F]
  * = soft-masked magnitudes of the S sources. */
-int dcs_model_forward_masked(dcs_model* m, const float* tiles_d, int64_t n_tiles, int eps_mode, int tie_mode,
+DCS_API int dcs_model_forward_masked(dcs_model* m, const float* tiles_d, int64_t n_tiles, int eps_mode, int tie_mode,
                              float* out_d);
 /* lasagne.layers.get_output(network2): p_d [n, channels_out, tc, F] before masking (testing aid) */
-int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n_tiles, int tie_mode, float* p_d);
-int dcs_model_out_channels(const dcs_model* m);
+DCS_API int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n_tiles, int tie_mode, float* p_d);
+DCS_API int dcs_model_out_channels(const dcs_model* m);
 /* Which kernel the fused path (dcs_separate*) runs for the decoder's last stage (transposed conv1 + bias + rectify + mask
  * + cross-fade) on n_clips clips of n_frames frames each: 0 = f32 MFMA, 64-bin workgroups (small launches); 1 = f32
  * MFMA, 128-bin workgroups; 2 = bf16 MFMA on operands split exactly into three bf16 terms (f32-class results, the
  * default for launches that fill the chip; DSD / hiphop graph); 3 = the one-batch kernel of csrc/dsd_lat.hip (one clip of
  * at most DCS_LAT_MAX_FRAMES frames, see dcs_model_set_latency_stages; the same bf16x3 arithmetic, 16 x 64 workgroups);
  * negative: not a fused-kernel graph.  bench.py prices its roofline block with this. */
-int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips, int eps_mode);
+DCS_API int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips, int eps_mode);
 
 /* ------------------------------------------------------------------ fused file-level path */
 /* The separation block of train_auto (separate_dsd.py:289-306) for one mono signal already in
@@ -169,7 +172,7 @@ int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips
  * iSTFT -> truncate to n_samples.  pcm_d [S, n_samples] float32.  n_tiles_out / n_frames_out
  * (host, optional) receive the tile and frame counts.  Returns DCS_EINVAL when the tiler yields
  * zero tiles (the reference raises in overlapadd_multi in that case). */
-int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap, int tiler,
+DCS_API int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap, int tiler,
                  float scale, int eps_mode, int tie_mode, float* pcm_d, int64_t* n_tiles_out,
                  int64_t* n_frames_out);
 
@@ -179,7 +182,7 @@ int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_s
  * -> / scale -> iSTFT.  The model must have ninst input channels.  pcm_d [S, n_samples] float32.  All tiles go through the
  * network in one pass (the script's batch loop gives the same values tile by tile).  Asynchronous (the note rectangles are
  * staged through the context's pinned upload ring; notes_h may be reused when the call returns). */
-int dcs_separate_scoreinformed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, const double* notes_h,
+DCS_API int dcs_separate_scoreinformed(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, const double* notes_h,
                                int ninst, int n_notes, int width, int overlap, float scale, int eps_mode, int tie_mode,
                                float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out);
 
@@ -190,7 +193,7 @@ int dcs_separate_scoreinformed(dcs_model* m, dcs_stft* plan, const float* audio_
  * launches; outputs agree with the single-clip call to fp32 rounding (the FFT / GEMM kernel variants are
  * chosen by the total amount of work).  The ikala / bach10 graphs stack the tiles of all clips into one pass of the
  * network (their dense-layer weights are then read once per group).  n_tiles_out / n_frames_out are per clip. */
-int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,
+DCS_API int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips,
                        int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode, int tie_mode,
                        float* pcm_d, int64_t* n_tiles_out, int64_t* n_frames_out);
 
@@ -206,7 +209,7 @@ int dcs_separate_batch(dcs_model* m, dcs_stft* plan, const float* audio_d, int64
  * n_tiles_out / n_frames_out: [n_clips] or NULL.  Equal lengths with pcm_stride == length take the
  * dcs_separate_batch path.  Asynchronous like every other call: the clip table goes out through a pinned staging ring owned
  * by the model (n_samples_h may be reused as soon as the call returns). */
-int dcs_separate_ragged(dcs_model* m, dcs_stft* plan, const float* audio_d, const int64_t* n_samples_h,
+DCS_API int dcs_separate_ragged(dcs_model* m, dcs_stft* plan, const float* audio_d, const int64_t* n_samples_h,
                         int64_t n_clips, int64_t clip_stride, int overlap, int tiler, float scale, int eps_mode,
                         int tie_mode, float* pcm_d, int64_t pcm_stride, int64_t* n_tiles_out, int64_t* n_frames_out);
 
@@ -216,19 +219,19 @@ int dcs_separate_ragged(dcs_model* m, dcs_stft* plan, const float* audio_d, cons
  * per input channel the mask of :176-180 (p / (sum over sources + 1e-12 r), source = mask * input + 1e-12 r, r = 0.1
  * standing in for the trainer's N(0, 0.1) draw), cross-fade, and the iSTFT with that channel's phase.
  * pcm_d [2][S][n_samples]; sep_d (optional) [2][S][n_frames, ld_out] scaled magnitudes.  Either may be NULL. */
-int dcs_separate_stereo(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t channel_stride,
+DCS_API int dcs_separate_stereo(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t channel_stride,
                         int overlap, int tiler, float scale, float* pcm_d, float* sep_d, int64_t ld_out,
                         int64_t* n_tiles_out, int64_t* n_frames_out);
 
 /* Same pipeline stopped before the iSTFT: sep_d [S][n_frames, ld_out] (scaled magnitudes, what the
  * reference calls mm[i,:len(ph)]) and phase_d [n_frames, ld_out]; either may be NULL. */
-int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
+DCS_API int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t n_samples, int overlap,
                          int tiler, float scale, int eps_mode, int tie_mode, float* sep_d, float* mag_d,
                          float* phase_d, int64_t ld_out);
 
 /* The wav sample format of every script: out_d[i] = (int16)(pcm_d[i] * 32767), truncation toward zero, no
  * clipping (separate_dsd.py:307-309).  Halves the bytes of the multi-GPU PCM gather. */
-int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d);
+DCS_API int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d);
 
 /* The one exchange of the multi-GPU path (tiles / clips are sharded over one process per GPU and nothing else is shared;
  * SURVEY 8b `dcs_gather(h, ncclComm_t, shard, count, full, root)`, counted in BYTES here so that the scripts' int16 PCM of
@@ -237,7 +240,7 @@ int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d
  * root < 0: all-gather, every rank's full_d [n_ranks][bytes] in rank order.  root >= 0: only that rank receives (grouped
  * ncclSend / ncclRecv: what a single writer process needs, 1 / n_ranks of the all-gather's traffic per link); full_d may be
  * NULL elsewhere.  Enqueued on the ctx stream like every other call; shard_d may be the rank's own slot of full_d. */
-int dcs_gather(dcs_ctx* ctx, void* nccl_comm, const void* shard_d, int64_t bytes, void* full_d, int root);
+DCS_API int dcs_gather(dcs_ctx* ctx, void* nccl_comm, const void* shard_d, int64_t bytes, void* full_d, int root);
 
 /* ------------------------------------------------------------------ score-informed front-end */
 /* filterSpec (examples/bach10_scoreinformed/separate_bach10.py:172-200) and the network input of :520-527.
@@ -249,7 +252,7 @@ int dcs_gather(dcs_ctx* ctx, void* nccl_comm, const void* shard_d, int64_t bytes
  * the caller like :503); mask_d [n_frames][ninst*F] = filterSpec's return value.  Either output may be NULL.
  * A bin range outside [0, F) is DCS_ESHAPE (NumPy raises IndexError there).  Asynchronous: the note rectangles go out through
  * a pinned staging ring owned by the context. */
-int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
+DCS_API int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
                     int ninst, int n_notes, int width, int64_t start, int64_t stop, float* out_d, float* mask_d);
 
 /* ------------------------------------------------------------------ timing aid for bench.py */
@@ -261,11 +264,11 @@ enum { DCS_TAG_STFT = 0, DCS_TAG_CONV1 = 1, DCS_TAG_CONV2 = 2, DCS_TAG_FC = 3, D
        DCS_TAG_UNPOOL = 11, DCS_TAG_MASK = 12, DCS_TAG_SCORE = 13,
        DCS_TAG_DECODER = 14 /* transposed conv2 + transposed conv1 in one kernel (Bach10 graph, f16 switch) */,
        DCS_TAG_COUNT = 15 };
-int dcs_timing_enable(dcs_ctx* ctx, unsigned tag_mask);
+DCS_API int dcs_timing_enable(dcs_ctx* ctx, unsigned tag_mask);
 /* bracket only every stride-th launch of an enabled tag (an event pair costs ~6 us of stream time each side) */
-int dcs_timing_stride(dcs_ctx* ctx, int stride);
-int dcs_timing_reset(dcs_ctx* ctx);
-int dcs_timing_query(dcs_ctx* ctx, int which, double* avg_ms, int64_t* launches);
+DCS_API int dcs_timing_stride(dcs_ctx* ctx, int stride);
+DCS_API int dcs_timing_reset(dcs_ctx* ctx);
+DCS_API int dcs_timing_query(dcs_ctx* ctx, int which, double* avg_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

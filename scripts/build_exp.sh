@@ -7,10 +7,10 @@ name=$1; src=$2; shift 2
 cd "$(dirname "$(readlink -f "$0")")/../deepconvsep_amd/csrc"
 mkdir -p build/exp
 obj=build/exp/${name}_${src%.hip}.o
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default "$@" -c "$src" -o "$obj"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden "$@" -c "$src" -o "$obj"
 objs=()
 for s in api dsd_lat fft fft_wave tiling gemm gemm_bf16x3 colconv_wreg slabconv_ps conv1_mfma deconv1_mfma dsd dsd_bf16x3 generic net score gather; do
   if [ "$s.hip" = "$src" ]; then objs+=("$obj"); else objs+=("build/$s.o"); fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -ldl -o ../_exp_${name}.so
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=libdcs.map "${objs[@]}" -ldl -o ../_exp_${name}.so
 echo "built deepconvsep_amd/_exp_${name}.so ($*)"

@@ -942,6 +942,7 @@ def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
     {"DCS_FINAL_CBW": "2"}, {"DCS_FINAL_CBW": "1"},               # 128-bin workgroups (bf16x3 kernel, G split by a pass) / 64-bin (f32)
     {"DCS_FINAL_CBW": "2", "DCS_FINAL_BF16X3": "0"},              # 128-bin workgroups, f32 kernel
     {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2"},                   # bf16x3 kernel fed by the streaming deconv2 (writes the planes)
+    {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2", "DCS_FINAL_DIRECT": "0"},   # ... its register-staged form (round 3's default)
     {"DCS_DECONV2": "2"}, {"DCS_DECONV2": "1"},                   # streaming / one-shot transposed conv2
     {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "1"}, {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "7"},
     {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "64"},              # ring iSTFT: hop-blocks per workgroup
