@@ -164,6 +164,9 @@ def main():
                     help="N > 1: the collective that carries every launch group's int16 PCM inside the timed region: "
                          "all_gather_into_tensor (every rank gets everything), gather to rank 0 (north_star: 'final gather'), "
                          "or none (replicas: every rank keeps its own output)")
+    ap.add_argument("--gather-impl", choices=["torch", "dcs"], default="torch",
+                    help="who issues the collective: torch.distributed (backend nccl = RCCL), or libdcs's own C-ABI entry "
+                         "dcs_gather on an RCCL communicator per HIP stream (deepconvsep_amd.dist.RcclComm)")
     ap.add_argument("--only-legs", action="store_true",
                     help="(counter passes) skip the headline timing: run only the legs given by --legs")
     args = ap.parse_args()
@@ -182,12 +185,23 @@ def main():
     if same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # DCS_BENCH_FORCE_GATHER (tests on a 1-GPU box): run the N > 1 code path -- int16 conversion, collective, checks -- with
+    # a world of ONE rank, so that `--gather-impl dcs` (RCCL through the C ABI) is exercised where only one GPU exists
+    force_gather = bool(os.environ.get("DCS_BENCH_FORCE_GATHER")) and world == 1
+    gathering = world > 1 or force_gather
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if same_device:                                           # RCCL refuses two ranks on one GPU: gloo for the check
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif force_gather:
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gather_impl == "dcs" and gathering and same_device:
+        raise SystemExit("bench.py: --gather-impl dcs needs one GPU per rank (RCCL refuses two ranks on one device)")
 
     import ctypes
 
@@ -230,9 +244,15 @@ def main():
                 self.pcm = torch.empty((CPL, 4, L), dtype=torch.float32, device=self.audio.device)
                 # multi-GPU: the separated PCM is gathered in the wav sample format (int16, separate_dsd.py:307-309);
                 # RCCL has no int16 type, so the buffers travel as bytes
-                self.pcm16 = torch.empty((CPL * 4, L), dtype=torch.int16, device=self.audio.device) if world > 1 else None
+                self.pcm16 = torch.empty((CPL * 4, L), dtype=torch.int16, device=self.audio.device) if gathering else None
                 self.gathered = (torch.empty((world * CPL * 4, L), dtype=torch.int16, device=self.audio.device)
-                                 if world > 1 else None)
+                                 if gathering else None)
+            # --gather-impl dcs: one RCCL communicator per lane (a communicator serialises its collectives; the lanes'
+            # streams must not), made collectively in lane order on every rank
+            self.comm = None
+            if gathering and args.gather_impl == "dcs":
+                from deepconvsep_amd.dist import RcclComm
+                self.comm = RcclComm.from_process_group(device=self.ctx)
             self.stream.synchronize()
             # the C entry point with its arguments bound once: dcs_separate_batch() enqueues on the context's
             # own stream, so the host cost of a launch group is one ctypes call (and, from the second identical
@@ -255,7 +275,7 @@ def main():
             if rc:
                 _lib.check(rc)
             self.launched_tiles += nclips * n_tiles
-            if world > 1 and gather_mode[0] != "none":
+            if gathering and gather_mode[0] != "none":
                 rc = self._to16(self.ctx._h, ctypes.c_void_p(self.pcm.data_ptr()), nclips * 4 * L,
                                 ctypes.c_void_p(self.pcm16.data_ptr()))
                 if rc:
@@ -264,6 +284,12 @@ def main():
 
         def gather(self, nclips):
             """RCCL over xGMI: the final gather of one launch group's separated PCM (int16, as bytes)."""
+            if self.comm is not None:                       # dcs_gather on the lane's own stream: no torch in the data path
+                root = 0 if gather_mode[0] == "root" else -1
+                src = self.pcm16[: nclips * 4]
+                full = self.gathered[: world * nclips * 4].view(world, nclips * 4, L) if (root < 0 or rank == root) else None
+                self.comm.gather(self.ctx, src, full, root=root)
+                return
             with torch.cuda.stream(self.stream):
                 src = self.pcm16[: nclips * 4].view(torch.uint8)
                 if gather_mode[0] == "root":
@@ -279,7 +305,7 @@ def main():
     ctx0 = lanes[0].ctx
 
     def barrier():
-        if world > 1:
+        if gathering:
             dist.barrier()
 
     def timed(group_sizes, use):
@@ -292,7 +318,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if gathering:
             tt = torch.tensor([el], dtype=torch.float64, device=lanes[0].audio.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
@@ -338,7 +364,7 @@ def main():
     # ---- N > 1: what the collective costs -- the same rounds with the gather switched off, and the collective alone (one
     # launch group's payload per call, back to back on lane 0), so that a scaling curve can be read: compute vs exchange
     gather_split = None
-    if world > 1:
+    if gathering:
         saved = gather_mode[0]
         gather_mode[0] = "none"
         for _ in range(2):
@@ -360,7 +386,9 @@ def main():
             tt = torch.tensor([alone], dtype=torch.float64, device=lanes[0].audio.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             alone = float(tt.item())
-        gather_split = {"mode": saved, "payload_bytes_per_rank_per_group": int(groups[0] * 4 * L * 2),
+        gather_split = {"mode": saved, "impl": ("dcs_gather (C ABI, RCCL communicator per HIP stream)" if args.gather_impl == "dcs"
+                                                else "torch.distributed (%s)" % dist.get_backend()),
+                        "payload_bytes_per_rank_per_group": int(groups[0] * 4 * L * 2),
                         "round_ms_without_gather": round(no_g * 1e3, 4), "round_ms_with_gather": round(med * 1e3, 4),
                         "ms_per_group_collective_alone": round(alone * 1e3, 4) if alone is not None else None,
                         "note": "rounds of the same K steps with the collective switched off, and the collective alone for one "
@@ -369,7 +397,7 @@ def main():
     # ---- optional self-check of the gather (tests): every rank's slice of the gathered buffer must be that rank's own
     # int16 PCM, bit for bit (digests exchanged out of band)
     gather_check = None
-    if world > 1 and os.environ.get("DCS_BENCH_CHECK_GATHER"):
+    if gathering and os.environ.get("DCS_BENCH_CHECK_GATHER"):
         import hashlib
         ln, g0 = lanes[0], groups[0]
         ln.step(g0)
@@ -569,7 +597,7 @@ def main():
                     "bytes_per_step": {"h2d_f32_audio": int(L * 4), "d2h_int16_pcm": int(4 * L * 2)},
                     "pcie_GBps": round((L * 4 + 4 * L * 2) * G0 * kg / eh / 1e9, 1),
                     "note": "pinned host buffers, async copies on the lanes' streams; not part of `value`"}
-    if world > 1:
+    if gathering:
         dist.barrier()
 
     # ---- CPU baseline: the oracle on this host's cores, same 32-tile batch (rank 0, N=1 only)
@@ -644,7 +672,7 @@ def main():
         want1 = pipeline.separate("dsd", params, ln.audio_h[0], SCALE, TC, OV, 32, N, HOP, np.hanning)
         err_single = float(np.max(np.abs(got1 - want1)))
         worst = max(err_group, err_single)
-        if world > 1:
+        if gathering:
             tt = torch.tensor([worst], dtype=torch.float64, device=lanes[0].audio.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             worst = float(tt.item())
@@ -698,7 +726,10 @@ def main():
         if gather_split is not None:
             line["gather"] = gather_split
         print(json.dumps(line))
-    if world > 1:
+    if gathering:
+        for ln in lanes:
+            if ln.comm is not None:
+                ln.comm.close()
         dist.destroy_process_group()
 
 

@@ -98,6 +98,7 @@ def load():
     proto("dcs_timing_stride", i32, vp, i32)
     proto("dcs_timing_reset", i32, vp)
     proto("dcs_timing_query", i32, vp, i32, POINTER(c_double), POINTER(i64))
+    proto("dcs_debug_check_guards", i32, vp, POINTER(i64))
     _lib = lib
     return lib
 

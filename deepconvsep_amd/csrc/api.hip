@@ -4,7 +4,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "dcs_internal.h"
@@ -22,26 +25,109 @@ extern "C" const char* dcs_last_error(void) { return g_err; }
 extern "C" int dcs_version(void) { return 100; }
 
 // ------------------------------------------------------------------------------- buffers / timing
+namespace {
+struct GuardRegistry {
+    std::mutex mu;
+    std::vector<DcsBuffer*> live;
+};
+GuardRegistry& guard_registry() {
+    static GuardRegistry r;
+    return r;
+}
+size_t guard_bytes_env() {
+    static const size_t v = getenv("DCS_WS_GUARD") ? (size_t)atoll(getenv("DCS_WS_GUARD")) / 256 * 256 : 0;
+    return v;
+}
+int guard_poison_env() {
+    static const int v = getenv("DCS_WS_POISON") ? (atoi(getenv("DCS_WS_POISON")) & 0xff) : 0xff;
+    return v;
+}
+}  // namespace
+
 int DcsBuffer::ensure(size_t need) {
     if (need <= bytes) return DCS_OK;
     if (ptr) {
         // other work on the stream may still read the old block
         DCS_HIP(hipDeviceSynchronize());
-        void* old = ptr;
-        ptr = nullptr;
-        bytes = 0;
-        DCS_HIP(hipFree(old));
+        release();
     }
-    size_t want = need + need / 8;
-    DCS_HIP(hipMalloc(&ptr, want));
-    bytes = want;
+    const size_t want = need + need / 8;
+    const size_t g = guard_bytes_env();
+    if (g == 0) {
+        DCS_HIP(hipMalloc(&ptr, want));
+        base = ptr;
+        bytes = want;
+        return DCS_OK;
+    }
+    const size_t payload = (want + 255) / 256 * 256;
+    DCS_HIP(hipMalloc(&base, payload + 2 * g));
+    DCS_HIP(hipMemset(base, guard_poison_env(), payload + 2 * g));
+    DCS_HIP(hipDeviceSynchronize());
+    ptr = (char*)base + g;
+    bytes = payload;
+    guard = g;
+    GuardRegistry& r = guard_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (std::find(r.live.begin(), r.live.end(), this) == r.live.end()) r.live.push_back(this);
     return DCS_OK;
 }
 
 void DcsBuffer::release() {
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    bytes = 0;
+    if (base) (void)hipFree(base);
+    else if (ptr) (void)hipFree(ptr);
+    ptr = base = nullptr;
+    bytes = guard = 0;
+}
+
+DcsBuffer::~DcsBuffer() {
+    if (guard_bytes_env() == 0) return;
+    GuardRegistry& r = guard_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    r.live.erase(std::remove(r.live.begin(), r.live.end(), this), r.live.end());
+}
+
+long long dcs_buffers_check_guards(char* where, size_t where_len) {
+    GuardRegistry& r = guard_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    long long bad = 0;
+    const unsigned char poison = (unsigned char)guard_poison_env();
+    std::vector<unsigned char> h;
+    for (DcsBuffer* b : r.live) {
+        if (!b->base || b->guard == 0) continue;
+        h.resize(b->guard);
+        for (int side = 0; side < 2; ++side) {
+            const char* src = side == 0 ? (const char*)b->base : (const char*)b->ptr + b->bytes;
+            if (hipMemcpy(h.data(), src, b->guard, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            for (size_t i = 0; i < b->guard; ++i)
+                if (h[i] != poison) {
+                    if (bad == 0 && where)
+                        snprintf(where, where_len, "%s red zone of a %zu-byte scratch block, byte %zu (%s the block)",
+                                 side == 0 ? "leading" : "trailing", b->bytes, i, side == 0 ? "counted from the red zone's start, before" : "past the end of");
+                    ++bad;
+                }
+        }
+    }
+    return bad;
+}
+
+extern "C" int dcs_debug_check_guards(dcs_ctx* ctx, int64_t* n_blocks_out) {
+    if (!ctx) DCS_FAIL(DCS_EINVAL, "dcs_debug_check_guards: null context");
+    if (guard_bytes_env() == 0)
+        DCS_FAIL(DCS_EUNSUPPORTED, "dcs_debug_check_guards: the process was started without DCS_WS_GUARD=<bytes>");
+    DCS_ON_DEVICE(ctx->device);
+    DCS_HIP(hipDeviceSynchronize());
+    if (n_blocks_out) {
+        GuardRegistry& r = guard_registry();
+        std::lock_guard<std::mutex> lk(r.mu);
+        int64_t n = 0;
+        for (DcsBuffer* b : r.live) n += (b->base && b->guard) ? 1 : 0;
+        *n_blocks_out = n;
+    }
+    char where[200] = "";
+    const long long bad = dcs_buffers_check_guards(where, sizeof(where));
+    if (bad < 0) DCS_FAIL(DCS_EHIP, "dcs_debug_check_guards: copying a red zone failed");
+    if (bad > 0) DCS_FAIL(DCS_EHIP, "scratch red zones damaged: %lld bytes, first in the %s", bad, where);
+    return DCS_OK;
 }
 
 int DcsUploadRing::begin(size_t bytes, void** host_out, void** dev_out) {

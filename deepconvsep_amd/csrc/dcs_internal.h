@@ -72,12 +72,21 @@ struct DcsOncePerDevice {
 
 // A grow-only device scratch buffer.  Regions handed out keep their address until the
 // buffer has to grow (then `generation` changes and zero-initialised regions are re-zeroed).
+// Memory-safety aid (tests/test_gpu_guard.py): with DCS_WS_GUARD=<bytes> in the environment every block is allocated with
+// that many bytes of red zone on either side and the WHOLE allocation (red zones and payload) is filled with the byte
+// DCS_WS_POISON (default 0xFF: float / bf16 NaN, int64 -1) -- a kernel that reads scratch nobody wrote computes on
+// NaNs, and dcs_debug_check_guards() finds writes outside the block.
 struct DcsBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
+    void* base = nullptr;      // what hipMalloc returned (== ptr without red zones)
+    size_t guard = 0;          // red-zone bytes on either side of [ptr, ptr + bytes)
     int ensure(size_t need);
     void release();
+    ~DcsBuffer();              // leaves the guard registry (the memory itself is freed by release())
 };
+// number of damaged red-zone bytes over every live guarded DcsBuffer (0 = intact), < 0 on a HIP error
+long long dcs_buffers_check_guards(char* where, size_t where_len);
 
 // Small host tables (clip lengths, note rectangles) on their way to the device without a stream synchronisation in the
 // call: begin() hands out a pinned host slot of a ring (waiting, if ever, for the upload that used the slot kSlots calls

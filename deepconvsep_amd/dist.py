@@ -176,6 +176,8 @@ class RcclComm:
         import ctypes
         import torch
         from ._lib import check
+        if ctx.device_index != self.device:
+            raise ValueError("the communicator was made on GPU %d, the context lives on GPU %d" % (self.device, ctx.device_index))
         if not shard.is_contiguous():
             shard = shard.contiguous()
         receives = root < 0 or root == self.rank

@@ -88,6 +88,13 @@ class Context(object):
     def synchronize(self):
         _lib.check(self._lib.dcs_synchronize(self._h))
 
+    def check_guards(self):
+        """``dcs_debug_check_guards``: with ``DCS_WS_GUARD=<bytes>`` in the environment, verify the red zones around every
+        scratch block libdcs holds (raises on damage); returns the number of guarded blocks."""
+        n = c_int64()
+        _lib.check(self._lib.dcs_debug_check_guards(self._h, byref(n)))
+        return n.value
+
     # -- kernel timing (bench.py) ---------------------------------------------------------------
     def timing_stride(self, stride):
         _lib.check(self._lib.dcs_timing_stride(self._h, int(stride)))

@@ -270,6 +270,14 @@ DCS_API int dcs_timing_stride(dcs_ctx* ctx, int stride);
 DCS_API int dcs_timing_reset(dcs_ctx* ctx);
 DCS_API int dcs_timing_query(dcs_ctx* ctx, int which, double* avg_ms, int64_t* launches);
 
+/* ------------------------------------------------------------------ memory-safety aid (tests/test_gpu_guard.py) */
+/* With DCS_WS_GUARD=<bytes> in the environment (read once per process) every scratch block libdcs allocates -- the
+ * per-model workspace, the K-split partial sums, the clip / note tables -- sits between two red zones of that size and is
+ * born filled with the byte DCS_WS_POISON (default 0xFF: float NaN).  This call synchronises the device and verifies every
+ * live red zone: DCS_OK, DCS_EHIP with the first damaged byte in dcs_last_error(), DCS_EUNSUPPORTED without the switch.
+ * No reference counterpart (the reference is NumPy / Theano); n_blocks_out (nullable) = guarded blocks alive. */
+DCS_API int dcs_debug_check_guards(dcs_ctx* ctx, int64_t* n_blocks_out);
+
 #ifdef __cplusplus
 }
 #endif

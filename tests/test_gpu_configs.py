@@ -397,3 +397,135 @@ def test_dcs_gather_through_the_c_abi_with_a_one_rank_rccl_communicator():
             _lib.check(ctx._lib.dcs_gather(ctx._h, None, ctypes.c_void_p(pcm16.data_ptr()), 16, ctypes.c_void_p(full2.data_ptr()), -1))
     finally:
         comm.close()
+
+
+# ------------------------------------------------------------------ multi-GPU paths that switch themselves on
+# The build box and the driver's GPU tier have ONE MI355X, so everything above runs two ranks on one device over gloo.  The
+# tests below need nothing but a second GPU: on a multi-GPU node they run the real thing -- backend nccl (= RCCL over xGMI),
+# one device per rank, dcs_gather on a two-rank communicator -- and skip here.  No scaling curve is implied by them.
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+needs_two_gpus = pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+
+
+def _run_bench(n, extra, env_extra, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
+    env.pop("DCS_BENCH_SAME_DEVICE", None)
+    args = ["--gpus", str(n), "--steps", "6", "--warmup", "2", "--sat-tiles", "0", "--min-time", "0.02", "--legs", "",
+            "--no-cpu-baseline", "--no-host-fed", "--no-cli"] + extra
+    if n > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("impl,mode", [("dcs", "allgather"), ("dcs", "root"), ("torch", "allgather")])
+def test_bench_gather_code_path_with_a_world_of_one_rank(impl, mode):
+    """What a 1-GPU box can run of the N > 1 leg on the REAL backend: DCS_BENCH_FORCE_GATHER makes bench.py --gpus 1 convert
+    every launch group's PCM to int16 and push it through the collective of a one-rank world -- with --gather-impl dcs that is
+    dcs_gather (the C-ABI entry of SURVEY 8b) on an RCCL communicator per HIP stream, inside the timed region."""
+    line = _run_bench(1, ["--gather", mode, "--gather-impl", impl], {"DCS_BENCH_FORCE_GATHER": "1", "DCS_BENCH_CHECK_GATHER": "1"})
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["gather_check"] == "ok"
+    assert line["gather"]["mode"] == mode and line["gather"]["impl"].startswith("dcs_gather" if impl == "dcs" else "torch.distributed")
+    assert line["gather"]["ms_per_group_collective_alone"] > 0
+    assert line["parity_check"]["ok"] is True
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("impl,mode", [("torch", "allgather"), ("torch", "root"), ("dcs", "allgather"), ("dcs", "root")])
+def test_bench_two_gpus_over_rccl_gather_is_exact(impl, mode):
+    """bench.py --gpus 2 exactly as the driver launches it, backend nccl, one GPU per rank: the gathered int16 PCM holds
+    every rank's own PCM bit for bit (DCS_BENCH_CHECK_GATHER), through torch.distributed and through dcs_gather."""
+    line = _run_bench(2, ["--gather", mode, "--gather-impl", impl], {"DCS_BENCH_CHECK_GATHER": "1"})
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["gather_check"] == "ok"
+    assert line["gather"]["mode"] == mode and line["gather"]["round_ms_without_gather"] > 0
+    assert line["parity_check"]["ok"] is True and line["parity_check"]["ranks"] == 2
+
+
+def _rccl_pair_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)         # side channel for the unique id only
+    from deepconvsep_amd.dist import RcclComm
+    from deepconvsep_amd.runtime import Context, pcm_to_int16
+    ctx = Context(rank)
+    comm = RcclComm.from_process_group(device=ctx)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(100 + rank)
+        pcm = (torch.rand((4, 70001), generator=g) * 2 - 1).to(ctx.device)
+        mine = pcm_to_int16(ctx, pcm)
+        full = comm.gather(ctx, mine, root=-1)                               # every rank receives
+        at_root = comm.gather(ctx, mine, root=1)                             # rank 1 is the writer
+        torch.cuda.synchronize()
+        ret["all_%d" % rank] = full.cpu().numpy()
+        ret["mine_%d" % rank] = mine.cpu().numpy()
+        ret["root_%d" % rank] = None if at_root is None else at_root.cpu().numpy()
+    finally:
+        comm.close()
+        dist.destroy_process_group()
+
+
+@needs_two_gpus
+def test_dcs_gather_on_a_two_rank_rccl_communicator():
+    """dcs_gather (include/dcs.h) with TWO ranks on two GPUs: the all-gather form on every rank and the root form on the
+    writer deliver both ranks' int16 PCM bit for bit, in rank order; a non-root rank of the root form gets nothing."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    ret = ctxm.Manager().dict()
+    mp.spawn(_rccl_pair_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    want = np.stack([ret["mine_0"], ret["mine_1"]])
+    assert not np.array_equal(want[0], want[1]) and want.dtype == np.int16
+    for r in range(2):
+        assert np.array_equal(ret["all_%d" % r], want)
+    assert ret["root_0"] is None and np.array_equal(ret["root_1"], want)
+
+
+def _long_file_nccl_worker(rank, world, port, audio, params, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from deepconvsep_amd.dist import separate_long_file
+    from deepconvsep_amd.runtime import default_context
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, 513, 1024, 512, np.hanning, device=rank)
+    dev = default_context(rank).to_device(audio, np.float32)
+
+    def fn(seg):
+        out = sep.net.separate(sep.plan, seg.contiguous(), 25, sep.tiler, 0.3)
+        sep.ctx.synchronize()                                  # the collective runs on torch's stream
+        return out
+    out = separate_long_file(fn, dev, 1024, 512, 30, 25)
+    ret["device_%d" % rank] = int(out.device.index)
+    if rank == 0:
+        ret["pcm"] = out.cpu().numpy()
+    dist.destroy_process_group()
+
+
+@needs_two_gpus
+def test_long_file_sharded_over_two_gpus_with_nccl_device_tensors():
+    """separate_long_file over backend nccl: each rank separates its halo-extended share on ITS GPU, the owned PCM ranges are
+    all-gathered as device tensors over RCCL; equals the single-GPU separation."""
+    import torch.multiprocessing as mp
+    params = synth_params("dsd", 30, 513, seed=2)
+    audio = synth_audio(6 * 44100, seed=8)
+    whole = dcs.Separator("dsd", params, 0.3, 30, 25, 32, 513, 1024, 512, np.hanning).separate(audio)
+    ctxm = mp.get_context("spawn")
+    ret = ctxm.Manager().dict()
+    mp.spawn(_long_file_nccl_worker, args=(2, _free_port(), audio, params, ret), nprocs=2, join=True)
+    assert ret["device_0"] == 0 and ret["device_1"] == 1
+    assert ret["pcm"].shape == whole.shape and np.max(np.abs(ret["pcm"] - whole)) < 2e-6
