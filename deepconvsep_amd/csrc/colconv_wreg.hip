@@ -288,7 +288,18 @@ struct DcsDecoderFused {
     int64_t n_runs;
 };
 
-template <int KH, int H>
+// CL (round 4): the dense layer's output arrives CHANNELS-LAST, in[image][row][x][Cin] (its weight columns are permuted when
+// the bf16 planes are packed, dcs_gemm_pack_bq), so a lane's eight channels of a (row, x) are 32 consecutive bytes -- four
+// 8-byte loads, 44 per column block instead of 88 four-byte ones, and a wave's loads of a row cover ONE contiguous run of
+// 16 x Cin floats.  With the channel-first layout (rows of W = 505 floats: every 64-byte segment of 16 x starts on a 4-byte
+// boundary and straddles two lines) the counters showed 2.68 x the algorithmic bytes moving (profiles/r03_traffic.json).
+// S2H (round 4, the default of the f16 switch; DCS_DECODER_S2=bf16x3 selects the three-way split): stage 2 -- the
+// transposed conv1 -- takes f16 inputs like stage 1: G is rounded to f16 once (it is the output of an f16-input
+// convolution already) and meets the f16 conv1 filter in ONE MFMA per tap half instead of six bf16 ones behind a 52-
+// instruction operand split per row -- 500 instead of 800 MFMAs and ~1 500 fewer vector instructions per column block.
+// BASELINE configs[3] names an "fp16 MFMA conv path"; its stated tolerance (network output 2e-3) is unchanged, the
+// f32-class result of this graph is the path with the switch off.
+template <int KH, int H, bool CL, bool S2H>
 __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
                                                                          const DcsDecoderFused d) {
     constexpr int HO = H + KH - 1, PH = KH - 1;
@@ -310,11 +321,11 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
         w[u][0] = as_h8(Wq[(u * 2) * 64 + lane]);
         w[u][1] = as_h8(Wq[(u * 2 + 1) * 64 + lane]);
     }
-    u32x4 w1[3][2];
+    u32x4 w1[S2H ? 1 : 3][2];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        w1[p][0] = d.Wq1[(p * 2) * 64 + lane];
-        w1[p][1] = d.Wq1[(p * 2 + 1) * 64 + lane];
+    for (int p = 0; p < (S2H ? 1 : 3); ++p) {
+        w1[p][0] = d.Wq1[((S2H ? 3 : p) * 2) * 64 + lane];          // section 3 of the packed array: the f16 fragments
+        w1[p][1] = d.Wq1[((S2H ? 3 : p) * 2 + 1) * 64 + lane];
     }
     // g.bias is not read: an InverseLayer has no bias (the generic path's vector for this layer is all zeros)
     const int W = g.W, n_xb = g.n_xb, F = d.F;
@@ -327,14 +338,36 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
     const int rt = lane >> 5, rq = lane & 31;
     const f32x4* pr = Pb + rt * 256 + (rq < 23 ? rq : 22) + 8;
     float raw[H][8];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // CL: the lane's channels 8 kq .. 8 kq + 7 as four pairs; pairs past Cin (30: the last pair of kq = 3) re-read the pair
+    // before them -- finite numbers that meet zero weights -- instead of running into the next position / past the buffer
+    const int Cin = g.Cin;
+    int pair_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 8 * kq + 2 * q;
+        pair_off[q] = c + 2 <= Cin ? c : Cin - 2;
+    }
 #define DCS_FETCH(img_, blk_)                                                                           \
     {                                                                                                   \
         const int xl_ = (blk_) * 16 + fi;                                                               \
-        const LaneIn li_ = lane_in(g, kq, xl_ < W ? xl_ : W - 1, HW);                                   \
         const float* ib_ = g.in + (img_) * g.in_n_stride;                                               \
-        _Pragma("unroll") for (int h = 0; h < H; ++h) {                                                 \
-            const float* ir_ = ib_ + h * W;                                                             \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) raw[h][j] = ir_[li_.idx[j]];                  \
+        if constexpr (CL) {                                                                             \
+            const float* ip_ = ib_ + (xl_ < W ? xl_ : W - 1) * Cin;                                     \
+            _Pragma("unroll") for (int h = 0; h < H; ++h) {                                             \
+                const float* ir_ = ip_ + h * W * Cin;                                                   \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                         \
+                    const f32x2 v_ = *reinterpret_cast<const f32x2*>(ir_ + pair_off[q]);                \
+                    raw[h][2 * q] = v_[0];                                                              \
+                    raw[h][2 * q + 1] = v_[1];                                                          \
+                }                                                                                       \
+            }                                                                                           \
+        } else {                                                                                        \
+            const LaneIn li_ = lane_in(g, kq, xl_ < W ? xl_ : W - 1, HW);                               \
+            _Pragma("unroll") for (int h = 0; h < H; ++h) {                                             \
+                const float* ir_ = ib_ + h * W;                                                         \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) raw[h][j] = ir_[li_.idx[j]];              \
+            }                                                                                           \
         }                                                                                               \
     }
     for (int64_t run = (int64_t)blockIdx.x * 4 + wave; run < d.n_runs; run += stride) {
@@ -354,6 +387,11 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
             }
             const bool x_ok = b * 16 + fi < W;               // columns past W (last block only) must not reach the rows
             const bool edge = b * 16 + 16 > W;
+            if (S2H && edge) {                               // wave-uniform.  No bias in either InverseLayer: a zero input column
+#pragma unroll                                               // gives a zero G column and zero products -- masked once, at the source
+                for (int h = 0; h < H; ++h)
+                    if (!x_ok) a[h] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
             const bool keep = b >= b_lo;                     // wave-uniform: false for the recomputed block
             const int f0 = 4 * (b * 16 + rq);
             float* orow = d.out + (img * HO + rt) * (int64_t)F + f0;
@@ -381,22 +419,28 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
                         gv[e] = acc[t][0][e];
                         gv[4 + e] = acc[t][1][e];
                     }
-                    u32x4 g0, g1, g2;
-                    split8(gv, g0, g1, g2);
+                    if constexpr (S2H) {
+                        const h8 gh = round8(gv);
 #pragma unroll
-                    for (int mh = 0; mh < 2; ++mh) {
-                        f32x4 p = zero4;
-                        p = mma_bf(w1[2][mh], g0, p);          // smallest products first
-                        p = mma_bf(w1[0][mh], g2, p);
-                        p = mma_bf(w1[1][mh], g1, p);
-                        p = mma_bf(w1[1][mh], g0, p);
-                        p = mma_bf(w1[0][mh], g1, p);
-                        p = mma_bf(w1[0][mh], g0, p);
-                        if (edge) {                            // wave-uniform: only the last block of an image
+                        for (int mh = 0; mh < 2; ++mh) pw[t * 256 + mh * 128] = mma(as_h8(w1[0][mh]), gh, zero4);
+                    } else {
+                        u32x4 g0, g1, g2;
+                        split8(gv, g0, g1, g2);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) p[e] = x_ok ? p[e] : 0.f;
+                        for (int mh = 0; mh < 2; ++mh) {
+                            f32x4 p = zero4;
+                            p = mma_bf(w1[2][mh], g0, p);          // smallest products first
+                            p = mma_bf(w1[0][mh], g2, p);
+                            p = mma_bf(w1[1][mh], g1, p);
+                            p = mma_bf(w1[1][mh], g0, p);
+                            p = mma_bf(w1[0][mh], g1, p);
+                            p = mma_bf(w1[0][mh], g0, p);
+                            if (edge) {                            // wave-uniform: only the last block of an image
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) p[e] = x_ok ? p[e] : 0.f;
+                            }
+                            pw[t * 256 + mh * 128] = p;
                         }
-                        pw[t * 256 + mh * 128] = p;
                     }
                 }
                 asm volatile("" ::: "memory");               // the pieces of both rows are written (LDS is in order per wave)
@@ -472,8 +516,9 @@ bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images
 
 // W1p: [nf1][C = 1][32 taps] (tap axis zero-padded) -> [3 planes][2 tap halves][64 lanes][8] bf16: lane (fi, kg) of tap
 // half mh holds, for row (mm = fi / 4 + 4 mh, r = fi % 4), the k slots j <-> ci = 4 kg + j (j < 4) | 16 + 4 kg + j - 4
+// ... followed by the same fragments rounded to f16 ([2 tap halves][64 lanes][8]: section 3, the S2H kernel's operand)
 void dcs_decoder_fused_pack(const float* W1p, int nf1, std::vector<uint16_t>* out) {
-    out->assign((size_t)3 * 2 * 64 * 8, 0);
+    out->assign((size_t)4 * 2 * 64 * 8, 0);
     for (int mh = 0; mh < 2; ++mh)
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
@@ -481,6 +526,12 @@ void dcs_decoder_fused_pack(const float* W1p, int nf1, std::vector<uint16_t>* ou
                 const int ci = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
                 const int tap = 4 * ((fi >> 2) + 4 * mh) + (fi & 3);
                 float r = ci < nf1 ? W1p[(size_t)ci * 32 + tap] : 0.f;
+                {
+                    const _Float16 hv = (_Float16)r;
+                    uint16_t hb;
+                    memcpy(&hb, &hv, 2);
+                    (*out)[(((size_t)3 * 2 + mh) * 64 + lane) * 8 + j] = hb;
+                }
                 for (int p = 0; p < 3; ++p) {
                     uint32_t bits;
                     memcpy(&bits, &r, 4);
@@ -500,8 +551,10 @@ bool dcs_decoder_fused_ok(const DcsColConv& a, int F) {
 }
 
 bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out,
-                              int F) {
+                              int F, bool in_channels_last) {
     if (!Wq || !Wq1 || !dcs_decoder_fused_ok(a, F)) return false;
+    // channels-last input: pairs of channels are fetched as 8-byte loads
+    if (in_channels_last && ((a.Cin & 1) || (a.in_n_stride & 1) || (reinterpret_cast<uintptr_t>(a.in) & 7))) return false;
     if (n_images <= 0) return true;
     // runs per image: fewest (rounds of waves) x (blocks per run + the recomputed one)
     const int64_t n_waves = (int64_t)ctx->n_cu * 4;
@@ -519,7 +572,13 @@ bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_image
     d.runs_per_image = best;
     d.n_runs = n_images * best;
     const unsigned grid = (unsigned)std::min<int64_t>(dcs_cdiv(d.n_runs, 4), ctx->n_cu);
-    hipLaunchKernelGGL((colconv_deconv1_fused_kernel<20, 11>), dim3(grid), dim3(kThreads), 0, ctx->stream, a,
-                       reinterpret_cast<const u32x4*>(Wq), d);
+    // DCS_DECODER_S2=bf16x3: the transposed conv1 inside the kernel on three-way split operands (f32-class, round 2/3)
+    static const bool s2h = !(getenv("DCS_DECODER_S2") && strcmp(getenv("DCS_DECODER_S2"), "bf16x3") == 0);
+    const u32x4* wq = reinterpret_cast<const u32x4*>(Wq);
+#define DCS_GO(CL_, S2H_) \
+    hipLaunchKernelGGL((colconv_deconv1_fused_kernel<20, 11, CL_, S2H_>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, d)
+    if (in_channels_last) { if (s2h) DCS_GO(true, true); else DCS_GO(true, false); }
+    else { if (s2h) DCS_GO(false, true); else DCS_GO(false, false); }
+#undef DCS_GO
     return true;
 }

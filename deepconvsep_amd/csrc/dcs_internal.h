@@ -196,13 +196,15 @@ struct DcsGemm {
     // set by the launcher only: K split over workgroups (few rows, very long K -- the 166 650-wide dense layer of
     // the Bach10 graph): slice z covers [z*kchunk, (z+1)*kchunk) and writes raw sums to partial[z][M][n_cols]
     float* partial; int kchunk;
+    int xcd_slices;     // K-split launches: map (slice, tile) -> workgroup so that the tiles of a slice share an XCD (gemm_rows_kernel)
     // optional: B split into three bf16 planes by dcs_gemm_pack_bq (gemm_bf16x3.hip); launches that fill the chip then
     // run on the bf16 matrix pipe with f32-class results
     const void* Bq;
 };
 int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag);
 size_t dcs_gemm_bq_bytes(int K, int n_cols);
-int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d);   // enqueued on the ctx stream
+// enqueued on the ctx stream; perm_c > 0: columns re-ordered from [channel perm_c][position perm_p] to [position][channel]
+int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d, int perm_c = 0, int perm_p = 0);
 bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g);
 struct DcsGemmBranches {         // (B planes, bias, C) of up to 4 GEMMs that share A and shape
     int n;

@@ -37,8 +37,24 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // K-split launches (gridDim.z slices): the row x column tiles of ONE K slice read the same A columns and B rows, so
+    // they must run on one XCD, close in time, for a slice to come from HBM once and from that XCD's L2 afterwards.
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id: XCD x takes a contiguous run of (slice, tile) pairs.
+    // (Counters before, Bach10 bottleneck 167 x 166 650 x 256 as 3 x 4 tiles x 64 slices: 929 MB moved for 282 MB of
+    // operands -- A fetched by each of the 4 column tiles, B by each of the 3 row tiles, every one on another XCD.)
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.partial && g.xcd_slices) {
+        const unsigned tiles = gridDim.x * gridDim.y, total = tiles * gridDim.z;
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const unsigned xcd = lin & 7, slot = lin >> 3, base = total >> 3, rem = total & 7;
+        const unsigned virt = xcd * base + (xcd < rem ? xcd : rem) + slot;     // XCD x owns base + (x < rem) virtual ids
+        bz = virt / tiles;
+        const unsigned t = virt - bz * tiles;
+        by = t / gridDim.x;
+        bx = t - by * gridDim.x;
+    }
+    const int64_t m0 = (int64_t)bx * BM;
+    const int n0 = by * BN;
     // kernel arguments as scalars (taking the struct's address would spill it to scratch)
     const int gK = g.K, gldb = g.ldb;
     const int64_t gM = g.M;
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
     for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // K tiles of this workgroup: all of them, or slice blockIdx.z of a K-split launch (kchunk % BK == 0)
-    const int kt0 = g.partial ? (int)blockIdx.z * (g.kchunk / BK) : 0;
+    const int kt0 = g.partial ? (int)bz * (g.kchunk / BK) : 0;
     int nkt = (gK + BK - 1) / BK;
     if (g.partial && kt0 + g.kchunk / BK < nkt) nkt = kt0 + g.kchunk / BK;
     if (kt0 < nkt) DCS_LOAD_TILES(kt0)
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int64_t row = m0 + r * 16 + kq * 4 + e;
-                if (row < g.M) g.partial[((int64_t)blockIdx.z * g.M + row) * g.n_cols + col] = acc[r][e];
+                if (row < g.M) g.partial[((int64_t)bz * g.M + row) * g.n_cols + col] = acc[r][e];
             }
     } else if (col < g.n_store) {
         const float bias = g.bias ? g.bias[col] : 0.f;
@@ -315,6 +331,8 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
             DcsGemm q = g;
             q.partial = (float*)ctx->gemm_ws.ptr;
             q.kchunk = kchunk;
+            static const bool xcd_env = !(getenv("DCS_GEMM_KSPLIT_XCD") && atoi(getenv("DCS_GEMM_KSPLIT_XCD")) == 0);
+            q.xcd_slices = xcd_env ? 1 : 0;
             // 64 x 64 LDS tiles reuse every operand 4x more often than the 16 x 16 register tiles (which stream A and B
             // from L2 with 4 flop/B): worth it from a few row groups on
             if (tiled)

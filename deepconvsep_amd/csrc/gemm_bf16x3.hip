@@ -49,20 +49,24 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// B f32 [K rows][ldb] (rows past K are read as zero) -> Bq[kt][plane][n_cols][4] pieces
+// B f32 [K rows][ldb] (rows past K are read as zero) -> Bq[kt][plane][n_cols][4] pieces.  perm_c > 0: output column
+// j < perm_c * perm_p is source column (j % perm_c) * perm_p + j / perm_c -- a [channel][position] column axis re-ordered
+// to [position][channel] (channels-last output of a dense layer whose consumer reads a position's channels together)
 __global__ __launch_bounds__(kThreads) void gemm_pack_bq_kernel(const float* __restrict__ B, int K, int ldb, int n_cols,
-                                                                u32x4* __restrict__ Bq, int64_t n_pieces /* kt * n_cols * 4 */) {
+                                                                u32x4* __restrict__ Bq, int64_t n_pieces /* kt * n_cols * 4 */,
+                                                                int perm_c, int perm_p) {
     const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;   // (kt, n, kq), n fastest within kq? -> kq fastest
     if (idx >= n_pieces) return;
     const int kq = (int)(idx & 3);
     const int64_t t = idx >> 2;
     const int n = (int)(t % n_cols);
     const int64_t kt = t / n_cols;
+    const int ns = (perm_c > 0 && n < perm_c * perm_p) ? (n % perm_c) * perm_p + n / perm_c : n;
     f32x4 x0, x1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int64_t k = kt * 32 + kq * 8 + j;
-        const float v = k < K ? B[k * ldb + n] : 0.f;
+        const float v = k < K ? B[k * ldb + ns] : 0.f;
         if (j < 4) x0[j] = v; else x1[j - 4] = v;
     }
     u32x4 p0, p1, p2;
@@ -329,10 +333,11 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
 
 size_t dcs_gemm_bq_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * 3 * (size_t)n_cols * 4 * 16; }
 
-int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d) {
+int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d, int perm_c, int perm_p) {
     const int64_t n_pieces = (int64_t)((K + 31) / 32) * n_cols * 4;
+    if (perm_c > 0 && (int64_t)perm_c * perm_p > n_cols) DCS_FAIL(DCS_EINVAL, "dcs_gemm_pack_bq: permutation wider than B");
     hipLaunchKernelGGL(gemm_pack_bq_kernel, dim3((unsigned)dcs_cdiv(n_pieces, kThreads)), dim3(kThreads), 0, ctx->stream, B_d, K,
-                       ldb, n_cols, reinterpret_cast<u32x4*>(Bq_d), n_pieces);
+                       ldb, n_cols, reinterpret_cast<u32x4*>(Bq_d), n_pieces, perm_c, perm_p);
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }

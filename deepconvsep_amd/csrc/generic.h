@@ -60,8 +60,9 @@ bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images
 // InverseLayer(conv2) + InverseLayer(conv1) in one kernel (Bach10 graph, f16 switch on): out [image][Ho][F]
 void dcs_decoder_fused_pack(const float* W1p, int nf1, std::vector<uint16_t>* out);
 bool dcs_decoder_fused_ok(const DcsColConv& a, int F);
+// in_channels_last: a.in is [image][H][W][Cin] (the dense layer wrote a position's channels together) instead of [image][Cin][H][W]
 bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out,
-                              int F);
+                              int F, bool in_channels_last = false);
 
 int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int F,
                        const std::vector<std::vector<float>>& params, DcsGenericNet** out);

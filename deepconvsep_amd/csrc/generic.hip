@@ -1283,6 +1283,8 @@ struct DcsGenericNet {
     void* Bdq[4] = {nullptr, nullptr, nullptr, nullptr};  // per-source dense weights as bf16 planes (gemm_bf16x3.hip)
     bool bdq_failed = false;                              // the planes did not fit in memory: the dense layers stay on the f32 GEMM
     float* biasd[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* biasd_cl[4] = {nullptr, nullptr, nullptr, nullptr};   // the same biases in [position][channel] order (channels-last D)
+    bool bdq_cl = false;                                         // column order the bf16 planes Bdq are packed in
     float* bout = nullptr;
     DcsBuffer ws;
     float* rise_d = nullptr;
@@ -1487,6 +1489,13 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
             memcpy(&Bd[(size_t)h * g->flat64], &P[8 + 2 * s][(size_t)h * d.flat], d.flat * sizeof(float));
         memcpy(bd.data(), P[9 + 2 * s].data(), d.flat * sizeof(float));
         UP(g->Bd[s], Bd) UP(g->biasd[s], bd)
+        {
+            // channels-last order of the same bias (see forward_chunk: the fused decoder reads D as [row][x][channel])
+            std::vector<float> bd_cl(bd);
+            const int Cc = d.nf2, Pp = d.h2 * d.w2;
+            for (int j = 0; j < Cc * Pp; ++j) bd_cl[j] = bd[(size_t)(j % Cc) * Pp + j / Cc];
+            UP(g->biasd_cl[s], bd_cl)
+        }
     }
     std::vector<float> bout(P[8 + 2 * d.n_fc]);
     UP(g->bout, bout)
@@ -1505,7 +1514,8 @@ void dcs_generic_destroy(DcsGenericNet* g) {
     if (!g) return;
     void* ptrs[] = {g->Wpc_q3, g->Wpc_t_q3, g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W1dq, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
-                    g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3]};
+                    g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3], g->biasd_cl[0], g->biasd_cl[1],
+                    g->biasd_cl[2], g->biasd_cl[3]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1721,23 +1731,43 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     }
     // per-source dense (rectify): D[n][branch][flat_p]; aliased branches (none in these graphs) would reuse a layer
     if (g->flat_p != d.flat) DCS_HIP(hipMemsetAsync(D, 0, (size_t)n * NB * g->flat_p * 4, ctx->stream));
+    // Will both InverseLayers run as ONE kernel (Bach10 graph with the f16 switch)?  Known before the dense layers run, and it
+    // decides their output layout: the fused decoder reads a position's channels together, so D is written CHANNELS-LAST
+    // ([branch][row][x][channel]) by packing the bf16 planes of the dense weights with permuted columns (DCS_DECODER_CL=0:
+    // channel-first as every other consumer takes it).
+    bool fuse_planned = false;
+    if (g->use_colconv && g->conv_f16 && g->W1q && g->Wcol_t_r) {
+        ColConvArgs c0{};
+        c0.Cin = d.nf2; c0.H = d.h2; c0.W = d.w2; c0.Cout = d.nf1; c0.Ho = tc; c0.ph = d.kh2 - 1; c0.kh = d.kh2;
+        fuse_planned = dcs_decoder_fused_ok(c0, F);
+    }
+    static const bool cl_env = !(getenv("DCS_DECODER_CL") && atoi(getenv("DCS_DECODER_CL")) == 0);
+    const bool want_cl = fuse_planned && cl_env && (d.nf2 & 1) == 0 && (g->flat_p & 1) == 0;
     // the bf16 planes of the dense weights, on first need: a launch of >= 128 rows against >= 1024 columns (smaller ones stay
     // on the f32 kernels whatever is packed, dcs_launch_gemm_bf16x3); same stream, so no synchronisation
     static const bool bf16_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
     if (bf16_on && n >= 128 && g->flat64 >= 1024) {
+        const int rows = (int)dcs_round_up(g->hid64, 128);
+        const int pc = want_cl ? d.nf2 : 0, pp = want_cl ? d.h2 * d.w2 : 0;
+        if (g->bdq_cl != want_cl) {
+            // the precision switch was flipped since the planes were packed: the existing blocks are re-packed in place, in
+            // the other column order (stream-ordered behind every earlier use)
+            for (int s2 = 0; s2 < d.n_fc; ++s2)
+                if (g->Bdq[s2]) DCS_CHECK(dcs_gemm_pack_bq(ctx, g->Bd[s2], rows, g->flat64, g->flat64, g->Bdq[s2], pc, pp));
+            g->bdq_cl = want_cl;
+        }
         for (int s2 = 0; s2 < d.n_fc && !g->bdq_failed; ++s2) {
             if (g->Bdq[s2]) continue;
             // published only when packed: a failed pack must not leave a non-null, unpacked plane set behind (later calls
             // would multiply by uninitialised memory).  Out of memory here (~1 GB for Bach10, outside the chunk budget) is
             // not an error of the forward pass: the layer stays on the f32 GEMM (q.Bq == nullptr) for the model's lifetime.
-            const int rows = (int)dcs_round_up(g->hid64, 128);
             void* planes = nullptr;
             if (hipMalloc(&planes, dcs_gemm_bq_bytes(rows, g->flat64)) != hipSuccess) {
                 (void)hipGetLastError();
                 g->bdq_failed = true;
                 break;
             }
-            const int rc = dcs_gemm_pack_bq(ctx, g->Bd[s2], rows, g->flat64, g->flat64, planes);
+            const int rc = dcs_gemm_pack_bq(ctx, g->Bd[s2], rows, g->flat64, g->flat64, planes, pc, pp);
             if (rc != DCS_OK) {
                 (void)hipFree(planes);
                 return rc;
@@ -1745,6 +1775,9 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             g->Bdq[s2] = planes;
         }
     }
+    // planes in channels-last order serve the all-branches launch below and nothing else: a launch that falls back to the
+    // per-branch GEMMs runs them on the f32 weights (channel-first), and the decoder is told which layout it got
+    const bool planes_cl = g->bdq_cl;
     bool branches_done = false;
     if (NB > 1) {                                        // every live branch in one launch when the shape allows it
         DcsGemm q{};
@@ -1755,18 +1788,19 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         br.n = NB;
         for (int b = 0; b < NB; ++b) {
             const int s = d.branch_fc[b];
-            br.Bq[b] = g->Bdq[s]; br.bias[b] = g->biasd[s]; br.C[b] = D + (int64_t)b * g->flat_p;
+            br.Bq[b] = g->Bdq[s]; br.bias[b] = planes_cl ? g->biasd_cl[s] : g->biasd[s]; br.C[b] = D + (int64_t)b * g->flat_p;
         }
         q.B = g->Bd[d.branch_fc[0]]; q.bias = br.bias[0]; q.Bq = br.Bq[0]; q.C = br.C[0];
         DcsTimer tm(ctx, DCS_TAG_FC1X);
         branches_done = dcs_launch_gemm_bf16x3_skinny(ctx, q, &br);
         if (branches_done) tm.done(); else tm.cancel();
     }
+    const bool d_cl = branches_done && planes_cl;        // layout of D as the decoder will find it
     for (int b = 0; b < NB && !branches_done; ++b) {
         const int s = d.branch_fc[b];
         DcsGemm q{};
         q.A = Z; q.lda = g->hid64; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
-        q.B = g->Bd[s]; q.ldb = g->flat64; q.bias = g->biasd[s]; q.Bq = g->Bdq[s];
+        q.B = g->Bd[s]; q.ldb = g->flat64; q.bias = g->biasd[s]; q.Bq = planes_cl ? nullptr : g->Bdq[s];
         q.C = D + (int64_t)b * g->flat_p; q.ldc = (int64_t)NB * g->flat_p; q.c_gdiv = 1 << 30; q.c_gmul = 0;
         q.M = n; q.n_cols = g->flat64; q.n_store = d.flat; q.K = g->hid64; q.relu = 1; q.a_vec = 1;
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC1X));
@@ -1787,10 +1821,12 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.ph = d.kh2 - 1; c.kh = d.kh2; c.n_xb = (c.W + 15) / 16;
             decoder_fused = g->conv_f16 && g->W1q && g->Wcol_t_r && dcs_decoder_fused_ok(c, F);
         }
+        if (d_cl && !decoder_fused) DCS_FAIL(DCS_EHIP, "generic graph: channels-last dense output without the fused decoder");
         if (decoder_fused) {                                 // both InverseLayers in one kernel: o directly
             DcsTimer tmf(ctx, DCS_TAG_DECODER);
-            dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F);
+            const bool ok = dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F, d_cl);
             tmf.done();
+            if (!ok) DCS_FAIL(DCS_EHIP, "generic graph: the fused decoder refused a launch it had accepted (channels-last %d)", (int)d_cl);
         }
         DcsTimer tm(ctx, decoder_fused ? -1 : DCS_TAG_DECONV2);
         if (decoder_fused) {

@@ -25,8 +25,11 @@ def main(argv=None):
     ap.add_argument("-m", "--mfile", required=True)
     ap.add_argument("-o", "--odir", required=True)
     ap.add_argument("-g", "--group", type=int, default=8, help="files read ahead and separated together")
+    ap.add_argument("--stats", action="store_true",
+                    help="print one JSON line at the end: files, seconds from model-ready to the last wav written, ms per file")
     ap.add_argument("files", nargs="+")
     args = ap.parse_args(argv)
+    import time
 
     import torch
     from deepconvsep_amd import separation as sp
@@ -37,6 +40,8 @@ def main(argv=None):
     frame, hop, window, overlap, bins = sp._SCRIPT_DEFAULTS[args.arch]
     sep = sp.Separator(args.arch, sp.load_model(args.mfile), 0.3, 30, overlap, 32, bins, frame, hop, window)
     mine = args.files[rank::world]
+    torch.cuda.synchronize()
+    t_ready = time.perf_counter()          # interpreter, torch import, model upload and plan are behind us
 
     failed = []
 
@@ -85,6 +90,11 @@ def main(argv=None):
             f.result()
     for path, exc in failed:
         print("%s: %s: %s" % (path, type(exc).__name__, exc), file=sys.stderr)
+    if args.stats:
+        import json
+        el = time.perf_counter() - t_ready
+        print(json.dumps({"rank": rank, "files": len(mine), "failed": len(failed), "seconds_after_model_ready": round(el, 4),
+                          "ms_per_file": round(el / max(1, len(mine)) * 1e3, 3), "group": G}))
     return 1 if failed else 0
 
 

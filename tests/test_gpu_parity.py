@@ -938,6 +938,54 @@ def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
     assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
 
 
+_CL_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from deepconvsep_amd.runtime import Network, default_context
+from deepconvsep_amd.synth import synth_params
+z = np.load(sys.argv[2])
+ctx = default_context()
+F = int(z['F'])
+net = Network(ctx, 'bach10', synth_params('bach10', 30, F, seed=4), 30, F)
+net.set_conv_precision('f16')
+x = ctx.to_device(z['x'], np.float32)
+p = net.forward_raw(x).cpu().numpy()
+net.set_conv_precision('f32')                      # flips the layout of the packed planes back ...
+q = net.forward_raw(x).cpu().numpy()
+net.set_conv_precision('f16')                      # ... and forth: the planes are re-packed in place
+p2 = net.forward_raw(x).cpu().numpy()
+np.savez(sys.argv[3], p=p, q=q, same=np.array_equal(p, p2))
+"""
+
+
+def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
+    """From 128 tiles on the Bach10 graph with the f16 switch packs the bf16 planes of its per-source dense layers with
+    permuted columns, so that D comes out channels-last and the fused decoder reads a position's channels as 32 consecutive
+    bytes (round 4).  140 tiles at F = 257: the default (channels-last) and DCS_DECODER_CL=0 (channel-first) must give the
+    SAME bits -- same products, same accumulation order, only the addresses differ -- and meet the f16 path's stated 2e-3
+    against the oracle; flipping the precision switch re-packs the planes in place (f32 result within 1e-4)."""
+    import subprocess
+    F, n = 257, 140
+    x = _tiles("bach10", n, 30, F, seed=21)
+    want = net_ref.forward("bach10", synth_params("bach10", 30, F, seed=4), x.astype(np.float64), inverse='explicit').numpy()
+    f = tmp_path / "case.npz"
+    np.savez(f, x=x, F=F)
+    res = {}
+    for name, env in (("cl", {}), ("cf", {"DCS_DECODER_CL": "0"})):
+        child_env = dict(os.environ)
+        child_env.update(env)
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _CL_CHILD, ROOT, str(f), out], env=child_env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-1500:])
+        res[name] = np.load(out)
+    assert np.max(np.abs(res["cl"]["p"] - want)) < 2e-3
+    assert np.max(np.abs(res["cl"]["q"] - want)) < 1e-4           # f32-class after the switch back
+    assert bool(res["cl"]["same"])                                  # and the f16 result again, to the bit, after re-packing
+    assert np.array_equal(res["cl"]["p"], res["cf"]["p"])
+    assert np.array_equal(res["cl"]["q"], res["cf"]["q"])
+
+
 @pytest.mark.parametrize("env", [
     {"DCS_FINAL_CBW": "2"}, {"DCS_FINAL_CBW": "1"},               # 128-bin workgroups (bf16x3 kernel, G split by a pass) / 64-bin (f32)
     {"DCS_FINAL_CBW": "2", "DCS_FINAL_BF16X3": "0"},              # 128-bin workgroups, f32 kernel
