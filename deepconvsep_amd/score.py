@@ -207,10 +207,56 @@ def score_masks(ctx, mag_t, notes, start, stop, want_input=True, want_mask=False
     return inp, mask
 
 
+def load_timbre_model(path):
+    """The pickled harmonic templates ``filterSpec`` takes (``harmonics[instrument, midi pitch, harmonic]``,
+    examples/bach10_scoreinformed/separate_bach10.py:173-175); Python-2 pickles load with ``latin1``."""
+    import pickle
+    with open(path, 'rb') as fh:
+        try:
+            h = pickle.load(fh)
+        except UnicodeDecodeError:
+            fh.seek(0)
+            h = pickle.load(fh, encoding='latin1')
+    h = np.asarray(h)
+    if h.ndim != 3:
+        raise ValueError("timbre model must be [instruments, pitches, harmonics], got shape %r" % (h.shape,))
+    return h
+
+
+def timbre_masks(shape, notes, ninst, start, stop, harmonics):
+    """The timbre-model branch of ``filterSpec`` (separate_bach10.py:189-191,195-196) on the host: a float32 field per
+    instrument that starts at 1e-18, to which every harmonic band of every note sounding in ``[start, stop)`` ADDS the
+    template weight ``harmonics[j, pitch, k]`` (float32 adds, notes in table order, harmonics in slot order: the sums are
+    order-dependent in the last bit, so the order is the reference's), divided by its own maximum.  Bands of one note are
+    not merged here -- overlapping bands add twice -- and the zero-width slots past the Nyquist bin add to nothing.
+    A few thousand small slice updates: this branch is not on ``train_auto``'s path (it never passes a model), so it stays
+    NumPy; the binary branch is the device kernel ``dcs_score_masks``."""
+    T, F = int(shape[0]), int(shape[1])
+    notes = np.asarray(notes, dtype=np.float64)
+    weights = np.asarray(harmonics)
+    mask = np.empty((T, ninst * F), dtype=np.float32)
+    for j in range(ninst):
+        field = np.full((T, F), np.float32(1e-18), dtype=np.float32)
+        tab = notes[j]
+        sounding = (tab[:, 2] > 0) & (np.minimum(tab[:, 1], stop) - np.maximum(tab[:, 0], start) > 0)
+        for row in tab[sounding]:
+            t0 = int(max(row[0], start)) - start
+            t1 = int(min(row[1], stop)) - start
+            lo, hi = row[3::2].astype(np.int64), row[4::2].astype(np.int64)
+            w = weights[j, int(row[2])].astype(np.float32)
+            for k in range(len(lo)):
+                band = field[t0:t1, lo[k]:hi[k]]
+                np.add(band, w[k], out=band)
+        np.divide(field, field.max(), out=mask[:, j * F:(j + 1) * F])
+    return mask
+
+
 def filterSpec(mag, notes, ninst, start, stop, timbre_model_path=None, ctx=None):
-    """Drop-in ``filterSpec``: NumPy ``mag [T, F]`` in, float32 mask ``[T, ninst*F]`` out (computed on the GPU)."""
+    """Drop-in ``filterSpec``: NumPy ``mag [T, F]`` in, float32 mask ``[T, ninst*F]`` out -- the binary harmonic masks on
+    the GPU (``dcs_score_masks``), or with ``timbre_model_path`` the template-weighted masks (:func:`timbre_masks`)."""
     if timbre_model_path is not None:
-        raise NotImplementedError("timbre models (pickled harmonic templates) are not part of the separation path")
+        return timbre_masks(np.shape(mag), np.asarray(notes)[:ninst], ninst, int(start), int(stop),
+                            load_timbre_model(timbre_model_path))
     from .runtime import default_context
     ctx = ctx if ctx is not None else default_context()
     mag_t = ctx.to_device(np.asarray(mag), np.float32)

@@ -297,13 +297,19 @@ class Separator(object):
         return np.ascontiguousarray(self.ctx.to_host(pcm).astype(np.float64).transpose(2, 1, 0))   # [L, S, 2]
 
     @_on_ctx_stream
-    def separate_scoreinformed(self, audio, melody):
+    def separate_scoreinformed(self, audio, melody, timbre_model_path=None):
         """Score-informed separation (examples/bach10_scoreinformed/separate_bach10.py:497-541), stage by stage on the
         device: STFT -> x scale -> harmonic masks of the score x spectrogram (``dcs_score_masks``) -> library tiler
         with one input channel per instrument (``util.generate_overlapadd``, :531) -> network (masks from the first
         ``S`` output channels, mixture = input channel 0, :473-486) -> overlapadd_multi -> iSTFT.
-        ``melody``: note tables ``[instruments, notes, 2*nharmonics+3]`` (``score.melody_table``)."""
+        ``melody``: note tables ``[instruments, notes, 2*nharmonics+3]`` (``score.melody_table``).
+        ``timbre_model_path``: the pickled harmonic templates of ``filterSpec(..., timbre_model_path)`` -- the masks are then
+        the template-weighted ones (host, ``score.timbre_masks``) and the path runs stage by stage."""
         a = self.ctx.to_device(np.asarray(audio), np.float32)
+        if timbre_model_path is not None:
+            from .score import load_timbre_model
+            pcm = self._separate_scoreinformed_staged(a, melody, load_timbre_model(timbre_model_path))
+            return self.ctx.to_host(pcm).astype(np.float64)
         return self.ctx.to_host(self.separate_scoreinformed_device(a, melody)).astype(np.float64)
 
     def separate_scoreinformed_device(self, a, melody, staged=False):
@@ -321,13 +327,21 @@ class Separator(object):
                                                tie_mode=self.tie_mode)
 
     @_on_ctx_stream
-    def _separate_scoreinformed_staged(self, a, melody):
+    def _separate_scoreinformed_staged(self, a, melody, harmonics=None):
         import torch
-        from .score import score_masks
+        from .score import score_masks, timbre_masks
         mag, ph = self.plan.forward(a, phase=True)
         T = int(mag.shape[0])
         mag = mag * np.float32(self.scale_factor)                       # :503
-        inp, _ = score_masks(self.ctx, mag, melody, 0, T)               # :520-527, [C, T, F]
+        if harmonics is None:
+            inp, _ = score_masks(self.ctx, mag, melody, 0, T)           # :520-527, [C, T, F]
+        else:
+            # timbre-model masks (host) x spectrogram, float32 products as the script forms them (:523-527)
+            mag_h = self.ctx.to_host(mag)
+            C = int(np.asarray(melody).shape[0])
+            F = int(mag_h.shape[1])
+            m = timbre_masks(mag_h.shape, melody, C, 0, T, harmonics)
+            inp = self.ctx.to_device(np.stack([m[:, j * F:(j + 1) * F] * mag_h for j in range(C)]), np.float32)
         tiles, n = tile(self.ctx, inp, self.tc, self.overlap, TILER_LIBRARY, 1.0)
         outs = []
         for b0 in range(0, n, self.batch_size):

@@ -48,7 +48,7 @@ def separate(arch, params, audio, scale_factor=0.3, time_context=30, overlap=25,
 
 
 def separate_scoreinformed(params, audio, melody, scale_factor=0.3, time_context=30, overlap=25, batch_size=32,
-                           frameSize=4096, hopSize=512, window=None, tie_mode='all', return_input=False):
+                           frameSize=4096, hopSize=512, window=None, tie_mode='all', return_input=False, harmonics=None):
     """``examples/bach10_scoreinformed/separate_bach10.py:497-541``: the network input is one channel per instrument,
     ``filterSpec`` mask x scaled magnitudes (:520-527); tiles come from the LIBRARY tiler (:531, ``util.
     generate_overlapadd``, ``toverlap`` there is an undefined name -- the script's ``overlap`` is meant); the masks
@@ -61,7 +61,7 @@ def separate_scoreinformed(params, audio, melody, scale_factor=0.3, time_context
     nframes = int(np.ceil(len(audio) / np.double(hopSize))) + 2
     mag, ph = stft_np.compute_file(audio, phase=True, frameSize=frameSize, hopSize=hopSize, window=window)
     mag = scale_factor * mag.astype(np.float32)
-    masks = score_np.network_input(mag, np.asarray(melody), nframes)          # [C, T, F] float64
+    masks = score_np.network_input(mag, np.asarray(melody), nframes, harmonics)   # [C, T, F] float64 (harmonics: timbre model)
     batches, nchunks = tiling_np.generate_overlapadd(masks, masks.shape[-1], time_context, overlap, batch_size,
                                                      tiler=tiling_np.LIBRARY, fill=0.0)
     if nchunks == 0:

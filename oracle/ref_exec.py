@@ -94,7 +94,8 @@ def score():
     import bisect
     import itertools
     ns = _NS(np=_NpText(), os=os, bisect_left=bisect.bisect_left, bisect_right=bisect.bisect_right, it=itertools,
-             nan=float("nan"), filter=lambda f, xs: [x for x in xs if f(x)], pickle=None, __name__="ref_exec.score")
+             nan=float("nan"), filter=lambda f, xs: [x for x in xs if f(x)], pickle=__import__("pickle"),
+             __name__="ref_exec.score")
     for name in ("lib_midi_const", "lib_remove_overlap", "lib_slices", "lib_expandmidi", "lib_midinum",
                  "script_si_filterspec"):
         relpath, first, last = _SLICES[name]

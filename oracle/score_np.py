@@ -10,7 +10,7 @@ Follows the reference line by line:
   slicefft_slices   util.py:171-180   band edges -> FFT bin ranges
   expandMidi        util.py:424-512   score text -> [notes, 2*nharmonics+3] = (begin frame, end frame, midi, bin ranges)
   getMidiNum        util.py:526-579   number of notes kept (sizes the note table)
-  filterSpec        examples/bach10_scoreinformed/separate_bach10.py:172-200   binary harmonic masks, floor 1e-18,
+  filterSpec        examples/bach10_scoreinformed/separate_bach10.py:172-200   binary harmonic masks (or timbre-model weights), floor 1e-18,
                     normalised by the per-instrument max
   front end         examples/bach10_scoreinformed/separate_bach10.py:500-527   net input [4, T, F] = mask_j * mag
 
@@ -197,7 +197,12 @@ def expandMidi(path, beginTime, finishTime, interval, tuning_freq, nharmonics, s
     return intervals
 
 
-def filterSpec(mag, notes, ninst, start, stop):  # separate_bach10.py:172-200 (timbre_model_path=None)
+def filterSpec(mag, notes, ninst, start, stop, harmonics=None):  # separate_bach10.py:172-200
+    """``harmonics`` None: the binary masks of ``timbre_model_path=None``.  Otherwise the timbre branch (:173-175,189-191)
+    with ``harmonics [ninst, midi pitch, nharmonics]`` = the unpickled model: every harmonic band of every active note ADDS
+    the instrument's template weight of that pitch and harmonic (in note, then harmonic order; float32 adds -- under the
+    reference's NumPy a float64 scalar met a float32 array as float32, which is what a float32 model gives under any NumPy),
+    bands of a note are NOT merged (overlapping bands add twice) and zero-width slots past the Nyquist bin add to nothing."""
     T, F = mag.shape
     filtered = np.ones((ninst, T, F), dtype=np.float32) * np.float32(1e-18)
     for j in range(ninst):
@@ -207,9 +212,13 @@ def filterSpec(mag, notes, ninst, start, stop):  # separate_bach10.py:172-200 (t
                 begin = int(max(n0, start)) - start
                 end = int(min(n1, stop)) - start
                 starts, stops = notes[j, p, 3::2], notes[j, p, 4::2]
-                for f in range(min(len(starts), len(stops))):
-                    if stops[f] > 0:
-                        filtered[j, begin:end, int(starts[f]):int(stops[f])] = 1.0
+                if harmonics is None:
+                    for f in range(min(len(starts), len(stops))):
+                        if stops[f] > 0:
+                            filtered[j, begin:end, int(starts[f]):int(stops[f])] = 1.0
+                else:
+                    for k in range(len(starts)):
+                        filtered[j, begin:end, int(starts[k]):int(stops[k])] += np.float32(harmonics[j, int(midi), k])
     mask = np.zeros((T, ninst * F), dtype=np.float32)
     for j in range(ninst):
         mask[:, j * F:(j + 1) * F] = filtered[j] / np.max(filtered[j])
@@ -229,11 +238,11 @@ def melody_table(score_paths, nframes, samplerate=44100, hop=512, window=4096, i
     return melody
 
 
-def network_input(mag, melody, nframes):
+def network_input(mag, melody, nframes, harmonics=None):
     """separate_bach10.py:520-527: [ninst, T, F] float64 = mask_j * mag (float32 product stored in float64)."""
     ninst = melody.shape[0]
     jump = mag.shape[-1]
-    masks_temp = filterSpec(mag, melody, ninst, 0, nframes)
+    masks_temp = filterSpec(mag, melody, ninst, 0, nframes, harmonics)
     masks = np.ones((ninst, mag.shape[0], mag.shape[1]))
     for j in range(ninst):
         masks[j] = masks_temp[:, j * jump:(j + 1) * jump] * mag

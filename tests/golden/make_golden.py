@@ -145,6 +145,46 @@ def main():
         print(name, melody.shape, nums, int((mask == 1).sum()))
 
 
+def score_timbre():
+    """The timbre-model branch of the reference's filterSpec (separate_bach10.py:173-175,189-191), executed: the model is a
+    seeded float32 array [instruments, 128 pitches, 20 harmonics] pickled to a temporary file (the reference's NumPy added a
+    float64 template weight to the float32 mask as float32; a float32 model makes that the arithmetic under any NumPy)."""
+    import pickle
+    import tempfile
+    from oracle import score_np
+    sc = ref_exec.score()
+    N, hop, seconds, seed = 1024, 512, 4.0, 302
+    L = int(seconds * 44100)
+    nframes = int(np.ceil(L / np.double(hop))) + 2
+    F = N // 2 + 1
+    harmonics = np.random.RandomState(77).uniform(0.05, 1.0, (4, 128, 20)).astype(np.float32)
+    harmonics[1, :, 3] = 0.0                                          # a harmonic the template does not have
+    with tempfile.TemporaryDirectory() as d:
+        texts, tables, nums = [], [], []
+        for i, ins in enumerate(["bassoon_b", "clarinet_b", "saxophone_b", "violin_b"]):
+            pth = score_np.synth_score(os.path.join(d, ins + ".txt"), seed * 10 + i, n_notes=40, total=seconds + 1.5,
+                                       lo=36 + 6 * i, hi=60 + 8 * i)
+            texts.append(open(pth).read())
+            tables.append(sc.expandMidi(ins, d, 0, 40.0, 50, 440, 20, 44100, hop, N, 0.2, 0.2, nframes, 0.5))
+            nums.append(sc.getMidiNum(ins, d, 0, 40.0))
+        melody = np.zeros((4, max(max(nums), 1), 43))
+        for i, t in enumerate(tables):
+            melody[i, :t.shape[0]] = t
+        mag = (0.3 * np.abs(np.random.RandomState(seed).randn(nframes, F)).astype(np.float32)).astype(np.float32)
+        model = os.path.join(d, "timbre.pkl")
+        with open(model, "wb") as fh:
+            pickle.dump(harmonics, fh, protocol=2)
+        mask = sc.filterSpec(mag, melody, 4, 0, nframes, timbre_model_path=model)
+        melody2 = melody.copy()
+        melody2[2] = 0
+        mask_win = sc.filterSpec(mag[40:140], melody2, 4, 40, 140, timbre_model_path=model)
+    assert mask.dtype == np.float32
+    np.savez_compressed(os.path.join(HERE, "score_timbre_n1024_hop512.npz"), frame=N, hop=hop, n_samples=L, nframes=nframes,
+                        texts=np.array(texts), melody=melody, nums=np.array(nums), mag_seed=seed, harmonics=harmonics,
+                        mask=mask, mask_win=mask_win)
+    print("score_timbre_n1024_hop512", mask.shape, "distinct values", len(np.unique(mask)))
+
+
 def networks():
     """Network fixtures: the reference's OWN ``build_ca`` source and mask expressions executed on the NumPy Lasagne
     stand-in (oracle/lasagne_np.py) -- graph wiring, filter sizes, parameter order and mask arithmetic come from the
@@ -173,6 +213,9 @@ def networks():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "networks":
         networks()
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "score_timbre":
+        score_timbre()
         raise SystemExit(0)
 
     main()

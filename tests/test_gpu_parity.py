@@ -1140,6 +1140,32 @@ def _golden_scores(g, d):
         (d / (ins + ".txt")).write_text(str(text))
 
 
+
+def test_scoreinformed_path_with_a_timbre_model_matches_oracle(golden, tmp_path):
+    """Separator.separate_scoreinformed(..., timbre_model_path): the template-weighted masks of filterSpec's timbre branch
+    (host; bit-exact against the reference's masks in tests/test_oracle_golden.py) through the device path -- STFT, tiles,
+    network, masks, cross-fade, iSTFT -- against oracle.pipeline.separate_scoreinformed with the same templates."""
+    import pickle
+    from deepconvsep_amd import score
+    g = golden("score_timbre_n1024_hop512")
+    N, hop, L = int(g["frame"]), int(g["hop"]), int(g["n_samples"])
+    F = N // 2 + 1
+    _golden_scores(g, tmp_path)
+    nframes = int(np.ceil(L / float(hop))) + 2
+    melody = score.melody_table([i + ".txt" for i in SI_INSTS], str(tmp_path), nframes, 44100, hop, N)
+    assert np.array_equal(melody, g["melody"])
+    model = tmp_path / "timbre.pkl"
+    with open(model, "wb") as fh:
+        pickle.dump(g["harmonics"], fh, protocol=2)
+    params = synth_params("bach10_si", 30, F, seed=5)
+    audio = synth_audio(L, seed=9)
+    sep = dcs.Separator("bach10_si", params, 0.3, 30, 25, 32, F, N, hop, np.hanning, tiler='library')
+    got = sep.separate_scoreinformed(audio, melody, timbre_model_path=str(model))
+    want = pipeline.separate_scoreinformed(params, audio, melody, 0.3, 30, 25, 32, N, hop, np.hanning, harmonics=g["harmonics"])
+    assert got.shape == want.shape and np.max(np.abs(got - want)) < 1e-4
+    plain = sep.separate_scoreinformed(audio, melody)
+    assert np.max(np.abs(plain - got)) > 1e-3                      # the templates do change the separation
+
 @pytest.mark.parametrize("name", ["score_n4096_hop512", "score_n1024_hop512", "score_n2048_hop256"])
 def test_score_masks_match_the_reference_filterSpec(golden, name, tmp_path):
     """dcs_score_masks against the masks the reference's own filterSpec produced (golden) and against the oracle's

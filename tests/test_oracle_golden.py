@@ -123,6 +123,54 @@ def test_score_oracle_matches_reference_tables_and_masks(golden, name, tmp_path)
     assert np.array_equal(score_np.filterSpec(mag[40:140], melody2, 4, 40, 140), g["mask_win"])
 
 
+def test_timbre_model_masks_match_the_reference_filterSpec(golden, tmp_path):
+    """The timbre-model branch of filterSpec (separate_bach10.py:173-175,189-191): the fixture holds the masks the
+    reference's own code produced from a seeded float32 template array; the oracle's restatement and the SHIPPED host
+    implementation (deepconvsep_amd.score.filterSpec with a pickled model; pure NumPy, no GPU) both match bit for bit, on the
+    whole clip and on a frame window with a silent instrument."""
+    import pickle
+    from oracle import score_np
+    from deepconvsep_amd import score
+    g = golden("score_timbre_n1024_hop512")
+    nframes = int(g["nframes"])
+    mag = golden_mag(g)
+    H = g["harmonics"]
+    assert np.array_equal(score_np.filterSpec(mag, g["melody"], 4, 0, nframes, H), g["mask"])
+    melody2 = g["melody"].copy()
+    melody2[2] = 0
+    assert np.array_equal(score_np.filterSpec(mag[40:140], melody2, 4, 40, 140, H), g["mask_win"])
+    model = tmp_path / "timbre.pkl"
+    with open(model, "wb") as fh:
+        pickle.dump(H, fh, protocol=2)
+    got = score.filterSpec(mag, g["melody"], 4, 0, nframes, timbre_model_path=str(model))
+    assert got.dtype == np.float32 and np.array_equal(got, g["mask"])
+    assert np.array_equal(score.filterSpec(mag[40:140], melody2, 4, 40, 140, timbre_model_path=str(model)), g["mask_win"])
+    assert len(np.unique(g["mask"])) > 100 and float(g["mask"].max()) == 1.0      # weighted, not binary; normalised per instrument
+
+
+@pytest.mark.skipif(not ref_exec.available(), reason="reference tree only exists in the build container")
+def test_live_reference_timbre_branch_agrees_on_fresh_models(tmp_path):
+    import pickle
+    from oracle import score_np
+    from deepconvsep_amd import score
+    sc = ref_exec.score()
+    for seed in range(6):
+        rs = np.random.RandomState(900 + seed)
+        p = score_np.synth_score(str(tmp_path / "t_b.txt"), 50 + seed, n_notes=25, total=6.0)
+        tab = sc.expandMidi("t_b", str(tmp_path), 0, 40.0, 50, 440, 20, 44100, 512, 2048, 0.2, 0.2, 520, 0.5)
+        melody = np.zeros((2, tab.shape[0], 43))
+        melody[0] = tab
+        melody[1, : tab.shape[0] // 2] = tab[: tab.shape[0] // 2]
+        H = rs.uniform(0.0, 2.0, (2, 128, 20)).astype(np.float32)
+        model = str(tmp_path / ("m%d.pkl" % seed))
+        with open(model, "wb") as fh:
+            pickle.dump(H, fh, protocol=2)
+        mag = np.abs(rs.randn(520, 1025)).astype(np.float32)
+        want = sc.filterSpec(mag[30:400], melody, 2, 30, 400, timbre_model_path=model)
+        assert np.array_equal(score_np.filterSpec(mag[30:400], melody, 2, 30, 400, H), want)
+        assert np.array_equal(score.filterSpec(mag[30:400], melody, 2, 30, 400, timbre_model_path=model), want)
+
+
 @pytest.mark.skipif(not ref_exec.available(), reason="reference tree only exists in the build container")
 def test_live_reference_score_code_agrees_on_fresh_scores(tmp_path):
     """The reference's own expandMidi / getMidiNum / filterSpec (Python-2 bodies executed with the shims of
