@@ -1,0 +1,403 @@
+// InverseLayer(conv2) + InverseLayer(conv1) of the Bach10 graph in ONE kernel with f32-class arithmetic
+// (separate_bach10.py:219-227; the f16 switch OFF) -- round 4.
+//
+// colconv_deconv1_fused_kernel (colconv_wreg.hip) fuses the two transposed convolutions for the f16 switch: a wave keeps
+// all 20 taps of the 20 x 1 filter in registers (160 VGPRs as f16) and nothing between the two layers reaches HBM.  As
+// three bf16 planes the same weights are 480 registers, so the f32-class graph stayed on two kernels: the f32-MFMA column
+// convolution (1.57 ms per 10 s clip, the last f32-MFMA convolution of the repository) and the transposed conv1 behind
+// it (0.39 ms), with the 1.2 GB [n * 4, 30, 30, 505] intermediate written and read back between them.
+//
+// Here TWO waves share a column block of 16 x:
+//   * wave `par` of the pair keeps the taps u = 2 k + par (k = 0 .. 9) as bf16 planes in registers (240 VGPRs), the pair
+//     one copy of the block's input rows as pre-split bf16 planes in LDS ([row -1 .. 11][plane][K piece][x], rows -1 and 11
+//     stay zero), filled once per block by both waves from the CHANNELS-LAST dense output (32 bytes per lane and (row, x):
+//     generic.hip packs the dense weights with permuted columns when this kernel is planned);
+//   * stage 1 (gather form, operands swapped as in the f16 kernel): for output row y the wave multiplies its tap k with
+//     input row h = y - 19 + 2 k + par -- the LDS address is the only thing that depends on `par`, so both waves run the
+//     same fully unrolled code; a (y, k) slot whose row is -1 or 11 for this wave meets the zero rows (120 slots per
+//     wave and block for 110 products: 9 % of the stage);  every product is six bf16 MFMAs (three-way split operands:
+//     f32-class), K = the 30 (32) input channels, two 16-channel halves of the output;
+//   * the two partial rows are exchanged through LDS (each wave hands over the partial of the row its partner finishes,
+//     one workgroup barrier per row pair; the workgroup IS the pair) and added: G[ci][x] of one row, complete, in the
+//     layout of a B operand of the second MFMA;
+//   * stage 2, the LDS shift-add, the carry between column blocks, the runs and the output stores are those of the f16
+//     kernel (conv1^T on three-way split operands), one output row per wave instead of two.
+// The workgroup is ONE pair (128 threads, 60 KB of LDS): two of them share a CU, each wave on a SIMD of its own (436
+// registers).  A four-wave workgroup of two pairs that step through their runs in lockstep (s_barrier is workgroup-wide) was
+// built and measured 10 % slower (1.27 against 1.15 ms per 10 s clip): the pairs wait for each other fifteen times a block.
+// Per block and wave 1 440 + 180 MFMAs of 16 cycles; 668 images x 32 blocks over 512 pairs -> 0.45 ms of matrix-pipe
+// time per 10 s clip, against 1.57 + 0.39 ms for the two kernels it replaces.  Index arithmetic emulated lane by lane in
+// tests/test_generic_layouts_cpu.py::test_x3_decoder_*.
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "dcs_internal.h"
+#include "generic.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // rows are F floats apart, F odd
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kTh = 128;      // the workgroup is ONE pair of waves
+constexpr int kPairTh = 128;
+
+__device__ __forceinline__ f32x4 mma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+// x = hi + mid + lo exactly (three bf16 by truncation); element j of a piece is k slot j
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = bf_trunc(x[j]);
+        const float r1 = x[j] - __uint_as_float(h[j]);
+        m[j] = bf_trunc(r1);
+        l[j] = bf_trunc(r1 - __uint_as_float(m[j]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hi[q] = (h[2 * q] >> 16) | h[2 * q + 1];
+        mid[q] = (m[2 * q] >> 16) | m[2 * q + 1];
+        lo[q] = (l[2 * q] >> 16) | l[2 * q + 1];
+    }
+}
+
+// slot s = t * NK + k of a row pair (rows y, y + 1) is live when the input row of tap 2 k -- or of tap 2 k + 1, one further
+// down -- exists: compile-time list walking for the fully unrolled kernel body
+template <int H, int PH, int NK>
+constexpr int x3_row0(int y, int s) { return (y + s / NK) - PH + 2 * (s % NK); }
+template <int H, int PH, int NK>
+constexpr bool x3_live(int y, int s) { return x3_row0<H, PH, NK>(y, s) >= -1 && x3_row0<H, PH, NK>(y, s) <= H - 1; }
+template <int H, int PH, int NK>
+constexpr int x3_next(int y, int s) {      // first live slot after s, or -1
+    for (int s2 = s + 1; s2 < 2 * NK; ++s2)
+        if (x3_live<H, PH, NK>(y, s2)) return s2;
+    return -1;
+}
+template <class F, int... I>
+__device__ __forceinline__ void x3_for_row_pairs(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, 2 * I>{}), ...);
+}
+template <class F, int... I>
+__device__ __forceinline__ void x3_for_slots(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+struct DcsDecoderX3 {
+    const u32x4* Wq;        // [2 parities][KH / 2 taps][3 planes][2 halves][64 lanes] pieces: conv2^T weights (A fragments)
+    const u32x4* Wq1;       // [3 planes][2 tap halves][64 lanes] pieces of the padded conv1 filter (dcs_decoder_fused_pack)
+    float* out;             // [image][HO][F]
+    int F;
+    int runs_per_image;
+    int64_t n_runs;
+};
+
+template <int KH, int H>
+__global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const DcsColConv g, const DcsDecoderX3 d) {
+    constexpr int HO = H + KH - 1, PH = KH - 1, NK = KH / 2;
+    static_assert(KH % 2 == 0 && HO % 2 == 0, "taps and output rows are dealt to the two waves by parity");
+    constexpr int kRowU = 3 * 4 * 16;                    // 16-byte units per input row: [plane][K piece kq][x]
+    constexpr int kPlanes = (H + 2) * kRowU;             // rows -1 .. H (index h + 1); rows -1 and H are zero
+    constexpr int kPb = 8 * 32;                          // per wave: [tap mm 8][32 slots] float4, slot 8 + x holds P[x][mm]
+    constexpr int kCb = (HO / 2) * 8;                    // per wave: the carry of its 15 rows, 8 float4 each
+    constexpr int kTasks = H * 64;                       // (row, x, K piece) fetch / split tasks per block
+    constexpr int NT = (kTasks + 127) / 128;             // per thread of a pair
+    __shared__ u32x4 planes[kPlanes];
+    __shared__ f32x4 PbS[2 * kPb];
+    __shared__ f32x4 CbS[2 * kCb];
+    __shared__ f32x4 Xs[2 * 2 * 128];                    // [buffer][writer parity][half][lane]: the partial row handed to the partner
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int par = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kq = lane >> 4;
+    f32x4* Pb = PbS + par * kPb;
+    f32x4* Cb = CbS + par * kCb;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 zeroq = u32x4{0u, 0u, 0u, 0u};
+    for (int i = lane; i < kPb; i += 64) Pb[i] = zero4;
+    for (int i = tid; i < kRowU; i += kPairTh) {
+        planes[i] = zeroq;                               // row -1
+        planes[(H + 1) * kRowU + i] = zeroq;             // row H
+    }
+    // this wave's taps, three planes, two output-channel halves: registers for the whole launch
+    u32x4 w[NK][3][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) w[k][p][hf] = d.Wq[((((par * NK + k) * 3 + p) * 2) + hf) * 64 + lane];
+    u32x4 w1[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        w1[p][0] = d.Wq1[(p * 2) * 64 + lane];
+        w1[p][1] = d.Wq1[(p * 2 + 1) * 64 + lane];
+    }
+    const int W = g.W, n_xb = g.n_xb, F = d.F, Cin = g.Cin;
+    const int rpi = d.runs_per_image;
+    // fetch / split task i = tid + 128 j (tid within the pair): row h = i / 64, x = (i % 64) / 4, K piece kqt = i % 4 (four consecutive threads
+    // read the 120 consecutive bytes of one position; the last pair of kqt = 3 -- channels 30, 31 -- re-reads 28, 29 and
+    // meets zero weights)
+    int t_off[NT], t_dst[NT], t_x[NT];
+    bool t_ok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int i = tid + kPairTh * j;
+        const int h = i >> 6, rem = i & 63, x = rem >> 2, kqt = rem & 3;
+        t_ok[j] = i < kTasks;
+        t_x[j] = x;
+        t_off[j] = h * W * Cin + 8 * kqt;                           // + (column) * Cin
+        t_dst[j] = ((h + 1) * 3 * 4 + kqt) * 16 + x;                // + plane * 64
+    }
+    int pair_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 8 * (tid & 3) + 2 * q;
+        pair_off[q] = (c + 2 <= Cin ? c : Cin - 2) - 8 * (tid & 3);  // relative to the task's first channel
+    }
+    float raw[NT][8];
+#define DCS_X3_FETCH(img_, blk_)                                                                        \
+    {                                                                                                   \
+        const float* ib_ = g.in + (img_) * g.in_n_stride;                                               \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                \
+            if (t_ok[j]) {                                                                              \
+                const int xl_ = (blk_) * 16 + t_x[j];                                                   \
+                const float* ip_ = ib_ + (t_off[j] + (xl_ < W ? xl_ : W - 1) * Cin);                    \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                         \
+                    const f32x2 v_ = *reinterpret_cast<const f32x2*>(ip_ + pair_off[q]);                \
+                    raw[j][2 * q] = v_[0];                                                              \
+                    raw[j][2 * q + 1] = v_[1];                                                          \
+                }                                                                                       \
+            }                                                                                           \
+        }                                                                                               \
+    }
+    // stage-2 write side: lane (x = fi, kq) owns taps mm = kq and kq + 4 of column x
+    f32x4* pw = Pb + kq * 32 + 8 + fi;
+    // read side: lane & 31 = q - 16 b (0 .. 22 are real); both half-waves compute the same sums, the first one stores
+    const int rq = lane & 31;
+    const f32x4* pr = Pb + (rq < 23 ? rq : 22) + 8;
+    const u32x4* bl = planes + lane;                     // B fragment of (row, plane): unit (row * 3 + plane) * 64 + lane
+    int xbuf = 0;
+    for (int64_t run = blockIdx.x; run < d.n_runs; run += gridDim.x) {
+        const bool have = true;
+        const int64_t img = run / rpi;
+        const int rr = (int)(run - img * rpi);
+        const int b_lo = (int)((int64_t)rr * n_xb / rpi), b_hi = (int)((int64_t)(rr + 1) * n_xb / rpi);
+        const int b_first = b_lo > 0 ? b_lo - 1 : 0;         // the block to the left is recomputed for its carry
+        const int n_it = b_hi - b_first;
+        for (int i = lane; i < kCb; i += 64) Cb[i] = zero4;
+        if (have) DCS_X3_FETCH(img, b_first)
+        for (int it = 0; it < n_it; ++it) {
+            const int b = b_first + it;
+            constexpr bool active = true;
+            __syncthreads();                                 // both waves are done with the previous block's planes
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (active && t_ok[j]) {
+                    u32x4 p0, p1, p2;
+                    split8(raw[j], p0, p1, p2);
+                    const bool x_ok = b * 16 + t_x[j] < W;   // columns past W (last block): zero input, zero G, zero products
+                    planes[t_dst[j]] = x_ok ? p0 : zeroq;
+                    planes[t_dst[j] + 64] = x_ok ? p1 : zeroq;
+                    planes[t_dst[j] + 128] = x_ok ? p2 : zeroq;
+                }
+            }
+            __syncthreads();
+            if (active) {
+                const int nb = b + 1 < b_hi ? b + 1 : b;     // last block of the run: a harmless re-read
+                DCS_X3_FETCH(img, nb)
+            }
+            const bool keep = b >= b_lo;                     // false for the recomputed block
+            const int f0 = 4 * (b * 16 + rq);
+            float* orow = d.out + (img * HO + par) * (int64_t)F + f0;
+            // the 15 row pairs and their (row, tap) slots are unrolled through integer sequences: every weight register index
+            // and every "is this slot live" is a compile-time constant (a `#pragma unroll` over 15 bodies of this size is
+            // declined by the optimiser)
+            x3_for_row_pairs([&](auto yc) {
+                constexpr int y = decltype(yc)::value;
+                f32x4 mine[2];
+                if (active) {
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = zero4;
+                // The B fragments of the NEXT live slot are requested before the twelve MFMAs of the current one are issued:
+                // one wave per SIMD, so nobody else hides the LDS latency.
+                u32x4 bc[3], bn[3];
+                {
+                    constexpr int s0 = x3_next<H, PH, NK>(y, -1);
+                    const u32x4* bp = bl + (x3_row0<H, PH, NK>(y, s0) + 1 + par) * kRowU;
+                    bc[0] = bp[0]; bc[1] = bp[64]; bc[2] = bp[128];
+                }
+                x3_for_slots([&](auto sc) {
+                    constexpr int sl = decltype(sc)::value;
+                    if constexpr (x3_live<H, PH, NK>(y, sl)) {
+                        constexpr int t = sl / NK, k = sl % NK;
+                        constexpr int s_next = x3_next<H, PH, NK>(y, sl);
+                        if constexpr (s_next >= 0) {
+                            const u32x4* bp = bl + (x3_row0<H, PH, NK>(y, s_next) + 1 + par) * kRowU;
+                            bn[0] = bp[0]; bn[1] = bp[64]; bn[2] = bp[128];
+                            // nothing moves across: the three requests stay IN FRONT of this slot's MFMAs (left alone the
+                            // scheduler re-uses the fragment registers and issues them behind the last MFMA: ~100 idle
+                            // cycles per slot with one wave per SIMD)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // smallest terms first; the two channel halves alternate so that no MFMA waits for the one before it
+                        acc[t][0] = mma_bf(w[k][2][0], bc[0], acc[t][0]);
+                        acc[t][1] = mma_bf(w[k][2][1], bc[0], acc[t][1]);
+                        acc[t][0] = mma_bf(w[k][0][0], bc[2], acc[t][0]);
+                        acc[t][1] = mma_bf(w[k][0][1], bc[2], acc[t][1]);
+                        acc[t][0] = mma_bf(w[k][1][0], bc[1], acc[t][0]);
+                        acc[t][1] = mma_bf(w[k][1][1], bc[1], acc[t][1]);
+                        acc[t][0] = mma_bf(w[k][1][0], bc[0], acc[t][0]);
+                        acc[t][1] = mma_bf(w[k][1][1], bc[0], acc[t][1]);
+                        acc[t][0] = mma_bf(w[k][0][0], bc[1], acc[t][0]);
+                        acc[t][1] = mma_bf(w[k][0][1], bc[1], acc[t][1]);
+                        acc[t][0] = mma_bf(w[k][0][0], bc[0], acc[t][0]);
+                        acc[t][1] = mma_bf(w[k][0][1], bc[0], acc[t][1]);
+                        if constexpr (s_next >= 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
+                        }
+                    }
+                }, std::make_integer_sequence<int, 2 * NK>{});
+                // this wave finishes row y + par: its partial of the OTHER row goes to the partner, the partner's partial of
+                // this row comes back
+                f32x4 other[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    mine[hf] = par ? acc[1][hf] : acc[0][hf];
+                    other[hf] = par ? acc[0][hf] : acc[1][hf];
+                }
+                f32x4* xw = Xs + (xbuf * 2 + par) * 128 + lane;
+                xw[0] = other[0];
+                xw[64] = other[1];
+                }
+                __syncthreads();
+                if (active) {
+                const f32x4* xr = Xs + (xbuf * 2 + (1 - par)) * 128 + lane;
+                mine[0] += xr[0];
+                mine[1] += xr[64];
+                float gv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gv[e] = mine[0][e];
+                    gv[4 + e] = mine[1][e];
+                }
+                u32x4 g0, g1, g2;
+                split8(gv, g0, g1, g2);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh) {
+                    f32x4 p = zero4;
+                    p = mma_bf(w1[2][mh], g0, p);
+                    p = mma_bf(w1[0][mh], g2, p);
+                    p = mma_bf(w1[1][mh], g1, p);
+                    p = mma_bf(w1[1][mh], g0, p);
+                    p = mma_bf(w1[0][mh], g1, p);
+                    p = mma_bf(w1[0][mh], g0, p);
+                    pw[mh * 128] = p;
+                }
+                asm volatile("" ::: "memory");               // the pieces of the row are written (LDS is in order per wave)
+                f32x4 sum = zero4;
+#pragma unroll
+                for (int mm = 0; mm < 8; ++mm) sum += pr[mm * 32 - mm];
+                const f32x4 cin = Cb[(y >> 1) * 8 + (rq & 7)];
+                if (rq < 8) sum += cin;
+                asm volatile("" ::: "memory");               // every lane has read the carry before it is replaced
+                if (lane >= 16 && lane < 24) Cb[(y >> 1) * 8 + lane - 16] = lane < 23 ? sum : zero4;
+                if (keep && lane < 16) {
+                    float* op = orow + (int64_t)y * F;
+                    if (f0 + 4 <= F) {
+                        *reinterpret_cast<f32x4u*>(op) = sum;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            if (f0 + e < F) op[e] = sum[e];
+                    }
+                }
+                asm volatile("" ::: "memory");
+                }
+                xbuf ^= 1;
+            }, std::make_integer_sequence<int, HO / 2>{});
+        }
+        // the carry: the tail of the image (and the zeros up to F) for the last run, otherwise the next run recomputes it
+        if (have && b_hi == n_xb) {
+#pragma unroll
+            for (int i = 0; i < (HO / 2 + 7) / 8; ++i) {
+                const int t = (lane >> 3) + 8 * i, f = 4 * (16 * n_xb + (lane & 7));
+                if (t < HO / 2) {
+                    const f32x4 v = Cb[t * 8 + (lane & 7)];
+                    float* op = d.out + (img * HO + 2 * t + par) * (int64_t)F + f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (f + e < F) op[e] = v[e];
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+#undef DCS_X3_FETCH
+}
+
+}  // namespace
+
+// Wf: [kh][32 out][40] f32, in-channel fastest (the transposed conv2 filter as the column kernels take it) ->
+// [2 parities][kh / 2][3 planes][2 halves][64 lanes] 16-byte pieces: lane (fi, kg) of tap u = 2 k + par, half hf holds
+// W[u][out = fi + 16 hf][in = 8 kg .. 8 kg + 7] as bf16 plane p (x = p0 + p1 + p2 exactly)
+void dcs_decoder_x3_pack(const float* Wf, int kh, std::vector<uint16_t>* out) {
+    const int nk = kh / 2;
+    out->assign((size_t)2 * nk * 3 * 2 * 64 * 8, 0);
+    for (int par = 0; par < 2; ++par)
+        for (int k = 0; k < nk; ++k)
+            for (int hf = 0; hf < 2; ++hf)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int u = 2 * k + par;
+                        float r = Wf[((size_t)u * 32 + (lane & 15) + 16 * hf) * 40 + (lane >> 4) * 8 + j];
+                        for (int p = 0; p < 3; ++p) {
+                            uint32_t bits;
+                            memcpy(&bits, &r, 4);
+                            bits &= 0xffff0000u;
+                            float part;
+                            memcpy(&part, &bits, 4);
+                            r -= part;
+                            (*out)[((((((size_t)par * nk + k) * 3 + p) * 2 + hf) * 64) + lane) * 8 + j] = (uint16_t)(bits >> 16);
+                        }
+                    }
+}
+
+bool dcs_decoder_x3_ok(const DcsColConv& a, int F) {
+    static const bool on = !(getenv("DCS_DECODER_X3") && atoi(getenv("DCS_DECODER_X3")) == 0);
+    return on && dcs_decoder_fused_ok(a, F) && (a.Cin & 1) == 0;
+}
+
+// the input MUST be channels-last ([image][H][W][Cin], 8-byte aligned): false = not launched
+bool dcs_launch_decoder_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out, int F) {
+    if (!Wq || !Wq1 || !dcs_decoder_x3_ok(a, F)) return false;
+    if ((a.in_n_stride & 1) || (reinterpret_cast<uintptr_t>(a.in) & 7)) return false;
+    if (n_images <= 0) return true;
+    // runs per image: fewest (rounds of wave pairs) x (blocks per run + the recomputed one); two pairs per CU
+    const int64_t n_pairs = (int64_t)ctx->n_cu * 2;
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int rpi = 1; rpi <= a.n_xb; ++rpi) {
+        const int64_t len = (a.n_xb + rpi - 1) / rpi + (rpi > 1 ? 1 : 0);
+        const int64_t cost = dcs_cdiv(n_images * rpi, n_pairs) * len;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rpi; }
+    }
+    DcsDecoderX3 d{};
+    d.Wq = reinterpret_cast<const u32x4*>(Wq);
+    d.Wq1 = reinterpret_cast<const u32x4*>(Wq1);
+    d.out = out;
+    d.F = F;
+    d.runs_per_image = best;
+    d.n_runs = n_images * best;
+    const unsigned grid = (unsigned)std::min<int64_t>(d.n_runs, n_pairs);
+    hipLaunchKernelGGL((colconv_deconv1_fused_x3_kernel<20, 11>), dim3(grid), dim3(kTh), 0, ctx->stream, a, d);
+    return true;
+}

@@ -64,6 +64,12 @@ bool dcs_decoder_fused_ok(const DcsColConv& a, int F);
 bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out,
                               int F, bool in_channels_last = false);
 
+// the same fusion with f32-class arithmetic (colconv_x3.hip): two waves per column block, ten taps each as bf16 planes in
+// registers; the input MUST be channels-last.  false = shape not covered / not launched
+void dcs_decoder_x3_pack(const float* Wf /* [kh][32 out][40], in-channel fastest */, int kh, std::vector<uint16_t>* out);
+bool dcs_decoder_x3_ok(const DcsColConv& a, int F);
+bool dcs_launch_decoder_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out, int F);
+
 int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int F,
                        const std::vector<std::vector<float>>& params, DcsGenericNet** out);
 void dcs_generic_destroy(DcsGenericNet* g);

@@ -1274,6 +1274,7 @@ struct DcsGenericNet {
     _Float16 *Wcol_h = nullptr, *Wcol_t_h = nullptr;     // [kh][32 co][40] halves, channel-fastest
     _Float16 *Wcol_r = nullptr, *Wcol_t_r = nullptr;     // the same weights as MFMA fragments (colconv_wreg.hip)
     uint16_t* W1q = nullptr;                             // padded conv1 filter as bf16 x 3 fragments (fused decoder)
+    uint16_t* Wx3 = nullptr;                             // transposed conv2 filter as bf16 x 3 fragments, taps dealt by parity (colconv_x3.hip)
     uint16_t* W1m = nullptr;                             // conv1 filter as bf16 x 3 fragments (conv1_mfma.hip)
     uint16_t* W1dq = nullptr;                            // the same for its InverseLayer (deconv1_mfma.hip)
     int use_colconv = 0;
@@ -1425,6 +1426,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     // Wcol_t[u][co][ci] = W2[co][ci][u]
     std::vector<float> Wcol, Wcol_t;
     std::vector<_Float16> Wcol_h, Wcol_t_h;
+    std::vector<float> Wcol_t_f;                         // the transposed filter once more in f32, [kh][32 out][40] (colconv_x3.hip)
     static const int col_env = getenv("DCS_COLCONV") ? atoi(getenv("DCS_COLCONV")) : 1;
     g->use_colconv = (kw == 1 && nf1 <= 32 && nf2 <= 32 && col_env) ? 1 : 0;
     if (g->use_colconv) {
@@ -1432,6 +1434,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         Wcol_t.assign((size_t)kh * 1024, 0.f);
         Wcol_h.assign((size_t)kh * 32 * 40, (_Float16)0.f);
         Wcol_t_h.assign((size_t)kh * 32 * 40, (_Float16)0.f);
+        Wcol_t_f.assign((size_t)kh * 32 * 40, 0.f);
         for (int co = 0; co < nf2; ++co)
             for (int ci = 0; ci < nf1; ++ci)
                 for (int u = 0; u < kh; ++u) {
@@ -1440,6 +1443,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
                     Wcol_t[colconv_wslot(u, co, ci)] = wt;
                     Wcol_h[((size_t)u * 32 + co) * 40 + ci] = (_Float16)wf;      // forward: out channel co, in channel ci
                     Wcol_t_h[((size_t)u * 32 + ci) * 40 + co] = (_Float16)wt;    // transpose: out channel ci, in channel co
+                    Wcol_t_f[((size_t)u * 32 + ci) * 40 + co] = wt;
                 }
     }
     // dense layers: the flattened [nf2, h2, w2] order is the storage order of a2b, so no permutation
@@ -1481,6 +1485,11 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
             std::vector<uint16_t> W1q;
             dcs_decoder_fused_pack(W1p.data(), nf1, &W1q);
             UP(g->W1q, W1q)
+            if (kh % 2 == 0) {                           // the f32-class fused decoder deals the taps to two waves by parity
+                std::vector<uint16_t> Wx3;
+                dcs_decoder_x3_pack(Wcol_t_f.data(), kh, &Wx3);
+                UP(g->Wx3, Wx3)
+            }
         }
     }
     for (int s = 0; s < d.n_fc && rc == DCS_OK; ++s) {
@@ -1515,7 +1524,7 @@ void dcs_generic_destroy(DcsGenericNet* g) {
     void* ptrs[] = {g->Wpc_q3, g->Wpc_t_q3, g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W1dq, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3], g->biasd_cl[0], g->biasd_cl[1],
-                    g->biasd_cl[2], g->biasd_cl[3]};
+                    g->biasd_cl[2], g->biasd_cl[3], g->Wx3};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1735,14 +1744,17 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // decides their output layout: the fused decoder reads a position's channels together, so D is written CHANNELS-LAST
     // ([branch][row][x][channel]) by packing the bf16 planes of the dense weights with permuted columns (DCS_DECODER_CL=0:
     // channel-first as every other consumer takes it).
-    bool fuse_planned = false;
-    if (g->use_colconv && g->conv_f16 && g->W1q && g->Wcol_t_r) {
+    // With the switch off the same fusion runs on three-way split operands (colconv_x3.hip, round 4: two waves per column
+    // block); that kernel takes the channels-last layout only, so it is planned when the layout can be had.
+    bool fuse_planned = false, fuse_x3 = false;
+    if (g->use_colconv && g->W1q && (g->conv_f16 ? g->Wcol_t_r != nullptr : g->Wx3 != nullptr)) {
         ColConvArgs c0{};
         c0.Cin = d.nf2; c0.H = d.h2; c0.W = d.w2; c0.Cout = d.nf1; c0.Ho = tc; c0.ph = d.kh2 - 1; c0.kh = d.kh2;
-        fuse_planned = dcs_decoder_fused_ok(c0, F);
+        fuse_planned = g->conv_f16 ? dcs_decoder_fused_ok(c0, F) : dcs_decoder_x3_ok(c0, F);
+        fuse_x3 = fuse_planned && !g->conv_f16;
     }
     static const bool cl_env = !(getenv("DCS_DECODER_CL") && atoi(getenv("DCS_DECODER_CL")) == 0);
-    const bool want_cl = fuse_planned && cl_env && (d.nf2 & 1) == 0 && (g->flat_p & 1) == 0;
+    const bool want_cl = fuse_planned && (cl_env || fuse_x3) && (d.nf2 & 1) == 0 && (g->flat_p & 1) == 0;
     // the bf16 planes of the dense weights, on first need: a launch of >= 128 rows against >= 1024 columns (smaller ones stay
     // on the f32 kernels whatever is packed, dcs_launch_gemm_bf16x3); same stream, so no synchronisation
     static const bool bf16_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
@@ -1819,12 +1831,14 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = d.kh2 - 1; c.kh = d.kh2; c.n_xb = (c.W + 15) / 16;
-            decoder_fused = g->conv_f16 && g->W1q && g->Wcol_t_r && dcs_decoder_fused_ok(c, F);
+            decoder_fused = g->conv_f16 ? (g->W1q && g->Wcol_t_r && dcs_decoder_fused_ok(c, F))
+                                        : (fuse_x3 && d_cl);       // f32-class: only on the channels-last layout
         }
         if (d_cl && !decoder_fused) DCS_FAIL(DCS_EHIP, "generic graph: channels-last dense output without the fused decoder");
         if (decoder_fused) {                                 // both InverseLayers in one kernel: o directly
             DcsTimer tmf(ctx, DCS_TAG_DECODER);
-            const bool ok = dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F, d_cl);
+            const bool ok = g->conv_f16 ? dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F, d_cl)
+                                        : dcs_launch_decoder_x3(ctx, c, n * NB, g->Wx3, g->W1q, o, F);
             tmf.done();
             if (!ok) DCS_FAIL(DCS_EHIP, "generic graph: the fused decoder refused a launch it had accepted (channels-last %d)", (int)d_cl);
         }

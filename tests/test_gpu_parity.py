@@ -971,7 +971,7 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
     f = tmp_path / "case.npz"
     np.savez(f, x=x, F=F)
     res = {}
-    for name, env in (("cl", {}), ("cf", {"DCS_DECODER_CL": "0"})):
+    for name, env in (("cl", {}), ("cf", {"DCS_DECODER_CL": "0"}), ("nox3", {"DCS_DECODER_X3": "0"})):
         child_env = dict(os.environ)
         child_env.update(env)
         out = str(tmp_path / (name + ".npz"))
@@ -984,6 +984,11 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
     assert bool(res["cl"]["same"])                                  # and the f16 result again, to the bit, after re-packing
     assert np.array_equal(res["cl"]["p"], res["cf"]["p"])
     assert np.array_equal(res["cl"]["q"], res["cf"]["q"])
+    # switch off: the f32-class fused decoder (colconv_x3.hip: two waves per column block, taps dealt by parity, three-way
+    # split operands) against the two kernels it replaces (DCS_DECODER_X3=0: f32-MFMA column convolution + transposed conv1)
+    assert np.max(np.abs(res["nox3"]["q"] - want)) < 1e-4
+    assert np.max(np.abs(res["cl"]["q"] - res["nox3"]["q"])) < 2e-6 * max(1.0, float(np.max(np.abs(want))))
+    assert np.array_equal(res["cl"]["p"], res["nox3"]["p"])
 
 
 @pytest.mark.parametrize("env", [
