@@ -63,7 +63,7 @@ FINAL_NAMES = {"one_batch": "lat_final_kernel (deconv1+bias+relu+mask+crossfade 
                "bf16x3": "final_bf16x3_kernel (deconv1+bias+relu+mask+crossfade; bf16 MFMA on operands split into "
                          "three bf16 terms, six products kept, f32 accumulation: f32-class results)"}
 PEAK_HBM_GBPS = 8000.0
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 # which kernel carries a timing tag in each leg (substring of the kernel name in the rocprofv3 counter files); used to look
 # up the HBM traffic record of a leg's kernels in TRAFFIC_FILE["legs"][leg]
 LEG_KERNELS = {
@@ -76,14 +76,15 @@ LEG_KERNELS = {
     "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
                        "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel"},
     "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
-                   "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel"},
+                   "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
 }
 # kernels that execute on the 16-bit matrix pipe: (products issued per f32 product, K padding factor)
 LEG_ISSUED = {
     "ikala": {"conv2": (6, 32.0 / 30.0), "deconv2": (6, 32.0 / 30.0)},   # 84 tiles: the dense layers stay on the f32 MFMA (M < 128)
     "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc1x": (6, 1.0)},
     "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
-    "bach10_f32": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
+    "bach10_f32": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0),
+                   "decoder": (6, 32.0 / 30.0 * 120.0 / 110.0)},     # + the (row, tap) slots that meet a zero row (colconv_x3.hip)
 }
 
 
@@ -879,7 +880,8 @@ KERNEL_NAMES = {
     "conv1": "conv1_kernel (strided conv1 + biases)", "conv2": "conv2 (slab / column convolution, MFMA)",
     "fc": "gemm_rows (bottleneck DenseLayer)", "fc1x": "gemm_rows (per-source DenseLayers)",
     "deconv2": "transposed conv2 (slab / column convolution, MFMA)", "final": "transposed conv1 (deconv1_reg / deconv1)",
-    "decoder": "colconv_deconv1_fused_kernel (transposed conv2 + transposed conv1, weights in registers)",
+    "decoder": "colconv_deconv1_fused_kernel / colconv_deconv1_fused_x3_kernel (transposed conv2 + transposed conv1 in one kernel, "
+               "conv2^T weights in registers; f16 inputs with the switch, three-way split bf16 operands without)",
 }
 
 

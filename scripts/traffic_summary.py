@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""HBM traffic per kernel launch from the rocprofv3 --pmc passes of scripts/gpu_traffic_r03.sh -> gpurun_out/traffic.json
-(committed as profiles/r03_traffic.json, read by bench.py):
+"""HBM traffic per kernel launch from the rocprofv3 --pmc passes of scripts/gpu_traffic_r04.sh -> gpurun_out/traffic.json
+(committed as profiles/r04_traffic.json, read by bench.py):
 
   "all":  { "<kernel>@grid_threads=<n>": {FETCH_SIZE_KiB, WRITE_SIZE_KiB, launches} }   headline / one-batch / saturating shapes
   "legs": { "<leg>": { "<kernel>@grid_threads=<n>": {...} } }                               one pass pair per leg (--only-legs)
@@ -51,7 +51,7 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
     tags = sorted(set(os.path.basename(p)[len("pmc_fetch_"):] for p in glob.glob(os.path.join(out, "pmc_fetch_*")) if os.path.isdir(p)))
     doc = {"all": {}, "legs": {}, "passes": tags,
-           "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes per workload (scripts/gpu_traffic_r03.sh); "
+           "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes per workload (scripts/gpu_traffic_r04.sh); "
                    "per launch, KiB, averaged over the launches of the same kernel and grid"}
     for t in tags:
         recs = merge(out, t)

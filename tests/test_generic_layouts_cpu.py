@@ -137,3 +137,82 @@ def test_column_convolution_fragment_layouts():
             if 0 <= row < H:
                 want += Wk[u, :Cin, :].T @ x[:, row, :]
         np.testing.assert_allclose(acc.reshape(32, 16), want, rtol=0, atol=1e-11)
+
+
+# ------------------------------------------------------------------ colconv_x3.hip (round 4): taps dealt to two waves by parity
+def _x3_row0(y, s, PH, NK):
+    return (y + s // NK) - PH + 2 * (s % NK)
+
+
+def _x3_live(y, s, H, PH, NK):
+    return -1 <= _x3_row0(y, s, PH, NK) <= H - 1
+
+
+def test_x3_decoder_slot_lists_rows_and_exchange_reproduce_the_transposed_column_convolution():
+    """The f32-class fused decoder keeps taps u = 2 k + par in wave `par` and runs ONE unrolled body in both waves: slot
+    (t, k) of row pair (y, y + 1) multiplies tap k of the wave with LDS row h0 + 1 + par, h0 = y + t - 19 + 2 k, where rows
+    -1 and 11 of the plane buffer are zero; each wave then hands its partial of the row the partner finishes through LDS.
+    Restated on whole rows in NumPy -- slot liveness, the row that depends on `par`, the zero rows, the weight fragment
+    packing [parity][k] and the exchange -- against the direct InverseLayer of a 'valid' 20 x 1 convolution."""
+    KH, H, NK = 20, 11, 10
+    HO, PH = H + KH - 1, KH - 1
+    rs = np.random.RandomState(3)
+    Cin, Cout, X = 30, 30, 16
+    Wt = rs.randn(KH, Cout, Cin)                               # transposed filter: W[u][out][in] (dcs_decoder_x3_pack source order)
+    inp = rs.randn(Cin, H, X)
+    # direct: out[co][y][x] = sum_u sum_ci W[u][co][ci] in[ci][y + u - PH][x]
+    want = np.zeros((Cout, HO, X))
+    for y in range(HO):
+        for u in range(KH):
+            h = y + u - PH
+            if 0 <= h < H:
+                want[:, y] += Wt[u] @ inp[:, h]
+    # the kernel: packed weights w[par][k] = W[2 k + par]; plane rows -1 .. H with zero guard rows
+    wq = np.stack([np.stack([Wt[2 * k + par] for k in range(NK)]) for par in range(2)])
+    rows = np.zeros((H + 2, Cin, X))
+    rows[1:H + 1] = inp.transpose(1, 0, 2)
+    got = np.zeros((Cout, HO, X))
+    n_slots = [0, 0]
+    for y in range(0, HO, 2):
+        acc = np.zeros((2, 2, Cout, X))                        # [wave][t]
+        for par in range(2):
+            for s in range(2 * NK):
+                if not _x3_live(y, s, H, PH, NK):
+                    continue
+                t, k = s // NK, s % NK
+                acc[par, t] += wq[par, k] @ rows[_x3_row0(y, s, PH, NK) + 1 + par]
+                n_slots[par] += 1
+        for par in range(2):                                   # wave `par` finishes row y + par: its own partial + the partner's
+            got[:, y + par] = acc[par, par] + acc[1 - par, par]
+    assert np.max(np.abs(got - want)) < 1e-12
+    # 120 slots per wave and block for 110 (row, tap) products: 10 meet a zero row
+    assert n_slots == [120, 120]
+    live = [(y, s) for y in range(0, HO, 2) for s in range(2 * NK) if _x3_live(y, s, H, PH, NK)]
+    assert sum(1 for y, s in live if _x3_row0(y, s, PH, NK) in (-1, H - 1)) == 20     # one parity of these meets a guard row
+
+
+def test_x3_decoder_channels_last_fetch_covers_every_channel_once():
+    """Fetch task i of a pair (128 threads, 6 rounds): row i // 64, x = (i % 64) // 4, K piece i % 4; four float pairs per
+    task at channel offsets 8 kq + 2 q, the pair past channel 29 re-reading 28 / 29 (it meets zero weights).  Every (row, x,
+    channel < 30) must be fetched exactly once into K slot (kq, j) with channel 8 kq + j, and the LDS unit of plane p is
+    ((row + 1) * 3 + p) * 64 + kq * 16 + x -- what the MFMA B fragment of lane 16 kq + x reads."""
+    H, Cin = 11, 30
+    seen = np.zeros((H, 16, 32), dtype=int)
+    units = set()
+    for i in range(H * 64):
+        h, rem = i >> 6, i & 63
+        x, kq = rem >> 2, rem & 3
+        for q in range(4):
+            c = 8 * kq + 2 * q
+            src = c if c + 2 <= Cin else Cin - 2
+            for e in range(2):
+                slot = 8 * kq + 2 * q + e                      # K slot the value lands in
+                if slot < Cin:
+                    assert src + e == slot                     # real channels sit in their own slot
+                seen[h, x, slot] += 1
+        for p in range(3):
+            u = ((h + 1) * 3 + p) * 64 + kq * 16 + x
+            assert u not in units
+            units.add(u)
+    assert (seen == 1).all()
+    assert min(units) == 192 and max(units) == (H + 1) * 192 - 1     # rows 0 (= -1) and 12 (= 11) of the buffer stay zero
