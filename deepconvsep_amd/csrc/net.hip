@@ -749,16 +749,65 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
         dsd_carve(m, p, n_all, rows1, rows2, &w, split, parts);
+        // launch groups of many clips: the front of the path as two half-chains side by side -- DCS_FORK=1, OFF by default:
+        // measured on MI355X at 20 x 32 tiles it LOSES, 12.9 against 10.6 us per step (a replayed hipGraph with two branches
+        // pays for its cross-queue dependencies more than the overlapped launch ramps give back; profiles/r04_e_fork_ab.txt).
+        // DCS_FORK_MIN_CLIPS: smallest group that forks.  Not with event timing (the brackets live on one stream), not with
+        // per-clip tables (the halves would need their own), not with a null stream (nothing to order the side stream with).
+        static const bool fork_env = getenv("DCS_FORK") && atoi(getenv("DCS_FORK")) == 1;
+        static const int fork_min = getenv("DCS_FORK_MIN_CLIPS") ? atoi(getenv("DCS_FORK_MIN_CLIPS")) : 8;
+        bool fork_halves = fork_env && lat == 0 && n_clips >= fork_min && n_clips >= 2 && !clip_tab_d && !phase &&
+                           m->ctx->timing_mask == 0 && m->ctx->stream != nullptr && m->C == 1;
+        if (fork_halves) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (!m->ctx->side_stream) {
+                // creating a stream inside a capture is not allowed: the first (eager) call of a shape creates it
+                if (hipStreamIsCapturing(m->ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) fork_halves = false;
+                else DCS_CHECK(dcs_ctx_side_stream(m->ctx));
+            }
+        }
         constexpr unsigned kFuse1 = DCS_LAT_STFT | DCS_LAT_CONV1 | DCS_LAT_FUSE1;
         if ((lat & kFuse1) == kFuse1 && ld != plan->frame / 2 + 4) lat &= ~(unsigned)DCS_LAT_FUSE1;
         if ((lat & kFuse1) == kFuse1)     // STFT + conv1 of the frames the tiles cover: H1 rows 0 .. Tcov-1 (Trows >= Tcov)
             DCS_CHECK(dcs_launch_lat_stft_conv1(plan, audio_d, L, mag, phase, unit, ld, Trows, T, m->B1, m->bias1, w.H1, rows1, m->CI, scale));
         else if (lat & DCS_LAT_STFT)
             DCS_CHECK(dcs_launch_lat_stft(plan, audio_d, L, mag, phase, unit, ld, Trows, T));
-        else
+        else if (fork_halves) {
+            // STFT -> conv1 -> conv2 -> bottleneck -> dense -> conv2^T are per-clip chains of small, latency-bound launches
+            // (60 - 240 workgroups each at 640 tiles): the two halves of the clips run side by side, clips [0, cA) on the
+            // context's stream and [cA, n_clips) on its side stream, and join in front of the final kernel, which -- like the
+            // inverse STFT -- fills the chip and stays one launch.  Every buffer is indexed by clip / row / tile, so a half
+            // is the same call on offset pointers.  (Inside a relaxed graph capture the event wait pulls the side stream
+            // into the capture: the replayed graph has the two branches.)
+            dcs_ctx* c = m->ctx;
+            const int64_t cA = n_clips / 2, cB = n_clips - cA;
+            hipStream_t main_s = c->stream;
+            DCS_HIP(hipEventRecord(c->ev_fork, main_s));
+            DCS_HIP(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+            int rc = DCS_OK;
+            for (int half = 0; half < 2 && rc == DCS_OK; ++half) {
+                const int64_t c0 = half ? cA : 0, nc = half ? cB : cA;
+                const int64_t r0 = c0 * Trows, t0 = c0 * n;
+                c->stream = half ? c->side_stream : main_s;
+                DsdScratch wh = w;
+                wh.H1 = w.H1 + r0 * m->CI; wh.C2 = w.C2 + r0 * m->CP; wh.Z = w.Z + t0 * m->hid64; wh.D = w.D + t0 * m->nd;
+                wh.G = w.G + t0 * m->d.n_fc * (int64_t)dsd_g_pitch(m->CI, tc);
+                if (w.Gs) wh.Gs = (char*)w.Gs + (size_t)t0 * m->d.n_fc * dsd_gs_pitch(m->CI, tc) * 16;
+                rc = dcs_launch_stft_forward_f32_clips(plan, audio_d + c0 * audio_stride, L, audio_stride, nc, mag + r0 * ld, nullptr,
+                                                       unit + r0 * ld, ld, Trows, T, false, nullptr);
+                if (rc == DCS_OK) rc = dsd_encode(m, mag + r0 * ld, ld, true, scale, n, st, true, wh, nc, Trows, 0);
+            }
+            c->stream = main_s;
+            // join even after an error: a capture in progress must not be left with a dangling branch
+            const hipError_t e1 = hipEventRecord(c->ev_join, c->side_stream);
+            const hipError_t e2 = hipStreamWaitEvent(main_s, c->ev_join, 0);
+            DCS_CHECK(rc);
+            DCS_HIP(e1);
+            DCS_HIP(e2);
+        } else
             DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,
                                                         false, clip_tab_d));
-        DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows, lat));
+        if (!fork_halves) DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows, lat));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
         a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
