@@ -183,6 +183,13 @@ int dcs_launch_stft_inverse_f64(dcs_stft* p, const double* mag, int64_t src_stri
                                 const double2* unit, int64_t ld, int64_t T, int n_src, double pre_div, double* audio,
                                 int64_t n_out);
 
+// ---------------------------------------------------------------------------------- clips of different lengths in one launch
+// Device table of kDcsClipTab int64 per clip (separate_impl, net.hip): {samples, frames, tiles, row offset, tile offset, rows}.
+// row offset < 0: the clips are stacked with a uniform pitch (the caller's strides apply; the generic graphs).  Otherwise the
+// DSD path's compact layout: clip c owns rows [row offset, + rows) of the spectrogram-shaped buffers (mag, unit, H1, C2) and
+// tiles [tile offset, + tiles) of the tile-shaped ones (Z, D, G) -- a group costs the SUM of its clips, not n x the longest.
+constexpr int kDcsClipTab = 6;
+
 // ---------------------------------------------------------------------------------- GEMM on rows
 // C[row(r)][0..n_store) = act( a_scale * A[arow(r)][0..K) . B[K][ldb] + bias )
 //   arow(r) = ((r / a_gdiv) * a_gmul + r % a_gdiv) * lda      (elements)
@@ -190,6 +197,8 @@ int dcs_launch_stft_inverse_f64(dcs_stft* p, const double* mag, int64_t src_stri
 // B is padded with zero rows to a multiple of 128 (the largest K tile) and ldb is a multiple of 64.
 struct DcsGemm {
     const float* A; int64_t lda; int a_gdiv; int64_t a_gmul; float a_scale;
+    const int* a_rowmap;     // optional (device): arow(r) = a_rowmap[r] * lda instead of the grouped-row formula (ragged clip groups
+                             // with per-clip row offsets: tile -> first row of its frames; f32 kernels of gemm.hip only)
     const float* B; int ldb;
     const float* bias;
     float* C; int64_t ldc; int c_gdiv; int64_t c_gmul;

@@ -35,8 +35,11 @@ struct DsdFinalArgs {
     const void* Gs;
     const void* Bpk;
     int64_t gs_clip_stride;   // 16-byte units
-    const int64_t* clip_tab;  // device {samples, frames, tiles} per clip when the stacked clips differ in length (n and
-                              // rows above are then the maxima that size the grid and the strides), else null
+    const int64_t* clip_tab;  // device table (kDcsClipTab entries per clip, dcs_internal.h) when the stacked clips differ in
+                              // length (n and rows above are then the maxima that size the grid and the output strides),
+                              // else null.  With row offsets >= 0 in it (compact layout) the mixture rows of clip c start at
+                              // row offset[c] and its G at tile offset[c] * g_tile_stride (gs_tile_stride: 16-byte units)
+    int64_t g_tile_stride, gs_tile_stride;
 };
 
 // Bw:  [CP][NG * gcols], column (g, c, dt) -> g*gcols + c*kh + dt holds W2c[co, g*GS + c, dt]   (few tiles)

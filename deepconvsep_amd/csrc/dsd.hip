@@ -347,9 +347,15 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
     int n = (int)a.n, rows = (int)a.rows;
     if (a.clip_tab) {   // stacked clips of different lengths: this clip's own tile and frame counts
-        rows = (int)a.clip_tab[3 * clip + 1];
-        n = (int)a.clip_tab[3 * clip + 2];
+        rows = (int)a.clip_tab[kDcsClipTab * clip + 1];
+        n = (int)a.clip_tab[kDcsClipTab * clip + 2];
         if (row0 >= rows) return;   // workgroup-uniform, before any barrier
+    }
+    // where this clip's mixture rows and G live: uniform pitch, or the compact layout's per-clip offsets
+    int64_t mix_off = clip * a.mix_clip_stride, g_off = clip * a.g_clip_stride;
+    if (a.clip_tab && a.clip_tab[kDcsClipTab * clip + 3] >= 0) {
+        mix_off = a.clip_tab[kDcsClipTab * clip + 3] * a.mix_ld;
+        g_off = a.clip_tab[kDcsClipTab * clip + 4] * a.g_tile_stride;
     }
 
     // ---- per-row state, once per workgroup: owner tile k0 / position j0 of each row, then the table of
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     // mixture value of this lane's 4 rows x 2 bins
     const bool vec = CBW == 2 && ((a.mix_ld | a.out_ld) & 1) == 0;  // rows 8-byte aligned (the fused path pads F to 4)
     f32x4 mixv[CBW];
-    const float* mix0 = a.mix + clip * a.mix_clip_stride + (int64_t)row0 * a.mix_ld;   // workgroup-uniform
+    const float* mix0 = a.mix + mix_off + (int64_t)row0 * a.mix_ld;   // workgroup-uniform
     const int rows_here = rows - row0 < 16 ? rows - row0 : 16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
             // CBW == 1 is the few-workgroups variant, where the duration is one workgroup's dependent chain: with the
             // full 64-bit address the compiler issues these loads ahead of the staging plan (15.3 -> 12.6 us at 32 tiles);
             // with many workgroups the cheaper 32-bit offset wins
-            const float* mp = CBW == 1 ? a.mix + clip * a.mix_clip_stride + (int64_t)(row0 + ri) * a.mix_ld + col
+            const float* mp = CBW == 1 ? a.mix + mix_off + (int64_t)(row0 + ri) * a.mix_ld + col
                                        : mix0 + (ri * (int)a.mix_ld + col);
             if (vec && col + 1 < a.F) {
                 const f32x2 v = *reinterpret_cast<const f32x2*>(mp);
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(kThreads, NBR == 3 ? 3 : 2) void final_kernel(const
     const int m_delta = (NBR * NGG * tc - st) * kDsdGch;
     const int kbase = meta_k0[0];
     // workgroup-uniform base; the per-slot offsets stay 32-bit
-    const float* gbase = a.G + clip * a.g_clip_stride + (int64_t)kbase * NBR * NGG * tc * kDsdGch;
+    const float* gbase = a.G + g_off + (int64_t)kbase * NBR * NGG * tc * kDsdGch;
     constexpr int NSL = (slots + kThreads - 1) / kThreads;   // float4 slots per thread: 3 (NBR = 3) or 4
     // A slot is loaded for EVERY covering tile: where tile m has no weight on the slot's row (up = 0, down = 1: the
     // row keeps what it has) the address is clamped to the last tile that does -- finite values that the epilogue

@@ -137,9 +137,15 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
     const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
     int n = (int)a.n, rows = (int)a.rows;
     if (a.clip_tab) {
-        rows = (int)a.clip_tab[3 * clip + 1];
-        n = (int)a.clip_tab[3 * clip + 2];
+        rows = (int)a.clip_tab[kDcsClipTab * clip + 1];
+        n = (int)a.clip_tab[kDcsClipTab * clip + 2];
         if (row0 >= rows) return;
+    }
+    // where this clip's mixture rows and G planes live: uniform pitch, or the compact layout's per-clip offsets
+    int64_t mix_off = clip * a.mix_clip_stride, gs_off = clip * a.gs_clip_stride;
+    if (a.clip_tab && a.clip_tab[kDcsClipTab * clip + 3] >= 0) {
+        mix_off = a.clip_tab[kDcsClipTab * clip + 3] * a.mix_ld;
+        gs_off = a.clip_tab[kDcsClipTab * clip + 4] * a.gs_tile_stride;
     }
 
     if (tid < 16 * mmax) {
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
 
     const bool vec = ((a.mix_ld | a.out_ld) & 1) == 0;
     f32x4 mixv[CBW];
-    const float* mix0 = a.mix + clip * a.mix_clip_stride + (int64_t)row0 * a.mix_ld;
+    const float* mix0 = a.mix + mix_off + (int64_t)row0 * a.mix_ld;
     const int rows_here = rows - row0 < 16 ? rows - row0 : 16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
     constexpr int NSL = (slots + kThreads - 1) / kThreads;   // 4
     const int m_delta = (NBR * kNgg * tc - st) * 3;          // 16-byte units from covering tile m to m + 1
     const int kbase = meta_k0[0];
-    const u32x4* gbase = reinterpret_cast<const u32x4*>(a.Gs) + clip * a.gs_clip_stride + (int64_t)kbase * NBR * kNgg * tc * 3;
+    const u32x4* gbase = reinterpret_cast<const u32x4*>(a.Gs) + gs_off + (int64_t)kbase * NBR * kNgg * tc * 3;
     // every slot is loaded for every covering tile, with the tile index clamped to the last one that has a weight on
     // the slot's row (see final_kernel in dsd.hip): no data-dependent branch in front of the loads
     int goff[NSL], dst[NSL], mlim[NSL];

@@ -331,12 +331,17 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     if (row >= rows_pc * n_clips) return;
     const int64_t clip = row / rows_pc;
     const int64_t t = row - clip * rows_pc;
-    if (clip_tab) {   // clips of different lengths share the launch: {samples, frames, tiles} per clip
-        L = clip_tab[3 * clip];
-        T = clip_tab[3 * clip + 1];
+    int64_t orow = interleave ? t * n_clips + clip : row;         // interleave: rows ordered [frame][clip]
+    if (clip_tab) {   // clips of different lengths share the launch: kDcsClipTab entries per clip (dcs_internal.h)
+        L = clip_tab[kDcsClipTab * clip];
+        T = clip_tab[kDcsClipTab * clip + 1];
+        const int64_t r0 = clip_tab[kDcsClipTab * clip + 3];
+        if (r0 >= 0) {                                            // compact layout: the clip's own rows at its own offset
+            if (t >= clip_tab[kDcsClipTab * clip + 5]) return;
+            orow = r0 + t;
+        }
     }
     audio += clip * audio_stride;
-    const int64_t orow = interleave ? t * n_clips + clip : row;   // interleave: rows ordered [frame][clip]
     float* mrow = mag + orow * ld;
     float* prow = phase ? phase + orow * ld : nullptr;
     float2* urow = unit ? unit + orow * ld : nullptr;
@@ -549,8 +554,8 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
     const int hp = hop >> 1, R = N / hop, rmask = ring_slots - 1;
     if (clip_tab) {   // clips of different lengths: this source's own sample / frame / hop-block counts
         const int64_t c = s / src_per_clip;
-        n_out = clip_tab[3 * c];
-        T = clip_tab[3 * c + 1];
+        n_out = clip_tab[kDcsClipTab * c];
+        T = clip_tab[kDcsClipTab * c + 1];
         n_blocks = (n_out + M + hop - 1) / hop;
         if ((int64_t)chunk * C >= n_blocks) return;   // workgroup-uniform, before any barrier
     }
@@ -582,7 +587,11 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
     const float inv_m = 1.f / (float)M;
     const float amp = 0.5f * (sqrt_n / pre_div);  // (mag / scale_factor) sqrt(N), and the 1/2 of the even/odd split
     const float* msrc = mag + (int64_t)s * src_stride;
-    unit += (int64_t)(s / src_per_clip) * unit_clip_stride;  // stacked clips: each has its own phasor rows
+    {   // stacked clips: each has its own phasor rows -- at a uniform pitch, or (compact ragged layout) at its row offset
+        const int64_t c_ = s / src_per_clip;
+        const int64_t r0_ = clip_tab ? clip_tab[kDcsClipTab * c_ + 3] : -1;
+        unit += r0_ >= 0 ? r0_ * ld : c_ * unit_clip_stride;
+    }
     float* dst = audio + (int64_t)s * out_stride;
     __syncthreads();
     WaveTw<LOG2M> wt;
@@ -769,8 +778,8 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
     if (chunk >= n_chunks) return;
     if (clip_tab) {   // clips of different lengths: this source's own sample / frame / hop-block counts
         const int64_t c = s / src_per_clip;
-        n_out = clip_tab[3 * c];
-        T = clip_tab[3 * c + 1];
+        n_out = clip_tab[kDcsClipTab * c];
+        T = clip_tab[kDcsClipTab * c + 1];
         n_blocks = (n_out + M + hop - 1) / hop;
     }
     const int64_t hb0 = chunk * C;
@@ -780,7 +789,11 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
     const int64_t n_last = (hb1 - 1 < T - 1) ? hb1 - 1 : T - 1;
     const float amp = 0.5f * (sqrt_n / pre_div);  // (mag / scale_factor) sqrt(N), and the 1/2 of the even/odd split
     const float* msrc = mag + (int64_t)s * src_stride;
-    unit += (int64_t)(s / src_per_clip) * unit_clip_stride;
+    {
+        const int64_t c_ = s / src_per_clip;
+        const int64_t r0_ = clip_tab ? clip_tab[kDcsClipTab * c_ + 3] : -1;
+        unit += r0_ >= 0 ? r0_ * ld : c_ * unit_clip_stride;
+    }
     float* dst = audio + (int64_t)s * out_stride;
     const bool dst_al = (reinterpret_cast<uintptr_t>(dst) & 7) == 0;   // sample pairs start at even offsets
     WaveTw<LOG2M> wt;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
         const int64_t r = m0 + row;
         a_ok[u] = (idx < A_F4) && (r < gM);
         const int64_t rr = a_ok[u] ? r : 0;
-        a_ptr[u] = g.A + ((rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda;
+        a_ptr[u] = g.A + (g.a_rowmap ? (int64_t)g.a_rowmap[rr] : (rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda;
     }
     const float* b_ptr[B_PER];
     int b_row[B_PER], b_c4[B_PER];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
     const int64_t r = m0 + fi;
     const bool row_ok = r < g.M;
     const int64_t rr = row_ok ? r : 0;
-    const float* a_ptr = g.A + ((rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda + 4 * kq;
+    const float* a_ptr = g.A + (g.a_rowmap ? (int64_t)g.a_rowmap[rr] : (rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda + 4 * kq;
     const float* b_ptr = g.B + (int64_t)(4 * kq) * gldb + n0 + fi;
 
     f32x4 a_cur[4], a_nxt[4];
@@ -306,7 +306,7 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     if (g.n_cols % BN) DCS_FAIL(DCS_EINVAL, "gemm_rows: n_cols %d not a multiple of %d", g.n_cols, BN);
     if (g.a_vec && ((g.K & 3) || (g.lda & 3))) DCS_FAIL(DCS_EINVAL, "gemm_rows: vector path needs K, lda %% 4 == 0");
     DcsTimer tm(ctx, tag);
-    if (dcs_launch_gemm_bf16x3(ctx, g)) {   // B available as bf16 planes and the launch fills the chip
+    if (!g.a_rowmap && dcs_launch_gemm_bf16x3(ctx, g)) {   // B available as bf16 planes and the launch fills the chip
         tm.done();
         DCS_HIP(hipGetLastError());
         return DCS_OK;

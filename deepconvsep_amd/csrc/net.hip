@@ -340,9 +340,12 @@ struct DsdScratch {
 //             (a multiple of st).  conv1 / conv2 simply run over all rows -- positions that straddle two clips are
 //             computed and never read -- and the bottleneck's A row of tile (c, k) is row c*clip_pitch + k*st.
 //   lat     : stage bits (dsd_lat.h) whose layer runs on the one-batch kernels of dsd_lat.hip (one clip, shared frames)
+//   ragged  : (rows_total, tiles_total, rowmap) -- clips of different lengths in the compact layout (kDcsClipTab): the rows of
+//             all clips back to back, the tiles of all clips back to back, rowmap[tile] = first C2 row of the tile / st
 int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, float a_scale, int64_t n,
                int64_t tile_row_stride /* st or tc */, bool shared_frames, const DsdScratch& w, int64_t n_clips = 1,
-               int64_t clip_pitch = 0, unsigned lat = 0) {
+               int64_t clip_pitch = 0, unsigned lat = 0, int64_t rows_total = 0, int64_t tiles_total = 0,
+               const int* rowmap = nullptr) {
     const Dims& d = m->d;
     const int tc = m->tc, CI = m->CI, CP = m->CP;
     const int64_t BIG = (int64_t)1 << 40;
@@ -358,7 +361,10 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     const bool split2 = (lat & DCS_LAT_CONV2) && (lat & DCS_LAT_FC) && !mid;
     const bool split3 = (lat & DCS_LAT_FC) && (lat & DCS_LAT_FC1X) && !mid;
     // conv1 + both biases  (separate_dsd.py:198-199)
-    const int64_t n_rows1 = clips ? n_clips * clip_pitch : (shared_frames ? (n - 1) * tile_row_stride + tc : n * tc);
+    const bool ragged = rowmap != nullptr;
+    if (ragged && (!clips || lat || rows_total < tc || tiles_total < 1)) DCS_FAIL(DCS_EINVAL, "dsd_encode: bad ragged batch");
+    const int64_t n_rows1 = ragged ? rows_total : (clips ? n_clips * clip_pitch : (shared_frames ? (n - 1) * tile_row_stride + tc : n * tc));
+    const int64_t n_tiles_all = ragged ? tiles_total : n * n_clips;
     DcsGemm g1{};
     g1.A = rows_src; g1.lda = lda; g1.a_gdiv = 1 << 30; g1.a_gmul = 0; g1.a_scale = a_scale;
     g1.B = m->B1; g1.ldb = 64; g1.bias = m->bias1;
@@ -408,9 +414,10 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     DcsGemm g3{};
     g3.A = w.C2; g3.lda = (shared_frames ? tile_row_stride : d.h2) * (int64_t)CP; g3.a_gdiv = 1 << 30; g3.a_gmul = 0;
     if (clips) { g3.a_gdiv = (int)n; g3.a_gmul = clip_pitch / tile_row_stride; }
+    if (ragged) g3.a_rowmap = rowmap;
     g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc;
     g3.C = w.Z; g3.ldc = m->hid64; g3.c_gdiv = 1 << 30; g3.c_gmul = 0;
-    g3.M = n * n_clips; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
+    g3.M = n_tiles_all; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
     if (lat & DCS_LAT_FC) {
         DcsLatGemm q{};   // the A row of tile k is h2 consecutive C2 rows from row k * st: one slice per row
         q.A = w.C2; q.a_row_stride = tile_row_stride * (int64_t)CP; q.a_scale = 1.f; q.Bp = m->Lfcp; q.bias = m->biasfc;
@@ -427,7 +434,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g4.A = w.Z; g4.lda = m->hid64; g4.a_gdiv = 1 << 30; g4.a_gmul = 0; g4.a_scale = 1.f;
     g4.B = m->Bd; g4.ldb = m->nd64; g4.bias = m->biasd; g4.Bq = m->Bdq;
     g4.C = w.D; g4.ldc = m->nd; g4.c_gdiv = 1 << 30; g4.c_gmul = 0;
-    g4.M = n * n_clips; g4.n_cols = m->nd64; g4.n_store = m->nd; g4.K = m->hid64; g4.relu = 1; g4.a_vec = 1;
+    g4.M = n_tiles_all; g4.n_cols = m->nd64; g4.n_store = m->nd; g4.K = m->hid64; g4.relu = 1; g4.a_vec = 1;
     if (lat & DCS_LAT_FC1X) {
         DcsLatGemm q{};
         q.A = w.Z; q.a_row_stride = m->hid64; q.a_scale = 1.f; q.Bp = m->Ldp; q.bias = m->biasd;
@@ -441,7 +448,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     if (lat & DCS_LAT_DECONV2)   // f32 G only when a consumer reads it (the one-batch final kernel multiplies the planes)
         return dcs_launch_lat_deconv2(m->ctx, w.D, m->Lw2p, (w.Gs && ((lat & DCS_LAT_FINAL) || clips)) ? nullptr : w.G, w.Gs,
                                       n * n_clips * d.n_fc);
-    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n * n_clips * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
+    return dcs_launch_dsd_deconv2(m->ctx, w.D, m->Bw2, m->Bw2s, w.G, n_tiles_all * d.n_fc, d.h2, CP, CI, d.kh2, tc, m->d2_ng, m->d2_gs,
                                   m->d2_gcols, w.Gs, m->Bw2q);
 }
 
@@ -682,29 +689,56 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
     int64_t T = dcs_frame_count(L, plan->hop);
     int64_t n = dcs_tile_count(T, tc, ov, tiler);
     const int64_t* clip_tab_d = nullptr;
+    const int* rowmap_d = nullptr;
+    bool ragged_compact = false;
+    int64_t rows_sum = 0, tiles_sum = 0;
     if (lens_h) {
         // clips of different lengths in one set of launches: strides and grids are sized by the longest clip (L on
         // entry), every kernel that depends on a clip's own length reads {samples, frames, tiles} from a device table
         if (m->arch == DCS_ARCH_DSD_ILD || m->C != 1 || !pcm_d || pcm_stride < L || n_clips < 2)
             DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_ragged: single-channel graphs with PCM output and pcm_stride >= longest clip only");
-        const size_t tab_n = (size_t)n_clips * 3;
+        // kDcsClipTab entries per clip {samples, frames, tiles, row offset, tile offset, rows} and, behind them, the
+        // bottleneck GEMM's tile -> row map (int32).  The DSD graph takes the COMPACT layout (DCS_RAGGED_COMPACT=0: the
+        // uniform pitch of round 3): clip c owns rows [row offset, + rows) and tiles [tile offset, + tiles), so the encoder
+        // GEMMs, the dense layers and the transposed conv2 run over the SUM of the clips, not n x the longest.
+        static const bool compact_env = !(getenv("DCS_RAGGED_COMPACT") && atoi(getenv("DCS_RAGGED_COMPACT")) == 0);
+        ragged_compact = compact_env && m->arch == DCS_ARCH_DSD;
+        int64_t tiles_bound = 0;
+        for (int64_t c = 0; c < n_clips; ++c) {
+            const int64_t Lc = lens_h[c];
+            if (Lc < 1 || Lc > L) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: clip %lld has %lld samples", (long long)c, (long long)Lc);
+            tiles_bound += dcs_tile_count(dcs_frame_count(Lc, plan->hop), tc, ov, tiler);
+        }
+        const size_t tab_n = (size_t)n_clips * kDcsClipTab;
+        const size_t tab_bytes = tab_n * sizeof(int64_t) + (ragged_compact ? (size_t)tiles_bound * sizeof(int) : 0);
         void *tab_h = nullptr, *tab_d = nullptr;
-        DCS_CHECK(m->clip_ring.begin(tab_n * sizeof(int64_t), &tab_h, &tab_d));
+        DCS_CHECK(m->clip_ring.begin(tab_bytes, &tab_h, &tab_d));
         int64_t* tab = (int64_t*)tab_h;
+        int* rowmap_h = (int*)(tab + tab_n);
         T = 0;
         n = 0;
         for (int64_t c = 0; c < n_clips; ++c) {
             const int64_t Lc = lens_h[c];
-            if (Lc < 1 || Lc > L) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: clip %lld has %lld samples", (long long)c, (long long)Lc);
             const int64_t Tc = dcs_frame_count(Lc, plan->hop), nc = dcs_tile_count(Tc, tc, ov, tiler);
             if (nc < 1) DCS_FAIL(DCS_EINVAL, "dcs_separate_ragged: clip %lld: %lld frames give no tile", (long long)c, (long long)Tc);
-            tab[3 * c] = Lc; tab[3 * c + 1] = Tc; tab[3 * c + 2] = nc;
+            const int64_t Tcov_c = (nc - 1) * st + tc;
+            const int64_t rows_c = dcs_round_up(Tcov_c > Tc ? Tcov_c : Tc, st);
+            tab[kDcsClipTab * c] = Lc; tab[kDcsClipTab * c + 1] = Tc; tab[kDcsClipTab * c + 2] = nc;
+            tab[kDcsClipTab * c + 3] = ragged_compact ? rows_sum : -1;
+            tab[kDcsClipTab * c + 4] = tiles_sum;
+            tab[kDcsClipTab * c + 5] = rows_c;
+            if (ragged_compact)
+                for (int64_t k = 0; k < nc; ++k) rowmap_h[tiles_sum + k] = (int)(rows_sum / st + k);
+            rows_sum += rows_c;
+            tiles_sum += nc;
             if (n_tiles_out) n_tiles_out[c] = nc;
             if (n_frames_out) n_frames_out[c] = Tc;
             if (Tc > T) T = Tc;
             if (nc > n) n = nc;
         }
-        DCS_CHECK(m->clip_ring.commit(tab_n * sizeof(int64_t), m->ctx->stream));   // no synchronisation: DcsUploadRing
+        if (rows_sum / st + n > 0x7fffffff) DCS_FAIL(DCS_EUNSUPPORTED, "dcs_separate_ragged: %lld rows", (long long)rows_sum);
+        DCS_CHECK(m->clip_ring.commit(tab_bytes, m->ctx->stream));   // no synchronisation: DcsUploadRing
+        rowmap_d = ragged_compact ? (const int*)((const int64_t*)tab_d + tab_n) : nullptr;
         clip_tab_d = (const int64_t*)tab_d;
     } else {
         if (n_tiles_out) *n_tiles_out = n;
@@ -807,7 +841,9 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         } else
             DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,
                                                         false, clip_tab_d));
-        if (!fork_halves) DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows, lat));
+        if (!fork_halves)
+            DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows, lat, ragged_compact ? rows_sum : 0,
+                                 ragged_compact ? tiles_sum : 0, ragged_compact ? rowmap_d : nullptr));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
         a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
@@ -820,6 +856,8 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         a.mix_clip_stride = Trows * ld;
         a.out_clip_stride = (int64_t)S * T * ld;
         a.clip_tab = clip_tab_d;
+        a.g_tile_stride = m->d.n_fc * (int64_t)dsd_g_pitch(m->CI, tc);       // compact ragged layout: G of clip c at its tile offset
+        a.gs_tile_stride = m->d.n_fc * (int64_t)dsd_gs_pitch(m->CI, tc);
         if (split) {
             a.Gs = w.Gs;
             a.Bpk = m->Bpk;

@@ -190,10 +190,12 @@ class Separator(object):
         pcm = self.net.separate(self.plan, a, self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)
         return self.ctx.to_host(pcm).astype(np.float64)
 
-    def separate_many(self, audios, max_group=16, max_ratio=1.5, on_error='raise'):
+    def separate_many(self, audios, max_group=16, max_ratio=None, on_error='raise'):
         """A list of clips -> a list of float64 ``[S, L_i]``.  Clips share sets of kernel launches (DSD / hiphop graph):
         sorted by length, they are cut into groups of at most ``max_group`` clips whose longest is at most
-        ``max_ratio`` times the shortest (a group costs what its longest clip costs, times its size); a group goes
+        ``max_ratio`` times the shortest (default 3 for the DSD graph, whose ragged launches cost the SUM of their clips since
+        round 4 -- per-clip row and tile offsets; 1.5 for the other graphs, where a group still costs what its longest clip
+        costs, times its size); a group goes
         through ``dcs_separate_ragged`` (``dcs_separate_batch`` when its lengths are equal).  Every clip gets exactly
         the frames, the tiles and the cross-fade :meth:`separate` gives it alone.  Frame sizes the wave STFT kernels do
         not cover share launches between clips of equal length only (``dcs_separate_batch``); groups of one go through
@@ -201,6 +203,8 @@ class Separator(object):
         (empty, or too short for one tile) never join a shared launch; ``on_error='return'`` puts the exception the
         single-clip path raises for them into their slot of the result instead of raising it."""
         audios = [np.asarray(a) for a in audios]
+        if max_ratio is None:
+            max_ratio = 3.0 if self.arch_name in ("dsd", "hiphop") else 1.5
         for i, a in enumerate(audios):
             if a.ndim != 1:
                 # [L, 1] / [1, L] mono arrays are flattened; reshape(-1) of a real [L, 2] array would interleave its

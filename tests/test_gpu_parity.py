@@ -1066,7 +1066,8 @@ sys.exit(0 if (e_many < 5e-6 and e_same < 5e-6 and e_ref < 1e-4) else 3)
 
 @pytest.mark.parametrize("N", [1024, 2048])
 @pytest.mark.parametrize("env", [{"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE": "0"},
-                                 {"DCS_FORK": "1", "DCS_FORK_MIN_CLIPS": "2"}])   # the front of a batch as two half-chains on two streams
+                                 {"DCS_FORK": "1", "DCS_FORK_MIN_CLIPS": "2"},    # the front of a batch as two half-chains on two streams
+                                 {"DCS_RAGGED_COMPACT": "0"}])                    # ragged groups at the uniform pitch of round 3 (default: per-clip row / tile offsets)
 def test_staged_istft_on_ragged_groups_and_batches(env, N, tmp_path):
     """The LDS-staged inverse STFT (normally long clips only) forced onto short ones: a ragged group (per-clip frame counts
     from the device table: the four waves of a workgroup must still walk the same frames), an equal-length batch and single
