@@ -21,6 +21,19 @@
 
 #include <stdlib.h>
 
+#ifdef DCS_FINAL_TRACE
+// in-kernel timeline (scripts/build_exp.sh finaltrace dsd_bf16x3.hip -DDCS_FINAL_TRACE; scripts/gpu_final_trace.py): s_memtime
+// stamps of wave 0 of the middle workgroup of the middle clip, read back through final_trace_dump()
+__device__ unsigned long long final_trace_buf[64];
+#define FT_STAMP(slot)                                                                                      \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)                 \
+            final_trace_buf[slot] = __builtin_amdgcn_s_memtime();                                           \
+    } while (0)
+#else
+#define FT_STAMP(slot)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -123,6 +136,7 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
     __shared__ int meta_j0[16];
     __shared__ int meta_mlim[16];
 
+    FT_STAMP(0);
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
@@ -229,7 +243,9 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
 #pragma unroll
         for (int c = 0; c < 4; ++c) res[cb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    FT_STAMP(1);    // tables written, B fragments and mixture rows requested
     __syncthreads();
+    FT_STAMP(2);    // table barrier passed
 
     // staging plan: the A set of a covering tile is [3 branches][16 rows][3 planes][7 channel groups] 16-byte pieces
     // (1008; the 8th group of the K = 64 axis is zeroed once below).  Slot idx -> (branch s, piece pg = plane * 7 + g, row i)
@@ -320,6 +336,15 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
                     else
                         af[p][kb] = a0[s * 16 * kRowLds + p * kPlaneLds + kb * 4];
                 }
+#ifdef DCS_FINAL_ABL_NOMFMA        // ablation: the fragments are consumed by one vector add each instead of twelve MFMAs
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int cb = 0; cb < CBW; ++cb) acc[s][cb] += __builtin_bit_cast(f32x4, af[p][kb]) * 1e-30f;
+            continue;
+#endif
             // smallest terms first; the two column blocks alternate so that no MFMA waits for the one before it
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -342,6 +367,13 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[0][kb], breg[cb][0][kb], acc[s][cb]);
         }
+#ifdef DCS_FINAL_ABL_NOEPI         // ablation: no mask / fold arithmetic (the accumulators are summed so that the MFMAs stay)
+        {
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) res[cb][0] += (acc[0][cb] + acc[1][cb]) + acc[2][cb];
+            return;
+        }
+#endif
         const f32x4 up4 = *reinterpret_cast<const f32x4*>(up_t + m * 16 + kq * 4);
         const f32x4 down4 = *reinterpret_cast<const f32x4*>(down_t + m * 16 + kq * 4);
 #pragma unroll
@@ -380,18 +412,37 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
     // more registers and measured slower: 0.360 vs 0.346 ms at 4096 tiles)
     if constexpr (DIRECT) {
         DCS_LOAD_A_DIRECT(0, As)
+        FT_STAMP(3);    // staging plan made, first A set requested
         for (int m = 0; m < mmax; m += 2) {
             // tile m's transfers (issued one compute phase ago) have landed -- here, and behind the barrier in the other
             // waves; the barrier also says that everybody is done with tile m - 1, whose buffer tile m + 1 now overwrites
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FT_STAMP(4 + 4 * m);     // own transfers of tile m landed
             __syncthreads();
+            FT_STAMP(5 + 4 * m);     // barrier passed
+#ifndef DCS_FINAL_ABL_NODMA       // ablation builds (scripts/build_exp.sh, never shipped): the first tile's data is re-used
             if (m + 1 < mmax) DCS_LOAD_A_DIRECT(m + 1, As1)
+#endif
+            FT_STAMP(6 + 4 * m);     // next tile requested
             if (live) compute(m, As + lane, As + lane1);
+            FT_STAMP(7 + 4 * m);     // fragments read, 72 MFMAs, mask + fold done
             if (m + 1 >= mmax) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FT_STAMP(8 + 4 * m);
+#ifndef DCS_FINAL_ABL_NOBARRIER
             __syncthreads();
+#endif
+            FT_STAMP(9 + 4 * m);
+#ifndef DCS_FINAL_ABL_NODMA
             if (m + 2 < mmax) DCS_LOAD_A_DIRECT(m + 2, As)
+#endif
+            FT_STAMP(10 + 4 * m);
+#ifdef DCS_FINAL_ABL_NODMA
+            if (live) compute(m + 1, As + lane, As + lane1);
+#else
             if (live) compute(m + 1, As1 + lane, As1 + lane1);
+#endif
+            FT_STAMP(11 + 4 * m);
         }
     } else {
         DCS_LOAD_A(0, pre)
@@ -406,6 +457,7 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
 #undef DCS_STORE_A
 #undef DCS_LOAD_A_DIRECT
 
+    FT_STAMP(28);   // every covering tile folded
     // per source a workgroup-uniform base (scalar registers) plus one 32-bit lane offset per row
     float* out0 = a.out + clip * a.out_clip_stride + (int64_t)row0 * a.out_ld;
     float* outc[4];
@@ -435,6 +487,11 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
             }
         }
     }
+#ifdef DCS_FINAL_TRACE
+    FT_STAMP(29);   // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FT_STAMP(30);   // stores acknowledged
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -656,4 +713,14 @@ int dcs_launch_dsd_final_bf16x3(dcs_ctx* ctx, const DsdFinalArgs& a, int n_colg,
     }
     DCS_HIP(hipGetLastError());
     return DCS_OK;
+}
+
+extern "C" DCS_API int final_trace_dump(unsigned long long* out, int n) {
+#ifdef DCS_FINAL_TRACE
+    if (!out || n < 64) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(final_trace_buf), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+#else
+    (void)out; (void)n;
+    return -2;
+#endif
 }

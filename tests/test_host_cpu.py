@@ -28,12 +28,12 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_library_exports_nothing_but_the_c_abi():
     """libdcs.so is built with -fvisibility=hidden, DCS_API on the declarations of include/dcs.h and a linker version script
-    (csrc/libdcs.map): its dynamic symbol table is the C ABI and the two trace dumps of the experiment builds -- no C++
+    (csrc/libdcs.map): its dynamic symbol table is the C ABI and the three trace dumps of the experiment builds -- no C++
     internals, no std:: template instantiations."""
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
-    assert exported == sorted(_lib.header_symbols() + ["fftw_trace_dump", "lat_trace_dump"]), exported
+    assert exported == sorted(_lib.header_symbols() + ["final_trace_dump", "fftw_trace_dump", "lat_trace_dump"]), exported
 
 
 def test_framing_integers_match_the_oracle():
