@@ -167,6 +167,34 @@ def test_bach10_f16_conv_path_at_full_size_stated_tolerance():
     assert perr.max() < 2e-3
 
 
+def test_bach10_fused_decoders_at_full_size_with_128_tiles_and_more():
+    """From 128 tiles on the Bach10 graph takes its round-4 paths: the bf16 planes of the per-source dense layers packed with
+    permuted columns (channels-last D) and BOTH InverseLayers in one kernel -- f32-class on three-way split operands
+    (colconv_x3.hip) without the switch, f16 inputs in both stages with it.  132 tiles at the real size (2049 bins, 505
+    columns: 31 full column blocks + one of 9) against the float64 oracle: 1e-4 per network-output bin f32-class, the f16
+    path's stated 2e-3."""
+    F, n = 2049, 132
+    params = synth_params("bach10", 30, F, seed=3)
+    rs = np.random.RandomState(31)
+    x = (0.3 * rs.uniform(0, 3, (n, 1, 30, F))).astype(np.float32)
+    x[1, :, 4:9] = 0.0
+    x[n - 1] = 0.0
+    want = net_ref.forward("bach10", params, x.astype(np.float64), inverse='explicit').numpy()
+    ctx = default_context()
+    net = Network(ctx, "bach10", params, 30, F)
+    xd = ctx.to_device(x, np.float32)
+    p32 = ctx.to_host(net.forward_raw(xd))
+    assert np.isfinite(p32).all() and np.max(np.abs(p32 - want)) < 1e-4
+    net.set_conv_precision('f16')
+    p16 = ctx.to_host(net.forward_raw(xd))
+    assert np.isfinite(p16).all() and np.max(np.abs(p16 - want)) < 2e-3
+    # fewer than 128 tiles: the f32 GEMM, channel-first D and the unfused / channel-first kernels -- same bars
+    net.set_conv_precision('f32')
+    q32 = ctx.to_host(net.forward_raw(xd[:40]))
+    assert np.max(np.abs(q32 - want[:40])) < 1e-4
+    assert np.max(np.abs(q32 - p32[:40])) < 2e-6 * max(1.0, float(np.max(np.abs(want))))
+
+
 def test_scoreinformed_batch_of_128_tiles_matches_oracle(tmp_path):
     """BASELINE configs[4]: score-conditioned masks, one batch of 128 four-channel tiles [128, 4, 30, 2049] through the
     whole score-informed path (7.66 s of audio, library tiler)."""
