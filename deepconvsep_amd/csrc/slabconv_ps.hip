@@ -69,8 +69,17 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
 // PU = false: a K block pairs the taps (u, v) and (u, v + 1) (filters wider than one column: iKala);
 // PU = true:  kw == 1 (Bach10 / score-informed in f32): a K block pairs the taps u = 2 up and 2 up + 1 of the one column,
 //             and a workgroup owns a tile of output columns (a 505-column row does not fit in LDS).
-template <int MODE, int NW /* waves per workgroup */, bool PU>
+//
+// FAST (wide filters only): the bounds arithmetic of the tap loop is done once per block -- a bit per tap pair for "some
+// lane of the block reads inside the image" and one for "every lane does", the live filter rows as a range -- and once
+// per weight stage (one address register per block: it advances by a constant per tap pair).
+// Lanes of an edge block that fall outside the image read a record of zeros kept in front of the slab: one select on the
+// address instead of twelve on the data.  The loop it replaces (FAST = false, DCS_SLABCONV_PS_FAST=0) spent 33 scalar
+// and 18 vector instructions per twelve MFMAs on that arithmetic (PMC, profiles/r02_e_pmc_legs.txt).  Same products in
+// the same order: the results are bit-identical.
+template <int MODE, int NW /* waves per workgroup */, bool PU, bool FAST>
 __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv g, const u32x4* __restrict__ Wq) {
+    static_assert(!(PU && FAST), "the mask-driven tap loop covers filters wider than one column");
     constexpr int NP = MODE == 0 ? 3 : 1;
     constexpr int RP = NP * 2;                            // 16-byte pieces per slab record
     constexpr int NTH = 64 * NW, NBW = 32 / NW;           // threads; blocks per wave
@@ -79,7 +88,8 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
     extern __shared__ u32x4 smem[];
     u32x4* Wl = smem;                                     // [2][pairs_per_stage][NP][2][64]
     const int wstage = g.pstage * kStage;
-    u32x4* slab = smem + 2 * wstage;                      // [rows_max][columns of the tile][RP]
+    u32x4* zrec = smem + 2 * wstage;                      // one record of zeros (FAST: what lanes outside the image read)
+    u32x4* slab = zrec + RP;                              // [rows_max][columns of the tile][RP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, kq = lane >> 4;
@@ -119,6 +129,29 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
         bx[i] = b < nblk ? xt0 + (b % nxb) * 16 : 0;
         acc0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // FAST: per block -- tap pairs with a lane inside the image (lm) / with every lane inside (im), the live filter rows
+    // [bu0, bu1], the input column of lane 0 at v = 0 (bxs) and the lane's slab index at (u, v) = (0, 0) (vb)
+    unsigned lm[NBW], im[NBW];
+    int bu0[NBW], bu1[NBW], bxs[NBW], vb[NBW];
+    const int lx = fi + (kq >> 1);
+    if constexpr (FAST) {
+        if (tid < RP) zrec[tid] = u32x4{0u, 0u, 0u, 0u};   // ordered before its first read by the barriers of the fill
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            lm[i] = 0u; im[i] = 0u; bu0[i] = 1; bu1[i] = 0; bxs[i] = 0; vb[i] = 0;
+            if (by[i] < 0) continue;
+            const int xs0 = bx[i] - g.pw;
+            for (int vp = 0; vp < nvp; ++vp) {
+                const int xs = xs0 + 2 * vp;
+                if (xs + 16 >= 0 && xs < g.W) lm[i] |= 1u << vp;
+                if (xs >= 0 && xs + 17 <= g.W) im[i] |= 1u << vp;
+            }
+            bu0[i] = g.ph - by[i];
+            bu1[i] = g.H - 1 + g.ph - by[i];
+            bxs[i] = xs0;
+            vb[i] = ((by[i] - g.ph - rbase) * SW + xs0 + lx) * RP + (kq & 1);
+        }
     }
     int u_lo = g.ph - (yb - 1), u_hi = g.ph - y0 + g.H - 1;
     if (u_lo < 0) u_lo = 0;
@@ -173,6 +206,66 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
             if (st + 1 < n_stage) DCS_PS_WFETCH(st + 1)
             const int so = st / nvs, i0 = (st - so * nvs) * g.pstage;
             const int np = i0 + g.pstage <= n_in ? g.pstage : n_in - i0;
+#define DCS_PS_MMA(i_, a0, a1, b)                                                                                \
+            if constexpr (MODE == 0) { /* smallest terms first */                                       \
+                acc0[i_] = mma<0>(a0[2], b[0], acc0[i_]);                                               \
+                acc1[i_] = mma<0>(a1[2], b[0], acc1[i_]);                                               \
+                acc0[i_] = mma<0>(a0[0], b[2], acc0[i_]);                                               \
+                acc1[i_] = mma<0>(a1[0], b[2], acc1[i_]);                                               \
+                acc0[i_] = mma<0>(a0[1], b[1], acc0[i_]);                                               \
+                acc1[i_] = mma<0>(a1[1], b[1], acc1[i_]);                                               \
+                acc0[i_] = mma<0>(a0[1], b[0], acc0[i_]);                                               \
+                acc1[i_] = mma<0>(a1[1], b[0], acc1[i_]);                                               \
+                acc0[i_] = mma<0>(a0[0], b[1], acc0[i_]);                                               \
+                acc1[i_] = mma<0>(a1[0], b[1], acc1[i_]);                                               \
+                acc0[i_] = mma<0>(a0[0], b[0], acc0[i_]);                                               \
+                acc1[i_] = mma<0>(a1[0], b[0], acc1[i_]);                                               \
+            } else {                                                                                    \
+                acc0[i_] = mma<1>(a0[0], b[0], acc0[i_]);                                               \
+                acc1[i_] = mma<1>(a1[0], b[0], acc1[i_]);                                               \
+            }
+            if constexpr (FAST) {
+                const int u = u_lo + so;
+                unsigned m[NBW], ne[NBW], many = 0u;
+                int va[NBW];
+#pragma unroll
+                for (int i = 0; i < NBW; ++i) {
+                    const bool rl = u >= bu0[i] && u <= bu1[i];          // (a slot without a block has an empty range)
+                    m[i] = rl ? (lm[i] >> i0) & ((1u << np) - 1u) : 0u;
+                    ne[i] = ~im[i] >> i0;
+                    va[i] = vb[i] + (u * SW + 2 * i0) * RP;
+                    many |= m[i];
+                }
+                const u32x4* wp = Wb + lane;
+                // (not unrolled: with the five pairs of a stage unrolled the accumulators left every conditional block
+                // in other registers -- fourteen copies per step)
+#pragma nounroll
+                for (int tp = 0; tp < np; ++tp, wp += kStage) {
+                    if ((many >> tp) & 1u) {
+                        u32x4 a0[NP], a1[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            a0[p] = wp[(p * 2) * 64];
+                            a1[p] = wp[(p * 2 + 1) * 64];
+                        }
+#pragma unroll
+                        for (int i = 0; i < NBW; ++i) {
+                            if (!((m[i] >> tp) & 1u)) continue;
+                            int idx = va[i];
+                            if ((ne[i] >> tp) & 1u) {                    // an edge block: lanes outside read the zeros
+                                const int xc = bxs[i] + 2 * (i0 + tp) + lx;
+                                idx = (unsigned)xc < (unsigned)g.W ? idx : (kq & 1) - RP;
+                            }
+                            u32x4 b[NP];
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) b[p] = slab[idx + p * 2];
+                            DCS_PS_MMA(i, a0, a1, b)
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i) va[i] += 2 * RP;
+                }
+            } else
             for (int tp = 0; tp < np; ++tp) {
                 const int u = PU ? 2 * (in_lo + i0 + tp) : u_lo + so;      // first tap of the pair
                 const int v = PU ? 0 : 2 * (i0 + tp);
@@ -216,25 +309,10 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
                             b[p] = ok ? t : u32x4{0u, 0u, 0u, 0u};
                         }
                     }
-                    if constexpr (MODE == 0) {   // smallest terms first
-                        acc0[i] = mma<0>(a0[2], b[0], acc0[i]);
-                        acc1[i] = mma<0>(a1[2], b[0], acc1[i]);
-                        acc0[i] = mma<0>(a0[0], b[2], acc0[i]);
-                        acc1[i] = mma<0>(a1[0], b[2], acc1[i]);
-                        acc0[i] = mma<0>(a0[1], b[1], acc0[i]);
-                        acc1[i] = mma<0>(a1[1], b[1], acc1[i]);
-                        acc0[i] = mma<0>(a0[1], b[0], acc0[i]);
-                        acc1[i] = mma<0>(a1[1], b[0], acc1[i]);
-                        acc0[i] = mma<0>(a0[0], b[1], acc0[i]);
-                        acc1[i] = mma<0>(a1[0], b[1], acc1[i]);
-                        acc0[i] = mma<0>(a0[0], b[0], acc0[i]);
-                        acc1[i] = mma<0>(a1[0], b[0], acc1[i]);
-                    } else {
-                        acc0[i] = mma<1>(a0[0], b[0], acc0[i]);
-                        acc1[i] = mma<1>(a1[0], b[0], acc1[i]);
-                    }
+                    DCS_PS_MMA(i, a0, a1, b)
                 }
             }
+#undef DCS_PS_MMA
         }
 #undef DCS_PS_WFETCH
     }
@@ -306,14 +384,24 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
     // whatever its share, so the best split is the one that wastes the fewest (wave, slot) pairs -- counting short last
     // bands / tiles and CUs left without a workgroup -- among those whose slab fits, discounted by the number of weight
     // stages (barriers) the leftover LDS forces; ties go to the larger weight stage, then to the larger share.  Wide filters keep whole rows (the halo of a column tile would be kw - 1 columns).
+    // Measured dead ends of round 4 (profiles/r04_m_ikala_*): (i) 8 waves x 4 blocks, or 16 x 4 on ten-row bands, halve the
+    // LDS reads of the weight fragments per MFMA and are 10 - 25 % SLOWER; (ii) requesting both blocks' input fragments and
+    // the next pair's weight fragments ahead of the MFMAs (software pipeline inside the wave) is 12 % slower.  Counters of
+    // the kernel as it is: LDS 31 % busy, 3 % of the wave-cycles wait for LDS, 47 % wait at s_barrier / s_waitcnt -- the
+    // sixteen waves of a stage have between 2 and 10 live (pair, block) steps (column blocks 0 and 5 of an 83-wide row see
+    // 8 and 2 of the 10 pairs) and the stage ends when the slowest is done.
+    static const bool fast_on = !(getenv("DCS_SLABCONV_PS_FAST") && atoi(getenv("DCS_SLABCONV_PS_FAST")) == 0);
+    const bool fast = fast_on && !pu && nvp <= 32;         // a bit per tap pair of a filter row
+    const int nw = 16, nbw = 2;
+    const int slots = nw * nbw;
     int band = 0, xt = 0, ps_best = 1;
     size_t lds = 0;
     double best = 0.0;
-    for (int cxt = pu ? 1 : nxb_all; cxt <= nxb_all && cxt <= 32; ++cxt) {     // 16-column blocks per tile
+    for (int cxt = pu ? 1 : nxb_all; cxt <= nxb_all && cxt <= slots; ++cxt) {     // 16-column blocks per tile
         const int n_xt = (nxb_all + cxt - 1) / cxt;
         int sw = cxt * 16 + (pu ? 0 : 2 * nvp - 1);
         if (sw > a.W) sw = a.W;
-        for (int cand = 1; cand <= a.Ho && cand * cxt <= 32; ++cand) {
+        for (int cand = 1; cand <= a.Ho && cand * cxt <= slots; ++cand) {
             int rows = cand + a.kh - 1;
             if (rows > a.H) rows = a.H;
             // weight stage: as many tap pairs as fit beside the slab (a barrier per stage: the fewer the better), at most 5
@@ -321,13 +409,13 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
             size_t need = 0;
             for (;; --ps) {
                 if (ps < 1) break;
-                need = (size_t)2 * ps * np * 128 * 16 + (size_t)rows * sw * rec;
+                need = (size_t)2 * ps * np * 128 * 16 + (size_t)(rows * sw + 1) * rec;   // + the record of zeros
                 if (need <= 160 * 1024) break;
             }
             if (ps < 1) break;
             const int64_t n_wg = n_images * ((a.Ho + cand - 1) / cand) * n_xt;
-            const int rounds = (cand * cxt + 15) / 16;                // block slots used per wave
-            double eff = (double)n_images * a.Ho * nxb_all / ((double)n_wg * 16 * rounds);
+            const int rounds = (cand * cxt + nw - 1) / nw;            // block slots used per wave
+            double eff = (double)n_images * a.Ho * nxb_all / ((double)n_wg * nw * rounds);
             if (n_wg < ctx->n_cu) eff *= (double)n_wg / ctx->n_cu;
             eff /= 1.0 + 0.6 / ps;                                    // a barrier per stage: measured, iKala 0.83 -> 0.67 ms
             const bool tie = eff > best - 1e-9;
@@ -344,12 +432,17 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
     a.xt = xt;
     a.n_xt = (nxb_all * 16 + xt - 1) / xt;
     typedef void (*kern_t)(const DcsSlabConv, const u32x4*);
-    kern_t kern = pu ? (mode == 0 ? (kern_t)slabconv_ps_kernel<0, 16, true> : (kern_t)slabconv_ps_kernel<1, 16, true>)
-                     : (mode == 0 ? (kern_t)slabconv_ps_kernel<0, 16, false> : (kern_t)slabconv_ps_kernel<1, 16, false>);
+    kern_t kern;
+    if (pu)
+        kern = mode == 0 ? (kern_t)slabconv_ps_kernel<0, 16, true, false> : (kern_t)slabconv_ps_kernel<1, 16, true, false>;
+    else if (!fast)
+        kern = mode == 0 ? (kern_t)slabconv_ps_kernel<0, 16, false, false> : (kern_t)slabconv_ps_kernel<1, 16, false, false>;
+    else
+        kern = mode == 0 ? (kern_t)slabconv_ps_kernel<0, 16, false, true> : (kern_t)slabconv_ps_kernel<1, 16, false, true>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * a.n_bands * a.n_xt)), dim3(1024), lds, ctx->stream, a,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_images * a.n_bands * a.n_xt)), dim3(64 * nw), lds, ctx->stream, a,
                        reinterpret_cast<const u32x4*>(Wq));
     return true;
 }

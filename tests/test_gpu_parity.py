@@ -872,11 +872,12 @@ sys.exit(0 if err < 1e-4 else 3)
 
 
 @pytest.mark.parametrize("env", [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}, {"DCS_SLABCONV_MX": "0"},
-                                 {"DCS_SLABCONV_PS": "0"}])
+                                 {"DCS_SLABCONV_PS": "0"}, {"DCS_SLABCONV_PS_FAST": "0"}])
 @pytest.mark.parametrize("F,n", [(513, 9), (1025, 3)])
 def test_ikala_conv2_kernels_agree_with_the_oracle(env, F, n, tmp_path):
     """conv2 of the iKala graph (10 x 20) and its transpose: slab kernel on the bf16 matrix pipe with the slab pre-split
-    into bf16 planes (default, slabconv_ps.hip), the one that splits per tap (DCS_SLABCONV_PS=0), the f32-MFMA slab kernel
+    into bf16 planes (default, slabconv_ps.hip: tap loop driven by per-block bit masks; DCS_SLABCONV_PS_FAST=0: bounds
+    arithmetic per tap), the one that splits per tap (DCS_SLABCONV_PS=0), the f32-MFMA slab kernel
     (DCS_SLABCONV_MX=0) and the implicit-GEMM fallback, on batch sizes that give several row bands per image."""
     import subprocess
     x = _tiles("ikala", n, 30, F, seed=16)
