@@ -41,8 +41,48 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // rows are F floats apart, F odd
+typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));    // channels-last positions are Cin (even) floats apart
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// timing ablations (scripts/build_exp.sh; results are wrong by construction): -DDCS_X3_ABL_NOTAIL drops everything behind a
+// row pair's exchange barrier, -DDCS_X3_ABL_NOS1 the stage-1 MFMAs (fragment reads stay), -DDCS_X3_ABL_NOFILL the operand
+// split and the LDS writes of the block fill, -DDCS_X3_ABL_NOXCHG the exchange write and its barrier
+#if defined(DCS_X3_ABL_NOTAIL)
+constexpr bool kAblTail = true;
+#else
+constexpr bool kAblTail = false;
+#endif
+#if defined(DCS_X3_ABL_NOS1)
+constexpr bool kAblS1 = true;
+#else
+constexpr bool kAblS1 = false;
+#endif
+#if defined(DCS_X3_ABL_NOFILL)
+constexpr bool kAblFill = true;
+#else
+constexpr bool kAblFill = false;
+#endif
+#if defined(DCS_X3_ABL_NOXCHG)
+constexpr bool kAblX = true;
+#else
+constexpr bool kAblX = false;
+#endif
+// -DDCS_X3_TRACE: the two waves of workgroup 0 add up s_memtime intervals (shader clocks) per phase -- [wave][0] stage 1,
+// [1] exchange write + barrier, [2] tail, [3] block fill, [4] whole run loop, [5] row pairs, [6 .. 11] the six pieces of
+// the tail (not overlapped form) -- read with x3_trace_dump()
+#if defined(DCS_X3_TRACE)
+__device__ unsigned long long x3_trace_buf[32];
+#define X3_NOW(v_)                                      \
+    {                                                   \
+        __builtin_amdgcn_sched_barrier(0);              \
+        v_ = __builtin_amdgcn_s_memtime();              \
+        __builtin_amdgcn_sched_barrier(0);              \
+    }
+#define X3_ADD(slot_, a_, b_) tr[slot_] += (b_) - (a_);
+#else
+#define X3_NOW(v_)
+#define X3_ADD(slot_, a_, b_)
+#endif
 constexpr int kTh = 128;      // the workgroup is ONE pair of waves
 constexpr int kPairTh = 128;
 
@@ -50,6 +90,11 @@ __device__ __forceinline__ f32x4 mma_bf(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+// Workgroup barrier that orders LDS traffic ONLY (the two waves of a pair talk through LDS alone; nobody reads `out`):
+// no s_waitcnt vmcnt(0) for the output store each row pair leaves in flight.  (Measured: no difference on this compiler --
+// its __syncthreads() did not wait for the stores either; kept because it states what the kernel needs.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // x = hi + mid + lo exactly (three bf16 by truncation); element j of a piece is k slot j
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
@@ -99,6 +144,10 @@ struct DcsDecoderX3 {
     int64_t n_runs;
 };
 
+// Measured dead end (round 4, profiles/r04_n_x3_timeline.txt): issuing the tail of a row pair (six pieces: partner's partial,
+// operand split, stage 2, shift-add, carry, store) between the MFMA groups of the NEXT row pair's stage 1 -- two accumulator
+// sets, sched_group_barrier interleaving -- made stage 1 exactly as much longer as the tail got shorter (issue is in order:
+// every dependent instruction of the tail stalls the MFMA stream behind it): 1.20 against 1.14 ms.
 template <int KH, int H>
 __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const DcsColConv g, const DcsDecoderX3 d) {
     constexpr int HO = H + KH - 1, PH = KH - 1, NK = KH / 2;
@@ -152,29 +201,26 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
         const int h = i >> 6, rem = i & 63, x = rem >> 2, kqt = rem & 3;
         t_ok[j] = i < kTasks;
         t_x[j] = x;
-        t_off[j] = h * W * Cin + 8 * kqt;                           // + (column) * Cin
+        t_off[j] = (i < kTasks ? h : 0) * W * Cin + 8 * kqt;        // + (column) * Cin
         t_dst[j] = ((h + 1) * 3 * 4 + kqt) * 16 + x;                // + plane * 64
     }
-    int pair_off[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = 8 * (tid & 3) + 2 * q;
-        pair_off[q] = (c + 2 <= Cin ? c : Cin - 2) - 8 * (tid & 3);  // relative to the task's first channel
-    }
-    float raw[NT][8];
+    const bool hi_dup = 8 * (tid & 3) + 8 > Cin;                         // K piece 3 of a 30-channel input
+    const int hi_off = hi_dup ? Cin - 4 - 8 * (tid & 3) : 4;              // relative to the task's first channel
+    f32x4a8 rlo[NT], rhi[NT];
+// Task j: the eight channels of one (row, x, K piece) as TWO 16-byte loads (8-byte aligned: a position is 120 bytes).  The
+// second load of K piece 3 (channels 28 .. 31 of 30) starts two channels early and its upper half is used twice: the weights
+// of channels 30 and 31 are zero, the values only have to be finite and inside the tensor.
+// NOTHING touches the loaded registers before the next block's split, and no branch surrounds the loads (tasks past the
+// last row re-read row 0): with element-wise copies or a select behind each load the compiler waited for every pair of loads
+// in turn -- six memory latencies, 8 200 cycles per block (13 % of the kernel; profiles/r04_n_x3_timeline.txt).
 #define DCS_X3_FETCH(img_, blk_)                                                                        \
     {                                                                                                   \
         const float* ib_ = g.in + (img_) * g.in_n_stride;                                               \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                \
-            if (t_ok[j]) {                                                                              \
-                const int xl_ = (blk_) * 16 + t_x[j];                                                   \
-                const float* ip_ = ib_ + (t_off[j] + (xl_ < W ? xl_ : W - 1) * Cin);                    \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                         \
-                    const f32x2 v_ = *reinterpret_cast<const f32x2*>(ip_ + pair_off[q]);                \
-                    raw[j][2 * q] = v_[0];                                                              \
-                    raw[j][2 * q + 1] = v_[1];                                                          \
-                }                                                                                       \
-            }                                                                                           \
+            const int xl_ = (blk_) * 16 + t_x[j];                                                       \
+            const float* ip_ = ib_ + (t_off[j] + (xl_ < W ? xl_ : W - 1) * Cin);                        \
+            rlo[j] = *reinterpret_cast<const f32x4a8*>(ip_);                                            \
+            rhi[j] = *reinterpret_cast<const f32x4a8*>(ip_ + hi_off);                                   \
         }                                                                                               \
     }
     // stage-2 write side: lane (x = fi, kq) owns taps mm = kq and kq + 4 of column x
@@ -184,6 +230,10 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
     const f32x4* pr = Pb + (rq < 23 ? rq : 22) + 8;
     const u32x4* bl = planes + lane;                     // B fragment of (row, plane): unit (row * 3 + plane) * 64 + lane
     int xbuf = 0;
+#if defined(DCS_X3_TRACE)
+    unsigned long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tf0 = 0, tf1 = 0, tf2 = 0, tp0 = 0, tp1 = 0, ta = 0, tb = 0, tc = 0, td = 0, t_run0 = 0, t_run1 = 0;
+    X3_NOW(t_run0)
+#endif
     for (int64_t run = blockIdx.x; run < d.n_runs; run += gridDim.x) {
         const bool have = true;
         const int64_t img = run / rpi;
@@ -196,34 +246,125 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
         for (int it = 0; it < n_it; ++it) {
             const int b = b_first + it;
             constexpr bool active = true;
-            __syncthreads();                                 // both waves are done with the previous block's planes
+            X3_NOW(ta)
+            lds_barrier();                                 // both waves are done with the previous block's planes
+            X3_NOW(tf0)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (active && t_ok[j]) {
+                if (active && t_ok[j] && !(kAblFill && it > 0)) {
                     u32x4 p0, p1, p2;
-                    split8(raw[j], p0, p1, p2);
+                    float rawj[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rawj[e] = rlo[j][e];
+                    rawj[4] = hi_dup ? rhi[j][2] : rhi[j][0];
+                    rawj[5] = hi_dup ? rhi[j][3] : rhi[j][1];
+                    rawj[6] = rhi[j][2];
+                    rawj[7] = rhi[j][3];
+                    split8(rawj, p0, p1, p2);
                     const bool x_ok = b * 16 + t_x[j] < W;   // columns past W (last block): zero input, zero G, zero products
                     planes[t_dst[j]] = x_ok ? p0 : zeroq;
                     planes[t_dst[j] + 64] = x_ok ? p1 : zeroq;
                     planes[t_dst[j] + 128] = x_ok ? p2 : zeroq;
                 }
             }
-            __syncthreads();
+            X3_NOW(tf1)
+            lds_barrier();
+            X3_NOW(tf2)
+            X3_ADD(12, ta, tf0)
+            X3_ADD(13, tf0, tf1)
+            X3_ADD(14, tf1, tf2)
             if (active) {
                 const int nb = b + 1 < b_hi ? b + 1 : b;     // last block of the run: a harmless re-read
                 DCS_X3_FETCH(img, nb)
             }
+            X3_NOW(tb)
+            X3_ADD(3, ta, tb)
+            X3_ADD(15, tf2, tb)
             const bool keep = b >= b_lo;                     // false for the recomputed block
             const int f0 = 4 * (b * 16 + rq);
             float* orow = d.out + (img * HO + par) * (int64_t)F + f0;
+            // state of the row pair being finished
+            f32x4 acc[2][2];                                 // [row of the pair][channel half]
+            f32x4 tm[2], tsum = zero4;
+            u32x4 tg[3];
+            const f32x4* t_xr = Xs;
+            constexpr int kPieces = 6;
+            auto tail = [&](auto pc, auto ypc) {
+                constexpr int P = decltype(pc)::value, yp = decltype(ypc)::value;
+                if constexpr (kAblTail) {
+                    if constexpr (P == 0) tsum += acc[0][0] + acc[1][1];      // keeps stage 1 alive
+                    if constexpr (P == 5 && yp == HO - 2)
+                        if (keep && lane < 16 && f0 + 4 <= F) *reinterpret_cast<f32x4u*>(orow) = tsum;
+                } else if constexpr (P == 0) {          // this wave finishes row yp + par: its own partial + the partner's
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) tm[hf] = par ? acc[1][hf] : acc[0][hf];
+                    tm[0] += t_xr[0];
+                    tm[1] += t_xr[64];
+                } else if constexpr (P == 1) {   // G[ci][x] of the row as three bf16 planes (a B operand of stage 2)
+                    float gv[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gv[e] = tm[0][e];
+                        gv[4 + e] = tm[1][e];
+                    }
+                    split8(gv, tg[0], tg[1], tg[2]);
+                } else if constexpr (P == 2) {
+                    // the two tap halves as FOUR chains of three products (smallest terms first in each): with one wave per
+                    // SIMD a chain of six dependent MFMAs per half was ~430 cycles of pure latency per row pair
+                    f32x4 pa[2], pb[2];
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh) {
+                        pa[mh] = mma_bf(w1[2][mh], tg[0], zero4);
+                        pb[mh] = mma_bf(w1[0][mh], tg[2], zero4);
+                    }
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh) {
+                        pa[mh] = mma_bf(w1[1][mh], tg[1], pa[mh]);
+                        pb[mh] = mma_bf(w1[1][mh], tg[0], pb[mh]);
+                    }
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh) {
+                        pa[mh] = mma_bf(w1[0][mh], tg[1], pa[mh]);
+                        pb[mh] = mma_bf(w1[0][mh], tg[0], pb[mh]);
+                    }
+                    pw[0] = pa[0] + pb[0];
+                    pw[128] = pa[1] + pb[1];
+                } else if constexpr (P == 3) {
+                } else if constexpr (P == 4) {
+                    asm volatile("" ::: "memory");           // the pieces of the row are written (LDS is in order per wave)
+                    // all nine reads in flight before the first addition (left alone the compiler waits for each in turn)
+                    f32x4 rd[8];
+#pragma unroll
+                    for (int mm = 0; mm < 8; ++mm) rd[mm] = pr[mm * 32 - mm];
+                    const f32x4 cin = Cb[(yp >> 1) * 8 + (rq & 7)];
+                    __builtin_amdgcn_sched_barrier(0);
+                    tsum = ((rd[0] + rd[1]) + (rd[2] + rd[3])) + ((rd[4] + rd[5]) + (rd[6] + rd[7])) + (rq < 8 ? cin : zero4);
+                } else {
+                    asm volatile("" ::: "memory");           // every lane has read the carry before it is replaced
+                    if (lane >= 16 && lane < 24) Cb[(yp >> 1) * 8 + lane - 16] = lane < 23 ? tsum : zero4;
+#if defined(DCS_X3_ABL_NOSTORE)
+                    if (keep && lane < 16 && tsum[0] == 12345.f) {
+#else
+                    if (keep && lane < 16) {
+#endif
+                        float* op = orow + (int64_t)yp * F;
+                        if (f0 + 4 <= F) {
+                            *reinterpret_cast<f32x4u*>(op) = tsum;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 3; ++e)
+                                if (f0 + e < F) op[e] = tsum[e];
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            };
             // the 15 row pairs and their (row, tap) slots are unrolled through integer sequences: every weight register index
             // and every "is this slot live" is a compile-time constant (a `#pragma unroll` over 15 bodies of this size is
             // declined by the optimiser)
             x3_for_row_pairs([&](auto yc) {
                 constexpr int y = decltype(yc)::value;
-                f32x4 mine[2];
-                if (active) {
-                f32x4 acc[2][2];
+                X3_NOW(ta)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = zero4;
                 // The B fragments of the NEXT live slot are requested before the twelve MFMAs of the current one are issued:
@@ -248,6 +389,9 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         // smallest terms first; the two channel halves alternate so that no MFMA waits for the one before it
+                        if constexpr (kAblS1) {
+                            acc[t][0][0] += __uint_as_float(bc[0][0] ^ bc[1][1] ^ bc[2][2]) + __uint_as_float(w[k][0][0][0]);
+                        } else {
                         acc[t][0] = mma_bf(w[k][2][0], bc[0], acc[t][0]);
                         acc[t][1] = mma_bf(w[k][2][1], bc[0], acc[t][1]);
                         acc[t][0] = mma_bf(w[k][0][0], bc[2], acc[t][0]);
@@ -260,6 +404,7 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
                         acc[t][1] = mma_bf(w[k][0][1], bc[1], acc[t][1]);
                         acc[t][0] = mma_bf(w[k][0][0], bc[0], acc[t][0]);
                         acc[t][1] = mma_bf(w[k][0][1], bc[0], acc[t][1]);
+                        }
                         if constexpr (s_next >= 0) {
                             __builtin_amdgcn_sched_barrier(0);
                             bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
@@ -268,61 +413,27 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
                 }, std::make_integer_sequence<int, 2 * NK>{});
                 // this wave finishes row y + par: its partial of the OTHER row goes to the partner, the partner's partial of
                 // this row comes back
-                f32x4 other[2];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    mine[hf] = par ? acc[1][hf] : acc[0][hf];
-                    other[hf] = par ? acc[0][hf] : acc[1][hf];
+                X3_NOW(tb)
+                if constexpr (!kAblX) {
+                    f32x4* xw = Xs + (xbuf * 2 + par) * 128 + lane;
+                    xw[0] = par ? acc[0][0] : acc[1][0];
+                    xw[64] = par ? acc[0][1] : acc[1][1];
+                    lds_barrier();
                 }
-                f32x4* xw = Xs + (xbuf * 2 + par) * 128 + lane;
-                xw[0] = other[0];
-                xw[64] = other[1];
-                }
-                __syncthreads();
-                if (active) {
-                const f32x4* xr = Xs + (xbuf * 2 + (1 - par)) * 128 + lane;
-                mine[0] += xr[0];
-                mine[1] += xr[64];
-                float gv[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    gv[e] = mine[0][e];
-                    gv[4 + e] = mine[1][e];
-                }
-                u32x4 g0, g1, g2;
-                split8(gv, g0, g1, g2);
-#pragma unroll
-                for (int mh = 0; mh < 2; ++mh) {
-                    f32x4 p = zero4;
-                    p = mma_bf(w1[2][mh], g0, p);
-                    p = mma_bf(w1[0][mh], g2, p);
-                    p = mma_bf(w1[1][mh], g1, p);
-                    p = mma_bf(w1[1][mh], g0, p);
-                    p = mma_bf(w1[0][mh], g1, p);
-                    p = mma_bf(w1[0][mh], g0, p);
-                    pw[mh * 128] = p;
-                }
-                asm volatile("" ::: "memory");               // the pieces of the row are written (LDS is in order per wave)
-                f32x4 sum = zero4;
-#pragma unroll
-                for (int mm = 0; mm < 8; ++mm) sum += pr[mm * 32 - mm];
-                const f32x4 cin = Cb[(y >> 1) * 8 + (rq & 7)];
-                if (rq < 8) sum += cin;
-                asm volatile("" ::: "memory");               // every lane has read the carry before it is replaced
-                if (lane >= 16 && lane < 24) Cb[(y >> 1) * 8 + lane - 16] = lane < 23 ? sum : zero4;
-                if (keep && lane < 16) {
-                    float* op = orow + (int64_t)y * F;
-                    if (f0 + 4 <= F) {
-                        *reinterpret_cast<f32x4u*>(op) = sum;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 3; ++e)
-                            if (f0 + e < F) op[e] = sum[e];
-                    }
-                }
-                asm volatile("" ::: "memory");
-                }
+                t_xr = Xs + (xbuf * 2 + (1 - par)) * 128 + lane;
                 xbuf ^= 1;
+                X3_NOW(tc)
+                x3_for_slots([&](auto pc) {
+                        X3_NOW(tp0)
+                        tail(pc, yc);
+                        X3_NOW(tp1)
+                        X3_ADD(6 + decltype(pc)::value, tp0, tp1)
+                    }, std::make_integer_sequence<int, kPieces>{});
+                X3_NOW(td)
+                X3_ADD(0, ta, tb)
+                X3_ADD(1, tb, tc)
+                X3_ADD(2, tc, td)
+                X3_ADD(5, ta, td)
             }, std::make_integer_sequence<int, HO / 2>{});
         }
         // the carry: the tail of the image (and the zeros up to F) for the last run, otherwise the next run recomputes it
@@ -341,10 +452,22 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
         }
         asm volatile("" ::: "memory");
     }
+#if defined(DCS_X3_TRACE)
+    X3_NOW(t_run1)
+    tr[4] = t_run1 - t_run0;
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 16; ++i) x3_trace_buf[par * 16 + i] = tr[i];
+#endif
 #undef DCS_X3_FETCH
 }
 
 }  // namespace
+
+#if defined(DCS_X3_TRACE)
+extern "C" __attribute__((visibility("default"))) int x3_trace_dump(unsigned long long* out32) {
+    return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(x3_trace_buf), sizeof(unsigned long long) * 32);
+}
+#endif
 
 // Wf: [kh][32 out][40] f32, in-channel fastest (the transposed conv2 filter as the column kernels take it) ->
 // [2 parities][kh / 2][3 planes][2 halves][64 lanes] 16-byte pieces: lane (fi, kg) of tap u = 2 k + par, half hf holds
@@ -373,7 +496,8 @@ void dcs_decoder_x3_pack(const float* Wf, int kh, std::vector<uint16_t>* out) {
 
 bool dcs_decoder_x3_ok(const DcsColConv& a, int F) {
     static const bool on = !(getenv("DCS_DECODER_X3") && atoi(getenv("DCS_DECODER_X3")) == 0);
-    return on && dcs_decoder_fused_ok(a, F) && (a.Cin & 1) == 0;
+    // 28 .. 32 channels: the first half of K piece 3 (channels 24 .. 27) is read as it is
+    return on && dcs_decoder_fused_ok(a, F) && (a.Cin & 1) == 0 && a.Cin >= 28;
 }
 
 // the input MUST be channels-last ([image][H][W][Cin], 8-byte aligned): false = not launched
