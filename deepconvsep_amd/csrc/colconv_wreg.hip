@@ -444,11 +444,14 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
                     }
                 }
                 asm volatile("" ::: "memory");               // the pieces of both rows are written (LDS is in order per wave)
-                f32x4 sum = zero4;
+                // all nine reads in flight before the first addition (left alone the compiler waits for each in turn: one
+                // wave per SIMD, nobody hides the latency), a select instead of a branch for the carry
+                f32x4 rd[8];
 #pragma unroll
-                for (int mm = 0; mm < 8; ++mm) sum += pr[mm * 32 - mm];
+                for (int mm = 0; mm < 8; ++mm) rd[mm] = pr[mm * 32 - mm];
                 const f32x4 cin = Cb[(y + rt) * 8 + (rq & 7)];
-                if (rq < 8) sum += cin;
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 sum = ((rd[0] + rd[1]) + (rd[2] + rd[3])) + ((rd[4] + rd[5]) + (rd[6] + rd[7])) + (rq < 8 ? cin : zero4);
                 if (rq >= 16 && rq < 24) Cb[(y + rt) * 8 + rq - 16] = rq < 23 ? sum : zero4;
                 if (keep && rq < 16) {
                     float* op = orow + (int64_t)y * F;

@@ -201,6 +201,21 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g, 
 // other's barrier, prologue and store-tail gaps; four blocks per wave = one wave per SIMD measured slower than the 64 x 64
 // tiling: 0.56 vs 0.52 ms for the four Bach10 launches).
 // ------------------------------------------------------------------------------------------------
+// -DDCS_SKINNY_TRACE: wave 0 of workgroup (0, 0) adds up s_memtime intervals per phase (shader clocks): [0] split + LDS writes,
+// [1] first barrier, [2] next tile's loads issued, [3] fragment reads + MFMAs, [4] second barrier, [5] epilogue, [6] whole kernel
+#if defined(DCS_SKINNY_TRACE)
+__device__ unsigned long long skinny_trace_buf[8];
+#define SK_NOW(v_)                                      \
+    {                                                   \
+        __builtin_amdgcn_sched_barrier(0);              \
+        v_ = __builtin_amdgcn_s_memtime();              \
+        __builtin_amdgcn_sched_barrier(0);              \
+    }
+#define SK_ADD(i_, a_, b_) sk[i_] += (b_) - (a_);
+#else
+#define SK_NOW(v_)
+#define SK_ADD(i_, a_, b_)
+#endif
 template <int RBT /* row blocks of 16 */, int CB /* 16-column blocks per wave */>
 __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_kernel(const DcsGemm g0, const DcsGemmBranches br) {
     // blockIdx.y = branch: the same A against another (B planes, bias, C) triple -- one launch for all sources
@@ -241,13 +256,18 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
     const int64_t b_plane = (int64_t)n_cols * 4, b_kt = 3 * b_plane;
     const u32x4* Bl = reinterpret_cast<const u32x4*>(g.Bq) + ((int64_t)((live ? n0 : 0) + (fi >> 2) * (4 * CB) + (fi & 3))) * 4 + kq;
     f32x4 ra[A_PER][2];
+    int ra_k[A_PER];                                       // first k of the piece in flight
     u32x4 bn[CB][3], bc[CB][3];
+// The loads are UNCONDITIONAL (rows past M read row 0, k past K reads the last four of the row) and nothing touches the
+// loaded registers before the next tile's split, where the out-of-range pieces are zeroed: with `ok ? load : 0` the compiler
+// waited for each load to feed the select -- 1 640 cycles per k tile to "issue" twelve loads, 15 % of the kernel (in-kernel
+// timeline, profiles/r04_o_skinny_timeline.txt).
 #define DCS_LOAD_A(kt_)                                                                                 \
     _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                                 \
         const int k = (kt_) * 32 + a_k0[u];                                                             \
-        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
-        ra[u][0] = (a_ok[u] && k < gK) ? *reinterpret_cast<const f32x4*>(a_ptr[u] + (kt_) * 32) : z;    \
-        ra[u][1] = (a_ok[u] && k + 4 < gK) ? *reinterpret_cast<const f32x4*>(a_ptr[u] + (kt_) * 32 + 4) : z; \
+        ra[u][0] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k < gK ? k : gK - 4) - a_k0[u]);         \
+        ra[u][1] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k + 4 < gK ? k + 4 : gK - 4) - a_k0[u]); \
+        ra_k[u] = k;                                                                                    \
     }
 #define DCS_LOAD_B(kt_)                                                                                 \
     _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                   \
@@ -257,14 +277,20 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
     for (int r = 0; r < RBT; ++r)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) acc[r][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if defined(DCS_SKINNY_TRACE)
+    unsigned long long sk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, sb = 0;
+    SK_NOW(sb)
+#endif
     DCS_LOAD_A(0)
     DCS_LOAD_B(0)
     for (int kt = 0; kt < nkt; ++kt) {
+        SK_NOW(s0)
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
             if (a_dst[u] >= 0) {
                 u32x4 p0, p1, p2;
-                split8(ra[u][0] * gscale, ra[u][1] * gscale, p0, p1, p2);
+                const float s0 = (a_ok[u] && ra_k[u] < gK) ? gscale : 0.f, s1 = (a_ok[u] && ra_k[u] + 4 < gK) ? gscale : 0.f;
+                split8(ra[u][0] * s0, ra[u][1] * s1, p0, p1, p2);
                 u32x4* dst = As + a_dst[u];
                 dst[0] = p0; dst[kPlane] = p1; dst[2 * kPlane] = p2;
             }
@@ -273,10 +299,13 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int p = 0; p < 3; ++p) bc[cb][p] = bn[cb][p];
+        SK_NOW(s1)
         __syncthreads();
+        SK_NOW(s2)
         const int ktn = kt + 1 < nkt ? kt + 1 : kt;       // last tile: a harmless re-read
         DCS_LOAD_A(ktn)
         DCS_LOAD_B(ktn)
+        SK_NOW(s3)
         const u32x4* Ab = As + fi * kRowU4 + kq;
 #pragma unroll
         for (int r = 0; r < RBT; ++r) {
@@ -293,7 +322,14 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
                 acc[r][cb] = c;
             }
         }
+        SK_NOW(s4)
         __syncthreads();                                  // every wave has read this k tile's planes
+        SK_NOW(s5)
+        SK_ADD(0, s0, s1)
+        SK_ADD(1, s1, s2)
+        SK_ADD(2, s2, s3)
+        SK_ADD(3, s3, s4)
+        SK_ADD(4, s4, s5)
     }
 #undef DCS_LOAD_A
 #undef DCS_LOAD_B
@@ -327,9 +363,22 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
             }
         }
     }
+#if defined(DCS_SKINNY_TRACE)
+    SK_NOW(s0)
+    sk[5] = s0 - s5;
+    sk[6] = s0 - sb;
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0)
+        for (int i = 0; i < 8; ++i) skinny_trace_buf[i] = sk[i];
+#endif
 }
 
 }  // namespace
+
+#if defined(DCS_SKINNY_TRACE)
+extern "C" __attribute__((visibility("default"))) int skinny_trace_dump(unsigned long long* out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(skinny_trace_buf), sizeof(unsigned long long) * 8);
+}
+#endif
 
 size_t dcs_gemm_bq_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * 3 * (size_t)n_cols * 4 * 16; }
 
