@@ -215,6 +215,16 @@ struct DcsGemm {
     // run on the bf16 matrix pipe with f32-class results
     const void* Bq;
 };
+
+// row r of a grouped operand: (r / gdiv) * gmul + r % gdiv.  Most launches have ONE group (gdiv = 2^30 > M): a 64-bit division
+// and remainder per row -- ~80 instructions, four times per thread in a GEMM epilogue, ~0.5 us of a 12 us launch with one wave
+// per SIMD -- for a result that is r.  `flat` is wave-uniform (kernel arguments only).
+#if defined(__HIPCC__)
+__device__ __forceinline__ int64_t dcs_group_row(int64_t r, int gdiv, int gmul, bool flat) {
+    return flat ? r : (r / gdiv) * gmul + (r % gdiv);
+}
+#endif
+
 int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag);
 size_t dcs_gemm_bq_bytes(int K, int n_cols);
 // enqueued on the ctx stream; perm_c > 0: columns re-ordered from [channel perm_c][position perm_p] to [position][channel]

@@ -90,14 +90,19 @@ __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
     const int64_t arow = g.a_gdiv > 0 ? (int64_t)(rr / g.a_gdiv) * g.a_gmul + rr % g.a_gdiv : rr;
     const float* a_ptr = g.A + arow * g.a_row_stride + (row_ok ? s : 0) * slice_len + 4 * kq;
     const f32x4* b_ptr = reinterpret_cast<const f32x4*>(g.Bp) + ((int64_t)((s < g.n_slices ? s : 0) * g.n_cb + cb) * J) * 64 + lane;
+    // Every load is UNCONDITIONAL (a lane without an operand reads the first floats of A) and nothing touches a loaded
+    // register before LAT_DRAIN: with `ok ? load : 0` the compiler copied single components of two of the loaded vectors
+    // into other registers at once -- `s_waitcnt vmcnt(0)` behind the 2nd and the 7th load of the NA = 4 kernels, two whole
+    // memory round trips in front of the remaining requests on a path that is nothing but round trips.
     f32x4 a[NA][J], b[J];
+    bool a_okj[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int kl = 16 * j + 4 * kq;
-        const bool ok = row_ok && kl < slice_len && s * slice_len + kl < g.K;
+        a_okj[j] = row_ok && kl < slice_len && s * slice_len + kl < g.K;
+        const float* ap = a_okj[j] ? a_ptr + 16 * j : g.A;
 #pragma unroll
-        for (int z = 0; z < NA; ++z)
-            a[z][j] = ok ? *reinterpret_cast<const f32x4*>(a_ptr + z * g.a_part_stride + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < NA; ++z) a[z][j] = *reinterpret_cast<const f32x4*>(ap + z * g.a_part_stride);
         b[j] = b_ptr[j * 64];
     }
     // requested with the operands: a load behind the LDS reduction would put one more memory latency on the chain
@@ -110,8 +115,9 @@ __global__ __launch_bounds__(1024) void lat_gemm_kernel(const DcsLatGemm g) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         f32x4 av = a[0][j];
+        if (NA > 1) av = (a[0][j] + a[1][j]) + (a[2][j] + a[3][j]);
+        if (!a_okj[j]) av = f32x4{0.f, 0.f, 0.f, 0.f};
         if (NA > 1) {
-            av = (a[0][j] + a[1][j]) + (a[2][j] + a[3][j]);
             if (g.relu_in) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) av[e] = fmaxf(av[e], 0.f);
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256) void lat_deconv2_kernel(const float* __restric
     f32x4 a[4];
 #pragma unroll
     for (int j = 0; j < 3; ++j) a[j] = *reinterpret_cast<const f32x4*>(Dp + 16 * j);
-    a[3] = kq == 0 ? *reinterpret_cast<const f32x4*>(Dp + 48) : f32x4{0.f, 0.f, 0.f, 0.f};
+    a[3] = *reinterpret_cast<const f32x4*>(kq == 0 ? Dp + 48 : Dp);   // unconditional; zeroed below for kq > 0
     f32x4 b[2][4];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -180,6 +186,9 @@ __global__ __launch_bounds__(256) void lat_deconv2_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[c][j] = bp[j * 64];
     }
+    // all twelve requests leave before anything waits (the scheduler sank the last four behind the first MFMAs' wait)
+    __builtin_amdgcn_sched_barrier(0);
+    if (kq != 0) a[3] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -993,22 +1002,41 @@ __global__ __launch_bounds__(256) void lat_stft_kernel(const float* __restrict__
         }
         return;
     }
-    for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
+    // Every load of the prologue -- twiddle table, samples, window -- is requested before the first one is used: written as
+    // `twl[k] = tw[k]` / `if (in range) x0 = audio[p]` loops the compiler made one memory round trip per iteration (ISA:
+    // s_waitcnt vmcnt(0) behind the 1st, 2nd and 4th load), and this path is nothing but round trips.  Samples outside
+    // the signal are read from a clamped index and zeroed afterwards.
+    constexpr int NI = M / 256;
+    float2 twr[NI + 1], xr[NI], wr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) twr[i] = tw[tid + 256 * i];
+    twr[NI] = tw[M];
     const int64_t base = t * (int64_t)hop - M;
     const float2* w2 = reinterpret_cast<const float2*>(win);
-    for (int m = tid; m < M; m += 256) {
-        const int64_t p = base + 2 * m;
-        float x0 = 0.f, x1 = 0.f;
-        if (vec && p >= 0 && p + 1 < L) {
-            const float2 x = *reinterpret_cast<const float2*>(audio + p);
-            x0 = x.x;
-            x1 = x.y;
-        } else {
-            if (p >= 0 && p < L) x0 = audio[p];
-            if (p + 1 >= 0 && p + 1 < L) x1 = audio[p + 1];
+    const bool inside = vec && base >= 0 && base + 2 * M <= L;   // uniform: the whole frame in range, pairs 8-byte aligned
+    if (inside) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xr[i] = *reinterpret_cast<const float2*>(audio + base + 2 * (tid + 256 * i));
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int64_t p = base + 2 * (tid + 256 * i);
+            const int64_t p0 = p < 0 ? 0 : (p >= L ? L - 1 : p), p1 = p + 1 < 0 ? 0 : (p + 1 >= L ? L - 1 : p + 1);
+            xr[i] = make_float2(audio[p0], audio[p1]);
         }
-        const float2 w = w2[m];
-        buf0[m] = make_float2(x0 * w.x, x1 * w.y);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wr[i] = w2[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) twl[tid + 256 * i] = twr[i];
+    if (tid == 0) twl[M] = twr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int m = tid + 256 * i;
+        const int64_t p = base + 2 * m;
+        const float x0 = (inside || (p >= 0 && p < L)) ? xr[i].x : 0.f;
+        const float x1 = (inside || (p + 1 >= 0 && p + 1 < L)) ? xr[i].y : 0.f;
+        buf0[m] = make_float2(x0 * wr[i].x, x1 * wr[i].y);
     }
     LAT_STAMP(6, 1);    // table + frame requested and written to LDS (the LDS writes wait for the loads)
     __syncthreads();
@@ -1204,14 +1232,31 @@ __global__ __launch_bounds__(NG * 256) void lat_ifft_kernel(const float* __restr
     const int64_t t = blockIdx.x;
     const int s = (int)blockIdx.y * NG + q;
     const bool live = s < n_src;
-    for (int k = tid; k <= M; k += NG * 256) twl[k] = tw[k];
+    // as in lat_stft_kernel: every load of the prologue in flight before the first use (the loops made a round trip per pass)
     {
+        constexpr int NI = M / 256, NT = NG * 256, NTW = (M + NT) / NT;
         const float* mrow = sep + (int64_t)(live ? s : 0) * src_stride + t * ld;
         const float2* urow = unit + t * ld;
-        for (int k = gt; k <= M; k += 256) {
-            const float am = (mrow[k] * pre_mul) * sqrt_n;
-            const float2 u = urow[k];
-            float2 x = make_float2(am * u.x, am * u.y);
+        float2 twr[NTW], uv[NI + 1];
+        float mv[NI + 1];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) twr[i] = tw[tid + NT * i <= M ? tid + NT * i : M];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            mv[i] = mrow[gt + 256 * i];
+            uv[i] = urow[gt + 256 * i];
+        }
+        mv[NI] = mrow[M];
+        uv[NI] = urow[M];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+            if (tid + NT * i <= M) twl[tid + NT * i] = twr[i];
+#pragma unroll
+        for (int i = 0; i <= NI; ++i) {
+            const int k = i < NI ? gt + 256 * i : M;
+            if (i == NI && gt != 0) break;
+            const float am = (mv[i] * pre_mul) * sqrt_n;
+            float2 x = make_float2(am * uv[i].x, am * uv[i].y);
             if (k == 0 || k == M) x.y = 0.f;     // numpy's irfft ignores the imaginary parts of DC and Nyquist
             b1[k] = x;
         }
@@ -1266,8 +1311,11 @@ __global__ __launch_bounds__(256) void lat_ola_kernel(const float2* __restrict__
         const int64_t t = h - (R - 1) + q;
         ok[q] = t >= 0 && t < T;
         const int pos2 = (int)((p - (t << log2hop)) >> 1);          // sample pair inside frame t
-        f[q] = ok[q] ? fr[((int64_t)s * T + t) * M + pos2] : make_float2(0.f, 0.f);
-        ws[q] = ok[q] ? wsq2[pos2] : make_float2(0.f, 0.f);
+        // unconditional (a frame that does not exist reads frame 0 / T - 1 at the same offset; dropped below): with
+        // `ok ? load : 0` the compiler waited behind the second load
+        const int64_t tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        f[q] = fr[((int64_t)s * T + tc) * M + pos2];
+        ws[q] = wsq2[pos2];
     }
 #pragma unroll
     for (int q = 0; q < R; ++q)
@@ -1521,8 +1569,10 @@ int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, cons
     const float pre_mul = 1.f / pre_div, sq = (float)sqrt((double)p->frame);
     float2* fr = reinterpret_cast<float2*>(frames);
     DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
-    {
-        constexpr int NG = 4;
+    // sources per workgroup (NG thread groups of 256, one FFT each, sharing the twiddle table): DCS_LAT_IFFT_NG = 1 / 2 / 4
+    static const int ng_env = getenv("DCS_LAT_IFFT_NG") ? atoi(getenv("DCS_LAT_IFFT_NG")) : 0;
+    auto launch_ifft = [&](auto ngc) -> int {
+        constexpr int NG = decltype(ngc)::value;
         const dim3 g1((unsigned)T, (unsigned)dcs_cdiv(n_src, NG));
         const size_t lds = ((size_t)(M + 2) + (size_t)NG * (2 * M + 2)) * sizeof(float2);
         auto k10 = lat_ifft_kernel<10, NG>;
@@ -1538,7 +1588,11 @@ int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, cons
         else
             hipLaunchKernelGGL(k9, g1, dim3(NG * 256), lds, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f, fr, T,
                                n_src, pre_mul, sq);
-    }
+        return DCS_OK;
+    };
+    if (ng_env == 1) DCS_CHECK(launch_ifft(std::integral_constant<int, 1>{}));
+    else if (ng_env == 2) DCS_CHECK(launch_ifft(std::integral_constant<int, 2>{}));
+    else DCS_CHECK(launch_ifft(std::integral_constant<int, 4>{}));
     const dim3 g2((unsigned)dcs_cdiv((n_out + 1) / 2, 256), (unsigned)n_src);
     if (R == 4)
         hipLaunchKernelGGL(lat_ola_kernel<4>, g2, dim3(256), 0, p->ctx->stream, fr, p->wsq_f, audio, n_out, log2hop, M, T);

@@ -367,27 +367,55 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     const float2* w2 = reinterpret_cast<const float2*>(win);
     // whole frame in range and its sample pairs 8-byte aligned: one 64-bit load per pair
     const bool inside = r_lo == 0 && r_hi == 2 * M && (reinterpret_cast<uintptr_t>(ap) & 7) == 0;
+    // All sample and window loads are issued before the first value is used, on the edge frames too: their loads are
+    // unconditional (index clamped into the clip) and the out-of-range samples are zeroed afterwards.  With `if (in range)
+    // x[0] = ap[r]` the compiler waited for each of an edge frame's 32 loads in turn -- sixteen memory round trips in the
+    // wave of the first / last frames of every clip, and a launch ends with its slowest wave.
+    cx xs[P], ws[P];
 #pragma unroll
     for (int b = 0; b < NB1; ++b)
 #pragma unroll
         for (int tt = 0; tt < R1; ++tt) {
             const int i = lane + 64 * b + tt * stride1;
-            const int r = 2 * i;
-            const cx w = ldc(w2 + i);
-            cx x = mk(0.f, 0.f);
+            ws[b * R1 + tt] = ldc(w2 + i);
+        }
+    if (inside) {
+#pragma unroll
+        for (int b = 0; b < NB1; ++b)
+#pragma unroll
+            for (int tt = 0; tt < R1; ++tt) {
+                const int r = 2 * (lane + 64 * b + tt * stride1);
 #ifdef DCS_STFT_ABL_NOLOAD
-            if (inside) {
-                x = mk((float)r, 1.f);
-            } else {
+                xs[b * R1 + tt] = mk((float)r, 1.f);
 #else
-            if (inside) {
-                x = *reinterpret_cast<const cx*>(ap + r);
-            } else {
+                xs[b * R1 + tt] = *reinterpret_cast<const cx*>(ap + r);
 #endif
-                if (r >= r_lo && r < r_hi) x[0] = ap[r];
-                if (r + 1 >= r_lo && r + 1 < r_hi) x[1] = ap[r + 1];
             }
-            v[b * R1 + tt] = x * w;
+    } else if (r_hi > r_lo) {
+#pragma unroll
+        for (int b = 0; b < NB1; ++b)
+#pragma unroll
+            for (int tt = 0; tt < R1; ++tt) {
+                const int r = 2 * (lane + 64 * b + tt * stride1);
+                const int r0 = r < r_lo ? r_lo : (r >= r_hi ? r_hi - 1 : r);
+                const int r1 = r + 1 < r_lo ? r_lo : (r + 1 >= r_hi ? r_hi - 1 : r + 1);
+                xs[b * R1 + tt] = mk(ap[r0], ap[r1]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) xs[i] = mk(0.f, 0.f);
+    }
+#pragma unroll
+    for (int b = 0; b < NB1; ++b)
+#pragma unroll
+        for (int tt = 0; tt < R1; ++tt) {
+            const int r = 2 * (lane + 64 * b + tt * stride1);
+            cx x = xs[b * R1 + tt];
+            if (!inside) {                                         // wave-uniform
+                x[0] = (r >= r_lo && r < r_hi) ? x[0] : 0.f;
+                x[1] = (r + 1 >= r_lo && r + 1 < r_hi) ? x[1] : 0.f;
+            }
+            v[b * R1 + tt] = x * ws[b * R1 + tt];
         }
     FW_STAMP(2);   // pass twiddles read, samples and window requested
     FW_DRAIN();

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
         const int64_t r = m0 + row;
         a_ok[u] = (idx < A_F4) && (r < gM);
         const int64_t rr = a_ok[u] ? r : 0;
-        a_ptr[u] = g.A + (g.a_rowmap ? (int64_t)g.a_rowmap[rr] : (rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda;
+        a_ptr[u] = g.A + (g.a_rowmap ? (int64_t)g.a_rowmap[rr] : dcs_group_row(rr, g.a_gdiv, g.a_gmul, g.a_gdiv >= g.M)) * g.lda;
     }
     const float* b_ptr[B_PER];
     int b_row[B_PER], b_c4[B_PER];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
                 if (row < g.M) {
                     float v = acc[r][e] + bias;
                     if (g.relu) v = fmaxf(v, 0.f);
-                    g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
+                    g.C[dcs_group_row(row, g.c_gdiv, g.c_gmul, g.c_gdiv >= g.M) * g.ldc + col] = v;
                 }
             }
         }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
     const int64_t r = m0 + fi;
     const bool row_ok = r < g.M;
     const int64_t rr = row_ok ? r : 0;
-    const float* a_ptr = g.A + (g.a_rowmap ? (int64_t)g.a_rowmap[rr] : (rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda + 4 * kq;
+    const float* a_ptr = g.A + (g.a_rowmap ? (int64_t)g.a_rowmap[rr] : dcs_group_row(rr, g.a_gdiv, g.a_gmul, g.a_gdiv >= g.M)) * g.lda + 4 * kq;
     const float* b_ptr = g.B + (int64_t)(4 * kq) * gldb + n0 + fi;
 
     f32x4 a_cur[4], a_nxt[4];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
                 if (row < g.M) {
                     float v = sum[e] + bias;
                     if (g.relu) v = fmaxf(v, 0.f);
-                    g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
+                    g.C[dcs_group_row(row, g.c_gdiv, g.c_gmul, g.c_gdiv >= g.M) * g.ldc + col] = v;
                 }
             }
         }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void gemm_ksplit_reduce_kernel(const DcsG
     for (; z < ksplit; ++z) v += p[z * zs];
     v += g.bias ? g.bias[col] : 0.f;
     if (g.relu) v = fmaxf(v, 0.f);
-    g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
+    g.C[dcs_group_row(row, g.c_gdiv, g.c_gmul, g.c_gdiv >= g.M) * g.ldc + col] = v;
 }
 
 template <int RB, int BK>

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g, 
         const int64_t r = m0 + row;
         a_ok[u] = idx < BM * 4 && r < gM;
         const int64_t rr = a_ok[u] ? r : 0;
-        a_ptr[u] = g.A + ((rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda + q * 8;
+        a_ptr[u] = g.A + (dcs_group_row(rr, g.a_gdiv, g.a_gmul, g.a_gdiv >= g.M)) * g.lda + q * 8;
         a_k0[u] = q * 8;
         a_dst[u] = row * kRowU4 + q;
     }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g, 
                 if (row < g.M) {
                     float v = acc[r][e] + bias;
                     if (g.relu) v = fmaxf(v, 0.f);
-                    g.C[((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + col] = v;
+                    g.C[dcs_group_row(row, g.c_gdiv, g.c_gmul, g.c_gdiv >= g.M) * g.ldc + col] = v;
                 }
             }
         }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
         const int row = idx >> 2, q = idx & 3;
         a_ok[u] = idx < ROWS * 4 && row < g.M;
         const int64_t rr = a_ok[u] ? row : 0;
-        a_ptr[u] = g.A + ((rr / g.a_gdiv) * g.a_gmul + (rr % g.a_gdiv)) * g.lda + q * 8;
+        a_ptr[u] = g.A + (dcs_group_row(rr, g.a_gdiv, g.a_gmul, g.a_gdiv >= g.M)) * g.lda + q * 8;
         a_k0[u] = q * 8;
         a_dst[u] = idx < ROWS * 4 ? row * kRowU4 + q : -1;
     }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
     for (int r = 0; r < RBT; ++r) {
         const int64_t row = r * 16 + fi;
         if (row < g.M) {
-            float* cp = g.C + ((row / g.c_gdiv) * g.c_gmul + (row % g.c_gdiv)) * g.ldc + c0;
+            float* cp = g.C + dcs_group_row(row, g.c_gdiv, g.c_gmul, g.c_gdiv >= g.M) * g.ldc + c0;
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 f32x4 v = acc[r][cb] + bias[cb];
