@@ -192,27 +192,128 @@ def test_x3_decoder_slot_lists_rows_and_exchange_reproduce_the_transposed_column
 
 
 def test_x3_decoder_channels_last_fetch_covers_every_channel_once():
-    """Fetch task i of a pair (128 threads, 6 rounds): row i // 64, x = (i % 64) // 4, K piece i % 4; four float pairs per
-    task at channel offsets 8 kq + 2 q, the pair past channel 29 re-reading 28 / 29 (it meets zero weights).  Every (row, x,
-    channel < 30) must be fetched exactly once into K slot (kq, j) with channel 8 kq + j, and the LDS unit of plane p is
-    ((row + 1) * 3 + p) * 64 + kq * 16 + x -- what the MFMA B fragment of lane 16 kq + x reads."""
-    H, Cin = 11, 30
-    seen = np.zeros((H, 16, 32), dtype=int)
-    units = set()
-    for i in range(H * 64):
-        h, rem = i >> 6, i & 63
-        x, kq = rem >> 2, rem & 3
-        for q in range(4):
-            c = 8 * kq + 2 * q
-            src = c if c + 2 <= Cin else Cin - 2
-            for e in range(2):
-                slot = 8 * kq + 2 * q + e                      # K slot the value lands in
+    """Fetch task i of a pair (128 threads, 6 rounds): row i // 64, x = (i % 64) // 4, K piece kq = i % 4; TWO 16-byte loads per
+    task -- channels 8 kq .. 8 kq + 3 and, `hi_off` floats further, four more.  For a K piece that runs past the last channel
+    (kq = 3 of 30 or 28 channels) the second load starts at channel Cin - 4 and its upper half is used twice (`hi_dup`): K
+    slots >= Cin meet zero weights and only have to hold finite values from INSIDE the position.  Every (row, x, channel <
+    Cin) must land exactly once in K slot = its channel, no load may leave the position's Cin floats, tasks past the last
+    row read row 0, and the LDS unit of plane p is ((row + 1) * 3 + p) * 64 + kq * 16 + x -- what the MFMA B fragment of
+    lane 16 kq + x reads."""
+    H = 11
+    for Cin in (28, 30, 32):
+        seen = np.zeros((H, 16, 32), dtype=int)
+        units = set()
+        for i in range(6 * 128):
+            h, rem = i >> 6, i & 63
+            x, kq = rem >> 2, rem & 3
+            ok = i < H * 64
+            hi_dup = 8 * kq + 8 > Cin
+            hi_off = Cin - 4 - 8 * kq if hi_dup else 4
+            row = h if ok else 0                                 # t_off of a task past the last row
+            lo = [8 * kq + e for e in range(4)]                  # channels of the first load
+            hi = [8 * kq + hi_off + e for e in range(4)]
+            assert 0 <= min(lo + hi) and max(lo + hi) < Cin and 0 <= row < H     # inside the position, 8-byte aligned
+            assert (8 * kq) % 2 == 0 and (8 * kq + hi_off) % 2 == 0
+            if not ok:
+                continue
+            slots = lo + ([hi[2], hi[3], hi[2], hi[3]] if hi_dup else hi)        # channel that lands in K slot 8 kq + j
+            for j, c in enumerate(slots):
+                slot = 8 * kq + j
                 if slot < Cin:
-                    assert src + e == slot                     # real channels sit in their own slot
+                    assert c == slot                              # real channels sit in their own slot
                 seen[h, x, slot] += 1
-        for p in range(3):
-            u = ((h + 1) * 3 + p) * 64 + kq * 16 + x
-            assert u not in units
-            units.add(u)
-    assert (seen == 1).all()
-    assert min(units) == 192 and max(units) == (H + 1) * 192 - 1     # rows 0 (= -1) and 12 (= 11) of the buffer stay zero
+            for p in range(3):
+                u = ((h + 1) * 3 + p) * 64 + kq * 16 + x
+                assert u not in units
+                units.add(u)
+        assert (seen == 1).all()
+        assert min(units) == 192 and max(units) == (H + 1) * 192 - 1     # rows 0 (= -1) and 12 (= 11) of the buffer stay zero
+
+
+# ------------------------------------------------------------------ slabconv_ps.hip, FAST tap loop (round 4)
+def test_slabconv_ps_mask_driven_tap_loop_visits_exactly_the_old_loops_steps():
+    """The iKala conv2 / conv2^T kernel walks (tap pair, 16-column block) steps; the old loop decided per step from the rows
+    and columns (`r`, `xs`, `inner`, per-lane `ok`), the new one from per-block bit masks (lm: some lane inside the image,
+    im: every lane inside), a live filter-row range [bu0, bu1] and a select between the lane's slab index and a record of
+    zeros.  Restated for both layers' shapes (conv2: 30 x 83 -> 21 x 64 'valid'; its InverseLayer: 21 x 64 -> 30 x 83 with
+    pads 9 / 19), every band the launcher can choose: same live steps, same `inner` flag, same lanes reading zeros, same
+    slab element for the others."""
+    KH, KW = 10, 20
+    nvp = (KW + 1) // 2
+    for (Hh, W, Ho, Wo, ph, pw) in ((30, 83, 21, 64, 0, 0), (21, 64, 30, 83, 9, 19)):
+        nxb = (Wo + 15) // 16
+        for band in (1, 4, 5):
+            for y0 in range(0, Ho, band):
+                yb = min(y0 + band, Ho)
+                rbase = max(y0 - ph, 0)
+                for by in range(y0, yb):
+                    for bxi in range(nxb):
+                        bx = bxi * 16
+                        xs0 = bx - pw
+                        lm = [(xs0 + 2 * vp + 16 >= 0 and xs0 + 2 * vp < W) for vp in range(nvp)]
+                        im = [(xs0 + 2 * vp >= 0 and xs0 + 2 * vp + 17 <= W) for vp in range(nvp)]
+                        bu0, bu1 = ph - by, Hh - 1 + ph - by
+                        for u in range(KH):
+                            for vp in range(nvp):
+                                # ---- the old loop
+                                r, xs = by + u - ph, bx + 2 * vp - pw
+                                old_live = not (r < 0 or r >= Hh or xs + 16 < 0 or xs >= W)
+                                old_inner = xs >= 0 and xs + 17 <= W
+                                # ---- the new one
+                                new_live = bu0 <= u <= bu1 and lm[vp]
+                                assert new_live == old_live
+                                if not old_live:
+                                    continue
+                                assert im[vp] == old_inner
+                                for lane in range(64):
+                                    fi, kq = lane & 15, lane >> 4
+                                    xc = xs + fi + (kq >> 1)
+                                    old_ok = 0 <= xc < W                      # (rows are live here)
+                                    old_idx = (r - rbase) * W + xc
+                                    lx = fi + (kq >> 1)
+                                    vb = (by - ph - rbase) * W + xs0 + lx      # records; the kernel carries (.. * RP + (kq & 1))
+                                    idx = vb + u * W + 2 * vp
+                                    reads_zero = (not im[vp]) and not (0 <= xs0 + 2 * vp + lx < W)
+                                    assert reads_zero == (not old_ok)
+                                    if old_ok:
+                                        assert idx == old_idx and idx >= 0
+
+
+# ------------------------------------------------------------------ forward STFT edge frames (round 4)
+def test_stft_edge_frames_clamped_loads_and_masks_reproduce_zero_padding():
+    """stft_forward_wave_kernel / lat_stft_kernel load the samples of a frame that hangs over either end of the signal from a
+    CLAMPED index (always inside the clip) and zero the out-of-range ones afterwards, instead of `if (in range) x = a[p]`
+    (which the compiler turned into one memory round trip per load).  Same frame as zero padding, every index inside [0, L)."""
+    M, hop = 8, 4
+    for L in (1, 5, 16, 23):
+        a = np.arange(1, L + 1, dtype=np.float64)
+        T = (L + M) // hop + 1
+        for t in range(T):
+            base = t * hop - M
+            r_lo = -base if base < 0 else 0
+            rem = L - base
+            r_hi = (0 if rem < 0 else rem) if rem < 2 * M else 2 * M
+            want = np.array([a[base + r] if 0 <= base + r < L else 0.0 for r in range(2 * M)])
+            got = np.zeros(2 * M)
+            if r_hi > r_lo:
+                for r in range(2 * M):
+                    rc = r_lo if r < r_lo else (r_hi - 1 if r >= r_hi else r)
+                    assert 0 <= base + rc < L
+                    got[r] = a[base + rc] if r_lo <= r < r_hi else 0.0
+            assert np.array_equal(got, want)
+            # lat_stft_kernel clamps the absolute position instead
+            got2 = np.zeros(2 * M)
+            for r in range(2 * M):
+                p = base + r
+                pc = 0 if p < 0 else (L - 1 if p >= L else p)
+                got2[r] = a[pc] if 0 <= p < L else 0.0
+            assert np.array_equal(got2, want)
+
+
+def test_group_row_shortcut_is_the_division_it_replaces():
+    """dcs_group_row: (r / gdiv) * gmul + r % gdiv, taken as r when the launch has one group (gdiv >= M)."""
+    for M, gdiv, gmul in ((640, 1 << 30, 0), (640, 640, 7), (640, 32, 40), (1, 1, 5), (33, 32, 100)):
+        flat = gdiv >= M
+        for r in range(M):
+            full = (r // gdiv) * gmul + r % gdiv
+            assert (r if flat else full) == full
