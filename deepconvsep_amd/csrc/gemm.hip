@@ -137,15 +137,32 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
         DCS_STORE_TILES()
         __syncthreads();
         if (kt + 1 < nkt) DCS_LOAD_TILES(kt + 1)
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const float b = Bs[(kk * 4 + kq) * BS + wave * 16 + fi];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const float a = As[(r * 16 + fi) * AS + kk * 4 + kq];
-                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r], 0, 0, 0);
-            }
+        // Operands of EIGHT k steps are read from LDS at a time, the next eight while the MFMAs of these run.  Left to
+        // itself the compiler emitted read / s_waitcnt lgkmcnt(0) / MFMA per step: with the few-workgroup shapes (one wave
+        // per SIMD) every MFMA then waited out an LDS latency -- the K tile of 128 cost ~3 100 cycles for 1 024 of MFMAs.
+        // Same products in the same order.
+        constexpr int KG = 8, NKG = (BK / 4) / KG;
+        float bq[2][KG], aq[2][RB][KG];
+#define DCS_READ_GROUP(g_)                                                                    \
+        _Pragma("unroll") for (int i = 0; i < KG; ++i) {                                      \
+            const int kk = (g_) * KG + i;                                                     \
+            bq[(g_) & 1][i] = Bs[(kk * 4 + kq) * BS + wave * 16 + fi];                        \
+            _Pragma("unroll") for (int r = 0; r < RB; ++r)                                    \
+                aq[(g_) & 1][r][i] = As[(r * 16 + fi) * AS + kk * 4 + kq];                    \
         }
+        DCS_READ_GROUP(0)
+#pragma unroll
+        for (int g_ = 0; g_ < NKG; ++g_) {
+            if (g_ + 1 < NKG) DCS_READ_GROUP(g_ + 1)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KG; ++i)
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[g_ & 1][r][i], bq[g_ & 1][i], acc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DCS_READ_GROUP
     }
 
     // epilogue: C/D layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
