@@ -317,3 +317,57 @@ def test_group_row_shortcut_is_the_division_it_replaces():
         for r in range(M):
             full = (r // gdiv) * gmul + r % gdiv
             assert (r if flat else full) == full
+
+
+def test_one_batch_prologues_request_every_element_once_and_only_inside_their_arrays():
+    """lat_stft_kernel / lat_ifft_kernel (dsd_lat.hip) request their twiddle table, spectrum row and samples in fully unrolled
+    batches with clamped indices (round 4; the loops they replace made one memory round trip per pass).  Restated: every
+    table entry 0 .. M is written by exactly one (thread, pass), every spectrum bin 0 .. M by exactly one thread group
+    member, and no index leaves [0, M]."""
+    for M in (512, 1024):
+        NI = M // 256
+        # lat_stft_kernel: 256 threads, NI passes + the entry M
+        written = np.zeros(M + 1, dtype=int)
+        for tid in range(256):
+            for i in range(NI):
+                assert 0 <= tid + 256 * i < M
+                written[tid + 256 * i] += 1
+            if tid == 0:
+                written[M] += 1
+        assert (written == 1).all()
+        # lat_ifft_kernel: NG thread groups of 256 share the table, each group fills its own spectrum buffer
+        for NG in (1, 2, 4):
+            NT = NG * 256
+            NTW = (M + NT) // NT
+            written = np.zeros(M + 1, dtype=int)
+            for tid in range(NT):
+                for i in range(NTW):
+                    k = tid + NT * i
+                    src = k if k <= M else M                          # the clamped load
+                    assert 0 <= src <= M
+                    if k <= M:
+                        written[k] += 1
+            assert (written == 1).all()
+            bins = np.zeros(M + 1, dtype=int)
+            for gt in range(256):
+                for i in range(NI + 1):
+                    if i == NI and gt != 0:
+                        break
+                    k = gt + 256 * i if i < NI else M
+                    assert 0 <= k <= M
+                    bins[k] += 1
+            assert (bins == 1).all()
+
+
+def test_f32_gemm_reads_its_lds_operands_in_groups_of_eight_k_steps_in_the_old_order():
+    """gemm_rows_kernel: the operands of eight k steps are read together (two register sets alternate) and multiplied in the
+    order of the plain loop -- the accumulation order, hence the bits, are those of `for kk: acc = mfma(a[kk], b[kk], acc)`."""
+    for BK in (32, 64, 128):
+        KG, steps = 8, BK // 4
+        order = []
+        sets = {0: list(range(0, KG))}
+        for g in range(steps // KG):
+            if g + 1 < steps // KG:
+                sets[(g + 1) & 1] = list(range((g + 1) * KG, (g + 2) * KG))
+            order += sets[g & 1]
+        assert order == list(range(steps))
