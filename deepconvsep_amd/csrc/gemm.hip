@@ -137,10 +137,13 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
         DCS_STORE_TILES()
         __syncthreads();
         if (kt + 1 < nkt) DCS_LOAD_TILES(kt + 1)
-        // Operands of EIGHT k steps are read from LDS at a time, the next eight while the MFMAs of these run.  Left to
-        // itself the compiler emitted read / s_waitcnt lgkmcnt(0) / MFMA per step: with the few-workgroup shapes (one wave
-        // per SIMD) every MFMA then waited out an LDS latency -- the K tile of 128 cost ~3 100 cycles for 1 024 of MFMAs.
-        // Same products in the same order.
+        if constexpr (BK == 128) {
+        // The few-workgroup shapes (BK = 128: one workgroup per CU, one wave per SIMD).  Operands of EIGHT k steps are read
+        // from LDS at a time, the next eight while the MFMAs of these run.  Left to itself the compiler emitted read /
+        // s_waitcnt lgkmcnt(0) / MFMA per step and every MFMA waited out an LDS latency -- the K tile of 128 cost ~3 100
+        // cycles for 1 024 of MFMAs.  Same products in the same order.  (NOT for the many-workgroup shapes below: there
+        // other waves hide the latency, and the 80 extra registers of RB = 4 cost occupancy -- Bach10's bottleneck layer
+        // 0.167 -> 0.206 ms with this loop.)
         constexpr int KG = 8, NKG = (BK / 4) / KG;
         float bq[2][KG], aq[2][RB][KG];
 #define DCS_READ_GROUP(g_)                                                                    \
@@ -163,6 +166,17 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef DCS_READ_GROUP
+        } else {
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const float b = Bs[(kk * 4 + kq) * BS + wave * 16 + fi];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float a = As[(r * 16 + fi) * AS + kk * 4 + kq];
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r], 0, 0, 0);
+            }
+        }
+        }
     }
 
     // epilogue: C/D layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
