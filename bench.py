@@ -32,12 +32,13 @@ line).  Every 4th round brackets the launches of the dominant kernel with HIP ev
 issues its K steps on stream 0 alone (kernel by kernel instead of replaying the hipGraph), because
 with kernels of other streams sharing the CUs an event pair measures a time-sliced duration.
 
-Rank 0 prints ONE JSON line.  `roofline` refers to the dominant kernel of the headline workload
-(transposed conv1 + bias + rectify + soft mask + cross-fade); `cpu_baseline` is the CPU oracle
-(reference-equivalent NumPy + torch-CPU float64 path) timed on this host; `legs` holds the other
-BASELINE configs (iKala 10 s, Bach10 with the f16 MFMA conv path, score-informed batch of 128),
-each with its own `roofline` and `cpu_baseline`; `saturating` repeats the headline measurement on
-a long clip (4096 tiles, 3 min 58 s) where one launch fills the chip (DESIGN.md "measurement").
+Rank 0 prints ONE compact JSON line (< 4 KB, strict JSON) as the LAST line of stdout: the contract keys, `roofline`
+of the dominant kernel of the headline workload (transposed conv1 + bias + rectify + soft mask + cross-fade),
+`cpu_baseline` (the CPU oracle -- reference-equivalent NumPy + torch-CPU float64 path -- timed on this host) and
+`parity_check`.  The full result object is written to bench_detail.json next to this file (and with --detail-stdout
+printed on an earlier stdout line): `legs` holds the other BASELINE configs (iKala 10 s, Bach10 with the f16 MFMA conv
+path, score-informed batch of 128), each with its own `roofline` and `cpu_baseline`; `saturating` repeats the headline
+measurement on a long clip (4096 tiles, 3 min 58 s) where one launch fills the chip (DESIGN.md "measurement").
 """
 import argparse
 import json
@@ -141,6 +142,100 @@ def time_cpu(fn, min_seconds, max_reps=1000):
             return el / reps, reps, el
 
 
+HEADLINE_LIMIT = 4096     # bytes: the driver keeps a bounded tail of stdout and parses the LAST line of it
+DETAIL_FILE = "bench_detail.json"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else None
+
+
+def _finite(x):
+    """Strict JSON has no NaN / Infinity: such numbers become null."""
+    if isinstance(x, float):
+        return x if (x == x and x not in (float("inf"), float("-inf"))) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
+def headline(line):
+    """The compact last stdout line (< HEADLINE_LIMIT bytes, strict JSON) cut out of the full result `line`: the
+    contract keys, the dominant kernel's roofline, the CPU baseline, the parity verdict and -- for N > 1 -- the
+    gather split.  Everything else (single_stream, launch_group, saturating, host_fed, legs, cli) goes to
+    DETAIL_FILE / the earlier `--detail-stdout` line."""
+    keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "x_realtime", "whole_path_algorithmic_tflops", "whole_path_frac_of_f32_peak",
+            "single_stream_ms_per_step", "single_stream_value", "rounds", "timed_region_s", "gather_check"]
+    h = {k: line[k] for k in keep if k in line}
+    cfg = dict(line.get("config") or {})
+    if len(str(cfg.get("workload", ""))) > 420:
+        cfg["workload"] = str(cfg["workload"])[:417] + "..."
+    h["config"] = cfg
+    r = line.get("roofline")
+    if r:
+        rr = _pick(r, ["bound", "kernel", "variant", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio",
+                       "algorithmic_bytes", "algorithmic_flops", "avg_kernel_ms", "launches", "tiles_per_launch"])
+        if len(str(rr.get("kernel", ""))) > 120:
+            rr["kernel"] = str(rr["kernel"])[:117] + "..."
+        if isinstance(r.get("issued"), dict):
+            rr["issued"] = _pick(r["issued"], ["achieved", "peak", "unit", "frac"])
+        h["roofline"] = rr
+    c = line.get("cpu_baseline")
+    if c:
+        cc = _pick(c, ["value", "unit", "cores", "kind", "cpu_model", "host_cpu_count", "label", "sample"])
+        if len(str(cc.get("sample", ""))) > 330:
+            cc["sample"] = str(cc["sample"])[:327] + "..."
+        h["cpu_baseline"] = cc
+    else:
+        h["cpu_baseline"] = None
+    pc = line.get("parity_check")
+    h["parity_check"] = _pick(pc, ["ok", "max_abs_pcm_err", "tolerance", "network_output_max_err", "mask_bins",
+                                   "masked_bins_outside_1e4", "conditioned_fraction", "ranks"]) if pc else None
+    g = line.get("gather")
+    if g:
+        gg = _pick(g, ["mode", "impl", "payload_bytes_per_rank_per_group", "round_ms_without_gather",
+                       "round_ms_with_gather", "ms_per_group_collective_alone"])
+        gg["impl"] = str(gg.get("impl", ""))[:60]
+        h["gather"] = gg
+    legs = line.get("legs")
+    if isinstance(legs, dict):      # one number per extra BASELINE config; the blocks themselves are in the detail
+        h["legs_ms_per_clip"] = {k: (v.get("ms_per_clip") if isinstance(v, dict) else None) for k, v in legs.items()}
+    h["detail"] = line.get("detail_file", DETAIL_FILE)
+    h = _finite(h)
+    text = json.dumps(h, allow_nan=False)
+    # belt and braces: drop the optional blocks, longest first, until the line fits
+    for k in ("legs_ms_per_clip", "gather_check", "whole_path_algorithmic_tflops", "x_realtime"):
+        if len(text) < HEADLINE_LIMIT:
+            break
+        h.pop(k, None)
+        text = json.dumps(h, allow_nan=False)
+    if len(text) >= HEADLINE_LIMIT:
+        h["config"] = {"workload": str(cfg.get("workload", ""))[:200]}
+        if isinstance(h.get("cpu_baseline"), dict):
+            h["cpu_baseline"]["sample"] = str(h["cpu_baseline"].get("sample", ""))[:120]
+        text = json.dumps(h, allow_nan=False)
+    return text
+
+
+def emit(line, detail_stdout=False, out=None):
+    """Write the full result to DETAIL_FILE (next to bench.py; best effort), optionally print it on an EARLIER stdout
+    line, then print the compact headline as the last stdout line."""
+    out = out or sys.stdout
+    full = json.dumps(_finite(line), allow_nan=False)
+    try:
+        with open(os.path.join(ROOT, DETAIL_FILE), "w") as fh:
+            fh.write(full + "\n")
+    except OSError:
+        pass
+    if detail_stdout:
+        out.write(full + "\n")
+    out.write(headline(line) + "\n")
+    out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +263,9 @@ def main():
     ap.add_argument("--gather-impl", choices=["torch", "dcs"], default="torch",
                     help="who issues the collective: torch.distributed (backend nccl = RCCL), or libdcs's own C-ABI entry "
                          "dcs_gather on an RCCL communicator per HIP stream (deepconvsep_amd.dist.RcclComm)")
+    ap.add_argument("--detail-stdout", action="store_true",
+                    help="also print the full result object (legs, cli, saturating ...) on a stdout line BEFORE the compact "
+                         "headline line; it is always written to bench_detail.json")
     ap.add_argument("--only-legs", action="store_true",
                     help="(counter passes) skip the headline timing: run only the legs given by --legs")
     args = ap.parse_args()
@@ -732,7 +830,7 @@ def main():
             line["gather_check"] = gather_check
         if gather_split is not None:
             line["gather"] = gather_split
-        print(json.dumps(line))
+        emit(line, detail_stdout=args.detail_stdout)
     if gathering:
         for ln in lanes:
             if ln.comm is not None:
