@@ -301,8 +301,11 @@ constexpr int kStftStageF2 = 256;
 #define DCS_STFT_WIDE_STORES 1
 #endif
 
+#ifndef DCS_STFT_MIN_WAVES
+#define DCS_STFT_MIN_WAVES 1   // waves per SIMD the forward kernel is sized for (experiment builds)
+#endif
 template <int LOG2M>
-__global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
+__global__ __launch_bounds__(256, DCS_STFT_MIN_WAVES) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
                                          const float2* __restrict__ tw, float* __restrict__ mag,
                                          float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
                                          int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,

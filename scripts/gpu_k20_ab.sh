@@ -16,7 +16,8 @@ for v in ${DCS_AB_VARIANTS:-default}; do
   vn=${v//\//_}
   for rep in $(seq 1 ${DCS_K20_REPS:-2}); do
     env $envs timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-fed --no-cli --legs= --sat-tiles 0 \
-        ${DCS_K20_ARGS:-} > $OUT/k20_$vn.json 2> $OUT/k20_$vn.err || { echo "== $v FAILED"; tail -n 3 $OUT/k20_$vn.err; }
+        ${DCS_K20_ARGS:-} > $OUT/k20_$vn.line 2> $OUT/k20_$vn.err || { echo "== $v FAILED"; tail -n 3 $OUT/k20_$vn.err; }
+    cp bench_detail.json $OUT/k20_$vn.json 2>/dev/null   # the full result (the stdout line is the compact headline)
     python - "$v" "$OUT/k20_$vn.json" <<'PY' | tee -a $OUT/k20_ab.txt
 import json, sys
 try:
@@ -35,7 +36,8 @@ done
 if [ "${DCS_K20_TRACE:-1}" = "1" ]; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_k20 -o bench -- \
       python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-fed --no-cli --legs= --sat-tiles 0 --no-parity-check \
-      > $GRAFT_REPO_ROOT/$OUT/prof_k20_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof_k20.err)
+      > $GRAFT_REPO_ROOT/$OUT/prof_k20_bench.line 2> $GRAFT_REPO_ROOT/$OUT/prof_k20.err)
+  cp bench_detail.json $OUT/prof_k20_bench.json 2>/dev/null
   echo "rocprof exit $?"
   python scripts/trace_by_grid.py $OUT/prof_k20 > $OUT/kernel_durations_by_grid_k20.txt 2>&1
   grep -E "final|istft|deconv2|stft_forward|gemm" $OUT/kernel_durations_by_grid_k20.txt
