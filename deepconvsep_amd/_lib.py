@@ -77,6 +77,7 @@ def load():
     proto("dcs_model_num_sources", i32, vp)
     proto("dcs_model_set_conv_precision", i32, vp, i32)
     proto("dcs_model_set_latency_stages", i32, vp, i32)
+    proto("dcs_model_set_score_semantics", i32, vp, i32, i32)
     proto("dcs_lat_pack_b_host", i64, vp, i32, i32, i32, i32, i32, vp, i64)
     proto("dcs_lat_pack_deconv2_host", i64, vp, i32, vp, i64)
     proto("dcs_model_out_channels", i32, vp)
@@ -87,6 +88,7 @@ def load():
     proto("dcs_pcm_to_int16", i32, vp, vp, i64, vp)
     proto("dcs_gather", i32, vp, vp, vp, i64, vp, i32)
     proto("dcs_score_masks", i32, vp, vp, i64, i64, i32, vp, i32, i32, i32, i64, i64, vp, vp)
+    proto("dcs_score_masks_norm", i32, vp, vp, i64, i64, i32, vp, i32, i32, i32, i64, i64, i32, vp, vp)
     proto("dcs_separate_stereo", i32, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, i64, POINTER(i64), POINTER(i64))
     proto("dcs_separate_scoreinformed", i32, vp, vp, vp, i64, POINTER(c_double), i32, i32, i32, i32, f32, i32, i32, vp,
           POINTER(i64), POINTER(i64))

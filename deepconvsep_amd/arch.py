@@ -9,12 +9,16 @@ script; the HIP model (``csrc/``) is instantiated from it.
                 trainer has 90 090 rows in fc.W instead of 13 230 -- `resolve` picks the graph from the shapes)
   bach10        examples/bach10/separate_bach10.py:172-229
   bach10_si     examples/bach10_scoreinformed/separate_bach10.py:388-447
+  bach10_si1    examples/bach10_scoreinformed/trainCNNrwc_samp.py:195-235   (the single-branch form, 11 arrays: the branch
+                ``predict_function2`` reads from the 17-array graph, written out on its own)
   dsd_ild       examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115   (stereo input, 4 branches x 2 channels)
 """
 import numpy as np
 
 # enum values shared with include/dcs.h
-ARCH_DSD, ARCH_IKALA, ARCH_BACH10, ARCH_BACH10_SI, ARCH_DSD_ILD, ARCH_IKALA_NOPOOL = 0, 1, 2, 3, 4, 5
+ARCH_DSD, ARCH_IKALA, ARCH_BACH10, ARCH_BACH10_SI, ARCH_DSD_ILD, ARCH_IKALA_NOPOOL, ARCH_BACH10_SI1 = 0, 1, 2, 3, 4, 5, 6
+SCORE_NORM_MAX, SCORE_NORM_SUM = 0, 1     # harmonic masks / own maximum (script) | / sum over instruments (trainers)
+MIX_CH0, MIX_SUM = 0, 1                   # soft masks x input channel 0 (script) | x channel sum (trainers)
 EPS_A, EPS_B = 0, 1
 EPS_ILD = 3   # per input channel, p / (sum + 1e-12 r), + 1e-12 r (trainCNN_ILD_DSD100.py:176-180); dcs_separate_stereo only
 TIE_ALL, TIE_FIRST = 0, 1
@@ -91,6 +95,8 @@ ARCHS = {
     'dsd_ild': Arch('dsd_ild', ARCH_DSD_ILD, 2, (50, 'F', 1), 0, (50, lambda tc: int(tc / 2), 1), 256,
                     [0, 1, 2, 3], 4, EPS_ILD, ['vocals', 'bass', 'drums', 'other']),
 }
+ARCHS['bach10_si1'] = Arch('bach10_si1', ARCH_BACH10_SI1, 4, (30, 30, 4), 0, (30, lambda tc: int(2 * tc / 3), 1), 256, [0], 4,
+                           EPS_B, ['bassoon', 'clarinet', 'saxphone', 'violin'])
 ARCHS['hiphop'] = ARCHS['dsd']
 ARCHS['ikala_nopool'] = Arch('ikala_nopool', ARCH_IKALA_NOPOOL, 1, (30, 30, 3), 0, (30, lambda tc: 10, 20), 256,
                              [0, 1], 2, EPS_A, ['voice', 'music'])
@@ -101,11 +107,26 @@ def resolve(arch, params, tc, F):
     (1, 4) max-pool (separate_ikala.py:176), ikala/trainCNN.py:92-100 without; the trainer's .pkl files therefore only load
     into the no-pool graph.  The bottleneck's input size tells them apart (fc.W rows 13 230 vs 90 090 at 513 bins)."""
     a = ARCHS[arch] if isinstance(arch, str) else arch
+    # score-informed: the 17-array graph of the separate script / trainCNNrwc.py, or the 11-array single-branch graph of
+    # trainCNNrwc_samp.py:195-235 -- the same script loads either .pkl
+    if a.name == 'bach10_si' and len(params) == len(ARCHS['bach10_si1'].param_shapes(tc, F)):
+        return ARCHS['bach10_si1']
     if a.name == 'ikala' and len(params) > 6 and np.ndim(params[6]) == 2:
         rows = int(np.shape(params[6])[0])
         if rows != a.dims(tc, F)['flat'] and rows == ARCHS['ikala_nopool'].dims(tc, F)['flat']:
             return ARCHS['ikala_nopool']
     return a
+
+
+def live_params(arch, params):
+    """The parameters ``predict_function2`` can reach, as a graph of their own.  Only the 17-array score-informed graph has
+    dead ones: its masks read ``prediction2[:, 0:4]`` = the four channels of decoder branch 0
+    (bach10_scoreinformed/separate_bach10.py:475-488), so three per-source dense layers (3 x 171 MB at 2049 bins) and twelve
+    output biases are never used -- what is left is exactly the 11-array graph ``bach10_si1``.  Returns (arch, params)."""
+    if arch.name == 'bach10_si' and len(params) == 17:
+        live = list(params[:10]) + [np.asarray(params[16])[:arch.C]]
+        return ARCHS['bach10_si1'], live
+    return arch, params
 
 
 def check_params(arch, params, tc, F):

@@ -240,7 +240,7 @@ bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemm
 
 int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
                            int ninst, int n_notes, int width, int64_t start, int64_t stop, float mag_scale, float* out_d,
-                           float* mask_d);
+                           float* mask_d, int normalise = DCS_SCORE_NORM_MAX);
 
 // ---------------------------------------------------------------------------------- tiling kernels
 int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F,

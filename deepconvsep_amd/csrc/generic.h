@@ -74,6 +74,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
                        const std::vector<std::vector<float>>& params, DcsGenericNet** out);
 void dcs_generic_destroy(DcsGenericNet* g);
 int dcs_generic_set_conv_f16(DcsGenericNet* g, int on);
+int dcs_generic_set_score_semantics(DcsGenericNet* g, int normalise, int mixture);
 // tiles [n, C, tc, F] -> mask_mode 0/1: out [S, n, tc, F] masked; mask_mode 2: p [n, n_branch*C, tc, F]
 int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mask_mode, int tie_mode, float* out);
 // n_clips equal-length clips (clip c at audio + c * audio_stride) go through one set of launches: their tiles are

@@ -1110,13 +1110,14 @@ __global__ __launch_bounds__(kThreads) void deconv1_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // concat + BiasLayer + rectify + soft mask (separate_ikala.py:190-217, separate_bach10.py:229-264).
-// o: [n, CH, tc, F] with CH = branches*C; masks use channels 0..S-1, the mixture is input channel 0.
+// o: [n, CH, tc, F] with CH = branches*C; masks use channels 0..S-1, the mixture is input channel 0 (every separate script) or
+// the sum of the first mix_n = C input channels (score-informed trainers, trainCNNrwc.py:258-263).
 // mode 0/1: out[s][n][t][f]; mode 2: p[ch][n][t][f] for all CH channels.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void mask_kernel(const float* __restrict__ o, const float* __restrict__ bias,
                                                         const float* __restrict__ x, float* __restrict__ out,
                                                         int64_t n, int CH, int S, int C, int64_t plane /* tc*F */,
-                                                        int mode) {
+                                                        int mode, int mix_n /* input channels the mixture adds up: 1 or C */) {
     const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (idx >= n * plane) return;
     const int64_t k = idx / plane, r = idx - k * plane;
@@ -1134,7 +1135,8 @@ __global__ __launch_bounds__(kThreads) void mask_kernel(const float* __restrict_
         den = (s == 0) ? p[s] : den + p[s];
     }
     if (mode == 1) den += eps_r;
-    const float mix = x[(k * C) * plane + r];
+    float mix = x[(k * C) * plane + r];
+    for (int c = 1; c < mix_n; ++c) mix += x[(k * C + c) * plane + r];   // the trainers' mixture: channels added left to right
     for (int s = 0; s < S; ++s) out[((int64_t)s * n + k) * plane + r] = (p[s] / den) * mix;
 }
 
@@ -1154,7 +1156,7 @@ __global__ __launch_bounds__(kThreads) void mask_ola_kernel(const float* __restr
                                                             const float* __restrict__ x, int64_t n, int64_t k_off, int CH,
                                                             int S, int C, int tc, int ov, int F,
                                                             const float* __restrict__ rise, float* __restrict__ sep,
-                                                            int64_t sep_stride, int64_t ld, int mode) {
+                                                            int64_t sep_stride, int64_t ld, int mode, int mix_n) {
     const int64_t t = blockIdx.x;
     const int st = tc - ov;
     const int64_t plane = (int64_t)tc * F;
@@ -1168,7 +1170,7 @@ __global__ __launch_bounds__(kThreads) void mask_ola_kernel(const float* __restr
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (j0 < tc) {
             constexpr int MA = MM > 0 ? MM : 1;
-            float v[MA][5];
+            float v[MA][8];                                            // [0..3] raw outputs, [4..7] input channels of the mixture
             bool valid[MA];
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
@@ -1178,7 +1180,9 @@ __global__ __launch_bounds__(kThreads) void mask_ola_kernel(const float* __restr
                 const int64_t r = (t - kc * st) * F + f;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) v[m][s] = o[((k_off + kc) * CH + s) * plane + r];
-                v[m][4] = x[((k_off + kc) * C) * plane + r];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)                            // mix_n is 1 or C <= 4, uniform over the launch
+                    v[m][4 + c] = c < mix_n ? x[((k_off + kc) * C + c) * plane + r] : 0.f;
             }
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
@@ -1193,7 +1197,10 @@ __global__ __launch_bounds__(kThreads) void mask_ola_kernel(const float* __restr
                     den = (s == 0) ? p[s] : den + p[s];
                 }
                 if (mode == 1) den += eps_r;
-                const float mix = v[m][4];
+                float mix = v[m][4];
+#pragma unroll
+                for (int c = 1; c < 4; ++c)
+                    if (c < mix_n) mix += v[m][4 + c];
                 if (m == 0) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[s] = (p[s] / den) * mix;
@@ -1222,7 +1229,8 @@ __global__ __launch_bounds__(kThreads) void mask_ola_kernel(const float* __restr
                     den = (s == 0) ? p[s] : den + p[s];
                 }
                 if (mode == 1) den += eps_r;
-                const float mix = x[((k_off + k) * C) * plane + r];
+                float mix = x[((k_off + k) * C) * plane + r];
+                for (int c = 1; c < mix_n; ++c) mix += x[((k_off + k) * C + c) * plane + r];
                 if (k == k0) {
                     for (int s = 0; s < S; ++s) acc[s] = (p[s] / den) * mix;
                 } else {
@@ -1292,6 +1300,9 @@ struct DcsGenericNet {
     int rise_ov = -1;
     const float* raw_o = nullptr;        // decoder output of the last deferred-mask pass (scratch of ws), its channel count
     int raw_ch = 0;
+    // score-informed graphs: the reference's two semantics (dcs_model_set_score_semantics)
+    int score_norm = DCS_SCORE_NORM_MAX;  // harmonic masks / own maximum (script) or / sum over instruments (trainers)
+    int mix_sum = 0;                      // soft masks x input channel 0 (script) or x the channel sum (trainers)
 };
 
 int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int F,
@@ -1916,13 +1927,13 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         // -> simplest exact form: launch with n_total as `n` stride when the chunk is the whole batch.
         if (n == n_total) {
             hipLaunchKernelGGL(mask_kernel, dim3((unsigned)dcs_cdiv(n * plane, kThreads)), dim3(kThreads), 0, ctx->stream,
-                               o, g->bout, tiles, out, n, CH, d.S, C, plane, mask_mode);
+                               o, g->bout, tiles, out, n, CH, d.S, C, plane, mask_mode, g->mix_sum ? C : 1);
         } else {
             // chunked batch: write into a compact [ch][n][plane] staging area, then scatter rows
             float* stage = (float*)w;
             const int nch = mask_mode == 2 ? CH : d.S;
             hipLaunchKernelGGL(mask_kernel, dim3((unsigned)dcs_cdiv(n * plane, kThreads)), dim3(kThreads), 0, ctx->stream,
-                               o, g->bout, tiles, stage, n, CH, d.S, C, plane, mask_mode);
+                               o, g->bout, tiles, stage, n, CH, d.S, C, plane, mask_mode, g->mix_sum ? C : 1);
             for (int ch = 0; ch < nch; ++ch)
                 DCS_HIP(hipMemcpyAsync(out + ((int64_t)ch * n_total + k_first) * plane, stage + (int64_t)ch * n * plane,
                                        (size_t)n * plane * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1946,6 +1957,17 @@ size_t chunk_bytes(const DcsGenericNet* g, int64_t n) {
 }
 
 }  // namespace
+
+int dcs_generic_set_score_semantics(DcsGenericNet* g, int normalise, int mixture) {
+    if (!g) DCS_FAIL(DCS_EINVAL, "null network");
+    if ((normalise != DCS_SCORE_NORM_MAX && normalise != DCS_SCORE_NORM_SUM) || (mixture != DCS_MIX_CH0 && mixture != DCS_MIX_SUM))
+        DCS_FAIL(DCS_EINVAL, "dcs_model_set_score_semantics: normalise %d, mixture %d", normalise, mixture);
+    if (g->C < 2) DCS_FAIL(DCS_EUNSUPPORTED, "score semantics belong to the multi-channel (score-informed) graphs");
+    if (g->C > 4) DCS_FAIL(DCS_EUNSUPPORTED, "channel-sum mixture: at most 4 input channels");
+    g->score_norm = normalise;
+    g->mix_sum = mixture == DCS_MIX_SUM ? 1 : 0;
+    return DCS_OK;
+}
 
 int dcs_generic_set_conv_f16(DcsGenericNet* g, int on) {
     if (!g) DCS_FAIL(DCS_EINVAL, "null network");
@@ -2017,7 +2039,7 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
         // separate_bach10.py (score-informed) :503-527: scaled magnitudes x filterSpec masks, one channel per instrument,
         // then the C-channel tiles (the masks multiply channel 0 of a tile, as in the script)
         DCS_CHECK(dcs_score_masks_scaled(ctx, mag, ld, T, F, notes->notes_h, notes->ninst, notes->n_notes, notes->width, 0, T,
-                                         scale, inp, nullptr));
+                                         scale, inp, nullptr, g->score_norm));
         DCS_CHECK(dcs_launch_tile(ctx, inp, T * (int64_t)F, F, g->C, T, F, tc, ov, tiler, 1.0f, tiles, n));
     } else {
         for (int64_t c = 0; c < n_clips; ++c)
@@ -2058,7 +2080,8 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
             const dim3 grid((unsigned)(nc[c] * st + tc), (unsigned)dcs_cdiv(F, kThreads));
 #define DCS_MASK_OLA(MM_)                                                                                                   \
             hipLaunchKernelGGL((mask_ola_kernel<MM_>), grid, dim3(kThreads), 0, ctx->stream, g->raw_o, g->bout, tiles, nc[c], off[c], \
-                               g->raw_ch, S, g->C, tc, ov, F, g->rise_d, sep + c * S * rows * ld, rows * ld, ld, eps_mode)
+                               g->raw_ch, S, g->C, tc, ov, F, g->rise_d, sep + c * S * rows * ld, rows * ld, ld, eps_mode,         \
+                               g->mix_sum ? g->C : 1)
             if (mm_env && S == 4 && mmax <= 6) DCS_MASK_OLA(6);
             else DCS_MASK_OLA(0);
 #undef DCS_MASK_OLA

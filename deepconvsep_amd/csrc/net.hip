@@ -46,10 +46,16 @@ int arch_dims(int arch, int C, int tc, int F, Dims* d) {
             break;
         case DCS_ARCH_BACH10:     // separate_bach10.py:197-227
         case DCS_ARCH_BACH10_SI:  // bach10_scoreinformed/separate_bach10.py:414-444
+        case DCS_ARCH_BACH10_SI1: // bach10_scoreinformed/trainCNNrwc_samp.py:195-235: one dense layer back, one decoder branch
             d->nf1 = 30; d->kw1 = 30; d->sw1 = 4; d->pool_w = 0;
             d->nf2 = 30; d->kh2 = (2 * tc) / 3; d->kw2 = 1; d->hidden = 256;
             d->n_fc = 4; d->n_branch = 4; d->S = 4;
             for (int i = 0; i < 4; ++i) d->branch_fc[i] = i;
+            if (arch == DCS_ARCH_BACH10_SI1) {
+                d->n_fc = 1; d->n_branch = 1;
+                for (int i = 1; i < 4; ++i) d->branch_fc[i] = 0;
+                if (C != 4) DCS_FAIL(DCS_EINVAL, "score-informed network takes 4 input channels");
+            }
             if (arch == DCS_ARCH_BACH10 && C != 1) DCS_FAIL(DCS_EINVAL, "bach10 network takes 1 input channel");
             if (arch == DCS_ARCH_BACH10_SI && C != 4)
                 DCS_FAIL(DCS_EINVAL, "score-informed network takes 4 input channels");
@@ -577,6 +583,12 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     if (m->Bdq) (void)hipFree(m->Bdq);
     delete m;
     return DCS_OK;
+}
+
+extern "C" int dcs_model_set_score_semantics(dcs_model* m, int normalise, int mixture) {
+    if (!m) DCS_FAIL(DCS_EINVAL, "dcs_model_set_score_semantics: null model");
+    if (!m->gen) DCS_FAIL(DCS_EUNSUPPORTED, "score semantics belong to the score-informed graphs");
+    return dcs_generic_set_score_semantics(m->gen, normalise, mixture);
 }
 
 extern "C" int dcs_model_set_conv_precision(dcs_model* m, int f16) {

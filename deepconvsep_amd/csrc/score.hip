@@ -6,6 +6,8 @@
 // value (x mag) everywhere, then one workgroup per rectangle overwrites its cells with the note value (x mag).
 // Rectangles of one instrument may overlap; they all write the same value, so the order does not matter.
 // HBM-bound: ninst * T * F * 4 B written (+ T * F * 4 read), 33.6 MB for a 10 s Bach10 file.
+// The trainers' variant (LargeDatasetMask2.filterSpec, dataset.py:839-879: every bin divided by the sum over the instruments)
+// takes a third pass, score_sumnorm_kernel below.
 #include "dcs_internal.h"
 
 #include <string.h>
@@ -25,9 +27,9 @@ __global__ __launch_bounds__(256) void score_floor_kernel(const float* __restric
     const int64_t t = blockIdx.x;
     const int j = blockIdx.y;
     const float v = lo[j];
-    const float* mrow = mag + t * ld;
+    const float* mrow = mag ? mag + t * ld : nullptr;    // mag == nullptr: the flag pass of the sum normalisation (v itself)
     for (int f = threadIdx.x; f < F; f += 256) {
-        if (out) out[((int64_t)j * T + t) * F + f] = v * (mag_scale * mrow[f]);
+        if (out) out[((int64_t)j * T + t) * F + f] = mrow ? v * (mag_scale * mrow[f]) : v;
         if (mask) mask[t * ((int64_t)ninst * F) + (int64_t)j * F + f] = v;
     }
 }
@@ -44,8 +46,35 @@ __global__ __launch_bounds__(256) void score_rect_kernel(const float* __restrict
     for (int64_t c = threadIdx.x; c < cells; c += 256) {
         const int64_t t = r.t0 + c / w;
         const int f = r.f0 + (int)(c % w);
-        if (out) out[((int64_t)r.inst * T + t) * F + f] = v * (mag_scale * mag[t * ld + f]);
+        if (out) out[((int64_t)r.inst * T + t) * F + f] = mag ? v * (mag_scale * mag[t * ld + f]) : v;
         if (mask) mask[t * ((int64_t)ninst * F) + (int64_t)r.inst * F + f] = v;
+    }
+}
+
+// DCS_SCORE_NORM_SUM (LargeDatasetMask2.filterSpec, dataset.py:839-879): mask_j = filtered_j / sum_i filtered_i with filtered in
+// {1e-18, 1} -- three passes over the outputs, no scratch: the floor / rectangle kernels above first leave FLAGS (0 = floor,
+// 1 = inside a note rectangle) where the values will go, then this kernel turns the ninst flags of every (frame, bin) into the
+// values: the float32 sum over the instruments in order (np.sum over axis 0 of a float32 array adds slice by slice), one IEEE
+// division per instrument.  `flags` is out (layout [j][t][f]) when out is written, else mask ([t][j * F + f]).
+__global__ __launch_bounds__(256) void score_sumnorm_kernel(const float* __restrict__ mag, int64_t ld, int64_t T, int F, int ninst,
+                                                            float* __restrict__ out, float* __restrict__ mask, float mag_scale) {
+    const int64_t t = blockIdx.x;
+    const float* mrow = mag + t * ld;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        unsigned on = 0;
+        float total = 0.f;
+        for (int j = 0; j < ninst; ++j) {
+            const float flag = out ? out[((int64_t)j * T + t) * F + f] : mask[t * ((int64_t)ninst * F) + (int64_t)j * F + f];
+            const float v = flag != 0.f ? 1.0f : 1e-18f;
+            on |= (flag != 0.f ? 1u : 0u) << j;
+            total = j == 0 ? v : total + v;
+        }
+        const float m = mag_scale * mrow[f];
+        for (int j = 0; j < ninst; ++j) {
+            const float v = (((on >> j) & 1u) ? 1.0f : 1e-18f) / total;
+            if (out) out[((int64_t)j * T + t) * F + f] = v * m;
+            if (mask) mask[t * ((int64_t)ninst * F) + (int64_t)j * F + f] = v;
+        }
     }
 }
 
@@ -54,7 +83,10 @@ __global__ __launch_bounds__(256) void score_rect_kernel(const float* __restrict
 // mag_scale: the spectrogram is multiplied by it first (the scripts' scale_factor, separate_bach10.py:503; 1 = already scaled)
 int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
                            int ninst, int n_notes, int width, int64_t start, int64_t stop, float mag_scale, float* out_d,
-                           float* mask_d) {
+                           float* mask_d, int normalise) {
+    if (normalise != DCS_SCORE_NORM_MAX && normalise != DCS_SCORE_NORM_SUM)
+        DCS_FAIL(DCS_EINVAL, "dcs_score_masks: normalise %d", normalise);
+    if (normalise == DCS_SCORE_NORM_SUM && ninst > 32) DCS_FAIL(DCS_EUNSUPPORTED, "dcs_score_masks: sum normalisation of %d instruments", ninst);
     if (!ctx || !mag_d || !notes_h) DCS_FAIL(DCS_EINVAL, "dcs_score_masks: null argument");
     if (!out_d && !mask_d) DCS_FAIL(DCS_EINVAL, "dcs_score_masks: nothing to write");
     if (ninst < 1 || ninst > 65535 || n_notes < 0 || width < 5 || ((width - 3) & 1) || F < 1 || ld < F || n_frames < 0)
@@ -93,6 +125,10 @@ int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t
         const float floor_v = 1e-18f, maxv = any ? 1.0f : floor_v;
         lo[j] = floor_v / maxv;
         hi[j] = 1.0f / maxv;
+        if (normalise == DCS_SCORE_NORM_SUM) {   // flags first: the values depend on the other instruments' rectangles
+            lo[j] = 0.f;
+            hi[j] = 1.f;
+        }
     }
     // rectangles + the two value rows travel as one block through the context's upload ring (no synchronisation here)
     const size_t b_rect = rects.size() * sizeof(ScoreRect), b_val = (size_t)ninst * sizeof(float);
@@ -105,11 +141,23 @@ int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t
     DCS_CHECK(ctx->score_ring.commit(off_hi + b_val, ctx->stream));
     char* base = (char*)dev;
     DcsTimer tm(ctx, DCS_TAG_SCORE);
-    hipLaunchKernelGGL(score_floor_kernel, dim3((unsigned)n_frames, (unsigned)ninst), dim3(256), 0, ctx->stream, mag_d, ld,
-                       n_frames, F, ninst, (const float*)(base + off_lo), out_d, mask_d, mag_scale);
-    if (!rects.empty())
-        hipLaunchKernelGGL(score_rect_kernel, dim3((unsigned)rects.size()), dim3(256), 0, ctx->stream, mag_d, ld, n_frames,
-                           F, ninst, (const ScoreRect*)base, (const float*)(base + off_hi), out_d, mask_d, mag_scale);
+    if (normalise == DCS_SCORE_NORM_SUM) {
+        // flags go where the values will go (ONE of the two outputs, un-multiplied: mag = nullptr selects the flag form)
+        float* f_out = out_d, *f_mask = out_d ? nullptr : mask_d;
+        hipLaunchKernelGGL(score_floor_kernel, dim3((unsigned)n_frames, (unsigned)ninst), dim3(256), 0, ctx->stream,
+                           (const float*)nullptr, ld, n_frames, F, ninst, (const float*)(base + off_lo), f_out, f_mask, 1.0f);
+        if (!rects.empty())
+            hipLaunchKernelGGL(score_rect_kernel, dim3((unsigned)rects.size()), dim3(256), 0, ctx->stream, (const float*)nullptr,
+                               ld, n_frames, F, ninst, (const ScoreRect*)base, (const float*)(base + off_hi), f_out, f_mask, 1.0f);
+        hipLaunchKernelGGL(score_sumnorm_kernel, dim3((unsigned)n_frames), dim3(256), 0, ctx->stream, mag_d, ld, n_frames, F,
+                           ninst, out_d, mask_d, mag_scale);
+    } else {
+        hipLaunchKernelGGL(score_floor_kernel, dim3((unsigned)n_frames, (unsigned)ninst), dim3(256), 0, ctx->stream, mag_d, ld,
+                           n_frames, F, ninst, (const float*)(base + off_lo), out_d, mask_d, mag_scale);
+        if (!rects.empty())
+            hipLaunchKernelGGL(score_rect_kernel, dim3((unsigned)rects.size()), dim3(256), 0, ctx->stream, mag_d, ld, n_frames,
+                               F, ninst, (const ScoreRect*)base, (const float*)(base + off_hi), out_d, mask_d, mag_scale);
+    }
     tm.done();
     DCS_HIP(hipGetLastError());
     return DCS_OK;
@@ -118,5 +166,13 @@ int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t
 extern "C" int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F,
                                const double* notes_h, int ninst, int n_notes, int width, int64_t start, int64_t stop,
                                float* out_d, float* mask_d) {
-    return dcs_score_masks_scaled(ctx, mag_d, ld, n_frames, F, notes_h, ninst, n_notes, width, start, stop, 1.0f, out_d, mask_d);
+    return dcs_score_masks_scaled(ctx, mag_d, ld, n_frames, F, notes_h, ninst, n_notes, width, start, stop, 1.0f, out_d, mask_d,
+                                  DCS_SCORE_NORM_MAX);
+}
+
+extern "C" int dcs_score_masks_norm(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F,
+                                    const double* notes_h, int ninst, int n_notes, int width, int64_t start, int64_t stop,
+                                    int normalise, float* out_d, float* mask_d) {
+    return dcs_score_masks_scaled(ctx, mag_d, ld, n_frames, F, notes_h, ninst, n_notes, width, start, stop, 1.0f, out_d, mask_d,
+                                  normalise);
 }

@@ -10,7 +10,8 @@ from ctypes import POINTER, byref, c_double, c_int64, c_void_p
 import numpy as np
 
 from . import _lib
-from .arch import ARCHS, EPS_A, EPS_B, TIE_ALL, TIE_FIRST, TILER_LIBRARY, TILER_SCRIPT, check_params, resolve as resolve_arch
+from .arch import (ARCHS, EPS_A, EPS_B, TIE_ALL, TIE_FIRST, TILER_LIBRARY, TILER_SCRIPT, check_params, live_params,
+                   resolve as resolve_arch)
 
 
 def _torch():
@@ -221,12 +222,19 @@ class Network(object):
     like ``set_all_param_values`` does (examples/dsd100/separate_dsd.py:250).
     """
 
-    def __init__(self, ctx, arch, params, time_context=30, feat_size=513):
+    def __init__(self, ctx, arch, params, time_context=30, feat_size=513, live_only=True):
         self.ctx = ctx
         self.tc, self.F = int(time_context), int(feat_size)
         params = [np.asarray(p) for p in params]
-        self.arch = resolve_arch(arch, params, self.tc, self.F)     # 'ikala': pooled or trainer (no-pool) graph by fc.W
+        # 'ikala': pooled or trainer (no-pool) graph by fc.W; 'bach10_si': 17-array or single-branch 11-array graph by count
+        self.arch = resolve_arch(arch, params, self.tc, self.F)
         check_params(self.arch, params, self.tc, self.F)
+        self.graph_arch = self.arch                                  # the graph the .pkl belongs to
+        if live_only:
+            # the 17-array score-informed graph: three of its four decoder branches never reach predict_function2 -- they are
+            # neither uploaded nor allocated (3 x 171 MB of dense weights at 2049 bins); forward_raw then returns the four
+            # live channels.  live_only=False keeps the whole graph (what lasagne.layers.get_output would evaluate).
+            self.arch, params = live_params(self.arch, params)
         # weight tensors hosted by torch (float32, as the pickles store them)
         self._params = [ctx.to_device(p, np.float32) for p in params]
         n = len(self._params)
@@ -256,6 +264,18 @@ class Network(object):
         0 none, else bits 1 STFT, 2 conv1, 4 conv2, 8 bottleneck, 16 per-source dense, 32 transposed conv2, 64 final,
         128 iSTFT."""
         _lib.check(self.ctx._lib.dcs_model_set_latency_stages(self._h, int(stages)))
+
+    def set_score_semantics(self, normalise='max', mixture='ch0'):
+        """Score-informed graphs: ``normalise`` ``'max'`` (the separate script: every instrument's harmonic mask divided by
+        its own maximum, separate_bach10.py:195) or ``'sum'`` (the trainers' dataset class: by the sum over the instruments,
+        dataset.py:862); ``mixture`` ``'ch0'`` (script: soft masks x input channel 0, :485) or ``'sum'`` (trainers: x the sum
+        of the input channels, trainCNNrwc.py:258-263).  ``dcs_model_set_score_semantics``."""
+        try:
+            n, m = {'max': 0, 'sum': 1}[normalise], {'ch0': 0, 'sum': 1}[mixture]
+        except KeyError:
+            raise ValueError("normalise must be 'max' or 'sum', mixture 'ch0' or 'sum'")
+        _lib.check(self.ctx._lib.dcs_model_set_score_semantics(self._h, n, m))
+        self.score_normalise, self.score_mixture = normalise, mixture
 
     def set_conv_precision(self, dtype):
         """``'f16'``: conv2 and its transpose use f16-input / f32-accumulate MFMA (BASELINE config 3);

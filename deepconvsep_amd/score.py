@@ -184,10 +184,17 @@ def melody_table(instruments, FilePath, nframes, samplerate=44100, hop=512, wind
     return melody
 
 
-def score_masks(ctx, mag_t, notes, start, stop, want_input=True, want_mask=False):
+_NORMALISE = {'max': 0, 'sum': 1}
+
+
+def score_masks(ctx, mag_t, notes, start, stop, want_input=True, want_mask=False, normalise='max'):
     """Device ``filterSpec`` and the products of separate_bach10.py:523-527.  mag_t ``[T, F]`` float32 device tensor
     (already scaled); notes ``[ninst, P, W]``.  Returns (input ``[ninst, T, F]`` or None, mask ``[T, ninst*F]`` or
-    None), float32 device tensors."""
+    None), float32 device tensors.  ``normalise``: ``'max'`` -- every instrument's field divided by its own maximum (the
+    script, separate_bach10.py:195); ``'sum'`` -- bin by bin by the sum over the instruments (the trainers' dataset class,
+    ``LargeDatasetMask2.filterSpec``, dataset.py:839-879)."""
+    if normalise not in _NORMALISE:
+        raise ValueError("normalise must be 'max' or 'sum'")
     from .runtime import _ptr, _torch
     torch = _torch()
     if mag_t.dim() != 2 or mag_t.stride(1) != 1:
@@ -200,10 +207,11 @@ def score_masks(ctx, mag_t, notes, start, stop, want_input=True, want_mask=False
     with ctx.stream_scope():
         inp = torch.empty((ninst, T, F), dtype=torch.float32, device=mag_t.device) if want_input else None
         mask = torch.empty((T, ninst * F), dtype=torch.float32, device=mag_t.device) if want_mask else None
-        _lib.check(ctx._lib.dcs_score_masks(ctx._h, _ptr(mag_t), int(mag_t.stride(0)), T, F,
-                                            notes.ctypes.data_as(POINTER(c_double)), ninst, P, W, int(start), int(stop),
-                                            _ptr(inp) if inp is not None else None,
-                                            _ptr(mask) if mask is not None else None))
+        _lib.check(ctx._lib.dcs_score_masks_norm(ctx._h, _ptr(mag_t), int(mag_t.stride(0)), T, F,
+                                                 notes.ctypes.data_as(POINTER(c_double)), ninst, P, W, int(start), int(stop),
+                                                 _NORMALISE[normalise],
+                                                 _ptr(inp) if inp is not None else None,
+                                                 _ptr(mask) if mask is not None else None))
     return inp, mask
 
 
@@ -223,18 +231,22 @@ def load_timbre_model(path):
     return h
 
 
-def timbre_masks(shape, notes, ninst, start, stop, harmonics):
+def timbre_masks(shape, notes, ninst, start, stop, harmonics, normalise='max'):
     """The timbre-model branch of ``filterSpec`` (separate_bach10.py:189-191,195-196) on the host: a float32 field per
     instrument that starts at 1e-18, to which every harmonic band of every note sounding in ``[start, stop)`` ADDS the
     template weight ``harmonics[j, pitch, k]`` (float32 adds, notes in table order, harmonics in slot order: the sums are
     order-dependent in the last bit, so the order is the reference's), divided by its own maximum.  Bands of one note are
     not merged here -- overlapping bands add twice -- and the zero-width slots past the Nyquist bin add to nothing.
     A few thousand small slice updates: this branch is not on ``train_auto``'s path (it never passes a model), so it stays
-    NumPy; the binary branch is the device kernel ``dcs_score_masks``."""
+    NumPy; the binary branch is the device kernel ``dcs_score_masks``.  ``normalise='sum'``: the fields are divided by their
+    sum over the instruments instead (dataset.py:862; float32, instruments added in order)."""
+    if normalise not in _NORMALISE:
+        raise ValueError("normalise must be 'max' or 'sum'")
     T, F = int(shape[0]), int(shape[1])
     notes = np.asarray(notes, dtype=np.float64)
     weights = np.asarray(harmonics)
     mask = np.empty((T, ninst * F), dtype=np.float32)
+    fields = []
     for j in range(ninst):
         field = np.full((T, F), np.float32(1e-18), dtype=np.float32)
         tab = notes[j]
@@ -247,18 +259,29 @@ def timbre_masks(shape, notes, ninst, start, stop, harmonics):
             for k in range(len(lo)):
                 band = field[t0:t1, lo[k]:hi[k]]
                 np.add(band, w[k], out=band)
-        np.divide(field, field.max(), out=mask[:, j * F:(j + 1) * F])
+        if normalise == 'sum':
+            fields.append(field)
+        else:
+            np.divide(field, field.max(), out=mask[:, j * F:(j + 1) * F])
+    if normalise == 'sum':
+        total = fields[0].copy()
+        for field in fields[1:]:
+            np.add(total, field, out=total)
+        for j, field in enumerate(fields):
+            np.divide(field, total, out=mask[:, j * F:(j + 1) * F])
     return mask
 
 
-def filterSpec(mag, notes, ninst, start, stop, timbre_model_path=None, ctx=None):
+def filterSpec(mag, notes, ninst, start, stop, timbre_model_path=None, ctx=None, normalise='max'):
     """Drop-in ``filterSpec``: NumPy ``mag [T, F]`` in, float32 mask ``[T, ninst*F]`` out -- the binary harmonic masks on
-    the GPU (``dcs_score_masks``), or with ``timbre_model_path`` the template-weighted masks (:func:`timbre_masks`)."""
+    the GPU (``dcs_score_masks``), or with ``timbre_model_path`` the template-weighted masks (:func:`timbre_masks`).
+    ``normalise='sum'`` gives ``LargeDatasetMask2.filterSpec`` (dataset.py:839-879), the masks the trainers feed."""
     if timbre_model_path is not None:
         return timbre_masks(np.shape(mag), np.asarray(notes)[:ninst], ninst, int(start), int(stop),
-                            load_timbre_model(timbre_model_path))
+                            load_timbre_model(timbre_model_path), normalise=normalise)
     from .runtime import default_context
     ctx = ctx if ctx is not None else default_context()
     mag_t = ctx.to_device(np.asarray(mag), np.float32)
-    _, mask = score_masks(ctx, mag_t, np.asarray(notes)[:ninst], start, stop, want_input=False, want_mask=True)
+    _, mask = score_masks(ctx, mag_t, np.asarray(notes)[:ninst], start, stop, want_input=False, want_mask=True,
+                          normalise=normalise)
     return ctx.to_host(mask)

@@ -169,7 +169,7 @@ class Separator(object):
 
     def __init__(self, arch, params, scale_factor=0.3, time_context=30, overlap=25, batch_size=32, input_size=513,
                  frameSize=1024, hopSize=512, window=np.hanning, tiler='script', tie_mode=TIE_ALL, device=None,
-                 ctx=None):
+                 ctx=None, score_normalise='max', score_mixture='ch0'):
         self.arch_name = arch
         self.arch = ARCHS[arch]
         self.scale_factor, self.tc, self.overlap, self.batch_size = scale_factor, time_context, overlap, batch_size
@@ -182,6 +182,12 @@ class Separator(object):
         self.window = window(frameSize)
         self.plan = StftPlan(self.ctx, frameSize, hopSize, self.window)
         self.net = Network(self.ctx, arch, params, time_context, input_size)
+        # score-informed graphs: the separate script's semantics by default, the trainers' on request:
+        # score_normalise 'max' | 'sum' (separate_bach10.py:195 | dataset.py:862), score_mixture 'ch0' | 'sum'
+        # (separate_bach10.py:485 | trainCNNrwc.py:258-263)
+        self.score_normalise, self.score_mixture = score_normalise, score_mixture
+        if (score_normalise, score_mixture) != ('max', 'ch0'):
+            self.net.set_score_semantics(score_normalise, score_mixture)
 
     @_on_ctx_stream
     def separate(self, audio):
@@ -338,13 +344,13 @@ class Separator(object):
         T = int(mag.shape[0])
         mag = mag * np.float32(self.scale_factor)                       # :503
         if harmonics is None:
-            inp, _ = score_masks(self.ctx, mag, melody, 0, T)           # :520-527, [C, T, F]
+            inp, _ = score_masks(self.ctx, mag, melody, 0, T, normalise=self.score_normalise)   # :520-527, [C, T, F]
         else:
             # timbre-model masks (host) x spectrogram, float32 products as the script forms them (:523-527)
             mag_h = self.ctx.to_host(mag)
             C = int(np.asarray(melody).shape[0])
             F = int(mag_h.shape[1])
-            m = timbre_masks(mag_h.shape, melody, C, 0, T, harmonics)
+            m = timbre_masks(mag_h.shape, melody, C, 0, T, harmonics, normalise=self.score_normalise)
             inp = self.ctx.to_device(np.stack([m[:, j * F:(j + 1) * F] * mag_h for j in range(C)]), np.float32)
         tiles, n = tile(self.ctx, inp, self.tc, self.overlap, TILER_LIBRARY, 1.0)
         outs = []
@@ -383,15 +389,19 @@ def output_paths(arch_name, filein, outdir):
 
 
 def train_auto(arch_name, filein, outdir, model, scale_factor=0.3, time_context=30, overlap=20, batch_size=32,
-               input_size=513, frameSize=None, hopSize=None, window=None, fused=True, device=None):
-    """``train_auto`` of the separate scripts: wav in, one wav per source out."""
+               input_size=513, frameSize=None, hopSize=None, window=None, fused=True, device=None, score_normalise='max',
+               score_mixture='ch0'):
+    """``train_auto`` of the separate scripts: wav in, one wav per source out.  ``score_normalise`` / ``score_mixture``
+    (score-informed only): ``('sum', 'sum')`` = what the trainer's own separation block computes
+    (bach10_scoreinformed/trainCNNrwc.py:360-416), for models that trainer wrote; the default is the separate script's."""
     d_frame, d_hop, d_win, _, _ = _SCRIPT_DEFAULTS[arch_name]
     frameSize = d_frame if frameSize is None else frameSize
     hopSize = d_hop if hopSize is None else hopSize
     window = d_win if window is None else window
     params = load_model(model) if isinstance(model, str) else model
     sep = Separator(arch_name, params, scale_factor, time_context, overlap, batch_size, input_size, frameSize,
-                    hopSize, window, tiler='library' if arch_name == 'bach10_si' else 'script', device=device)
+                    hopSize, window, tiler='library' if arch_name == 'bach10_si' else 'script', device=device,
+                    score_normalise=score_normalise, score_mixture=score_mixture)
     sampleRate, audioObj = read_wav(filein)
     if sampleRate == 44100:
         audio = to_mono(audioObj, arch_name)

@@ -53,11 +53,22 @@ typedef enum {
 enum { DCS_ARCH_DSD = 0, DCS_ARCH_IKALA = 1, DCS_ARCH_BACH10 = 2, DCS_ARCH_BACH10_SI = 3,
        DCS_ARCH_DSD_ILD = 4 /* stereo DSD100 graph of examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115 */,
        DCS_ARCH_IKALA_NOPOOL = 5 /* the iKala TRAINER's graph (examples/ikala/trainCNN.py:87-118): as DCS_ARCH_IKALA without
-                                    the (1, 4) max-pool, fc.W has 30 * 21 * 143 = 90 090 rows at 513 bins */ };
+                                    the (1, 4) max-pool, fc.W has 30 * 21 * 143 = 90 090 rows at 513 bins */,
+       DCS_ARCH_BACH10_SI1 = 6 /* the single-branch score-informed graph (examples/bach10_scoreinformed/trainCNNrwc_samp.py:
+                                  195-235): 4 input channels, ONE per-source dense layer and pair of InverseLayers, 4 output
+                                  channels, 11 arrays -- also what predict_function2 of the 17-array DCS_ARCH_BACH10_SI graph
+                                  evaluates (its other three branches never reach the masks) */ };
 /* soft-mask epsilon convention: A = separate_dsd.py:258-266, B = separate_bach10.py:251-259 */
 enum { DCS_EPS_A = 0, DCS_EPS_B = 1 };
 /* max-pool gradient tie routing: ALL = Theano 0.9 CPU MaxPoolGrad, FIRST = cuDNN */
 enum { DCS_TIE_ALL = 0, DCS_TIE_FIRST = 1 };
+/* score-informed path, the two places where the separate script and the trainers differ:
+ * harmonic masks divided by each instrument's own maximum (script filterSpec, separate_bach10.py:195; dataset.py:781) or, bin by
+ * bin, by the sum over the instruments (LargeDatasetMask2.filterSpec, dataset.py:862 -- the class trainCNNrwc.py:657 trains on);
+ * soft masks applied to input channel 0 (script, separate_bach10.py:485) or to the sum of the input channels (trainers,
+ * trainCNNrwc.py:258-263, trainCNNrwc_samp.py:300-305). */
+enum { DCS_SCORE_NORM_MAX = 0, DCS_SCORE_NORM_SUM = 1 };
+enum { DCS_MIX_CH0 = 0, DCS_MIX_SUM = 1 };
 /* tiler: SCRIPT = separate_dsd.py:114-135 (drops the tail), LIBRARY = util.py:220-248 (zero pads) */
 enum { DCS_TILER_SCRIPT = 0, DCS_TILER_LIBRARY = 1 };
 
@@ -133,6 +144,11 @@ DCS_API int dcs_model_num_sources(const dcs_model* m);
  * bf16 pipe with three-way split operands (f32-class), the activations between them never rounded below f32.  The ikala
  * graph (10 x 20 filters) takes the same slab kernel in either precision (one f16 plane instead of three bf16 planes). */
 DCS_API int dcs_model_set_conv_precision(dcs_model* m, int f16);
+/* Score-informed graphs (DCS_ARCH_BACH10_SI / _SI1): which of the reference's two semantics dcs_separate_scoreinformed and
+ * dcs_model_forward_masked follow (the enums above).  Default = the separate script's: DCS_SCORE_NORM_MAX, DCS_MIX_CH0.
+ * A model trained by trainCNNrwc.py saw sum-normalised inputs and a channel-sum mixture: (DCS_SCORE_NORM_SUM, DCS_MIX_SUM).
+ * DCS_MIX_SUM adds the C input channels left to right in float32.  DCS_EUNSUPPORTED for single-channel graphs. */
+DCS_API int dcs_model_set_score_semantics(dcs_model* m, int normalise, int mixture);
 /* Which stages of dcs_separate run on the one-batch ("latency") kernels of csrc/dsd_lat.hip -- the shape of the
  * reference's own call, predict_function2 on ONE batch of 32 tiles (separate_dsd.py:296-298), where a kernel's duration
  * is its chain of dependent memory latencies.  stages = -1 (default): automatic, all of them for one clip of at most
@@ -178,7 +194,8 @@ DCS_API int dcs_separate(dcs_model* m, dcs_stft* plan, const float* audio_d, int
 
 /* The separation block of the score-informed script (examples/bach10_scoreinformed/separate_bach10.py:497-571) in one
  * call: STFT -> x scale -> filterSpec masks of the note table (notes_h exactly as for dcs_score_masks, frame window
- * (0, n_frames)) -> ninst-channel tiles of the library tiler -> network -> masks (applied to input channel 0) -> cross-fade
+ * (0, n_frames)) -> ninst-channel tiles of the library tiler -> network -> masks (applied to input channel 0, or to the channel
+ * sum after dcs_model_set_score_semantics; the same call selects the sum-normalised harmonic masks) -> cross-fade
  * -> / scale -> iSTFT.  The model must have ninst input channels.  pcm_d [S, n_samples] float32.  All tiles go through the
  * network in one pass (the script's batch loop gives the same values tile by tile).  Asynchronous (the note rectangles are
  * staged through the context's pinned upload ring; notes_h may be reused when the call returns). */
@@ -254,6 +271,14 @@ DCS_API int dcs_gather(dcs_ctx* ctx, void* nccl_comm, const void* shard_d, int64
  * a pinned staging ring owned by the context. */
 DCS_API int dcs_score_masks(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
                     int ninst, int n_notes, int width, int64_t start, int64_t stop, float* out_d, float* mask_d);
+
+/* The same with the normalisation of the masks chosen by the caller: DCS_SCORE_NORM_MAX = dcs_score_masks; DCS_SCORE_NORM_SUM =
+ * LargeDatasetMask2.filterSpec (dataset.py:839-879): mask_j = filtered_j / sum_i filtered_i, float32, instruments added in order
+ * -- a bin nobody plays is 1e-18 / (4 x 1e-18 added in turn) = 0.25 for four instruments, a bin k instruments play is 1 / k for
+ * them and 1e-18 / k for the others.  At most 32 instruments. */
+DCS_API int dcs_score_masks_norm(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
+                         int ninst, int n_notes, int width, int64_t start, int64_t stop, int normalise, float* out_d,
+                         float* mask_d);
 
 /* ------------------------------------------------------------------ timing aid for bench.py */
 /* Average duration (ms) of the kernels tagged `which` since the last reset, measured with HIP events

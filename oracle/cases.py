@@ -104,6 +104,7 @@ NET_CASES = [
     ("net_dsdild_f33_glorot", "dsd_ild", 33, 1, 41, "glorot"),
     ("net_ikalanp_f150_glorot", "ikala_nopool", 150, 1, 42, "glorot"),     # the iKala trainer's graph (no max-pool)
     ("net_ikalanp_f150_sparse", "ikala_nopool", 150, 1, 43, "sparse"),
+    ("net_bach10si1_f129_sparse", "bach10_si1", 129, 1, 44, "sparse"),     # the single-branch score-informed graph (11 arrays)
 ]
 
 
@@ -113,6 +114,7 @@ NET_CASES = [
 # to exact zeros) to positive, inputs from dense noise to few-level / silent rows (max-pool ties in the iKala graph).
 RANDOM_GRAPHS = (("dsd", 65), ("dsd", 129), ("ikala", 270), ("ikala", 303), ("bach10", 129), ("bach10_si", 129),
                  ("ikala_nopool", 150))
+# (appending a graph here would re-deal every seed: the single-branch score-informed graph has its own draws, tests/test_oracle_net.py)
 
 
 def random_draw(seed):

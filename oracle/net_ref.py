@@ -6,6 +6,7 @@ Graphs restated (all ``build_ca``):
   ikala (pool)   ``examples/ikala/separate_ikala.py:172-192``
   bach10         ``examples/bach10/separate_bach10.py:172-229``
   bach10_si      ``examples/bach10_scoreinformed/separate_bach10.py:388-447``
+  bach10_si1     ``examples/bach10_scoreinformed/trainCNNrwc_samp.py:195-235`` (the single-branch form: 11 arrays)
   dsd_ild        ``examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py:66-115`` (stereo input, one branch
                  per source, every branch returns both channels: output channel ``s*C + c``)
 Mask expressions: ``separate_dsd.py:258-271`` (convention A),
@@ -91,6 +92,10 @@ SPECS = {
                       [0, 1, 2, 3], 4, 'B'),
     'bach10_si': NetSpec('bach10_si', 4, (30, 30, 4), None, (30, lambda tc: int(2 * tc / 3), 1),
                          256, [0, 1, 2, 3], 4, 'B'),
+    # the single-branch score-informed graph of bach10_scoreinformed/trainCNNrwc_samp.py:195-235: one dense layer back, one
+    # pair of InverseLayers, 4 output channels = the only channels predict_function2 reads from the 17-array graph
+    'bach10_si1': NetSpec('bach10_si1', 4, (30, 30, 4), None, (30, lambda tc: int(2 * tc / 3), 1),
+                          256, [0], 4, 'B'),
     'dsd_ild': NetSpec('dsd_ild', 2, (50, 'F', 1), None, (50, lambda tc: int(tc / 2), 1), 256,
                        [0, 1, 2, 3], 4, 'ILD'),
 }
@@ -184,8 +189,12 @@ def forward(arch, params, x, tie_mode='all', inverse='autograd'):
     return torch.relu(y)
 
 
-def soft_mask(arch, p, x, eps_mode=None):
+def soft_mask(arch, p, x, eps_mode=None, mixture='ch0'):
     """Masked magnitudes, list of S tensors ``[B,1,tc,F]``.
+
+    ``mixture``: what the masks multiply -- ``'ch0'`` input channel 0 (every script; separate_bach10.py:485 for the
+    score-informed one), ``'sum'`` the sum of the input channels, left to right (the score-informed TRAINERS:
+    ``input_var = input_var2[:,0:1] + [:,1:2] + [:,2:3] + [:,3:4]``, trainCNNrwc.py:258-263, trainCNNrwc_samp.py:300-305).
 
     Convention A (separate_dsd.py:258-271): ``s_i = p_i + eps*r``,
     ``m_i = s_i / sum_j s_j``.  Convention B (separate_bach10.py:251-264):
@@ -197,6 +206,11 @@ def soft_mask(arch, p, x, eps_mode=None):
     mode = eps_mode or spec.eps_mode
     x = _t(x)
     mix = x[:, 0:1]
+    if mixture == 'sum':
+        for c in range(1, x.shape[1]):
+            mix = mix + x[:, c:c + 1]
+    elif mixture != 'ch0':
+        raise ValueError(mixture)
     r = EPS * RAND
     ch = [p[:, i:i + 1] for i in range(spec.S)]
     if mode == 'A':
@@ -214,12 +228,12 @@ def soft_mask(arch, p, x, eps_mode=None):
     raise ValueError(mode)
 
 
-def predict(arch, params, x, tie_mode='all', inverse='autograd', eps_mode=None):
+def predict(arch, params, x, tie_mode='all', inverse='autograd', eps_mode=None, mixture='ch0'):
     """``predict_function2`` of the reference: list of S float64 ndarrays
     ``[B,1,tc,F]`` (separate_dsd.py:273)."""
     with torch.no_grad() if inverse != 'autograd' else torch.enable_grad():
         p = forward(arch, params, x, tie_mode=tie_mode, inverse=inverse)
-        outs = soft_mask(arch, p.detach(), x, eps_mode=eps_mode)
+        outs = soft_mask(arch, p.detach(), x, eps_mode=eps_mode, mixture=mixture)
     return [o.detach().numpy() for o in outs]
 
 

@@ -48,12 +48,18 @@ def separate(arch, params, audio, scale_factor=0.3, time_context=30, overlap=25,
 
 
 def separate_scoreinformed(params, audio, melody, scale_factor=0.3, time_context=30, overlap=25, batch_size=32,
-                           frameSize=4096, hopSize=512, window=None, tie_mode='all', return_input=False, harmonics=None):
+                           frameSize=4096, hopSize=512, window=None, tie_mode='all', return_input=False, harmonics=None,
+                           normalise='max', mixture='ch0', arch='bach10_si'):
     """``examples/bach10_scoreinformed/separate_bach10.py:497-541``: the network input is one channel per instrument,
     ``filterSpec`` mask x scaled magnitudes (:520-527); tiles come from the LIBRARY tiler (:531, ``util.
     generate_overlapadd``, ``toverlap`` there is an undefined name -- the script's ``overlap`` is meant); the masks
     are built from the first four output channels and applied to input channel 0 (:473-486); ``overlapadd_multi``
-    and the iSTFT as in the other scripts."""
+    and the iSTFT as in the other scripts.
+
+    ``normalise='sum'`` / ``mixture='sum'``: the semantics of the TRAINERS' own separation block
+    (bach10_scoreinformed/trainCNNrwc.py:360-416): masks from ``LargeDatasetMask2.filterSpec`` (dataset.py:839-866, every
+    bin divided by the sum over the instruments) and the soft masks applied to the sum of the four input channels
+    (trainCNNrwc.py:258-263).  ``arch='bach10_si1'``: the single-branch graph of trainCNNrwc_samp.py:195-235 (11 arrays)."""
     from . import score_np
     if window is None:
         from scipy.signal.windows import blackmanharris as window
@@ -61,14 +67,14 @@ def separate_scoreinformed(params, audio, melody, scale_factor=0.3, time_context
     nframes = int(np.ceil(len(audio) / np.double(hopSize))) + 2
     mag, ph = stft_np.compute_file(audio, phase=True, frameSize=frameSize, hopSize=hopSize, window=window)
     mag = scale_factor * mag.astype(np.float32)
-    masks = score_np.network_input(mag, np.asarray(melody), nframes, harmonics)   # [C, T, F] float64 (harmonics: timbre model)
+    masks = score_np.network_input(mag, np.asarray(melody), nframes, harmonics, normalise=normalise)   # [C, T, F] float64 (harmonics: timbre model)
     batches, nchunks = tiling_np.generate_overlapadd(masks, masks.shape[-1], time_context, overlap, batch_size,
                                                      tiler=tiling_np.LIBRARY, fill=0.0)
     if nchunks == 0:
         raise IndexError("tuple index out of range")
     output = []
     for batch in batches:
-        output.append(net_ref.predict('bach10_si', params, batch, tie_mode=tie_mode))
+        output.append(net_ref.predict(arch, params, batch, tie_mode=tie_mode, mixture=mixture))
     output = np.array(output)
     mm = tiling_np.overlapadd_multi(output, nchunks, overlap=overlap)
     pcm = []

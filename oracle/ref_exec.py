@@ -38,6 +38,9 @@ _SLICES = {
     "lib_expandmidi": ("util.py", 424, 512),
     "lib_midinum": ("util.py", 526, 606),
     "script_si_filterspec": ("examples/bach10_scoreinformed/separate_bach10.py", 172, 200),
+    # the dataset class the score-informed trainers instantiate (trainCNNrwc.py:657): LargeDatasetMask2.filterSpec, a method
+    # (self.ninst, self.tensortype, self.timbre_model_path, self.harmonics) -- every bin divided by the sum over instruments
+    "lib_dataset_filterspec_sum": ("dataset.py", 839, 879),
 }
 
 
@@ -103,6 +106,26 @@ def score():
     return ns
 
 
+def dataset_filterspec_sum(tensortype=np.float32, harmonics=None):
+    """``LargeDatasetMask2.filterSpec`` (dataset.py:839-879), the body of the method executed as it stands with a stand-in
+    ``self`` that carries the four attributes it reads: ``f(mag, notes, start, stop) -> mask [T, ninst*F]``.  The trainers
+    build the class with ``tensortype=theano.config.floatX`` (trainCNNrwc.py:657-658): float32."""
+    import textwrap
+    import types
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    relpath, first, last = _SLICES["lib_dataset_filterspec_sum"]
+    ns = _NS(np=np, __name__="ref_exec.dataset")
+    exec(compile("\n" * (first - 1) + textwrap.dedent(_slice(relpath, first, last)), relpath, "exec"), ns)
+    fn = ns["filterSpec"]
+
+    def run(mag, notes, start, stop):
+        me = types.SimpleNamespace(tensortype=tensortype, timbre_model_path=None if harmonics is None else "model",
+                                   harmonics=harmonics)
+        return fn(me, mag, notes, start, stop)
+    return run
+
+
 def script_dsd():
     return load("script_dsd")
 
@@ -131,6 +154,8 @@ _NET_FILES = {
     "ikala_nopool": "examples/ikala/trainCNN.py",                      # the trainer's graph: no MaxPool2DLayer
     "bach10": "examples/bach10/separate_bach10.py",
     "bach10_si": "examples/bach10_scoreinformed/separate_bach10.py",
+    "bach10_si1": "examples/bach10_scoreinformed/trainCNNrwc_samp.py",   # a trainer: the single-branch build_ca (:195-235)
+    "bach10_si_trainer": "examples/bach10_scoreinformed/trainCNNrwc.py", # a trainer: the 17-array graph, masks x channel SUM
     "dsd_ild": "examples/dsd100_2ch_ILD/trainCNN_ILD_DSD100.py",     # a trainer: build_ca only, returns a dict of layers
 }
 
@@ -162,7 +187,7 @@ def build_network(arch, x, time_context=None, **extra):
     ns = dict(np=np, lasagne=lasagne_np, __name__="ref_exec.net." + arch)
     exec(compile("\n" * (first - 1) + src, _NET_FILES[arch], "exec"), ns)
     kw = dict(input_var=x, batch_size=B, time_context=tc, feat_size=F)
-    if arch in ("bach10_si", "dsd_ild"):
+    if arch in ("bach10_si", "bach10_si1", "bach10_si_trainer", "dsd_ild"):
         kw["nchannels"] = C
     kw.update(extra)
     net = ns["build_ca"](**kw)
@@ -200,7 +225,10 @@ def mask_sources(arch, prediction2, x, rand=0.5):
     fn = next(i for i in range(t0, len(lines)) if "predict_function2" in lines[i] and "theano.function" in lines[i])
     draw = max(i for i in range(t0, fn) if "rand_num = np.random.uniform" in lines[i])
     eps_line = next(l for l in lines[t0:fn] if re.match(r"\s*eps\s*=", l))
-    body = textwrap.dedent("".join(lines[draw + 1:fn]))
+    # a trainer's train_auto goes on with the losses and the update rules (lasagne.objectives / theano.function) before it
+    # reaches predict_function2: the mask expressions end where the first of those begins
+    stop = next((i for i in range(draw + 1, fn) if "lasagne." in lines[i] or "theano." in lines[i]), fn)
+    body = textwrap.dedent("".join(lines[draw + 1:stop]))
     names = re.search(r"\[input_var2\]\s*,\s*\[([^\]]*)\]", lines[fn]).group(1).split(",")
     x = np.asarray(x, dtype=np.float64)
     ns = dict(np=np, prediction2=np.asarray(prediction2, dtype=np.float64), input_var2=x,

@@ -197,8 +197,11 @@ def expandMidi(path, beginTime, finishTime, interval, tuning_freq, nharmonics, s
     return intervals
 
 
-def filterSpec(mag, notes, ninst, start, stop, harmonics=None):  # separate_bach10.py:172-200
-    """``harmonics`` None: the binary masks of ``timbre_model_path=None``.  Otherwise the timbre branch (:173-175,189-191)
+def filterSpec(mag, notes, ninst, start, stop, harmonics=None, normalise='max'):  # separate_bach10.py:172-200
+    """``normalise``: ``'max'`` divides every instrument's field by its own maximum (the script, separate_bach10.py:195, and
+    dataset.py:781 ``LargeDatasetMask``); ``'sum'`` divides by the sum over the instruments, bin by bin (the class the
+    score-informed trainers use: ``LargeDatasetMask2.filterSpec``, dataset.py:839-866, ``filtered[j] / np.sum(filtered,
+    axis=0)`` -- float32, instruments added in order).  ``harmonics`` None: the binary masks of ``timbre_model_path=None``.  Otherwise the timbre branch (:173-175,189-191)
     with ``harmonics [ninst, midi pitch, nharmonics]`` = the unpickled model: every harmonic band of every active note ADDS
     the instrument's template weight of that pitch and harmonic (in note, then harmonic order; float32 adds -- under the
     reference's NumPy a float64 scalar met a float32 array as float32, which is what a float32 model gives under any NumPy),
@@ -220,6 +223,13 @@ def filterSpec(mag, notes, ninst, start, stop, harmonics=None):  # separate_bach
                     for k in range(len(starts)):
                         filtered[j, begin:end, int(starts[k]):int(stops[k])] += np.float32(harmonics[j, int(midi), k])
     mask = np.zeros((T, ninst * F), dtype=np.float32)
+    if normalise == 'sum':
+        total = np.sum(filtered, axis=0)                      # float32, ((f0 + f1) + f2) + ...
+        for j in range(ninst):
+            mask[:, j * F:(j + 1) * F] = filtered[j] / total
+        return mask
+    if normalise != 'max':
+        raise ValueError(normalise)
     for j in range(ninst):
         mask[:, j * F:(j + 1) * F] = filtered[j] / np.max(filtered[j])
     return mask
@@ -238,11 +248,12 @@ def melody_table(score_paths, nframes, samplerate=44100, hop=512, window=4096, i
     return melody
 
 
-def network_input(mag, melody, nframes, harmonics=None):
-    """separate_bach10.py:520-527: [ninst, T, F] float64 = mask_j * mag (float32 product stored in float64)."""
+def network_input(mag, melody, nframes, harmonics=None, normalise='max'):
+    """separate_bach10.py:520-527 (trainCNNrwc.py:388-396 with ``normalise='sum'``): [ninst, T, F] float64 = mask_j * mag
+    (float32 product stored in float64)."""
     ninst = melody.shape[0]
     jump = mag.shape[-1]
-    masks_temp = filterSpec(mag, melody, ninst, 0, nframes, harmonics)
+    masks_temp = filterSpec(mag, melody, ninst, 0, nframes, harmonics, normalise=normalise)
     masks = np.ones((ninst, mag.shape[0], mag.shape[1]))
     for j in range(ninst):
         masks[j] = masks_temp[:, j * jump:(j + 1) * jump] * mag

@@ -185,12 +185,38 @@ def score_timbre():
     print("score_timbre_n1024_hop512", mask.shape, "distinct values", len(np.unique(mask)))
 
 
-def networks():
+def score_sum():
+    """The TRAINERS' harmonic masks: ``LargeDatasetMask2.filterSpec`` (dataset.py:839-879, every bin divided by the sum over
+    the instruments), the class bach10_scoreinformed/trainCNNrwc.py:657 instantiates with ``tensortype=floatX`` -- its method
+    body executed as it stands on the note tables and magnitudes of the committed score fixtures (binary branch), and on the
+    timbre fixture's templates (timbre branch)."""
+    for base in ("score_n1024_hop512", "score_n4096_hop512"):
+        g = np.load(os.path.join(HERE, base + ".npz"))
+        nframes, N, seed = int(g["nframes"]), int(g["frame"]), int(g["mag_seed"])
+        F = N // 2 + 1
+        mag = (0.3 * np.abs(np.random.RandomState(seed).randn(nframes, F)).astype(np.float32)).astype(np.float32)
+        f = ref_exec.dataset_filterspec_sum()
+        mask = f(mag, g["melody"], 0, nframes)
+        melody2 = g["melody"].copy()
+        melody2[2] = 0                                               # an instrument without notes
+        mask_win = ref_exec.dataset_filterspec_sum()(mag[40:140], melody2, 40, 140)
+        assert mask.dtype == np.float32 and mask.shape == (nframes, 4 * F)
+        d = dict(base=base, mask=mask, mask_win=mask_win, values=np.unique(mask))
+        if base == "score_n1024_hop512":
+            t = np.load(os.path.join(HERE, "score_timbre_n1024_hop512.npz"))
+            d["mask_timbre"] = ref_exec.dataset_filterspec_sum(harmonics=t["harmonics"])(mag, t["melody"], 0, nframes)
+        np.savez_compressed(os.path.join(HERE, base.replace("score_", "score_sum_") + ".npz"), **d)
+        print(base, "sum-normalised", mask.shape, "values", np.unique(mask))
+
+
+def networks(only=None):
     """Network fixtures: the reference's OWN ``build_ca`` source and mask expressions executed on the NumPy Lasagne
     stand-in (oracle/lasagne_np.py) -- graph wiring, filter sizes, parameter order and mask arithmetic come from the
     reference's code; the layer semantics are restated Lasagne / Theano behaviour (PARITY of those stays unpinned)."""
     from oracle import cases
     for name, arch, F, B, seed, kind in cases.NET_CASES:
+        if only and name not in only:
+            continue
         x = cases.make_input(arch, B, 30, F, seed + 500)
         params = cases.calibrate(arch, 30, F, seed, kind, x)
         shapes = ref_exec.network_param_shapes(arch, B, x.shape[1], 30, F)
@@ -204,15 +230,25 @@ def networks():
             # the masks of the separate script (separate_ikala.py:211-216, eps 1e-18): the drop-in surface is that script fed
             # a .pkl the trainer wrote; the trainer's own block uses its training epsilon 1e-8 (ikala/trainCNN.py:155)
             d["masked"] = np.stack(ref_exec.mask_sources("ikala", p, x))
+        elif arch == "bach10_si1":
+            # a trainer's graph (trainCNNrwc_samp.py): its own mask expressions multiply the SUM of the input channels
+            # (:300-305); the separate script fed this .pkl multiplies channel 0 (separate_bach10.py:485)
+            d["masked_sum"] = np.stack(ref_exec.mask_sources("bach10_si1", p, x))
+            d["masked"] = np.stack(ref_exec.mask_sources("bach10_si", p, x))
         elif arch != "dsd_ild":
             d["masked"] = np.stack(ref_exec.mask_sources(arch, p, x))
+        if arch == "bach10_si":
+            d["masked_sum"] = np.stack(ref_exec.mask_sources("bach10_si_trainer", p, x))   # trainCNNrwc.py:253-263
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         print(name, p.shape, "zeros %.3f" % d["zero_fraction"], "max %.3f" % p.max())
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "networks":
-        networks()
+        networks(only=sys.argv[2:] or None)
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "score_sum":
+        score_sum()
         raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "score_timbre":
         score_timbre()

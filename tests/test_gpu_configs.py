@@ -218,6 +218,17 @@ def test_scoreinformed_batch_of_128_tiles_matches_oracle(tmp_path):
     # the reference's batch of 32 (predict_function2 is called per batch) gives the same result
     sep32 = dcs.Separator("bach10_si", params, 0.3, 30, 25, 32, F, N, 512, dcs.blackmanharris, tiler='library')
     assert np.max(np.abs(sep32.separate_scoreinformed(audio, melody) - got)) < 2e-6
+    # the TRAINERS' semantics at the same size (masks / sum over instruments, soft masks x channel sum) and the
+    # single-branch .pkl layout of trainCNNrwc_samp.py (the live part of the 17 arrays): 1e-4 against the oracle
+    from deepconvsep_amd.arch import ARCHS, live_params
+    _, params11 = live_params(ARCHS["bach10_si"], params)
+    sep_t = dcs.Separator("bach10_si", params11, 0.3, 30, 25, 128, F, N, 512, dcs.blackmanharris, tiler='library',
+                          score_normalise='sum', score_mixture='sum')
+    assert sep_t.net.arch.name == "bach10_si1"
+    got_t = sep_t.separate_scoreinformed(audio, melody)
+    want_t = pipeline.separate_scoreinformed(params11, audio, melody, 0.3, 30, 25, 32, N, 512, dcs.blackmanharris,
+                                             normalise='sum', mixture='sum', arch='bach10_si1')
+    assert np.max(np.abs(got_t - want_t)) < 1e-4 and np.max(np.abs(want_t - want)) > 1e-3
 
 
 # ------------------------------------------------------------------------------------------------ streams

@@ -337,7 +337,7 @@ def test_generic_graphs_match_oracle(arch, F, n):
     params = synth_params(arch, tc, F, seed=3)
     x = _tiles(arch, n, tc, F, seed=12)
     ctx = default_context()
-    net = Network(ctx, arch, params, tc, F)
+    net = Network(ctx, arch, params, tc, F, live_only=False)      # the whole graph (all 16 channels of the score-informed one)
     xd = ctx.to_device(x, np.float32)
     p = net.forward_raw(xd).cpu().numpy()
     want = net_ref.forward(arch, params, x.astype(np.float64), inverse='explicit').numpy()
@@ -1206,6 +1206,114 @@ def test_score_masks_match_the_reference_filterSpec(golden, name, tmp_path):
     bad[0, 0, 4] = N // 2 + 5                                        # bin range past the spectrum: IndexError in NumPy
     with pytest.raises(ValueError):
         score.score_masks(ctx, mag_t, bad, 0, nframes)
+
+
+@pytest.mark.parametrize("name", ["score_n1024_hop512", "score_n4096_hop512"])
+def test_sum_normalised_score_masks_match_the_trainers_dataset_class(golden, name):
+    """dcs_score_masks_norm(DCS_SCORE_NORM_SUM) against the masks the reference's LargeDatasetMask2.filterSpec body produced
+    (dataset.py:839-879; tests/golden/score_sum_*.npz): every bin divided by the float32 sum over the instruments -- bit exact,
+    with either output alone (the flags of the first two passes live in whichever buffer is written), a frame window that
+    does not start at 0 with a silent instrument, and the products mask x spectrogram against the oracle."""
+    from deepconvsep_amd import score
+    from oracle import score_np
+    g, gs = golden(name), golden(name.replace("score_", "score_sum_"))
+    N, nframes = int(g["frame"]), int(g["nframes"])
+    F = N // 2 + 1
+    mag = (0.3 * np.abs(np.random.RandomState(int(g["mag_seed"])).randn(nframes, F)).astype(np.float32)).astype(np.float32)
+    ctx = default_context()
+    mag_t = ctx.to_device(mag, np.float32)
+    inp, mask = score.score_masks(ctx, mag_t, g["melody"], 0, nframes, want_input=True, want_mask=True, normalise='sum')
+    assert np.array_equal(mask.cpu().numpy(), gs["mask"])
+    want = score_np.network_input(mag, g["melody"], nframes, normalise='sum')
+    assert np.array_equal(inp.cpu().numpy().astype(np.float64), want)
+    _, only_mask = score.score_masks(ctx, mag_t, g["melody"], 0, nframes, want_input=False, want_mask=True, normalise='sum')
+    assert np.array_equal(only_mask.cpu().numpy(), gs["mask"])
+    only_inp, _ = score.score_masks(ctx, mag_t, g["melody"], 0, nframes, want_input=True, want_mask=False, normalise='sum')
+    assert np.array_equal(only_inp.cpu().numpy(), inp.cpu().numpy())
+    melody2 = g["melody"].copy()
+    melody2[2] = 0
+    got = score.filterSpec(mag[40:140], melody2, 4, 40, 140, normalise='sum')
+    assert got.dtype == np.float32 and np.array_equal(got, gs["mask_win"])
+    # the default is still the script's normalisation, and an unknown one is refused
+    _, mx = score.score_masks(ctx, mag_t, g["melody"], 0, nframes, want_input=False, want_mask=True)
+    assert int((mx.cpu().numpy() == 1).sum()) == int(g["mask_ones"])
+    with pytest.raises(ValueError):
+        score.score_masks(ctx, mag_t, g["melody"], 0, nframes, normalise='mean')
+
+
+@pytest.mark.parametrize("normalise,mixture", [("sum", "sum"), ("sum", "ch0"), ("max", "sum")])
+def test_scoreinformed_separation_with_the_trainers_semantics(normalise, mixture, tmp_path):
+    """the whole score-informed path with the harmonic masks divided by their sum over the instruments
+    (dataset.py:862) and / or the soft masks applied to the sum of the input channels (trainCNNrwc.py:258-263), one fused call
+    and the stage-level composition, against oracle.pipeline.separate_scoreinformed with the same switches -- and the four
+    combinations really are four different functions."""
+    from deepconvsep_amd import score
+    from oracle import score_np
+    N, seconds = 1024, 3.0
+    F, L = N // 2 + 1, int(seconds * 44100)
+    audio = synth_audio(L, seed=91)
+    for i, ins in enumerate(SI_INSTS):
+        score_np.synth_score(str(tmp_path / (ins + ".txt")), 700 + i, n_notes=16, total=seconds + 0.5, lo=40 + 5 * i,
+                             hi=64 + 6 * i)
+    nframes = int(np.ceil(L / 512.0)) + 2
+    melody = score.melody_table([i + ".txt" for i in SI_INSTS], str(tmp_path), nframes, 44100, 512, N)
+    params = synth_params("bach10_si", 30, F, seed=5)
+    sep = dcs.Separator("bach10_si", params, 0.3, 30, 25, 32, F, N, 512, np.hanning, tiler='library',
+                        score_normalise=normalise, score_mixture=mixture)
+    got = sep.separate_scoreinformed(audio, melody)
+    want = pipeline.separate_scoreinformed(params, audio, melody, 0.3, 30, 25, 32, N, 512, np.hanning,
+                                           normalise=normalise, mixture=mixture)
+    assert got.shape == want.shape == (4, L) and np.max(np.abs(got - want)) < 1e-4
+    a = sep.ctx.to_device(audio, np.float32)
+    staged = sep.ctx.to_host(sep.separate_scoreinformed_device(a, melody, staged=True)).astype(np.float64)
+    assert np.max(np.abs(staged - want)) < 1e-4 and np.max(np.abs(staged - got)) < 2e-5
+    script = pipeline.separate_scoreinformed(params, audio, melody, 0.3, 30, 25, 32, N, 512, np.hanning)
+    assert np.max(np.abs(want - script)) > 1e-3
+    # the switch is model state: back to the script's semantics on the same handle
+    sep.net.set_score_semantics('max', 'ch0')
+    sep.score_normalise = 'max'
+    assert np.max(np.abs(sep.separate_scoreinformed(audio, melody) - script)) < 1e-4
+    with pytest.raises(ValueError):
+        sep.net.set_score_semantics('sum', 'all')
+    with pytest.raises(NotImplementedError):
+        dcs.Separator("bach10", synth_params("bach10", 30, F, seed=5), 0.3, 30, 25, 32, F, N, 512, np.hanning,
+                      score_mixture='sum')
+
+
+def test_single_branch_score_informed_model_and_pruned_17_array_model():
+    """The 11-array .pkl of trainCNNrwc_samp.py:195-235 loads through the same 'bach10_si' entry (arch.resolve), and a
+    17-array .pkl is instantiated as its live part only (arch.live_params: branch 0; three dense layers never uploaded):
+    network output and masked sources, script and trainer mixtures, against the float64 oracle; live_only=False keeps all
+    16 channels and its first four agree with the pruned model to fp32 rounding."""
+    tc, F, n = 30, 257, 3
+    params17 = synth_params("bach10_si", tc, F, seed=3)
+    params11 = synth_params("bach10_si1", tc, F, seed=4)
+    x = _tiles("bach10_si", n, tc, F, seed=12)
+    ctx = default_context()
+    xd = ctx.to_device(x, np.float32)
+    one = Network(ctx, "bach10_si", params11, tc, F)
+    assert one.arch.name == "bach10_si1" and one.out_channels == 4 and one.S == 4
+    p = one.forward_raw(xd).cpu().numpy()
+    want = net_ref.forward("bach10_si1", params11, x.astype(np.float64), inverse='explicit').numpy()
+    assert p.shape == want.shape == (n, 4, tc, F) and np.max(np.abs(p - want)) < 1e-4
+    for mixture in ("ch0", "sum"):
+        one.set_score_semantics('max', mixture)
+        got = one.forward_masked(xd).cpu().numpy()
+        ref = net_ref.predict("bach10_si1", params11, x.astype(np.float64), inverse='explicit', mixture=mixture)
+        mix = x[:, 0].astype(np.float64) if mixture == "ch0" else x.astype(np.float64).sum(axis=1)
+        _assert_masked(got, ref, want, mix, 4, p_got=p, conv='B', label="bach10_si1 %s" % mixture)
+    pruned = Network(ctx, "bach10_si", params17, tc, F)
+    assert pruned.graph_arch.name == "bach10_si" and pruned.arch.name == "bach10_si1" and pruned.out_channels == 4
+    full = Network(ctx, "bach10_si", params17, tc, F, live_only=False)
+    assert full.arch.name == "bach10_si" and full.out_channels == 16
+    pf = full.forward_raw(xd).cpu().numpy()
+    pp = pruned.forward_raw(xd).cpu().numpy()
+    w17 = net_ref.forward("bach10_si", params17, x.astype(np.float64), inverse='explicit').numpy()
+    assert np.max(np.abs(pf - w17)) < 1e-4 and np.max(np.abs(pp - w17[:, :4])) < 1e-4
+    assert np.max(np.abs(pp - pf[:, :4])) < 2e-6 * max(1.0, float(np.max(np.abs(w17))))
+    assert np.max(np.abs(pruned.forward_masked(xd).cpu().numpy() - full.forward_masked(xd).cpu().numpy())) < 2e-6
+    with pytest.raises(ValueError):
+        Network(ctx, "bach10_si", params17[:12], tc, F)               # neither layout: set_all_param_values would raise
 
 
 @pytest.mark.parametrize("N,seconds", [(1024, 3.0), (4096, 2.0)])

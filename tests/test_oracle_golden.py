@@ -68,6 +68,62 @@ def test_overlapadd_matches_reference_bitwise(golden, name):
         assert np.array_equal(tiling_np.overlapadd_frame_parallel(tiles[s], ov), g["sep"][s])
 
 
+@pytest.mark.parametrize("name", ["score_n1024_hop512", "score_n4096_hop512"])
+def test_sum_normalised_masks_match_the_trainers_dataset_class(golden, name, tmp_path):
+    """the score-informed TRAINERS feed masks divided by the sum over the instruments
+    (LargeDatasetMask2.filterSpec, dataset.py:839-879 -- fixtures made by that method body, make_golden.py score_sum): the
+    oracle's restatement and the product's host implementation (timbre branch; the binary branch is the device kernel,
+    tests/test_gpu_parity.py) reproduce them bit for bit, and they differ from the script's max-normalised masks."""
+    from oracle import score_np
+    from deepconvsep_amd import score
+    g, gs = golden(name), golden(name.replace("score_", "score_sum_"))
+    nframes, F = int(g["nframes"]), int(g["frame"]) // 2 + 1
+    mag = (0.3 * np.abs(np.random.RandomState(int(g["mag_seed"])).randn(nframes, F)).astype(np.float32)).astype(np.float32)
+    mask = score_np.filterSpec(mag, g["melody"], 4, 0, nframes, normalise='sum')
+    assert mask.dtype == np.float32 and np.array_equal(mask, gs["mask"])
+    # the values a four-instrument score can produce: 1 / k and 1e-18 / k for k playing instruments, 1e-18 / (4 x 1e-18) = 0.25
+    assert set(np.unique(mask).tolist()) <= set(np.float32(v) for v in gs["values"].tolist())
+    cols = mask.reshape(nframes, 4, F).astype(np.float64).sum(axis=1)
+    assert np.max(np.abs(cols - 1.0)) < 1e-6                          # the masks of a bin sum to one: what "sum" buys
+    melody2 = g["melody"].copy()
+    melody2[2] = 0
+    assert np.array_equal(score_np.filterSpec(mag[40:140], melody2, 4, 40, 140, normalise='sum'), gs["mask_win"])
+    assert not np.array_equal(mask, score_np.filterSpec(mag, g["melody"], 4, 0, nframes))
+    if "mask_timbre" in gs.files:
+        t = golden("score_timbre_n1024_hop512")
+        assert np.array_equal(score_np.filterSpec(mag, t["melody"], 4, 0, nframes, t["harmonics"], normalise='sum'), gs["mask_timbre"])
+        import pickle
+        model = tmp_path / "timbre.pkl"
+        with open(str(model), "wb") as fh:
+            pickle.dump(t["harmonics"], fh, protocol=2)
+        got = score.filterSpec(mag, t["melody"], 4, 0, nframes, timbre_model_path=str(model), normalise='sum')
+        assert got.dtype == np.float32 and np.array_equal(got, gs["mask_timbre"])
+
+
+@pytest.mark.skipif(not ref_exec.available(), reason="reference tree only exists in the build container")
+def test_live_trainer_filterspec_agrees_on_fresh_scores():
+    """The reference's LargeDatasetMask2.filterSpec executed now against the restatement: seeded rectangles that overlap
+    within and across instruments, windows that do not start at frame 0, an instrument without notes."""
+    from oracle import score_np
+    f = ref_exec.dataset_filterspec_sum()
+    for seed in range(6):
+        rs = np.random.RandomState(700 + seed)
+        T, F, ninst = int(rs.randint(40, 90)), int(rs.randint(60, 300)), int(rs.randint(2, 6))
+        mag = rs.rand(T, F).astype(np.float32)
+        notes = np.zeros((ninst, 6, 43))
+        for j in range(ninst):
+            for p in range(0 if j == ninst - 1 and seed % 2 else int(rs.randint(1, 6))):
+                b = int(rs.randint(0, T + 20))
+                notes[j, p, :3] = (b, b + int(rs.randint(1, 30)), 40 + p)
+                for k in range(int(rs.randint(1, 12))):
+                    f0 = int(rs.randint(0, F - 16))
+                    notes[j, p, 3 + 2 * k], notes[j, p, 4 + 2 * k] = f0, f0 + int(rs.randint(1, 16))
+        start = int(rs.randint(0, 10))
+        want = f(mag[start:], notes, start, T)
+        got = score_np.filterSpec(mag[start:], notes, ninst, start, T, normalise='sum')
+        assert want.dtype == got.dtype == np.float32 and np.array_equal(want, got)
+
+
 @pytest.mark.skipif(not ref_exec.available(), reason="reference tree only exists in the build container")
 def test_live_reference_agrees_on_fresh_input():
     rs = np.random.RandomState(99)

@@ -178,12 +178,17 @@ def test_net_ref_matches_the_reference_graph_fixtures(golden, name):
         assert len(m) == g["masked"].shape[0]
         for a, b in zip(m, g["masked"]):
             assert np.max(np.abs(a - b)) < 1e-12
+    if "masked_sum" in g.files:      # the score-informed TRAINERS' mask expressions: x the sum of the input channels
+        m = net_ref.predict(arch, params, x, inverse='explicit', mixture='sum')
+        for a, b in zip(m, g["masked_sum"]):
+            assert np.max(np.abs(a - b)) < 1e-12
+        assert np.max(np.abs(g["masked_sum"] - g["masked"])) > 1e-3      # the two semantics are different functions
 
 
 @pytest.mark.skipif(not ref_exec.available(), reason="needs /root/reference (build container only)")
 @pytest.mark.parametrize("arch,C,F", [("dsd", 1, 513), ("dsd", 1, 1025), ("hiphop", 1, 513), ("ikala", 1, 513),
                                       ("ikala", 1, 1025), ("ikala_nopool", 1, 513), ("bach10", 1, 2049), ("bach10_si", 4, 2049),
-                                      ("dsd_ild", 2, 513)])
+                                      ("bach10_si1", 4, 2049), ("dsd_ild", 2, 513)])
 def test_parameter_order_comes_from_the_reference_graph(arch, C, F):
     """``get_all_params`` of the reference's own build_ca at the real sizes == the shape list the HIP model checks
     (deepconvsep_amd.arch) and the one the torch oracle uses -- count, order and shapes (13 / 15 / 17 arrays)."""
@@ -203,6 +208,52 @@ def test_fixtures_regenerate_bit_for_bit(golden, name):
     x = g["x"]
     fresh = cases.calibrate(arch, 30, int(g["F"]), int(g["seed"]), str(g["kind"]), x)
     assert np.array_equal(fresh[-1], g["out_bias"])
+
+
+def test_single_branch_score_informed_graph_is_the_live_part_of_the_17_array_graph():
+    """trainCNNrwc_samp.py:195-235 (11 arrays) against separate_bach10.py:388-447 (17 arrays): with the first ten arrays and
+    the first four output biases shared, the single-branch graph's four channels ARE channels 0..3 of the big graph -- the
+    only ones predict_function2 reads (:475-488).  `arch.live_params` makes that cut; `arch.resolve` tells the two .pkl
+    layouts apart by their length."""
+    from deepconvsep_amd.arch import live_params, resolve
+    tc, F = 30, 129
+    params = synth_params("bach10_si", tc, F, seed=8)
+    a1, live = live_params(ARCHS["bach10_si"], params)
+    assert a1.name == "bach10_si1" and len(live) == 11 and live[-1].shape == (4,)
+    check_params(a1, live, tc, F)
+    assert [tuple(p.shape) for p in live] == [tuple(s_) for s_ in net_ref.SPECS["bach10_si1"].param_shapes(tc, F)]
+    assert resolve("bach10_si", live, tc, F).name == "bach10_si1" and resolve("bach10_si", params, tc, F).name == "bach10_si"
+    assert live_params(ARCHS["bach10"], synth_params("bach10", tc, F, seed=8))[0].name == "bach10"     # nothing to cut elsewhere
+    x = _input("bach10_si", 2, tc, F)
+    big = net_ref.forward("bach10_si", params, x, inverse='explicit').numpy()
+    one = net_ref.forward("bach10_si1", live, x, inverse='explicit').numpy()
+    assert one.shape == (2, 4, tc, F) and np.array_equal(one, big[:, :4])
+    for mixture in ("ch0", "sum"):
+        for a, b in zip(net_ref.predict("bach10_si", params, x, inverse='explicit', mixture=mixture),
+                        net_ref.predict("bach10_si1", live, x, inverse='explicit', mixture=mixture)):
+            assert np.array_equal(a, b)
+    assert ARCHS["bach10_si1"].flops_per_tile(tc, F) == ARCHS["bach10_si"].flops_per_tile(tc, F, live_only=True)
+
+
+@pytest.mark.skipif(not ref_exec.available(), reason="needs /root/reference (build container only)")
+@pytest.mark.parametrize("seed", range(4))
+def test_single_branch_graph_and_trainer_masks_equal_the_executed_reference(seed):
+    """Seeded draws of the single-branch graph: the reference's own build_ca of trainCNNrwc_samp.py and the TRAINERS' mask
+    lines (trainCNNrwc_samp.py:288-305, trainCNNrwc.py:246-263: masks x channel sum) executed, against net_ref."""
+    rs = np.random.RandomState(500 + seed)
+    tc, F, B = 30, 129, int(rs.randint(1, 3))
+    params = synth_params("bach10_si1", tc, F, seed=int(rs.randint(1 << 30)), gain=float(rs.uniform(0.6, 2.0)))
+    x = (0.3 * rs.uniform(0, 3, (B, 4, tc, F)) * (rs.uniform(size=(B, 4, tc, F)) < 0.6)).astype(np.float32)
+    y = cases.pre_bias_output("bach10_si1", params, x)
+    params[-1] = np.array([-np.quantile(y[:, c], 0.7) for c in range(4)], dtype=np.float32)
+    p_ref = ref_exec.network_output("bach10_si1", params, x)
+    p = net_ref.forward("bach10_si1", params, x.astype(np.float64), inverse='explicit').numpy()
+    assert p.shape == p_ref.shape == (B, 4, tc, F) and np.max(np.abs(p - p_ref)) < 1e-11
+    for which, mixture in (("bach10_si1", "sum"), ("bach10_si_trainer", "sum"), ("bach10_si", "ch0")):
+        m_ref = ref_exec.mask_sources(which, p_ref, x)
+        m = net_ref.predict("bach10_si1", params, x.astype(np.float64), inverse='explicit', mixture=mixture)
+        for a, b in zip(m, m_ref):
+            assert np.max(np.abs(a - b)) < 1e-11
 
 
 def test_lasagne_standin_layer_order_and_alias():
