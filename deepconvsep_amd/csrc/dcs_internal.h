@@ -59,14 +59,25 @@ struct DcsDeviceGuard {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the CURRENT device's function object: a launcher that wants to
 // pay for it once (the one-batch kernels: the host call is on the latency path) must remember it per device, thread-safely.
-// `static DcsOncePerDevice once; if (once.first(ctx->device)) { set the attributes }` -- a second thread that loses the race sets
-// them again, which is harmless.
+//   static DcsOncePerDevice once;
+//   DCS_CHECK(once.run(ctx->device, [&]() -> int { DCS_HIP(hipFuncSetAttribute(...)); return DCS_OK; }));
+// The device's bit is published only AFTER the attribute calls have succeeded, and they run under a mutex: a second thread
+// either finds the bit set (the attributes are in place, it may launch) or waits for the first one and then finds it set; a
+// failed attempt leaves the bit clear, so the next call tries again instead of launching a kernel that cannot get its LDS.
+#include <mutex>
 struct DcsOncePerDevice {
-    unsigned long long mask = 0;   // devices 0..63; higher ordinals always report `first`
-    bool first(int device) {
-        if (device < 0 || device >= 64) return true;
-        const unsigned long long bit = 1ull << device;
-        return (__atomic_fetch_or(&mask, bit, __ATOMIC_ACQ_REL) & bit) == 0;
+    unsigned long long mask = 0;   // devices 0..63; higher ordinals run `fn` every time
+    std::mutex mu;
+    template <typename Fn>
+    int run(int device, Fn fn) {
+        const bool tracked = device >= 0 && device < 64;
+        const unsigned long long bit = tracked ? 1ull << device : 0;
+        if (tracked && (__atomic_load_n(&mask, __ATOMIC_ACQUIRE) & bit)) return DCS_OK;
+        std::lock_guard<std::mutex> lock(mu);
+        if (tracked && (__atomic_load_n(&mask, __ATOMIC_ACQUIRE) & bit)) return DCS_OK;
+        const int rc = fn();
+        if (rc == DCS_OK && tracked) __atomic_fetch_or(&mask, bit, __ATOMIC_RELEASE);
+        return rc;
     }
 };
 
@@ -220,7 +231,7 @@ struct DcsGemm {
 // and remainder per row -- ~80 instructions, four times per thread in a GEMM epilogue, ~0.5 us of a 12 us launch with one wave
 // per SIMD -- for a result that is r.  `flat` is wave-uniform (kernel arguments only).
 #if defined(__HIPCC__)
-__device__ __forceinline__ int64_t dcs_group_row(int64_t r, int gdiv, int gmul, bool flat) {
+__device__ __forceinline__ int64_t dcs_group_row(int64_t r, int gdiv, int64_t gmul, bool flat) {
     return flat ? r : (r / gdiv) * gmul + (r % gdiv);
 }
 #endif

@@ -1486,10 +1486,11 @@ int dcs_launch_lat_final(dcs_ctx* ctx, const DsdFinalArgs& a) {
     auto k0 = lat_final_kernel<0>;
     auto k1 = lat_final_kernel<1>;
     static DcsOncePerDevice attr_once;   // the attribute belongs to the device's function object (round-3 advisor finding)
-    if (attr_once.first(ctx->device)) {
+    DCS_CHECK(attr_once.run(ctx->device, [&]() -> int {
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+        return DCS_OK;
+    }));
     const dim3 grid((unsigned)dcs_cdiv(a.F, 64), (unsigned)dcs_cdiv(a.rows, 16));
     DcsTimer tm(ctx, DCS_TAG_FINAL);
     if (a.mask_mode == 0)
@@ -1519,10 +1520,11 @@ int dcs_launch_lat_stft_conv1(dcs_stft* p, const float* audio, int64_t L, float*
     auto k10 = lat_stft_conv1_kernel<10>;
     auto k9 = lat_stft_conv1_kernel<9>;
     static DcsOncePerDevice attr_once;
-    if (attr_once.first(p->ctx->device)) {
+    DCS_CHECK(attr_once.run(p->ctx->device, [&]() -> int {
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k10), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    }
+        return DCS_OK;
+    }));
     const dim3 grid((unsigned)dcs_cdiv(rows_out, 4));
     DcsTimer tm(p->ctx, DCS_TAG_STFT);
     if (p->frame == 2048)
@@ -1578,10 +1580,11 @@ int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, cons
         auto k10 = lat_ifft_kernel<10, NG>;
         auto k9 = lat_ifft_kernel<9, NG>;
         static DcsOncePerDevice attr_once;
-        if (attr_once.first(p->ctx->device)) {
+        DCS_CHECK(attr_once.run(p->ctx->device, [&]() -> int {
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k10), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        }
+            return DCS_OK;
+        }));
         if (p->frame == 2048)
             hipLaunchKernelGGL(k10, g1, dim3(NG * 256), lds, p->ctx->stream, sep, src_stride, unit, ld, p->win_f, p->tw_f, fr, T,
                                n_src, pre_mul, sq);

@@ -1639,6 +1639,24 @@ int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16
 static const bool kF16Igemm = getenv("DCS_F16_IGEMM") && atoi(getenv("DCS_F16_IGEMM")) != 0;
 static const bool kSlabMx = !(getenv("DCS_SLABCONV_MX") && atoi(getenv("DCS_SLABCONV_MX")) == 0);   // 0: the f32-MFMA slab kernel
 
+// Will both InverseLayers run as ONE kernel, and does that kernel want the dense output channels-last?  One place decides it:
+// forward_chunk (layout of the dense layers' output) and dcs_generic_forward (chunk size: the layout can only be produced by
+// the all-rows dense kernel, 128 .. 176 tiles per launch).
+bool plans_channels_last(const DcsGenericNet* g, bool* fuse_planned_out, bool* fuse_x3_out) {
+    const DcsGenericDims& d = g->d;
+    bool fuse_planned = false, fuse_x3 = false;
+    if (g->use_colconv && g->W1q && (g->conv_f16 ? g->Wcol_t_r != nullptr : g->Wx3 != nullptr)) {
+        ColConvArgs c0{};
+        c0.Cin = d.nf2; c0.H = d.h2; c0.W = d.w2; c0.Cout = d.nf1; c0.Ho = g->tc; c0.ph = d.kh2 - 1; c0.kh = d.kh2;
+        fuse_planned = g->conv_f16 ? dcs_decoder_fused_ok(c0, g->F) : dcs_decoder_x3_ok(c0, g->F);
+        fuse_x3 = fuse_planned && !g->conv_f16;
+    }
+    static const bool cl_env = !(getenv("DCS_DECODER_CL") && atoi(getenv("DCS_DECODER_CL")) == 0);
+    if (fuse_planned_out) *fuse_planned_out = fuse_planned;
+    if (fuse_x3_out) *fuse_x3_out = fuse_x3;
+    return fuse_planned && (cl_env || fuse_x3) && (d.nf2 & 1) == 0 && (g->flat_p & 1) == 0;
+}
+
 // one chunk of tiles through the graph; scratch carved from `w`
 int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_total, int64_t k_first, int mask_mode,
                   int tie_mode, float* out, char* w) {
@@ -1758,14 +1776,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // With the switch off the same fusion runs on three-way split operands (colconv_x3.hip, round 4: two waves per column
     // block); that kernel takes the channels-last layout only, so it is planned when the layout can be had.
     bool fuse_planned = false, fuse_x3 = false;
-    if (g->use_colconv && g->W1q && (g->conv_f16 ? g->Wcol_t_r != nullptr : g->Wx3 != nullptr)) {
-        ColConvArgs c0{};
-        c0.Cin = d.nf2; c0.H = d.h2; c0.W = d.w2; c0.Cout = d.nf1; c0.Ho = tc; c0.ph = d.kh2 - 1; c0.kh = d.kh2;
-        fuse_planned = g->conv_f16 ? dcs_decoder_fused_ok(c0, F) : dcs_decoder_x3_ok(c0, F);
-        fuse_x3 = fuse_planned && !g->conv_f16;
-    }
-    static const bool cl_env = !(getenv("DCS_DECODER_CL") && atoi(getenv("DCS_DECODER_CL")) == 0);
-    const bool want_cl = fuse_planned && (cl_env || fuse_x3) && (d.nf2 & 1) == 0 && (g->flat_p & 1) == 0;
+    const bool want_cl = plans_channels_last(g, &fuse_planned, &fuse_x3);
     // the bf16 planes of the dense weights, on first need: a launch of >= 128 rows against >= 1024 columns (smaller ones stay
     // on the f32 kernels whatever is packed, dcs_launch_gemm_bf16x3); same stream, so no synchronisation
     static const bool bf16_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
@@ -1845,7 +1856,20 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             decoder_fused = g->conv_f16 ? (g->W1q && g->Wcol_t_r && dcs_decoder_fused_ok(c, F))
                                         : (fuse_x3 && d_cl);       // f32-class: only on the channels-last layout
         }
-        if (d_cl && !decoder_fused) DCS_FAIL(DCS_EHIP, "generic graph: channels-last dense output without the fused decoder");
+        if (d_cl && !decoder_fused) {
+            // cannot happen while the plan above and the launch conditions agree (the layout is only asked for when the fused
+            // decoder is planned); if they ever disagree, redo the dense layers channel-first on the f32 weights instead of
+            // failing the call: every other consumer takes that layout
+            for (int b = 0; b < NB; ++b) {
+                const int s = d.branch_fc[b];
+                DcsGemm q{};
+                q.A = Z; q.lda = g->hid64; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
+                q.B = g->Bd[s]; q.ldb = g->flat64; q.bias = g->biasd[s]; q.Bq = nullptr;
+                q.C = D + (int64_t)b * g->flat_p; q.ldc = (int64_t)NB * g->flat_p; q.c_gdiv = 1 << 30; q.c_gmul = 0;
+                q.M = n; q.n_cols = g->flat64; q.n_store = d.flat; q.K = g->hid64; q.relu = 1; q.a_vec = 1;
+                DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC1X));
+            }
+        }
         if (decoder_fused) {                                 // both InverseLayers in one kernel: o directly
             DcsTimer tmf(ctx, DCS_TAG_DECODER);
             const bool ok = g->conv_f16 ? dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F, d_cl)
@@ -1982,6 +2006,17 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
     static const int64_t chunk_env = getenv("DCS_GENERIC_CHUNK") ? atoll(getenv("DCS_GENERIC_CHUNK")) : 0;
     int64_t chunk = chunk_env > 0 ? chunk_env : (int64_t)(((size_t)4 << 30) / (chunk_bytes(g, 64) / 64 + 1));
     if (chunk < 64 && chunk_env <= 0) chunk = 64;
+    // Graphs whose decoder is the fused kernel on channels-last input (Bach10): that layout only comes out of the all-rows dense
+    // kernel, which takes 128 .. 176 tiles per launch.  A longer pass would drop to the f32 GEMM for its 256 x 166 650 dense
+    // layers AND to the two-kernel decoder -- a 20 s clip several times slower per tile than a 10 s one.  Cut such passes into
+    // equal pieces inside the window instead (the dense weights are re-read once per piece: 0.85 GB, ~0.2 ms; the deferred-mask
+    // form below is single-chunk, so such a pass takes the separate mask and cross-fade kernels).
+    static const bool cap_env = !(getenv("DCS_GENERIC_CHUNK_CAP") && atoi(getenv("DCS_GENERIC_CHUNK_CAP")) == 0);
+    if (cap_env && chunk_env <= 0 && n > 176 && g->d.n_branch > 1 && g->flat64 >= 8192 && plans_channels_last(g, nullptr, nullptr)) {
+        const int64_t pieces = (n + 175) / 176, per = (n + pieces - 1) / pieces;
+        const int64_t capped = per >= 128 ? per : 176;
+        if (capped < chunk) chunk = capped;
+    }
     if (mask_mode < 0 && n > chunk) return DCS_EUNSUPPORTED;   // deferred mask: one chunk only (quiet: the caller falls back)
     const int64_t per = n < chunk ? n : chunk;
     DCS_CHECK(g->ws.ensure(chunk_bytes(g, per)));

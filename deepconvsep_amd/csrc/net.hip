@@ -782,6 +782,9 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
             static const int batch_mask = getenv("DCS_LAT_BATCH") ? atoi(getenv("DCS_LAT_BATCH")) : kLatBatchDefault;
             lat = (unsigned)batch_mask & (DCS_LAT_CONV1 | DCS_LAT_CONV2 | DCS_LAT_FC | DCS_LAT_FC1X | DCS_LAT_DECONV2);
             if ((int64_t)n * n_clips * 3 > 0x7fffffff / 8 || rows1_of(n, n_clips, Trows, st, tc) > 0x7fffffff / 64) lat = 0;
+            // clips of different lengths (uniform pitch or compact layout) only exist for the throughput kernels: the sliced-K
+            // stages index tiles as clip * n + k (DCS_LAT_BATCH made dcs_separate_ragged fail with 'bad ragged batch')
+            if (clip_tab_d) lat = 0;
         }
         const bool split = (lat & DCS_LAT_FINAL) || (m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode));
         const size_t b_fr = (lat & DCS_LAT_ISTFT) && pcm_d ? align256(dcs_lat_istft_scratch_bytes(plan, T, S)) : 0;

@@ -140,8 +140,11 @@ DCS_API int dcs_model_num_sources(const dcs_model* m);
 /* f16 = 1: conv2 and its transpose of the ikala / bach10 / score-informed graphs run with f16 inputs and
  * f32 accumulation on the matrix cores (BASELINE config 3, "fp16 MFMA conv path"); 0 (default): f32-class arithmetic
  * everywhere (f32 MFMA, or the bf16 pipe with operands split exactly into three bf16 terms).  With the switch on, the
- * single-channel bach10 graph runs both InverseLayers in one kernel (colconv_wreg.hip): conv2^T in f16, conv1^T on the
- * bf16 pipe with three-way split operands (f32-class), the activations between them never rounded below f32.  The ikala
+ * single-channel bach10 graph runs both InverseLayers in one kernel (colconv_wreg.hip): conv2^T in f16 and -- the default since
+ * round 4 -- conv1^T in f16 as well: the activations between the two InverseLayers are rounded to f16 and meet an f16 conv1
+ * filter in one MFMA per tile (f32 accumulation).  Results stay within the f16 path's stated tolerance (2e-3 of the network
+ * output, tests/test_gpu_configs.py), not within 1e-4.  DCS_DECODER_S2=bf16x3 in the environment restores the f32-class second
+ * stage (conv1^T on the bf16 pipe with three-way split operands, the intermediate never rounded below f32).  The ikala
  * graph (10 x 20 filters) takes the same slab kernel in either precision (one f16 plane instead of three bf16 planes). */
 DCS_API int dcs_model_set_conv_precision(dcs_model* m, int f16);
 /* Score-informed graphs (DCS_ARCH_BACH10_SI / _SI1): which of the reference's two semantics dcs_separate_scoreinformed and
