@@ -18,7 +18,7 @@ def test_random_draws_hip_network_matches_oracle(seed):
     arch, F, params, x = cases.random_draw(seed)
     tc, n, S = 30, x.shape[0], ARCHS[arch].S
     ctx = default_context()
-    net = Network(ctx, arch, params, tc, F)
+    net = Network(ctx, arch, params, tc, F, live_only=False)     # every output channel of the graph (score-informed: all 16)
     xd = ctx.to_device(x, np.float32)
     x64 = x.astype(np.float64)
     ties = (("all", TIE_ALL), ("first", TIE_FIRST)) if arch == "ikala" else (("all", TIE_ALL),)
@@ -27,8 +27,13 @@ def test_random_draws_hip_network_matches_oracle(seed):
         p = net.forward_raw(xd, tie_mode=tmode).cpu().numpy()
         assert p.shape == want.shape and np.isfinite(p).all()
         assert np.max(np.abs(p - want)) < 1e-4, (seed, arch, tname)
-        conv = 'A' if arch in ("dsd", "ikala") else 'B'
+        # the graph's own mask convention (round 4 derived it from a name list that missed 'ikala_nopool': its HIP masks were
+        # computed with convention B and compared with the convention-A oracle -- the 88 / 12 740 / 7 384 "bins outside 1e-4"
+        # of draws 6 / 13 / 20 in profiles/r04_r_mask_bins.txt were that mix-up, all-zero bins being 1/S under A and 0 under B)
+        conv = 'A' if ARCHS[arch].eps_mode == EPS_A else 'B'
         got = net.forward_masked(xd, eps_mode=EPS_A if conv == 'A' else EPS_B, tie_mode=tmode).cpu().numpy()
-        ref = net_ref.predict(arch, params, x64, tie_mode=tname, inverse='explicit')
-        check_masked(got, np.stack([r[:, 0] for r in ref]), want, p, x64[:, 0], S, conv,
-                     label="random draw %d: %s F=%d, %d tiles, ties %s" % (seed, arch, F, n, tname))
+        ref = net_ref.predict(arch, params, x64, tie_mode=tname, inverse='explicit', eps_mode=conv)
+        rec = check_masked(got, np.stack([r[:, 0] for r in ref]), want, p, x64[:, 0], S, conv,
+                           label="random draw %d: %s F=%d, %d tiles, ties %s" % (seed, arch, F, n, tname))
+        # north_star "within 1e-4 per mask bin", as a count: none of the 24 draws may leave a bin outside it
+        assert rec["bins_outside_1e4"] == 0, rec
