@@ -86,6 +86,7 @@ def load():
     proto("dcs_model_forward", i32, vp, vp, i64, i32, vp)
     proto("dcs_separate", i32, vp, vp, vp, i64, i32, i32, f32, i32, i32, vp, POINTER(i64), POINTER(i64))
     proto("dcs_pcm_to_int16", i32, vp, vp, i64, vp)
+    proto("dcs_pcm16_to_float", i32, vp, vp, i64, i32, i32, i64, i64, vp, i64)
     proto("dcs_gather", i32, vp, vp, vp, i64, vp, i32)
     proto("dcs_score_masks", i32, vp, vp, i64, i64, i32, vp, i32, i32, i32, i64, i64, vp, vp)
     proto("dcs_score_masks_norm", i32, vp, vp, i64, i64, i32, vp, i32, i32, i32, i64, i64, i32, vp, vp)

@@ -61,21 +61,46 @@ __global__ __launch_bounds__(kThreads) void overlap_add_kernel(const float* __re
 }
 
 // (audio_out * 32767).astype('int16') of the scripts (separate_dsd.py:307-309): truncation toward zero, no
-// clipping -- an out-of-range product wraps the way NumPy's float -> int16 cast does on x86-64 (through int32).
+// clipping -- an out-of-range product wraps the way NumPy's float -> int16 cast does on x86-64 (through int32).  The scripts'
+// audio_out is float64: the product is formed in double (exact for a float32 sample: 24 + 15 significant bits), so the int16
+// value is the one the host path gets from `(pcm.astype(float64) * 32767).astype('int16')` -- bit for bit, which a float32
+// product is not (it rounds before the truncation: one LSB off on a few samples per million).
+__device__ __forceinline__ int16_t pcm_i16(float v) { return (int16_t)(int32_t)((double)v * 32767.0); }
+
 __global__ __launch_bounds__(kThreads) void pcm_int16_kernel(const float* __restrict__ pcm, int64_t n,
                                                              int16_t* __restrict__ out) {
     const int64_t i0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
     if (i0 + 3 < n && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
         const float4 v = *reinterpret_cast<const float4*>(pcm + i0);
         short4 o;
-        o.x = (int16_t)(int32_t)(v.x * 32767.f);
-        o.y = (int16_t)(int32_t)(v.y * 32767.f);
-        o.z = (int16_t)(int32_t)(v.z * 32767.f);
-        o.w = (int16_t)(int32_t)(v.w * 32767.f);
+        o.x = pcm_i16(v.x);
+        o.y = pcm_i16(v.y);
+        o.z = pcm_i16(v.z);
+        o.w = pcm_i16(v.w);
         *reinterpret_cast<short4*>(out + i0) = o;
     } else {
-        for (int64_t i = i0; i < n && i < i0 + 4; ++i) out[i] = (int16_t)(int32_t)(pcm[i] * 32767.f);
+        for (int64_t i = i0; i < n && i < i0 + 4; ++i) out[i] = pcm_i16(pcm[i]);
     }
+}
+
+// wav samples -> the mono float signal the scripts separate (separate_dsd.py:275-287, separate_ikala.py:229): int16 frames
+// [n][channels] interleaved as scipy.io.wavfile.read delivers them; x = sample.astype('float') / 32767 in float64, then
+//   mode 0 (DSD / hiphop / Bach10): (L + R) / 2 when there are two or more channels, the only channel otherwise
+//   mode 1 (iKala):                 L + R (no halving)
+// and the float32 value the device path has always worked on (the cast Context.to_device applies to the float64 array).
+// Clips are stacked: clip c reads in + c * in_stride (int16 elements), writes out + c * out_stride.
+__global__ __launch_bounds__(kThreads) void pcm16_to_float_kernel(const int16_t* __restrict__ in, int64_t n, int ch, int mode,
+                                                                  int64_t in_stride, float* __restrict__ out, int64_t out_stride) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int16_t* p = in + (int64_t)blockIdx.y * in_stride + i * ch;
+    const double l = (double)p[0] / 32767.0;
+    double v = l;
+    if (ch > 1) {
+        const double r = (double)p[1] / 32767.0;
+        v = mode == 1 ? l + r : (l + r) / 2;
+    }
+    out[(int64_t)blockIdx.y * out_stride + i] = (float)v;
 }
 
 }  // namespace
@@ -90,6 +115,23 @@ extern "C" int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int
     return DCS_OK;
 }
 
+
+extern "C" int dcs_pcm16_to_float(dcs_ctx* ctx, const int16_t* pcm16_d, int64_t n_frames, int channels, int mode, int64_t n_clips,
+                                  int64_t in_stride, float* out_d, int64_t out_stride) {
+    if (!ctx || !pcm16_d || !out_d || n_frames < 0 || n_clips < 0) DCS_FAIL(DCS_EINVAL, "dcs_pcm16_to_float: bad argument");
+    if (channels < 1 || (mode != 0 && mode != 1)) DCS_FAIL(DCS_EINVAL, "dcs_pcm16_to_float: %d channels, mode %d", channels, mode);
+    if (mode == 1 && channels < 2)
+        DCS_FAIL(DCS_EINVAL, "too many indices for array");   // separate_ikala.py:229 indexes [:, 1] of a mono array: IndexError
+    if (n_clips > 65535) DCS_FAIL(DCS_EINVAL, "dcs_pcm16_to_float: %lld clips in one call", (long long)n_clips);
+    if (n_clips > 1 && (in_stride < n_frames * channels || out_stride < n_frames))
+        DCS_FAIL(DCS_EINVAL, "dcs_pcm16_to_float: clip strides shorter than a clip");
+    if (n_frames == 0 || n_clips == 0) return DCS_OK;
+    DCS_ON_DEVICE(ctx->device);
+    hipLaunchKernelGGL(pcm16_to_float_kernel, dim3((unsigned)dcs_cdiv(n_frames, kThreads), (unsigned)n_clips), dim3(kThreads), 0,
+                       ctx->stream, pcm16_d, n_frames, channels, mode, in_stride, out_d, out_stride);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
+}
 
 int dcs_launch_tile(dcs_ctx* ctx, const float* mag, int64_t ch_stride, int64_t ld, int C, int64_t T, int F, int tc,
                     int ov, int tiler, float scale, float* tiles, int64_t n) {

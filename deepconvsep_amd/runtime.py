@@ -465,6 +465,23 @@ def pcm_to_int16(ctx, pcm_t, out=None):
     return out
 
 
+def pcm16_to_float(ctx, pcm16_t, channels, mode=0, out=None):
+    """``dcs_pcm16_to_float``: int16 wav frames on the device -> the mono float32 signal the scripts separate.  ``pcm16_t``
+    ``[B, stride]`` int16 (row c = clip c's interleaved frames, zero padded), ``channels`` per frame; returns ``[B, stride //
+    channels]`` float32.  ``mode`` 0: (L + R) / 2 for two or more channels, the channel itself for mono (separate_dsd.py:
+    285-287); 1: L + R (separate_ikala.py:229)."""
+    torch = _torch()
+    if pcm16_t.dim() != 2 or pcm16_t.stride(1) != 1 or pcm16_t.dtype != torch.int16:
+        raise ValueError("pcm16_to_float expects a [clips, interleaved samples] int16 tensor with contiguous rows")
+    B, n = int(pcm16_t.shape[0]), int(pcm16_t.shape[1]) // int(channels)
+    with ctx.stream_scope():
+        if out is None:
+            out = torch.empty((B, n), dtype=torch.float32, device=pcm16_t.device)
+        _lib.check(ctx._lib.dcs_pcm16_to_float(ctx._h, _ptr(pcm16_t), n, int(channels), int(mode), B, int(pcm16_t.stride(0)),
+                                               _ptr(out), int(out.stride(0))))
+    return out
+
+
 def overlap_add(ctx, out_t, overlap):
     """``overlapadd_multi`` on the device: out_t ``[S, n, tc, F]`` float32 -> ``[S, n*(tc-ov)+tc, F]``."""
     torch = _torch()

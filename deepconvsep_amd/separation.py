@@ -20,7 +20,7 @@ import scipy.io.wavfile
 
 from . import _lib
 from .arch import ARCHS, TIE_ALL, TILER_LIBRARY, TILER_SCRIPT
-from .runtime import Network, StftPlan, _on_ctx_stream, default_context, overlap_add, tile
+from .runtime import Network, StftPlan, _on_ctx_stream, default_context, overlap_add, pcm16_to_float, pcm_to_int16, tile
 
 
 def blackmanharris(n):
@@ -274,6 +274,101 @@ class Separator(object):
                 continue
             for b, i in enumerate(idx):
                 out[i] = pcm[b, :, :lens[b]].astype(np.float64)
+        return out
+
+    @_on_ctx_stream
+    def separate_many_pcm16(self, clips, max_group=16, max_ratio=None, on_error='raise', ring=3):
+        """The batch-of-files path without host arithmetic: ``clips`` are the int16 frames of 16-bit PCM wav files exactly as
+        ``scipy.io.wavfile.read`` returns them (``[L]`` mono or ``[L, channels]``; NumPy arrays or pinned torch CPU tensors, e.g.
+        from :func:`deepconvsep_amd.wavio.read_pcm16`), the result a list of int16 arrays ``[S, L_i]`` -- the samples the
+        scripts write (``(audio_out * 32767).astype('int16')``, separate_dsd.py:307-309).  The division by 32767, the mix-down
+        (separate_dsd.py:285-287; iKala: L + R, separate_ikala.py:229) and the int16 conversion run on the device
+        (``dcs_pcm16_to_float`` / ``dcs_pcm_to_int16``, float64 arithmetic like the scripts'): the values are those of
+        ``separate_many(to_mono(read_wav(f)))`` + ``write_wav`` bit for bit, for a quarter of the PCIe bytes.  Grouping as in
+        :meth:`separate_many` (clips of one group also share their channel count).  The returned arrays are views of a ring
+        of ``ring`` pinned host buffers: they stay valid until ``ring - 1`` further calls have been made (copy them to keep
+        them longer); ``ring=0`` returns fresh arrays."""
+        import torch
+        if max_ratio is None:
+            max_ratio = 3.0 if self.arch_name in ("dsd", "hiphop") else 1.5
+        mode = 1 if self.arch_name in ("ikala", "ikala_nopool") else 0
+        S = self.net.S
+        tens = []
+        for c in clips:
+            t = c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c))
+            if t.dtype != torch.int16 or t.dim() not in (1, 2):
+                raise ValueError("separate_many_pcm16 takes int16 frames [L] or [L, channels]")
+            tens.append(t.contiguous())
+        chans = [1 if t.dim() == 1 else int(t.shape[1]) for t in tens]
+        frames = [int(t.shape[0]) for t in tens]
+        out = [None] * len(tens)
+        ragged_ok = (self.arch.C == 1 and self.frameSize in (1024, 2048, 4096) and self.frameSize % self.hopSize == 0
+                     and self.hopSize % 2 == 0)
+        if not ragged_ok:
+            max_ratio = 1.0
+
+        def n_tiles(L):
+            return _lib.tile_count(_lib.frame_count(L, self.hopSize), self.tc, self.overlap, self.tiler)
+        bad = {}
+        for i in range(len(tens)):
+            if mode == 1 and chans[i] < 2:
+                bad[i] = IndexError("too many indices for array")            # separate_ikala.py:229 on a mono file
+            elif frames[i] == 0 or n_tiles(frames[i]) < 1:
+                bad[i] = ValueError("dcs_separate: %d frames give no tile (the reference fails in overlapadd_multi)"
+                                    % _lib.frame_count(frames[i], self.hopSize))
+        if bad and on_error == 'raise':
+            raise bad[min(bad)]
+        for i, exc in bad.items():
+            out[i] = exc
+        groups = []
+        for ch in sorted(set(chans)):
+            idx = [i for i in range(len(tens)) if chans[i] == ch and i not in bad]
+            for g in length_groups([frames[i] for i in idx], max_group if self.arch.C == 1 else 1, max_ratio):
+                groups.append([idx[k] for k in g])
+        if not groups:
+            return out
+        # one pinned output block per call, cut out of a small ring: the writer threads of the caller stream the int16
+        # samples to the files straight from it
+        total = sum(S * frames[i] for g in groups for i in g)
+        if ring:
+            if not hasattr(self, "_pcm16_ring"):
+                self._pcm16_ring, self._pcm16_next = [None] * int(ring), 0
+            slot = self._pcm16_next % len(self._pcm16_ring)
+            self._pcm16_next += 1
+            if self._pcm16_ring[slot] is None or self._pcm16_ring[slot].numel() < total:
+                self._pcm16_ring[slot] = torch.empty((max(total, 1 << 20) * 5 // 4,), dtype=torch.int16).pin_memory()
+            host = self._pcm16_ring[slot]
+        else:
+            host = torch.empty((total,), dtype=torch.int16)
+        pos = 0
+        views = []
+        dev = self.ctx.device
+        for idx in groups:
+            ch = chans[idx[0]]
+            lens = [frames[i] for i in idx]
+            B, Lmax = len(idx), max(lens)
+            stack = torch.zeros((B, Lmax * ch), dtype=torch.int16, device=dev) if min(lens) != Lmax else \
+                torch.empty((B, Lmax * ch), dtype=torch.int16, device=dev)
+            for b, i in enumerate(idx):
+                stack[b, :lens[b] * ch].copy_(tens[i].reshape(-1), non_blocking=True)
+            mono = pcm16_to_float(self.ctx, stack, ch, mode)                                        # [B, Lmax] float32
+            if B == 1:
+                pcm = self.net.separate(self.plan, mono[0], self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)[None]
+            elif min(lens) == Lmax:
+                pcm = self.net.separate_batch(self.plan, mono, self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)
+            else:
+                pcm = self.net.separate_ragged(self.plan, mono, lens, self.overlap, self.tiler, self.scale_factor, None,
+                                               self.tie_mode)
+            p16 = pcm_to_int16(self.ctx, pcm)                                                       # [B, S, Lmax] int16
+            for b, i in enumerate(idx):
+                n = S * lens[b]
+                dst = host[pos:pos + n].view(S, lens[b])
+                dst.copy_(p16[b, :, :lens[b]], non_blocking=True)
+                views.append((i, dst))
+                pos += n
+        self.ctx.torch_stream.synchronize()
+        for i, v in views:
+            out[i] = v.numpy()
         return out
 
     @_on_ctx_stream

@@ -7,9 +7,16 @@
 
 Every file gets its own sub-directory ``outdir/<stem>/`` holding the wav files the single-file script
 writes.  With several ranks (one process per GPU) the files are dealt round-robin: replicas only, no
-collective on the data path.  While the GPU separates file i the host reads file i+1 and writes file i-1
-(two worker threads), so wav I/O overlaps the kernels.  ``--group G`` (default 8) takes G files at a time; those
-of equal length share one set of kernel launches.
+collective on the data path.  ``--group G`` (default 8) takes G files at a time; they share sets of kernel launches
+(``Separator.separate_many_pcm16``: equal lengths ``dcs_separate_batch``, different lengths ``dcs_separate_ragged``).
+
+16-bit PCM files (the datasets' format) never become floats on the host: a worker thread reads a file's int16 frames
+straight into a pinned staging buffer (``wavio.read_pcm16_into``), the frames go to the GPU as they are, the division by
+32767, the mix-down (separate_dsd.py:278-287) and the int16 conversion of the results (:307-309) run on the device in the
+scripts' float64 arithmetic, the int16 samples come back into pinned memory and worker threads write them behind the 44-byte
+header ``scipy.io.wavfile.write`` would produce -- the output files are byte-identical to those of the float path.  Any other
+sample format takes the float path (``read_wav`` / ``to_mono`` / ``separate_many`` / ``write_wav``) file by file.
+While the GPU separates group i the workers read group i+1 and write group i-1.
 """
 import argparse
 import os
@@ -25,6 +32,10 @@ def main(argv=None):
     ap.add_argument("-m", "--mfile", required=True)
     ap.add_argument("-o", "--odir", required=True)
     ap.add_argument("-g", "--group", type=int, default=8, help="files read ahead and separated together")
+    ap.add_argument("-w", "--workers", type=int, default=0, help="I/O worker threads (default: min(8, cores))")
+    ap.add_argument("--float-path", action="store_true",
+                    help="force the float path of the single-file scripts (read_wav / to_mono on the host, float32 upload, "
+                         "float64 download, scipy writes) also for 16-bit PCM files")
     ap.add_argument("--stats", action="store_true",
                     help="print one JSON line at the end: files, seconds from model-ready to the last wav written, ms per file")
     ap.add_argument("files", nargs="+")
@@ -44,48 +55,84 @@ def main(argv=None):
     t_ready = time.perf_counter()          # interpreter, torch import, model upload and plan are behind us
 
     failed = []
+    from deepconvsep_amd import wavio
+    n_workers = max(2, min(args.workers or 8, (os.cpu_count() or 2)))
+    G = max(1, args.group)
+    chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
+    # pinned input arenas, one per chunk in flight (the chunk being separated and the one being read)
+    arenas = [None, None]
 
-    def read(path):
-        # a file that cannot be read or mixed down fails alone (the notebook runs one process per file)
+    def arena_for(k, nbytes):
+        a = arenas[k % 2]
+        if a is None or a.numel() < nbytes:
+            a = arenas[k % 2] = torch.empty((max(nbytes, 1 << 22) * 5 // 4,), dtype=torch.uint8).pin_memory()
+        return a
+
+    def read(path, arena, off, cap):
+        """16-bit PCM: (path, rate, pinned int16 tensor [L] / [L, ch]); otherwise the float path's mono signal."""
         try:
+            got = wavio.read_pcm16_into(path, arena.numpy()[off:off + cap]) if not args.float_path else None
+            if got is not None:
+                sr, frames, ch = got
+                t = arena[off:off + 2 * frames * ch].view(torch.int16)
+                return path, sr, (t if ch == 1 else t.view(frames, ch)), True
             sr, audio = sp.read_wav(path)
-            return path, sr, (sp.to_mono(audio, args.arch) if sr == 44100 else None)
-        except Exception as exc:
-            return path, None, exc
+            return path, sr, (sp.to_mono(audio, args.arch) if sr == 44100 else None), False
+        except Exception as exc:      # a file that cannot be read or mixed down fails alone (the notebook: one process per file)
+            return path, None, exc, False
 
-    def write(path, sr, pcm):
+    def submit_reads(pool, k):
+        if k >= len(chunks):
+            return []
+        sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in chunks[k]]
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + (sz + 63) // 64 * 64)
+        arena = arena_for(k, offs[-1])
+        return [pool.submit(read, f, arena, offs[j], sizes[j]) for j, f in enumerate(chunks[k])]
+
+    def out_dir(path):
         out = os.path.join(args.odir, os.path.splitext(os.path.basename(path))[0])
         os.makedirs(out, exist_ok=True)
-        for dst, sig in zip(sp.output_paths(args.arch, path, out), pcm):
+        return out
+
+    def write16(dst, sr, samples):
+        wavio.write_pcm16(dst, sr, samples)
+
+    def write_float(path, sr, pcm):
+        for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
             sp.write_wav(dst, sig, sr)
 
-    # --group G: G files are read ahead and separated together; those of equal length (a dataset cut into fixed
-    # excerpts) share one set of kernel launches (dcs_separate_batch), the rest go one by one
-    G = max(1, args.group)
-    with ThreadPoolExecutor(max_workers=2) as pool:
-        chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
-        nxt = [pool.submit(read, f) for f in chunks[0]] if chunks else []
+    with ThreadPoolExecutor(max_workers=n_workers) as pool:
+        nxt = submit_reads(pool, 0)
         pending = []
         for ci in range(len(chunks)):
             got = [f.result() for f in nxt]
-            nxt = [pool.submit(read, f) for f in chunks[ci + 1]] if ci + 1 < len(chunks) else []
-            ok = []
-            for path, sr, audio in got:
+            nxt = submit_reads(pool, ci + 1)
+            fast, slow = [], []
+            for path, sr, audio, is16 in got:
                 if isinstance(audio, Exception):
                     failed.append((path, audio))
-                elif audio is None:
+                elif sr != 44100 or audio is None:
                     print("Sample rate is not 44100")          # separate_dsd.py:313
                 else:
-                    ok.append((path, sr, audio))
-            pcms = sep.separate_many([a for _, _, a in ok], on_error='return')
-            for f in pending:
-                f.result()
+                    (fast if is16 else slow).append((path, sr, audio))
+            res16 = sep.separate_many_pcm16([a for _, _, a in fast], on_error='return') if fast else []
+            resf = sep.separate_many([a for _, _, a in slow], on_error='return') if slow else []
+            for f in pending:                                   # the writes of the previous chunk (their pinned block is two
+                f.result()                                      # calls old when it is reused: ring of three)
             pending = []
-            for (path, sr, _), pcm in zip(ok, pcms):
+            for (path, sr, _), pcm in zip(fast, res16):
+                if isinstance(pcm, Exception):
+                    failed.append((path, pcm))
+                    continue
+                for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
+                    pending.append(pool.submit(write16, dst, sr, sig))
+            for (path, sr, _), pcm in zip(slow, resf):
                 if isinstance(pcm, Exception):
                     failed.append((path, pcm))
                 else:
-                    pending.append(pool.submit(write, path, sr, pcm))
+                    pending.append(pool.submit(write_float, path, sr, pcm))
         for f in pending:
             f.result()
     for path, exc in failed:
@@ -94,7 +141,8 @@ def main(argv=None):
         import json
         el = time.perf_counter() - t_ready
         print(json.dumps({"rank": rank, "files": len(mine), "failed": len(failed), "seconds_after_model_ready": round(el, 4),
-                          "ms_per_file": round(el / max(1, len(mine)) * 1e3, 3), "group": G}))
+                          "ms_per_file": round(el / max(1, len(mine)) * 1e3, 3), "group": G, "workers": n_workers,
+                          "path": "float" if args.float_path else "int16 frames (device mix-down and int16 conversion)"}))
     return 1 if failed else 0
 
 

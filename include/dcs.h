@@ -250,8 +250,20 @@ DCS_API int dcs_separate_spectra(dcs_model* m, dcs_stft* plan, const float* audi
                          float* phase_d, int64_t ld_out);
 
 /* The wav sample format of every script: out_d[i] = (int16)(pcm_d[i] * 32767), truncation toward zero, no
- * clipping (separate_dsd.py:307-309).  Halves the bytes of the multi-GPU PCM gather. */
+ * clipping (separate_dsd.py:307-309); the product is formed in double like the scripts' float64 `audio_out * maxn`, so the
+ * values are those of `(pcm.astype(float64) * 32767).astype('int16')` bit for bit.  Halves the bytes of the multi-GPU PCM
+ * gather and of the batch driver's device-to-host copy. */
 DCS_API int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_t* out_d);
+
+/* The other end of a wav file: int16 frames as scipy.io.wavfile.read returns them ([n_frames][channels], interleaved) -> the
+ * mono float32 signal the scripts separate: sample.astype('float') / 32767 (separate_dsd.py:275-282, float64), then
+ * mode 0: (L + R) / 2 for two or more channels, the channel itself for mono (separate_dsd.py:285-287, separate_bach10.py);
+ * mode 1: L + R (separate_ikala.py:229; a mono file is DCS_EINVAL with NumPy's IndexError text), computed in double and
+ * rounded to float32 once -- the value the host path `to_device(to_mono(read_wav(f)))` uploads, bit for bit, for half (stereo)
+ * or a quarter (mono) of its PCIe bytes and none of its host arithmetic.  n_clips stacked clips: clip c at
+ * pcm16_d + c * in_stride (int16 elements, >= n_frames * channels), out_d + c * out_stride. */
+DCS_API int dcs_pcm16_to_float(dcs_ctx* ctx, const int16_t* pcm16_d, int64_t n_frames, int channels, int mode, int64_t n_clips,
+                       int64_t in_stride, float* out_d, int64_t out_stride);
 
 /* The one exchange of the multi-GPU path (tiles / clips are sharded over one process per GPU and nothing else is shared;
  * SURVEY 8b `dcs_gather(h, ncclComm_t, shard, count, full, root)`, counted in BYTES here so that the scripts' int16 PCM of

@@ -572,6 +572,85 @@ def test_batch_driver_matches_single_file_runs(tmp_path):
             assert np.array_equal(data, (want[s] * 32767).astype('int16'))
 
 
+def test_pcm16_frames_to_mono_float_is_the_scripts_arithmetic():
+    """dcs_pcm16_to_float: int16 wav frames -> sample / 32767 (float64), (L + R) / 2 or L + R or the mono channel, one rounding
+    to float32 -- bit for bit the array `to_device(to_mono(read_wav(f)))` uploads (separate_dsd.py:275-287,
+    separate_ikala.py:229), for stacked clips with padded strides; a mono file under the iKala rule is the reference's
+    IndexError."""
+    import torch
+    from deepconvsep_amd.runtime import pcm16_to_float
+    from deepconvsep_amd.separation import to_mono
+    ctx = default_context()
+    rs = np.random.RandomState(5)
+    for ch in (1, 2, 3):
+        for n in (1, 255, 4097):
+            x = rs.randint(-32768, 32768, (2, n, ch)).astype(np.int16)
+            x[0, 0] = 32767
+            x[1, -1] = -32768
+            dev = torch.zeros((2, (n + 5) * ch), dtype=torch.int16, device=ctx.device)
+            dev[:, :n * ch] = torch.from_numpy(x.reshape(2, -1)).to(ctx.device)
+            for mode, arch in ((0, "dsd"), (1, "ikala")):
+                if mode == 1 and ch < 2:
+                    with pytest.raises(ValueError):
+                        pcm16_to_float(ctx, dev, ch, mode)
+                    continue
+                got = pcm16_to_float(ctx, dev, ch, mode).cpu().numpy()
+                assert got.shape == (2, n + 5) and got.dtype == np.float32
+                for c in range(2):
+                    f = x[c].astype('float') / 32767
+                    want = to_mono(f if ch > 1 else f[:, 0], arch).astype(np.float32)
+                    assert np.array_equal(got[c, :n], want) and not got[c, n:].any()
+
+
+def test_batch_driver_int16_path_writes_the_same_bytes_as_the_float_path(tmp_path):
+    """examples/separate_batch.py: 16-bit PCM files go to the GPU as int16 frames (pinned staging, device mix-down and int16
+    conversion, RIFF header written directly) -- the wav files are byte-identical to those of --float-path (read_wav / to_mono
+    / float32 upload / float64 download / scipy writes), for stereo and mono inputs of equal and different lengths in one
+    group; a float32 wav in the same run takes the float path; an unreadable file fails alone."""
+    import importlib.util
+    import os
+    import scipy.io.wavfile
+    F = 513
+    params = synth_params("dsd", 30, F, seed=2)
+    model = str(tmp_path / "model.pkl")
+    dcs.save_model(model, params)
+    wavs = []
+    for i, (n, ch) in enumerate([(40000, 2), (40000, 2), (31000, 1), (52000, 2), (40000, 1), (36000, 3)]):
+        a = synth_audio(n, seed=60 + i, channels=ch)
+        w = str(tmp_path / ("clip%d.wav" % i))
+        scipy.io.wavfile.write(w, 44100, (a * 32767).astype('int16'))
+        wavs.append(w)
+    fl = str(tmp_path / "floaty.wav")
+    scipy.io.wavfile.write(fl, 44100, synth_audio(33000, seed=70).astype(np.float32))
+    broken = str(tmp_path / "broken.wav")
+    with open(broken, "wb") as fh:
+        fh.write(b"RIFF\x00\x00\x00\x00WAVEjunk")
+    spec = importlib.util.spec_from_file_location(
+        "separate_batch", os.path.join(os.path.dirname(__file__), "..", "examples", "separate_batch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    outs = {}
+    for name, extra in (("int16", []), ("float", ["--float-path"])):
+        out = tmp_path / name
+        out.mkdir()
+        rc = mod.main(["-a", "dsd", "-m", model, "-o", str(out), "--group", "4"] + extra + wavs + [fl, broken])
+        assert rc == 1                                               # the broken file is reported, the others are done
+        outs[name] = out
+    sep = dcs.Separator("dsd", params, 0.3, 30, 25, 32, F, 1024, 512, np.hanning)
+    for w in wavs + [fl]:
+        stem = os.path.splitext(os.path.basename(w))[0]
+        sr, audio = dcs.separation.read_wav(w)
+        alone = sep.separate(dcs.separation.to_mono(audio, "dsd"))
+        for s_, src in enumerate(["vocals", "bass", "drums", "other"]):
+            a = open(str(outs["int16"] / stem / (src + ".wav")), "rb").read()
+            b = open(str(outs["float"] / stem / (src + ".wav")), "rb").read()
+            assert a == b, (stem, src)
+            sr2, data = scipy.io.wavfile.read(str(outs["int16"] / stem / (src + ".wav")))
+            assert sr2 == 44100 and data.dtype == np.int16 and data.shape[0] == audio.shape[0]
+            assert np.max(np.abs(data.astype(np.int32) - (alone[s_] * 32767).astype('int16').astype(np.int32))) <= 1
+    assert not (outs["int16"] / "broken").exists() or not os.listdir(str(outs["int16"] / "broken"))
+
+
 def test_batch_driver_groups_equal_lengths(tmp_path):
     """--group: files share sets of launches (Separator.separate_many -> dcs_separate_ragged / dcs_separate_batch); every
     file still gets what the single-file path gives it (kernel variants depend on the launch size, so float results
@@ -1432,17 +1511,17 @@ def test_pcm_to_int16_is_the_scripts_wav_format():
         x[:min(n, 4)] = np.array([0.99999, -0.99999, 3.05e-5, -3.06e-5], np.float32)[:min(n, 4)]
         if n > 100:
             x[50:54] = np.array([1.0, -1.0, 1.2, -1.3], np.float32)          # clipping input: wraps, as in the reference
-        want = (x.astype(np.float32) * np.float32(32767)).astype(np.int32).astype(np.int16)
+        want = (x.astype(np.float64) * 32767.0).astype(np.int32).astype(np.int16)      # the scripts' float64 product, exact
         got = pcm_to_int16(ctx, ctx.to_device(x, np.float32)).cpu().numpy()
         assert got.dtype == np.int16 and np.array_equal(got, want)
         if n > 8:                                                             # unaligned views
             t = ctx.to_device(x, np.float32)
             assert np.array_equal(pcm_to_int16(ctx, t[1:]).cpu().numpy(), want[1:])
-    # against the float64 product of the scripts: at most one LSB apart (float32 product)
-    x = rs.uniform(-1.0, 1.0, 5000)
-    ref = (x * 32767).astype('int16')
+    # = what the float path writes: the float32 PCM widened to float64, times 32767, truncated -- identical, not "one LSB apart"
+    x = rs.uniform(-1.0, 1.0, 50000).astype(np.float32)
+    ref = (x.astype(np.float64) * 32767).astype('int16')
     got = pcm_to_int16(ctx, ctx.to_device(x, np.float32)).cpu().numpy()
-    assert np.max(np.abs(got.astype(np.int32) - ref.astype(np.int32))) <= 1
+    assert np.array_equal(got, ref)
 
 
 # ------------------------------------------------------------------ stereo (ILD) graph, SURVEY 8f-4
