@@ -274,7 +274,7 @@ def main():
     ap.add_argument("--min-time", type=float, default=0.25, help="seconds of timed rounds to accumulate")
     ap.add_argument("--max-rounds", type=int, default=4000)
     ap.add_argument("--sat-tiles", type=int, default=4096, help="tiles of the saturating extra run (0 = skip)")
-    ap.add_argument("--legs", default="ikala,bach10_f16,bach10_f32,score_informed",
+    ap.add_argument("--legs", default="ikala,bach10_f16,bach10_f32,score_informed,transform",
                     help="comma list of extra BASELINE configs to measure on rank 0 at N=1 ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive extra leg")
@@ -337,6 +337,9 @@ def main():
     if args.only_legs:
         legs = {}
         for name in [x for x in args.legs.split(",") if x]:
+            if name == "transform":
+                legs[name] = run_transform_leg(torch, dcs, synth_audio)
+                continue
             legs[name] = run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_audio, synth_params,
                                  synth_score_text, not args.no_cpu_baseline, cpu_model(), os.cpu_count() or 1,
                                  with_parity=not args.no_parity_check)
@@ -772,6 +775,9 @@ def main():
         legs = {}
         for name in [x for x in args.legs.split(",") if x]:
             try:
+                if name == "transform":
+                    legs[name] = run_transform_leg(torch, dcs, synth_audio)
+                    continue
                 legs[name] = run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_audio, synth_params,
                                      synth_score_text, not args.no_cpu_baseline, cpu_name, ncpu,
                                      with_parity=not args.no_parity_check)
@@ -937,7 +943,6 @@ def run_cli(torch, dcs, synth_audio, synth_params):
                 steady = json.loads(ln)
                 break
     import shutil
-    shutil.rmtree(tmp, ignore_errors=True)
     res = {"workload": "DSD as shipped (frameSize 1024, hop 512, 513 bins), 10 s stereo 44.1 kHz int16 wavs, synthetic weights",
            "separate_dsd_py_process_s": round(t_proc, 3),
            "separate_dsd_py_note": "python separate_dsd.py -i clip.wav -o out -m model.pkl as a process: interpreter start, torch / "
@@ -952,8 +957,20 @@ def run_cli(torch, dcs, synth_audio, synth_params):
                                "ms_per_file": steady["ms_per_file"],
                                "x_realtime": round(Lc / float(SR) / (steady["ms_per_file"] * 1e-3), 1),
                                "frames_per_s": round(frames / (steady["ms_per_file"] * 1e-3), 1),
-                               "note": "separate_batch.py --stats over 550 wav files (read + mix-down + H2D + kernels + D2H + 4 wavs "
-                                       "written per file, two I/O threads), clock started when the model is resident"}
+                               "workers": steady.get("workers"), "path": steady.get("path"),
+                               "note": "separate_batch.py --stats over 550 wav files (int16 frames read into pinned staging, H2D, "
+                                       "device mix-down, kernels, device int16 conversion, D2H, 4 wavs written per file by a "
+                                       "pool of I/O threads), clock started when the model is resident"}
+        # the float path of the single-file scripts through the same driver (round 4's figure: 2.0 - 2.3 ms per file)
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "separate_batch.py"), "-a", "dsd", "-m", model, "-o",
+                             out550, "--stats", "--float-path"] + wavs * 4, capture_output=True, text=True, timeout=1800) \
+            if os.path.isdir(tmp) else None
+        if r2 is not None and r2.returncode == 0:
+            for ln in reversed(r2.stdout.splitlines()):
+                if ln.startswith("{"):
+                    res["steady_state"]["float_path_ms_per_file"] = json.loads(ln)["ms_per_file"]
+                    break
+    shutil.rmtree(tmp, ignore_errors=True)
     return res
 
 
@@ -1017,6 +1034,58 @@ KERNEL_NAMES = {
 
 
 _ORACLE_CACHE = {}     # (graph, frame size, overlap, weight seed, samples) -> (oracle PCM, cpu_baseline block): the two Bach10 legs share one
+
+
+def run_transform_leg(torch, dcs, synth_audio):
+    """transformFFT.compute_transform as the dataset builders call it (examples/dsd100/compute_features.py:83-112:
+    one song = the mixture and its four sources as the columns of audio[t, i]).  Per (frameSize, precision): the ONE
+    STFT launch over all columns with input and output resident in HBM (HIP events; HBM-bound: algorithmic bytes = samples
+    read + magnitudes written, against 8 TB/s) and the whole call host array -> host array (upload, device transpose,
+    launch, pinned download)."""
+    from deepconvsep_amd.runtime import default_context
+    ctx = default_context()
+    cols, seconds = 5, 60.0
+    L = int(seconds * SR)
+    base = np.stack([synth_audio(L, seed=900 + c) for c in range(cols)], axis=1)
+    res = {"workload": "compute_transform(audio[t, 5]): 60 s of 44.1 kHz audio x 5 columns (mixture + 4 sources), hop 512, "
+                       "magnitudes only, all columns in one launch", "cases": {}}
+    for N, precision in ((1024, 'float64'), (4096, 'float64'), (1024, 'float32'), (4096, 'float32')):
+        tt = dcs.transformFFT(frameSize=N, hopSize=HOP, precision=precision)
+        plan = tt._get_plan()
+        dt = np.float64 if precision == 'float64' else np.float32
+        a = ctx.to_device(np.ascontiguousarray(base.T), dt)
+        T, F = _frame_count(L), N // 2 + 1
+        mag = torch.empty((cols, T, F), dtype=a.dtype, device=a.device)
+        for _ in range(3):
+            plan.forward_clips(a, phase=False, mag_out=mag)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        with ctx.stream_scope():
+            ev0.record()
+            for _ in range(reps):
+                plan.forward_clips(a, phase=False, mag_out=mag)
+            ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / reps
+        nbytes = cols * (L + T * F) * np.dtype(dt).itemsize
+        tt.compute_transform(base, phase=False, save=False)
+        t0 = time.perf_counter()
+        tt.compute_transform(base, phase=False, save=False)
+        wall = time.perf_counter() - t0
+        res["cases"]["N%d_%s" % (N, precision)] = {
+            "frames": int(cols * T), "kernel_ms": round(ms, 4), "frames_per_s": round(cols * T / (ms * 1e-3), 1),
+            "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+            "host_to_host_ms": round(wall * 1e3, 2), "host_to_host_frames_per_s": round(cols * T / wall, 1),
+            "output_MB": round(cols * T * F * 8 / 1e6, 1)}
+        del a, mag, tt
+    torch.cuda.empty_cache()
+    return res
+
+
+def _frame_count(L, hop=HOP):
+    return int(np.ceil(L / float(hop)) + 2)
 
 
 def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_audio, synth_params, synth_score_text,

@@ -68,6 +68,8 @@ def load():
     proto("dcs_stft_plan_destroy", i32, vp)
     proto("dcs_stft_forward_f32", i32, vp, vp, i64, vp, vp, i64, i64)
     proto("dcs_stft_forward_f64", i32, vp, vp, i64, vp, vp, i64, i64)
+    proto("dcs_stft_forward_f32_clips", i32, vp, vp, i64, i64, i64, vp, vp, i64, i64)
+    proto("dcs_stft_forward_f64_clips", i32, vp, vp, i64, i64, i64, vp, vp, i64, i64)
     proto("dcs_stft_inverse_f32", i32, vp, vp, i64, vp, i64, i64, i32, f32, vp, i64)
     proto("dcs_stft_inverse_f64", i32, vp, vp, i64, vp, i64, i64, i32, f64, vp, i64)
     proto("dcs_tile", i32, vp, vp, i64, i64, i32, i64, i32, i32, i32, i32, f32, vp, i64)

@@ -399,6 +399,35 @@ extern "C" int dcs_stft_forward_f64(dcs_stft* p, const double* audio_d, int64_t 
     return forward_checked<double, double2>(p, audio_d, n, mag_d, phase_d, ld, rows_out, dcs_launch_stft_forward_f64);
 }
 
+// compute_transform (transform.py:80-131): every column of audio[t, i] -- n_clips signals of equal length -- in ONE launch
+static int forward_clips_check(dcs_stft* p, const void* audio, int64_t L, int64_t n_clips, int64_t clip_stride, const void* mag,
+                               int64_t ld, int64_t rows_out, int64_t* T) {
+    if (!p || !mag || (!audio && L > 0)) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward_clips: null argument");
+    if (L < 0 || n_clips < 0) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward_clips: negative size");
+    if (n_clips > 1 && clip_stride < L) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward_clips: clip stride %lld < length %lld", (long long)clip_stride, (long long)L);
+    *T = dcs_frame_count(L, p->hop);
+    if (ld < p->frame / 2 + 1) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: ld %lld < bins %d", (long long)ld, p->frame / 2 + 1);
+    if (rows_out < *T) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward: rows_out %lld < frames %lld", (long long)rows_out, (long long)*T);
+    if (rows_out * n_clips > 0x7fffffffLL) DCS_FAIL(DCS_EINVAL, "dcs_stft_forward_clips: %lld rows in one launch", (long long)(rows_out * n_clips));
+    return DCS_OK;
+}
+extern "C" int dcs_stft_forward_f32_clips(dcs_stft* p, const float* audio_d, int64_t n, int64_t n_clips, int64_t clip_stride,
+                                          float* mag_d, float* phase_d, int64_t ld, int64_t rows_out) {
+    int64_t T = 0;
+    DCS_CHECK(forward_clips_check(p, audio_d, n, n_clips, clip_stride, mag_d, ld, rows_out, &T));
+    if (n_clips == 0) return DCS_OK;
+    DCS_ON_DEVICE(p->ctx->device);
+    return dcs_launch_stft_forward_f32_clips(p, audio_d, n, clip_stride, n_clips, mag_d, phase_d, nullptr, ld, rows_out, T, false);
+}
+extern "C" int dcs_stft_forward_f64_clips(dcs_stft* p, const double* audio_d, int64_t n, int64_t n_clips, int64_t clip_stride,
+                                          double* mag_d, double* phase_d, int64_t ld, int64_t rows_out) {
+    int64_t T = 0;
+    DCS_CHECK(forward_clips_check(p, audio_d, n, n_clips, clip_stride, mag_d, ld, rows_out, &T));
+    if (n_clips == 0) return DCS_OK;
+    DCS_ON_DEVICE(p->ctx->device);
+    return dcs_launch_stft_forward_f64_clips(p, audio_d, n, clip_stride, n_clips, mag_d, phase_d, ld, rows_out, T);
+}
+
 template <typename R, typename R2>
 static int inverse_checked(dcs_stft* p, const R* mag, int64_t src_stride, const R* phase, int64_t ld, int64_t T,
                            int n_src, R pre_div, R* audio, int64_t n_out,

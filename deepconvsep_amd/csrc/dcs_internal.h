@@ -187,6 +187,8 @@ int dcs_launch_stft_inverse_f32_clips(dcs_stft* p, const float* mag, int64_t src
                                       int64_t out_stride = 0);
 int dcs_launch_stft_forward_f64(dcs_stft* p, const double* audio, int64_t L, double* mag, double* phase,
                                 double2* unit, int64_t ld, int64_t rows_out, int64_t T);
+int dcs_launch_stft_forward_f64_clips(dcs_stft* p, const double* audio, int64_t L, int64_t audio_stride, int64_t n_clips,
+                                      double* mag, double* phase, int64_t ld, int64_t rows_out, int64_t T);
 int dcs_launch_stft_inverse_f32(dcs_stft* p, const float* mag, int64_t src_stride, const float* phase,
                                 const float2* unit, int64_t ld, int64_t T, int n_src, float pre_div, float* audio,
                                 int64_t n_out);

@@ -179,6 +179,24 @@ class StftPlan(object):
         return mag, ph
 
     @_on_ctx_stream
+    def forward_clips(self, audio_t, phase=True, mag_out=None, phase_out=None):
+        """``compute_transform`` (transform.py:80-131): audio_t ``[clips, samples]`` float32 / float64 device tensor (rows
+        contiguous) -> (mag, phase|None) ``[clips, T, bins]`` from ONE launch (``dcs_stft_forward_f32/f64_clips``)."""
+        torch = _torch()
+        if audio_t.dim() != 2 or audio_t.stride(1) != 1:
+            raise ValueError("forward_clips expects a [clips, samples] tensor with contiguous rows")
+        B, L = int(audio_t.shape[0]), int(audio_t.shape[1])
+        T = _lib.frame_count(L, self.hop)
+        f64 = audio_t.dtype == torch.float64
+        mag = mag_out if mag_out is not None else torch.empty((B, T, self.bins), dtype=audio_t.dtype, device=audio_t.device)
+        ph = None
+        if phase:
+            ph = phase_out if phase_out is not None else torch.empty((B, T, self.bins), dtype=audio_t.dtype, device=audio_t.device)
+        fn = self.ctx._lib.dcs_stft_forward_f64_clips if f64 else self.ctx._lib.dcs_stft_forward_f32_clips
+        _lib.check(fn(self._h, _ptr(audio_t), L, B, int(audio_t.stride(0)), _ptr(mag), _ptr(ph), self.bins, T))
+        return mag, ph
+
+    @_on_ctx_stream
     def inverse(self, mag_t, phase_t, n_out=None, pre_div=1.0):
         """mag_t ``[S, T, ld]`` or ``[T, ld]``, phase_t ``[T, ld]`` (same ld).  Returns ``[S, n_out]``
         (or ``[n_out]``)."""

@@ -66,7 +66,8 @@ class Transforms(object):
     # -- transform.py:80-131 -------------------------------------------------------------------
     def compute_transform(self, audio, out_path=None, phase=False, save=True):
         """STFT of every column of ``audio[t, i]``; saved as ``.data``/``.shape`` or returned as
-        ``[i, T, F]`` float64."""
+        ``[i, T, F]`` float64.  (Base class: column by column through ``compute_file``; :class:`transformFFT` transforms all
+        columns in one launch.)"""
         self.out_path = out_path
         mags = phs = None
         for i in range(audio.shape[1]):
@@ -81,6 +82,9 @@ class Transforms(object):
             mags[i] = mag
             if phase:
                 phs[i] = ph
+        return self._finish_transform(mags, phs, phase, save)
+
+    def _finish_transform(self, mags, phs, phase, save):
         if save and self.out_path is not None:
             self.saveTensor(mags, '_' + self.suffix + '_m_')
             if phase:
@@ -142,6 +146,38 @@ class transformFFT(Transforms):
 
     def _np_dtype(self):
         return np.float64 if self.precision == 'float64' else np.float32
+
+    def compute_transform(self, audio, out_path=None, phase=False, save=True):
+        """``compute_transform`` (transform.py:80-131; the dataset builders call it once per song with the mixture and
+        the sources as columns, examples/dsd100/compute_features.py:83-112): ALL columns of ``audio[t, i]`` go through
+        the device in one upload, ONE STFT launch (``dcs_stft_forward_f64_clips``; float32 with ``precision='float32'``) and
+        one download into pinned memory, from which the ``.data`` file is written directly -- ``[i, T, F]`` float64, the
+        array the reference builds column by column."""
+        import torch
+        self.out_path = out_path
+        audio = np.asarray(audio)
+        if audio.ndim != 2:
+            raise IndexError("tuple index out of range")           # audio.shape[1] of a 1-D array (transform.py:107)
+        if audio.shape[1] == 0:
+            raise UnboundLocalError("local variable 'mags' referenced before assignment")    # the loop never runs (:107-121)
+        plan = self._get_plan()
+        ctx = plan.ctx
+        with ctx.stream_scope():
+            a = ctx.to_device(audio, self._np_dtype()).t().contiguous()          # [i, t] rows = signals (device transpose)
+            mag, ph = plan.forward_clips(a, phase=phase)
+            outs = []
+            for t in (mag, ph):
+                if t is None:
+                    outs.append(None)
+                    continue
+                t64 = t if t.dtype == torch.float64 else t.double()
+                host = torch.empty(t64.shape, dtype=torch.float64).pin_memory()
+                host.copy_(t64, non_blocking=True)
+                outs.append(host)
+            ctx.torch_stream.synchronize()
+        mags = outs[0].numpy()
+        phs = outs[1].numpy() if phase else None
+        return self._finish_transform(mags, phs, phase, save)
 
     def compute_file(self, audio, phase=False, sampleRate=44100):
         """``mag = |STFT| / sqrt(frameSize)`` (``[T, frameSize/2+1]`` float64) and, with

@@ -104,6 +104,15 @@ DCS_API int dcs_stft_forward_f32(dcs_stft* plan, const float* audio_d, int64_t n
 DCS_API int dcs_stft_forward_f64(dcs_stft* plan, const double* audio_d, int64_t n_samples, double* mag_d,
                          double* phase_d, int64_t ld, int64_t rows_out);
 
+/* compute_transform (transform.py:80-131; caller examples/dsd100/compute_features.py:83-112): the same transform for every
+ * column of audio[t, i] -- n_clips signals of n_samples each, signal c at audio_d + c * clip_stride -- in ONE launch:
+ * mag_d / phase_d [n_clips][rows_out, ld], i.e. the reference's mags[i] = compute_file(audio[:, i]) stacked, ready to be
+ * written as the .data file.  phase_d may be NULL. */
+DCS_API int dcs_stft_forward_f32_clips(dcs_stft* plan, const float* audio_d, int64_t n_samples, int64_t n_clips, int64_t clip_stride,
+                               float* mag_d, float* phase_d, int64_t ld, int64_t rows_out);
+DCS_API int dcs_stft_forward_f64_clips(dcs_stft* plan, const double* audio_d, int64_t n_samples, int64_t n_clips, int64_t clip_stride,
+                               double* mag_d, double* phase_d, int64_t ld, int64_t rows_out);
+
 /* compute_inverse for n_src magnitude matrices sharing one phase:       transform.py:271-273, 337-396
  *   X = (mag / pre_div) * sqrt(N) * exp(j*phase) -> irfft -> window -> overlap-add -> / sum(w*w)
  * mag_d [n_src][n_frames, ld] (source stride src_stride elements), phase_d [n_frames, ld],

@@ -110,6 +110,42 @@ def test_compute_transform_writes_reference_format(tmp_path):
     assert np.array_equal(back, mags)
 
 
+@pytest.mark.parametrize("N,hop,precision,cols,L", [(1024, 512, 'float64', 5, 30011), (4096, 512, 'float64', 3, 20000),
+                                                     (2048, 512, 'float32', 5, 30011), (512, 200, 'float64', 2, 7001)])
+def test_compute_transform_all_columns_in_one_launch(N, hop, precision, cols, L, tmp_path):
+    """transformFFT.compute_transform (transform.py:80-131): every column of audio[t, i] through ONE STFT launch
+    (dcs_stft_forward_f64_clips / _f32_clips) equals compute_file column by column -- the same kernel per frame: bit for bit --
+    and the oracle (float64 1e-11, float32 2e-5); magnitudes and phases land in the .data / .shape files in the
+    reference's layout [i, T, F]; the reference's failure modes for a 1-D array and for zero columns."""
+    audio = np.stack([synth_audio(L, seed=80 + c) for c in range(cols)], axis=1)
+    audio[:, 1] = 0.0                                                # a silent column
+    tt = dcs.transformFFT(frameSize=N, hopSize=hop, suffix="s", precision=precision)
+    mags, phs = tt.compute_transform(audio, phase=True, save=False)
+    T, F = stft_np.frame_count(L, hop), N // 2 + 1
+    assert mags.shape == phs.shape == (cols, T, F) and mags.dtype == phs.dtype == np.float64
+    tol = 1e-11 if precision == 'float64' else 2e-5
+    for c in range(cols):
+        m1, p1 = tt.compute_file(audio[:, c], phase=True)
+        assert np.array_equal(mags[c], m1) and np.array_equal(phs[c], p1)
+        m0, p0 = stft_np.compute_file(audio[:, c], phase=True, frameSize=N, hopSize=hop)
+        assert np.max(np.abs(mags[c] - m0)) < tol
+        z = mags[c] * np.exp(1j * phs[c]) - m0 * np.exp(1j * p0)      # phases compare through the spectrum (angle wraps)
+        assert np.max(np.abs(z)) < 2 * tol
+    assert not mags[1].any()
+    out = str(tmp_path / "song.data")
+    assert tt.compute_transform(audio, out_path=out, phase=True, save=True) is None
+    for tag, want in (("_s_m_", mags), ("_s_p_", phs)):
+        shape = tt.get_shape(out.replace(".data", tag + ".shape"))
+        assert shape == (cols, T, F)
+        assert np.array_equal(np.fromfile(out.replace(".data", tag + ".data")).reshape(shape), want)
+    only = tt.compute_transform(audio, phase=False, save=False)
+    assert np.array_equal(only, mags)
+    with pytest.raises(IndexError):
+        tt.compute_transform(audio[:, 0])
+    with pytest.raises(UnboundLocalError):
+        tt.compute_transform(audio[:, :0])
+
+
 # ------------------------------------------------------------------------------------------ tiling
 @pytest.mark.parametrize("name", TILE_CASES)
 def test_generate_overlapadd_matches_reference(golden, name):
