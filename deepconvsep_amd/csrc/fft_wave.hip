@@ -979,6 +979,214 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// inverse, chained form (round 5): the barrier-free kernel above gives every wave C hop-blocks AND the R - 1 frames in front
+// of them to warm its accumulators up -- at the launch-group sizes of a batch-of-files server (C = 8, R = 4) three of a wave's
+// eleven frames, and a launch lasts as long as its longest chain of frames.  Here the NW = 8 waves of a workgroup walk NW
+// CONSECUTIVE runs of LC frames of ONE source: only the first wave of a workgroup warms up (its R - 1 first blocks belong to
+// the workgroup on its left), every other wave starts cold and leaves the R - 1 blocks it cannot complete -- its "head" --
+// as partial sums in LDS, and the wave on its left, whose last R - 1 accumulators -- its "tail" -- are the missing halves,
+// adds the two after ONE workgroup barrier at the end: block = tail + head, i.e. (frames g-3.. of the left wave, added in
+// order) + (frames .. g of the right wave, added in order).  The reference adds the frames of a block strictly in order
+// (transform.py:381-389); here the R - 1 blocks at each of the NW - 1 seams of a workgroup add two in-order partial sums
+// instead -- the same float32 error class (one rounding per addend either way), not the same bits; every other block is
+// accumulated exactly as before.  A chain is LC frames instead of C + R - 1 for the same number of resident waves: 8 against 11
+// at 20 x 32 tiles, 12 against 15 at 32 x 32.  Costs (R - 1) * hop floats of LDS per seam (118 KB per workgroup at N = 2048:
+// one workgroup of 8 waves per CU -- the register budget of 2 waves per SIMD allows no more anyway).
+// Phasor input only (the fused paths); frames of R in {2, 4} hop-blocks, N <= 2048, like the kernel above.
+// ------------------------------------------------------------------------------------------------
+constexpr int kChainWaves = 8;
+template <int LOG2M, int R>
+__global__ __launch_bounds__(64 * kChainWaves) void istft_chain_kernel(const float* __restrict__ mag, int64_t src_stride,
+                                                                        const float2* __restrict__ unit, int64_t ld,
+                                                                        const float* __restrict__ win, const float* __restrict__ wsq,
+                                                                        const float2* __restrict__ tw, float* __restrict__ audio,
+                                                                        int64_t n_out, int64_t T, int LC, int G /* workgroups per source */,
+                                                                        int64_t n_blocks, int64_t n_units, float pre_div, float sqrt_n,
+                                                                        int64_t unit_clip_stride, int src_per_clip,
+                                                                        const int64_t* __restrict__ clip_tab, int64_t out_stride) {
+    constexpr int M = 1 << LOG2M, N = 2 * M, P = M / 64, MP = M + M / 32, NW = kChainWaves;
+    constexpr int hop = N / R, hp = hop / 2, VPB = hp / 64;   // sample pairs a lane owns in one hop-block
+    constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
+    static_assert(WaveTw<LOG2M>::REG3 && VPB * R == P && VPB >= 1, "lean twiddles, whole pairs per lane");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* winl = reinterpret_cast<float2*>(smem);          // [M] window pairs times 1/M
+    float2* fbuf = winl + M;                                 // [NW][MP]
+    float2* heads = fbuf + NW * MP;                          // [NW - 1][R - 1][hp]: wave w's head blocks at (w - 1)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2* buf = fbuf + wave * MP;
+    const float inv_m = 1.f / (float)M;
+    {
+        const float2* w2g = reinterpret_cast<const float2*>(win);
+        for (int k = tid; k < M; k += 64 * NW) stc(winl + k, ldc(w2g + k) * inv_m);
+    }
+    // workgroup -> (unit = (clip, run of the clip), source of the clip): the sources of a unit read the same phasor rows; they get
+    // block ids 8 apart (same XCD, dispatched together), so one of them pulls a row from HBM and the others hit that L2
+    int64_t u;
+    int s4;
+    {
+        const int64_t b = blockIdx.x, full = (n_units >> 3) * 8 * src_per_clip;
+        if (b < full) {
+            u = (b / (8 * src_per_clip)) * 8 + (b & 7);
+            s4 = (int)((b >> 3) % src_per_clip);
+        } else {
+            const int64_t r = n_units & 7, b2 = b - full;
+            u = (n_units >> 3) * 8 + b2 % r;
+            s4 = (int)(b2 / r);
+        }
+    }
+    const int64_t clip = u / G;
+    const int jg = (int)(u - clip * G);
+    const int64_t s = clip * src_per_clip + s4;
+    if (clip_tab) {   // clips of different lengths: this source's own sample / frame / hop-block counts
+        n_out = clip_tab[kDcsClipTab * clip];
+        T = clip_tab[kDcsClipTab * clip + 1];
+        n_blocks = (n_out + M + hop - 1) / hop;
+    }
+    const int64_t Sb = (int64_t)NW * LC - (R - 1);           // blocks a workgroup owns (the first one of a source R - 1 more)
+    const int64_t wg0 = (int64_t)jg * Sb;                     // first frame slot of the workgroup
+    const int64_t blk0 = jg == 0 ? 0 : wg0 + (R - 1);         // first block it owns
+    if (blk0 >= n_blocks) return;                             // workgroup-uniform, before any barrier
+    __syncthreads();
+    const int64_t f0 = wg0 + (int64_t)wave * LC, f1 = f0 + LC;   // this wave's frame slots [f0, f1)
+    const int64_t n_last = T - 1;
+    const float amp = 0.5f * (sqrt_n / pre_div);
+    const float* msrc = mag + s * src_stride;
+    {
+        const int64_t r0_ = clip_tab ? clip_tab[kDcsClipTab * clip + 3] : -1;
+        unit += r0_ >= 0 ? r0_ * ld : clip * unit_clip_stride;
+    }
+    float* dst = audio + s * out_stride;
+    const bool dst_al = (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
+    WaveTw<LOG2M> wt;
+    wt.init(tw, lane);
+    const cx wl = ldc(tw + lane);
+    cx nrm[VPB];
+#pragma unroll
+    for (int v = 0; v < VPB; ++v) {
+        const int q = 2 * (lane + 64 * v);
+        float nx = 0.f, ny = 0.f;
+#pragma unroll
+        for (int d = R - 1; d >= 0; --d) {   // frames in increasing order
+            nx += wsq[q + d * hop];
+            ny += wsq[q + 1 + d * hop];
+        }
+        nrm[v] = mk(nx == 0.f ? 1.f : 1.f / nx, ny == 0.f ? 1.f : 1.f / ny);
+    }
+    cx acc[R][VPB];
+#pragma unroll
+    for (int d = 0; d < R; ++d)
+#pragma unroll
+        for (int v = 0; v < VPB; ++v) acc[d][v] = mk(0.f, 0.f);
+    const float2* wlane = winl + lane;
+    const float2* blane = buf + pad(lane);
+    // block g is complete: normalise by the frames that reach it and store (the steady-state blocks multiply by the reciprocal
+    // kept in registers, the first / last R - 1 blocks of a signal divide by their own sum -- as in the kernel above)
+    auto store_block = [&](int64_t g, const cx (&blk)[VPB]) {
+        const bool steady = g >= R - 1 && g <= T - 1;
+        const int64_t m0 = g * hop - M;
+        if (steady && dst_al && m0 >= 0 && m0 + hop <= n_out) {
+            float* op = dst + m0 + 2 * lane;
+#pragma unroll
+            for (int vv = 0; vv < VPB; ++vv) *reinterpret_cast<cx*>(op + 128 * vv) = blk[vv] * nrm[vv];
+            return;
+        }
+        const int64_t f_hi = g < T - 1 ? g : T - 1;
+        const int64_t f_lo = g < R ? 0 : g - (R - 1);
+#pragma unroll
+        for (int vv = 0; vv < VPB; ++vv) {
+            const int q = 2 * (lane + 64 * vv);
+            const int64_t m = m0 + q;
+            if (m + 1 < 0 || m >= n_out) continue;
+            float nx = 0.f, ny = 0.f;
+            for (int64_t f = f_lo; f <= f_hi; ++f) {
+                nx += wsq[(g - f) * hop + q];
+                ny += wsq[(g - f) * hop + q + 1];
+            }
+            if (nx == 0.f) nx = 1.f;
+            if (ny == 0.f) ny = 1.f;
+            if (m >= 0) dst[m] = steady ? blk[vv][0] * nrm[vv][0] : blk[vv][0] / nx;
+            if (m + 1 < n_out) dst[m + 1] = steady ? blk[vv][1] * nrm[vv][1] : blk[vv][1] / ny;
+        }
+    };
+    for (int64_t nb = (f0 / R) * R; nb < f1; nb += R) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int64_t n = nb + j;
+            if (n < f0 || n >= f1) continue;        // wave-uniform; slots outside the wave's run leave the accumulators alone
+            if (n <= n_last) {
+                const float* mrow = msrc + n * ld;
+                const float2* urow = unit + n * ld;
+                cx v[P];
+#pragma unroll
+                for (int b = 0; b < NB1; ++b)
+#pragma unroll
+                    for (int tt = 0; tt < R1; ++tt) {
+                        const int k = lane + 64 * b + tt * stride1;  // 0 <= k < M
+                        const int km = M - k;                         // 1..M
+                        const float a = mrow[k] * amp;
+                        const float b2 = mrow[km] * amp;
+                        cx xk = ldc(urow + k) * a;
+                        cx xm = ldc(urow + km) * b2;
+                        if (b == 0 && tt == 0) {  // k == 0 only there: imaginary parts of DC / Nyquist are ignored (numpy irfft)
+                            if (lane == 0) {
+                                xk[1] = 0.f;
+                                xm[1] = 0.f;
+                            }
+                        }
+                        const cx e = c_add_conj(xk, xm), d = c_sub_conj(xk, xm);
+                        const int jj = (b + tt * NB1) * (1024 / M);
+                        const cx wk = jj == 0 ? wl : c_mul(wl, w_pi16(jj));
+                        const cx o = c_mul_conj(d, wk);
+                        v[b * R1 + tt] = c_add_i(e, o);
+                    }
+                fft_wave<LOG2M, +1>(v, lane, wt, tw, buf);
+                // frame n covers the hop-blocks n .. n + R - 1: block g lives in register slot g % R = (j + d) % R
+#pragma unroll
+                for (int d = 0; d < R; ++d)
+#pragma unroll
+                    for (int vv = 0; vv < VPB; ++vv) {
+                        const int k = d * hp + 64 * vv;
+                        const cx z = ldc(blane + cpad(k));
+                        acc[(j + d) % R][vv] += z * ldc(wlane + k);
+                    }
+            }
+            // block g = n has received every frame of THIS wave that touches it
+            const int64_t g = n;
+            const bool head = g < f0 + (R - 1) && f0 > 0;            // frames before f0 reach it too (f0 == 0: nothing before)
+            if (!head) {
+                if (g < n_blocks) store_block(g, acc[j]);
+            } else if (wave > 0) {                                    // the left wave completes it after the barrier
+                float2* hb = heads + ((wave - 1) * (R - 1) + (int)(g - f0)) * hp + lane;
+#pragma unroll
+                for (int vv = 0; vv < VPB; ++vv) stc(hb + 64 * vv, acc[j][vv]);
+            }                                                         // wave 0 of a later workgroup: warm-up, the left workgroup owns it
+#pragma unroll
+            for (int vv = 0; vv < VPB; ++vv) acc[j][vv] = mk(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    if (wave < NW - 1) {   // the seam with the wave on the right: blocks f1 .. f1 + R - 2 = my tail + its head
+#pragma unroll
+        for (int d = 0; d < R - 1; ++d) {
+            const int64_t g = f1 + d;
+            if (g >= n_blocks) break;
+            const float2* hb = heads + (wave * (R - 1) + d) * hp + lane;
+            cx sum[VPB];
+            const int slot = (int)(g % R);
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+                if (q == slot) {
+#pragma unroll
+                    for (int vv = 0; vv < VPB; ++vv) sum[vv] = acc[q][vv] + ldc(hb + 64 * vv);
+                }
+            store_block(g, sum);
+        }
+    }
+}
+
 template <int LOG2M>
 int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride, int64_t n_clips, float* mag,
                float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave,
@@ -1042,6 +1250,53 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
                                (unit_clip_stride & 1) == 0 &&
                                ((reinterpret_cast<uintptr_t>(mag) | reinterpret_cast<uintptr_t>(unit)) & 15) == 0;
             const size_t lds_stage = lds_s + (2 * (size_t)(M + 4)) * sizeof(float2) + 4 * (size_t)(M + 4) * sizeof(float);
+            // chained form (istft_chain_kernel): when the staged form does not apply and its chain of frames is strictly shorter
+            // than this kernel's Cs + R - 1.  LC = the fewest frames per wave for which every workgroup of the launch is resident
+            // at once (one workgroup of 8 waves per CU at N = 2048).
+            static const int chain_env = getenv("DCS_ISTFT_CHAIN") ? atoi(getenv("DCS_ISTFT_CHAIN")) : 1;   // 0: off; > 1: LC
+            if (chain_env && unit && !stage && n_src % spc == 0) {
+                const size_t lds_c = ((size_t)M + kChainWaves * (size_t)MP + (size_t)(kChainWaves - 1) * (R_ - 1) * (hop / 2)) * sizeof(float2);
+                const int64_t n_clips_c = n_src / spc;
+                // workgroups of 8 waves the chip holds at once: registers (230 .. 254 at N = 2048: one per CU) and LDS decide
+                static int wg_cache[2][64];                          // [R == 4][device]; 0 = not asked yet (a race writes the same value twice)
+                const int dev_i = p->ctx->device >= 0 && p->ctx->device < 64 ? p->ctx->device : 0;
+                int wg_per_cu = wg_cache[R_ == 4][dev_i];
+                if (wg_per_cu == 0) {
+                    const hipError_t e = R_ == 4
+                        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, istft_chain_kernel<LOG2M, 4>, 64 * kChainWaves, lds_c)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, istft_chain_kernel<LOG2M, 2>, 64 * kChainWaves, lds_c);
+                    if (e != hipSuccess || wg_per_cu < 1) { (void)hipGetLastError(); wg_per_cu = 1; }
+                    wg_cache[R_ == 4][dev_i] = wg_per_cu;
+                }
+                const int64_t resident_wg = (int64_t)p->ctx->n_cu * wg_per_cu;
+                int64_t LC = R_ - 1 > 1 ? R_ - 1 : 1, Gc = 0;
+                for (;; ++LC) {
+                    const int64_t Sb = (int64_t)kChainWaves * LC - (R_ - 1);
+                    Gc = n_blocks <= R_ - 1 ? 1 : (n_blocks - (R_ - 1) + Sb - 1) / Sb;
+                    if (Gc * n_src <= resident_wg || LC >= Cs + R_ - 1) break;
+                }
+                if (chain_env > 1) {
+                    LC = chain_env < R_ - 1 ? R_ - 1 : chain_env;
+                    const int64_t Sb = (int64_t)kChainWaves * LC - (R_ - 1);
+                    Gc = n_blocks <= R_ - 1 ? 1 : (n_blocks - (R_ - 1) + Sb - 1) / Sb;
+                }
+                if ((LC < Cs + R_ - 1 || chain_env > 1) && lds_c <= 160 * 1024 && Gc * n_src < 0x7fffffff) {
+                    const int64_t n_units = n_clips_c * Gc;
+#define DCS_CHAIN(R__)                                                                                               \
+                    {                                                                                                \
+                        auto kern = istft_chain_kernel<LOG2M, R__>;                                                  \
+                        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));        \
+                        hipLaunchKernelGGL(kern, dim3((unsigned)(n_units * spc)), dim3(64 * kChainWaves), lds_c, p->ctx->stream, mag, \
+                                           src_stride, unit, ld, p->win_f, p->wsq_f, p->tw_f, audio, n_out, T, (int)LC, (int)Gc, \
+                                           n_blocks, n_units, pre_div, (float)sqrt((double)N), unit_clip_stride, spc, clip_tab, \
+                                           out_stride > 0 ? out_stride : n_out);                                     \
+                    }
+                    if (R_ == 4) DCS_CHAIN(4) else DCS_CHAIN(2)
+#undef DCS_CHAIN
+                    return DCS_OK;
+                }
+            }
 #define DCS_SEQ_STAGE(R__)                                                                                           \
             {                                                                                                        \
                 auto kern = stage_env == 2 ? istft_seq_kernel<LOG2M, true, R__, 2> : istft_seq_kernel<LOG2M, true, R__, 1>; \

@@ -1160,6 +1160,7 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
     {"DCS_GRAPH": "0"},
     {"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE_MIN": "1", "DCS_ISTFT_STAGE": "2"},   # spectra through LDS (long clips' iSTFT) on a short clip
     {"DCS_ISTFT_STAGE": "0"},
+    {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "7"},   # chained iSTFT off / forced frames per wave
 ])
 @pytest.mark.parametrize("N", [1024, 2048])
 def test_kernel_variants_selected_by_size_agree_with_the_oracle(env, N, tmp_path):
@@ -1221,6 +1222,7 @@ sys.exit(0 if (e_many < 5e-6 and e_same < 5e-6 and e_ref < 1e-4) else 3)
 
 @pytest.mark.parametrize("N", [1024, 2048])
 @pytest.mark.parametrize("env", [{"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE": "0"},
+                                 {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "5"},   # chained iSTFT: off, forced run lengths (seams at other places)
                                  {"DCS_FORK": "1", "DCS_FORK_MIN_CLIPS": "2"},    # the front of a batch as two half-chains on two streams
                                  {"DCS_RAGGED_COMPACT": "0"}])                    # ragged groups at the uniform pitch of round 3 (default: per-clip row / tile offsets)
 def test_staged_istft_on_ragged_groups_and_batches(env, N, tmp_path):
