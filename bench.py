@@ -957,7 +957,8 @@ def run_cli(torch, dcs, synth_audio, synth_params):
                                "ms_per_file": steady["ms_per_file"],
                                "x_realtime": round(Lc / float(SR) / (steady["ms_per_file"] * 1e-3), 1),
                                "frames_per_s": round(frames / (steady["ms_per_file"] * 1e-3), 1),
-                               "workers": steady.get("workers"), "path": steady.get("path"),
+                               "workers": steady.get("workers"), "path": steady.get("path"), "group": steady.get("group"),
+                               "main_thread_ms_per_file": steady.get("main_thread_ms_per_file"),
                                "note": "separate_batch.py --stats over 550 wav files (int16 frames read into pinned staging, H2D, "
                                        "device mix-down, kernels, device int16 conversion, D2H, 4 wavs written per file by a "
                                        "pool of I/O threads), clock started when the model is resident"}
@@ -1073,11 +1074,21 @@ def run_transform_leg(torch, dcs, synth_audio):
         t0 = time.perf_counter()
         tt.compute_transform(base, phase=False, save=False)
         wall = time.perf_counter() - t0
+        # as the dataset builders call it: results into the .data / .shape files (pinned staging block reused song after song)
+        tdir = tempfile.mkdtemp(prefix="dcs_tf_")
+        tt.suffix = "b"
+        tt.compute_transform(base, out_path=os.path.join(tdir, "song.data"), phase=False, save=True)
+        t0 = time.perf_counter()
+        tt.compute_transform(base, out_path=os.path.join(tdir, "song.data"), phase=False, save=True)
+        wall_file = time.perf_counter() - t0
+        import shutil
+        shutil.rmtree(tdir, ignore_errors=True)
         res["cases"]["N%d_%s" % (N, precision)] = {
             "frames": int(cols * T), "kernel_ms": round(ms, 4), "frames_per_s": round(cols * T / (ms * 1e-3), 1),
             "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
             "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
             "host_to_host_ms": round(wall * 1e3, 2), "host_to_host_frames_per_s": round(cols * T / wall, 1),
+            "to_data_file_ms": round(wall_file * 1e3, 2), "to_data_file_frames_per_s": round(cols * T / wall_file, 1),
             "output_MB": round(cols * T * F * 8 / 1e6, 1)}
         del a, mag, tt
     torch.cuda.empty_cache()

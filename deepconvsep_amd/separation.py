@@ -285,7 +285,7 @@ class Separator(object):
         (separate_dsd.py:285-287; iKala: L + R, separate_ikala.py:229) and the int16 conversion run on the device
         (``dcs_pcm16_to_float`` / ``dcs_pcm_to_int16``, float64 arithmetic like the scripts'): the values are those of
         ``separate_many(to_mono(read_wav(f)))`` + ``write_wav`` bit for bit, for a quarter of the PCIe bytes.  Grouping as in
-        :meth:`separate_many` (clips of one group also share their channel count).  The returned arrays are views of a ring
+        :meth:`separate_many`.  The returned arrays are views of a ring
         of ``ring`` pinned host buffers: they stay valid until ``ring - 1`` further calls have been made (copy them to keep
         them longer); ``ring=0`` returns fresh arrays."""
         import torch
@@ -320,11 +320,11 @@ class Separator(object):
             raise bad[min(bad)]
         for i, exc in bad.items():
             out[i] = exc
-        groups = []
-        for ch in sorted(set(chans)):
-            idx = [i for i in range(len(tens)) if chans[i] == ch and i not in bad]
-            for g in length_groups([frames[i] for i in idx], max_group if self.arch.C == 1 else 1, max_ratio):
-                groups.append([idx[k] for k in g])
+        # groups by length alone, exactly as separate_many forms them (the channel count only matters for the mix-down, which
+        # is done clip by clip): the same clips share the same launches on either path, so the results agree bit for bit
+        idx_ok = [i for i in range(len(tens)) if i not in bad]
+        groups = [[idx_ok[k] for k in g]
+                  for g in length_groups([frames[i] for i in idx_ok], max_group if self.arch.C == 1 else 1, max_ratio)]
         if not groups:
             return out
         # one pinned output block per call, cut out of a small ring: the writer threads of the caller stream the int16
@@ -344,14 +344,14 @@ class Separator(object):
         views = []
         dev = self.ctx.device
         for idx in groups:
-            ch = chans[idx[0]]
             lens = [frames[i] for i in idx]
             B, Lmax = len(idx), max(lens)
-            stack = torch.zeros((B, Lmax * ch), dtype=torch.int16, device=dev) if min(lens) != Lmax else \
-                torch.empty((B, Lmax * ch), dtype=torch.int16, device=dev)
+            mono = torch.zeros((B, Lmax), dtype=torch.float32, device=dev) if min(lens) != Lmax else \
+                torch.empty((B, Lmax), dtype=torch.float32, device=dev)
             for b, i in enumerate(idx):
-                stack[b, :lens[b] * ch].copy_(tens[i].reshape(-1), non_blocking=True)
-            mono = pcm16_to_float(self.ctx, stack, ch, mode)                                        # [B, Lmax] float32
+                raw = torch.empty((1, lens[b] * chans[i]), dtype=torch.int16, device=dev)
+                raw[0].copy_(tens[i].reshape(-1), non_blocking=True)
+                pcm16_to_float(self.ctx, raw, chans[i], mode, out=mono[b:b + 1, :lens[b]])
             if B == 1:
                 pcm = self.net.separate(self.plan, mono[0], self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)[None]
             elif min(lens) == Lmax:

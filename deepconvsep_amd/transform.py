@@ -162,22 +162,37 @@ class transformFFT(Transforms):
             raise UnboundLocalError("local variable 'mags' referenced before assignment")    # the loop never runs (:107-121)
         plan = self._get_plan()
         ctx = plan.ctx
+        keep = save and self.out_path is not None          # the arrays only live until the .data files are written
         with ctx.stream_scope():
             a = ctx.to_device(audio, self._np_dtype()).t().contiguous()          # [i, t] rows = signals (device transpose)
             mag, ph = plan.forward_clips(a, phase=phase)
             outs = []
-            for t in (mag, ph):
+            for role, t in (("m", mag), ("p", ph)):
                 if t is None:
                     outs.append(None)
                     continue
                 t64 = t if t.dtype == torch.float64 else t.double()
-                host = torch.empty(t64.shape, dtype=torch.float64).pin_memory()
-                host.copy_(t64, non_blocking=True)
+                if keep:
+                    # dataset building: one grow-only pinned staging block per output, reused song after song (allocating
+                    # pinned memory costs more than the whole transform), written to disk straight from it
+                    host = self._pinned(role, t64.numel()).view(t64.shape)
+                else:
+                    host = torch.empty(t64.shape, dtype=torch.float64)       # the caller keeps the array: its own memory
+                host.copy_(t64, non_blocking=keep)
                 outs.append(host)
             ctx.torch_stream.synchronize()
         mags = outs[0].numpy()
         phs = outs[1].numpy() if phase else None
         return self._finish_transform(mags, phs, phase, save)
+
+    def _pinned(self, role, numel):
+        import torch
+        if not hasattr(self, "_pin"):
+            self._pin = {}
+        buf = self._pin.get(role)
+        if buf is None or buf.numel() < numel:
+            buf = self._pin[role] = torch.empty((int(numel * 5 // 4) + 1,), dtype=torch.float64).pin_memory()
+        return buf[:numel]
 
     def compute_file(self, audio, phase=False, sampleRate=44100):
         """``mag = |STFT| / sqrt(frameSize)`` (``[T, frameSize/2+1]`` float64) and, with

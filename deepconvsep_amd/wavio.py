@@ -95,10 +95,21 @@ def header_pcm16(rate, n_frames, channels=1):
 
 
 def write_pcm16(path, rate, samples):
-    """``scipy.io.wavfile.write(path, rate, samples)`` for an int16 array ``[n]`` or ``[n, channels]``: header + the bytes."""
+    """``scipy.io.wavfile.write(path, rate, samples)`` for an int16 array ``[n]`` or ``[n, channels]``: header + the bytes, one
+    ``writev`` on a raw descriptor (no buffered file object between the pinned samples and the page cache)."""
+    import os
     samples = np.ascontiguousarray(samples, dtype="<i2")
     channels = 1 if samples.ndim == 1 else samples.shape[1]
-    with open(path, "wb") as fh:
-        fh.write(header_pcm16(rate, samples.shape[0], channels))
+    head = header_pcm16(rate, samples.shape[0], channels)
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
         if samples.size:
-            fh.write(memoryview(samples.reshape(-1)).cast("B"))
+            body = memoryview(samples.reshape(-1)).cast("B")
+            done = os.writev(fd, [head, body])
+            done -= len(head)
+            while done < len(body):                      # a short write (signal, quota): finish with plain writes
+                done += os.write(fd, body[done:])
+        else:
+            os.write(fd, head)
+    finally:
+        os.close(fd)

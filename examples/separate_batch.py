@@ -7,7 +7,7 @@
 
 Every file gets its own sub-directory ``outdir/<stem>/`` holding the wav files the single-file script
 writes.  With several ranks (one process per GPU) the files are dealt round-robin: replicas only, no
-collective on the data path.  ``--group G`` (default 8) takes G files at a time; they share sets of kernel launches
+collective on the data path.  ``--group G`` (default 16) takes G files at a time; they share sets of kernel launches
 (``Separator.separate_many_pcm16``: equal lengths ``dcs_separate_batch``, different lengths ``dcs_separate_ragged``).
 
 16-bit PCM files (the datasets' format) never become floats on the host: a worker thread reads a file's int16 frames
@@ -31,8 +31,8 @@ def main(argv=None):
     ap.add_argument("-a", "--arch", default="dsd", choices=["dsd", "hiphop", "ikala", "bach10"])
     ap.add_argument("-m", "--mfile", required=True)
     ap.add_argument("-o", "--odir", required=True)
-    ap.add_argument("-g", "--group", type=int, default=8, help="files read ahead and separated together")
-    ap.add_argument("-w", "--workers", type=int, default=0, help="I/O worker threads (default: min(8, cores))")
+    ap.add_argument("-g", "--group", type=int, default=16, help="files read ahead and separated together")
+    ap.add_argument("-w", "--workers", type=int, default=0, help="I/O worker threads (default: min(16, cores))")
     ap.add_argument("--float-path", action="store_true",
                     help="force the float path of the single-file scripts (read_wav / to_mono on the host, float32 upload, "
                          "float64 download, scipy writes) also for 16-bit PCM files")
@@ -56,7 +56,7 @@ def main(argv=None):
 
     failed = []
     from deepconvsep_amd import wavio
-    n_workers = max(2, min(args.workers or 8, (os.cpu_count() or 2)))
+    n_workers = max(2, min(args.workers or 16, (os.cpu_count() or 2)))
     G = max(1, args.group)
     chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
     # pinned input arenas, one per chunk in flight (the chunk being separated and the one being read)
@@ -103,11 +103,14 @@ def main(argv=None):
         for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
             sp.write_wav(dst, sig, sr)
 
+    t_stage = {"wait_reads": 0.0, "separate": 0.0, "wait_writes": 0.0, "submit": 0.0}
     with ThreadPoolExecutor(max_workers=n_workers) as pool:
         nxt = submit_reads(pool, 0)
         pending = []
         for ci in range(len(chunks)):
+            t0 = time.perf_counter()
             got = [f.result() for f in nxt]
+            t_stage["wait_reads"] += time.perf_counter() - t0
             nxt = submit_reads(pool, ci + 1)
             fast, slow = [], []
             for path, sr, audio, is16 in got:
@@ -117,10 +120,15 @@ def main(argv=None):
                     print("Sample rate is not 44100")          # separate_dsd.py:313
                 else:
                     (fast if is16 else slow).append((path, sr, audio))
-            res16 = sep.separate_many_pcm16([a for _, _, a in fast], on_error='return') if fast else []
+            t0 = time.perf_counter()
+            res16 = sep.separate_many_pcm16([a for _, _, a in fast], max_group=max(16, G), on_error='return') if fast else []
             resf = sep.separate_many([a for _, _, a in slow], on_error='return') if slow else []
+            t1 = time.perf_counter()
             for f in pending:                                   # the writes of the previous chunk (their pinned block is two
                 f.result()                                      # calls old when it is reused: ring of three)
+            t2 = time.perf_counter()
+            t_stage["separate"] += t1 - t0
+            t_stage["wait_writes"] += t2 - t1
             pending = []
             for (path, sr, _), pcm in zip(fast, res16):
                 if isinstance(pcm, Exception):
@@ -133,8 +141,11 @@ def main(argv=None):
                     failed.append((path, pcm))
                 else:
                     pending.append(pool.submit(write_float, path, sr, pcm))
+            t_stage["submit"] += time.perf_counter() - t2
+        t0 = time.perf_counter()
         for f in pending:
             f.result()
+        t_stage["wait_writes"] += time.perf_counter() - t0
     for path, exc in failed:
         print("%s: %s: %s" % (path, type(exc).__name__, exc), file=sys.stderr)
     if args.stats:
@@ -142,7 +153,8 @@ def main(argv=None):
         el = time.perf_counter() - t_ready
         print(json.dumps({"rank": rank, "files": len(mine), "failed": len(failed), "seconds_after_model_ready": round(el, 4),
                           "ms_per_file": round(el / max(1, len(mine)) * 1e3, 3), "group": G, "workers": n_workers,
-                          "path": "float" if args.float_path else "int16 frames (device mix-down and int16 conversion)"}))
+                          "path": "float" if args.float_path else "int16 frames (device mix-down and int16 conversion)",
+                          "main_thread_ms_per_file": {k: round(v / max(1, len(mine)) * 1e3, 3) for k, v in t_stage.items()}}))
     return 1 if failed else 0
 
 
