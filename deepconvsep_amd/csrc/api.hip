@@ -264,20 +264,10 @@ extern "C" int dcs_destroy(dcs_ctx* ctx) {
     ctx->gemm_ws.release();
     ctx->score_ring.release();
     if (ctx->ola_rise_d) (void)hipFree(ctx->ola_rise_d);
-    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
     return DCS_OK;
 }
 
-int dcs_ctx_side_stream(dcs_ctx* ctx) {
-    if (ctx->side_stream) return DCS_OK;
-    DCS_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-    DCS_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    DCS_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    return DCS_OK;
-}
 
 extern "C" int dcs_synchronize(dcs_ctx* ctx) {
     if (!ctx) DCS_FAIL(DCS_EINVAL, "dcs_synchronize: null ctx");

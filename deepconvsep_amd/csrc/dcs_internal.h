@@ -135,12 +135,7 @@ struct dcs_ctx {
     float* ola_rise_d = nullptr;
     std::vector<float> ola_rise_h;
     DcsUploadRing score_ring;  // note rectangles and floor values of dcs_score_masks
-    // a second stream of the context's own + fork / join events: launch groups of many clips run the per-clip chains of
-    // their two halves side by side (net.hip, separate_impl); created on first use, joined before the call returns
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
-int dcs_ctx_side_stream(dcs_ctx* ctx);   // creates side_stream / ev_fork / ev_join once (never inside a graph capture)
 
 // RAII-ish helper: records a start event on construction and a stop event in done().
 struct DcsTimer {

@@ -651,8 +651,7 @@ int dcs_launch_dsd_deconv2(dcs_ctx* ctx, const float* D, const float* Bw, const 
     const int ngg = (CI + kDsdGch - 1) / kDsdGch;
     const bool can_stream = nrb == 1 && kh <= 16 && tc <= 32 && H2 + kh - 1 <= 32;
     const bool stream = can_stream && (force ? force == 2 : n_ks >= 4 * (int64_t)ctx->n_cu);
-    static const bool d2_bf16 = !(getenv("DCS_DECONV2_BF16") && atoi(getenv("DCS_DECONV2_BF16")) == 0);
-    if (stream && Gs && Bq && d2_bf16) {
+    if (stream && Gs && Bq) {
         // the consumer is the bf16x3 final kernel: the transposed conv2 runs on the bf16 matrix pipe too and writes the
         // three planes of G (dsd_bf16x3.hip)
         const int rc = dcs_launch_dsd_deconv2_bf16(ctx, D, Bq, Gs, n_ks, H2, CP, CI, kh, tc);
@@ -696,8 +695,7 @@ int dsd_final_cbw(const dcs_ctx* ctx, int64_t rows, int F, int64_t n_clips) {
 }
 
 bool dsd_final_bf16x3(const dcs_ctx* ctx, int64_t rows, int F, int64_t n_clips, int CI, int mask_mode) {
-    static const bool on = !(getenv("DCS_FINAL_BF16X3") && atoi(getenv("DCS_FINAL_BF16X3")) == 0);
-    return on && CI == 52 && mask_mode < 2 && dsd_final_cbw(ctx, rows, F, n_clips) == 2;
+    return CI == 52 && mask_mode < 2 && dsd_final_cbw(ctx, rows, F, n_clips) == 2;
 }
 
 int dcs_launch_dsd_final(dcs_ctx* ctx, const DsdFinalArgs& a, bool fold) {

@@ -44,17 +44,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
 constexpr int kNgg = 7;                 // channel groups of 8 that carry data (50 filters -> 56); group 7 of the K = 64 axis is zero
-#ifndef DCS_FINAL_STAGE_MEMORY_ORDER
-constexpr int kRowLds = 25;             // LDS row stride in 16-byte units: 100 words, fi * 100 mod 64 = 16 distinct bank quads
-constexpr int kPlaneLds = 8;
-#else
-// Round-3 experiment (scripts/build_exp.sh ... -DDCS_FINAL_STAGE_MEMORY_ORDER): staging lanes in the order of the pieces in
-// memory (plane, then row; plane p of a row at 9 p, rows 27 apart so that consecutive lanes write consecutive piece offsets
-// modulo 8) -- what the one-batch kernel of dsd_lat.hip does.  Measured on this kernel: SLOWER, 109.3 vs 103.6 us per 1024
-// tiles, 303 vs 300 us at 4096 (the 27-piece row stride is 2-way conflicted for the MFMA fragment reads).
-constexpr int kRowLds = 27;
-constexpr int kPlaneLds = 9;
-#endif
 
 __device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
 
@@ -106,30 +95,26 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-#ifndef DCS_FINAL_WGS_PER_CU
-#define DCS_FINAL_WGS_PER_CU 2       // workgroups per CU = waves per SIMD the register budget of the staged form is sized for
-#endif
-// DIRECT (round 4, the default; DCS_FINAL_DIRECT=0 selects the register-staged form): the A set of a covering tile goes
-// from HBM straight into LDS (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l, scripts/ubench/lds_async.hip)
+// The A set of a covering tile goes from HBM straight into LDS (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l, scripts/ubench/lds_async.hip)
 // in PIECE-major order -- unit (sp, i) = piece column sp = branch * 21 + plane * 7 + group of row i at sp * 16 + i:
-//   * no prefetch registers (16) and no LDS destination registers (4): 168 registers = THREE workgroups per CU (the staged
-//     form needs 188 and spills 21 when sized for three);
+//   * no prefetch registers and no LDS destination registers: 168 registers = THREE workgroups per CU (round 3's form, which
+//     staged the pieces through registers, needed 188, spilled 21 when sized for three and measured 65 vs 58.5 us at 640 tiles;
+//     removed in round 5);
 //   * no ds_write of the staged pieces, no second pass over them in registers;
 //   * an MFMA A fragment (row fi, K piece kq) of (branch, plane, K block 0) is unit (..)*16 + 16 kq + fi = a constant + the
-//     LANE index: every ds_read_b128 of the kernel reads 1 KB of consecutive LDS -- conflict-free by construction (the
-//     staged form's row stride of 25 units measured an LDS bank-conflict ratio of 1.53);
+//     LANE index: every ds_read_b128 of the kernel reads 1 KB of consecutive LDS -- conflict-free by construction;
 //   * K channels 56..63 (K block 1, kq = 3) do not exist in G: their B rows are zero (Bpk, net.hip), so those lanes read
 //     K piece 3 of the SAME row again -- finite numbers times zero -- and no LDS is zero-filled.
-template <int MODE, bool DIRECT>
-__global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void final_bf16x3_kernel(const DsdFinalArgs a, int n_colg) {
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 3) void final_bf16x3_kernel(const DsdFinalArgs a, int n_colg) {
     constexpr int CBW = 2, NBR = 3;
-    constexpr int kABuf = DIRECT ? 1024 : NBR * 16 * kRowLds;
+    constexpr int kABuf = 1024;
     constexpr int kMaxM = 16;
-    // DIRECT: the two buffers are two ARRAYS and the loop over the covering tiles is unrolled by two, so that the compiler
+    // the two buffers are two ARRAYS and the loop over the covering tiles is unrolled by two, so that the compiler
     // sees transfers into one array and fragment reads from the other -- with one array and a buffer index it must assume
     // that an LDS read may alias a transfer in flight and waits for vmcnt(0) in front of the first ds_read of every tile
-    __shared__ u32x4 As[DIRECT ? kABuf : 2 * kABuf];
-    __shared__ u32x4 As1[DIRECT ? kABuf : 1];
+    __shared__ u32x4 As[kABuf];
+    __shared__ u32x4 As1[kABuf];
     __shared__ __attribute__((aligned(16))) float up_t[kMaxM * 16];
     __shared__ __attribute__((aligned(16))) float down_t[kMaxM * 16];
     __shared__ int meta_k0[16];
@@ -257,39 +242,23 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
     const u32x4* gbase = reinterpret_cast<const u32x4*>(a.Gs) + gs_off + (int64_t)kbase * NBR * kNgg * tc * 3;
     // every slot is loaded for every covering tile, with the tile index clamped to the last one that has a weight on
     // the slot's row (see final_kernel in dsd.hip): no data-dependent branch in front of the loads
-    int goff[NSL], dst[NSL], mlim[NSL];
+    int goff[NSL], mlim[NSL];
     bool in_slot[NSL];
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
         const int idx = tid + u * kThreads;
-#ifndef DCS_FINAL_STAGE_MEMORY_ORDER
         const int i = idx & 15, sp = idx >> 4;               // sp = s * 21 + plane * 7 + g
         const int s = sp / (3 * kNgg), pg = sp - s * (3 * kNgg);
         const int plane = pg / kNgg, g = pg - plane * kNgg;
-#else
-        // plane fastest, then the row: the order of the pieces in memory ([item][g][t][plane], the rows of one tile are
-        // consecutive t) -- 48 consecutive lanes read runs of up to 240 contiguous bytes instead of 16 bytes out of every 48
-        const int t3 = idx / 3, plane = idx - 3 * t3;
-        const int i = t3 & 15, gs = t3 >> 4;
-        const int s = gs / kNgg, g = gs - s * kNgg;
-#endif
         const bool in = (u + 1) * kThreads <= slots || idx < slots;   // compile-time true for all but the last slot
         in_slot[u] = in;
         const int lim = in ? meta_mlim[i] : -1;
         const int j0 = lim >= 0 ? meta_j0[i] : 0;
         const int dk = lim >= 0 ? meta_k0[i] - kbase : 0;
         mlim[u] = lim >= 0 ? lim : 0;
-        dst[u] = (s * 16 + i) * kRowLds + plane * kPlaneLds + g;
         goff[u] = (((dk * NBR + s) * kNgg + g) * tc + j0) * 3 + plane;
     }
-    if constexpr (!DIRECT) {
-        for (int idx = tid; idx < 2 * NBR * 16 * 3; idx += kThreads) {   // K channels 56..63: zero in both buffers
-            const int buf = idx / (NBR * 16 * 3), r = idx - buf * (NBR * 16 * 3);
-            As[buf * kABuf + (r / 3) * kRowLds + (r % 3) * kPlaneLds + 7] = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    u32x4 pre[DIRECT ? 1 : NSL];
-    // DIRECT: slot idx = tid + 256 u IS LDS unit idx (row fastest, then the piece column): wave w's transfer u covers units
+    // slot idx = tid + 256 u IS LDS unit idx (row fastest, then the piece column): wave w's transfer u covers units
     // 256 u + 64 w .. + 63, a wave-uniform LDS base
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #define DCS_LOAD_A_DIRECT(m_, buf_)                                                             \
@@ -299,21 +268,8 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
             lds_dma16(gbase + (goff[u] + mm * m_delta), (buf_) + (u * kThreads + wave_u * 64)); \
         }                                                                                       \
     }
-#define DCS_LOAD_A(m_, dst_)                                                                    \
-    _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};                                                        \
-        if ((u + 1) * kThreads <= slots || in_slot[u]) {                                        \
-            const int mm = (m_) < mlim[u] ? (m_) : mlim[u];                                     \
-            v = gbase[goff[u] + mm * m_delta];                                                  \
-        }                                                                                       \
-        dst_[u] = v;                                                                            \
-    }
-#define DCS_STORE_A(buf_)                                                                       \
-    _Pragma("unroll") for (int u = 0; u < NSL; ++u) {                                           \
-        if ((u + 1) * kThreads <= slots || in_slot[u]) As[(buf_) * kABuf + dst[u]] = pre[u];    \
-    }
 
-    // DIRECT fragment bases: K block 0 -> unit lane (= 16 kq + fi), K block 1 -> group 4 + kq, or group 3 again for kq = 3
+    // fragment bases: K block 0 -> unit lane (= 16 kq + fi), K block 1 -> group 4 + kq, or group 3 again for kq = 3
     const int lane1 = kq < 3 ? lane + 64 : lane;
     // one covering tile: fragments from a0 (K block 0) / a1 (K block 1), 72 MFMAs, mask + fold in registers
     auto compute = [&](const int m, const u32x4* a0, const u32x4* a1) {
@@ -331,20 +287,8 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    if constexpr (DIRECT)
-                        af[p][kb] = (kb ? a1 : a0)[(s * 3 * kNgg + p * kNgg) * 16];
-                    else
-                        af[p][kb] = a0[s * 16 * kRowLds + p * kPlaneLds + kb * 4];
+                    af[p][kb] = (kb ? a1 : a0)[(s * 3 * kNgg + p * kNgg) * 16];
                 }
-#ifdef DCS_FINAL_ABL_NOMFMA        // ablation: the fragments are consumed by one vector add each instead of twelve MFMAs
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb) acc[s][cb] += __builtin_bit_cast(f32x4, af[p][kb]) * 1e-30f;
-            continue;
-#endif
             // smallest terms first; the two column blocks alternate so that no MFMA waits for the one before it
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -367,13 +311,6 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb) acc[s][cb] = mma(af[0][kb], breg[cb][0][kb], acc[s][cb]);
         }
-#ifdef DCS_FINAL_ABL_NOEPI         // ablation: no mask / fold arithmetic (the accumulators are summed so that the MFMAs stay)
-        {
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) res[cb][0] += (acc[0][cb] + acc[1][cb]) + acc[2][cb];
-            return;
-        }
-#endif
         const f32x4 up4 = *reinterpret_cast<const f32x4*>(up_t + m * 16 + kq * 4);
         const f32x4 down4 = *reinterpret_cast<const f32x4*>(down_t + m * 16 + kq * 4);
 #pragma unroll
@@ -410,7 +347,7 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
     };
     // the A set of covering tile m + 1 is requested while tile m is multiplied (requesting it two tiles ahead costs 20
     // more registers and measured slower: 0.360 vs 0.346 ms at 4096 tiles)
-    if constexpr (DIRECT) {
+    {
         DCS_LOAD_A_DIRECT(0, As)
         FT_STAMP(3);    // staging plan made, first A set requested
         for (int m = 0; m < mmax; m += 2) {
@@ -420,41 +357,21 @@ __global__ __launch_bounds__(kThreads, DIRECT ? 3 : DCS_FINAL_WGS_PER_CU) void f
             FT_STAMP(4 + 4 * m);     // own transfers of tile m landed
             __syncthreads();
             FT_STAMP(5 + 4 * m);     // barrier passed
-#ifndef DCS_FINAL_ABL_NODMA       // ablation builds (scripts/build_exp.sh, never shipped): the first tile's data is re-used
             if (m + 1 < mmax) DCS_LOAD_A_DIRECT(m + 1, As1)
-#endif
             FT_STAMP(6 + 4 * m);     // next tile requested
             if (live) compute(m, As + lane, As + lane1);
             FT_STAMP(7 + 4 * m);     // fragments read, 72 MFMAs, mask + fold done
             if (m + 1 >= mmax) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FT_STAMP(8 + 4 * m);
-#ifndef DCS_FINAL_ABL_NOBARRIER
             __syncthreads();
-#endif
             FT_STAMP(9 + 4 * m);
-#ifndef DCS_FINAL_ABL_NODMA
             if (m + 2 < mmax) DCS_LOAD_A_DIRECT(m + 2, As)
-#endif
             FT_STAMP(10 + 4 * m);
-#ifdef DCS_FINAL_ABL_NODMA
-            if (live) compute(m + 1, As + lane, As + lane1);
-#else
             if (live) compute(m + 1, As1 + lane, As1 + lane1);
-#endif
             FT_STAMP(11 + 4 * m);
         }
-    } else {
-        DCS_LOAD_A(0, pre)
-        for (int m = 0; m < mmax; ++m) {
-            DCS_STORE_A(m & 1)
-            __syncthreads();
-            if (m + 1 < mmax) DCS_LOAD_A(m + 1, pre)
-            if (live) compute(m, As + (m & 1) * kABuf + fi * kRowLds + kq, nullptr);
-        }
     }
-#undef DCS_LOAD_A
-#undef DCS_STORE_A
 #undef DCS_LOAD_A_DIRECT
 
     FT_STAMP(28);   // every covering tile folded
@@ -672,7 +589,7 @@ int dcs_launch_dsd_deconv2_bf16(dcs_ctx* ctx, const float* D, const void* Bq, vo
     // kernel behind it 4-8 % slower, a wash; with the direct-to-LDS final kernel of round 4 the step gains: 20 x 32 tiles
     // deconv2 33.2 -> 29.6 us with the final kernel unchanged (63.1 / 63.3), 4096 tiles 0.8526 -> 0.8449 ms per clip
     // (profiles/r04_b_*).  DCS_DECONV2_WAVES=4 | 16 forces one.
-    static const int nw_env = getenv("DCS_DECONV2_WAVES") ? atoi(getenv("DCS_DECONV2_WAVES")) : 0;
+    constexpr int nw_env = 0;
     const int nw = nw_env == 16 ? 16 : (nw_env == 4 ? 4 : (n_ks >= 1024 ? 16 : 4));
     const int slots = (nw == 16 ? 1 : 2) * ctx->n_cu;   // workgroups resident at once (77 / 152 KB of LDS each), one round
     const double units = n_full + (tail_ch ? (double)((tail_ch + 1) / 2) / (kDsdGch / 2) : 0.0);
@@ -701,16 +618,9 @@ int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_item
 }
 
 int dcs_launch_dsd_final_bf16x3(dcs_ctx* ctx, const DsdFinalArgs& a, int n_colg, int64_t n_wg, unsigned n_clips) {
-    // DCS_FINAL_DIRECT=0: the register-staged form (two workgroups per CU)
-    static const bool direct = !(getenv("DCS_FINAL_DIRECT") && atoi(getenv("DCS_FINAL_DIRECT")) == 0);
     const dim3 grid((unsigned)n_wg, n_clips), block(kThreads);
-    if (direct) {
-        if (a.mask_mode == 0) hipLaunchKernelGGL((final_bf16x3_kernel<0, true>), grid, block, 0, ctx->stream, a, n_colg);
-        else hipLaunchKernelGGL((final_bf16x3_kernel<1, true>), grid, block, 0, ctx->stream, a, n_colg);
-    } else {
-        if (a.mask_mode == 0) hipLaunchKernelGGL((final_bf16x3_kernel<0, false>), grid, block, 0, ctx->stream, a, n_colg);
-        else hipLaunchKernelGGL((final_bf16x3_kernel<1, false>), grid, block, 0, ctx->stream, a, n_colg);
-    }
+    if (a.mask_mode == 0) hipLaunchKernelGGL((final_bf16x3_kernel<0>), grid, block, 0, ctx->stream, a, n_colg);
+    else hipLaunchKernelGGL((final_bf16x3_kernel<1>), grid, block, 0, ctx->stream, a, n_colg);
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }

@@ -13,11 +13,10 @@
 enum {
     DCS_LAT_STFT = 1, DCS_LAT_CONV1 = 2, DCS_LAT_CONV2 = 4, DCS_LAT_FC = 8, DCS_LAT_FC1X = 16, DCS_LAT_DECONV2 = 32,
     DCS_LAT_FINAL = 64, DCS_LAT_ISTFT = 128,
-    DCS_LAT_MID = 256,    // with CONV2 | FC | FC1X | DECONV2 all set: those four as ONE launch (lat_mid_kernel)
-    DCS_LAT_FUSE1 = 512,  // with STFT | CONV1 set: those two as ONE launch (lat_stft_conv1_kernel)
-    DCS_LAT_ALL = 1023
+    DCS_LAT_ALL = 255
 };
-constexpr int kDcsLatMidMaxTiles = 256;
+// (Round 3 also built conv2 .. conv2^T as ONE launch of 8-workgroup clusters exchanging through tagged granules, and STFT +
+// conv1 as one launch: 51.9 / 54.1 us per step against 49.7 -- removed in round 5, numbers in scripts/README.md.)
 
 // C[r][0..n_store) = act(a_scale * A_r[0..K) . B + bias),  A_r = A + r * a_row_stride (K contiguous floats, 16-byte
 // aligned).  K is cut into n_slices slices of slice_len (multiple of 4); wave s of a workgroup multiplies slice s of one
@@ -46,21 +45,6 @@ int dcs_launch_lat_gemm(dcs_ctx* ctx, const DcsLatGemm& g, int tag);
 void dcs_lat_pack_deconv2(const float* Bw2s, int n_ci8, std::vector<float>* out);
 int dcs_launch_lat_deconv2(dcs_ctx* ctx, const float* D, const float* Wp, float* G, void* Gs, int64_t n_items);
 
-// conv2 -> bottleneck -> per-source dense -> transposed conv2 in ONE launch: clusters of 8 workgroups per tile, the
-// exchanges inside a cluster through tagged 8-byte granules (lat_mid_kernel).  state: dcs_lat_mid_state_bytes(max_tiles)
-// bytes of device memory owned by the model, initialised once by dcs_lat_mid_state_init.
-struct DcsLatMidArgs {
-    const float *H1, *W2p, *bias2, *Wfc, *biasfc, *Wd, *biasd, *Wdc;
-    void* state;
-    float* G;      // nullable
-    void* Gs;      // nullable
-    int n_tiles, st;
-};
-void dcs_lat_pack_mid(const float* Bfc, int ld_fc, const float* Bd, int ld_d, std::vector<float>* wfc, std::vector<float>* wd);
-size_t dcs_lat_mid_state_bytes(int max_tiles);
-int dcs_lat_mid_state_init(void* state_d, int max_tiles);
-int dcs_launch_lat_mid(dcs_ctx* ctx, const DcsLatMidArgs& a);
-
 // fused transposed conv1 + bias + rectify + soft mask + cross-fade (final_bf16x3_kernel's arithmetic) with 16 rows x 64
 // bins per workgroup and every covering tile's A set staged at once; needs a.Gs / a.Bpk, one clip, mask_mode 0 / 1
 int dcs_lat_final_max_covers();   // ceil(overlap / stride) + 1 must not exceed this (6)
@@ -74,9 +58,5 @@ int dcs_launch_lat_stft(dcs_stft* p, const float* audio, int64_t L, float* mag, 
 // the inverse is two launches (every frame transformed once, then the overlap-add); frames: scratch of
 // dcs_lat_istft_scratch_bytes() bytes, [source][frame][frameSize] float32
 size_t dcs_lat_istft_scratch_bytes(const dcs_stft* p, int64_t T, int n_src);
-// STFT and conv1 (+ both biases) in one launch, four frames per workgroup; B1 [K1][64] as pack_dsd lays it out
-int dcs_launch_lat_stft_conv1(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase /* nullable */, float2* unit,
-                              int64_t ld, int64_t rows_out, int64_t T, const float* B1, const float* bias1, float* H1,
-                              int64_t h1_rows /* rows of H1 to write */, int CI, float scale);
 int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, const float2* unit, int64_t ld, int64_t T,
                          int n_src, float pre_div, float* audio, int64_t n_out, float* frames);

@@ -549,361 +549,6 @@ __global__ __launch_bounds__(512) void lat_final_kernel(const DsdFinalArgs a) {
     LAT_STAMP_END(5, 8);
 }
 
-// ------------------------------------------------------------------------------------------------ the middle, one launch
-// conv2 -> bottleneck -> per-source dense -> transposed conv2 of one TILE touch 1.9 MB of weights and a few KB of data, and
-// as four launches they cost 4 x (2.4 us of dispatch + ~1 us of cold start + 2-3 us of dependent loads) = 20 us for
-// 57 MFLOP.  Here a CLUSTER of 8 workgroups (8 consecutive block ids: the dispatcher hands them out in order, so at most
-// one cluster per launch is ever partially resident) owns one tile; every workgroup streams an eighth of every layer's
-// weights into REGISTERS at kernel start (they do not depend on data), and the three exchanges inside the cluster go
-// through 8-byte {tag, value} granules (MI355X guide, recipe R2): the data is the flag, one relaxed agent-scope store per
-// value, consumers re-read their granules until every tag is this launch's -- no fences, no flag words, no grid barrier.
-//   phase 1  conv2 (separate_dsd.py:202-203): members 0..3 = the four 16-column blocks, 16 positions x 780 on the f32 MFMA,
-//            K split by taps over the 4 waves                                              -> 832 granules
-//   phase 2  bottleneck + rectify (:206): member c = hidden units 16c..16c+15, vector ALU     -> 128 granules
-//   phase 3  per-source dense + rectify (:209,215,221): member c = columns 312c..312c+311     -> 2496 granules
-//   phase 4  InverseLayer(., l_conv2) (:211,217,223): the 21 (branch, 8-channel group) units dealt round-robin, GEMM +
-//            col2im as lat_deconv2_kernel                                                     -> G / Gs in HBM
-// Tags are launch epoch * 4 + phase; the epoch lives in device memory and is advanced by the last workgroup to finish (a
-// kernel argument would be frozen in a replayed hipGraph), so nothing has to be zeroed between launches.
-typedef unsigned long long u64;
-constexpr int kMidC2 = 832, kMidZ = 128, kMidD = 2496;
-constexpr int kMidTileGranules = 1024 + 128 + 2560;     // per tile: conv2 output, bottleneck, dense outputs (padded)
-constexpr unsigned kMidSpinLimit = 1u << 22;
-
-__device__ __forceinline__ void granule_store(u64* g, unsigned tag, float v) {
-    __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// re-reads this thread's granules idx = first + 256 u (clamped to count - 1: every load is issued, none sits behind a
-// branch -- with one exec-masked branch and one wait per granule a sweep was NU serial round trips) until all carry `tag`;
-// false on give-up: state[2] is set AND every value of the sweep is returned as NaN, so a timed-out exchange (a cluster
-// that was pre-empted, only partially resident, stopped by a debugger) poisons this tile's G, the separated spectrogram
-// and the PCM -- the caller sees NaNs, never stale granules that look like audio (round-3 advisor finding)
-template <int NU>
-__device__ __forceinline__ bool granule_sweep(const u64* g, int first, int count, unsigned tag, float (&v)[NU], unsigned* state) {
-    const u64* p[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int idx = first + 256 * u;
-        p[u] = g + (idx < count ? idx : count - 1);
-    }
-    for (unsigned spins = 0;; ++spins) {
-        u64 x[NU];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) x[u] = __hip_atomic_load(p[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool ok = true;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            ok = ok & ((unsigned)(x[u] >> 32) == tag);
-            v[u] = __uint_as_float((unsigned)x[u]);
-        }
-        if (ok) return true;
-        if (spins > kMidSpinLimit) {
-            __hip_atomic_store(state + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < NU; ++u) v[u] = __uint_as_float(0x7fc00000u);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-struct DcsLatMid {
-    const float* H1;       // [rows][52] conv1 output (+ biases), tile k starts at row k * st
-    const float* W2p;      // conv2 weights, fragment order [tap 15][column block 4][4][64][4]   (dcs_lat_pack_b)
-    const float* bias2;    // [64]
-    const float* Wfc;      // [member 8][832][16]
-    const float* biasfc;   // [128]
-    const float* Wd;       // [member 8][129][312], row 128 zero
-    const float* biasd;    // [2496]
-    const float* Wdc;      // transposed-conv2 fragments [56 channels][4][64][4]   (dcs_lat_pack_deconv2)
-    u64* gran;             // [tiles][kMidTileGranules]
-    unsigned* state;       // [0] launch epoch (>= 1), [1] workgroups finished (ever), [2] tag a sweep gave up on (0: none)
-    float* G;              // nullable
-    u32x4* Gs;             // nullable
-    int n_tiles, st;
-};
-
-__global__ __launch_bounds__(256) void lat_mid_kernel(const DcsLatMid a) {
-    __shared__ __attribute__((aligned(16))) float H1l[30 * 52 + 16];
-    __shared__ __attribute__((aligned(16))) float C2l[kMidC2];
-    __shared__ __attribute__((aligned(16))) float Zl[kMidZ];
-    __shared__ __attribute__((aligned(16))) float Dl[3 * kMidC2];
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64];          // conv2: [wave][e][lane]; fc: [64][16]; fc1x: [3][312]
-    __shared__ __attribute__((aligned(16))) float Ps[4 * 2 * kPsChan];
-    __shared__ __attribute__((aligned(16))) float Gl[30 * 8];
-    LAT_STAMP(4, 0);
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int fi = lane & 15, kq = lane >> 4;
-    const int c = (int)(blockIdx.x & 7);                  // member
-    const int cl = (int)(blockIdx.x >> 3), ncl = (int)(gridDim.x >> 3);
-    const unsigned epoch = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    // ---- weights -> registers.  A wave's loads return in order, so the order of the requests is the order in which the
-    // phases can start: the first tile's conv1 rows and the conv2 / bottleneck weights first (187 KB per workgroup at
-    // most); the dense and transposed-conv2 weights (184 KB) are requested once the conv2 products have been issued
-    // (LAT_PIN keeps the compiler from hoisting them) and arrive while the cluster exchanges the conv2 output.
-#define LAT_PIN(off_) asm volatile("" : "+s"(off_))   // an opaque zero offset: the loads behind it cannot be hoisted above it
-    f32x4 h1pre[2];
-    {
-        const float* src = a.H1 + (int64_t)cl * a.st * 52;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + 256 * u;
-            h1pre[u] = (c < 4 && cl < a.n_tiles && i < 30 * 13) ? *reinterpret_cast<const f32x4*>(src + 4 * i)
-                                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    f32x4 w2[4][4];                                        // conv2: taps wave, wave+4, wave+8, wave+12 of column block c
-    if (c < 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int u = wave + 4 * q;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                w2[q][j] = reinterpret_cast<const f32x4*>(a.W2p)[((int64_t)(u * 4 + c) * 4 + j) * 64 + lane];   // tap 15: zeros
-        }
-    }
-    const float b2 = c < 4 ? a.bias2[c * 16 + (tid & 15)] : 0.f;
-    const int h4 = tid & 3, ks = tid >> 2;                 // bottleneck: 4 hidden units x slice ks of 13 inputs
-    f32x4 wfc[13];
-#pragma unroll
-    for (int j = 0; j < 13; ++j)
-        wfc[j] = *reinterpret_cast<const f32x4*>(a.Wfc + ((int64_t)(c * kMidC2 + ks * 13 + j) * 16 + 4 * h4));
-    const float bfc = tid < 16 ? a.biasfc[c * 16 + tid] : 0.f;
-    const int cq = tid % 78, ksd = tid / 78;               // dense: 4 columns x slice ksd of 43 hidden units (tid < 234)
-    const int n_units = c < 5 ? 3 : 2;                     // transposed conv2: units c, c + 8, c + 16 of the 21
-    f32x4 wd[43];
-    f32x4 wdc[3][2][4];
-    f32x4 bd = f32x4{0.f, 0.f, 0.f, 0.f};
-    LAT_STAMP(4, 1);    // first requests out
-    // conv2 products of one tile (members 0..3): conv1 rows -> LDS, 4 taps x 16 MFMAs per wave, partial sums -> red
-#define LAT_MID_CONV2(tile_, first_)                                                                                  \
-    if (c < 4) {                                                                                                      \
-        if (first_) {                                                                                                 \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                             \
-                if (tid + 256 * u < 30 * 13) *reinterpret_cast<f32x4*>(H1l + 4 * (tid + 256 * u)) = h1pre[u];        \
-        } else {                                                                                                      \
-            const float* src = a.H1 + (int64_t)(tile_) * a.st * 52;                                                   \
-            for (int i = tid; i < 30 * 13; i += 256)                                                                  \
-                *reinterpret_cast<f32x4*>(H1l + 4 * i) = *reinterpret_cast<const f32x4*>(src + 4 * i);                \
-        }                                                                                                             \
-        __syncthreads();                                                                                              \
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                     \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                               \
-            const int u = wave + 4 * q;                                                                               \
-            if (u < 15) {                                                                                             \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
-                    const f32x4 av = (j < 3 || kq == 0)                                                               \
-                                         ? *reinterpret_cast<const f32x4*>(H1l + (fi + u) * 52 + 16 * j + 4 * kq)     \
-                                         : f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w2[q][j][0], acc0, 0, 0, 0);                   \
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], w2[q][j][1], acc1, 0, 0, 0);                   \
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], w2[q][j][2], acc0, 0, 0, 0);                   \
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w2[q][j][3], acc1, 0, 0, 0);                   \
-                }                                                                                                     \
-            }                                                                                                         \
-        }                                                                                                             \
-        const f32x4 acc = acc0 + acc1;                                                                                \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) red[(wave * 4 + e) * 64 + lane] = acc[e];                       \
-    }
-
-    if (cl < a.n_tiles) { LAT_MID_CONV2(cl, true) }
-    // the weights of phases 3 and 4, requested behind the first tile's conv2 products
-    {
-        int zero = 0;
-        LAT_PIN(zero);
-        const float* Wd = a.Wd + zero;
-        const float* Wdc = a.Wdc + zero;
-        const float* bdp = a.biasd + zero;
-        // unconditional loads (a branch per load otherwise): idle threads read slice 0, the packed array has a zero row 128
-        const int cqc = tid < 234 ? cq : 0, ksc = tid < 234 ? ksd : 0;
-#pragma unroll
-        for (int j = 0; j < 43; ++j)
-            wd[j] = *reinterpret_cast<const f32x4*>(Wd + ((int64_t)(c * 129 + ksc * 43 + j) * 312 + 4 * cqc));
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int v = q < n_units ? c + 8 * q : c, g = v % 7;
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    wdc[q][cc][j] = reinterpret_cast<const f32x4*>(Wdc)[((int64_t)(g * 8 + wave * 2 + cc) * 4 + j) * 64 + lane];
-        }
-        bd = *reinterpret_cast<const f32x4*>(bdp + c * 312 + 4 * (tid < 78 ? tid : 0));
-    }
-
-    for (int tile = cl; tile < a.n_tiles; tile += ncl) {
-        u64* gC2 = a.gran + (int64_t)tile * kMidTileGranules;
-        u64* gZ = gC2 + 1024;
-        u64* gD = gZ + 128;
-        const unsigned tag1 = epoch * 4 + 1, tag2 = epoch * 4 + 2, tag3 = epoch * 4 + 3;
-        // ---- phase 1: conv2 of the tile's 16 positions
-        if (tile != cl) { LAT_MID_CONV2(tile, false) }
-        if (c < 4) {
-            __syncthreads();
-            {
-                const int l = tid & 63, e = tid >> 6;
-                const float sum = ((red[(0 * 4 + e) * 64 + l] + red[(1 * 4 + e) * 64 + l]) + red[(2 * 4 + e) * 64 + l]) +
-                                  red[(3 * 4 + e) * 64 + l];
-                const int col = c * 16 + (l & 15), pos = (l >> 4) * 4 + e;
-                if (col < 52) granule_store(gC2 + pos * 52 + col, tag1, sum + b2);
-            }
-        }
-        LAT_STAMP(4, 2);    // conv2 done and published (members 0..3)
-        // ---- phase 2: bottleneck
-        {
-            float v[4];
-            granule_sweep<4>(gC2, tid, kMidC2, tag1, v, a.state);
-            LAT_STAMP(4, 3);    // conv2 output of the whole cluster seen
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (tid + 256 * u < kMidC2) C2l[tid + 256 * u] = v[u];
-            __syncthreads();
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 13; ++j) acc += C2l[ks * 13 + j] * wfc[j];
-            *reinterpret_cast<f32x4*>(red + ks * 16 + 4 * h4) = acc;
-            __syncthreads();
-            {   // 64 slices -> 16 partial sums per hidden unit -> 1
-                const int h = tid & 15, part = tid >> 4;
-                const float s4 = ((red[(4 * part) * 16 + h] + red[(4 * part + 1) * 16 + h]) + red[(4 * part + 2) * 16 + h]) +
-                                 red[(4 * part + 3) * 16 + h];
-                __syncthreads();
-                red[part * 16 + h] = s4;
-            }
-            __syncthreads();
-            if (tid < 16) {
-                float s = 0.f;
-#pragma unroll
-                for (int part = 0; part < 16; ++part) s += red[part * 16 + tid];
-                granule_store(gZ + c * 16 + tid, tag2, fmaxf(s + bfc, 0.f));
-            }
-        }
-        LAT_STAMP(4, 4);    // bottleneck slice published
-        // ---- phase 3: per-source dense layers
-        {
-            float v[1];
-            granule_sweep<1>(gZ, tid, kMidZ, tag2, v, a.state);
-            LAT_STAMP(4, 5);    // bottleneck seen
-            __syncthreads();                                  // red is free again
-            if (tid < kMidZ) Zl[tid] = v[0];
-            __syncthreads();
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 43; ++j) {
-                const int h = ksd * 43 + j;
-                acc += Zl[h < kMidZ ? h : 0] * wd[j];         // wd is zero past the last hidden unit
-            }
-            if (tid < 234) *reinterpret_cast<f32x4*>(red + ksd * 312 + 4 * cq) = acc;
-            __syncthreads();
-            if (tid < 78) {
-                const f32x4 s = (*reinterpret_cast<const f32x4*>(red + 4 * tid) + *reinterpret_cast<const f32x4*>(red + 312 + 4 * tid)) +
-                                *reinterpret_cast<const f32x4*>(red + 624 + 4 * tid) + bd;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) granule_store(gD + c * 312 + 4 * tid + e, tag3, fmaxf(s[e], 0.f));
-            }
-        }
-        LAT_STAMP(4, 6);    // dense slice published
-        // ---- phase 4: transposed conv2 of this member's units
-        {
-            float v[10];
-            granule_sweep<10>(gD, tid, kMidD, tag3, v, a.state);
-            LAT_STAMP(4, 7);    // dense outputs seen
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 10; ++u)
-                if (tid + 256 * u < kMidD) Dl[tid + 256 * u] = v[u];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (q < n_units) {                            // uniform per workgroup
-                    const int vu = c + 8 * q, br = vu / 7, grp = vu - 7 * br;
-                    const float* Dp = Dl + br * kMidC2 + fi * 52 + 4 * kq;
-                    f32x4 av[4];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) av[j] = *reinterpret_cast<const f32x4*>(Dp + 16 * j);
-                    av[3] = kq == 0 ? *reinterpret_cast<const f32x4*>(Dp + 48) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int cc = 0; cc < 2; ++cc)
-                                acc[cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], wdc[q][cc][j][e], acc[cc], 0, 0, 0);
-                    float* Pw = Ps + wave * 2 * kPsChan;
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) Pw[cc * kPsChan + (kq * 4 + e + fi) * kPsStride + fi] = acc[cc][e];
-                    __syncthreads();
-                    {
-                        const int cc = lane >> 5, t = lane & 31;
-                        if (t < 30) {
-                            const f32x4* rowp = reinterpret_cast<const f32x4*>(Pw + cc * kPsChan + t * kPsStride);
-                            float x[16];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const f32x4 y = rowp[r];
-                                x[4 * r] = y[0]; x[4 * r + 1] = y[1]; x[4 * r + 2] = y[2]; x[4 * r + 3] = y[3];
-                            }
-                            float sum = 0.f;
-#pragma unroll
-                            for (int dt = 0; dt < 15; ++dt) {
-                                const int tp = t - dt;
-                                sum += (tp >= 0 && tp < 16) ? x[dt] : 0.f;
-                            }
-                            Gl[t * 8 + wave * 2 + cc] = sum;
-                        }
-                    }
-                    __syncthreads();
-                    if (tid < 30) {
-                        const int t = tid;
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(Gl + t * 8), x1 = *reinterpret_cast<const f32x4*>(Gl + t * 8 + 4);
-                        const int64_t rowi = (((int64_t)tile * 3 + br) * 7 + grp) * 30 + t;
-                        if (a.G) {
-                            *reinterpret_cast<f32x4*>(a.G + rowi * 8) = x0;
-                            *reinterpret_cast<f32x4*>(a.G + rowi * 8 + 4) = x1;
-                        }
-                        if (a.Gs) {
-                            float y[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                            unsigned pl[3][8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const unsigned hh = bf_trunc(y[j]);
-                                const float r1 = y[j] - __uint_as_float(hh);
-                                const unsigned mm = bf_trunc(r1);
-                                const float r2 = r1 - __uint_as_float(mm);
-                                pl[0][j] = hh; pl[1][j] = mm; pl[2][j] = bf_trunc(r2);
-                            }
-#pragma unroll
-                            for (int q3 = 0; q3 < 3; ++q3) {
-                                u32x4 w;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) w[r] = (pl[q3][2 * r] >> 16) | (pl[q3][2 * r + 1] & 0xffff0000u);
-                                a.Gs[rowi * 3 + q3] = w;
-                            }
-                        }
-                    }
-                    __syncthreads();                          // Gl / Ps are rewritten by the next unit
-                }
-            }
-        }
-    }
-    LAT_STAMP(4, 8);        // transposed conv2 done, stores issued
-    LAT_DRAIN();
-    LAT_STAMP_END(4, 9);
-    // ---- the last workgroup of the launch advances the epoch for the next one
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned total = gridDim.x;
-        const unsigned old = __hip_atomic_fetch_add(a.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old + 1) % total == 0)
-            __hip_atomic_store(a.state, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ FFT in LDS
 // w(j) = exp(DIR * 2 pi i j / N), 0 <= j < N, from the half-circle table tw[0..M] (forward sign), N = 2 M
 template <int DIR>
@@ -1068,141 +713,6 @@ __global__ __launch_bounds__(256) void lat_stft_kernel(const float* __restrict__
     LAT_STAMP(6, 4);    // stores issued
     LAT_DRAIN();
     LAT_STAMP_END(6, 5);
-}
-
-// STFT + conv1 in one launch (one launch fewer on the one-batch chain: ~1.5 us of dispatch + ~1 us of cold start + a round
-// trip of the magnitudes through HBM).  conv1's weights are 263 KB: a workgroup per frame would stream them 188 times through
-// the CUs' L1s (measured rate with every CU streaming: ~34 B/clk/CU, 3 us per workgroup), so a workgroup takes FOUR frames
-// (four thread groups of 256, one FFT each, as lat_stft_kernel) and every thread holds 1/1024 of the weights -- 16 loads of
-// 16 bytes, requested first and landing while the FFTs run.  conv1 itself is 4 x 51 k multiply-adds per workgroup on the
-// vector ALU: thread (wave w, f_sub = lane >> 4, 4 columns) multiplies rows f = 64 w + 4 j + f_sub of B1[f][64] with the
-// scaled magnitudes xs[f][4 frames] from LDS; the 64 partial sums per (frame, column) are added by two lane shuffles and
-// one LDS pass.   H1[t][c] = sum_f (scale * mag[t][f]) * W1[c, 0, 0, F-1-f] + b1[c] + b1b[c]   (separate_dsd.py:198-199)
-template <int LOG2M>
-__global__ __launch_bounds__(1024) void lat_stft_conv1_kernel(const float* __restrict__ audio, int64_t L,
-                                                              const float* __restrict__ win, const float2* __restrict__ tw,
-                                                              float* __restrict__ mag, float* __restrict__ phase,
-                                                              float2* __restrict__ unit, int64_t ld, int hop, int64_t T,
-                                                              int64_t rows_out, float inv_sqrt_n, int vec,
-                                                              const float* __restrict__ B1 /* [K1][64] */,
-                                                              const float* __restrict__ bias1, float* __restrict__ H1,
-                                                              int64_t h1_rows, int CI, float scale) {
-    constexpr int M = 1 << LOG2M;
-    constexpr int RPW = M / 16;                // rows of B1 per wave (K1 = M + 4: the last 4 rows are wave 0's extra load)
-    constexpr int NL = RPW / 4;                // 16-byte loads per thread
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* twl = reinterpret_cast<float2*>(smem);                      // [M + 2]
-    const int tid = threadIdx.x;
-    const int q = tid >> 8, gt = tid & 255;
-    float2* buf0 = twl + (M + 2) + q * (2 * M);
-    float2* buf1 = buf0 + M;
-    f32x4* xs = reinterpret_cast<f32x4*>(twl + (M + 2) + 4 * (2 * M));   // [M + 4] rows x 4 frames
-    float* red = reinterpret_cast<float*>(xs + (M + 4));                // [16 waves][4 frames][64 columns]
-    const int wave = tid >> 6, lane = tid & 63;
-    const int f_sub = lane >> 4, c4 = (lane & 15) * 4;
-
-    // conv1 weights first: they do not depend on anything
-    f32x4 breg[NL], btail = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NL; ++j) breg[j] = *reinterpret_cast<const f32x4*>(B1 + (int64_t)(wave * RPW + 4 * j + f_sub) * 64 + c4);
-    if (wave == 0) btail = *reinterpret_cast<const f32x4*>(B1 + (int64_t)(M + f_sub) * 64 + c4);
-    const float b1 = tid < 256 ? bias1[tid & 63] : 0.f;
-
-    const int64_t t = (int64_t)blockIdx.x * 4 + q;
-    const bool in_grid = t < rows_out, live = in_grid && t < T;
-    float* mrow = mag + (in_grid ? t : 0) * ld;
-    float* prow = phase ? phase + (in_grid ? t : 0) * ld : nullptr;
-    float2* urow = unit + (in_grid ? t : 0) * ld;
-    for (int k = tid; k <= M; k += 1024) twl[k] = tw[k];
-    {
-        const int64_t base = t * (int64_t)hop - M;
-        const float2* w2 = reinterpret_cast<const float2*>(win);
-        for (int m = gt; m < M; m += 256) {
-            const int64_t p = base + 2 * m;
-            float x0 = 0.f, x1 = 0.f;
-            if (live) {
-                if (vec && p >= 0 && p + 1 < L) {
-                    const float2 x = *reinterpret_cast<const float2*>(audio + p);
-                    x0 = x.x;
-                    x1 = x.y;
-                } else {
-                    if (p >= 0 && p < L) x0 = audio[p];
-                    if (p + 1 >= 0 && p + 1 < L) x1 = audio[p + 1];
-                }
-            }
-            const float2 w = w2[m];
-            buf0[m] = make_float2(x0 * w.x, x1 * w.y);
-        }
-    }
-    __syncthreads();
-    const float2* Z = lat_fft<LOG2M, -1>(buf0, buf1, twl, gt);
-    float* xsf = reinterpret_cast<float*>(xs);
-    for (int k = gt; k <= M; k += 256) {
-        const float2 zk = Z[k & (M - 1)];
-        const float2 zm = Z[(M - k) & (M - 1)];
-        const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
-        const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-        const float2 w = twl[k];
-        const float xr = er + (w.x * orr - w.y * oi);
-        const float xi = ei + (w.x * oi + w.y * orr);
-        const float ax = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
-        const float rx = __builtin_amdgcn_rcpf(ax);
-        const float mg = live ? ax * inv_sqrt_n : 0.f;          // rows past the last frame: zeros (zero-padding tiler)
-        xsf[k * 4 + q] = scale * mg;
-        if (in_grid) {
-            mrow[k] = mg;
-            if (prow) prow[k] = live ? atan2f(xi, xr) : 0.f;
-            urow[k] = (live && ax > 0.f) ? make_float2(xr * rx, xi * rx) : make_float2(1.f, 0.f);
-        }
-    }
-    for (int k = M + 1 + gt; k < M + 4; k += 256) {             // row padding (ld = M + 4 for these frame sizes)
-        xsf[k * 4 + q] = 0.f;
-        if (in_grid && k < ld) {
-            mrow[k] = 0.f;
-            if (prow) prow[k] = 0.f;
-            urow[k] = make_float2(1.f, 0.f);
-        }
-    }
-    __syncthreads();
-    // conv1 partial sums: 4 frames x 4 columns per thread
-    f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-        const f32x4 xv = xs[wave * RPW + 4 * j + f_sub];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] += xv[g] * breg[j];
-    }
-    if (wave == 0) {
-        const f32x4 xv = xs[M + f_sub];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] += xv[g] * btail;
-    }
-    // the 4 row phases of a wave sit 16 lanes apart
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = acc[g][e];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            acc[g][e] = v;
-        }
-    if (f_sub == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(red + (wave * 4 + g) * 64 + c4) = acc[g];
-    }
-    __syncthreads();
-    if (tid < 256) {
-        const int g = tid >> 6, col = tid & 63;
-        float part[16];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) part[w] = red[(w * 4 + g) * 64 + col];
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) sum += part[w];
-        const int64_t tt = (int64_t)blockIdx.x * 4 + g;
-        if (tt < h1_rows && col < CI) H1[tt * CI + col] = sum + b1;
-    }
 }
 
 // inverse, two kernels.  (The first version did both in one: a workgroup per (source, hop block) transformed the N/hop
@@ -1418,43 +928,6 @@ int dcs_launch_lat_gemm(dcs_ctx* ctx, const DcsLatGemm& g, int tag) {
     return DCS_OK;
 }
 
-// ---- the middle in one launch (lat_mid_kernel)
-void dcs_lat_pack_mid(const float* Bfc, int ld_fc, const float* Bd, int ld_d, std::vector<float>* wfc, std::vector<float>* wd) {
-    wfc->assign((size_t)8 * kMidC2 * 16, 0.f);     // [member][input kk][16 hidden units of the member]
-    for (int c = 0; c < 8; ++c)
-        for (int kk = 0; kk < kMidC2; ++kk)
-            for (int h = 0; h < 16; ++h) (*wfc)[((size_t)c * kMidC2 + kk) * 16 + h] = Bfc[(size_t)kk * ld_fc + 16 * c + h];
-    wd->assign((size_t)8 * 129 * 312, 0.f);        // [member][hidden unit, 3 slices of 43 = 129 rows, the last zero][312 columns]
-    for (int c = 0; c < 8; ++c)
-        for (int h = 0; h < kMidZ; ++h)
-            for (int j = 0; j < 312; ++j) (*wd)[((size_t)c * 129 + h) * 312 + j] = Bd[(size_t)h * ld_d + 312 * c + j];
-}
-size_t dcs_lat_mid_state_bytes(int max_tiles) { return 256 + (size_t)max_tiles * kMidTileGranules * sizeof(u64); }
-int dcs_lat_mid_state_init(void* state_d, int max_tiles) {   // once per model: granules zero (no launch has tag 0), epoch 1
-    DCS_HIP(hipMemset(state_d, 0, dcs_lat_mid_state_bytes(max_tiles)));
-    const unsigned one = 1;
-    DCS_HIP(hipMemcpy(state_d, &one, sizeof(one), hipMemcpyHostToDevice));
-    return DCS_OK;
-}
-int dcs_launch_lat_mid(dcs_ctx* ctx, const DcsLatMidArgs& h) {
-    if (h.n_tiles <= 0) return DCS_OK;
-    // 32 clusters of 8 workgroups, one workgroup per CU, must all be resident: a device (or partition) with fewer CUs
-    // would leave clusters waiting for members that cannot start
-    if (ctx->n_cu < 256) DCS_FAIL(DCS_EUNSUPPORTED, "lat_mid: the cluster launch needs 256 CUs, this device has %d", ctx->n_cu);
-    DcsLatMid a{};
-    a.H1 = h.H1; a.W2p = h.W2p; a.bias2 = h.bias2; a.Wfc = h.Wfc; a.biasfc = h.biasfc; a.Wd = h.Wd; a.biasd = h.biasd;
-    a.Wdc = h.Wdc; a.state = reinterpret_cast<unsigned*>(h.state);
-    a.gran = reinterpret_cast<u64*>(reinterpret_cast<char*>(h.state) + 256);
-    a.G = h.G; a.Gs = reinterpret_cast<u32x4*>(h.Gs); a.n_tiles = h.n_tiles; a.st = h.st;
-    // ALWAYS 32 clusters of 8 workgroups: the epoch hand-over counts workgroups modulo the grid size, and one workgroup
-    // per CU is what the register budget (512 per lane: all weights of a member live in registers) admits anyway
-    DcsTimer tm(ctx, DCS_TAG_CONV2);
-    hipLaunchKernelGGL(lat_mid_kernel, dim3(256), dim3(256), 0, ctx->stream, a);
-    tm.done();
-    DCS_HIP(hipGetLastError());
-    return DCS_OK;
-}
-
 int dcs_launch_lat_deconv2(dcs_ctx* ctx, const float* D, const float* Wp, float* G, void* Gs, int64_t n_items) {
     if (n_items <= 0) return DCS_OK;
     DcsTimer tm(ctx, DCS_TAG_DECONV2);
@@ -1508,36 +981,6 @@ bool dcs_lat_stft_supported(const dcs_stft* p) {
     return R * p->hop == p->frame && (R == 2 || R == 4);
 }
 
-int dcs_launch_lat_stft_conv1(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
-                              int64_t rows_out, int64_t T, const float* B1, const float* bias1, float* H1, int64_t h1_rows, int CI,
-                              float scale) {
-    if (rows_out <= 0) return DCS_OK;
-    const int M = p->frame / 2;
-    if (!dcs_lat_stft_supported(p) || ld != M + 4) DCS_FAIL(DCS_EINVAL, "lat_stft_conv1: frameSize %d, row pitch %lld", p->frame, (long long)ld);
-    const int vec = (((uintptr_t)audio & 7) == 0 && (p->hop & 1) == 0) ? 1 : 0;
-    const float sq = (float)(1.0 / sqrt((double)p->frame));
-    const size_t lds = ((size_t)(M + 2) + 4 * (size_t)(2 * M)) * sizeof(float2) + (size_t)(M + 4) * 16 + 16 * 4 * 64 * 4;
-    auto k10 = lat_stft_conv1_kernel<10>;
-    auto k9 = lat_stft_conv1_kernel<9>;
-    static DcsOncePerDevice attr_once;
-    DCS_CHECK(attr_once.run(p->ctx->device, [&]() -> int {
-        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k10), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        return DCS_OK;
-    }));
-    const dim3 grid((unsigned)dcs_cdiv(rows_out, 4));
-    DcsTimer tm(p->ctx, DCS_TAG_STFT);
-    if (p->frame == 2048)
-        hipLaunchKernelGGL(k10, grid, dim3(1024), lds, p->ctx->stream, audio, L, p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T,
-                           rows_out, sq, vec, B1, bias1, H1, h1_rows < rows_out ? h1_rows : rows_out, CI, scale);
-    else
-        hipLaunchKernelGGL(k9, grid, dim3(1024), lds, p->ctx->stream, audio, L, p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T,
-                           rows_out, sq, vec, B1, bias1, H1, h1_rows < rows_out ? h1_rows : rows_out, CI, scale);
-    tm.done();
-    DCS_HIP(hipGetLastError());
-    return DCS_OK;
-}
-
 int dcs_launch_lat_stft(dcs_stft* p, const float* audio, int64_t L, float* mag, float* phase, float2* unit, int64_t ld,
                         int64_t rows_out, int64_t T) {
     if (rows_out <= 0) return DCS_OK;
@@ -1572,7 +1015,7 @@ int dcs_launch_lat_istft(dcs_stft* p, const float* sep, int64_t src_stride, cons
     float2* fr = reinterpret_cast<float2*>(frames);
     DcsTimer tm(p->ctx, DCS_TAG_ISTFT);
     // sources per workgroup (NG thread groups of 256, one FFT each, sharing the twiddle table): DCS_LAT_IFFT_NG = 1 / 2 / 4
-    static const int ng_env = getenv("DCS_LAT_IFFT_NG") ? atoi(getenv("DCS_LAT_IFFT_NG")) : 0;
+    constexpr int ng_env = 0;   // sources per workgroup of lat_ifft_kernel: 1 / 2 / 4 all measure 47.0 - 47.5 us per step; 4 kept
     auto launch_ifft = [&](auto ngc) -> int {
         constexpr int NG = decltype(ngc)::value;
         const dim3 g1((unsigned)T, (unsigned)dcs_cdiv(n_src, NG));

@@ -383,7 +383,7 @@ int launch_inverse(dcs_stft* p, const R* win, const R2* tw, const R* wsq, const 
     const size_t fixed = tw_lds ? fixed_tw : fixed_notw;
     size_t lds = fixed + (size_t)C * hop * sizeof(R);
     // LDS per workgroup decides how many workgroups share a CU (their barriers overlap); 48 KiB = 3 per CU
-    static const size_t lds_cap = getenv("DCS_ISTFT_LDS_KB") ? (size_t)atoi(getenv("DCS_ISTFT_LDS_KB")) * 1024 : 48 * 1024;
+    constexpr size_t lds_cap = 48 * 1024;
     while (lds > lds_cap && C > 1) {
         C = C / 2;
         lds = fixed + (size_t)C * hop * sizeof(R);

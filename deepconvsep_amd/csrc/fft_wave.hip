@@ -291,21 +291,13 @@ __device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, c
 // ------------------------------------------------------------------------------------------------
 // forward (compute_file): FPW frames per workgroup, one per wave
 // ------------------------------------------------------------------------------------------------
-#ifndef DCS_STFT_TW_GLOBAL
-#define DCS_STFT_TW_GLOBAL 0   // measured: the 18 per-lane twiddle gathers from global memory cost more than the table fill (0.099 vs 0.089 ms)
-#endif
-__host__ __device__ constexpr bool stft_fwd_tw_global(int log2m) { return DCS_STFT_TW_GLOBAL && log2m <= 10; }
+// (the pass twiddles gathered from global memory instead of an LDS table -- no fill, no barrier, 4 waves per SIMD -- measured
+// slower at every size: 0.099 vs 0.089 ms at 4096 tiles, 25 - 27 vs 22 us at 640; scripts/README.md)
 // per-wave staging of the forward kernel's outputs: 256 magnitudes (1 KB) + 128 phasors (1 KB), see the wide store path
 constexpr int kStftStageF2 = 256;
-#ifndef DCS_STFT_WIDE_STORES
-#define DCS_STFT_WIDE_STORES 1
-#endif
 
-#ifndef DCS_STFT_MIN_WAVES
-#define DCS_STFT_MIN_WAVES 1   // waves per SIMD the forward kernel is sized for (experiment builds)
-#endif
 template <int LOG2M>
-__global__ __launch_bounds__(256, DCS_STFT_MIN_WAVES) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
+__global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
                                          const float2* __restrict__ tw, float* __restrict__ mag,
                                          float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
                                          int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
@@ -315,20 +307,14 @@ __global__ __launch_bounds__(256, DCS_STFT_MIN_WAVES) void stft_forward_wave_ker
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row pointers stay in SGPRs
-    // M <= 1024: the passes take their twiddles from registers (WaveTw), so the table is only read by WaveTw::init and by
-    // the even / odd split -- both straight from global memory (8 KB, L1 / L2 resident), requested together with the samples:
-    // no table fill, no workgroup barrier in front of the first load, 8 KB less LDS (4 workgroups per CU instead of 3)
     FW_STAMP(0);
-    constexpr bool kTwGlobal = stft_fwd_tw_global(LOG2M);
     // [waves][kStageF2] output staging (16-byte aligned: first in the segment), then the table, then the waves' exchange buffers
     float2* stage = reinterpret_cast<float2*>(smem) + wave * kStftStageF2;
     float2* lds0 = reinterpret_cast<float2*>(smem) + (blockDim.x >> 6) * kStftStageF2;
-    const float2* twl = kTwGlobal ? tw : lds0;
-    float2* buf = lds0 + (kTwGlobal ? 0 : (M + 1)) + wave * MP;
-    if (!kTwGlobal) {
-        for (int k = tid; k <= M; k += blockDim.x) lds0[k] = tw[k];
-        __syncthreads();
-    }
+    const float2* twl = lds0;
+    float2* buf = lds0 + (M + 1) + wave * MP;
+    for (int k = tid; k <= M; k += blockDim.x) lds0[k] = tw[k];
+    __syncthreads();
     // output row -> (clip, frame): clips of equal length are stacked with a pitch of rows_pc rows
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (row >= rows_pc * n_clips) return;
@@ -388,11 +374,7 @@ __global__ __launch_bounds__(256, DCS_STFT_MIN_WAVES) void stft_forward_wave_ker
 #pragma unroll
             for (int tt = 0; tt < R1; ++tt) {
                 const int r = 2 * (lane + 64 * b + tt * stride1);
-#ifdef DCS_STFT_ABL_NOLOAD
-                xs[b * R1 + tt] = mk((float)r, 1.f);
-#else
                 xs[b * R1 + tt] = *reinterpret_cast<const cx*>(ap + r);
-#endif
             }
     } else if (r_hi > r_lo) {
 #pragma unroll
@@ -423,11 +405,7 @@ __global__ __launch_bounds__(256, DCS_STFT_MIN_WAVES) void stft_forward_wave_ker
     FW_STAMP(2);   // pass twiddles read, samples and window requested
     FW_DRAIN();
     FW_STAMP(3);   // arrived
-#ifdef DCS_STFT_ABL_NOFFT
-    for (int i = 0; i < P; ++i) stc(buf + pad(lane) + cpad(64 * i), v[i]);
-#else
     fft_wave<LOG2M, -1>(v, lane, wt, twl, buf);
-#endif
     FW_STAMP(8);   // pass 3 done, stores issued
     // even/odd split: X[k] = E + w^k O with E = (Z[k] + conj Z[M-k])/2, O = -i (Z[k] - conj Z[M-k])/2.
     // k = lane + 64 u; M - k = (64 - lane) + (M - 64 (u + 1)): constant parts are multiples of 64.
@@ -456,7 +434,7 @@ __global__ __launch_bounds__(256, DCS_STFT_MIN_WAVES) void stft_forward_wave_ker
     // their bytes -- without stores 0.062 instead of 0.088 ms at 4096 tiles): four 64-bin blocks of magnitudes / two of
     // phasors go through a wave-private 2 KB staging area and leave as ONE 16-byte store per lane (1 KB per instruction):
     // 4 + 8 + 3 store instructions per frame.  Needs rows of exactly M + 4 bins on 16-byte boundaries and no phase output.
-    const bool wide = DCS_STFT_WIDE_STORES && (P % 4 == 0) && ld == M + 4 && !prow && urow &&
+    const bool wide = (P % 4 == 0) && ld == M + 4 && !prow && urow &&
                       ((reinterpret_cast<uintptr_t>(mag) | reinterpret_cast<uintptr_t>(unit)) & 15) == 0;
     if (wide) {
         float* sm = reinterpret_cast<float*>(stage);          // [256] magnitudes of bins 256 g .. 256 g + 255
@@ -499,13 +477,9 @@ __global__ __launch_bounds__(256, DCS_STFT_MIN_WAVES) void stft_forward_wave_ker
             if (u == P && lane > 0) break;  // k <= M
             float ax, xr, xi;
             bin(u, ax, xr, xi);
-#ifdef DCS_STFT_ABL_NOSTORE
-            if (ax == 12345.678f) mrow[k] = ax;    // never true: keeps the arithmetic alive
-#else
             mrow[k] = ax * inv_sqrt_n;
             if (prow) prow[k] = atan2f(xi, xr);
             if (urow) stc(urow + k, phasor(ax, xr, xi));
-#endif
         }
         for (int k = M + 1 + lane; k < ld; k += 64) {
             mrow[k] = 0.f;
@@ -538,12 +512,11 @@ __device__ __forceinline__ cx w_pi16(int j) {
     return mk(c[j & 15], c[(j + 8) & 15] * ((j & 15) >= 8 ? -1.f : 1.f));
 }
 
-// WREG = N / hop when the window pairs a thread needs fit in registers (hop/2 <= 256, N/hop in {2, 4}), else 0.
-// With WREG > 0 and M <= 1024 the kernel keeps neither the twiddle table nor the window in LDS -- the pre-processing
-// twiddle w^k, k = lane + 64 j, is w^lane (one register pair) times a constant -- which brings a workgroup to
-// 52 KB and 3 of them onto a CU (measured: 2 -> 1 workgroups per CU costs 1.6x).
-template <int LOG2M, bool UNIT, int WREG>
-__global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_wave_kernel(const float* __restrict__ mag, int64_t src_stride,
+// The general form: any hop | N (frameSize 4096, or more than four hop-blocks per frame); the configurations the reference ships
+// for frameSize <= 2048 take the barrier-free kernels below.  (Round 1 - 4 kept variants of this kernel with the window pairs
+// in registers for the shapes those kernels now cover; removed in round 5.)
+template <int LOG2M, bool UNIT>
+__global__ __launch_bounds__(256) void istft_wave_kernel(const float* __restrict__ mag, int64_t src_stride,
                                                          const float* __restrict__ phase,
                                                          const float2* __restrict__ unit, int64_t ld,
                                                          const float* __restrict__ win, const float* __restrict__ wsq,
@@ -554,15 +527,14 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
                                                          const int64_t* __restrict__ clip_tab, int64_t out_stride) {
     constexpr int M = 1 << LOG2M, N = 2 * M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
-    constexpr bool LEAN = WREG > 0 && WaveTw<LOG2M>::REG3;   // no twiddle / window tables in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* lp = reinterpret_cast<float2*>(smem);
-    float2* twl = lp;                                    // [M + 1]   (not LEAN)
-    if (!LEAN) lp += M + 1;
+    float2* twl = lp;                                    // [M + 1]
+    lp += M + 1;
     float2* fbuf = lp;                                   // [4][MP] transformed frames
     lp += 4 * MP;
-    float2* winl = lp;                                   // [M] window as (even, odd) pairs   (WREG == 0)
-    if (WREG == 0) lp += M;
+    float2* winl = lp;                                   // [M] window as (even, odd) pairs
+    lp += M;
     float2* ring = lp;                                   // [ring_slots][hop/2]
     float* norm_s = reinterpret_cast<float*>(ring + (size_t)ring_slots * (hop >> 1));  // [hop] steady-state 1 / sum(w^2)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -593,17 +565,10 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
     const int64_t hb0 = (int64_t)chunk * C;
     const int64_t hb1 = (hb0 + C < n_blocks) ? hb0 + C : n_blocks;
 
-    cx wreg[WREG > 0 ? WREG : 1];                        // window pairs of this thread's column, one per frame block
     {
         const float2* w2g = reinterpret_cast<const float2*>(win);
-        if (WREG == 0) {
-            for (int k = tid; k < M; k += 256) winl[k] = w2g[k];
-        } else {
-#pragma unroll
-            for (int d = 0; d < WREG; ++d) wreg[d] = tid < hp ? ldc(w2g + d * hp + tid) : mk(0.f, 0.f);
-        }
-        if (!LEAN)
-            for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
+        for (int k = tid; k < M; k += 256) winl[k] = w2g[k];
+        for (int k = tid; k <= M; k += 256) twl[k] = tw[k];
         for (int q = tid; q < ring_slots * hp; q += 256) stc(ring + q, mk(0.f, 0.f));
         for (int q = tid; q < hop; q += 256) {
             float nrm = 0.f;
@@ -626,8 +591,7 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
     float* dst = audio + (int64_t)s * out_stride;
     __syncthreads();
     WaveTw<LOG2M> wt;
-    wt.init(LEAN ? tw : twl, lane);
-    const cx wl = ldc(tw + lane);                        // w^lane (LEAN)
+    wt.init(twl, lane);
 
     int64_t g_done = hb0;  // next block to write out
     // flush blocks [g_done, g_end): every frame that touches them has been added (or does not exist)
@@ -700,13 +664,7 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
                     }
                     // E = (xk + conj xm)/2 ; D = (xk - conj xm)/2 ; O = D conj(w^k) ; Z = E + i O   (1/2 is in amp)
                     const cx e = c_add_conj(xk, xm), d = c_sub_conj(xk, xm);
-                    cx wk;
-                    if (LEAN) {   // k = lane + 64 j: w^k = w^lane * exp(-i pi 64 j / M)
-                        const int jj = (b + tt * NB1) * (1024 / M);
-                        wk = jj == 0 ? wl : c_mul(wl, w_pi16(jj));
-                    } else {
-                        wk = ldc(twl + k);
-                    }
+                    const cx wk = ldc(twl + k);
                     const cx o = c_mul_conj(d, wk);
                     v[b * R1 + tt] = c_add_i(e, o);
                 }
@@ -714,22 +672,6 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
         }
         __syncthreads();
         // frame n2 covers the hop-blocks n2 .. n2 + R - 1
-        if (WREG > 0) {
-            if (tid < hp) {
-                for (int w = 0; w < 4; ++w) {
-                    const int64_t n2 = nb + w;
-                    if (n2 > n_hi) break;
-#pragma unroll
-                    for (int d = 0; d < WREG; ++d) {
-                        const int64_t g = n2 + d;
-                        if (g < hb0 || g >= hb1) continue;
-                        float2* rp = ring + (int)(g & rmask) * hp + tid;
-                        const cx z = ldc(fbuf + w * MP + pad(d * hp + tid));
-                        stc(rp, ldc(rp) + (z * inv_m) * wreg[d]);
-                    }
-                }
-            }
-        } else
         for (int w = 0; w < 4; ++w) {
             const int64_t n2 = nb + w;
             if (n2 > n_hi) break;
@@ -774,7 +716,7 @@ __global__ __launch_bounds__(256, (WREG > 0 && LOG2M <= 10) ? 3 : 1) void istft_
 // waves of the workgroup) as 16-byte-per-lane global_load_lds transfers -- 8 instead of 64 vector-memory instructions per
 // frame, no registers, a whole FFT ahead of their use -- and reads them back lane by lane from LDS.  Costs one workgroup
 // barrier per frame: the four waves walk the same frames, which they do anyway (same chunk, same clip).
-template <int LOG2M, bool UNIT, int R, int STAGE = 0 /* 1: magnitudes and phasors through LDS, 2: magnitudes only (no barrier) */>
+template <int LOG2M, bool UNIT, int R, int STAGE = 0 /* 1: magnitudes and phasors through LDS */>
 __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restrict__ mag, int64_t src_stride,
                                                           const float* __restrict__ phase, const float2* __restrict__ unit,
                                                           int64_t ld, const float* __restrict__ win,
@@ -860,7 +802,6 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < M / 256; ++c) __builtin_amdgcn_global_load_lds(m4 + 64 * c + lane, sm4 + 64 * c, 16, 0, 0);
         if (lane == 0) __builtin_amdgcn_global_load_lds(m4 + M / 4, sm4 + M / 4, 16, 0, 0);
-        if (STAGE == 2) return;
         const f4* u4 = reinterpret_cast<const f4*>(unit + n * ld);
         f4* su4 = reinterpret_cast<f4*>(sunit + (int)(n & 1) * (M + 4));
         constexpr int UQ = M / 2 / 4;                         // 16-byte pieces per wave: M / 2 of the M / 2 * 4 + 2
@@ -883,7 +824,7 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
                     // the barrier also says that everybody is done reading frame n - 1's phasors.  (Waiting only down to the
                     // VPB block stores issued behind the request measured the same: 0.1974 vs 0.1980 ms at 4096 tiles.)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (STAGE == 1) __syncthreads();
+                    __syncthreads();
                 }
                 const float2* su = sunit + (int)(n & 1) * (M + 4);
                 cx v[P];
@@ -893,21 +834,12 @@ __global__ __launch_bounds__(256, 2) void istft_seq_kernel(const float* __restri
                     for (int tt = 0; tt < R1; ++tt) {
                         const int k = lane + 64 * b + tt * stride1;  // 0 <= k < M
                         const int km = M - k;                         // 1..M
-#ifdef DCS_ISTFT_ABL_NOMAG
-                        const float a = (float)(k + 1) * amp, b2 = (float)(km + 1) * amp;
-#else
                         const float a = (STAGE ? smag[k] : mrow[k]) * amp;
                         const float b2 = (STAGE ? smag[km] : mrow[km]) * amp;
-#endif
                         cx xk, xm;
                         if (UNIT) {
-#ifdef DCS_ISTFT_ABL_NOUNIT
-                            xk = mk(0.6f, 0.8f) * a;
-                            xm = mk(0.8f, -0.6f) * b2;
-#else
                             xk = (STAGE == 1 ? ldc(su + k) : ldc(urow + k)) * a;
                             xm = (STAGE == 1 ? ldc(su + km) : ldc(urow + km)) * b2;
-#endif
                         } else {
                             float sn, cs;
                             sincosf(prow[k], &sn, &cs);
@@ -1192,12 +1124,11 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride,
                float* phase, float2* unit, int64_t ld, int64_t rows_out, int64_t T, bool interleave,
                const int64_t* clip_tab) {
     constexpr int M = 1 << LOG2M, MP = M + M / 32;
-    // frames per workgroup: 4 when there are plenty of frames, 1 to spread a short signal over the CUs
-    static const int fpw_env = getenv("DCS_STFT_FPW") ? atoi(getenv("DCS_STFT_FPW")) : 0;
+    // frames per workgroup: 4 when there are plenty of frames, 1 to spread a short signal over the CUs (1 / 2 / 3 per
+    // workgroup at 640 tiles: 33.1 / 27.5 / 22.4 us against 22.0 with 4)
     const int64_t rows_all = rows_out * n_clips;
-    int fpw = rows_all >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
-    if (fpw_env) fpw = fpw_env;
-    const size_t lds = ((stft_fwd_tw_global(LOG2M) ? 0 : (size_t)(M + 1)) + (size_t)fpw * (MP + kStftStageF2)) * sizeof(float2);
+    const int fpw = rows_all >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
+    const size_t lds = ((size_t)(M + 1) + (size_t)fpw * (MP + kStftStageF2)) * sizeof(float2);
     auto kern = stft_forward_wave_kernel<LOG2M>;
     if (lds > 48 * 1024)
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1217,16 +1148,11 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
     const int64_t n_blocks = (n_out + N / 2 + hop - 1) / hop;
     int ring_slots = 8;
     while (ring_slots < R_ + 3) ring_slots *= 2;
-    // window pairs in registers when a thread owns one pair per hop-block and a frame is 2 or 4 blocks; then (M <= 1024)
-    // neither the window nor the twiddle table take LDS
-    static const int lean_env = getenv("DCS_ISTFT_LEAN") ? atoi(getenv("DCS_ISTFT_LEAN")) : 1;
-    const int wreg = (lean_env && hop / 2 <= 256 && (R_ == 2 || R_ == 4) && LOG2M <= 10) ? R_ : 0;
-    const size_t lds = ((wreg ? 0 : (size_t)(M + 1)) + 4 * (size_t)MP + (wreg ? 0 : (size_t)M) +
-                        (size_t)ring_slots * (hop / 2)) * sizeof(float2) + (size_t)hop * sizeof(float);
+    const size_t lds = ((size_t)(M + 1) + 4 * (size_t)MP + (size_t)M + (size_t)ring_slots * (hop / 2)) * sizeof(float2) +
+                       (size_t)hop * sizeof(float);
     // barrier-free wave-sequential kernel: N <= 2048, frames of 2 or 4 hop-blocks, hop / 2 a multiple of 64
-    static const int seq_env = getenv("DCS_ISTFT_SEQ") ? atoi(getenv("DCS_ISTFT_SEQ")) : 1;
     if constexpr (LOG2M <= 10) {
-        if (seq_env && (R_ == 2 || R_ == 4) && (hop / 2) % 64 == 0 && R_ * (hop / 2) == M) {
+        if ((R_ == 2 || R_ == 4) && (hop / 2) % 64 == 0 && R_ * (hop / 2) == M) {
             static const int c_seq = getenv("DCS_ISTFT_SEQ_HOPS") ? atoi(getenv("DCS_ISTFT_SEQ_HOPS")) : 0;
             const int64_t total_s = n_blocks * n_src;
             // 2 waves per SIMD: the kernel needs ~240 registers (the R blocks in flight, the pass twiddles, a frame's points);
@@ -1240,7 +1166,7 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
             const dim3 grid_s((unsigned)(((int64_t)n_chunks_s * n_src + 3) / 4));
             // spectra through LDS (istft_seq_kernel<..., true>): four sources per clip in one workgroup, phasor input, rows of
             // M + 4 bins whose starts are 16-byte aligned; DCS_ISTFT_STAGE=0 switches it off
-            static const int stage_env = getenv("DCS_ISTFT_STAGE") ? atoi(getenv("DCS_ISTFT_STAGE")) : 1;   // 2: magnitudes only
+            static const int stage_env = getenv("DCS_ISTFT_STAGE") ? atoi(getenv("DCS_ISTFT_STAGE")) : 1;
             const int spc = src_per_clip > 0 ? src_per_clip : n_src;
             // measured (profiles/r03_e_istft_stage_sweep.txt): 4096 tiles 0.229 -> 0.198 ms, 2048 tiles 0.129 -> 0.113, but 1024
             // tiles 0.063 -> 0.069 and 640 tiles 0.048 -> 0.052 -- with few hop-blocks per wave the chip's memory system is not
@@ -1299,7 +1225,7 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
             }
 #define DCS_SEQ_STAGE(R__)                                                                                           \
             {                                                                                                        \
-                auto kern = stage_env == 2 ? istft_seq_kernel<LOG2M, true, R__, 2> : istft_seq_kernel<LOG2M, true, R__, 1>; \
+                auto kern = istft_seq_kernel<LOG2M, true, R__, 1>;                                                   \
                 DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stage));            \
                 hipLaunchKernelGGL(kern, grid_s, dim3(256), lds_stage, p->ctx->stream, mag, src_stride, phase, unit, ld, \
@@ -1329,37 +1255,30 @@ int launch_inv(dcs_stft* p, const float* mag, int64_t src_stride, const float* p
             return DCS_OK;
         }
     }
-    static const int pad_env = getenv("DCS_ISTFT_LDSPAD") ? atoi(getenv("DCS_ISTFT_LDSPAD")) : 0;  // occupancy experiments
-    const size_t lds_req = lds + (size_t)pad_env;
-    if (lds_req > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "wave iSTFT: %zu bytes of LDS", lds_req);
+    if (lds > 160 * 1024) DCS_FAIL(DCS_EUNSUPPORTED, "wave iSTFT: %zu bytes of LDS", lds);
     // C hop-blocks per workgroup (C + R_ - 1 frames are transformed, 4 per step): one round of resident
     // workgroups, all of the same length.  Measured on MI355X, N = 2048: 4096 tiles C = 161 0.384 ms, 81 0.403,
     // 41 0.425, 9 0.548; 32 tiles (752 blocks) C = 2 18.1 us, 1 22.3, 5 19.4.
-    static const int c_env = getenv("DCS_ISTFT_HOPS") ? atoi(getenv("DCS_ISTFT_HOPS")) : 0;
     const int64_t total = n_blocks * n_src;
     const int64_t resident = (int64_t)p->ctx->n_cu * (lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3));
     int64_t C = (total + resident - 1) / resident;
     if (C >= 8) C = (C + R_ - 1 + 3) / 4 * 4 - (R_ - 1);  // C + R_ - 1 a multiple of 4: no half-empty last step
     if (C < 1) C = 1;
-    if (c_env > 0) C = c_env;
     const int n_chunks = (int)((n_blocks + C - 1) / C);
     const dim3 grid((unsigned)n_chunks * (unsigned)n_src);
-#define DCS_GO(UNIT_) \
-    { if (wreg == 4) { DCS_GO2(UNIT_, 4) } else if (wreg == 2) { DCS_GO2(UNIT_, 2) } else { DCS_GO2(UNIT_, 0) } }
-#define DCS_GO2(UNIT_, WREG_)                                                                                     \
+#define DCS_GO(UNIT_)                                                                                             \
     {                                                                                                             \
-        auto kern = istft_wave_kernel<LOG2M, UNIT_, (LOG2M <= 10 ? WREG_ : 0)>;                                    \
-        if (lds_req > 48 * 1024)                                                                                  \
+        auto kern = istft_wave_kernel<LOG2M, UNIT_>;                                                              \
+        if (lds > 48 * 1024)                                                                                      \
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req));               \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_req, p->ctx->stream, mag, src_stride, phase, unit, ld, p->win_f, \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, p->ctx->stream, mag, src_stride, phase, unit, ld, p->win_f, \
                            p->wsq_f, p->tw_f, audio, n_out, hop, T, (int)C, n_blocks, n_chunks, n_src, ring_slots,  \
                            pre_div, (float)sqrt((double)N), unit_clip_stride, src_per_clip > 0 ? src_per_clip : n_src, \
                            clip_tab, out_stride > 0 ? out_stride : n_out);                                         \
     }
     if (unit) DCS_GO(true) else DCS_GO(false)
 #undef DCS_GO
-#undef DCS_GO2
     return DCS_OK;
 }
 

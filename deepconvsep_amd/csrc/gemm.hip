@@ -350,7 +350,7 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     static const int ks_env = getenv("DCS_GEMM_KSPLIT") ? atoi(getenv("DCS_GEMM_KSPLIT")) : -1;   // 0 disables
     const int64_t tiles16 = groups16 * (g.n_cols / 16);
     if (g.a_vec && ks_env != 0 && g.K >= 16384 && tiles16 < 4 * (int64_t)ctx->n_cu) {
-        static const int ks_tile = getenv("DCS_GEMM_KSPLIT_TILED") ? atoi(getenv("DCS_GEMM_KSPLIT_TILED")) : 1;
+        constexpr int ks_tile = 1;
         const bool tiled = ks_tile && g.M >= 48;
         const int64_t units = tiled ? dcs_cdiv(g.M, 64) * (g.n_cols / BN) : tiles16;
         int ksplit = ks_env > 0 ? ks_env : (int)(((tiled ? 3 : 8) * (int64_t)ctx->n_cu + units - 1) / units);
@@ -362,7 +362,7 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
             DcsGemm q = g;
             q.partial = (float*)ctx->gemm_ws.ptr;
             q.kchunk = kchunk;
-            static const bool xcd_env = !(getenv("DCS_GEMM_KSPLIT_XCD") && atoi(getenv("DCS_GEMM_KSPLIT_XCD")) == 0);
+            constexpr bool xcd_env = true;
             q.xcd_slices = xcd_env ? 1 : 0;
             // 64 x 64 LDS tiles reuse every operand 4x more often than the 16 x 16 register tiles (which stream A and B
             // from L2 with 4 flop/B): worth it from a few row groups on
@@ -380,7 +380,7 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
             return DCS_OK;
         }
     }
-    static const int force = getenv("DCS_GEMM_FORCE") ? atoi(getenv("DCS_GEMM_FORCE")) : 0;   // experiments: RB * 1000 + BK
+    constexpr int force = 0;   // (RB * 1000 + BK forced a tile shape in the round-1 .. 4 experiments; the heuristic below won every time)
     if (force) {
         switch (force) {
             case 1032: launch_rb<1, 32>(ctx, g); break;
@@ -396,7 +396,7 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
         DCS_HIP(hipGetLastError());
         return DCS_OK;
     }
-    static const int64_t sk_env = getenv("DCS_GEMM_SPLITK_MAX") ? atoll(getenv("DCS_GEMM_SPLITK_MAX")) : -1;
+    constexpr int64_t sk_env = -1;
     const int64_t sk_max = sk_env >= 0 ? sk_env : (int64_t)ctx->n_cu / 2;
     if (g.a_vec && groups16 * col_groups <= sk_max) {
         dim3 grid((unsigned)groups16, (unsigned)(g.n_cols / 16));

@@ -402,7 +402,7 @@ bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
     // conv1 0.041 -> 0.047 ms, fc 0.020 -> 0.021, while fc1x 0.042 -> 0.036; Bach10 fc1x (167 x 256 x 666 600) 0.72 -> 0.58
     if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu || g.n_cols < 1024 || g.M < 128) return false;
     if (dcs_launch_gemm_bf16x3_skinny(ctx, g, nullptr)) return true;
-    static const int xcd_map = !(getenv("DCS_GEMM_XCD") && atoi(getenv("DCS_GEMM_XCD")) == 0);
+    constexpr int xcd_map = 1;
     if (groups16 * col_groups <= 16 * (int64_t)ctx->n_cu)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2>), dim3((unsigned)dcs_cdiv(g.M, 32), (unsigned)col_groups), dim3(kThreads), 0,
                            ctx->stream, g, xcd_map);
@@ -426,7 +426,7 @@ bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemm
     for (int i = 0; i < (b.n > 0 ? b.n : 1); ++i)
         if (((uintptr_t)(b.n > 0 ? b.C[i] : g.C) & 15) || (b.n > 0 && !b.Bq[i])) return false;
     const int rbt = g.M <= 128 ? 8 : 11;
-    static const int cb_env = getenv("DCS_GEMM_SKINNY_CB") ? atoi(getenv("DCS_GEMM_SKINNY_CB")) : 2;
+    constexpr int cb_env = 2;   // four column blocks per wave measured 0.56 vs 0.52 ms (round 2)
     const int cb = cb_env == 4 ? 4 : 2;
     const size_t lds = (size_t)3 * rbt * 16 * kRowU4 * 16;
     auto kern = rbt == 8 ? (cb == 4 ? gemm_bf16x3_skinny_kernel<8, 4> : gemm_bf16x3_skinny_kernel<8, 2>)

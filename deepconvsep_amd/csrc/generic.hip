@@ -1575,7 +1575,7 @@ bool launch_slabconv(dcs_ctx* ctx, SlabConvArgs a, int64_t n_images, const uint1
     if (Wq) {
         // 16 waves per workgroup: LDS allows one workgroup per CU, so the waves that hide each other's LDS latency have
         // to come from inside it
-        static const int nw_env = getenv("DCS_SLABCONV_WAVES") ? atoi(getenv("DCS_SLABCONV_WAVES")) : 16;
+        constexpr int nw_env = 16;
         auto kern = nw_env == 8 ? (mode == 0 ? slabconv_mx_kernel<0, 8> : slabconv_mx_kernel<1, 8>)
                                 : (mode == 0 ? slabconv_mx_kernel<0, 16> : slabconv_mx_kernel<1, 16>);
         if (lds > 48 * 1024 &&
@@ -1596,7 +1596,7 @@ int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16
                    const uint16_t* Wps = nullptr) {
     a.n_xb = (a.W + 15) / 16;
     if (Wh && Wr && dcs_launch_colconv_wreg(ctx, a, n_images, Wr)) return DCS_OK;
-    static const bool ps_col = !(getenv("DCS_COLCONV_PS") && atoi(getenv("DCS_COLCONV_PS")) == 0);
+    constexpr bool ps_col = true;
     // f32-class forward conv2: bf16 x 3 with the slab pre-split in LDS (0.41 -> 0.25 ms on the score-informed batch).  The
     // transpose stays with the f32 column kernel: 7 of 20 taps are valid on average there and that kernel walks only
     // those (0.34 against 0.38 ms)
@@ -1636,8 +1636,8 @@ int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16
     return DCS_OK;
 }
 
-static const bool kF16Igemm = getenv("DCS_F16_IGEMM") && atoi(getenv("DCS_F16_IGEMM")) != 0;
-static const bool kSlabMx = !(getenv("DCS_SLABCONV_MX") && atoi(getenv("DCS_SLABCONV_MX")) == 0);   // 0: the f32-MFMA slab kernel
+constexpr bool kF16Igemm = false;
+constexpr bool kSlabMx = true;
 
 // Will both InverseLayers run as ONE kernel, and does that kernel want the dense output channels-last?  One place decides it:
 // forward_chunk (layout of the dense layers' output) and dcs_generic_forward (chunk size: the layout can only be produced by
@@ -2011,7 +2011,7 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
     // layers AND to the two-kernel decoder -- a 20 s clip several times slower per tile than a 10 s one.  Cut such passes into
     // equal pieces inside the window instead (the dense weights are re-read once per piece: 0.85 GB, ~0.2 ms; the deferred-mask
     // form below is single-chunk, so such a pass takes the separate mask and cross-fade kernels).
-    static const bool cap_env = !(getenv("DCS_GENERIC_CHUNK_CAP") && atoi(getenv("DCS_GENERIC_CHUNK_CAP")) == 0);
+    constexpr bool cap_env = true;
     if (cap_env && chunk_env <= 0 && n > 176 && g->d.n_branch > 1 && g->flat64 >= 8192 && plans_channels_last(g, nullptr, nullptr)) {
         const int64_t pieces = (n + 175) / 176, per = (n + pieces - 1) / pieces;
         const int64_t capped = per >= 128 ? per : 176;
@@ -2109,7 +2109,7 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
     // past its own n_c * st + tc stay unwritten (the iSTFT only reads its own T_c frames)
     if (mask_fused) {
         DcsTimer tm(ctx, DCS_TAG_MASK);
-        static const int mm_env = getenv("DCS_MASK_OLA_MM") ? atoi(getenv("DCS_MASK_OLA_MM")) : 1;   // 0: the loop form
+        constexpr int mm_env = 1;   // (0 selected the loop form: 2.6 TB/s on the Bach10 clip against the all-requests-first form)
         const int mmax = (ov + st - 1) / st + 1;             // tiles that can reach one frame
         for (int64_t c = 0; c < n_clips; ++c) {
             const dim3 grid((unsigned)(nc[c] * st + tc), (unsigned)dcs_cdiv(F, kThreads));

@@ -104,8 +104,6 @@ struct dcs_model {
     // one-batch ("latency") kernels, dsd_lat.hip: the GEMM B operands in MFMA fragment order, the transposed-conv2
     // weights likewise; lat_stages = -1: automatic (all stages for one clip of at most lat_max_frames frames)
     float *L1p = nullptr, *L2p = nullptr, *Lfcp = nullptr, *Ldp = nullptr, *Lw2p = nullptr;
-    float *Lmfc = nullptr, *Lmd = nullptr;   // bottleneck / dense weights per cluster member (lat_mid_kernel)
-    void* lat_mid_state = nullptr;           // epoch, counters and granules of lat_mid_kernel
     int lat_slice1 = 0;
     bool lat_ok = false;
     int lat_stages = -1;
@@ -315,7 +313,7 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
         m->lat_slice1 = (int)dcs_round_up((m->K1 + 15) / 16, 4);
         dcs_lat_pack_b(B1.data(), 64, m->K1, 4, m->lat_slice1, 16, &pk);
         DCS_CHECK(upload(&m->L1p, pk));
-        dcs_lat_pack_b(B2.data(), 64, kh * CI, 4, CI, kh + 1, &pk);   // one more (zero) tap: lat_mid_kernel loads 16 unconditionally
+        dcs_lat_pack_b(B2.data(), 64, kh * CI, 4, CI, kh, &pk);       // one slice per tap
         DCS_CHECK(upload(&m->L2p, pk));
         dcs_lat_pack_b(Bfc.data(), m->hid64, d.h2 * CP, m->hid64 / 16, CP, d.h2, &pk);
         DCS_CHECK(upload(&m->Lfcp, pk));
@@ -323,12 +321,6 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
         DCS_CHECK(upload(&m->Ldp, pk));
         dcs_lat_pack_deconv2(Bw2s.data(), (int)dcs_round_up(CI, kDsdGch), &pk);
         DCS_CHECK(upload(&m->Lw2p, pk));
-        std::vector<float> wfc, wd;
-        dcs_lat_pack_mid(Bfc.data(), m->hid64, Bd.data(), m->nd64, &wfc, &wd);
-        DCS_CHECK(upload(&m->Lmfc, wfc));
-        DCS_CHECK(upload(&m->Lmd, wd));
-        DCS_HIP(hipMalloc(&m->lat_mid_state, dcs_lat_mid_state_bytes(kDcsLatMidMaxTiles)));
-        DCS_CHECK(dcs_lat_mid_state_init(m->lat_mid_state, kDcsLatMidMaxTiles));
         m->lat_ok = true;
     }
     return DCS_OK;
@@ -359,13 +351,11 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     if (clips && (!shared_frames || clip_pitch % tile_row_stride != 0 || n > 0x7fffffff))
         DCS_FAIL(DCS_EINVAL, "dsd_encode: bad clip batch");
     if (lat && (!shared_frames || !a_vec || !m->lat_ok)) DCS_FAIL(DCS_EINVAL, "dsd_encode: the one-batch kernels need shared frames");
-    constexpr unsigned kMidAll = DCS_LAT_CONV2 | DCS_LAT_FC | DCS_LAT_FC1X | DCS_LAT_DECONV2 | DCS_LAT_MID;
-    const bool mid = (lat & kMidAll) == kMidAll && n <= kDcsLatMidMaxTiles && m->lat_mid_state && !clips;
     // two consecutive one-batch GEMMs: the first leaves its K reduction as 4 partial arrays (4 workgroups of 4 waves per
     // output block instead of one of 16), the second adds them while it loads its operand (DESIGN.md "one batch")
-    const bool split1 = (lat & DCS_LAT_CONV1) && (lat & DCS_LAT_CONV2) && !mid && (lat & (DCS_LAT_STFT | DCS_LAT_FUSE1)) != (DCS_LAT_STFT | DCS_LAT_FUSE1);
-    const bool split2 = (lat & DCS_LAT_CONV2) && (lat & DCS_LAT_FC) && !mid;
-    const bool split3 = (lat & DCS_LAT_FC) && (lat & DCS_LAT_FC1X) && !mid;
+    const bool split1 = (lat & DCS_LAT_CONV1) && (lat & DCS_LAT_CONV2);
+    const bool split2 = (lat & DCS_LAT_CONV2) && (lat & DCS_LAT_FC);
+    const bool split3 = (lat & DCS_LAT_FC) && (lat & DCS_LAT_FC1X);
     // conv1 + both biases  (separate_dsd.py:198-199)
     const bool ragged = rowmap != nullptr;
     if (ragged && (!clips || lat || rows_total < tc || tiles_total < 1)) DCS_FAIL(DCS_EINVAL, "dsd_encode: bad ragged batch");
@@ -377,10 +367,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g1.C = w.H1; g1.ldc = CI; g1.c_gdiv = 1 << 30; g1.c_gmul = 0;
     g1.M = n_rows1; g1.n_cols = 64; g1.n_store = CI; g1.K = a_vec ? m->K1 : m->F; g1.relu = 0; g1.a_vec = a_vec;
     (void)BIG;
-    constexpr unsigned kFuse1 = DCS_LAT_STFT | DCS_LAT_CONV1 | DCS_LAT_FUSE1;
-    if ((lat & kFuse1) == kFuse1) {
-        // conv1 was computed by the STFT launch (lat_stft_conv1_kernel)
-    } else if (lat & DCS_LAT_CONV1) {
+    if (lat & DCS_LAT_CONV1) {
         DcsLatGemm q{};
         q.A = rows_src; q.a_row_stride = lda; q.a_scale = a_scale; q.Bp = m->L1p; q.bias = m->bias1;
         q.C = w.H1; q.ldc = CI; q.M = (int)n_rows1; q.n_store = CI; q.K = m->K1; q.slice_len = m->lat_slice1;
@@ -389,14 +376,6 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
         DCS_CHECK(dcs_launch_lat_gemm(m->ctx, q, DCS_TAG_CONV1));
     } else
         DCS_CHECK(dcs_launch_gemm_rows(m->ctx, g1, DCS_TAG_CONV1));
-    if (mid) {
-        // conv2 -> bottleneck -> dense -> transposed conv2 of every tile in one launch (clusters of 8 workgroups)
-        DcsLatMidArgs q{};
-        q.H1 = w.H1; q.W2p = m->L2p; q.bias2 = m->bias2; q.Wfc = m->Lmfc; q.biasfc = m->biasfc; q.Wd = m->Lmd;
-        q.biasd = m->biasd; q.Wdc = m->Lw2p; q.state = m->lat_mid_state;
-        q.G = ((lat & DCS_LAT_FINAL) && w.Gs) ? nullptr : w.G; q.Gs = w.Gs; q.n_tiles = (int)n; q.st = (int)tile_row_stride;
-        return dcs_launch_lat_mid(m->ctx, q);
-    }
     // conv2 + both biases (separate_dsd.py:202-203): output row = position; its A row is kh consecutive H1 rows
     DcsGemm g2{};
     g2.A = w.H1; g2.lda = CI; g2.a_scale = 1.f;
@@ -569,8 +548,7 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
         if (p) (void)hipFree(p);
     for (auto& t : m->rise_tabs)
         if (t.second) (void)hipFree(t.second);
-    if (m->lat_mid_state) (void)hipFree(m->lat_mid_state);
-    float* lat[] = {m->L1p, m->L2p, m->Lfcp, m->Ldp, m->Lw2p, m->Lmfc, m->Lmd};
+    float* lat[] = {m->L1p, m->L2p, m->Lfcp, m->Ldp, m->Lw2p};
     for (float* p : lat)
         if (p) (void)hipFree(p);
     if (m->gen) dcs_generic_destroy(m->gen);
@@ -620,12 +598,12 @@ extern "C" int dcs_model_out_channels(const dcs_model* m) { return m ? m->d.n_br
 // the call is replayed from a hipGraph) and dcs_model_final_kernel (what bench.py prices) all ask here.  plan == nullptr /
 // ov < 0: the caller does not know them (dcs_model_final_kernel) -- the frame-size and covering-tile conditions are then
 // taken as met, which holds for every configuration the reference ships (frame 1024 / 2048, hop 512, overlap <= 25).
-constexpr int kLatDefault = DCS_LAT_ALL & ~DCS_LAT_MID & ~DCS_LAT_FUSE1;
+constexpr int kLatDefault = DCS_LAT_ALL;
 static unsigned dsd_lat_mask(const dcs_model* m, const dcs_stft* plan, int64_t T, int64_t n_clips, bool ragged, int ov,
                              int eps_mode) {
     if (!m->lat_ok || n_clips != 1 || ragged) return 0;
     if (plan && !dcs_lat_stft_supported(plan)) return 0;
-    static const int env_mask = getenv("DCS_LAT") ? atoi(getenv("DCS_LAT")) : -1;
+    constexpr int env_mask = -1;   // (stage selection: dcs_model_set_latency_stages)
     const int want = m->lat_stages >= 0 ? m->lat_stages : (env_mask >= 0 ? env_mask : (T <= dcs_lat_max_frames() ? kLatDefault : 0));
     unsigned lat = (unsigned)want & DCS_LAT_ALL;
     const int st = ov >= 0 ? m->tc - ov : 0;
@@ -666,12 +644,6 @@ extern "C" int dcs_model_forward(dcs_model* m, const float* tiles_d, int64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------ fused path
-// the automatic selection: one launch per layer.  The 8-workgroup-cluster launch of the middle (DCS_LAT_MID) is built and
-// tested but measured slower (a cluster per tile re-reads the 1.9 MB of weights per tile: 77 MB per batch through L2)
-constexpr int kLatBatchDefault = 0;
-static inline int64_t rows1_of(int64_t n, int64_t n_clips, int64_t Trows, int st, int tc) {
-    return n_clips > 1 ? n_clips * Trows : (n - 1) * st + tc;
-}
 
 static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int64_t L, int ov, int tiler, float scale,
                          int eps_mode, int tie_mode, float* pcm_d, float* sep_out, float* mag_out, float* phase_out,
@@ -713,7 +685,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         // bottleneck GEMM's tile -> row map (int32).  The DSD graph takes the COMPACT layout (DCS_RAGGED_COMPACT=0: the
         // uniform pitch of round 3): clip c owns rows [row offset, + rows) and tiles [tile offset, + tiles), so the encoder
         // GEMMs, the dense layers and the transposed conv2 run over the SUM of the clips, not n x the longest.
-        static const bool compact_env = !(getenv("DCS_RAGGED_COMPACT") && atoi(getenv("DCS_RAGGED_COMPACT")) == 0);
+        constexpr bool compact_env = true;
         ragged_compact = compact_env && m->arch == DCS_ARCH_DSD;
         int64_t tiles_bound = 0;
         for (int64_t c = 0; c < n_clips; ++c) {
@@ -776,16 +748,6 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         // one batch per call (the reference's predict_function2 shape): every stage on the short-chain kernels of
         // dsd_lat.hip.  DCS_LAT=<stage bits> / dcs_model_set_latency_stages force a selection (A/B tests, profiling).
         unsigned lat = dsd_lat_mask(m, plan, T, n_clips, clip_tab_d != nullptr, ov, eps_mode);
-        if (lat == 0 && m->lat_ok) {
-            // launches of many tiles: the encoder layers (and the transposed conv2) may still take the sliced-K kernels of
-            // dsd_lat.hip -- DCS_LAT_BATCH=<stage bits 2 | 4 | 8 | 16 | 32>, measured per shape in profiles/r03_*
-            static const int batch_mask = getenv("DCS_LAT_BATCH") ? atoi(getenv("DCS_LAT_BATCH")) : kLatBatchDefault;
-            lat = (unsigned)batch_mask & (DCS_LAT_CONV1 | DCS_LAT_CONV2 | DCS_LAT_FC | DCS_LAT_FC1X | DCS_LAT_DECONV2);
-            if ((int64_t)n * n_clips * 3 > 0x7fffffff / 8 || rows1_of(n, n_clips, Trows, st, tc) > 0x7fffffff / 64) lat = 0;
-            // clips of different lengths (uniform pitch or compact layout) only exist for the throughput kernels: the sliced-K
-            // stages index tiles as clip * n + k (DCS_LAT_BATCH made dcs_separate_ragged fail with 'bad ragged batch')
-            if (clip_tab_d) lat = 0;
-        }
         const bool split = (lat & DCS_LAT_FINAL) || (m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode));
         const size_t b_fr = (lat & DCS_LAT_ISTFT) && pcm_d ? align256(dcs_lat_istft_scratch_bytes(plan, T, S)) : 0;
         const int parts = lat ? 4 : 1;
@@ -798,67 +760,13 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         float* sep = (float*)p; p += b_sep;
         DsdScratch w;
         dsd_carve(m, p, n_all, rows1, rows2, &w, split, parts);
-        // launch groups of many clips: the front of the path as two half-chains side by side -- DCS_FORK=1, OFF by default:
-        // measured on MI355X at 20 x 32 tiles it LOSES, 12.9 against 10.6 us per step (a replayed hipGraph with two branches
-        // pays for its cross-queue dependencies more than the overlapped launch ramps give back; profiles/r04_e_fork_ab.txt).
-        // DCS_FORK_MIN_CLIPS: smallest group that forks.  Not with event timing (the brackets live on one stream), not with
-        // per-clip tables (the halves would need their own), not with a null stream (nothing to order the side stream with).
-        static const bool fork_env = getenv("DCS_FORK") && atoi(getenv("DCS_FORK")) == 1;
-        static const int fork_min = getenv("DCS_FORK_MIN_CLIPS") ? atoi(getenv("DCS_FORK_MIN_CLIPS")) : 8;
-        bool fork_halves = fork_env && lat == 0 && n_clips >= fork_min && n_clips >= 2 && !clip_tab_d && !phase &&
-                           m->ctx->timing_mask == 0 && m->ctx->stream != nullptr && m->C == 1;
-        if (fork_halves) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (!m->ctx->side_stream) {
-                // creating a stream inside a capture is not allowed: the first (eager) call of a shape creates it
-                if (hipStreamIsCapturing(m->ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) fork_halves = false;
-                else DCS_CHECK(dcs_ctx_side_stream(m->ctx));
-            }
-        }
-        constexpr unsigned kFuse1 = DCS_LAT_STFT | DCS_LAT_CONV1 | DCS_LAT_FUSE1;
-        if ((lat & kFuse1) == kFuse1 && ld != plan->frame / 2 + 4) lat &= ~(unsigned)DCS_LAT_FUSE1;
-        if ((lat & kFuse1) == kFuse1)     // STFT + conv1 of the frames the tiles cover: H1 rows 0 .. Tcov-1 (Trows >= Tcov)
-            DCS_CHECK(dcs_launch_lat_stft_conv1(plan, audio_d, L, mag, phase, unit, ld, Trows, T, m->B1, m->bias1, w.H1, rows1, m->CI, scale));
-        else if (lat & DCS_LAT_STFT)
+        if (lat & DCS_LAT_STFT)
             DCS_CHECK(dcs_launch_lat_stft(plan, audio_d, L, mag, phase, unit, ld, Trows, T));
-        else if (fork_halves) {
-            // STFT -> conv1 -> conv2 -> bottleneck -> dense -> conv2^T are per-clip chains of small, latency-bound launches
-            // (60 - 240 workgroups each at 640 tiles): the two halves of the clips run side by side, clips [0, cA) on the
-            // context's stream and [cA, n_clips) on its side stream, and join in front of the final kernel, which -- like the
-            // inverse STFT -- fills the chip and stays one launch.  Every buffer is indexed by clip / row / tile, so a half
-            // is the same call on offset pointers.  (Inside a relaxed graph capture the event wait pulls the side stream
-            // into the capture: the replayed graph has the two branches.)
-            dcs_ctx* c = m->ctx;
-            const int64_t cA = n_clips / 2, cB = n_clips - cA;
-            hipStream_t main_s = c->stream;
-            DCS_HIP(hipEventRecord(c->ev_fork, main_s));
-            DCS_HIP(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-            int rc = DCS_OK;
-            for (int half = 0; half < 2 && rc == DCS_OK; ++half) {
-                const int64_t c0 = half ? cA : 0, nc = half ? cB : cA;
-                const int64_t r0 = c0 * Trows, t0 = c0 * n;
-                c->stream = half ? c->side_stream : main_s;
-                DsdScratch wh = w;
-                wh.H1 = w.H1 + r0 * m->CI; wh.C2 = w.C2 + r0 * m->CP; wh.Z = w.Z + t0 * m->hid64; wh.D = w.D + t0 * m->nd;
-                wh.G = w.G + t0 * m->d.n_fc * (int64_t)dsd_g_pitch(m->CI, tc);
-                if (w.Gs) wh.Gs = (char*)w.Gs + (size_t)t0 * m->d.n_fc * dsd_gs_pitch(m->CI, tc) * 16;
-                rc = dcs_launch_stft_forward_f32_clips(plan, audio_d + c0 * audio_stride, L, audio_stride, nc, mag + r0 * ld, nullptr,
-                                                       unit + r0 * ld, ld, Trows, T, false, nullptr);
-                if (rc == DCS_OK) rc = dsd_encode(m, mag + r0 * ld, ld, true, scale, n, st, true, wh, nc, Trows, 0);
-            }
-            c->stream = main_s;
-            // join even after an error: a capture in progress must not be left with a dangling branch
-            const hipError_t e1 = hipEventRecord(c->ev_join, c->side_stream);
-            const hipError_t e2 = hipStreamWaitEvent(main_s, c->ev_join, 0);
-            DCS_CHECK(rc);
-            DCS_HIP(e1);
-            DCS_HIP(e2);
-        } else
+        else
             DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,
                                                         false, clip_tab_d));
-        if (!fork_halves)
-            DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows, lat, ragged_compact ? rows_sum : 0,
-                                 ragged_compact ? tiles_sum : 0, ragged_compact ? rowmap_d : nullptr));
+        DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows, lat, ragged_compact ? rows_sum : 0,
+                             ragged_compact ? tiles_sum : 0, ragged_compact ? rowmap_d : nullptr));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
         a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
@@ -914,13 +822,12 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     // graph replay needs a capturable (non-null) stream, no event timing, and an identical repeat call
     // A replayed hipGraph costs ~4 us more per call than the same launches issued eagerly from a host that keeps ahead of
     // the GPU (measured on MI355X / ROCm 7.2, one 32-tile batch per call: 55.2 vs 51.3 us; profiles/r03_*): graphs pay off
-    // when several streams compete for the host (launch groups), not for one short call after another.  DCS_LAT_GRAPH=1
-    // replays the one-batch path as a graph anyway.
-    static const bool lat_graph = getenv("DCS_LAT_GRAPH") && atoi(getenv("DCS_LAT_GRAPH")) != 0;
+    // when several streams compete for the host (launch groups), not for one short call after another: the one-batch path
+    // is always issued eagerly.
     const bool lat_call = plan && m->arch == DCS_ARCH_DSD &&
                           dsd_lat_mask(m, plan, dcs_frame_count(n_samples, plan->hop), n_clips, false, overlap, eps_mode) != 0;
     const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD &&
-                           (!lat_call || lat_graph);
+                           !lat_call;
     auto eager = [&]() {
         return separate_impl(m, plan, audio_d, n_samples, overlap, tiler, scale, eps_mode, tie_mode, pcm_d, nullptr, nullptr,
                              nullptr, 0, n_tiles_out, n_frames_out, n_clips, audio_stride);

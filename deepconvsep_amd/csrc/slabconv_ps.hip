@@ -390,7 +390,7 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
     // the kernel as it is: LDS 31 % busy, 3 % of the wave-cycles wait for LDS, 47 % wait at s_barrier / s_waitcnt -- the
     // sixteen waves of a stage have between 2 and 10 live (pair, block) steps (column blocks 0 and 5 of an 83-wide row see
     // 8 and 2 of the 10 pairs) and the stage ends when the slowest is done.
-    static const bool fast_on = !(getenv("DCS_SLABCONV_PS_FAST") && atoi(getenv("DCS_SLABCONV_PS_FAST")) == 0);
+    constexpr bool fast_on = true;
     const bool fast = fast_on && !pu && nvp <= 32;         // a bit per tap pair of a filter row
     const int nw = 16, nbw = 2;
     const int slots = nw * nbw;

@@ -165,9 +165,7 @@ DCS_API int dcs_model_set_score_semantics(dcs_model* m, int normalise, int mixtu
  * reference's own call, predict_function2 on ONE batch of 32 tiles (separate_dsd.py:296-298), where a kernel's duration
  * is its chain of dependent memory latencies.  stages = -1 (default): automatic, all of them for one clip of at most
  * DCS_LAT_MAX_FRAMES (1024) frames; 0: the throughput kernels; else a bit set: 1 STFT, 2 conv1, 4 conv2, 8 bottleneck,
- * 16 per-source dense, 32 transposed conv2, 64 final (transposed conv1 + mask + cross-fade), 128 iSTFT, 256 (with 4 .. 32
- * all set) conv2 .. transposed conv2 as ONE launch of 8-workgroup clusters that exchange through tagged granules, 512 (with
- * 1 and 2 set) STFT and conv1 as ONE launch (four frames per workgroup).  Both families
+ * 16 per-source dense, 32 transposed conv2, 64 final (transposed conv1 + mask + cross-fade), 128 iSTFT.  Both families
  * read and write the same buffers, so any mix is valid (tests compare each stage against the other family).  DSD graph
  * only (DCS_EUNSUPPORTED otherwise). */
 DCS_API int dcs_model_set_latency_stages(dcs_model* m, int stages);

@@ -1025,14 +1025,12 @@ sys.exit(0 if err < 1e-4 else 3)
 """
 
 
-@pytest.mark.parametrize("env", [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}, {"DCS_SLABCONV_MX": "0"},
-                                 {"DCS_SLABCONV_PS": "0"}, {"DCS_SLABCONV_PS_FAST": "0"}])
+@pytest.mark.parametrize("env", [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}, {"DCS_SLABCONV_PS": "0"}])
 @pytest.mark.parametrize("F,n", [(513, 9), (1025, 3)])
 def test_ikala_conv2_kernels_agree_with_the_oracle(env, F, n, tmp_path):
     """conv2 of the iKala graph (10 x 20) and its transpose: slab kernel on the bf16 matrix pipe with the slab pre-split
-    into bf16 planes (default, slabconv_ps.hip: tap loop driven by per-block bit masks; DCS_SLABCONV_PS_FAST=0: bounds
-    arithmetic per tap), the one that splits per tap (DCS_SLABCONV_PS=0), the f32-MFMA slab kernel
-    (DCS_SLABCONV_MX=0) and the implicit-GEMM fallback, on batch sizes that give several row bands per image."""
+    into bf16 planes (default, slabconv_ps.hip: tap loop driven by per-block bit masks), the one that splits per tap
+    (DCS_SLABCONV_PS=0) and the implicit-GEMM fallback, on batch sizes that give several row bands per image."""
     import subprocess
     x = _tiles("ikala", n, 30, F, seed=16)
     want = net_ref.forward("ikala", synth_params("ikala", 30, F, seed=4), x.astype(np.float64), inverse='explicit').numpy()
@@ -1066,7 +1064,7 @@ sys.exit(0 if err < (2e-3 if f16 else 1e-4) else 3)
 
 
 @pytest.mark.parametrize("env", [{"DCS_GENERIC_CHUNK": "8"}, {"DCS_GEMM_KSPLIT": "0"}, {"DCS_GEMM_KSPLIT": "5"},
-                                 {"DCS_GEMM_KSPLIT": "64"}, {"DCS_GEMM_KSPLIT_TILED": "0"},
+                                 {"DCS_GEMM_KSPLIT": "64"},
                                  {"DCS_COLCONV": "0"}, {"DCS_GEMM_BF16": "0"},
                                  {"DCS_CONV1_MFMA": "0"}, {"DCS_CONV1_MFMA": "0", "DCS_CONV1_REG": "0"}, {"DCS_DECONV1_MFMA": "0"},
                                  {"DCS_DECONV1_MFMA": "0", "DCS_DECONV1_REG": "0"},
@@ -1148,15 +1146,10 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
 
 @pytest.mark.parametrize("env", [
     {"DCS_FINAL_CBW": "2"}, {"DCS_FINAL_CBW": "1"},               # 128-bin workgroups (bf16x3 kernel, G split by a pass) / 64-bin (f32)
-    {"DCS_FINAL_CBW": "2", "DCS_FINAL_BF16X3": "0"},              # 128-bin workgroups, f32 kernel
     {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2"},                   # bf16x3 kernel fed by the streaming deconv2 (writes the planes)
-    {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2", "DCS_FINAL_DIRECT": "0"},   # ... its register-staged form (round 3's default)
     {"DCS_DECONV2": "2"}, {"DCS_DECONV2": "1"},                   # streaming / one-shot transposed conv2
-    {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "1"}, {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "7"},
-    {"DCS_ISTFT_SEQ": "0", "DCS_ISTFT_HOPS": "64"},              # ring iSTFT: hop-blocks per workgroup
     {"DCS_STFT_WAVE_MIN": "1"}, {"DCS_FFT_BLOCK": "1"},           # wave-per-frame / block-level FFT everywhere
-    {"DCS_ISTFT_LEAN": "0", "DCS_ISTFT_SEQ": "0"},               # ring iSTFT with its twiddle / window tables in LDS
-    {"DCS_ISTFT_SEQ": "0"}, {"DCS_ISTFT_SEQ_HOPS": "1"}, {"DCS_ISTFT_SEQ_HOPS": "37"},   # ring iSTFT; blocks per wave of the sequential one
+    {"DCS_ISTFT_CHAIN": "0", "DCS_ISTFT_SEQ_HOPS": "1"}, {"DCS_ISTFT_CHAIN": "0", "DCS_ISTFT_SEQ_HOPS": "37"},   # blocks per wave of the barrier-free iSTFT
     {"DCS_GRAPH": "0"},
     {"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE_MIN": "1", "DCS_ISTFT_STAGE": "2"},   # spectra through LDS (long clips' iSTFT) on a short clip
     {"DCS_ISTFT_STAGE": "0"},
@@ -1223,8 +1216,7 @@ sys.exit(0 if (e_many < 5e-6 and e_same < 5e-6 and e_ref < 1e-4) else 3)
 @pytest.mark.parametrize("N", [1024, 2048])
 @pytest.mark.parametrize("env", [{"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE": "0"},
                                  {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "5"},   # chained iSTFT: off, forced run lengths (seams at other places)
-                                 {"DCS_FORK": "1", "DCS_FORK_MIN_CLIPS": "2"},    # the front of a batch as two half-chains on two streams
-                                 {"DCS_RAGGED_COMPACT": "0"}])                    # ragged groups at the uniform pitch of round 3 (default: per-clip row / tile offsets)
+                                 ])
 def test_staged_istft_on_ragged_groups_and_batches(env, N, tmp_path):
     """The LDS-staged inverse STFT (normally long clips only) forced onto short ones: a ragged group (per-clip frame counts
     from the device table: the four waves of a workgroup must still walk the same frames), an equal-length batch and single
@@ -1262,7 +1254,7 @@ def test_bf16x3_final_kernel_meets_the_parity_bar(kind, tmp_path):
     np.savez(f, audio=audio, N=N, n_params=len(params), **{"p%d" % i: p for i, p in enumerate(params)})
     res = {}
     for name, env in (("bf16x3", {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2"}),
-                      ("f32", {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2", "DCS_FINAL_BF16X3": "0"})):
+                      ("f32", {"DCS_FINAL_CBW": "1", "DCS_DECONV2": "2"})):          # the f32-MFMA kernel (64-bin workgroups)
         child_env = dict(os.environ)
         child_env.update(env)
         o1, o2 = str(tmp_path / (name + "_sep.npy")), str(tmp_path / (name + "_pcm.npy"))
