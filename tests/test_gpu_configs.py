@@ -41,7 +41,7 @@ def test_hip_network_matches_the_reference_graph_fixtures(golden, name):
     arch, F, seed, kind = str(g["arch"]), int(g["F"]), int(g["seed"]), str(g["kind"])
     params = cases.case_params(arch, 30, F, seed, kind, g["out_bias"] if kind != "glorot" else None)
     ctx = default_context()
-    net = Network(ctx, arch, params, 30, F)
+    net = Network(ctx, arch, params, 30, F, live_only=False)     # the whole graph, as the fixture holds it (score-informed: 16 channels)
     xd = ctx.to_device(g["x"], np.float32)
     p = ctx.to_host(net.forward_raw(xd))
     assert p.shape == g["p"].shape
@@ -55,6 +55,15 @@ def test_hip_network_matches_the_reference_graph_fixtures(golden, name):
     rec = check_masked(got, g["masked"][:, :, 0], g["p"], p, g["x"][:, 0], S, conv, label="%s (%s)" % (name, kind))
     if arch == "dsd" and kind in ("glorot", "dominant"):
         assert rec["bins_outside_1e4"] == 0
+    if "masked_sum" in g.files:       # the score-informed trainers' mask expressions (x the sum of the input channels), and the pruned model
+        net.set_score_semantics('max', 'sum')
+        got = ctx.to_host(net.forward_masked(xd))
+        check_masked(got, g["masked_sum"][:, :, 0], g["p"], p, g["x"].astype(np.float64).sum(axis=1), S, conv,
+                     label="%s (%s), channel-sum mixture" % (name, kind))
+        live = Network(ctx, arch, params, 30, F)
+        live.set_score_semantics('max', 'sum')
+        assert live.out_channels == 4
+        assert np.max(np.abs(ctx.to_host(live.forward_masked(xd)) - got)) < 2e-6
 
 
 def test_ikala_trainer_pkl_selects_the_no_pool_graph(tmp_path):
