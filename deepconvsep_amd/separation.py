@@ -289,6 +289,8 @@ class Separator(object):
         of ``ring`` pinned host buffers: they stay valid until ``ring - 1`` further calls have been made (copy them to keep
         them longer); ``ring=0`` returns fresh arrays."""
         import torch
+        from .runtime import _torch as _device_torch
+        dtorch = _device_torch()            # device allocations (the memory-safety harness routes them through guarded arenas)
         if max_ratio is None:
             max_ratio = 3.0 if self.arch_name in ("dsd", "hiphop") else 1.5
         mode = 1 if self.arch_name in ("ikala", "ikala_nopool") else 0
@@ -346,10 +348,10 @@ class Separator(object):
         for idx in groups:
             lens = [frames[i] for i in idx]
             B, Lmax = len(idx), max(lens)
-            mono = torch.zeros((B, Lmax), dtype=torch.float32, device=dev) if min(lens) != Lmax else \
-                torch.empty((B, Lmax), dtype=torch.float32, device=dev)
+            mono = dtorch.zeros((B, Lmax), dtype=torch.float32, device=dev) if min(lens) != Lmax else \
+                dtorch.empty((B, Lmax), dtype=torch.float32, device=dev)
             for b, i in enumerate(idx):
-                raw = torch.empty((1, lens[b] * chans[i]), dtype=torch.int16, device=dev)
+                raw = dtorch.empty((1, lens[b] * chans[i]), dtype=torch.int16, device=dev)
                 raw[0].copy_(tens[i].reshape(-1), non_blocking=True)
                 pcm16_to_float(self.ctx, raw, chans[i], mode, out=mono[b:b + 1, :lens[b]])
             if B == 1:

@@ -437,7 +437,7 @@ def test_dcs_gather_through_the_c_abi_with_a_one_rank_rccl_communicator():
         assert comm.gather(ctx, pcm16, full2, root=0) is full2
         torch.cuda.synchronize()
         assert torch.equal(full2[0], pcm16)
-        want = (pcm.cpu().numpy() * 32767).astype(np.int16)           # the scripts' truncation (separate_dsd.py:307-309)
+        want = (pcm.cpu().numpy().astype(np.float64) * 32767).astype(np.int16)   # the scripts' float64 product, truncated (separate_dsd.py:307-309)
         assert np.array_equal(full2[0].cpu().numpy(), want)
         with pytest.raises(ValueError):
             comm.gather(ctx, pcm16, full2, root=3)                      # no such rank

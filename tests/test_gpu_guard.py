@@ -142,12 +142,10 @@ if want("dsd_32_throughput"):
     sep.net.set_latency_stages(0)
     record("dsd_32_throughput", sep.separate(synth_audio(tiles_samples(32) + 311, seed=3)))
     sep.net.set_latency_stages(-1)
-if want("dsd_lat_cluster"):
-    sep.net.set_latency_stages(511 & ~512)                                                # conv2..conv2^T as one cluster launch
-    try:
-        record("dsd_lat_cluster", sep.separate(synth_audio(tiles_samples(32), seed=2)))
-    finally:
-        sep.net.set_latency_stages(-1)
+if want("dsd_pcm16_group"):
+    # the batch driver's int16 path (round 5): int16 frames up, device mix-down, shared launches, device int16 conversion
+    frames16 = [(synth_audio(tiles_samples(8) + 100 * i, seed=20 + i, channels=1 + (i & 1)) * 32767).astype(np.int16) for i in range(3)]
+    record("dsd_pcm16_group", *[o.astype(np.float32) for o in sep.separate_many_pcm16(frames16, ring=0)])
 if want("dsd_640_batch"):
     clips = np.stack([synth_audio(tiles_samples(32), seed=10 + c) for c in range(20)])
     a = ctx.to_device(clips, np.float32)
