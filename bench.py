@@ -64,7 +64,7 @@ FINAL_NAMES = {"one_batch": "lat_final_kernel (deconv1+bias+relu+mask+crossfade 
                "bf16x3": "final_bf16x3_kernel (deconv1+bias+relu+mask+crossfade; bf16 MFMA on operands split into "
                          "three bf16 terms, six products kept, f32 accumulation: f32-class results)"}
 PEAK_HBM_GBPS = 8000.0
-TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
 # which kernel carries a timing tag in each leg (substring of the kernel name in the rocprofv3 counter files); used to look
 # up the HBM traffic record of a leg's kernels in TRAFFIC_FILE["legs"][leg]
 LEG_KERNELS = {
@@ -642,6 +642,24 @@ def main():
               "kernels_ms_sum": round(sum(kernels_ms.values()), 5)}
     launch_group = {"clips": groups[0], "tiles": groups[0] * n_tiles, "kernels_ms": group_ms,
                     "kernels_ms_sum": round(sum(group_ms.values()), 5)}
+    # the two HBM-bound kernels of the group against 8 TB/s: algorithmic bytes per frame x the frames of the launch
+    # over the kernel's HIP-event duration; counter traffic = the record of that kernel whose grid is closest to this launch's
+    if N == 2048:
+        g_frames = groups[0] * T
+        hbm = {}
+        for tag, kname, per_frame, threads in (("stft", "stft_forward_wave_kernel", HOP * 4 + 2 * F * 4, 64.0 * g_frames),
+                                               ("istft", "istft_", (4 + 1) * F * 4 + 4 * HOP * 4, 512.0 * groups[0] * 4 * 3)):
+            ms = group_ms.get(tag)
+            if not ms:
+                continue
+            alg = int(per_frame * g_frames)
+            cands = [(abs(int(k.split("=")[1]) - threads), k) for k in traffic_all if k.startswith(kname) and "=" in k]
+            key = min(cands)[1] if cands else None
+            tr = traffic_bytes(traffic_all.get(key)) if key else None
+            hbm[tag] = {"ms": ms, "algorithmic_bytes": alg, "GBps": round(alg / (ms * 1e-3) / 1e9, 1),
+                        "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": tr,
+                        "traffic_ratio": round(tr / float(alg), 3) if tr else None, "traffic_record": key}
+        launch_group["hbm_kernels"] = hbm
 
     # ---- saturating regime (extra): same path, one long clip per launch, one stream
     saturating = None
