@@ -345,14 +345,35 @@ class Separator(object):
         pos = 0
         views = []
         dev = self.ctx.device
+        # clips cut out of ONE pinned staging block (the batch driver's read arena) travel as one host-to-device copy
+        arena_dev, arena_lo = None, 0
+        live = [i for g in groups for i in g]
+        try:
+            bases = set(tens[i].untyped_storage().data_ptr() for i in live)
+            if len(bases) == 1 and len(live) > 1 and all(tens[i].is_pinned() for i in live):
+                lo = min(tens[i].data_ptr() for i in live)
+                hi = max(tens[i].data_ptr() + tens[i].numel() * 2 for i in live)
+                if hi - lo <= 2 * sum(tens[i].numel() * 2 for i in live) + 4096:       # the block is (nearly) all payload
+                    st0 = tens[live[0]].untyped_storage()
+                    whole = torch.empty(0, dtype=torch.uint8).set_(st0, lo - st0.data_ptr(), (hi - lo,))
+                    arena_dev = dtorch.empty((hi - lo,), dtype=torch.uint8, device=dev)
+                    arena_dev.copy_(whole, non_blocking=True)
+                    arena_lo = lo
+        except Exception:
+            arena_dev = None
         for idx in groups:
             lens = [frames[i] for i in idx]
             B, Lmax = len(idx), max(lens)
             mono = dtorch.zeros((B, Lmax), dtype=torch.float32, device=dev) if min(lens) != Lmax else \
                 dtorch.empty((B, Lmax), dtype=torch.float32, device=dev)
             for b, i in enumerate(idx):
-                raw = dtorch.empty((1, lens[b] * chans[i]), dtype=torch.int16, device=dev)
-                raw[0].copy_(tens[i].reshape(-1), non_blocking=True)
+                nel = lens[b] * chans[i]
+                if arena_dev is not None:
+                    off = tens[i].data_ptr() - arena_lo
+                    raw = arena_dev[off:off + 2 * nel].view(torch.int16).view(1, nel)
+                else:
+                    raw = dtorch.empty((1, nel), dtype=torch.int16, device=dev)
+                    raw[0].copy_(tens[i].reshape(-1), non_blocking=True)
                 pcm16_to_float(self.ctx, raw, chans[i], mode, out=mono[b:b + 1, :lens[b]])
             if B == 1:
                 pcm = self.net.separate(self.plan, mono[0], self.overlap, self.tiler, self.scale_factor, None, self.tie_mode)[None]
@@ -362,12 +383,19 @@ class Separator(object):
                 pcm = self.net.separate_ragged(self.plan, mono, lens, self.overlap, self.tiler, self.scale_factor, None,
                                                self.tie_mode)
             p16 = pcm_to_int16(self.ctx, pcm)                                                       # [B, S, Lmax] int16
-            for b, i in enumerate(idx):
-                n = S * lens[b]
-                dst = host[pos:pos + n].view(S, lens[b])
-                dst.copy_(p16[b, :, :lens[b]], non_blocking=True)
-                views.append((i, dst))
-                pos += n
+            if min(lens) == Lmax:                      # equal lengths: the group's samples leave as one copy
+                blk = host[pos:pos + B * S * Lmax].view(B, S, Lmax)
+                blk.copy_(p16, non_blocking=True)
+                for b, i in enumerate(idx):
+                    views.append((i, blk[b]))
+                pos += B * S * Lmax
+            else:
+                for b, i in enumerate(idx):
+                    n = S * lens[b]
+                    dst = host[pos:pos + n].view(S, lens[b])
+                    dst.copy_(p16[b, :, :lens[b]], non_blocking=True)
+                    views.append((i, dst))
+                    pos += n
         self.ctx.torch_stream.synchronize()
         for i, v in views:
             out[i] = v.numpy()

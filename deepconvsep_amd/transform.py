@@ -173,12 +173,14 @@ class transformFFT(Transforms):
                     continue
                 t64 = t if t.dtype == torch.float64 else t.double()
                 if keep:
-                    # dataset building: one grow-only pinned staging block per output, reused song after song (allocating
-                    # pinned memory costs more than the whole transform), written to disk straight from it
+                    # dataset building: one grow-only pinned staging block per output, reused song after song, written to
+                    # disk straight from it
                     host = self._pinned(role, t64.numel()).view(t64.shape)
                 else:
-                    host = torch.empty(t64.shape, dtype=torch.float64)       # the caller keeps the array: its own memory
-                host.copy_(t64, non_blocking=keep)
+                    # the caller keeps the array: pinned memory of its own (torch's caching host allocator hands the block
+                    # of an earlier call back; a pageable destination measured 19 against 6.8 ms for 106 MB)
+                    host = torch.empty(t64.shape, dtype=torch.float64).pin_memory()
+                host.copy_(t64, non_blocking=True)
                 outs.append(host)
             ctx.torch_stream.synchronize()
         mags = outs[0].numpy()

@@ -96,8 +96,9 @@ def main(argv=None):
         os.makedirs(out, exist_ok=True)
         return out
 
-    def write16(dst, sr, samples):
-        wavio.write_pcm16(dst, sr, samples)
+    def write16(path, sr, pcm):
+        for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
+            wavio.write_pcm16(dst, sr, sig)
 
     def write_float(path, sr, pcm):
         for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
@@ -134,8 +135,7 @@ def main(argv=None):
                 if isinstance(pcm, Exception):
                     failed.append((path, pcm))
                     continue
-                for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
-                    pending.append(pool.submit(write16, dst, sr, sig))
+                pending.append(pool.submit(write16, path, sr, pcm))
             for (path, sr, _), pcm in zip(slow, resf):
                 if isinstance(pcm, Exception):
                     failed.append((path, pcm))
