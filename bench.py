@@ -604,10 +604,6 @@ def main():
         colg = (F + binpad - 1) // binpad
         kname = {"bf16x3": "final_bf16x3_kernel", "one_batch": "lat_final_kernel"}.get(variant, "final_kernel")
         wg_per_clip = rows16 * colg
-        if variant == "bf16x3" and F % 128 == 1 and F > 128:
-            # round 5: F // 128 column groups of 128 bins + the Nyquist bin through a few one-thread-per-frame workgroups
-            colg = F // 128
-            wg_per_clip = rows16 * colg + (clip_frames + 2 + 255) // 256
         grid_threads = (512 if variant == "one_batch" else 256) * wg_per_clip * clips
         rec = traffic_all.get("%s@grid_threads=%d" % (kname, grid_threads)) if N == 2048 else None
         traffic = traffic_bytes(rec)
@@ -625,7 +621,7 @@ def main():
              "avg_kernel_ms": round(ms, 5), "launches": int(launches),
              "tiles_per_launch": round(float(tiles_per_launch), 2)}
         if variant in ("bf16x3", "one_batch"):
-            issued = ach * 6.0 * (64.0 / 50.0) * (max(colg * binpad, F) / float(F))
+            issued = ach * 6.0 * (64.0 / 50.0) * (colg * binpad / float(F))
             r["issued"] = {"achieved": round(issued, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s (bf16 MFMA)",
                            "frac": round(issued / PEAK_F16_TFLOPS, 4),
                            "note": "6 bf16 products per f32 product, K 50->64, bins padded to %d-bin workgroups" % binpad}

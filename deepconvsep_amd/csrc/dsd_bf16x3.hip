@@ -95,84 +95,6 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// The Nyquist bin.  F = N/2 + 1 is one more than a multiple of 128 for every power-of-two frame size, so a grid of 128-bin
-// column groups spent its last group -- a ninth of the workgroups at F = 1025 -- on ONE live bin each: full prologue, six A-set
-// transfers and twelve barriers for 1/128 of a workgroup's output.  That bin is now produced by a few extra workgroups of the
-// same launch (block ids behind the regular ones), one THREAD per frame: the covering tiles' rows are read back from the bf16
-// planes (x = p0 + p1 + p2 exactly), multiplied with the bin's f32 weight column in an fmaf chain (f32-class like the MFMA
-// path, another summation order), and folded with the expressions of `compute` below.  900 multiply-adds per frame.
-__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
-
-template <int MODE>
-__device__ __forceinline__ void final_nyquist_row(const DsdFinalArgs& a, int r, int64_t clip, int bin) {
-    constexpr int NBR = 3;
-    const int tc = a.tc, st = a.st, ov = a.ov, mmax = a.mmax;
-    int n = (int)a.n, rows = (int)a.rows;
-    if (a.clip_tab) {
-        rows = (int)a.clip_tab[kDcsClipTab * clip + 1];
-        n = (int)a.clip_tab[kDcsClipTab * clip + 2];
-    }
-    if (r >= rows) return;
-    int64_t mix_off = clip * a.mix_clip_stride, gs_off = clip * a.gs_clip_stride;
-    if (a.clip_tab && a.clip_tab[kDcsClipTab * clip + 3] >= 0) {
-        mix_off = a.clip_tab[kDcsClipTab * clip + 3] * a.mix_ld;
-        gs_off = a.clip_tab[kDcsClipTab * clip + 4] * a.gs_tile_stride;
-    }
-    int k0 = 0, j0 = -1;
-    {
-        int kk = (r < ov) ? 0 : (int)((unsigned)(r - ov) / (unsigned)st);
-        if (kk > n - 1) kk = n - 1;
-        const int jj = r - kk * st;
-        if (jj < tc) {
-            k0 = kk;
-            j0 = jj;
-        }
-    }
-    const float bias0 = a.bias[0], bias1 = a.bias[1], bias2 = a.bias[2], bias3 = a.bias[3];
-    const float eps_r = 5e-19f;
-    const float mix = a.mix_scale * a.mix[mix_off + (int64_t)r * a.mix_ld + bin];
-    const float* bw = a.Bw + bin;
-    const u32x4* gs = reinterpret_cast<const u32x4*>(a.Gs) + gs_off;
-    float res[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int m = 0; m < mmax; ++m) {
-        const int j = j0 - m * st;
-        if (!(j0 >= 0 && j >= 0 && k0 + m < n)) continue;   // no weight on this row: the main path folds with up = 0, down = 1
-        float x[NBR] = {bias0, bias1, bias2};
-#pragma unroll 1
-        for (int sb = 0; sb < NBR; ++sb) {
-            const u32x4* gp = gs + ((((int64_t)(k0 + m) * NBR + sb) * kNgg) * tc + j) * 3;
-            float acc = sb == 0 ? bias0 : (sb == 1 ? bias1 : bias2);
-#pragma unroll 1
-            for (int g = 0; g < kNgg; ++g) {
-                const u32x4 p0 = gp[(int64_t)g * tc * 3], p1 = gp[(int64_t)g * tc * 3 + 1], p2 = gp[(int64_t)g * tc * 3 + 2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 8 * g + 2 * q;
-                    if (c < a.CI) acc = fmaf((bf_lo(p0[q]) + bf_lo(p1[q])) + bf_lo(p2[q]), bw[(int64_t)c * a.ldb], acc);
-                    if (c + 1 < a.CI) acc = fmaf((bf_hi(p0[q]) + bf_hi(p1[q])) + bf_hi(p2[q]), bw[(int64_t)(c + 1) * a.ldb], acc);
-                }
-            }
-            if (sb == 0) x[0] = acc;
-            else if (sb == 1) x[1] = acc;
-            else x[2] = acc;
-        }
-        const float up = m == 0 ? 1.f : a.rise[j], down = m == 0 ? 0.f : a.rise[ov - 1 - j];
-        const float lo = MODE == 0 ? eps_r : 0.f;
-        const float x3 = x[1] + (bias3 - bias1);
-        const float p0 = fmaxf(x[0], lo), p1 = fmaxf(x[1], lo), p2 = fmaxf(x[2], lo), p3 = fmaxf(x3, lo);
-        const float den = MODE == 0 ? ((p0 + p1) + p2) + p3 : (((p0 + p1) + p2) + p3) + eps_r;
-        const float w = __builtin_amdgcn_rcpf(den) * (mix * up);
-        res[0] = fmaf(down, res[0], p0 * w);
-        res[1] = fmaf(down, res[1], p1 * w);
-        res[2] = fmaf(down, res[2], p2 * w);
-        res[3] = fmaf(down, res[3], p3 * w);
-    }
-    float* out = a.out + clip * a.out_clip_stride + (int64_t)r * a.out_ld + bin;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) out[c * a.out_src_stride] = res[c];
-}
-
 // The A set of a covering tile goes from HBM straight into LDS (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l, scripts/ubench/lds_async.hip)
 // in PIECE-major order -- unit (sp, i) = piece column sp = branch * 21 + plane * 7 + group of row i at sp * 16 + i:
 //   * no prefetch registers and no LDS destination registers: 168 registers = THREE workgroups per CU (round 3's form, which
@@ -184,7 +106,7 @@ __device__ __forceinline__ void final_nyquist_row(const DsdFinalArgs& a, int r, 
 //   * K channels 56..63 (K block 1, kq = 3) do not exist in G: their B rows are zero (Bpk, net.hip), so those lanes read
 //     K piece 3 of the SAME row again -- finite numbers times zero -- and no LDS is zero-filled.
 template <int MODE>
-__global__ __launch_bounds__(kThreads, 3) void final_bf16x3_kernel(const DsdFinalArgs a, int n_colg, unsigned n_reg, int nyq_bin) {
+__global__ __launch_bounds__(kThreads, 3) void final_bf16x3_kernel(const DsdFinalArgs a, int n_colg) {
     constexpr int CBW = 2, NBR = 3;
     constexpr int kABuf = 1024;
     constexpr int kMaxM = 16;
@@ -203,11 +125,7 @@ __global__ __launch_bounds__(kThreads, 3) void final_bf16x3_kernel(const DsdFina
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
-    const unsigned nwg = n_reg, bid = blockIdx.x;             // n_reg regular workgroups, then the Nyquist bin's (one thread per frame)
-    if (bid >= n_reg) {
-        final_nyquist_row<MODE>(a, (int)(bid - n_reg) * kThreads + (int)threadIdx.x, (int64_t)blockIdx.y, nyq_bin);
-        return;
-    }
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const unsigned swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int64_t clip = blockIdx.y;
@@ -700,19 +618,9 @@ int dcs_launch_dsd_gsplit(dcs_ctx* ctx, const float* G, void* Gs, int64_t n_item
 }
 
 int dcs_launch_dsd_final_bf16x3(dcs_ctx* ctx, const DsdFinalArgs& a, int n_colg, int64_t n_wg, unsigned n_clips) {
-    // F = 128 q + 1 (every power-of-two frame size): q regular column groups and the last bin through the per-frame path
-    int nyq_bin = -1;
-    int64_t n_reg = n_wg, extra = 0;
-    if (a.F % 128 == 1 && n_colg == a.F / 128 + 1 && a.F > 128 && a.Bw) {
-        nyq_bin = a.F - 1;
-        n_reg = n_wg / n_colg * (n_colg - 1);
-        n_colg -= 1;
-        extra = dcs_cdiv(a.rows, kThreads);
-    }
-    if (n_reg + extra > 0x7fffffff) DCS_FAIL(DCS_EUNSUPPORTED, "final: %lld workgroups", (long long)(n_reg + extra));
-    const dim3 grid((unsigned)(n_reg + extra), n_clips), block(kThreads);
-    if (a.mask_mode == 0) hipLaunchKernelGGL((final_bf16x3_kernel<0>), grid, block, 0, ctx->stream, a, n_colg, (unsigned)n_reg, nyq_bin);
-    else hipLaunchKernelGGL((final_bf16x3_kernel<1>), grid, block, 0, ctx->stream, a, n_colg, (unsigned)n_reg, nyq_bin);
+    const dim3 grid((unsigned)n_wg, n_clips), block(kThreads);
+    if (a.mask_mode == 0) hipLaunchKernelGGL((final_bf16x3_kernel<0>), grid, block, 0, ctx->stream, a, n_colg);
+    else hipLaunchKernelGGL((final_bf16x3_kernel<1>), grid, block, 0, ctx->stream, a, n_colg);
     DCS_HIP(hipGetLastError());
     return DCS_OK;
 }

@@ -211,3 +211,46 @@ def test_bf16_three_way_split_is_exact_and_six_products_are_fp32_class():
     assert np.max(np.abs(kept - exact) / scale) < 3.0 * 2.0 ** -24   # the three dropped pairs
     f32 = (a @ b).astype(f)                                        # a float32 accumulation for comparison
     assert np.max(np.abs(kept - exact) / scale) < 4.0 * np.max(np.abs(f32 - exact) / scale) + 2.0 ** -24
+
+
+def test_wavio_reads_and_writes_what_scipy_does(tmp_path):
+    """deepconvsep_amd.wavio (the batch driver's int16 path): `read_pcm16` / `read_pcm16_into` return exactly the frames
+    `scipy.io.wavfile.read` returns for 16-bit PCM files (mono, stereo, three channels, empty, odd chunk layouts) and decline
+    everything else; `write_pcm16` produces the bytes `scipy.io.wavfile.write` produces."""
+    import struct
+    import scipy.io.wavfile
+    from deepconvsep_amd import wavio
+    rs = np.random.RandomState(0)
+    a, b = str(tmp_path / "a.wav"), str(tmp_path / "b.wav")
+    for ch in (1, 2, 3):
+        for n in (0, 1, 5, 4411):
+            x = rs.randint(-32768, 32768, (n, ch) if ch > 1 else (n,)).astype(np.int16)
+            scipy.io.wavfile.write(a, 44100, x)
+            wavio.write_pcm16(b, 44100, x)
+            assert open(a, "rb").read() == open(b, "rb").read(), (ch, n)
+            rate, y = wavio.read_pcm16(a)
+            sr, want = scipy.io.wavfile.read(a)
+            assert rate == sr and y.dtype == want.dtype and y.shape == want.shape and np.array_equal(y, want)
+            buf = np.zeros(os.path.getsize(a), np.uint8)
+            assert wavio.read_pcm16_into(a, buf) == (44100, n, ch)
+            assert np.array_equal(buf[:2 * n * ch].view(np.int16), x.reshape(-1))
+            if n:
+                assert wavio.read_pcm16_into(a, buf[:2 * n * ch - 1]) is None          # does not fit: the caller falls back
+    # a LIST chunk in front of the data and an odd-sized chunk with its pad byte (scipy reads these too)
+    x = rs.randint(-32768, 32768, (100, 2)).astype(np.int16)
+    fmt = struct.pack("<HHIIHH", 1, 2, 44100, 44100 * 4, 4, 16)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"LIST" + struct.pack("<I", 5) + b"abcde\x00" + \
+        b"data" + struct.pack("<I", x.nbytes) + x.tobytes()
+    with open(a, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    sr, want = scipy.io.wavfile.read(a)
+    rate, y = wavio.read_pcm16(a)
+    assert rate == sr == 44100 and np.array_equal(y, want) and np.array_equal(y, x)
+    # not 16-bit PCM: float32 samples, 8-bit samples, no RIFF header at all
+    scipy.io.wavfile.write(a, 44100, rs.rand(100).astype(np.float32))
+    assert wavio.read_pcm16(a) is None and wavio.read_pcm16_into(a, np.zeros(4096, np.uint8)) is None
+    scipy.io.wavfile.write(a, 22050, rs.randint(0, 255, 100).astype(np.uint8))
+    assert wavio.read_pcm16(a) is None
+    with open(a, "wb") as fh:
+        fh.write(b"RIFF\x00\x00\x00\x00WAVEjunk")
+    assert wavio.read_pcm16(a) is None
