@@ -296,24 +296,27 @@ __device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, c
 // per-wave staging of the forward kernel's outputs: 256 magnitudes (1 KB) + 128 phasors (1 KB), see the wide store path
 constexpr int kStftStageF2 = 256;
 
-// one frame of one wave: row -> (clip, frame), samples x window -> packed FFT -> even / odd split -> magnitudes and unit phasors
 template <int LOG2M>
-__device__ __forceinline__ void stft_forward_wave_row(const int64_t row, const int lane_in, const WaveTw<LOG2M>& wt, const float2* twl_in,
-                                                      float2* buf, float2* stage, const float* __restrict__ audio, int64_t L,
-                                                      const float* __restrict__ win, float* __restrict__ mag,
-                                                      float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
-                                                      int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
-                                                      float sqrt_n, int interleave, const int64_t* __restrict__ clip_tab) {
-    constexpr int M = 1 << LOG2M, P = M / 64;
+__global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
+                                         const float2* __restrict__ tw, float* __restrict__ mag,
+                                         float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
+                                         int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
+                                         float sqrt_n, int interleave, const int64_t* __restrict__ clip_tab) {
+    constexpr int M = 1 << LOG2M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
-    // the window values depend on the lane only: inside the caller's loop over rows the compiler would hoist the P window loads
-    // (and keep 2 P registers live across the whole frame); an opaque copy of the pointer keeps them where they are used
-    // ... and an opaque copy of the lane index does the same for every other lane-only quantity (split twiddles, addresses)
-    const float2* twl = twl_in;
-    int lane = lane_in;
-    asm volatile("" : "+s"(win));
-    asm volatile("" : "+v"(lane));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row pointers stay in SGPRs
+    FW_STAMP(0);
+    // [waves][kStageF2] output staging (16-byte aligned: first in the segment), then the table, then the waves' exchange buffers
+    float2* stage = reinterpret_cast<float2*>(smem) + wave * kStftStageF2;
+    float2* lds0 = reinterpret_cast<float2*>(smem) + (blockDim.x >> 6) * kStftStageF2;
+    const float2* twl = lds0;
+    float2* buf = lds0 + (M + 1) + wave * MP;
+    for (int k = tid; k <= M; k += blockDim.x) lds0[k] = tw[k];
+    __syncthreads();
     // output row -> (clip, frame): clips of equal length are stacked with a pitch of rows_pc rows
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (row >= rows_pc * n_clips) return;
     const int64_t clip = row / rows_pc;
     const int64_t t = row - clip * rows_pc;
@@ -340,6 +343,8 @@ __device__ __forceinline__ void stft_forward_wave_row(const int64_t row, const i
         return;
     }
     FW_STAMP(1);   // table filled, barrier passed
+    WaveTw<LOG2M> wt;
+    wt.init(twl, lane);
     cx v[P];
     const int64_t base = t * (int64_t)hop - M;
     // 32-bit window-relative bounds instead of two 64-bit compares per sample
@@ -485,40 +490,6 @@ __device__ __forceinline__ void stft_forward_wave_row(const int64_t row, const i
     FW_STAMP(9);    // split + magnitude / phasor done, every store issued
     FW_DRAIN();
     FW_STAMP(10);   // stores acknowledged
-}
-
-template <int LOG2M>
-__global__ __launch_bounds__(256, LOG2M <= 10 ? 3 : 1) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
-                                         const float2* __restrict__ tw, float* __restrict__ mag,
-                                         float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
-                                         int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
-                                         float sqrt_n, int interleave, const int64_t* __restrict__ clip_tab,
-                                         int rows_per_wave) {
-    constexpr int M = 1 << LOG2M, P = M / 64, MP = M + M / 32;
-    constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row pointers stay in SGPRs
-    FW_STAMP(0);
-    // [waves][kStageF2] output staging (16-byte aligned: first in the segment), then the table, then the waves' exchange buffers
-    float2* stage = reinterpret_cast<float2*>(smem) + wave * kStftStageF2;
-    float2* lds0 = reinterpret_cast<float2*>(smem) + (blockDim.x >> 6) * kStftStageF2;
-    const float2* twl = lds0;
-    float2* buf = lds0 + (M + 1) + wave * MP;
-    for (int k = tid; k <= M; k += blockDim.x) lds0[k] = tw[k];
-    __syncthreads();
-    // rows_per_wave > 1 (launches of between one and two rounds of resident waves -- 640 tiles: 3 800 frames for 3 072 wave
-    // slots): a wave transforms row, row + n_waves, ... one after the other, so that the whole launch is ONE round of waves that
-    // pay for the table fill, the barrier and the pass twiddles once; no prefetch across frames (the persistent form with the
-    // next frame's samples in flight needed 168 registers and lost: scripts/README.md)
-    WaveTw<LOG2M> wt;
-    wt.init(twl, lane);
-    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t row0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-#pragma unroll 1
-    for (int f = 0; f < rows_per_wave; ++f)
-        stft_forward_wave_row<LOG2M>(row0 + f * n_waves, lane, wt, twl, buf, stage, audio, L, win, mag, phase, unit, ld, hop, T, rows_pc,
-                                     n_clips, audio_stride, sqrt_n, interleave, clip_tab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1157,22 +1128,14 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride,
     // workgroup at 640 tiles: 33.1 / 27.5 / 22.4 us against 22.0 with 4)
     const int64_t rows_all = rows_out * n_clips;
     const int fpw = rows_all >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
-    // waves resident at once: 3 per SIMD by registers (130 at N = 2048), 3 four-wave workgroups per CU by LDS
-    static const int rpw_env = getenv("DCS_STFT_ROWS_PER_WAVE") ? atoi(getenv("DCS_STFT_ROWS_PER_WAVE")) : 0;   // 0: by size
-    int rows_per_wave = 1;
-    if (fpw == 4) {
-        const int64_t slots = (int64_t)p->ctx->n_cu * 12;
-        if (rows_all > slots && rows_all <= 2 * slots) rows_per_wave = 2;     // between one and two rounds: one round of two rows
-    }
-    if (rpw_env > 0) rows_per_wave = rpw_env;
     const size_t lds = ((size_t)(M + 1) + (size_t)fpw * (MP + kStftStageF2)) * sizeof(float2);
     auto kern = stft_forward_wave_kernel<LOG2M>;
     if (lds > 48 * 1024)
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(dcs_cdiv(rows_all, rows_per_wave), fpw)), dim3(64 * fpw), lds, p->ctx->stream, audio, L,
+    hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(rows_all, fpw)), dim3(64 * fpw), lds, p->ctx->stream, audio, L,
                        p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T, rows_out, n_clips, audio_stride,
-                       (float)sqrt((double)p->frame), interleave ? 1 : 0, clip_tab, rows_per_wave);
+                       (float)sqrt((double)p->frame), interleave ? 1 : 0, clip_tab);
     return DCS_OK;
 }
 
