@@ -90,6 +90,12 @@ def load():
     proto("dcs_pcm_to_int16", i32, vp, vp, i64, vp)
     proto("dcs_pcm16_to_float", i32, vp, vp, i64, i32, i32, i64, i64, vp, i64)
     proto("dcs_gather", i32, vp, vp, vp, i64, vp, i32)
+    proto("dcs_wav_pool_create", i32, i32, POINTER(vp))
+    proto("dcs_wav_pool_destroy", None, vp)
+    proto("dcs_wav_read_pcm16_async", i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, POINTER(vp))
+    proto("dcs_wav_write_pcm16_async", i32, vp, i32, vp, vp, vp, vp, vp, vp, POINTER(vp))
+    proto("dcs_wav_batch_done", i32, vp)
+    proto("dcs_wav_batch_wait", i32, vp)
     proto("dcs_score_masks", i32, vp, vp, i64, i64, i32, vp, i32, i32, i32, i64, i64, vp, vp)
     proto("dcs_score_masks_norm", i32, vp, vp, i64, i64, i32, vp, i32, i32, i32, i64, i64, i32, vp, vp)
     proto("dcs_separate_stereo", i32, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, i64, POINTER(i64), POINTER(i64))

@@ -163,6 +163,25 @@ def length_groups(sizes, max_group=16, max_ratio=1.5):
     return groups
 
 
+class Pcm16Pending(object):
+    """What ``Separator.separate_many_pcm16(..., wait=False)`` returns: the enqueued work of one call."""
+
+    def __init__(self, event, out, views, keep):
+        self._event, self._out, self._views, self._keep = event, out, views, keep
+
+    def done(self):
+        return self._event is None or self._event.query()
+
+    def result(self):
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+            for i, v in self._views:
+                self._out[i] = v.numpy()
+            self._views, self._keep = [], None
+        return self._out
+
+
 class Separator(object):
     """Model + STFT plan resident on one GPU; ``separate(audio)`` is the body of ``train_auto``
     between reading and writing the wav files (separate_dsd.py:289-306)."""
@@ -277,7 +296,7 @@ class Separator(object):
         return out
 
     @_on_ctx_stream
-    def separate_many_pcm16(self, clips, max_group=16, max_ratio=None, on_error='raise', ring=3):
+    def separate_many_pcm16(self, clips, max_group=16, max_ratio=None, on_error='raise', ring=3, wait=True):
         """The batch-of-files path without host arithmetic: ``clips`` are the int16 frames of 16-bit PCM wav files exactly as
         ``scipy.io.wavfile.read`` returns them (``[L]`` mono or ``[L, channels]``; NumPy arrays or pinned torch CPU tensors, e.g.
         from :func:`deepconvsep_amd.wavio.read_pcm16`), the result a list of int16 arrays ``[S, L_i]`` -- the samples the
@@ -287,7 +306,12 @@ class Separator(object):
         ``separate_many(to_mono(read_wav(f)))`` + ``write_wav`` bit for bit, for a quarter of the PCIe bytes.  Grouping as in
         :meth:`separate_many`.  The returned arrays are views of a ring
         of ``ring`` pinned host buffers: they stay valid until ``ring - 1`` further calls have been made (copy them to keep
-        them longer); ``ring=0`` returns fresh arrays."""
+        them longer); ``ring=0`` returns fresh arrays.
+
+        ``wait=False`` returns as soon as the copies and kernels are enqueued: the result is a :class:`Pcm16Pending` whose
+        ``result()`` waits for the device and hands out the list.  The caller's input buffers must stay untouched until then
+        (they are the source of an asynchronous host-to-device copy); a driver that reads group i + 1 and writes group i - 1
+        while the device separates group i needs nothing else (``examples/separate_batch.py``)."""
         import torch
         from .runtime import _torch as _device_torch
         dtorch = _device_torch()            # device allocations (the memory-safety harness routes them through guarded arenas)
@@ -328,7 +352,7 @@ class Separator(object):
         groups = [[idx_ok[k] for k in g]
                   for g in length_groups([frames[i] for i in idx_ok], max_group if self.arch.C == 1 else 1, max_ratio)]
         if not groups:
-            return out
+            return out if wait else Pcm16Pending(None, out, [], None)
         # one pinned output block per call, cut out of a small ring: the writer threads of the caller stream the int16
         # samples to the files straight from it
         total = sum(S * frames[i] for g in groups for i in g)
@@ -338,7 +362,7 @@ class Separator(object):
             slot = self._pcm16_next % len(self._pcm16_ring)
             self._pcm16_next += 1
             if self._pcm16_ring[slot] is None or self._pcm16_ring[slot].numel() < total:
-                self._pcm16_ring[slot] = torch.empty((max(total, 1 << 20) * 5 // 4,), dtype=torch.int16).pin_memory()
+                self._pcm16_ring[slot] = torch.empty((max(total, 1 << 20) * 9 // 8,), dtype=torch.int16, pin_memory=True)
             host = self._pcm16_ring[slot]
         else:
             host = torch.empty((total,), dtype=torch.int16)
@@ -396,6 +420,10 @@ class Separator(object):
                     dst.copy_(p16[b, :, :lens[b]], non_blocking=True)
                     views.append((i, dst))
                     pos += n
+        if not wait:
+            done = torch.cuda.Event()
+            done.record(self.ctx.torch_stream)
+            return Pcm16Pending(done, out, views, (tens, host))
         self.ctx.torch_stream.synchronize()
         for i, v in views:
             out[i] = v.numpy()

@@ -179,7 +179,7 @@ class transformFFT(Transforms):
                 else:
                     # the caller keeps the array: pinned memory of its own (torch's caching host allocator hands the block
                     # of an earlier call back; a pageable destination measured 19 against 6.8 ms for 106 MB)
-                    host = torch.empty(t64.shape, dtype=torch.float64).pin_memory()
+                    host = torch.empty(t64.shape, dtype=torch.float64, pin_memory=True)
                 host.copy_(t64, non_blocking=True)
                 outs.append(host)
             ctx.torch_stream.synchronize()
@@ -193,7 +193,7 @@ class transformFFT(Transforms):
             self._pin = {}
         buf = self._pin.get(role)
         if buf is None or buf.numel() < numel:
-            buf = self._pin[role] = torch.empty((int(numel * 5 // 4) + 1,), dtype=torch.float64).pin_memory()
+            buf = self._pin[role] = torch.empty((int(numel * 5 // 4) + 1,), dtype=torch.float64, pin_memory=True)
         return buf[:numel]
 
     def compute_file(self, audio, phase=False, sampleRate=44100):

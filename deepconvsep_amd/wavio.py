@@ -7,6 +7,10 @@ reads the block as it lies in the file (one ``np.fromfile``), hands it to the de
 happen there, ``dcs_pcm16_to_float``) and writes the int16 block the device returns (``dcs_pcm_to_int16``) behind the 44-byte
 header ``scipy.io.wavfile.write`` produces -- the files are byte-identical to the reference's, the host does no arithmetic.
 Anything else (float or 24-bit samples, exotic chunk layouts) returns ``None`` and the caller falls back to scipy.
+
+:class:`WavPool` is the same pair of operations for a batch of files at a time on the I/O threads of ``libdcs.so``
+(``dcs_wav_read_pcm16_async`` / ``dcs_wav_write_pcm16_async``, ``csrc/wavio.hip``): one call per batch that returns at once,
+no interpreter lock on the workers' side.
 """
 import struct
 
@@ -113,3 +117,125 @@ def write_pcm16(path, rate, samples):
             os.write(fd, head)
     finally:
         os.close(fd)
+
+
+class WavBatch(object):
+    """An enqueued batch of :class:`WavPool`; ``result()`` waits for it."""
+
+    def __init__(self, lib, handle, keep, finish):
+        self._lib, self._h, self._keep, self._finish, self._res = lib, handle, keep, finish, None
+
+    def done(self):
+        return self._h is None or bool(self._lib.dcs_wav_batch_done(self._h))
+
+    def result(self):
+        if self._h is not None:
+            from . import _lib
+            h, self._h = self._h, None
+            _lib.check(self._lib.dcs_wav_batch_wait(h))
+            self._res = self._finish()
+            self._keep = self._finish = None
+        return self._res
+
+
+class WavPool(object):
+    """I/O threads of ``libdcs.so`` for 16-bit PCM wav files (``dcs_wav_pool_create``).
+
+    ``read_into(paths, buffers)``: the frames of file i go into ``buffers[i]`` (a writable, C-contiguous byte buffer such as a
+    slice of a pinned staging area); the batch's ``result()`` is a list with, per file, ``(rate, n_frames, channels)``, ``None``
+    (not plain 16-bit PCM or larger than the buffer -- :func:`read_pcm16_into`'s contract: the caller falls back to scipy) or an
+    ``OSError``.  ``write(paths, rates, arrays)``: file i = ``scipy.io.wavfile.write(paths[i], rates[i], arrays[i])`` for int16
+    arrays ``[n]`` / ``[n, channels]`` (C-contiguous; they are NOT copied and must stay untouched until ``result()``, which is a
+    list of ``None`` or ``OSError``); missing parent directories are created."""
+
+    def __init__(self, n_threads=16):
+        import ctypes
+        from . import _lib
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.dcs_wav_pool_create(int(n_threads), ctypes.byref(h)))
+        self._h = h
+        self.n_threads = int(n_threads)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._lib.dcs_wav_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @staticmethod
+    def _paths(paths):
+        import ctypes
+        import os
+        enc = [os.fsencode(p) for p in paths]
+        return enc, (ctypes.c_char_p * len(enc))(*enc)
+
+    def read_into(self, paths, buffers):
+        import ctypes
+        from . import _lib
+        n = len(paths)
+        if len(buffers) != n:
+            raise ValueError("one buffer per path")
+        enc, cpaths = self._paths(paths)
+        arrs = [np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b.reshape(-1).view(np.uint8) for b in buffers]
+        for a in arrs:
+            if not a.flags.writeable or not a.flags.c_contiguous:
+                raise ValueError("read_into needs writable contiguous buffers")
+        dst = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        cap = (ctypes.c_int64 * n)(*[a.nbytes for a in arrs])
+        rate, frames = (ctypes.c_int32 * n)(), (ctypes.c_int64 * n)()
+        chans, status = (ctypes.c_int32 * n)(), (ctypes.c_int32 * n)()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.dcs_wav_read_pcm16_async(self._h, n, cpaths, dst, cap, rate, frames, chans, status, ctypes.byref(h)))
+
+        def finish():
+            import os
+            out = []
+            for i in range(n):
+                if status[i] == 0:
+                    out.append((int(rate[i]), int(frames[i]), int(chans[i])))
+                elif status[i] > 0:
+                    out.append(None)
+                else:
+                    out.append(OSError(-status[i], os.strerror(-status[i]), paths[i]))
+            return out
+        return WavBatch(self._lib, h, (enc, cpaths, arrs, dst, cap, rate, frames, chans, status), finish)
+
+    def write(self, paths, rates, arrays):
+        import ctypes
+        from . import _lib
+        n = len(paths)
+        if len(arrays) != n or len(rates) != n:
+            raise ValueError("one rate and one array per path")
+        enc, cpaths = self._paths(paths)
+        arrs = []
+        for a in arrays:
+            a = np.asarray(a)
+            if a.dtype != np.int16 or a.ndim not in (1, 2) or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a, dtype="<i2")
+                if a.ndim not in (1, 2):
+                    raise ValueError("write takes int16 arrays [n] or [n, channels]")
+            arrs.append(a)
+        data = (ctypes.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+        nfr = (ctypes.c_int64 * n)(*[a.shape[0] for a in arrs])
+        chans = (ctypes.c_int32 * n)(*[1 if a.ndim == 1 else a.shape[1] for a in arrs])
+        crates = (ctypes.c_int32 * n)(*[int(r) for r in rates])
+        status = (ctypes.c_int32 * n)()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.dcs_wav_write_pcm16_async(self._h, n, cpaths, data, nfr, chans, crates, status, ctypes.byref(h)))
+
+        def finish():
+            import os
+            return [None if status[i] == 0 else OSError(-status[i], os.strerror(-status[i]), paths[i]) for i in range(n)]
+        return WavBatch(self._lib, h, (enc, cpaths, arrs, data, nfr, chans, crates, status), finish)

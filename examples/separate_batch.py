@@ -10,13 +10,15 @@ writes.  With several ranks (one process per GPU) the files are dealt round-robi
 collective on the data path.  ``--group G`` (default 16) takes G files at a time; they share sets of kernel launches
 (``Separator.separate_many_pcm16``: equal lengths ``dcs_separate_batch``, different lengths ``dcs_separate_ragged``).
 
-16-bit PCM files (the datasets' format) never become floats on the host: a worker thread reads a file's int16 frames
-straight into a pinned staging buffer (``wavio.read_pcm16_into``), the frames go to the GPU as they are, the division by
+16-bit PCM files (the datasets' format) never become floats on the host: the I/O threads of ``libdcs.so``
+(``wavio.WavPool``: one call per group of files, no interpreter lock on the workers' side) read a file's int16 frames
+straight into a pinned staging buffer, the frames go to the GPU as they are, the division by
 32767, the mix-down (separate_dsd.py:278-287) and the int16 conversion of the results (:307-309) run on the device in the
-scripts' float64 arithmetic, the int16 samples come back into pinned memory and worker threads write them behind the 44-byte
+scripts' float64 arithmetic, the int16 samples come back into pinned memory and the same threads write them behind the 44-byte
 header ``scipy.io.wavfile.write`` would produce -- the output files are byte-identical to those of the float path.  Any other
 sample format takes the float path (``read_wav`` / ``to_mono`` / ``separate_many`` / ``write_wav``) file by file.
-While the GPU separates group i the workers read group i+1 and write group i-1.
+While the GPU separates group i the workers read group i+1 and write group i-1, and the main thread does not wait for
+the device either: a group is enqueued (``separate_many_pcm16(..., wait=False)``) and collected one iteration later.
 """
 import argparse
 import os
@@ -59,96 +61,153 @@ def main(argv=None):
     n_workers = max(2, min(args.workers or 16, (os.cpu_count() or 2)))
     G = max(1, args.group)
     chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
-    # pinned input arenas, one per chunk in flight (the chunk being separated and the one being read)
-    arenas = [None, None]
+    # pinned input arenas, one per chunk in flight (being read | enqueued, its upload possibly not yet executed | collected)
+    arenas = [None, None, None]
 
     def arena_for(k, nbytes):
-        a = arenas[k % 2]
+        a = arenas[k % 3]
         if a is None or a.numel() < nbytes:
-            a = arenas[k % 2] = torch.empty((max(nbytes, 1 << 22) * 5 // 4,), dtype=torch.uint8).pin_memory()
+            a = arenas[k % 3] = torch.empty((max(nbytes, 1 << 22) * 9 // 8,), dtype=torch.uint8, pin_memory=True)
         return a
 
-    def read(path, arena, off, cap):
-        """16-bit PCM: (path, rate, pinned int16 tensor [L] / [L, ch]); otherwise the float path's mono signal."""
+    def read_float(path):
+        """The scripts' own read (scipy) + mix-down: (path, rate, mono float signal | None | the exception)."""
         try:
-            got = wavio.read_pcm16_into(path, arena.numpy()[off:off + cap]) if not args.float_path else None
-            if got is not None:
-                sr, frames, ch = got
-                t = arena[off:off + 2 * frames * ch].view(torch.int16)
-                return path, sr, (t if ch == 1 else t.view(frames, ch)), True
             sr, audio = sp.read_wav(path)
-            return path, sr, (sp.to_mono(audio, args.arch) if sr == 44100 else None), False
+            return path, sr, (sp.to_mono(audio, args.arch) if sr == 44100 else None)
         except Exception as exc:      # a file that cannot be read or mixed down fails alone (the notebook: one process per file)
-            return path, None, exc, False
+            return path, None, exc
 
-    def submit_reads(pool, k):
+    def submit_reads(io, tp, k):
+        """Chunk k's reads: a native batch into the chunk's pinned arena (16-bit PCM) or scipy reads on the Python pool."""
         if k >= len(chunks):
-            return []
-        sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in chunks[k]]
+            return None
+        files = chunks[k]
+        if args.float_path:
+            return ("float", [tp.submit(read_float, f) for f in files])
+        sizes = []
+        for f in files:
+            try:
+                sizes.append(os.path.getsize(f))
+            except OSError:
+                sizes.append(0)
         offs = [0]
         for sz in sizes:
             offs.append(offs[-1] + (sz + 63) // 64 * 64)
         arena = arena_for(k, offs[-1])
-        return [pool.submit(read, f, arena, offs[j], sizes[j]) for j, f in enumerate(chunks[k])]
+        flat = arena.numpy()
+        return ("pcm16", io.read_into(files, [flat[offs[j]:offs[j] + sizes[j]] for j in range(len(files))]), arena, offs)
+
+    def take_reads(pending_reads, ci):
+        """-> (fast, slow): [(path, rate, pinned int16 tensor [L] / [L, ch])], [(path, rate, mono float signal)]."""
+        fast, slow = [], []
+
+        def classify(path, sr, audio):
+            if isinstance(audio, Exception):
+                failed.append((path, audio))
+            elif sr != 44100 or audio is None:
+                print("Sample rate is not 44100")          # separate_dsd.py:313
+            else:
+                slow.append((path, sr, audio))
+        if pending_reads[0] == "float":
+            for f in pending_reads[1]:
+                classify(*f.result())
+            return fast, slow
+        _, batch, arena, offs = pending_reads
+        for j, (path, got) in enumerate(zip(chunks[ci], batch.result())):
+            if isinstance(got, Exception):
+                failed.append((path, got))
+            elif got is None:                                # not plain 16-bit PCM: the scripts' float path for this file
+                classify(*read_float(path))
+            elif got[0] != 44100:
+                print("Sample rate is not 44100")
+            else:
+                sr, frames, ch = got
+                t = arena[offs[j]:offs[j] + 2 * frames * ch].view(torch.int16)
+                fast.append((path, sr, t if ch == 1 else t.view(frames, ch)))
+        return fast, slow
 
     def out_dir(path):
-        out = os.path.join(args.odir, os.path.splitext(os.path.basename(path))[0])
-        os.makedirs(out, exist_ok=True)
-        return out
-
-    def write16(path, sr, pcm):
-        for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
-            wavio.write_pcm16(dst, sr, sig)
+        return os.path.join(args.odir, os.path.splitext(os.path.basename(path))[0])
 
     def write_float(path, sr, pcm):
+        os.makedirs(out_dir(path), exist_ok=True)
         for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
             sp.write_wav(dst, sig, sr)
 
-    t_stage = {"wait_reads": 0.0, "separate": 0.0, "wait_writes": 0.0, "submit": 0.0}
+    t_stage = {"wait_reads": 0.0, "enqueue": 0.0, "wait_device": 0.0, "wait_writes": 0.0, "submit": 0.0}
     t_first = None
-    with ThreadPoolExecutor(max_workers=n_workers) as pool:
-        nxt = submit_reads(pool, 0)
-        pending = []
+    now = time.perf_counter
+
+    def finish_writes(pending):
+        for kind, w, paths in pending:
+            if kind == "pcm16":
+                for path, err in zip(paths, w.result()):
+                    if err is not None:
+                        failed.append((path, err))
+            else:
+                try:
+                    w.result()
+                except Exception as exc:
+                    failed.append((paths, exc))
+
+    def collect(io, tp, inflight, pending):
+        """The device's results of an enqueued chunk -> write batches.  Waits for the writes of the chunk before it first:
+        their pinned block is the one the NEXT enqueue reuses (ring of three)."""
+        fast, h16, slow, resf = inflight
+        t0 = now()
+        res16 = h16.result() if h16 is not None else []
+        t1 = now()
+        finish_writes(pending)
+        t2 = now()
+        t_stage["wait_device"] += t1 - t0
+        t_stage["wait_writes"] += t2 - t1
+        out = []
+        paths, rates, arrays = [], [], []
+        for (path, sr, _), pcm in zip(fast, res16):
+            if isinstance(pcm, Exception):
+                failed.append((path, pcm))
+                continue
+            for dst, sig in zip(sp.output_paths(args.arch, path, out_dir(path)), pcm):
+                paths.append(dst)
+                rates.append(sr)
+                arrays.append(sig)
+        if paths:
+            out.append(("pcm16", io.write(paths, rates, arrays), paths))        # one call; the directories are made by the pool
+        for (path, sr, _), pcm in zip(slow, resf):
+            if isinstance(pcm, Exception):
+                failed.append((path, pcm))
+            else:
+                out.append(("float", tp.submit(write_float, path, sr, pcm), path))
+        t_stage["submit"] += now() - t2
+        return out
+
+    with wavio.WavPool(n_workers) as io, ThreadPoolExecutor(max_workers=min(n_workers, 8)) as tp:
+        nxt = submit_reads(io, tp, 0)
+        pending, inflight = [], None
         for ci in range(len(chunks)):
-            t0 = time.perf_counter()
-            got = [f.result() for f in nxt]
-            t_stage["wait_reads"] += time.perf_counter() - t0
-            nxt = submit_reads(pool, ci + 1)
-            fast, slow = [], []
-            for path, sr, audio, is16 in got:
-                if isinstance(audio, Exception):
-                    failed.append((path, audio))
-                elif sr != 44100 or audio is None:
-                    print("Sample rate is not 44100")          # separate_dsd.py:313
-                else:
-                    (fast if is16 else slow).append((path, sr, audio))
-            t0 = time.perf_counter()
-            res16 = sep.separate_many_pcm16([a for _, _, a in fast], max_group=max(16, G), on_error='return') if fast else []
+            t0 = now()
+            fast, slow = take_reads(nxt, ci)
+            t_stage["wait_reads"] += now() - t0
+            t0 = now()
+            h16 = (sep.separate_many_pcm16([a for _, _, a in fast], max_group=max(16, G), on_error='return', wait=False)
+                   if fast else None)
             resf = sep.separate_many([a for _, _, a in slow], on_error='return') if slow else []
-            t1 = time.perf_counter()
-            for f in pending:                                   # the writes of the previous chunk (their pinned block is two
-                f.result()                                      # calls old when it is reused: ring of three)
-            t2 = time.perf_counter()
-            t_stage["separate"] += t1 - t0
-            t_stage["wait_writes"] += t2 - t1
-            pending = []
-            for (path, sr, _), pcm in zip(fast, res16):
-                if isinstance(pcm, Exception):
-                    failed.append((path, pcm))
-                    continue
-                pending.append(pool.submit(write16, path, sr, pcm))
-            for (path, sr, _), pcm in zip(slow, resf):
-                if isinstance(pcm, Exception):
-                    failed.append((path, pcm))
-                else:
-                    pending.append(pool.submit(write_float, path, sr, pcm))
-            t_stage["submit"] += time.perf_counter() - t2
+            t_stage["enqueue"] += now() - t0
+            # the arena of chunk ci + 1 was last used by chunk ci - 2, collected in the previous iteration
+            t0 = now()
+            nxt = submit_reads(io, tp, ci + 1)
+            t_stage["submit"] += now() - t0
+            if inflight is not None:
+                pending = collect(io, tp, inflight, pending)
+            inflight = (fast, h16, slow, resf)
             if ci == 0:
-                t_first = time.perf_counter()          # the first group also pays for the pinned staging blocks and the workspace
-        t0 = time.perf_counter()
-        for f in pending:
-            f.result()
-        t_stage["wait_writes"] += time.perf_counter() - t0
+                t_first = now()          # the first group also pays for the pinned staging blocks and the workspace
+        if inflight is not None:
+            pending = collect(io, tp, inflight, pending)
+        t0 = now()
+        finish_writes(pending)
+        t_stage["wait_writes"] += now() - t0
     for path, exc in failed:
         print("%s: %s: %s" % (path, type(exc).__name__, exc), file=sys.stderr)
     if args.stats:

@@ -272,6 +272,34 @@ DCS_API int dcs_pcm_to_int16(dcs_ctx* ctx, const float* pcm_d, int64_t n, int16_
 DCS_API int dcs_pcm16_to_float(dcs_ctx* ctx, const int16_t* pcm16_d, int64_t n_frames, int channels, int mode, int64_t n_clips,
                        int64_t in_stride, float* out_d, int64_t out_stride);
 
+/* ---- wav files of the batch-of-files driver (host side, no device work) ----------------------------------------------
+ * What scipy.io.wavfile.read / .write do in every script (separate_dsd.py:275-282, :307-309) for 16-bit PCM files, by a pool of
+ * I/O threads and without the float detour: int16 frames go from the file into the caller's (pinned) staging memory and from
+ * it into a file behind the 44-byte header scipy.io.wavfile.write produces -- the division by 32767, the mix-down and the int16
+ * conversion are dcs_pcm16_to_float / dcs_pcm_to_int16 on the device.  A batch of reads or writes is one call that returns at
+ * once; the caller collects it with dcs_wav_batch_wait.  Thread-safe; the threads never call back into the caller. */
+typedef struct dcs_wav_pool dcs_wav_pool;
+typedef struct dcs_wav_batch dcs_wav_batch;
+DCS_API int dcs_wav_pool_create(int n_threads, dcs_wav_pool** out);
+/* Completes every enqueued batch first.  Batches that were not waited for stay valid for dcs_wav_batch_wait. */
+DCS_API void dcs_wav_pool_destroy(dcs_wav_pool* pool);
+/* Enqueue n reads.  File i: its frames go to dst_h[i] (capacity cap[i] bytes); after the wait status[i] is 0 (rate[i],
+ * n_frames[i], channels[i] are set, the frames lie at dst_h[i] as [n_frames][channels] int16), 1 (not plain 16-bit PCM, e.g.
+ * float / 24-bit samples, a damaged header, or larger than cap[i]: take the scripts' float path for this file) or -errno (the
+ * file could not be opened or read).  The paths are copied; every other array must stay valid until the wait. */
+DCS_API int dcs_wav_read_pcm16_async(dcs_wav_pool* pool, int n, const char* const* paths, void* const* dst_h, const int64_t* cap,
+                                     int32_t* rate, int64_t* n_frames, int32_t* channels, int32_t* status, dcs_wav_batch** out);
+/* Enqueue n writes.  File i = the 44 header bytes of scipy.io.wavfile.write(path, rate[i], int16 [n_frames[i]] or
+ * [n_frames[i], channels[i]]) followed by the frames at data_h[i], one writev; missing parent directories are created.
+ * status[i] after the wait: 0 or -errno.  DCS_EINVAL for a file that would not fit a wav header (>= 4 GiB). */
+DCS_API int dcs_wav_write_pcm16_async(dcs_wav_pool* pool, int n, const char* const* paths, const int16_t* const* data_h,
+                                      const int64_t* n_frames, const int32_t* channels, const int32_t* rate, int32_t* status,
+                                      dcs_wav_batch** out);
+/* 1 when every file of the batch has been handled (the batch stays valid), 0 otherwise. */
+DCS_API int dcs_wav_batch_done(dcs_wav_batch* batch);
+/* Blocks until the batch is complete and releases it. */
+DCS_API int dcs_wav_batch_wait(dcs_wav_batch* batch);
+
 /* The one exchange of the multi-GPU path (tiles / clips are sharded over one process per GPU and nothing else is shared;
  * SURVEY 8b `dcs_gather(h, ncclComm_t, shard, count, full, root)`, counted in BYTES here so that the scripts' int16 PCM of
  * dcs_pcm_to_int16 travels as it is).  nccl_comm is the caller's ncclComm_t (RCCL: ncclCommInitRank, one rank per GPU);

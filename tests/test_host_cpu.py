@@ -254,3 +254,72 @@ def test_wavio_reads_and_writes_what_scipy_does(tmp_path):
     with open(a, "wb") as fh:
         fh.write(b"RIFF\x00\x00\x00\x00WAVEjunk")
     assert wavio.read_pcm16(a) is None
+
+
+def test_wav_pool_of_libdcs_reads_and_writes_what_scipy_does(tmp_path):
+    """wavio.WavPool = the I/O threads of libdcs.so (dcs_wav_read_pcm16_async / dcs_wav_write_pcm16_async, csrc/wavio.hip; host
+    code, no device): a batch of writes produces the bytes `scipy.io.wavfile.write` produces (parent directories made on the way),
+    a batch of reads delivers the frames `scipy.io.wavfile.read` returns into the caller's buffers -- same verdict per file as
+    the Python reader `read_pcm16_into` (frames | None for anything that is not plain 16-bit PCM or does not fit | OSError)."""
+    import struct
+    import scipy.io.wavfile
+    from deepconvsep_amd import wavio
+    rs = np.random.RandomState(1)
+    ref = str(tmp_path / "ref.wav")
+    cases = [(n, ch) for ch in (1, 2, 3) for n in (0, 1, 5, 4411, 70001)]
+    arrays = [rs.randint(-32768, 32768, (n, ch) if ch > 1 else (n,)).astype(np.int16) for n, ch in cases]
+    rates = [44100 if i % 2 == 0 else 22050 for i in range(len(cases))]
+    paths = [str(tmp_path / "deep" / ("d%d" % (i % 3)) / ("f%02d.wav" % i)) for i in range(len(cases))]
+    with wavio.WavPool(5) as pool:
+        batch = pool.write(paths, rates, arrays)
+        assert batch.result() == [None] * len(cases) and batch.done() and batch.result() == [None] * len(cases)
+        for p, x, sr in zip(paths, arrays, rates):
+            scipy.io.wavfile.write(ref, sr, x)
+            assert open(ref, "rb").read() == open(p, "rb").read(), p
+        # odd chunk layouts, an extensible header, not-PCM files, a missing file, a buffer that is too small -- one batch
+        x = rs.randint(-32768, 32768, (100, 2)).astype(np.int16)
+        fmt = struct.pack("<HHIIHH", 1, 2, 44100, 44100 * 4, 4, 16)
+        odd = str(tmp_path / "odd.wav")
+        body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"LIST" + struct.pack("<I", 5) + b"abcde\x00" + \
+            b"data" + struct.pack("<I", x.nbytes) + x.tobytes()
+        with open(odd, "wb") as fh:
+            fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        ext = str(tmp_path / "ext.wav")
+        fmt_ext = struct.pack("<HHIIHH", 0xFFFE, 2, 44100, 44100 * 4, 4, 16) + struct.pack("<HHI", 22, 16, 3) + \
+            b"\x01\x00\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+        body = b"WAVE" + b"fmt " + struct.pack("<I", 40) + fmt_ext + b"data" + struct.pack("<I", x.nbytes) + x.tobytes()
+        with open(ext, "wb") as fh:
+            fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        trunc = str(tmp_path / "trunc.wav")              # the data chunk promises more than the file holds: whole frames of the rest
+        with open(trunc, "wb") as fh:
+            fh.write(open(odd, "rb").read()[:-7])
+        flt, u8, junk = str(tmp_path / "flt.wav"), str(tmp_path / "u8.wav"), str(tmp_path / "junk.wav")
+        scipy.io.wavfile.write(flt, 44100, rs.rand(100).astype(np.float32))
+        scipy.io.wavfile.write(u8, 22050, rs.randint(0, 255, 100).astype(np.uint8))
+        with open(junk, "wb") as fh:
+            fh.write(b"RIFF\x00\x00\x00\x00WAVEjunk")
+        files = paths + [odd, ext, trunc, flt, u8, junk, str(tmp_path / "missing.wav"), paths[4]]
+        bufs = [np.zeros(os.path.getsize(f) if os.path.exists(f) else 16, np.uint8) for f in files]
+        bufs[-1] = np.zeros(2 * 70001 - 1, np.uint8)                                   # one byte short
+        got = pool.read_into(files, bufs).result()
+        for i, (f, b) in enumerate(zip(files, bufs)):
+            if i == len(files) - 2:
+                assert isinstance(got[i], OSError) and got[i].errno == 2
+                continue
+            assert got[i] == wavio.read_pcm16_into(f, np.zeros_like(b)), f             # the Python reader's verdict
+            if got[i] is not None:
+                sr, want = scipy.io.wavfile.read(f) if f != trunc else (44100, x[:98])
+                rate, n, ch = got[i]
+                assert rate == sr and n == want.shape[0] and np.array_equal(b[:2 * n * ch].view(np.int16), want.reshape(-1)), f
+        assert got[len(paths)] == (44100, 100, 2) and got[len(paths) + 1] == (44100, 100, 2) and got[len(paths) + 2] == (44100, 98, 2)
+        assert got[len(paths) + 3] is None and got[len(paths) + 4] is None and got[len(paths) + 5] is None and got[-1] is None
+        # a directory that cannot be made: the file fails alone
+        blocker = str(tmp_path / "blocker")
+        open(blocker, "w").close()
+        res = pool.write([os.path.join(blocker, "x.wav"), str(tmp_path / "fine.wav")], [44100, 44100], [arrays[1], arrays[1]]).result()
+        assert isinstance(res[0], OSError) and res[1] is None
+        # many small batches in flight at once
+        batches = [pool.write([str(tmp_path / ("m%d_%d.wav" % (k, j))) for j in range(7)], [8000] * 7, [arrays[2]] * 7) for k in range(20)]
+        assert all(b.result() == [None] * 7 for b in batches)
+    with pytest.raises(ValueError):
+        wavio.WavPool(0)
