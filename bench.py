@@ -983,9 +983,10 @@ def run_cli(torch, dcs, synth_audio, synth_params):
                                "workers": steady.get("workers"), "path": steady.get("path"), "group": steady.get("group"),
                                "ms_per_file_after_first_group": steady.get("ms_per_file_after_first_group"),
                                "main_thread_ms_per_file": steady.get("main_thread_ms_per_file"),
-                               "note": "separate_batch.py --stats over 550 wav files (int16 frames read into pinned staging, H2D, "
-                                       "device mix-down, kernels, device int16 conversion, D2H, 4 wavs written per file by a "
-                                       "pool of I/O threads), clock started when the model is resident"}
+                               "note": "separate_batch.py --stats over 550 wav files (int16 frames read into pinned staging by "
+                                       "the I/O threads of libdcs.so, H2D, device mix-down, kernels, device int16 conversion, "
+                                       "D2H, 4 wavs written per file by the same threads; the main thread enqueues a group and "
+                                       "collects it one iteration later), clock started when the model is resident"}
         # the float path of the single-file scripts through the same driver (round 4's figure: 2.0 - 2.3 ms per file)
         r2 = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "separate_batch.py"), "-a", "dsd", "-m", model, "-o",
                              out550, "--stats", "--float-path"] + wavs * 4, capture_output=True, text=True, timeout=1800) \
