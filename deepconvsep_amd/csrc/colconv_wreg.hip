@@ -517,34 +517,37 @@ bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images
     return false;
 }
 
-// W1p: [nf1][C = 1][32 taps] (tap axis zero-padded) -> [3 planes][2 tap halves][64 lanes][8] bf16: lane (fi, kg) of tap
-// half mh holds, for row (mm = fi / 4 + 4 mh, r = fi % 4), the k slots j <-> ci = 4 kg + j (j < 4) | 16 + 4 kg + j - 4
-// ... followed by the same fragments rounded to f16 ([2 tap halves][64 lanes][8]: section 3, the S2H kernel's operand)
-void dcs_decoder_fused_pack(const float* W1p, int nf1, std::vector<uint16_t>* out) {
-    out->assign((size_t)4 * 2 * 64 * 8, 0);
-    for (int mh = 0; mh < 2; ++mh)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-                const int fi = lane & 15, kg = lane >> 4;
-                const int ci = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
-                const int tap = 4 * ((fi >> 2) + 4 * mh) + (fi & 3);
-                float r = ci < nf1 ? W1p[(size_t)ci * 32 + tap] : 0.f;
-                {
-                    const _Float16 hv = (_Float16)r;
-                    uint16_t hb;
-                    memcpy(&hb, &hv, 2);
-                    (*out)[(((size_t)3 * 2 + mh) * 64 + lane) * 8 + j] = hb;
+// W1p: [nf1][C][32 taps] (tap axis zero-padded) -> per output channel c of conv1^T (= input channel of the graph)
+// [3 planes][2 tap halves][64 lanes][8] bf16: lane (fi, kg) of tap half mh holds, for row (mm = fi / 4 + 4 mh, r = fi % 4), the k
+// slots j <-> ci = 4 kg + j (j < 4) | 16 + 4 kg + j - 4 ... followed by the same fragments rounded to f16 ([2 tap halves][64
+// lanes][8]: section 3, the S2H kernel's operand).  Channel c's four sections start at c * 4 * 2 * 64 * 8.
+void dcs_decoder_fused_pack(const float* W1p, int nf1, int C, std::vector<uint16_t>* out) {
+    out->assign((size_t)C * 4 * 2 * 64 * 8, 0);
+    for (int c = 0; c < C; ++c)
+        for (int mh = 0; mh < 2; ++mh)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int fi = lane & 15, kg = lane >> 4;
+                    const int ci = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
+                    const int tap = 4 * ((fi >> 2) + 4 * mh) + (fi & 3);
+                    float r = ci < nf1 ? W1p[((size_t)ci * C + c) * 32 + tap] : 0.f;
+                    uint16_t* o = out->data() + (size_t)c * 4 * 2 * 64 * 8;
+                    {
+                        const _Float16 hv = (_Float16)r;
+                        uint16_t hb;
+                        memcpy(&hb, &hv, 2);
+                        o[(((size_t)3 * 2 + mh) * 64 + lane) * 8 + j] = hb;
+                    }
+                    for (int p = 0; p < 3; ++p) {
+                        uint32_t bits;
+                        memcpy(&bits, &r, 4);
+                        bits &= 0xffff0000u;
+                        float part;
+                        memcpy(&part, &bits, 4);
+                        r -= part;
+                        o[(((size_t)p * 2 + mh) * 64 + lane) * 8 + j] = (uint16_t)(bits >> 16);
+                    }
                 }
-                for (int p = 0; p < 3; ++p) {
-                    uint32_t bits;
-                    memcpy(&bits, &r, 4);
-                    bits &= 0xffff0000u;
-                    float part;
-                    memcpy(&part, &bits, 4);
-                    r -= part;
-                    (*out)[(((size_t)p * 2 + mh) * 64 + lane) * 8 + j] = (uint16_t)(bits >> 16);
-                }
-            }
 }
 
 bool dcs_decoder_fused_ok(const DcsColConv& a, int F) {

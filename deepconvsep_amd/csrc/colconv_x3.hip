@@ -137,8 +137,9 @@ __device__ __forceinline__ void x3_for_slots(F&& f, std::integer_sequence<int, I
 
 struct DcsDecoderX3 {
     const u32x4* Wq;        // [2 parities][KH / 2 taps][3 planes][2 halves][64 lanes] pieces: conv2^T weights (A fragments)
-    const u32x4* Wq1;       // [3 planes][2 tap halves][64 lanes] pieces of the padded conv1 filter (dcs_decoder_fused_pack)
-    float* out;             // [image][HO][F]
+    const u32x4* Wq1;       // [output channel][4 sections][2 tap halves][64 lanes] pieces of the padded conv1 filter
+                            // (dcs_decoder_fused_pack; sections 0 .. 2 are the bf16 planes)
+    float* out;             // [image][CO][HO][F]
     int F;
     int runs_per_image;
     int64_t n_runs;
@@ -148,14 +149,24 @@ struct DcsDecoderX3 {
 // operand split, stage 2, shift-add, carry, store) between the MFMA groups of the NEXT row pair's stage 1 -- two accumulator
 // sets, sched_group_barrier interleaving -- made stage 1 exactly as much longer as the tail got shorter (issue is in order:
 // every dependent instruction of the tail stalls the MFMA stream behind it): 1.20 against 1.14 ms.
-template <int KH, int H>
+//
+// CO = the channels conv1^T produces (the INPUT channels of the graph): 1 for Bach10, 4 for the score-informed graph
+// (bach10_scoreinformed/separate_bach10.py:388-447: one decoder branch, four output channels).  With CO > 1 stage 1 is
+// unchanged (G[ci][x] of a row does not depend on the output channel) and the rest of a row's tail -- stage 2, shift-add,
+// carry, store -- runs once per output channel on that channel's conv1 taps.  Those taps (six 16-byte fragments per lane and
+// channel) do not fit the register file next to the conv2^T taps (436 registers) nor LDS next to a second workgroup
+// (60 + 12 KB here, 25 KB of taps): they are read from global memory (24.6 KB, L2-resident, the same for every wave), each
+// channel's set requested two channels ahead into the register set that channel's products have just released (two sets; the
+// first two channels' sets by the last two channels of the row pair before), so that the loads land behind work that does
+// not need them.
+template <int KH, int H, int CO>
 __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const DcsColConv g, const DcsDecoderX3 d) {
     constexpr int HO = H + KH - 1, PH = KH - 1, NK = KH / 2;
     static_assert(KH % 2 == 0 && HO % 2 == 0, "taps and output rows are dealt to the two waves by parity");
     constexpr int kRowU = 3 * 4 * 16;                    // 16-byte units per input row: [plane][K piece kq][x]
     constexpr int kPlanes = (H + 2) * kRowU;             // rows -1 .. H (index h + 1); rows -1 and H are zero
     constexpr int kPb = 8 * 32;                          // per wave: [tap mm 8][32 slots] float4, slot 8 + x holds P[x][mm]
-    constexpr int kCb = (HO / 2) * 8;                    // per wave: the carry of its 15 rows, 8 float4 each
+    constexpr int kCb = (HO / 2) * CO * 8;               // per wave: the carry of its 15 rows x CO channels, 8 float4 each
     constexpr int kTasks = H * 64;                       // (row, x, K piece) fetch / split tasks per block
     constexpr int NT = (kTasks + 127) / 128;             // per thread of a pair
     __shared__ u32x4 planes[kPlanes];
@@ -182,12 +193,16 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) w[k][p][hf] = d.Wq[((((par * NK + k) * 3 + p) * 2) + hf) * 64 + lane];
-    u32x4 w1[3][2];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        w1[p][0] = d.Wq1[(p * 2) * 64 + lane];
-        w1[p][1] = d.Wq1[(p * 2 + 1) * 64 + lane];
+    // conv1^T taps: CO == 1 keeps its one set for the whole launch; CO > 1 holds the set in use and the one in flight
+    u32x4 w1s[CO > 1 ? 2 : 1][3][2];
+    const u32x4* w1g = d.Wq1 + lane;                     // channel c, plane p, half mh: w1g[((c * 4 + p) * 2 + mh) * 64]
+#define DCS_X3_W1_REQUEST(dst_, c_)                                                                   \
+    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                                \
+        dst_[p_][0] = w1g[(((c_) * 4 + p_) * 2) * 64];                                                \
+        dst_[p_][1] = w1g[(((c_) * 4 + p_) * 2 + 1) * 64];                                            \
     }
+    DCS_X3_W1_REQUEST(w1s[0], 0)
+    if constexpr (CO > 1) DCS_X3_W1_REQUEST(w1s[1], 1)
     const int W = g.W, n_xb = g.n_xb, F = d.F, Cin = g.Cin;
     const int rpi = d.runs_per_image;
     // fetch / split task i = tid + 128 j (tid within the pair): row h = i / 64, x = (i % 64) / 4, K piece kqt = i % 4 (four consecutive threads
@@ -282,36 +297,43 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
             X3_ADD(15, tf2, tb)
             const bool keep = b >= b_lo;                     // false for the recomputed block
             const int f0 = 4 * (b * 16 + rq);
-            float* orow = d.out + (img * HO + par) * (int64_t)F + f0;
+            float* orow = d.out + (img * CO * HO + par) * (int64_t)F + f0;      // channel c: + c * HO * F
             // state of the row pair being finished
             f32x4 acc[2][2];                                 // [row of the pair][channel half]
             f32x4 tm[2], tsum = zero4;
+            f32x4 pq[CO > 1 ? 2 : 1][2][2];                  // stage-2 products of the channel being finished / the next one
             u32x4 tg[3];
             const f32x4* t_xr = Xs;
             constexpr int kPieces = 6;
-            auto tail = [&](auto pc, auto ypc) {
-                constexpr int P = decltype(pc)::value, yp = decltype(ypc)::value;
+            auto tail = [&](auto pc, auto ypc, auto cc) {
+                constexpr int P = decltype(pc)::value, yp = decltype(ypc)::value, c = decltype(cc)::value;
                 if constexpr (kAblTail) {
-                    if constexpr (P == 0) tsum += acc[0][0] + acc[1][1];      // keeps stage 1 alive
-                    if constexpr (P == 5 && yp == HO - 2)
+                    if constexpr (P == 0 && c == 0) tsum += acc[0][0] + acc[1][1];      // keeps stage 1 alive
+                    if constexpr (P == 5 && yp == HO - 2 && c == 0)
                         if (keep && lane < 16 && f0 + 4 <= F) *reinterpret_cast<f32x4u*>(orow) = tsum;
                 } else if constexpr (P == 0) {          // this wave finishes row yp + par: its own partial + the partner's
+                    if constexpr (c == 0) {
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) tm[hf] = par ? acc[1][hf] : acc[0][hf];
-                    tm[0] += t_xr[0];
-                    tm[1] += t_xr[64];
-                } else if constexpr (P == 1) {   // G[ci][x] of the row as three bf16 planes (a B operand of stage 2)
-                    float gv[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        gv[e] = tm[0][e];
-                        gv[4 + e] = tm[1][e];
+                        for (int hf = 0; hf < 2; ++hf) tm[hf] = par ? acc[1][hf] : acc[0][hf];
+                        tm[0] += t_xr[0];
+                        tm[1] += t_xr[64];
                     }
-                    split8(gv, tg[0], tg[1], tg[2]);
+                } else if constexpr (P == 1) {   // G[ci][x] of the row as three bf16 planes (a B operand of stage 2)
+                    if constexpr (c == 0) {
+                        float gv[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gv[e] = tm[0][e];
+                            gv[4 + e] = tm[1][e];
+                        }
+                        split8(gv, tg[0], tg[1], tg[2]);
+                    }
                 } else if constexpr (P == 2) {
+                    auto& w1 = w1s[c & 1];
                     // the two tap halves as FOUR chains of three products (smallest terms first in each): with one wave per
                     // SIMD a chain of six dependent MFMAs per half was ~430 cycles of pure latency per row pair
-                    f32x4 pa[2], pb[2];
+                    f32x4 (&pa)[2] = pq[c & 1][0];
+                    f32x4 (&pb)[2] = pq[c & 1][1];
 #pragma unroll
                     for (int mh = 0; mh < 2; ++mh) {
                         pa[mh] = mma_bf(w1[2][mh], tg[0], zero4);
@@ -327,27 +349,32 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
                         pa[mh] = mma_bf(w1[0][mh], tg[1], pa[mh]);
                         pb[mh] = mma_bf(w1[0][mh], tg[0], pb[mh]);
                     }
-                    pw[0] = pa[0] + pb[0];
-                    pw[128] = pa[1] + pb[1];
+                    if constexpr (CO > 1) {              // this set is free: the taps of channel c + 2 (of the next row pair
+                        __builtin_amdgcn_sched_barrier(0);      // for the last two channels) land behind the work in between
+                        DCS_X3_W1_REQUEST(w1s[c & 1], (c + 2) % CO)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 } else if constexpr (P == 3) {
+                    pw[0] = pq[c & 1][0][0] + pq[c & 1][1][0];
+                    pw[128] = pq[c & 1][0][1] + pq[c & 1][1][1];
                 } else if constexpr (P == 4) {
                     asm volatile("" ::: "memory");           // the pieces of the row are written (LDS is in order per wave)
                     // all nine reads in flight before the first addition (left alone the compiler waits for each in turn)
                     f32x4 rd[8];
 #pragma unroll
                     for (int mm = 0; mm < 8; ++mm) rd[mm] = pr[mm * 32 - mm];
-                    const f32x4 cin = Cb[(yp >> 1) * 8 + (rq & 7)];
+                    const f32x4 cin = Cb[((yp >> 1) * CO + c) * 8 + (rq & 7)];
                     __builtin_amdgcn_sched_barrier(0);
                     tsum = ((rd[0] + rd[1]) + (rd[2] + rd[3])) + ((rd[4] + rd[5]) + (rd[6] + rd[7])) + (rq < 8 ? cin : zero4);
                 } else {
                     asm volatile("" ::: "memory");           // every lane has read the carry before it is replaced
-                    if (lane >= 16 && lane < 24) Cb[(yp >> 1) * 8 + lane - 16] = lane < 23 ? tsum : zero4;
+                    if (lane >= 16 && lane < 24) Cb[((yp >> 1) * CO + c) * 8 + lane - 16] = lane < 23 ? tsum : zero4;
 #if defined(DCS_X3_ABL_NOSTORE)
                     if (keep && lane < 16 && tsum[0] == 12345.f) {
 #else
                     if (keep && lane < 16) {
 #endif
-                        float* op = orow + (int64_t)yp * F;
+                        float* op = orow + ((int64_t)c * HO + yp) * F;
                         if (f0 + 4 <= F) {
                             *reinterpret_cast<f32x4u*>(op) = tsum;
                         } else {
@@ -356,7 +383,7 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
                                 if (f0 + e < F) op[e] = tsum[e];
                         }
                     }
-                    asm volatile("" ::: "memory");
+                    asm volatile("" ::: "memory");       // (and the pieces of this channel are read before the next one's are written)
                 }
             };
             // the 15 row pairs and their (row, tap) slots are unrolled through integer sequences: every weight register index
@@ -423,12 +450,30 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
                 t_xr = Xs + (xbuf * 2 + (1 - par)) * 128 + lane;
                 xbuf ^= 1;
                 X3_NOW(tc)
-                x3_for_slots([&](auto pc) {
-                        X3_NOW(tp0)
-                        tail(pc, yc);
-                        X3_NOW(tp1)
-                        X3_ADD(6 + decltype(pc)::value, tp0, tp1)
-                    }, std::make_integer_sequence<int, kPieces>{});
+                // pieces of a row's tail: 0 partner's partial, 1 operand split (once per row); 2 stage-2 products, 3 their LDS
+                // write, 4 shift-add, 5 carry + store (once per output channel).  The products of channel c + 1 are issued
+                // BEFORE channel c is shifted, added and stored: their latency (three dependent MFMAs) passes behind that work.
+                auto piece = [&](auto pc, auto cc) {
+                    X3_NOW(tp0)
+                    tail(pc, yc, cc);
+                    X3_NOW(tp1)
+                    X3_ADD(6 + decltype(pc)::value, tp0, tp1)
+                };
+                using I0 = std::integral_constant<int, 0>;
+                piece(std::integral_constant<int, 0>{}, I0{});
+                piece(std::integral_constant<int, 1>{}, I0{});
+                piece(std::integral_constant<int, 2>{}, I0{});
+                x3_for_slots([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+#if defined(DCS_X3_SEQ_TAILS)   // experiment build: channel c + 1's products only after channel c is stored
+                    if constexpr (c > 0) piece(std::integral_constant<int, 2>{}, cc);
+#else
+                    if constexpr (c + 1 < CO) piece(std::integral_constant<int, 2>{}, std::integral_constant<int, c + 1>{});
+#endif
+                    piece(std::integral_constant<int, 3>{}, cc);
+                    piece(std::integral_constant<int, 4>{}, cc);
+                    piece(std::integral_constant<int, 5>{}, cc);
+                }, std::make_integer_sequence<int, CO>{});
                 X3_NOW(td)
                 X3_ADD(0, ta, tb)
                 X3_ADD(1, tb, tc)
@@ -439,11 +484,12 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
         // the carry: the tail of the image (and the zeros up to F) for the last run, otherwise the next run recomputes it
         if (have && b_hi == n_xb) {
 #pragma unroll
-            for (int i = 0; i < (HO / 2 + 7) / 8; ++i) {
-                const int t = (lane >> 3) + 8 * i, f = 4 * (16 * n_xb + (lane & 7));
-                if (t < HO / 2) {
-                    const f32x4 v = Cb[t * 8 + (lane & 7)];
-                    float* op = d.out + (img * HO + 2 * t + par) * (int64_t)F + f;
+            for (int i = 0; i < (HO / 2 * CO + 7) / 8; ++i) {
+                const int tc_ = (lane >> 3) + 8 * i, f = 4 * (16 * n_xb + (lane & 7));      // (row of this wave, channel)
+                if (tc_ < HO / 2 * CO) {
+                    const int t = tc_ / CO, c = tc_ - t * CO;
+                    const f32x4 v = Cb[tc_ * 8 + (lane & 7)];
+                    float* op = d.out + ((img * CO + c) * HO + 2 * t + par) * (int64_t)F + f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (f + e < F) op[e] = v[e];
@@ -459,6 +505,7 @@ __global__ __launch_bounds__(kTh) void colconv_deconv1_fused_x3_kernel(const Dcs
         for (int i = 0; i < 16; ++i) x3_trace_buf[par * 16 + i] = tr[i];
 #endif
 #undef DCS_X3_FETCH
+#undef DCS_X3_W1_REQUEST
 }
 
 }  // namespace
@@ -494,15 +541,17 @@ void dcs_decoder_x3_pack(const float* Wf, int kh, std::vector<uint16_t>* out) {
                     }
 }
 
-bool dcs_decoder_x3_ok(const DcsColConv& a, int F) {
+// n_out: the channels conv1^T produces (the graph's input channels)
+bool dcs_decoder_x3_ok(const DcsColConv& a, int F, int n_out) {
     static const bool on = !(getenv("DCS_DECODER_X3") && atoi(getenv("DCS_DECODER_X3")) == 0);
     // 28 .. 32 channels: the first half of K piece 3 (channels 24 .. 27) is read as it is
-    return on && dcs_decoder_fused_ok(a, F) && (a.Cin & 1) == 0 && a.Cin >= 28;
+    return on && (n_out == 1 || n_out == 4) && dcs_decoder_fused_ok(a, F) && (a.Cin & 1) == 0 && a.Cin >= 28;
 }
 
 // the input MUST be channels-last ([image][H][W][Cin], 8-byte aligned): false = not launched
-bool dcs_launch_decoder_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out, int F) {
-    if (!Wq || !Wq1 || !dcs_decoder_x3_ok(a, F)) return false;
+bool dcs_launch_decoder_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out, int F,
+                           int n_out) {
+    if (!Wq || !Wq1 || !dcs_decoder_x3_ok(a, F, n_out)) return false;
     if ((a.in_n_stride & 1) || (reinterpret_cast<uintptr_t>(a.in) & 7)) return false;
     if (n_images <= 0) return true;
     // runs per image: fewest (rounds of wave pairs) x (blocks per run + the recomputed one); two pairs per CU
@@ -522,6 +571,9 @@ bool dcs_launch_decoder_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, 
     d.runs_per_image = best;
     d.n_runs = n_images * best;
     const unsigned grid = (unsigned)std::min<int64_t>(d.n_runs, n_pairs);
-    hipLaunchKernelGGL((colconv_deconv1_fused_x3_kernel<20, 11>), dim3(grid), dim3(kTh), 0, ctx->stream, a, d);
+    if (n_out == 4)
+        hipLaunchKernelGGL((colconv_deconv1_fused_x3_kernel<20, 11, 4>), dim3(grid), dim3(kTh), 0, ctx->stream, a, d);
+    else
+        hipLaunchKernelGGL((colconv_deconv1_fused_x3_kernel<20, 11, 1>), dim3(grid), dim3(kTh), 0, ctx->stream, a, d);
     return true;
 }

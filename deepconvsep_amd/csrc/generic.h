@@ -58,7 +58,7 @@ bool dcs_launch_deconv1_mfma(dcs_ctx* ctx, const float* g, const void* Wq, float
 void dcs_colconv_wreg_pack(const _Float16* Wh, int kh, std::vector<_Float16>* out);
 bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq);
 // InverseLayer(conv2) + InverseLayer(conv1) in one kernel (Bach10 graph, f16 switch on): out [image][Ho][F]
-void dcs_decoder_fused_pack(const float* W1p, int nf1, std::vector<uint16_t>* out);
+void dcs_decoder_fused_pack(const float* W1p, int nf1, int C, std::vector<uint16_t>* out);
 bool dcs_decoder_fused_ok(const DcsColConv& a, int F);
 // in_channels_last: a.in is [image][H][W][Cin] (the dense layer wrote a position's channels together) instead of [image][Cin][H][W]
 bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out,
@@ -67,8 +67,9 @@ bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_image
 // the same fusion with f32-class arithmetic (colconv_x3.hip): two waves per column block, ten taps each as bf16 planes in
 // registers; the input MUST be channels-last.  false = shape not covered / not launched
 void dcs_decoder_x3_pack(const float* Wf /* [kh][32 out][40], in-channel fastest */, int kh, std::vector<uint16_t>* out);
-bool dcs_decoder_x3_ok(const DcsColConv& a, int F);
-bool dcs_launch_decoder_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out, int F);
+bool dcs_decoder_x3_ok(const DcsColConv& a, int F, int n_out = 1);
+bool dcs_launch_decoder_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out, int F,
+                           int n_out = 1);
 
 int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int F,
                        const std::vector<std::vector<float>>& params, DcsGenericNet** out);

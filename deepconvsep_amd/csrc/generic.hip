@@ -1492,9 +1492,11 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         dcs_slabconv_ps_pack(Wcol_t.data(), kh, 1, slot, 0, &Wpc_t_q3);
         UP(g->Wpc_q3, Wpc_q3) UP(g->Wpc_t_q3, Wpc_t_q3)
         UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) UP(g->Wcol_r, Wcol_r) UP(g->Wcol_t_r, Wcol_t_r)
-        if (C == 1 && d.sw1 == 4 && kw1 > 28 && kw1 <= 32 && !d.pool_w && !W1p.empty()) {
+        // both InverseLayers in one kernel: single-channel graphs (Bach10), and the f32-class kernel also with the four
+        // output channels of the score-informed graph
+        if ((C == 1 || C == 4) && d.sw1 == 4 && kw1 > 28 && kw1 <= 32 && !d.pool_w && !W1p.empty()) {
             std::vector<uint16_t> W1q;
-            dcs_decoder_fused_pack(W1p.data(), nf1, &W1q);
+            dcs_decoder_fused_pack(W1p.data(), nf1, C, &W1q);
             UP(g->W1q, W1q)
             if (kh % 2 == 0) {                           // the f32-class fused decoder deals the taps to two waves by parity
                 std::vector<uint16_t> Wx3;
@@ -1648,7 +1650,7 @@ bool plans_channels_last(const DcsGenericNet* g, bool* fuse_planned_out, bool* f
     if (g->use_colconv && g->W1q && (g->conv_f16 ? g->Wcol_t_r != nullptr : g->Wx3 != nullptr)) {
         ColConvArgs c0{};
         c0.Cin = d.nf2; c0.H = d.h2; c0.W = d.w2; c0.Cout = d.nf1; c0.Ho = g->tc; c0.ph = d.kh2 - 1; c0.kh = d.kh2;
-        fuse_planned = g->conv_f16 ? dcs_decoder_fused_ok(c0, g->F) : dcs_decoder_x3_ok(c0, g->F);
+        fuse_planned = g->conv_f16 ? (g->C == 1 && dcs_decoder_fused_ok(c0, g->F)) : dcs_decoder_x3_ok(c0, g->F, g->C);
         fuse_x3 = fuse_planned && !g->conv_f16;
     }
     static const bool cl_env = !(getenv("DCS_DECODER_CL") && atoi(getenv("DCS_DECODER_CL")) == 0);
@@ -1813,7 +1815,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // per-branch GEMMs runs them on the f32 weights (channel-first), and the decoder is told which layout it got
     const bool planes_cl = g->bdq_cl;
     bool branches_done = false;
-    if (NB > 1) {                                        // every live branch in one launch when the shape allows it
+    if (NB > 1 || want_cl) {                             // every live branch in one launch when the shape allows it
         DcsGemm q{};
         q.A = Z; q.lda = g->hid64; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
         q.ldb = g->flat64; q.ldc = (int64_t)NB * g->flat_p; q.c_gdiv = 1 << 30; q.c_gmul = 0;
@@ -1853,7 +1855,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol_t; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = d.kh2 - 1; c.kh = d.kh2; c.n_xb = (c.W + 15) / 16;
-            decoder_fused = g->conv_f16 ? (g->W1q && g->Wcol_t_r && dcs_decoder_fused_ok(c, F))
+            decoder_fused = g->conv_f16 ? (C == 1 && g->W1q && g->Wcol_t_r && dcs_decoder_fused_ok(c, F))
                                         : (fuse_x3 && d_cl);       // f32-class: only on the channels-last layout
         }
         if (d_cl && !decoder_fused) {
@@ -1873,7 +1875,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         if (decoder_fused) {                                 // both InverseLayers in one kernel: o directly
             DcsTimer tmf(ctx, DCS_TAG_DECODER);
             const bool ok = g->conv_f16 ? dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F, d_cl)
-                                        : dcs_launch_decoder_x3(ctx, c, n * NB, g->Wx3, g->W1q, o, F);
+                                        : dcs_launch_decoder_x3(ctx, c, n * NB, g->Wx3, g->W1q, o, F, C);
             tmf.done();
             if (!ok) DCS_FAIL(DCS_EHIP, "generic graph: the fused decoder refused a launch it had accepted (channels-last %d)", (int)d_cl);
         }
@@ -2006,13 +2008,13 @@ int dcs_generic_forward(DcsGenericNet* g, const float* tiles, int64_t n, int mas
     static const int64_t chunk_env = getenv("DCS_GENERIC_CHUNK") ? atoll(getenv("DCS_GENERIC_CHUNK")) : 0;
     int64_t chunk = chunk_env > 0 ? chunk_env : (int64_t)(((size_t)4 << 30) / (chunk_bytes(g, 64) / 64 + 1));
     if (chunk < 64 && chunk_env <= 0) chunk = 64;
-    // Graphs whose decoder is the fused kernel on channels-last input (Bach10): that layout only comes out of the all-rows dense
+    // Graphs whose decoder is the fused kernel on channels-last input (Bach10, f32-class score-informed): that layout only comes out of the all-rows dense
     // kernel, which takes 128 .. 176 tiles per launch.  A longer pass would drop to the f32 GEMM for its 256 x 166 650 dense
     // layers AND to the two-kernel decoder -- a 20 s clip several times slower per tile than a 10 s one.  Cut such passes into
     // equal pieces inside the window instead (the dense weights are re-read once per piece: 0.85 GB, ~0.2 ms; the deferred-mask
     // form below is single-chunk, so such a pass takes the separate mask and cross-fade kernels).
     constexpr bool cap_env = true;
-    if (cap_env && chunk_env <= 0 && n > 176 && g->d.n_branch > 1 && g->flat64 >= 8192 && plans_channels_last(g, nullptr, nullptr)) {
+    if (cap_env && chunk_env <= 0 && n > 176 && g->flat64 >= 8192 && plans_channels_last(g, nullptr, nullptr)) {
         const int64_t pieces = (n + 175) / 176, per = (n + pieces - 1) / pieces;
         const int64_t capped = per >= 128 ? per : 176;
         if (capped < chunk) chunk = capped;

@@ -1144,6 +1144,60 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
     assert np.array_equal(res["cl"]["p"], res["nox3"]["p"])
 
 
+_SI_X3_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from deepconvsep_amd.runtime import Network, default_context
+from deepconvsep_amd.synth import synth_params
+z = np.load(sys.argv[2])
+ctx = default_context()
+F = int(z['F'])
+net = Network(ctx, 'bach10_si1', synth_params('bach10_si1', 30, F, seed=4), 30, F)
+out = {}
+for n in (140, 128, 300, 64):                       # one launch | one launch | pieces of 150 | below the window: two kernels
+    out['n%d' % n] = net.forward_raw(ctx.to_device(z['x'][:n], np.float32)).cpu().numpy()
+ctx.timing(['decoder', 'deconv2', 'final'])
+net.forward_raw(ctx.to_device(z['x'][:140], np.float32)); ctx.synchronize()
+out['decoder_ms'] = np.float64(ctx.timing_query('decoder')[0])
+out['deconv2_ms'] = np.float64(ctx.timing_query('deconv2')[0])
+np.savez(sys.argv[3], **out)
+"""
+
+
+def test_scoreinformed_decoder_runs_on_the_fused_three_way_split_kernel(tmp_path):
+    """The score-informed graph's two InverseLayers (one decoder branch, FOUR output channels) through the fused f32-class
+    decoder (colconv_x3.hip, CO = 4: stage 1 once per row, stage 2 / shift-add / carry / store once per output channel with
+    that channel's conv1 taps requested one channel ahead): against the float64 oracle 1e-4, against the two kernels it
+    replaces (DCS_DECODER_X3=0) 2e-6 relative, for a launch inside the all-rows dense kernel's window (128, 140 tiles), a pass
+    cut into pieces (300) and one below the window (64: the two-kernel path either way, identical bits); the timer tags tell
+    which path ran."""
+    import subprocess
+    F = 257
+    x = _tiles("bach10_si1", 300, 30, F, seed=23)
+    want = net_ref.forward("bach10_si1", synth_params("bach10_si1", 30, F, seed=4), x.astype(np.float64), inverse='explicit').numpy()
+    f = tmp_path / "case.npz"
+    np.savez(f, x=x, F=F)
+    res = {}
+    for name, env in (("x3", {}), ("two", {"DCS_DECODER_X3": "0"})):
+        child_env = dict(os.environ)
+        child_env.update(env)
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _SI_X3_CHILD, ROOT, str(f), out], env=child_env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-1500:])
+        res[name] = np.load(out)
+    scale = max(1.0, float(np.max(np.abs(want))))
+    for n in (140, 128, 300, 64):
+        k = "n%d" % n
+        assert res["x3"][k].shape == want[:n].shape
+        assert np.max(np.abs(res["x3"][k] - want[:n])) < 1e-4, n
+        assert np.max(np.abs(res["two"][k] - want[:n])) < 1e-4, n
+        assert np.max(np.abs(res["x3"][k] - res["two"][k])) < 2e-6 * scale, n
+    assert np.array_equal(res["x3"]["n64"], res["two"]["n64"])
+    assert float(res["x3"]["decoder_ms"]) > 0 and float(res["x3"]["deconv2_ms"]) == 0      # fused
+    assert float(res["two"]["decoder_ms"]) == 0 and float(res["two"]["deconv2_ms"]) > 0    # two kernels
+
+
 @pytest.mark.parametrize("env", [
     {"DCS_FINAL_CBW": "2"}, {"DCS_FINAL_CBW": "1"},               # 128-bin workgroups (bf16x3 kernel, G split by a pass) / 64-bin (f32)
     {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2"},                   # bf16x3 kernel fed by the streaming deconv2 (writes the planes)
