@@ -478,22 +478,23 @@ from deepconvsep_amd.runtime import Network, default_context
 from deepconvsep_amd.synth import synth_params
 z = np.load(sys.argv[2])
 ctx = default_context()
-F = int(z['F'])
-net = Network(ctx, 'ikala', synth_params('ikala', 30, F, seed=9), 30, F)
-xd = ctx.to_device(z['x'], np.float32)
 worst = 0.0
-for mode, key in ((TIE_ALL, 'want_all'), (TIE_FIRST, 'want_first')):
-    p = net.forward_raw(xd, tie_mode=mode).cpu().numpy()
-    worst = max(worst, float(np.max(np.abs(p - z[key]))))
-print('max err %.3e' % worst)
+for F in (513, 1025, 271):                 # every size in one process: the switches are read once either way
+    net = Network(ctx, 'ikala', synth_params('ikala', 30, F, seed=9), 30, F)
+    xd = ctx.to_device(z['x%d' % F], np.float32)
+    for mode, key in ((TIE_ALL, 'want_all%d' % F), (TIE_FIRST, 'want_first%d' % F)):
+        p = net.forward_raw(xd, tie_mode=mode).cpu().numpy()
+        err = float(np.max(np.abs(p - z[key])))
+        print('F %d %s max err %.3e' % (F, key, err))
+        worst = max(worst, err)
 sys.exit(0 if worst < 1e-4 else 3)
 """
+_IKALA_POOL_CASE = {}
 
 
-@pytest.mark.parametrize("F", [513, 1025, 271])
 @pytest.mark.parametrize("env", [{}, {"DCS_POOL_FUSED": "0"}, {"DCS_POOL_FUSED": "0", "DCS_CONV1_REG": "0"},
                                  {"DCS_DECONV1_REG": "0"}])
-def test_ikala_pool_fused_and_separate_kernels_agree_with_the_oracle(env, F, tmp_path):
+def test_ikala_pool_fused_and_separate_kernels_agree_with_the_oracle(env, tmp_path):
     """The iKala graph's max-pool runs inside conv1 and its VJP inside conv1^T by default (routing bits instead of the
     full-resolution activations); DCS_POOL_FUSED=0 (or either register kernel switched off) takes the four separate
     kernels.  Both against the oracle for both tie routings, on tiles with digital-silence rows and a silent band (every
@@ -503,19 +504,24 @@ def test_ikala_pool_fused_and_separate_kernels_agree_with_the_oracle(env, F, tmp
     # differently in float64 -- seed 30 is the draw (of seeds 30..79, three tiles) with the widest smallest margin at all three
     # sizes: 2.6e-6 of the largest activation, ~10x the rounding error of a 30-tap float32 dot product
     n = 3
-    x = _tiles("ikala", n, 30, F, seed=30)
-    x[0, 0, 10:14] = 0.0
-    x[2, 0, :, 40:90] = 0.0
-    params = synth_params("ikala", 30, F, seed=9)
-    want_all = net_ref.forward("ikala", params, x.astype(np.float64), tie_mode='all', inverse='explicit').numpy()
-    want_first = net_ref.forward("ikala", params, x.astype(np.float64), tie_mode='first', inverse='explicit').numpy()
+    if not _IKALA_POOL_CASE:                             # inputs and oracle outputs, once per session
+        for F in (513, 1025, 271):
+            x = _tiles("ikala", n, 30, F, seed=30)
+            x[0, 0, 10:14] = 0.0
+            x[2, 0, :, 40:90] = 0.0
+            params = synth_params("ikala", 30, F, seed=9)
+            _IKALA_POOL_CASE["x%d" % F] = x
+            _IKALA_POOL_CASE["want_all%d" % F] = net_ref.forward("ikala", params, x.astype(np.float64), tie_mode='all',
+                                                                 inverse='explicit').numpy()
+            _IKALA_POOL_CASE["want_first%d" % F] = net_ref.forward("ikala", params, x.astype(np.float64), tie_mode='first',
+                                                                   inverse='explicit').numpy()
     f = tmp_path / "case.npz"
-    np.savez(f, x=x, want_all=want_all, want_first=want_first, F=F)
+    np.savez(f, **_IKALA_POOL_CASE)
     child_env = dict(os.environ)
     child_env.update(env)
     r = subprocess.run([sys.executable, "-c", _IKALA_POOL_CHILD, ROOT, str(f)], env=child_env, capture_output=True, text=True,
                        timeout=200)
-    assert r.returncode == 0, (env, F, r.stdout[-400:], r.stderr[-800:])
+    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
 
 
 def test_generic_chunked_batch_equals_small_batches():
@@ -998,14 +1004,17 @@ sys.path.insert(0, sys.argv[1])
 import deepconvsep_amd as dcs
 from deepconvsep_amd.synth import synth_params
 z = np.load(sys.argv[2])
-N = int(z['N']); F = N // 2 + 1
-sep = dcs.Separator('dsd', synth_params('dsd', 30, F, seed=2), 0.3, 30, 25, 32, F, N, 512, np.hanning)
-sep.net.set_latency_stages(0)             # the throughput kernels these switches select among (a 3 s clip would take the one-batch family)
-for rep in range(3):                      # eager, graph capture, graph replay
-    got = sep.separate(z['audio'])
-err = float(np.max(np.abs(got - z['want'])))
-print('max err %.3e' % err)
-sys.exit(0 if err < 1e-4 else 3)
+worst = 0.0
+for N in (1024, 2048):                    # both frame sizes in one process: the switches are read once either way
+    F = N // 2 + 1
+    sep = dcs.Separator('dsd', synth_params('dsd', 30, F, seed=2), 0.3, 30, 25, 32, F, N, 512, np.hanning)
+    sep.net.set_latency_stages(0)         # the throughput kernels these switches select among (a 3 s clip would take the one-batch family)
+    for rep in range(3):                  # eager, graph capture, graph replay
+        got = sep.separate(z['audio'])
+    err = float(np.max(np.abs(got - z['want%d' % N])))
+    print('N %d max err %.3e' % (N, err))
+    worst = max(worst, err)
+sys.exit(0 if worst < 1e-4 else 3)
 """
 
 
@@ -1043,6 +1052,7 @@ def test_ikala_conv2_kernels_agree_with_the_oracle(env, F, n, tmp_path):
     assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
 
 
+_GENERIC_CASE = []
 _GENERIC_CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
@@ -1079,9 +1089,11 @@ def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
     kernels, the LDS column kernel instead of the weights-in-registers one, and the fused decoder on 8-tile chunks."""
     import subprocess
     F, n = 257, 52
-    x = _tiles("bach10", n, 30, F, seed=15)
-    want = net_ref.forward("bach10", synth_params("bach10", 30, F, seed=4), x.astype(np.float64),
-                           inverse='explicit').numpy()
+    if not _GENERIC_CASE:                                # once per session
+        x = _tiles("bach10", n, 30, F, seed=15)
+        _GENERIC_CASE.append((x, net_ref.forward("bach10", synth_params("bach10", 30, F, seed=4), x.astype(np.float64),
+                                                 inverse='explicit').numpy()))
+    x, want = _GENERIC_CASE[0]
     f = tmp_path / "case.npz"
     np.savez(f, x=x, want=want, F=F)
     child_env = dict(os.environ)
@@ -1205,26 +1217,35 @@ def test_scoreinformed_decoder_runs_on_the_fused_three_way_split_kernel(tmp_path
     {"DCS_STFT_WAVE_MIN": "1"}, {"DCS_FFT_BLOCK": "1"},           # wave-per-frame / block-level FFT everywhere
     {"DCS_ISTFT_CHAIN": "0", "DCS_ISTFT_SEQ_HOPS": "1"}, {"DCS_ISTFT_CHAIN": "0", "DCS_ISTFT_SEQ_HOPS": "37"},   # blocks per wave of the barrier-free iSTFT
     {"DCS_GRAPH": "0"},
-    {"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE_MIN": "1", "DCS_ISTFT_STAGE": "2"},   # spectra through LDS (long clips' iSTFT) on a short clip
+    {"DCS_ISTFT_STAGE_MIN": "1"},                                  # spectra through LDS (long clips' iSTFT) on a short clip
     {"DCS_ISTFT_STAGE": "0"},
     {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "7"},   # chained iSTFT off / forced frames per wave
 ])
-@pytest.mark.parametrize("N", [1024, 2048])
-def test_kernel_variants_selected_by_size_agree_with_the_oracle(env, N, tmp_path):
+def test_kernel_variants_selected_by_size_agree_with_the_oracle(env, tmp_path):
     """The launchers pick kernel variants by problem size; the debugging switches force each variant on the
-    same 3 s clip (fresh process: the switches are read once) and every one must meet the parity bar."""
+    same 3 s clip at both frame sizes (fresh process: the switches are read once) and every one must meet the parity bar."""
     import subprocess
-    audio = synth_audio(3 * 44100, seed=77)
-    audio[40000:52000] = 0.0
-    want = pipeline.separate("dsd", synth_params("dsd", 30, N // 2 + 1, seed=2), audio, 0.3, 30, 25, 32, N, 512,
-                             np.hanning)
+    audio, want = _variant_case()
     f = tmp_path / "case.npz"
-    np.savez(f, audio=audio, want=want, N=N)
+    np.savez(f, audio=audio, want1024=want[1024], want2048=want[2048])
     child_env = dict(os.environ)
     child_env.update(env)
     r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, ROOT, str(f)], env=child_env, capture_output=True,
                        text=True, timeout=200)
     assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
+
+
+_VARIANT_CASE = []
+
+
+def _variant_case():
+    """The 3 s clip of the kernel-variant tests and its oracle output per frame size (computed once per session)."""
+    if not _VARIANT_CASE:
+        audio = synth_audio(3 * 44100, seed=77)
+        audio[40000:52000] = 0.0
+        _VARIANT_CASE.append((audio, {N: pipeline.separate("dsd", synth_params("dsd", 30, N // 2 + 1, seed=2), audio, 0.3, 30, 25,
+                                                          32, N, 512, np.hanning) for N in (1024, 2048)}))
+    return _VARIANT_CASE[0]
 
 
 _BF16X3_CHILD = r"""
@@ -1252,39 +1273,47 @@ sys.path.insert(0, sys.argv[1])
 import deepconvsep_amd as dcs
 from deepconvsep_amd.synth import synth_audio, synth_params
 z = np.load(sys.argv[2])
-N = int(z['N']); F = N // 2 + 1
-sep = dcs.Separator('dsd', synth_params('dsd', 30, F, seed=2), 0.3, 30, 25, 32, F, N, 512, np.hanning)
-sep.net.set_latency_stages(0)
-clips = [z['a0'], z['a1'], z['a2'], z['a0'][:len(z['a0']) - 4111]]
-many = sep.separate_many(clips)                      # sorted by length, one ragged group: per-clip frame counts in one launch
-alone = [sep.separate(c) for c in clips]
-same = sep.ctx.to_host(sep.net.separate_batch(sep.plan, sep.ctx.to_device(np.stack([z['a1'], z['a1'][::-1].copy()]), np.float32), 25, sep.tiler, 0.3))
-e_many = max(float(np.max(np.abs(m - a))) for m, a in zip(many, alone))
-e_same = float(np.max(np.abs(same[0] - alone[1])))
-e_ref = float(np.max(np.abs(alone[2] - z['want2'])))
-print('ragged vs alone %.2e, batch vs alone %.2e, vs oracle %.2e' % (e_many, e_same, e_ref))
-sys.exit(0 if (e_many < 5e-6 and e_same < 5e-6 and e_ref < 1e-4) else 3)
+ok = True
+for N in (1024, 2048):
+    F = N // 2 + 1
+    sep = dcs.Separator('dsd', synth_params('dsd', 30, F, seed=2), 0.3, 30, 25, 32, F, N, 512, np.hanning)
+    sep.net.set_latency_stages(0)
+    clips = [z['a0'], z['a1'], z['a2'], z['a0'][:len(z['a0']) - 4111]]
+    many = sep.separate_many(clips)                  # sorted by length, one ragged group: per-clip frame counts in one launch
+    alone = [sep.separate(c) for c in clips]
+    same = sep.ctx.to_host(sep.net.separate_batch(sep.plan, sep.ctx.to_device(np.stack([z['a1'], z['a1'][::-1].copy()]), np.float32), 25, sep.tiler, 0.3))
+    e_many = max(float(np.max(np.abs(m - a))) for m, a in zip(many, alone))
+    e_same = float(np.max(np.abs(same[0] - alone[1])))
+    e_ref = float(np.max(np.abs(alone[2] - z['want2_%d' % N])))
+    print('N %d: ragged vs alone %.2e, batch vs alone %.2e, vs oracle %.2e' % (N, e_many, e_same, e_ref))
+    ok = ok and e_many < 5e-6 and e_same < 5e-6 and e_ref < 1e-4
+sys.exit(0 if ok else 3)
 """
 
 
-@pytest.mark.parametrize("N", [1024, 2048])
+_STAGED_CASE = []
+
+
 @pytest.mark.parametrize("env", [{"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE": "0"},
                                  {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "5"},   # chained iSTFT: off, forced run lengths (seams at other places)
                                  ])
-def test_staged_istft_on_ragged_groups_and_batches(env, N, tmp_path):
+def test_staged_istft_on_ragged_groups_and_batches(env, tmp_path):
     """The LDS-staged inverse STFT (normally long clips only) forced onto short ones: a ragged group (per-clip frame counts
     from the device table: the four waves of a workgroup must still walk the same frames), an equal-length batch and single
     clips agree with each other, and a single clip with the oracle.  DCS_ISTFT_STAGE=0: the same with the plain loads."""
     import subprocess
-    a = [synth_audio(int(44100 * sec) + odd, seed=60 + i) for i, (sec, odd) in enumerate(((1.9, 0), (1.5, 0), (1.7, 313)))]
-    want2 = pipeline.separate("dsd", synth_params("dsd", 30, N // 2 + 1, seed=2), a[2], 0.3, 30, 25, 32, N, 512, np.hanning)
+    if not _STAGED_CASE:                                 # the clips and the oracle's output for one of them, once per session
+        a = [synth_audio(int(44100 * sec) + odd, seed=60 + i) for i, (sec, odd) in enumerate(((1.9, 0), (1.5, 0), (1.7, 313)))]
+        _STAGED_CASE.append((a, {N: pipeline.separate("dsd", synth_params("dsd", 30, N // 2 + 1, seed=2), a[2], 0.3, 30, 25, 32, N,
+                                                      512, np.hanning) for N in (1024, 2048)}))
+    a, want2 = _STAGED_CASE[0]
     f = tmp_path / "case.npz"
-    np.savez(f, a0=a[0], a1=a[1], a2=a[2], want2=want2, N=N)
+    np.savez(f, a0=a[0], a1=a[1], a2=a[2], want2_1024=want2[1024], want2_2048=want2[2048])
     child_env = dict(os.environ)
     child_env.update(env)
     r = subprocess.run([sys.executable, "-c", _STAGED_CHILD, ROOT, str(f)], env=child_env, capture_output=True, text=True,
                        timeout=300)
-    assert r.returncode == 0, (env, N, r.stdout[-400:], r.stderr[-800:])
+    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
 
 
 @pytest.mark.parametrize("kind", ["glorot", "sparse", "tiny"])
