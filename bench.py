@@ -75,7 +75,7 @@ LEG_KERNELS = {
     "bach10_f16": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_wreg_scatter_kernel", "decoder": "colconv_deconv1_fused_kernel",
                    "fc": "gemm_rows", "fc1x": "gemm_bf16x3_skinny_kernel"},
     "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
-                       "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel"},
+                       "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
     "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
                    "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
 }
@@ -83,7 +83,8 @@ LEG_KERNELS = {
 LEG_ISSUED = {
     "ikala": {"conv2": (6, 32.0 / 30.0), "deconv2": (6, 32.0 / 30.0)},   # 84 tiles: the dense layers stay on the f32 MFMA (M < 128)
     "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc1x": (6, 1.0)},
-    "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0)},
+    "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0),
+                       "decoder": (6, 32.0 / 30.0 * 120.0 / 110.0)},
     "bach10_f32": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0),
                    "decoder": (6, 32.0 / 30.0 * 120.0 / 110.0)},     # + the (row, tap) slots that meet a zero row (colconv_x3.hip)
 }
