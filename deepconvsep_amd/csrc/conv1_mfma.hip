@@ -6,10 +6,10 @@
 // conv1_reg_kernel (generic.hip) does this on the vector ALU: 900 multiply-adds per position and input channel, 0.33 ms for
 // the 4-channel score-informed batch (28 % of the vector peak).  As a GEMM the K axis of a channel is its 30 taps padded
 // to 32 = ONE MFMA K block, and with a stride of 4 a position's taps start 16 bytes after its neighbour's: a workgroup
-// copies the 1 056 input floats that 256 positions of one (tile, frame) row can touch into LDS per channel, a lane
-// (position fi, kg) reads its taps 8 kg .. 8 kg + 7 as two aligned ds_read_b128, splits them exactly into three bf16
-// terms (truncation; six products kept, as everywhere in this library) and issues 12 MFMAs per (16 positions, channel)
-// against weight fragments that stay in registers.  The accumulators (rows = positions) go through an LDS tile so that
+// splits the 1 056 input floats that 256 positions of one (tile, frame) row can touch exactly into three bf16 terms
+// (truncation; six products kept, as everywhere in this library) on their way into LDS, a lane (position fi, kg) reads its
+// taps 8 kg .. 8 kg + 7 of every plane as two ds_read_b64 and issues 12 MFMAs per (16 positions, channel) against weight
+// fragments that stay in registers.  The accumulators (rows = positions) go through an LDS tile so that
 // the stores are rows of up to 256 consecutive positions of one filter, not 64-byte pieces.
 #include <string.h>
 
@@ -20,6 +20,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // rows are F floats apart, F odd
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kThreads = 256;
 constexpr int kPos = 256;                    // positions per workgroup
@@ -50,12 +52,39 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// three bf16 planes of four consecutive floats (truncation, x = hi + mid + lo exactly), packed two per word in memory order
+__device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& mid, u32x2& lo) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = bf_trunc(x[j]);
+        const float r1 = x[j] - __uint_as_float(h[j]);
+        m[j] = bf_trunc(r1);
+        l[j] = bf_trunc(r1 - __uint_as_float(m[j]));
+    }
+    hi = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+    mid = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+    lo = u32x2{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+}
+
+// Round 5: the input floats are split ONCE, when they enter LDS (three bf16 planes, [plane][channel][float index]); a lane's A
+// fragment of a plane is then 16 consecutive bytes of that plane -- two ds_read_b64 (the start is 8-byte aligned: position
+// stride 4 floats = 8 bytes of bf16).  Before, every lane split the eight floats of its fragment itself: a float sits in the
+// fragments of eight (position, K piece) pairs, so the split ran eight times per float -- 1 024 of the ~1 900 vector
+// instructions of a wave, next to a per-float load loop with a division by 1 056; the kernel was bound by instruction issue at
+// 0.46 of the f32 peak (score-informed batch: 0.197 ms).  Same terms, same products, same order: bit-identical results.
 template <int C>
-__global__ __launch_bounds__(kThreads) void conv1_mfma_kernel(const float* __restrict__ x, const u32x4* __restrict__ Wq,
+__global__ __launch_bounds__(kThreads, C > 1 ? 3 : 4) void conv1_mfma_kernel(const float* __restrict__ x, const u32x4* __restrict__ Wq,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int NF, int tc, int F, int w1) {
-    __shared__ __attribute__((aligned(16))) float xin[C * kInW];
-    __shared__ __attribute__((aligned(16))) float obuf[32 * kOutS];
+    constexpr int kQ = kInW / 4;                                  // float4 chunks per channel
+    constexpr int kPl = C * kInW / 4;                             // u32x2 units (4 bf16) per plane
+    // the planes [plane][channel][chunk] and, once every wave is done with them, the output tile [32 filters][kOutS] in the
+    // same bytes (a third barrier instead of 33 KB more LDS: three workgroups per CU instead of two)
+    constexpr int kLdsBytes = 3 * kPl * 8 > 32 * kOutS * 4 ? 3 * kPl * 8 : 32 * kOutS * 4;
+    __shared__ __attribute__((aligned(16))) char lds_raw[kLdsBytes];
+    u32x2* xpl = reinterpret_cast<u32x2*>(lds_raw);
+    float* obuf = reinterpret_cast<float*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = tid >> 6;
     const int fi = lane & 15, kq = lane >> 4;
@@ -64,6 +93,29 @@ __global__ __launch_bounds__(kThreads) void conv1_mfma_kernel(const float* __res
     const int t = (int)(nt - n * tc);
     const int j_base = blockIdx.y * kPos;
     const int cnt = w1 - j_base < kPos ? w1 - j_base : kPos;      // positions of this workgroup
+    // input first (the longest wait): the floats [4 j_base, 4 j_base + kInW) of the C rows, zero past the row
+    const int f0 = 4 * j_base;
+    constexpr int kIt = (kQ + kThreads - 1) / kThreads;
+    f32x4 raw[C][kIt];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float* row = x + ((n * C + c) * tc + t) * (int64_t)F + f0;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int q = tid + it * kThreads, k = 4 * q;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < kQ) {
+                if (f0 + k + 3 < F) {
+                    v = *reinterpret_cast<const f32x4u*>(row + k);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (f0 + k + e < F) v[e] = row[k + e];
+                }
+            }
+            raw[c][it] = v;
+        }
+    }
     // weights: B fragments [c][plane][filter half], lane (filter fi (+16), kg) = taps 8 kg .. 8 kg + 7
     u32x4 w[C][3][2];
 #pragma unroll
@@ -74,21 +126,39 @@ __global__ __launch_bounds__(kThreads) void conv1_mfma_kernel(const float* __res
             w[c][p][1] = Wq[((c * 3 + p) * 2 + 1) * 64 + lane];
         }
     const float b0 = fi < NF ? bias[fi] : 0.f, b1 = 16 + fi < NF ? bias[16 + fi] : 0.f;
-    // input: the floats [4 j_base, 4 j_base + kInW) of the C rows, zero past the row
-    const int f0 = 4 * j_base;
-    for (int i = tid; i < C * kInW; i += kThreads) {
-        const int c = i / kInW, k = i - c * kInW;
-        xin[i] = f0 + k < F ? x[((n * C + c) * tc + t) * (int64_t)F + f0 + k] : 0.f;
-    }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int q = tid + it * kThreads;
+            if (q < kQ) {
+                u32x2 hi, mid, lo;
+                split4(raw[c][it], hi, mid, lo);
+                xpl[c * kQ + q] = hi;
+                xpl[kPl + c * kQ + q] = mid;
+                xpl[2 * kPl + c * kQ + q] = lo;
+            }
+        }
     __syncthreads();
     const int n_blk = (cnt + 15) >> 4;
-    for (int b = wave; b < n_blk; b += 4) {
+    constexpr int kBw = kPos / 16 / 4;                            // column blocks per wave
+    f32x4 acc[kBw][2];
+#pragma unroll
+    for (int bi = 0; bi < kBw; ++bi) {
+        const int b = wave + 4 * bi;
         f32x4 acc0 = f32x4{b0, b0, b0, b0}, acc1 = f32x4{b1, b1, b1, b1};
+        if (b < n_blk) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const f32x4* xp = reinterpret_cast<const f32x4*>(xin + c * kInW + 4 * (16 * b + fi) + 8 * kq);
-            u32x4 a0, a1, a2;
-            split8(xp[0], xp[1], a0, a1, a2);
+            // floats 4 (16 b + fi) + 8 kq .. + 7 of channel c = chunks (16 b + fi) + 2 kq and the next one
+            const u32x2* xp = xpl + c * kQ + (16 * b + fi) + 2 * kq;
+            u32x4 a[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const u32x2 lo2 = xp[p * kPl], hi2 = xp[p * kPl + 1];
+                a[p] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+            }
+            const u32x4 a0 = a[0], a1 = a[1], a2 = a[2];
             acc0 = mma(a2, w[c][0][0], acc0);   // smallest products first
             acc1 = mma(a2, w[c][0][1], acc1);
             acc0 = mma(a0, w[c][2][0], acc0);
@@ -102,9 +172,18 @@ __global__ __launch_bounds__(kThreads) void conv1_mfma_kernel(const float* __res
             acc0 = mma(a0, w[c][0][0], acc0);
             acc1 = mma(a0, w[c][0][1], acc1);
         }
-        // lane (filter fi, kq): positions 16 b + 4 kq .. + 3
-        *reinterpret_cast<f32x4*>(obuf + fi * kOutS + 16 * b + 4 * kq) = acc0;
-        *reinterpret_cast<f32x4*>(obuf + (16 + fi) * kOutS + 16 * b + 4 * kq) = acc1;
+        }
+        acc[bi][0] = acc0;
+        acc[bi][1] = acc1;
+    }
+    __syncthreads();                                              // every wave has read its planes: the tile may overwrite them
+#pragma unroll
+    for (int bi = 0; bi < kBw; ++bi) {
+        const int b = wave + 4 * bi;
+        if (b < n_blk) {   // lane (filter fi, kq): positions 16 b + 4 kq .. + 3
+            *reinterpret_cast<f32x4*>(obuf + fi * kOutS + 16 * b + 4 * kq) = acc[bi][0];
+            *reinterpret_cast<f32x4*>(obuf + (16 + fi) * kOutS + 16 * b + 4 * kq) = acc[bi][1];
+        }
     }
     __syncthreads();
     // rows of consecutive positions: a wave instruction writes 256 contiguous bytes of one filter's row.  (Groups of four
