@@ -245,6 +245,7 @@ struct DcsGemmBranches {         // (B planes, bias, C) of up to 4 GEMMs that sh
     float* C[4];
 };
 bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemmBranches* br);   // false: not taken
+bool dcs_launch_gemm_bf16x3_longk(dcs_ctx* ctx, const DcsGemm& g);                                   // false: not taken
 
 int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
                            int ninst, int n_notes, int width, int64_t start, int64_t stop, float mag_scale, float* out_d,

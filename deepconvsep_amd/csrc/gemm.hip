@@ -350,6 +350,11 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     static const int ks_env = getenv("DCS_GEMM_KSPLIT") ? atoi(getenv("DCS_GEMM_KSPLIT")) : -1;   // 0 disables
     const int64_t tiles16 = groups16 * (g.n_cols / 16);
     if (g.a_vec && ks_env != 0 && g.K >= 16384 && tiles16 < 4 * (int64_t)ctx->n_cu) {
+        if (ks_env < 0 && dcs_launch_gemm_bf16x3_longk(ctx, g)) {   // 128 .. 176 rows and B as bf16 planes: the matrix pipe's K-split
+            tm.done();
+            DCS_HIP(hipGetLastError());
+            return DCS_OK;
+        }
         constexpr int ks_tile = 1;
         const bool tiled = ks_tile && g.M >= 48;
         const int64_t units = tiled ? dcs_cdiv(g.M, 64) * (g.n_cols / BN) : tiles16;

@@ -233,7 +233,10 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
     const int n_cols = g.n_cols, gK = g.K;
-    const int nkt = (gK + 31) / 32;
+    // K slices (g.partial: the long-K form, blockIdx.z = slice of g.kchunk columns of A): k tiles [kt_lo, kt_hi), raw sums out
+    const int nkt_all = (gK + 31) / 32;
+    const int kt_lo = g.partial ? (int)blockIdx.z * (g.kchunk / 32) : 0;
+    const int nkt = (g.partial && kt_lo + g.kchunk / 32 < nkt_all) ? kt_lo + g.kchunk / 32 : nkt_all;
     const float gscale = g.a_scale;
     const int n0 = (blockIdx.x * 4 + wave) * CW;          // this wave's columns
     const bool live = n0 < n_cols;                        // n_cols is a multiple of 64
@@ -281,9 +284,9 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
     unsigned long long sk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, sb = 0;
     SK_NOW(sb)
 #endif
-    DCS_LOAD_A(0)
-    DCS_LOAD_B(0)
-    for (int kt = 0; kt < nkt; ++kt) {
+    DCS_LOAD_A(kt_lo)
+    DCS_LOAD_B(kt_lo)
+    for (int kt = kt_lo; kt < nkt; ++kt) {
         SK_NOW(s0)
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
@@ -336,6 +339,18 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
     if (!live) return;
     // lane (row fi of block r, kq): columns n0 + 4 CB kq + 4 cb + e
     const int c0 = n0 + kq * (4 * CB);
+    if (g.partial) {   // raw sums of this K slice, [slice][row][column]: the reduce pass adds the slices in order, bias, rectifier
+#pragma unroll
+        for (int r = 0; r < RBT; ++r) {
+            const int64_t row = r * 16 + fi;
+            if (row < g.M) {
+                float* pp = g.partial + ((int64_t)blockIdx.z * g.M + row) * n_cols + c0;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<f32x4*>(pp + cb * 4) = acc[r][cb];
+            }
+        }
+        return;
+    }
     f32x4 bias[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -379,6 +394,77 @@ extern "C" __attribute__((visibility("default"))) int skinny_trace_dump(unsigned
     return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(skinny_trace_buf), sizeof(unsigned long long) * 8);
 }
 #endif
+
+namespace {
+
+// Second pass of the long-K launch: 64 consecutive outputs per workgroup, the slices dealt to its four waves in four contiguous
+// runs (each wave adds its run in slice order, sixteen loads in flight), the four run sums added in run order: deterministic,
+// and a few hundred slices cost two or three memory round trips instead of one per eight slices.
+__global__ __launch_bounds__(kThreads) void gemm_longk_reduce_kernel(const DcsGemm g, int ksplit) {
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x, o = tid & 63, run = tid >> 6;
+    const int64_t total = g.M * (int64_t)g.n_cols;
+    const int64_t idx = (int64_t)blockIdx.x * 64 + o;
+    const int per = (ksplit + 3) / 4;
+    const int z0 = run * per, z1 = z0 + per < ksplit ? z0 + per : ksplit;
+    float v = 0.f;
+    if (idx < total) {
+        const float* p = g.partial + idx;
+        int z = z0;
+        for (; z + 16 <= z1; z += 16) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = p[(z + u) * total];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v += t[u];
+        }
+        for (; z < z1; ++z) v += p[z * total];
+    }
+    part[run][o] = v;
+    __syncthreads();
+    if (run == 0 && idx < total) {
+        const int64_t row = idx / g.n_cols;
+        const int col = (int)(idx - row * g.n_cols);
+        if (col < g.n_store) {
+            float s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+            s += g.bias ? g.bias[col] : 0.f;
+            if (g.relu) s = fmaxf(s, 0.f);
+            g.C[dcs_group_row(row, g.c_gdiv, g.c_gmul, g.c_gdiv >= g.M) * g.ldc + col] = s;
+        }
+    }
+}
+
+}  // namespace
+
+// Few rows, few columns, very long K (the bottleneck dense layer of the Bach10 / score-informed graphs: 128 .. 176 x 166 650 x
+// 256) on the bf16 matrix pipe: the all-rows kernel above with K cut into slices (blockIdx.z; two workgroups per CU), raw
+// sums per slice into ctx->gemm_ws, then gemm_longk_reduce_kernel.  false: not taken (shape, no planes, no scratch).
+bool dcs_launch_gemm_bf16x3_longk(dcs_ctx* ctx, const DcsGemm& g) {
+    static const bool on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);   // (DCS_GEMM_KSPLIT=n forces the f32 K-split)
+    if (!on || !g.Bq || !g.a_vec || g.partial || g.a_rowmap || (g.K & 3) || (g.lda & 3)) return false;
+    if (g.M < 128 || g.M > 176 || (g.n_cols % 128) || g.n_cols > 1024 || g.K < 16384) return false;
+    const int col_wgs = g.n_cols / 128;
+    int ksplit = (int)((2 * (int64_t)ctx->n_cu + col_wgs - 1) / col_wgs);
+    const int nkt = (g.K + 31) / 32;
+    if (ksplit > nkt) ksplit = nkt;
+    const int kts = (nkt + ksplit - 1) / ksplit;                   // k tiles per slice
+    ksplit = (nkt + kts - 1) / kts;
+    if (ksplit < 2) return false;
+    if (ctx->gemm_ws.ensure((size_t)ksplit * g.M * g.n_cols * sizeof(float)) != DCS_OK) return false;
+    DcsGemm q = g;
+    q.partial = (float*)ctx->gemm_ws.ptr;
+    q.kchunk = kts * 32;
+    const int rbt = g.M <= 128 ? 8 : 11;
+    const size_t lds = (size_t)3 * rbt * 16 * kRowU4 * 16;
+    auto kern = rbt == 8 ? gemm_bf16x3_skinny_kernel<8, 2> : gemm_bf16x3_skinny_kernel<11, 2>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+    DcsGemmBranches none{};
+    hipLaunchKernelGGL(kern, dim3((unsigned)col_wgs, 1, (unsigned)ksplit), dim3(kThreads), lds, ctx->stream, q, none);
+    hipLaunchKernelGGL(gemm_longk_reduce_kernel, dim3((unsigned)dcs_cdiv(g.M * g.n_cols, 64)), dim3(kThreads), 0, ctx->stream, q, ksplit);
+    return true;
+}
 
 size_t dcs_gemm_bq_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * 3 * (size_t)n_cols * 4 * 16; }
 

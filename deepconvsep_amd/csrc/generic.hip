@@ -1288,6 +1288,8 @@ struct DcsGenericNet {
     int use_colconv = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
+    void* Bfcq = nullptr;                                // the bottleneck weights as bf16 x 3 planes (long-K launches of 128 .. 176 rows), on first need
+    bool bfcq_failed = false;
     float* Bd[4] = {nullptr, nullptr, nullptr, nullptr};
     void* Bdq[4] = {nullptr, nullptr, nullptr, nullptr};  // per-source dense weights as bf16 planes (gemm_bf16x3.hip)
     bool bdq_failed = false;                              // the planes did not fit in memory: the dense layers stay on the f32 GEMM
@@ -1537,7 +1539,7 @@ void dcs_generic_destroy(DcsGenericNet* g) {
     void* ptrs[] = {g->Wpc_q3, g->Wpc_t_q3, g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W1dq, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3], g->biasd_cl[0], g->biasd_cl[1],
-                    g->biasd_cl[2], g->biasd_cl[3], g->Wx3};
+                    g->biasd_cl[2], g->biasd_cl[3], g->Wx3, g->Bfcq};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1767,6 +1769,25 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         q.B = g->Bfc; q.ldb = g->hid64; q.bias = g->biasfc;
         q.C = Z; q.ldc = g->hid64; q.c_gdiv = 1 << 30; q.c_gmul = 0;
         q.M = n; q.n_cols = g->hid64; q.n_store = g->hid64; q.K = g->flat_p; q.relu = 1; q.a_vec = 1;
+        // 128 .. 176 tiles against a very long K (166 650 for the Bach10 graphs): the all-rows bf16 x 3 kernel with K cut into
+        // slices (dcs_launch_gemm_bf16x3_longk) -- the planes (1.5 x the f32 weights) are made on first need; without them,
+        // or for any other row count, the f32 K-split of gemm.hip
+        static const bool fcq_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
+        if (fcq_on && n >= 128 && n <= 176 && g->flat_p >= 16384 && (g->hid64 % 128) == 0 && !g->Bfcq && !g->bfcq_failed) {
+            void* planes = nullptr;
+            if (hipMalloc(&planes, dcs_gemm_bq_bytes(g->flat_p, g->hid64)) != hipSuccess) {
+                (void)hipGetLastError();
+                g->bfcq_failed = true;
+            } else {
+                const int rc = dcs_gemm_pack_bq(ctx, g->Bfc, g->flat_p, g->hid64, g->hid64, planes);
+                if (rc != DCS_OK) {
+                    (void)hipFree(planes);
+                    return rc;
+                }
+                g->Bfcq = planes;
+            }
+        }
+        q.Bq = g->Bfcq;
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC));
     }
     // per-source dense (rectify): D[n][branch][flat_p]; aliased branches (none in these graphs) would reuse a layer

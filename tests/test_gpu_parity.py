@@ -1136,7 +1136,7 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
     f = tmp_path / "case.npz"
     np.savez(f, x=x, F=F)
     res = {}
-    for name, env in (("cl", {}), ("cf", {"DCS_DECODER_CL": "0"}), ("nox3", {"DCS_DECODER_X3": "0"})):
+    for name, env in (("cl", {}), ("cf", {"DCS_DECODER_CL": "0"}), ("nox3", {"DCS_DECODER_X3": "0"}), ("f32fc", {"DCS_GEMM_KSPLIT": "40"})):
         child_env = dict(os.environ)
         child_env.update(env)
         out = str(tmp_path / (name + ".npz"))
@@ -1154,6 +1154,10 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
     assert np.max(np.abs(res["nox3"]["q"] - want)) < 1e-4
     assert np.max(np.abs(res["cl"]["q"] - res["nox3"]["q"])) < 2e-6 * max(1.0, float(np.max(np.abs(want))))
     assert np.array_equal(res["cl"]["p"], res["nox3"]["p"])
+    # the bottleneck layer (140 x 18 810 x 256): bf16 x 3 all-rows kernel with K cut into slices (default from 128 rows and
+    # 16 384 columns of A on) against the f32 K-split it replaces (DCS_GEMM_KSPLIT=n forces it)
+    assert np.max(np.abs(res["f32fc"]["q"] - want)) < 1e-4
+    assert np.max(np.abs(res["cl"]["q"] - res["f32fc"]["q"])) < 2e-6 * max(1.0, float(np.max(np.abs(want))))
 
 
 _SI_X3_CHILD = r"""
