@@ -72,20 +72,24 @@ LEG_KERNELS = {
     # (84 tiles: both dense layers run on gemm_rows_kernel -- the bottleneck K-split over 424 workgroups, the per-source layer 1890)
     "ikala": {"conv1": "conv1_reg_kernel", "conv2": ("slabconv_ps_kernel", "min"), "deconv2": "slabconv_ps_kernel",
               "fc": "gemm_rows_kernel@grid_threads=108544", "fc1x": "gemm_rows_kernel@grid_threads=483840", "final": "deconv1_reg_kernel"},
+    # (the bottleneck layer is the all-rows bf16 x 3 kernel with K cut into 256 slices: 2 x 248 workgroups; the per-source layers
+    # are the same kernel at its widest grid)
     "bach10_f16": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_wreg_scatter_kernel", "decoder": "colconv_deconv1_fused_kernel",
-                   "fc": "gemm_rows", "fc1x": "gemm_bf16x3_skinny_kernel"},
-    "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
-                       "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
-    "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel", "fc": "gemm_rows",
-                   "fc1x": "gemm_bf16x3_skinny_kernel", "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
+                   "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel"},
+    "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel",
+                       "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel",
+                       "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
+    "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel",
+                   "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel",
+                   "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
 }
 # kernels that execute on the 16-bit matrix pipe: (products issued per f32 product, K padding factor)
 LEG_ISSUED = {
     "ikala": {"conv2": (6, 32.0 / 30.0), "deconv2": (6, 32.0 / 30.0)},   # 84 tiles: the dense layers stay on the f32 MFMA (M < 128)
-    "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc1x": (6, 1.0)},
-    "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0),
+    "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc": (6, 1.0), "fc1x": (6, 1.0)},
+    "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc": (6, 1.0), "fc1x": (6, 1.0),
                        "decoder": (6, 32.0 / 30.0 * 120.0 / 110.0)},
-    "bach10_f32": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc1x": (6, 1.0),
+    "bach10_f32": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc": (6, 1.0), "fc1x": (6, 1.0),
                    "decoder": (6, 32.0 / 30.0 * 120.0 / 110.0)},     # + the (row, tap) slots that meet a zero row (colconv_x3.hip)
 }
 
