@@ -222,6 +222,9 @@ struct DcsGemm {
     // optional: B split into three bf16 planes by dcs_gemm_pack_bq (gemm_bf16x3.hip); launches that fill the chip then
     // run on the bf16 matrix pipe with f32-class results
     const void* Bq;
+    // optional (all-rows kernel only): A already split into three bf16 planes by dcs_gemm_split_a, [k tile][plane][aq_rows][4 pieces]
+    // -- the workgroups then copy their k tile's pieces into LDS instead of each splitting all the rows again
+    const void* Aq; int aq_rows;
 };
 
 // row r of a grouped operand: (r / gdiv) * gmul + r % gdiv.  Most launches have ONE group (gdiv = 2^30 > M): a 64-bit division
@@ -246,6 +249,9 @@ struct DcsGemmBranches {         // (B planes, bias, C) of up to 4 GEMMs that sh
 };
 bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemmBranches* br);   // false: not taken
 bool dcs_launch_gemm_bf16x3_longk(dcs_ctx* ctx, const DcsGemm& g);                                   // false: not taken
+// A [M][K] f32 (lda) -> bf16 x 3 planes for DcsGemm::Aq: [(K + 31) / 32][3][rows_pad][4] 16-byte pieces, rows >= M and k >= K zero
+size_t dcs_gemm_aq_bytes(int K, int rows_pad);
+int dcs_gemm_split_a(dcs_ctx* ctx, const float* A_d, int64_t lda, int64_t M, int K, int rows_pad, void* Aq_d);
 
 int dcs_score_masks_scaled(dcs_ctx* ctx, const float* mag_d, int64_t ld, int64_t n_frames, int F, const double* notes_h,
                            int ninst, int n_notes, int width, int64_t start, int64_t stop, float mag_scale, float* out_d,

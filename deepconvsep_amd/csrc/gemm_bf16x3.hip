@@ -216,7 +216,10 @@ __device__ unsigned long long skinny_trace_buf[8];
 #define SK_NOW(v_)
 #define SK_ADD(i_, a_, b_)
 #endif
-template <int RBT /* row blocks of 16 */, int CB /* 16-column blocks per wave */>
+// AQ: the rows come pre-split (DcsGemm::Aq, round 5): the staging of a k tile is three 16-byte loads and three LDS writes per
+// piece, no arithmetic -- with hundreds of workgroups each splitting all 128 .. 176 rows of every k tile the split was 22 % of
+// the kernel (profiles/r04_o_skinny_timeline.txt).  Same planes, same products: bit-identical results.
+template <int RBT /* row blocks of 16 */, int CB /* 16-column blocks per wave */, bool AQ = false>
 __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_kernel(const DcsGemm g0, const DcsGemmBranches br) {
     // blockIdx.y = branch: the same A against another (B planes, bias, C) triple -- one launch for all sources
     DcsGemm g = g0;
@@ -258,7 +261,16 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
     // B: piece (kt, plane, column, kg); MFMA row fi of block cb is column n0 + 4 CB (fi / 4) + 4 cb + fi % 4
     const int64_t b_plane = (int64_t)n_cols * 4, b_kt = 3 * b_plane;
     const u32x4* Bl = reinterpret_cast<const u32x4*>(g.Bq) + ((int64_t)((live ? n0 : 0) + (fi >> 2) * (4 * CB) + (fi & 3))) * 4 + kq;
-    f32x4 ra[A_PER][2];
+    f32x4 ra[AQ ? 1 : A_PER][2];
+    u32x4 rq[AQ ? A_PER : 1][3];                           // AQ: the three planes of the piece in flight
+    const u32x4* aq_ptr[A_PER];                            // AQ: plane 0 of this thread's piece of k tile 0
+    const int64_t aq_plane = (int64_t)g.aq_rows * 4, aq_kt = 3 * aq_plane;
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        const int idx = tid + u * kThreads;
+        const int row = idx >> 2, q = idx & 3;
+        aq_ptr[u] = reinterpret_cast<const u32x4*>(g.Aq) + (int64_t)(idx < ROWS * 4 ? row : 0) * 4 + q;
+    }
     int ra_k[A_PER];                                       // first k of the piece in flight
     u32x4 bn[CB][3], bc[CB][3];
 // The loads are UNCONDITIONAL (rows past M read row 0, k past K reads the last four of the row) and nothing touches the
@@ -267,10 +279,14 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
 // timeline, profiles/r04_o_skinny_timeline.txt).
 #define DCS_LOAD_A(kt_)                                                                                 \
     _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                                 \
-        const int k = (kt_) * 32 + a_k0[u];                                                             \
-        ra[u][0] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k < gK ? k : gK - 4) - a_k0[u]);         \
-        ra[u][1] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k + 4 < gK ? k + 4 : gK - 4) - a_k0[u]); \
-        ra_k[u] = k;                                                                                    \
+        if constexpr (AQ) {                                                                             \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) rq[u][p] = aq_ptr[u][(kt_) * aq_kt + p * aq_plane]; \
+        } else {                                                                                        \
+            const int k = (kt_) * 32 + a_k0[u];                                                         \
+            ra[u][0] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k < gK ? k : gK - 4) - a_k0[u]);     \
+            ra[u][1] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k + 4 < gK ? k + 4 : gK - 4) - a_k0[u]); \
+            ra_k[u] = k;                                                                                \
+        }                                                                                               \
     }
 #define DCS_LOAD_B(kt_)                                                                                 \
     _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                   \
@@ -291,11 +307,15 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
             if (a_dst[u] >= 0) {
-                u32x4 p0, p1, p2;
-                const float s0 = (a_ok[u] && ra_k[u] < gK) ? gscale : 0.f, s1 = (a_ok[u] && ra_k[u] + 4 < gK) ? gscale : 0.f;
-                split8(ra[u][0] * s0, ra[u][1] * s1, p0, p1, p2);
                 u32x4* dst = As + a_dst[u];
-                dst[0] = p0; dst[kPlane] = p1; dst[2 * kPlane] = p2;
+                if constexpr (AQ) {                       // (rows past M and k past K are zero in the planes)
+                    dst[0] = rq[u][0]; dst[kPlane] = rq[u][1]; dst[2 * kPlane] = rq[u][2];
+                } else {
+                    u32x4 p0, p1, p2;
+                    const float s0 = (a_ok[u] && ra_k[u] < gK) ? gscale : 0.f, s1 = (a_ok[u] && ra_k[u] + 4 < gK) ? gscale : 0.f;
+                    split8(ra[u][0] * s0, ra[u][1] * s1, p0, p1, p2);
+                    dst[0] = p0; dst[kPlane] = p1; dst[2 * kPlane] = p2;
+                }
             }
         }
 #pragma unroll
@@ -454,6 +474,7 @@ bool dcs_launch_gemm_bf16x3_longk(dcs_ctx* ctx, const DcsGemm& g) {
     DcsGemm q = g;
     q.partial = (float*)ctx->gemm_ws.ptr;
     q.kchunk = kts * 32;
+    q.Aq = nullptr;
     const int rbt = g.M <= 128 ? 8 : 11;
     const size_t lds = (size_t)3 * rbt * 16 * kRowU4 * 16;
     auto kern = rbt == 8 ? gemm_bf16x3_skinny_kernel<8, 2> : gemm_bf16x3_skinny_kernel<11, 2>;
@@ -515,12 +536,58 @@ bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemm
     constexpr int cb_env = 2;   // four column blocks per wave measured 0.56 vs 0.52 ms (round 2)
     const int cb = cb_env == 4 ? 4 : 2;
     const size_t lds = (size_t)3 * rbt * 16 * kRowU4 * 16;
-    auto kern = rbt == 8 ? (cb == 4 ? gemm_bf16x3_skinny_kernel<8, 4> : gemm_bf16x3_skinny_kernel<8, 2>)
-                         : (cb == 4 ? gemm_bf16x3_skinny_kernel<11, 4> : gemm_bf16x3_skinny_kernel<11, 2>);
+    // pre-split rows (dcs_gemm_split_a): only as made for this launch's row tiling, and only with a_scale == 1 (the planes hold A as it is)
+#if defined(DCS_NO_AQ)   // experiment build: every workgroup splits the rows itself
+    const bool aq = false;
+#else
+    const bool aq = g.Aq && g.aq_rows == rbt * 16 && g.a_scale == 1.f && g.a_gdiv >= g.M;
+#endif
+    auto kern = rbt == 8 ? (cb == 4 ? gemm_bf16x3_skinny_kernel<8, 4> : (aq ? gemm_bf16x3_skinny_kernel<8, 2, true> : gemm_bf16x3_skinny_kernel<8, 2>))
+                         : (cb == 4 ? gemm_bf16x3_skinny_kernel<11, 4> : (aq ? gemm_bf16x3_skinny_kernel<11, 2, true> : gemm_bf16x3_skinny_kernel<11, 2>));
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
     hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(g.n_cols, 64 * cb), (unsigned)(b.n > 0 ? b.n : 1)), dim3(kThreads), lds,
                        ctx->stream, g, b);
     return true;
+}
+
+namespace {
+
+// piece (kt, row, q): the 8 consecutive k of one row, split exactly into three bf16 terms
+__global__ __launch_bounds__(kThreads) void gemm_split_a_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K, int rows_pad,
+                                                                u32x4* __restrict__ Aq, int64_t n_pieces) {
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;   // q fastest, then row, then k tile
+    if (idx >= n_pieces) return;
+    const int q = (int)(idx & 3);
+    const int64_t t = idx >> 2;
+    const int row = (int)(t % rows_pad);
+    const int64_t kt = t / rows_pad;
+    f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
+    if (row < M) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = kt * 32 + q * 8 + j;
+            const float v = k < K ? A[row * lda + k] : 0.f;
+            if (j < 4) x0[j] = v; else x1[j - 4] = v;
+        }
+    }
+    u32x4 p0, p1, p2;
+    split8(x0, x1, p0, p1, p2);
+    const int64_t base = (kt * 3 * rows_pad + row) * 4 + q;
+    Aq[base] = p0;
+    Aq[base + (int64_t)rows_pad * 4] = p1;
+    Aq[base + (int64_t)rows_pad * 8] = p2;
+}
+
+}  // namespace
+
+size_t dcs_gemm_aq_bytes(int K, int rows_pad) { return (size_t)((K + 31) / 32) * 3 * (size_t)rows_pad * 4 * 16; }
+
+int dcs_gemm_split_a(dcs_ctx* ctx, const float* A_d, int64_t lda, int64_t M, int K, int rows_pad, void* Aq_d) {
+    const int64_t n_pieces = (int64_t)((K + 31) / 32) * rows_pad * 4;
+    hipLaunchKernelGGL(gemm_split_a_kernel, dim3((unsigned)dcs_cdiv(n_pieces, kThreads)), dim3(kThreads), 0, ctx->stream, A_d, lda, M, K,
+                       rows_pad, reinterpret_cast<u32x4*>(Aq_d), n_pieces);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
 }

@@ -2,7 +2,7 @@
 # Round 5, visit Q: decoder stage 1 with both rows of a pair interleaved (four accumulator chains) -- parity, then same-box A/B.
 set -u
 export TMPDIR=/tmp
-export DCS_CONV2_X3=0
+
 OUT=gpurun_out; mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider \
   -k "decoder or channels_last or bach10_fused or scoreinformed_batch or bach10_full_size or graph_fixtures" > $OUT/r05_q_pytest.log 2>&1
