@@ -371,3 +371,53 @@ def test_f32_gemm_reads_its_lds_operands_in_groups_of_eight_k_steps_in_the_old_o
                 sets[(g + 1) & 1] = list(range((g + 1) * KG, (g + 2) * KG))
             order += sets[g & 1]
         assert order == list(range(steps))
+
+
+def test_long_k_slices_of_the_bottleneck_layer_cover_every_k_tile_once():
+    """dcs_launch_gemm_bf16x3_longk (gemm_bf16x3.hip): K is cut into slices of whole 32-wide k tiles, about two workgroups per CU;
+    slice z of the all-rows kernel walks the tiles [z * kts, min(nkt, (z + 1) * kts)).  Restated here: every tile belongs to
+    exactly one slice, no slice is empty, the scratch holds one [M][n_cols] block per slice, and the reduce pass deals the
+    slices to its four runs in order without gaps."""
+    for n_cu in (256, 304, 64):
+        for K in (16384, 18810, 166650, 166656, 666600, 32 * 1000 + 4):
+            for n_cols in (128, 256, 512):
+                col_wgs = n_cols // 128
+                ksplit = (2 * n_cu + col_wgs - 1) // col_wgs
+                nkt = (K + 31) // 32
+                ksplit = min(ksplit, nkt)
+                kts = (nkt + ksplit - 1) // ksplit
+                ksplit = (nkt + kts - 1) // kts
+                assert ksplit >= 2 and kts >= 1
+                seen = np.zeros(nkt, dtype=int)
+                for z in range(ksplit):
+                    lo = z * kts                                   # kt_lo of the kernel (g.kchunk / 32 == kts)
+                    hi = lo + kts if lo + kts < nkt else nkt
+                    assert lo < hi <= nkt, (K, n_cols, z)
+                    seen[lo:hi] += 1
+                assert (seen == 1).all()
+                per = (ksplit + 3) // 4                            # gemm_longk_reduce_kernel: run r adds slices [r * per, ...)
+                order = []
+                for run in range(4):
+                    z0 = run * per
+                    z1 = z0 + per if z0 + per < ksplit else ksplit
+                    order += list(range(z0, max(z0, z1)))
+                assert order == list(range(ksplit))
+
+
+def test_conv1_planes_in_lds_give_every_fragment_the_floats_the_old_kernel_split():
+    """conv1_mfma_kernel (round 5): a row's floats are split once into [plane][channel][chunk of 4] units of 8 bytes; lane (position
+    fi, K piece kq) of column block b reads chunks (16 b + fi) + 2 kq and the next one = floats 4 (16 b + fi) + 8 kq .. + 7 -- the
+    eight taps the old kernel read as two 16-byte LDS loads and split itself.  Every chunk a fragment touches lies inside the
+    1 056 floats staged per channel, and the output tile may overwrite the planes (it is at least as large)."""
+    kPos, kInW, kOutS = 256, 4 * 256 + 32, 256 + 4
+    kQ = kInW // 4
+    for b in range(kPos // 16):
+        for fi in range(16):
+            for kq in range(4):
+                c0 = (16 * b + fi) + 2 * kq
+                assert c0 + 1 < kQ
+                floats = [4 * c0 + j for j in range(8)]
+                assert floats == [4 * (16 * b + fi) + 8 * kq + j for j in range(8)]
+    for C in (1, 4):
+        planes_bytes = 3 * C * kInW * 2
+        assert max(planes_bytes, 32 * kOutS * 4) == 32 * kOutS * 4         # the tile decides the LDS size
