@@ -73,7 +73,10 @@ __device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& mid, u3
 // fragments of eight (position, K piece) pairs, so the split ran eight times per float -- 1 024 of the ~1 900 vector
 // instructions of a wave, next to a per-float load loop with a division by 1 056; the kernel was bound by instruction issue at
 // 0.46 of the f32 peak (score-informed batch: 0.197 ms).  Same terms, same products, same order: bit-identical results.
-template <int C>
+//
+// CL: the output channels-last, out[n][t][j][o] (NF floats per position) -- the layout colconv_fwd_x3_kernel (conv2 of the
+// f32-class Bach10 / score-informed graphs) reads a position's channels from; the tile in LDS is then [position][36].
+template <int C, bool CL>
 __global__ __launch_bounds__(kThreads, C > 1 ? 3 : 4) void conv1_mfma_kernel(const float* __restrict__ x, const u32x4* __restrict__ Wq,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int NF, int tc, int F, int w1) {
@@ -81,7 +84,10 @@ __global__ __launch_bounds__(kThreads, C > 1 ? 3 : 4) void conv1_mfma_kernel(con
     constexpr int kPl = C * kInW / 4;                             // u32x2 units (4 bf16) per plane
     // the planes [plane][channel][chunk] and, once every wave is done with them, the output tile [32 filters][kOutS] in the
     // same bytes (a third barrier instead of 33 KB more LDS: three workgroups per CU instead of two)
-    constexpr int kLdsBytes = 3 * kPl * 8 > 32 * kOutS * 4 ? 3 * kPl * 8 : 32 * kOutS * 4;
+    constexpr int kClS = 36;                                      // floats per position of the channels-last tile (32 + 4: the
+                                                                  // four K-piece groups of a wave write 16 banks apart)
+    constexpr int kTileBytes = CL ? kPos * kClS * 4 : 32 * kOutS * 4;
+    constexpr int kLdsBytes = 3 * kPl * 8 > kTileBytes ? 3 * kPl * 8 : kTileBytes;
     __shared__ __attribute__((aligned(16))) char lds_raw[kLdsBytes];
     u32x2* xpl = reinterpret_cast<u32x2*>(lds_raw);
     float* obuf = reinterpret_cast<float*>(lds_raw);
@@ -181,14 +187,30 @@ __global__ __launch_bounds__(kThreads, C > 1 ? 3 : 4) void conv1_mfma_kernel(con
     for (int bi = 0; bi < kBw; ++bi) {
         const int b = wave + 4 * bi;
         if (b < n_blk) {   // lane (filter fi, kq): positions 16 b + 4 kq .. + 3
-            *reinterpret_cast<f32x4*>(obuf + fi * kOutS + 16 * b + 4 * kq) = acc[bi][0];
-            *reinterpret_cast<f32x4*>(obuf + (16 + fi) * kOutS + 16 * b + 4 * kq) = acc[bi][1];
+            if (CL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    obuf[(16 * b + 4 * kq + e) * kClS + fi] = acc[bi][0][e];
+                    obuf[(16 * b + 4 * kq + e) * kClS + 16 + fi] = acc[bi][1][e];
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(obuf + fi * kOutS + 16 * b + 4 * kq) = acc[bi][0];
+                *reinterpret_cast<f32x4*>(obuf + (16 + fi) * kOutS + 16 * b + 4 * kq) = acc[bi][1];
+            }
         }
     }
     __syncthreads();
     // rows of consecutive positions: a wave instruction writes 256 contiguous bytes of one filter's row.  (Groups of four
     // positions on 16-byte boundaries of `out` -- the alignment depends on the row -- with the head as scalars were slower:
     // 0.22 vs 0.19 ms on the score-informed batch.)
+    if (CL) {   // NF * cnt consecutive floats of the output
+        float* op = out + ((n * tc + t) * (int64_t)w1 + j_base) * NF;
+        for (int i = tid; i < NF * cnt; i += kThreads) {
+            const int jj = i / NF, o = i - jj * NF;
+            op[i] = obuf[jj * kClS + o];
+        }
+        return;
+    }
     for (int i = tid; i < NF * kPos; i += kThreads) {
         const int o = i / kPos, jj = i - o * kPos;
         if (jj < cnt) out[((n * NF + o) * tc + t) * (int64_t)w1 + j_base + jj] = obuf[o * kOutS + jj];
@@ -220,15 +242,19 @@ void dcs_conv1_mfma_pack(const float* Wc, int NF, int C, int kw, std::vector<uin
 
 // false: shape not covered, nothing launched.  bias: [NF]
 bool dcs_launch_conv1_mfma(dcs_ctx* ctx, const float* x, const void* Wq, const float* bias, float* out, int64_t n, int C,
-                           int NF, int tc, int F, int kw, int sw, int w1) {
+                           int NF, int tc, int F, int kw, int sw, int w1, bool channels_last) {
     static const bool on = !(getenv("DCS_CONV1_MFMA") && atoi(getenv("DCS_CONV1_MFMA")) == 0);
     if (!on || !Wq || sw != 4 || kw > 32 || NF > 32 || (C != 1 && C != 4) || n * tc > 0x7fffffff) return false;
     if (n <= 0) return true;
     const dim3 grid((unsigned)(n * tc), (unsigned)dcs_cdiv(w1, kPos));
     const u32x4* wq = reinterpret_cast<const u32x4*>(Wq);
-    if (C == 1)
-        hipLaunchKernelGGL((conv1_mfma_kernel<1>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+    if (C == 1 && channels_last)
+        hipLaunchKernelGGL((conv1_mfma_kernel<1, true>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+    else if (C == 1)
+        hipLaunchKernelGGL((conv1_mfma_kernel<1, false>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+    else if (channels_last)
+        hipLaunchKernelGGL((conv1_mfma_kernel<4, true>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
     else
-        hipLaunchKernelGGL((conv1_mfma_kernel<4>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+        hipLaunchKernelGGL((conv1_mfma_kernel<4, false>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
     return true;
 }

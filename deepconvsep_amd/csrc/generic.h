@@ -49,7 +49,10 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
 // conv1 with a frequency stride of 4 on the bf16 matrix pipe (conv1_mfma.hip): false = shape not covered, nothing launched
 void dcs_conv1_mfma_pack(const float* Wc, int NF, int C, int kw, std::vector<uint16_t>* out);
 bool dcs_launch_conv1_mfma(dcs_ctx* ctx, const float* x, const void* Wq, const float* bias, float* out, int64_t n, int C,
-                           int NF, int tc, int F, int kw, int sw, int w1);
+                           int NF, int tc, int F, int kw, int sw, int w1, bool channels_last = false);
+// conv2 of the Bach10 / score-informed graphs, f32-class, weights in registers (colconv_fwd_x3.hip): channels-last input
+bool dcs_colconv_fwd_x3_ok(const DcsColConv& a);
+bool dcs_launch_colconv_fwd_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq);
 // InverseLayer(conv1) with a frequency stride of 4 on the bf16 matrix pipe (deconv1_mfma.hip)
 void dcs_deconv1_mfma_pack(const float* W1p, int nf1, int C, std::vector<uint16_t>* out);
 bool dcs_launch_deconv1_mfma(dcs_ctx* ctx, const float* g, const void* Wq, float* out, int64_t n_images, int NF, int C, int tc,

@@ -1283,6 +1283,7 @@ struct DcsGenericNet {
     _Float16 *Wcol_r = nullptr, *Wcol_t_r = nullptr;     // the same weights as MFMA fragments (colconv_wreg.hip)
     uint16_t* W1q = nullptr;                             // padded conv1 filter as bf16 x 3 fragments (fused decoder)
     uint16_t* Wx3 = nullptr;                             // transposed conv2 filter as bf16 x 3 fragments, taps dealt by parity (colconv_x3.hip)
+    uint16_t* Wfx3 = nullptr;                            // the forward conv2 filter in the same fragment format (colconv_fwd_x3.hip)
     uint16_t* W1m = nullptr;                             // conv1 filter as bf16 x 3 fragments (conv1_mfma.hip)
     uint16_t* W1dq = nullptr;                            // the same for its InverseLayer (deconv1_mfma.hip)
     int use_colconv = 0;
@@ -1440,6 +1441,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
     std::vector<float> Wcol, Wcol_t;
     std::vector<_Float16> Wcol_h, Wcol_t_h;
     std::vector<float> Wcol_t_f;                         // the transposed filter once more in f32, [kh][32 out][40] (colconv_x3.hip)
+    std::vector<float> Wcol_f;                           // the forward filter in that format (colconv_fwd_x3.hip)
     static const int col_env = getenv("DCS_COLCONV") ? atoi(getenv("DCS_COLCONV")) : 1;
     g->use_colconv = (kw == 1 && nf1 <= 32 && nf2 <= 32 && col_env) ? 1 : 0;
     if (g->use_colconv) {
@@ -1448,6 +1450,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         Wcol_h.assign((size_t)kh * 32 * 40, (_Float16)0.f);
         Wcol_t_h.assign((size_t)kh * 32 * 40, (_Float16)0.f);
         Wcol_t_f.assign((size_t)kh * 32 * 40, 0.f);
+        Wcol_f.assign((size_t)kh * 32 * 40, 0.f);
         for (int co = 0; co < nf2; ++co)
             for (int ci = 0; ci < nf1; ++ci)
                 for (int u = 0; u < kh; ++u) {
@@ -1457,6 +1460,7 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
                     Wcol_h[((size_t)u * 32 + co) * 40 + ci] = (_Float16)wf;      // forward: out channel co, in channel ci
                     Wcol_t_h[((size_t)u * 32 + ci) * 40 + co] = (_Float16)wt;    // transpose: out channel ci, in channel co
                     Wcol_t_f[((size_t)u * 32 + ci) * 40 + co] = wt;
+                    Wcol_f[((size_t)u * 32 + co) * 40 + ci] = wf;
                 }
     }
     // dense layers: the flattened [nf2, h2, w2] order is the storage order of a2b, so no permutation
@@ -1494,6 +1498,11 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
         dcs_slabconv_ps_pack(Wcol_t.data(), kh, 1, slot, 0, &Wpc_t_q3);
         UP(g->Wpc_q3, Wpc_q3) UP(g->Wpc_t_q3, Wpc_t_q3)
         UP(g->Wcol, Wcol) UP(g->Wcol_t, Wcol_t) UP(g->Wcol_h, Wcol_h) UP(g->Wcol_t_h, Wcol_t_h) UP(g->Wcol_r, Wcol_r) UP(g->Wcol_t_r, Wcol_t_r)
+        if (kh % 2 == 0 && !d.pool_w) {                   // f32-class conv2 with the weights in registers (colconv_fwd_x3.hip)
+            std::vector<uint16_t> Wfx3;
+            dcs_decoder_x3_pack(Wcol_f.data(), kh, &Wfx3);
+            UP(g->Wfx3, Wfx3)
+        }
         // both InverseLayers in one kernel: single-channel graphs (Bach10), and the f32-class kernel also with the four
         // output channels of the score-informed graph
         if ((C == 1 || C == 4) && d.sw1 == 4 && kw1 > 28 && kw1 <= 32 && !d.pool_w && !W1p.empty()) {
@@ -1539,7 +1548,7 @@ void dcs_generic_destroy(DcsGenericNet* g) {
     void* ptrs[] = {g->Wpc_q3, g->Wpc_t_q3, g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W1dq, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3], g->biasd_cl[0], g->biasd_cl[1],
-                    g->biasd_cl[2], g->biasd_cl[3], g->Wx3, g->Bfcq};
+                    g->biasd_cl[2], g->biasd_cl[3], g->Wx3, g->Bfcq, g->Wfx3};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1674,6 +1683,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // dcs_model_forward (mask_mode 2: the whole network output) evaluates all of them.
     const int NB = mask_mode == 2 ? d.n_branch : (d.S + C - 1) / C < d.n_branch ? (d.S + C - 1) / C : d.n_branch;
     const int64_t plane1 = (int64_t)tc * d.w1, planep = (int64_t)tc * d.wp;
+    bool want_a1_cl = false, a1_cl = false;             // conv1's output channels-last: asked for / written that way
     float* a1b = (float*)w; w += align256((size_t)n * d.nf1 * plane1 * 4);
     float* p1 = a1b;
     if (d.pool_w) { p1 = (float*)w; w += align256((size_t)n * d.nf1 * planep * 4); }
@@ -1705,12 +1715,22 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
         DcsTimer tm(ctx, DCS_TAG_CONV1);
+        // f32-class column conv2 with the weights in registers (colconv_fwd_x3.hip) reads a position's channels together: conv1
+        // then writes its output channels-last (only the bf16-pipe conv1 kernel can; nothing else reads a1b in these graphs)
+        {
+            ColConvArgs c2{};
+            c2.in = a1b; c2.in_n_stride = (int64_t)d.nf1 * plane1; c2.Cin = d.nf1; c2.H = tc; c2.W = d.w1;
+            c2.Cout = d.nf2; c2.Ho = d.h2; c2.ph = 0; c2.kh = d.kh2;
+            want_a1_cl = !g->conv_f16 && g->use_colconv && g->Wfx3 && g->W1m && !d.pool_w && d.wp == d.w1 && dcs_colconv_fwd_x3_ok(c2) &&
+                         (c2.in_n_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(a1b) & 7) == 0;
+        }
         static const int reg1 = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
         const dim3 grid1((unsigned)dcs_cdiv(d.w1, kThreads), (unsigned)(n * tc));
         if (pool_fused) {   // conv1 + max-pool: pooled rows to p1, the un-pooling routing bits where the activations would go
             hipLaunchKernelGGL((conv1_reg_kernel<30, 3, true>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, p1, C,
                                tc, F, d.kw1, d.w1, pool_bits, d.wp, pool_mw, tie_mode == DCS_TIE_FIRST ? 1 : 0);
-        } else if (g->W1m && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1)) {
+        } else if (g->W1m && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1, want_a1_cl)) {
+            a1_cl = want_a1_cl;
         } else if (reg1 && d.nf1 == 30 && d.kw1 <= 32 && d.sw1 == 4)   // the register kernel is built for 30 filters
             hipLaunchKernelGGL((conv1_reg_kernel<30, 4>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, a1b, C,
                                tc, F, d.kw1, d.w1);
@@ -1742,6 +1762,10 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = 0; c.kh = d.kh2;
+            if (a1_cl) {
+                if (!dcs_launch_colconv_fwd_x3(ctx, c, n, g->Wfx3))
+                    DCS_FAIL(DCS_EHIP, "generic graph: conv2 refused the channels-last input conv1 was asked to write");
+            } else
             DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr, g->Wcol_r, g->Wpc_q3));
         } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
             // general filters (iKala, 10 x 20) go through the slab kernel in either precision unless DCS_F16_IGEMM=1 asks
