@@ -76,10 +76,10 @@ LEG_KERNELS = {
     # are the same kernel at its widest grid)
     "bach10_f16": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_wreg_scatter_kernel", "decoder": "colconv_deconv1_fused_kernel",
                    "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel"},
-    "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_fwd_x3_kernel", "deconv2": "colconv_kernel",
+    "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel",
                        "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel",
                        "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
-    "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_fwd_x3_kernel", "deconv2": "colconv_kernel",
+    "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel",
                    "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel",
                    "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
 }

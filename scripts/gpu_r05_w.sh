@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, visit W: conv2 of the Bach10 / score-informed graphs with the weights in registers, one wave per half of the output channels.
+# Round 5, visit W: conv2 of the Bach10 / score-informed graphs with the weights in registers (opt-in since: DCS_CONV2_X3=1 / unset; the script predates that and compares default-on with DCS_CONV2_X3=0).
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out; mkdir -p $OUT

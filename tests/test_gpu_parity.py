@@ -1075,7 +1075,7 @@ sys.exit(0 if err < (2e-3 if f16 else 1e-4) else 3)
 
 @pytest.mark.parametrize("env", [{"DCS_GENERIC_CHUNK": "8"}, {"DCS_GEMM_KSPLIT": "0"}, {"DCS_GEMM_KSPLIT": "5"},
                                  {"DCS_GEMM_KSPLIT": "64"},
-                                 {"DCS_COLCONV": "0"}, {"DCS_GEMM_BF16": "0"}, {"DCS_CONV2_X3": "0"},
+                                 {"DCS_COLCONV": "0"}, {"DCS_GEMM_BF16": "0"}, {"DCS_CONV2_X3": "1"},
                                  {"DCS_CONV1_MFMA": "0"}, {"DCS_CONV1_MFMA": "0", "DCS_CONV1_REG": "0"}, {"DCS_DECONV1_MFMA": "0"},
                                  {"DCS_DECONV1_MFMA": "0", "DCS_DECONV1_REG": "0"},
                                  {"DCS_TEST_F16": "1"}, {"DCS_TEST_F16": "1", "DCS_DECODER_FUSED": "0"},
