@@ -421,3 +421,38 @@ def test_conv1_planes_in_lds_give_every_fragment_the_floats_the_old_kernel_split
     for C in (1, 4):
         planes_bytes = 3 * C * kInW * 2
         assert max(planes_bytes, 32 * kOutS * 4) == 32 * kOutS * 4         # the tile decides the LDS size
+
+
+def test_opt_in_conv2_kernel_visits_every_row_tap_pair_once_and_never_overwrites_a_ring_slot_in_use():
+    """colconv_fwd_x3_kernel (DCS_CONV2_X3=1): KH = 20 taps, H = 30 input rows, HO = 11 output rows.  Step s multiplies input row s
+    with every tap u whose output row y = s - u exists; the rows live in a ring of three chunks of two rows (slot = chunk % 3).
+    Restated: every (y, u) pair is visited exactly once, in increasing u for a fixed y (the accumulation order of a chain); in
+    interval i the chunk being written (i + 2, of the next block from i = 13 on) never shares a slot with the chunks being read
+    (i: steps 2 i, 2 i + 1; i + 1: the prefetch for step 2 i + 2); the raw-register slot of a fetched chunk (chunk % 3) is the
+    one its split reads three intervals later, also across the block boundary (15 chunks per block, 15 % 3 == 0)."""
+    KH, H = 20, 30
+    HO, NCH, RING = H - KH + 1, H // 2, 3
+    seen = {}
+    for i in range(NCH):
+        for s in (2 * i, 2 * i + 1):
+            u_lo, u_hi = max(0, s - (HO - 1)), min(s, KH - 1)
+            ring_row = ((s // 2) % RING) * 2 + s % 2
+            assert s // 2 == i and ring_row // 2 == i % RING            # the row of step s is in the chunk of interval i
+            for u in range(u_lo, u_hi + 1):
+                y = s - u
+                assert 0 <= y < HO
+                seen.setdefault(y, []).append(u)
+            if s + 1 < H:                                              # prefetch of the next step's row
+                nxt = ((s + 1) // 2) % RING
+                assert nxt in (i % RING, (i + 1) % RING)
+        written = (i + 2) % RING                                       # chunk i + 2 goes where chunk i - 1 was
+        assert written not in (i % RING, (i + 1) % RING)
+        fetched = (i + 2 + RING) % NCH if i + 2 + RING >= NCH else i + 2 + RING
+        assert fetched % RING == (i + 2) % RING                        # the raw slot just consumed is the one refilled
+    assert sorted(seen) == list(range(HO))
+    for y, us in seen.items():
+        assert us == list(range(KH)), y                                # every tap once, in order
+    assert NCH % RING == 0
+    # the packed weights: tap u = 2 k + parity sits at [parity][k] of dcs_decoder_x3_pack's array
+    for u in range(KH):
+        assert 2 * (u >> 1) + (u & 1) == u
