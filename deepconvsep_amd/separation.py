@@ -296,7 +296,7 @@ class Separator(object):
         return out
 
     @_on_ctx_stream
-    def separate_many_pcm16(self, clips, max_group=16, max_ratio=None, on_error='raise', ring=3, wait=True):
+    def separate_many_pcm16(self, clips, max_group=16, max_ratio=None, on_error='raise', ring=None, wait=True):
         """The batch-of-files path without host arithmetic: ``clips`` are the int16 frames of 16-bit PCM wav files exactly as
         ``scipy.io.wavfile.read`` returns them (``[L]`` mono or ``[L, channels]``; NumPy arrays or pinned torch CPU tensors, e.g.
         from :func:`deepconvsep_amd.wavio.read_pcm16`), the result a list of int16 arrays ``[S, L_i]`` -- the samples the
@@ -304,9 +304,10 @@ class Separator(object):
         (separate_dsd.py:285-287; iKala: L + R, separate_ikala.py:229) and the int16 conversion run on the device
         (``dcs_pcm16_to_float`` / ``dcs_pcm_to_int16``, float64 arithmetic like the scripts'): the values are those of
         ``separate_many(to_mono(read_wav(f)))`` + ``write_wav`` bit for bit, for a quarter of the PCIe bytes.  Grouping as in
-        :meth:`separate_many`.  The returned arrays are views of a ring
-        of ``ring`` pinned host buffers: they stay valid until ``ring - 1`` further calls have been made (copy them to keep
-        them longer); ``ring=0`` returns fresh arrays.
+        :meth:`separate_many`.  ``ring=0`` returns fresh arrays (the default with ``wait=True``: what :meth:`separate_many`
+        callers expect); ``ring=k`` > 0 returns views of a ring of ``k`` pinned host buffers that stay valid until ``k - 1``
+        further calls have been made (the default, 3, with ``wait=False`` -- the batch driver's writer threads stream the
+        samples to the files straight from pinned memory).  A different ``ring`` on a later call re-sizes the ring.
 
         ``wait=False`` returns as soon as the copies and kernels are enqueued: the result is a :class:`Pcm16Pending` whose
         ``result()`` waits for the device and hands out the list.  The caller's input buffers must stay untouched until then
@@ -356,8 +357,10 @@ class Separator(object):
         # one pinned output block per call, cut out of a small ring: the writer threads of the caller stream the int16
         # samples to the files straight from it
         total = sum(S * frames[i] for g in groups for i in g)
+        if ring is None:
+            ring = 0 if wait else 3
         if ring:
-            if not hasattr(self, "_pcm16_ring"):
+            if len(getattr(self, "_pcm16_ring", ())) != int(ring):       # first call, or the caller changed the ring length
                 self._pcm16_ring, self._pcm16_next = [None] * int(ring), 0
             slot = self._pcm16_next % len(self._pcm16_ring)
             self._pcm16_next += 1
@@ -372,7 +375,8 @@ class Separator(object):
         # clips cut out of ONE pinned staging block (the batch driver's read arena) travel as one host-to-device copy
         arena_dev, arena_lo = None, 0
         live = [i for g in groups for i in g]
-        try:
+        whole = None
+        try:                                            # storage introspection only: anything unusual means "no arena"
             bases = set(tens[i].untyped_storage().data_ptr() for i in live)
             if len(bases) == 1 and len(live) > 1 and all(tens[i].is_pinned() for i in live):
                 lo = min(tens[i].data_ptr() for i in live)
@@ -380,11 +384,12 @@ class Separator(object):
                 if hi - lo <= 2 * sum(tens[i].numel() * 2 for i in live) + 4096:       # the block is (nearly) all payload
                     st0 = tens[live[0]].untyped_storage()
                     whole = torch.empty(0, dtype=torch.uint8).set_(st0, lo - st0.data_ptr(), (hi - lo,))
-                    arena_dev = dtorch.empty((hi - lo,), dtype=torch.uint8, device=dev)
-                    arena_dev.copy_(whole, non_blocking=True)
                     arena_lo = lo
-        except Exception:
-            arena_dev = None
+        except (RuntimeError, AttributeError, TypeError):
+            whole = None
+        if whole is not None:                           # allocation / copy errors (out of memory ...) are the caller's to see
+            arena_dev = dtorch.empty((whole.numel(),), dtype=torch.uint8, device=dev)
+            arena_dev.copy_(whole, non_blocking=True)
         for idx in groups:
             lens = [frames[i] for i in idx]
             B, Lmax = len(idx), max(lens)

@@ -154,11 +154,14 @@ class transformFFT(Transforms):
         one download into pinned memory, from which the ``.data`` file is written directly -- ``[i, T, F]`` float64, the
         array the reference builds column by column."""
         import torch
+        if type(self).compute_file is not transformFFT.compute_file:
+            # a subclass with its own compute_file: the reference's compute_transform dispatches through it column by column
+            # (transform.py:107-121), so does the base class here -- the one-launch path would silently bypass it
+            return super(transformFFT, self).compute_transform(audio, out_path=out_path, phase=phase, save=save)
         self.out_path = out_path
         audio = np.asarray(audio)
-        if audio.ndim != 2:
-            raise IndexError("tuple index out of range")           # audio.shape[1] of a 1-D array (transform.py:107)
-        if audio.shape[1] == 0:
+        n_cols = audio.shape[1]                                    # a 1-D array fails here as it does at transform.py:107
+        if n_cols == 0:
             raise UnboundLocalError("local variable 'mags' referenced before assignment")    # the loop never runs (:107-121)
         plan = self._get_plan()
         ctx = plan.ctx

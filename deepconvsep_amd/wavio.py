@@ -33,7 +33,7 @@ def _find_data(fh):
         tag, size = ck[:4], struct.unpack("<I", ck[4:])[0]
         if tag == b"fmt ":
             fmt = fh.read(size)
-            if size < 16:
+            if size < 16 or len(fmt) < 16:               # a file that ends inside the fmt chunk: not plain PCM, as documented
                 return None
             code, channels, rate, _, align, bits = struct.unpack("<HHIIHH", fmt[:16])
             if code == _EXTENSIBLE and size >= 40 and fmt[24:40] == _PCM_SUBFORMAT:
@@ -107,14 +107,14 @@ def write_pcm16(path, rate, samples):
     head = header_pcm16(rate, samples.shape[0], channels)
     fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
     try:
-        if samples.size:
-            body = memoryview(samples.reshape(-1)).cast("B")
-            done = os.writev(fd, [head, body])
-            done -= len(head)
-            while done < len(body):                      # a short write (signal, quota): finish with plain writes
-                done += os.write(fd, body[done:])
-        else:
-            os.write(fd, head)
+        body = memoryview(samples.reshape(-1)).cast("B") if samples.size else memoryview(b"")
+        total = len(head) + len(body)
+        done = os.writev(fd, [head, body] if len(body) else [head])
+        while done < total:                              # a short write (signal, quota) may end inside the header as well:
+            if done < len(head):                         # one remaining-bytes counter over header + body, as the C writer does
+                done += os.write(fd, head[done:])
+            else:
+                done += os.write(fd, body[done - len(head):])
     finally:
         os.close(fd)
 
@@ -136,6 +136,18 @@ class WavBatch(object):
             self._res = self._finish()
             self._keep = self._finish = None
         return self._res
+
+    def __del__(self):
+        # a batch dropped without result() (fire-and-forget write): the native I/O threads still read the sample arrays and
+        # write status / rate / frames through the pointers in self._keep -- wait for them before those objects are freed
+        # (dcs_wav_batch_wait also releases the native batch object)
+        h = getattr(self, "_h", None)
+        if h is not None:
+            self._h = None
+            try:
+                self._lib.dcs_wav_batch_wait(h)
+            except Exception:
+                pass
 
 
 class WavPool(object):

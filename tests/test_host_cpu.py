@@ -74,6 +74,27 @@ def test_transform_object_keeps_reference_attributes():
     np.testing.assert_allclose(dcs.sinebell(8), np.sin(np.pi * np.arange(8) / 8.0))
 
 
+def test_compute_transform_dispatches_through_a_subclass_compute_file(tmp_path):
+    """transform.py:107-121: compute_transform calls self.compute_file once per column, so a subclass that customises
+    compute_file is honoured (the one-launch device path is only taken for transformFFT's own compute_file)."""
+    calls = []
+
+    class Mine(dcs.transformFFT):
+        def compute_file(self, audio, phase=False, sampleRate=44100):
+            calls.append(np.array(audio))
+            mag = np.full((3, 5), float(len(calls)))
+            return (mag, -mag) if phase else mag
+
+    tt = Mine(frameSize=8, hopSize=4, suffix='x')
+    audio = np.arange(12.0).reshape(6, 2)
+    mags, phs = tt.compute_transform(audio, phase=True, save=False)
+    assert len(calls) == 2 and np.array_equal(calls[1], audio[:, 1])
+    assert mags.shape == (2, 3, 5) and np.all(mags[1] == 2.0) and np.all(phs[0] == -1.0)
+    out = str(tmp_path / "song.data")
+    assert tt.compute_transform(audio, out_path=out, phase=False, save=True) is None
+    assert tt.shape == (2, 3, 5) and os.path.isfile(str(tmp_path / "song_x_m_.data"))
+
+
 def test_model_pickle_round_trip_py2_protocol(tmp_path):
     from deepconvsep_amd.synth import synth_params
     params = synth_params("dsd", 30, 33)
@@ -254,6 +275,40 @@ def test_wavio_reads_and_writes_what_scipy_does(tmp_path):
     with open(a, "wb") as fh:
         fh.write(b"RIFF\x00\x00\x00\x00WAVEjunk")
     assert wavio.read_pcm16(a) is None
+    # a file that ends inside its fmt chunk: None (the caller falls back to scipy), not struct.error
+    with open(a, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 100) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt[:9])
+    assert wavio.read_pcm16(a) is None and wavio.read_pcm16_into(a, np.zeros(64, np.uint8)) is None
+    # a short writev that ends INSIDE the 44-byte header: the rest of the header and the body still arrive
+    real_writev = os.writev
+    try:
+        os.writev = lambda fd, bufs: os.write(fd, bytes(bufs[0])[:17])
+        wavio.write_pcm16(b, 44100, x)
+    finally:
+        os.writev = real_writev
+    scipy.io.wavfile.write(a, 44100, x)
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_wav_batch_dropped_without_result_still_finishes(tmp_path):
+    """A WavBatch that is dropped without result() (fire-and-forget write) waits for the native I/O threads in its finalizer:
+    they read the sample arrays and write the status array the batch object keeps alive."""
+    import gc
+    import scipy.io.wavfile
+    from deepconvsep_amd import wavio
+    rs = np.random.RandomState(2)
+    paths = [str(tmp_path / ("ff%02d.wav" % i)) for i in range(24)]
+    want = []
+    with wavio.WavPool(3) as pool:
+        for rnd in range(4):
+            arrays = [rs.randint(-32768, 32768, (50000, 2)).astype(np.int16) for _ in paths]
+            want = [a.copy() for a in arrays]
+            pool.write(paths, [44100] * len(paths), arrays)      # the batch object and `arrays` die here
+            del arrays
+            gc.collect()
+    for p, x in zip(paths, want):
+        sr, y = scipy.io.wavfile.read(p)
+        assert sr == 44100 and np.array_equal(y, x), p
 
 
 def test_wav_pool_of_libdcs_reads_and_writes_what_scipy_does(tmp_path):
