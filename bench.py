@@ -182,7 +182,7 @@ def headline(line):
     r = line.get("roofline")
     if r:
         rr = _pick(r, ["bound", "kernel", "variant", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio",
-                       "algorithmic_bytes", "algorithmic_flops", "avg_kernel_ms", "launches", "tiles_per_launch"])
+                       "traffic_key_missing", "algorithmic_bytes", "algorithmic_flops", "avg_kernel_ms", "launches", "tiles_per_launch"])
         if len(str(rr.get("kernel", ""))) > 120:
             rr["kernel"] = str(rr["kernel"])[:117] + "..."
         if isinstance(r.get("issued"), dict):
@@ -197,8 +197,11 @@ def headline(line):
     else:
         h["cpu_baseline"] = None
     pc = line.get("parity_check")
-    h["parity_check"] = _pick(pc, ["ok", "max_abs_pcm_err", "tolerance", "network_output_max_err", "mask_bins",
+    h["parity_check"] = _pick(pc, ["ok", "max_abs_pcm_err", "tolerance", "network_output_max_err", "mask_criterion_ok", "mask_bins",
                                    "masked_bins_outside_1e4", "conditioned_fraction", "ranks"]) if pc else None
+    hs = line.get("hbm_stages")
+    if isinstance(hs, dict):        # {"stft": {frac, GBps, traffic_ratio}, "istft": {...}}: < 200 bytes
+        h["hbm_stages"] = {k: _pick(v, ["frac", "GBps", "traffic_ratio"]) for k, v in hs.items()}
     g = line.get("gather")
     if g:
         gg = _pick(g, ["mode", "impl", "payload_bytes_per_rank_per_group", "round_ms_without_gather",
@@ -262,7 +265,14 @@ def mask_bin_report(net, arch_name, params, tiles, conv):
             "conditioned_fraction": round(rec["conditioned_fraction"], 6),
             "max_err_where_conditioned": rec["max_err_where_conditioned"], "max_err": rec["max_err"],
             "network_output_max_err": float(np.max(np.abs(p_got[:, :S] - p_ref[:, :S]))),
-            "within_conditioning_bound": rec["within_conditioning_bound"], "zero_fraction_of_network_output": round(rec["zero_fraction_of_p"], 4)}
+            "within_conditioning_bound": rec["within_conditioning_bound"], "valid_magnitudes": rec["valid_magnitudes"],
+            "conditioned_bins_within_tol": rec["conditioned_bins_within_tol"],
+            "mask_consistent": rec["mask_consistent"], "mask_consistency_max_err": rec["mask_consistency_max_err"],
+            "unconditioned_bins": rec["unconditioned_bins"],
+            # the four-part criterion of oracle/maskcheck.py: what `ok` requires of the masks
+            "criterion_ok": bool(rec["within_conditioning_bound"] and rec["valid_magnitudes"] and
+                                 rec["conditioned_bins_within_tol"] and rec["mask_consistent"]),
+            "zero_fraction_of_network_output": round(rec["zero_fraction_of_p"], 4)}
 
 
 def main():
@@ -618,6 +628,8 @@ def main():
              "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
              "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
              "traffic_ratio": round(traffic / float(alg_bytes), 3) if traffic else None,
+             # no committed counter record of this kernel at this grid: said so instead of silently dropping the ratio
+             "traffic_key_missing": (None if rec else "%s@grid_threads=%d" % (kname, grid_threads)),
              "traffic_source": ("%s, record %s@grid_threads=%d (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                 "this launch shape, 2*FETCH+WRITE; not measured in this run)"
                                 % (TRAFFIC_FILE, kname, grid_threads)) if rec else None,
@@ -646,6 +658,7 @@ def main():
               "steps_per_round": k1, "rounds": len(single_rounds),
               "roofline": roof(n_tiles, final_ms1, final_launches1), "kernels_ms": kernels_ms,
               "kernels_ms_sum": round(sum(kernels_ms.values()), 5)}
+    hbm_stages = None
     launch_group = {"clips": groups[0], "tiles": groups[0] * n_tiles, "kernels_ms": group_ms,
                     "kernels_ms_sum": round(sum(group_ms.values()), 5)}
     # the two HBM-bound kernels of the group against 8 TB/s: algorithmic bytes per frame x the frames of the launch
@@ -670,6 +683,9 @@ def main():
                         "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": tr,
                         "traffic_ratio": round(tr / float(alg), 3) if tr else None, "traffic_record": key}
         launch_group["hbm_kernels"] = hbm
+        # north_star "rocprof reports achieved HBM GB/s on STFT/mask stages": the same numbers, compact, for the headline
+        hbm_stages = {t: {"frac": v["frac_of_hbm_peak"], "GBps": v["GBps"], "traffic_ratio": v["traffic_ratio"]}
+                      for t, v in hbm.items()}
 
     # ---- saturating regime (extra): same path, one long clip per launch, one stream
     saturating = None
@@ -841,7 +857,9 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             worst = float(tt.item())
         parity_check = {"max_abs_pcm_err": worst, "tolerance": 1e-4,
-                        "ok": bool(worst < 1e-4 and np.isfinite(worst) and bins["within_conditioning_bound"]),
+                        "ok": bool(worst < 1e-4 and np.isfinite(worst) and bins["criterion_ok"] and
+                                   bins["network_output_max_err"] < 1e-4),
+                        "mask_criterion_ok": bins["criterion_ok"],
                         "mask_bins": bins["mask_bins"], "masked_bins_outside_1e4": bins["masked_bins_outside_1e4"],
                         "conditioned_fraction": bins["conditioned_fraction"],
                         "network_output_max_err": bins["network_output_max_err"], "mask_bin_check": bins,
@@ -892,6 +910,8 @@ def main():
                        "parallelism": "tiles sharded by rank (dp%d)" % world},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_stream": single, "launch_group": launch_group,
             "saturating": saturating, "host_fed": host_fed, "legs": legs, "cli": cli,
+            # the two HBM-bound kernels of the launch group against 8 TB/s (algorithmic bytes of SURVEY 8d over HIP-event time)
+            "hbm_stages": hbm_stages,
         }
         if gather_check is not None:
             line["gather_check"] = gather_check
@@ -1383,7 +1403,9 @@ def run_leg(name, torch, dcs, _lib, ARCHS, TILER_LIBRARY, TILER_SCRIPT, synth_au
                 res["parity_check"].update(mask_bins=bins["mask_bins"], masked_bins_outside_1e4=bins["masked_bins_outside_1e4"],
                                            conditioned_fraction=bins["conditioned_fraction"],
                                            network_output_max_err=bins["network_output_max_err"], mask_bin_check=bins)
-                res["parity_check"]["ok"] = bool(res["parity_check"]["ok"] and bins["within_conditioning_bound"])
+                res["parity_check"]["mask_criterion_ok"] = bins["criterion_ok"]
+                res["parity_check"]["ok"] = bool(res["parity_check"]["ok"] and bins["criterion_ok"] and
+                                                 bins["network_output_max_err"] < 1e-4)
     del sep, a, out, params
     torch.cuda.empty_cache()
     return res

@@ -143,6 +143,17 @@ __global__ __launch_bounds__(kThreads) void conv1_reg_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// the pad columns [width, pitch) of `rows` rows of a row-major buffer: the dense layers read rows of `pitch` = width rounded
+// up to 4 floats, the producers write `width` (one thread per pad element: 1 - 3 per row.  A whole-buffer hipMemsetAsync in
+// front of the producers zero-filled 265 MB per Bach10 clip for 2 KB of pad: 27 us per launch, profiles/r05_u_*)
+__global__ __launch_bounds__(kThreads) void zero_pad_cols_kernel(float* __restrict__ buf, int64_t rows, int width, int pitch) {
+    const int npad = pitch - width;
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= rows * npad) return;
+    const int64_t r = idx / npad;
+    buf[r * pitch + width + (int)(idx - r * npad)] = 0.f;
+}
+
 // max-pool (1,pw), stride pw, ignore_border: rows of w1 -> rows of wp
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void pool_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -1749,7 +1760,9 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         tm.done();
     }
     // conv2 + both biases -> a2b[n][flat_p] (pad columns zeroed)
-    if (g->flat_p != d.flat) DCS_HIP(hipMemsetAsync(a2b, 0, (size_t)n * g->flat_p * 4, ctx->stream));
+    if (g->flat_p != d.flat)
+        hipLaunchKernelGGL(zero_pad_cols_kernel, dim3((unsigned)dcs_cdiv(n * (g->flat_p - d.flat), kThreads)), dim3(kThreads), 0,
+                           ctx->stream, a2b, n, d.flat, g->flat_p);
     {
         IgemmArgs a{};
         a.in = p1; a.in_n_stride = (int64_t)d.nf1 * planep; a.Cin = d.nf1; a.H = tc; a.W = d.wp;
@@ -1816,7 +1829,9 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC));
     }
     // per-source dense (rectify): D[n][branch][flat_p]; aliased branches (none in these graphs) would reuse a layer
-    if (g->flat_p != d.flat) DCS_HIP(hipMemsetAsync(D, 0, (size_t)n * NB * g->flat_p * 4, ctx->stream));
+    if (g->flat_p != d.flat)
+        hipLaunchKernelGGL(zero_pad_cols_kernel, dim3((unsigned)dcs_cdiv(n * NB * (g->flat_p - d.flat), kThreads)), dim3(kThreads), 0,
+                           ctx->stream, D, n * NB, d.flat, g->flat_p);
     // Will both InverseLayers run as ONE kernel (Bach10 graph with the f16 switch)?  Known before the dense layers run, and it
     // decides their output layout: the fused decoder reads a position's channels together, so D is written CHANNELS-LAST
     // ([branch][row][x][channel]) by packing the bf16 planes of the dense weights with permuted columns (DCS_DECODER_CL=0:

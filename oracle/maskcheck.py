@@ -13,10 +13,25 @@ D the reference denominator,
 
     |m_i' - m_i| = |e_i D - n_i E| / (D (D + E))  <=  (S + 1) d / (D - S d)          (|e_i| <= d, |E| <= S d, n_i <= D)
 
-so  |out_i' - out_i| <= mix * min(1, (S + 1) d / (D - S d))  (+ float32 rounding of the product).  Every bin must
-satisfy that bound, the output must be a valid masked magnitude (0 <= out <= mix), and wherever the bound is below
-the north-star tolerance the plain 1e-4 bar is asserted.  The number of bins whose error exceeds 1e-4 is counted and
-reported (``gpurun_out/mask_bins.txt``).
+so  |out_i' - out_i| <= mix * min(1, (S + 1) d / (D - S d))  (+ float32 rounding of the product).
+
+The criterion ("within 1e-4 per mask bin" stated so that a correct float32 kernel cannot fail it by chance, and an
+incorrect one cannot pass it):
+
+  1. every bin satisfies the conditioning bound above;
+  2. the output is a valid masked magnitude, 0 <= out <= mix;
+  3. wherever the bound is below the north-star tolerance, the plain 1e-4 bar holds;
+  4. MASK CONSISTENCY, on every bin, no conditioning involved: the kernel's masked output equals the REFERENCE's mask
+     expression evaluated (in float64) at the kernel's OWN network output, |out' - mix * m(p')| <= 4e-6 (1 + mix).  The
+     mask is a well-conditioned function of the numbers it is given (a sum of non-negative terms, one division); only
+     the comparison with the masks of a DIFFERENT network output (the float64 oracle's, 1e-6 away) is ill-conditioned.
+     Together with the network-output check of the callers (every bin of p' within 1e-4 of the oracle, measured 4e-6)
+     this says: the right function of a network output that is right to float32 accuracy.
+
+The number of bins whose error against the oracle's masks exceeds 1e-4 is counted and reported
+(``gpurun_out/mask_bins.txt``) together with the share of bins whose bound exceeds 1e-4 (``unconditioned_bins``: the
+only bins that can ever be counted) -- reported, not asserted: whether such a bin lands at 3.9e-5 or at 1.8e-4 depends on
+the last bit of p' (profiles/r05_w_*: two correct conv2 kernels, the more accurate one lost), not on correctness.
 """
 import os
 
@@ -47,6 +62,13 @@ def check_masked(got, ref, p_ref, p_got, mix, S, conv, tol=1e-4, label=None, rep
     over = worst > bound
     valid = bool(np.all(got >= 0.0) and np.all(got <= mix[None] * (1 + 1e-5) + 1e-12))
     meaningful = bound <= tol
+    # 4. mask consistency: the reference's mask expression at the kernel's own network output, float64
+    e = S * EPS_R if conv == 'A' else EPS_R
+    den_got = p_got.sum(axis=1) + e                           # [n, tc, F]
+    own = np.stack([(p_got[:, i] + (EPS_R if conv == 'A' else 0.0)) / den_got * mix for i in range(S)])
+    cons = np.abs(got - own)
+    cons_tol = 4e-6 * (1.0 + mix)
+    inconsistent = (cons > cons_tol[None]) if p_got is not p_ref else np.zeros(cons.shape, dtype=bool)
     if strict:
         assert not over.any(), "%s: %d bins exceed the mask-conditioning bound; worst excess %.3e" % (
             label, int(over.sum()), float((worst - bound).max()))
@@ -54,11 +76,15 @@ def check_masked(got, ref, p_ref, p_got, mix, S, conv, tol=1e-4, label=None, rep
         assert valid, label
         # 3. the plain north-star bar wherever the mask is conditioned well enough for it to be meaningful
         assert np.all(worst[meaningful] <= tol)
+        # 4. the masks are the reference's function of the kernel's own network output
+        assert not inconsistent.any(), "%s: %d bins differ from the mask of the kernel's own network output; worst %.3e" % (
+            label, int(inconsistent.sum()), float(cons.max()))
     outside = worst > tol
     rec = dict(label=label or "", bins=int(worst.size), network_output_max_err=d,
                within_conditioning_bound=bool(not over.any()), valid_magnitudes=valid,
                conditioned_bins_within_tol=bool(np.all(worst[meaningful] <= tol)),
-               bins_outside_1e4=int(outside.sum()),
+               bins_outside_1e4=int(outside.sum()), unconditioned_bins=int((~meaningful).sum()),
+               mask_consistent=bool(not inconsistent.any()), mask_consistency_max_err=float(cons.max()),
                outside_where_all_sources_below_1e5=int((outside & (p_ref.max(axis=1) < 1e-5)).sum()),
                max_err_where_conditioned=float(worst[meaningful].max()) if meaningful.any() else 0.0,
                conditioned_fraction=float(meaningful.mean()), max_err=float(worst.max()),
@@ -69,5 +95,6 @@ def check_masked(got, ref, p_ref, p_got, mix, S, conv, tol=1e-4, label=None, rep
             fh.write("%(label)s: %(bins)d bins, network output max|err| %(network_output_max_err).2e, p == 0 on "
                      "%(zero_fraction_of_p).3f; bins outside 1e-4: %(bins_outside_1e4)d (of which every source < 1e-5: "
                      "%(outside_where_all_sources_below_1e5)d); bound <= 1e-4 on %(conditioned_fraction).4f of the bins, "
-                     "max err there %(max_err_where_conditioned).2e; max err overall %(max_err).2e\n" % rec)
+                     "max err there %(max_err_where_conditioned).2e; max err overall %(max_err).2e; mask of the kernel's own "
+                     "network output: max |diff| %(mask_consistency_max_err).2e\n" % rec)
     return rec

@@ -47,6 +47,24 @@ def test_headline_is_compact_strict_json_with_the_contract_keys():
         assert big not in h
 
 
+def test_headline_carries_the_hbm_stage_fractions_and_says_when_a_traffic_record_is_missing():
+    """north_star "achieved HBM GB/s on STFT / mask stages": the STFT / iSTFT fractions of the 8 TB/s peak ride in the
+    driver-parsed line (< 200 bytes), and a roofline without a committed counter record of its grid says which key missed."""
+    full = _full()
+    full["hbm_stages"] = {"stft": {"frac": 0.2171, "GBps": 1736.9, "traffic_ratio": 1.587, "ms": 0.02},
+                          "istft": {"frac": 0.2927, "GBps": 2341.4, "traffic_ratio": None}}
+    full["roofline"]["traffic"] = None
+    full["roofline"]["traffic_ratio"] = None
+    full["roofline"]["traffic_key_missing"] = "final_bf16x3_kernel@grid_threads=552960"
+    text = bench.headline(full)
+    h = json.loads(text, parse_constant=_no_constants)
+    assert len(text.encode()) < bench.HEADLINE_LIMIT
+    assert h["hbm_stages"] == {"stft": {"frac": 0.2171, "GBps": 1736.9, "traffic_ratio": 1.587},
+                               "istft": {"frac": 0.2927, "GBps": 2341.4, "traffic_ratio": None}}
+    assert len(json.dumps(h["hbm_stages"])) < 200
+    assert h["roofline"]["traffic"] is None and h["roofline"]["traffic_key_missing"].startswith("final_bf16x3_kernel@")
+
+
 def test_headline_of_an_n_gpu_line_carries_the_gather_split_and_stays_small():
     full = _full()
     full.update(n_gpus=8, cpu_baseline=None, legs=None, cli=None, host_fed=None, saturating=None, gather_check="ok")
