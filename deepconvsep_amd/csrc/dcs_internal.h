@@ -225,10 +225,6 @@ struct DcsGemm {
     // optional (all-rows kernel only): A already split into three bf16 planes by dcs_gemm_split_a, [k tile][plane][aq_rows][4 pieces]
     // -- the workgroups then copy their k tile's pieces into LDS instead of each splitting all the rows again
     const void* Aq; int aq_rows;
-    // K split over workgroups with the hand-over of the one-batch kernels (gemm_ks.hip): the operand is the SUM of a_parts
-    // arrays a_part_stride floats apart (0 / 1: one array; the producer's slices, slice 0 carries its bias), and a sliced
-    // launch leaves its own raw sums in arrays c_part_stride floats apart
-    int a_parts; int64_t a_part_stride; int64_t c_part_stride;
 };
 
 // row r of a grouped operand: (r / gdiv) * gmul + r % gdiv.  Most launches have ONE group (gdiv = 2^30 > M): a 64-bit division
@@ -245,9 +241,7 @@ size_t dcs_gemm_bq_bytes(int K, int n_cols);
 // enqueued on the ctx stream; perm_c > 0: columns re-ordered from [channel perm_c][position perm_p] to [position][channel]
 int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d, int perm_c = 0, int perm_p = 0);
 bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g);
-// gemm_ks.hip (conv1 / conv2 of the DSD graph at launch-group sizes): K split over workgroups AND over the waves of a workgroup.
-int dcs_gemm_ks_slices(const DcsGemm& g);                      // output arrays the launch would leave (4), 0: not taken
-bool dcs_launch_gemm_ks(dcs_ctx* ctx, const DcsGemm& g, int* rc);   // false: not taken
+bool dcs_launch_gemm_ks(dcs_ctx* ctx, const DcsGemm& g);   // gemm_ks.hip: K split over the waves of a workgroup (>= 512 rows, B as planes); false: not taken
 struct DcsGemmBranches {         // (B planes, bias, C) of up to 4 GEMMs that share A and shape
     int n;
     const void* Bq[4];

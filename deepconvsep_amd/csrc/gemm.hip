@@ -59,8 +59,6 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
     const int gK = g.K, gldb = g.ldb;
     const int64_t gM = g.M;
     const float gscale = g.a_scale;
-    const int a_parts = g.a_parts > 1 ? g.a_parts : 1;   // the operand as the sum of a producer's K slices (gemm_ks.hip)
-    const int64_t a_pstride = g.a_part_stride;
 
     // per-thread A source rows
     const float* a_ptr[A_PER];
@@ -99,11 +97,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                              \
             if (a_ok[u]) {                                                                    \
                 if (VEC) {                                                                    \
-                    if (k < gK) {                                                             \
-                        v = *reinterpret_cast<const f32x4*>(a_ptr[u] + k);                    \
-                        for (int p_ = 1; p_ < a_parts; ++p_)                                  \
-                            v += *reinterpret_cast<const f32x4*>(a_ptr[u] + p_ * a_pstride + k); \
-                    }                                                                         \
+                    if (k < gK) v = *reinterpret_cast<const f32x4*>(a_ptr[u] + k);            \
                 } else {                                                                      \
                     if (k + 0 < gK) v[0] = a_ptr[u][k + 0];                                   \
                     if (k + 1 < gK) v[1] = a_ptr[u][k + 1];                                   \
@@ -234,8 +228,6 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
     const int n0 = blockIdx.y * 16;
     const int gK = g.K, gldb = g.ldb;
     const float gscale = g.a_scale;
-    const int a_parts = g.a_parts > 1 ? g.a_parts : 1;   // the operand as the sum of a producer's K slices (gemm_ks.hip)
-    const int64_t a_pstride = g.a_part_stride;
     const int64_t r = m0 + fi;
     const bool row_ok = r < g.M;
     const int64_t rr = row_ok ? r : 0;
@@ -249,8 +241,6 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
         const int k = (kc_) + 16 * j;                                                             \
         A_[j] = (row_ok && k + 4 * kq < gK) ? *reinterpret_cast<const f32x4*>(a_ptr + k)          \
                                             : f32x4{0.f, 0.f, 0.f, 0.f};                          \
-        for (int p_ = 1; p_ < a_parts; ++p_)                                                      \
-            if (row_ok && k + 4 * kq < gK) A_[j] += *reinterpret_cast<const f32x4*>(a_ptr + p_ * a_pstride + k); \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) B_[4 * j + e] = b_ptr[(int64_t)(k + e) * gldb]; \
     }
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -347,16 +337,12 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     if (g.n_cols % BN) DCS_FAIL(DCS_EINVAL, "gemm_rows: n_cols %d not a multiple of %d", g.n_cols, BN);
     if (g.a_vec && ((g.K & 3) || (g.lda & 3))) DCS_FAIL(DCS_EINVAL, "gemm_rows: vector path needs K, lda %% 4 == 0");
     DcsTimer tm(ctx, tag);
-    int ks_rc = DCS_OK;
-    if (dcs_launch_gemm_ks(ctx, g, &ks_rc)) {   // conv1 / conv2 of the DSD encoder at launch-group sizes (gemm_ks.hip)
+    if (dcs_launch_gemm_ks(ctx, g)) {   // launch-group sizes of the DSD encoder: the chain-cutting kernel of gemm_ks.hip
         tm.done();
-        DCS_CHECK(ks_rc);
         DCS_HIP(hipGetLastError());
         return DCS_OK;
     }
-    if (g.c_part_stride > 0 && dcs_gemm_ks_slices(g) > 1) DCS_FAIL(DCS_EINVAL, "gemm_rows: sliced output asked for, launch not taken");
-    if (g.a_parts > 1 && !g.a_vec) DCS_FAIL(DCS_EINVAL, "gemm_rows: a sliced operand needs the vector path");
-    if (!g.a_rowmap && g.a_parts <= 1 && dcs_launch_gemm_bf16x3(ctx, g)) {   // B available as bf16 planes and the launch fills the chip
+    if (!g.a_rowmap && dcs_launch_gemm_bf16x3(ctx, g)) {   // B available as bf16 planes and the launch fills the chip
         tm.done();
         DCS_HIP(hipGetLastError());
         return DCS_OK;
@@ -368,7 +354,7 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     // workgroups streaming 170 MB of weights at 0.24 TB/s -> also split K over workgroups, two passes
     static const int ks_env = getenv("DCS_GEMM_KSPLIT") ? atoi(getenv("DCS_GEMM_KSPLIT")) : -1;   // 0 disables
     const int64_t tiles16 = groups16 * (g.n_cols / 16);
-    if (g.a_vec && ks_env != 0 && g.K >= 16384 && g.a_parts <= 1 && tiles16 < 4 * (int64_t)ctx->n_cu) {
+    if (g.a_vec && ks_env != 0 && g.K >= 16384 && tiles16 < 4 * (int64_t)ctx->n_cu) {
         if (ks_env < 0 && dcs_launch_gemm_bf16x3_longk(ctx, g)) {   // 128 .. 176 rows and B as bf16 planes: the matrix pipe's K-split
             tm.done();
             DCS_HIP(hipGetLastError());

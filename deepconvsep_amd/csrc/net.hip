@@ -101,7 +101,7 @@ struct dcs_model {
     uint16_t* Bpk = nullptr;
     uint16_t* Bw2q = nullptr;
     void* Bdq = nullptr;   // per-source dense weights as bf16 planes (gemm_bf16x3.hip)
-    void *B1q = nullptr, *B2q = nullptr;   // conv1 / conv2 weights as bf16 planes (gemm_ks.hip, launch groups)
+    void *B1q = nullptr, *B2q = nullptr, *Bfcq = nullptr;   // conv1 / conv2 / bottleneck weights as bf16 planes (gemm_ks.hip, launch groups)
     // one-batch ("latency") kernels, dsd_lat.hip: the GEMM B operands in MFMA fragment order, the transposed-conv2
     // weights likewise; lat_stages = -1: automatic (all stages for one clip of at most lat_max_frames frames)
     float *L1p = nullptr, *L2p = nullptr, *Lfcp = nullptr, *Ldp = nullptr, *Lw2p = nullptr;
@@ -266,11 +266,13 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
         const int rows = (int)dcs_round_up(m->hid64, 128);
         DCS_HIP(hipMalloc(&m->Bdq, dcs_gemm_bq_bytes(rows, m->nd64)));
         DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->Bd, rows, m->nd64, m->nd64, m->Bdq));
-        // conv1 / conv2 likewise (0.7 MB): launches of >= 512 rows split K over workgroups and waves (gemm_ks.hip)
+        // the encoder's weights likewise (0.9 MB): launches of >= 512 rows split K over the waves of a workgroup (gemm_ks.hip)
         DCS_HIP(hipMalloc(&m->B1q, dcs_gemm_bq_bytes(m->K1, 64)));
         DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->B1, m->K1, 64, 64, m->B1q));
         DCS_HIP(hipMalloc(&m->B2q, dcs_gemm_bq_bytes(kh * CI, 64)));
         DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->B2, kh * CI, 64, 64, m->B2q));
+        DCS_HIP(hipMalloc(&m->Bfcq, dcs_gemm_bq_bytes(d.h2 * CP, m->hid64)));
+        DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->Bfc, d.h2 * CP, m->hid64, m->hid64, m->Bfcq));
     }
     if (C == 1) {
         // bf16x3 variant of the final kernel: Bpk[bin][plane 3][K block 2][lane group 4][8 channels], channel
@@ -349,7 +351,7 @@ struct DsdScratch {
 int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, float a_scale, int64_t n,
                int64_t tile_row_stride /* st or tc */, bool shared_frames, const DsdScratch& w, int64_t n_clips = 1,
                int64_t clip_pitch = 0, unsigned lat = 0, int64_t rows_total = 0, int64_t tiles_total = 0,
-               const int* rowmap = nullptr, bool slice_ok = false /* H1 / C2 were carved with room for 4 K slices */) {
+               const int* rowmap = nullptr) {
     const Dims& d = m->d;
     const int tc = m->tc, CI = m->CI, CP = m->CP;
     const int64_t BIG = (int64_t)1 << 40;
@@ -372,11 +374,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g1.B = m->B1; g1.ldb = 64; g1.bias = m->bias1;
     g1.C = w.H1; g1.ldc = CI; g1.c_gdiv = 1 << 30; g1.c_gmul = 0;
     g1.M = n_rows1; g1.n_cols = 64; g1.n_store = CI; g1.K = a_vec ? m->K1 : m->F; g1.relu = 0; g1.a_vec = a_vec;
-    // launch-group sizes: K split over workgroups (gemm_ks.hip) -- conv1 leaves four arrays of raw sums, conv2 adds them while it
-    // loads and leaves four of its own, the bottleneck layer adds those
-    g1.Bq = (a_vec && slice_ok && !lat) ? m->B1q : nullptr;
-    const int nz1 = dcs_gemm_ks_slices(g1);
-    if (nz1 > 1) g1.c_part_stride = n_rows1 * CI; else g1.Bq = nullptr;
+    g1.Bq = a_vec ? m->B1q : nullptr;       // (the planes are packed for K1 rows; taken by launches of >= 512 rows only, gemm_ks.hip)
     (void)BIG;
     if (lat & DCS_LAT_CONV1) {
         DcsLatGemm q{};
@@ -395,11 +393,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     else { g2.a_gdiv = d.h2; g2.a_gmul = tc; g2.M = n * d.h2; }
     g2.B = m->B2; g2.ldb = 64; g2.bias = m->bias2;
     g2.C = w.C2; g2.ldc = CP; g2.c_gdiv = 1 << 30; g2.c_gmul = 0;
-    g2.n_cols = 64; g2.n_store = CP; g2.K = d.kh2 * CI; g2.relu = 0; g2.a_vec = 1;
-    if (nz1 > 1) { g2.a_parts = nz1; g2.a_part_stride = n_rows1 * CI; }
-    g2.Bq = (slice_ok && !lat) ? m->B2q : nullptr;
-    const int nz2 = dcs_gemm_ks_slices(g2);
-    if (nz2 > 1) g2.c_part_stride = g2.M * CP; else g2.Bq = nullptr;
+    g2.n_cols = 64; g2.n_store = CP; g2.K = d.kh2 * CI; g2.relu = 0; g2.a_vec = 1; g2.Bq = m->B2q;
     if (lat & DCS_LAT_CONV2) {
         DcsLatGemm q{};   // the A row of position p is kh consecutive H1 rows = kh * CI contiguous floats: one slice per tap
         q.A = w.H1; q.a_row_stride = CI; q.a_scale = 1.f; q.Bp = m->L2p; q.bias = m->bias2;
@@ -417,8 +411,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     if (ragged) g3.a_rowmap = rowmap;
     g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc;
     g3.C = w.Z; g3.ldc = m->hid64; g3.c_gdiv = 1 << 30; g3.c_gmul = 0;
-    g3.M = n_tiles_all; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
-    if (nz2 > 1) { g3.a_parts = nz2; g3.a_part_stride = g2.M * CP; }
+    g3.M = n_tiles_all; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1; g3.Bq = m->Bfcq;
     if (lat & DCS_LAT_FC) {
         DcsLatGemm q{};   // the A row of tile k is h2 consecutive C2 rows from row k * st: one slice per row
         q.A = w.C2; q.a_row_stride = tile_row_stride * (int64_t)CP; q.a_scale = 1.f; q.Bp = m->Lfcp; q.bias = m->biasfc;
@@ -577,6 +570,7 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     if (m->Bdq) (void)hipFree(m->Bdq);
     if (m->B1q) (void)hipFree(m->B1q);
     if (m->B2q) (void)hipFree(m->B2q);
+    if (m->Bfcq) (void)hipFree(m->Bfcq);
     delete m;
     return DCS_OK;
 }
@@ -768,7 +762,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
         unsigned lat = dsd_lat_mask(m, plan, T, n_clips, clip_tab_d != nullptr, ov, eps_mode);
         const bool split = (lat & DCS_LAT_FINAL) || (m->Bpk && dsd_final_bf16x3(m->ctx, T, F, n_clips, m->CI, eps_mode));
         const size_t b_fr = (lat & DCS_LAT_ISTFT) && pcm_d ? align256(dcs_lat_istft_scratch_bytes(plan, T, S)) : 0;
-        const int parts = 4;     // the one-batch GEMMs and the K-sliced conv1 / conv2 of launch groups (gemm_ks.hip) hand over 4 arrays
+        const int parts = lat ? 4 : 1;
         DCS_CHECK(m->ws.ensure(b_mag + b_unit + b_ph + b_sep + b_fr + dsd_scratch_bytes(m, n_all, rows1, rows2, split, parts)));
         char* p = (char*)m->ws.ptr;
         float* frames = (float*)p; p += b_fr;
@@ -784,7 +778,7 @@ static int separate_impl(dcs_model* m, dcs_stft* plan, const float* audio_d, int
             DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio_d, L, audio_stride, n_clips, mag, phase, unit, ld, Trows, T,
                                                         false, clip_tab_d));
         DCS_CHECK(dsd_encode(m, mag, ld, true, scale, n, st, true, w, n_clips, Trows, lat, ragged_compact ? rows_sum : 0,
-                             ragged_compact ? tiles_sum : 0, ragged_compact ? rowmap_d : nullptr, /*slice_ok=*/true));
+                             ragged_compact ? tiles_sum : 0, ragged_compact ? rowmap_d : nullptr));
         DCS_CHECK(ensure_rise(m, ov));
         DsdFinalArgs a{};
         a.G = w.G; a.Bw = m->Bfin; a.ldb = m->Fpad; a.bias = m->bout;
