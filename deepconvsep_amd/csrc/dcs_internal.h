@@ -241,7 +241,6 @@ size_t dcs_gemm_bq_bytes(int K, int n_cols);
 // enqueued on the ctx stream; perm_c > 0: columns re-ordered from [channel perm_c][position perm_p] to [position][channel]
 int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d, int perm_c = 0, int perm_p = 0);
 bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g);
-bool dcs_launch_gemm_ks(dcs_ctx* ctx, const DcsGemm& g);   // gemm_ks.hip: K split over the waves of a workgroup (>= 512 rows, B as planes); false: not taken
 struct DcsGemmBranches {         // (B planes, bias, C) of up to 4 GEMMs that share A and shape
     int n;
     const void* Bq[4];

@@ -337,11 +337,6 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     if (g.n_cols % BN) DCS_FAIL(DCS_EINVAL, "gemm_rows: n_cols %d not a multiple of %d", g.n_cols, BN);
     if (g.a_vec && ((g.K & 3) || (g.lda & 3))) DCS_FAIL(DCS_EINVAL, "gemm_rows: vector path needs K, lda %% 4 == 0");
     DcsTimer tm(ctx, tag);
-    if (dcs_launch_gemm_ks(ctx, g)) {   // launch-group sizes of the DSD encoder: the chain-cutting kernel of gemm_ks.hip
-        tm.done();
-        DCS_HIP(hipGetLastError());
-        return DCS_OK;
-    }
     if (!g.a_rowmap && dcs_launch_gemm_bf16x3(ctx, g)) {   // B available as bf16 planes and the launch fills the chip
         tm.done();
         DCS_HIP(hipGetLastError());

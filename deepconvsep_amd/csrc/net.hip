@@ -101,7 +101,6 @@ struct dcs_model {
     uint16_t* Bpk = nullptr;
     uint16_t* Bw2q = nullptr;
     void* Bdq = nullptr;   // per-source dense weights as bf16 planes (gemm_bf16x3.hip)
-    void *B1q = nullptr, *B2q = nullptr, *Bfcq = nullptr;   // conv1 / conv2 / bottleneck weights as bf16 planes (gemm_ks.hip, launch groups)
     // one-batch ("latency") kernels, dsd_lat.hip: the GEMM B operands in MFMA fragment order, the transposed-conv2
     // weights likewise; lat_stages = -1: automatic (all stages for one clip of at most lat_max_frames frames)
     float *L1p = nullptr, *L2p = nullptr, *Lfcp = nullptr, *Ldp = nullptr, *Lw2p = nullptr;
@@ -266,13 +265,6 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
         const int rows = (int)dcs_round_up(m->hid64, 128);
         DCS_HIP(hipMalloc(&m->Bdq, dcs_gemm_bq_bytes(rows, m->nd64)));
         DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->Bd, rows, m->nd64, m->nd64, m->Bdq));
-        // the encoder's weights likewise (0.9 MB): launches of >= 512 rows split K over the waves of a workgroup (gemm_ks.hip)
-        DCS_HIP(hipMalloc(&m->B1q, dcs_gemm_bq_bytes(m->K1, 64)));
-        DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->B1, m->K1, 64, 64, m->B1q));
-        DCS_HIP(hipMalloc(&m->B2q, dcs_gemm_bq_bytes(kh * CI, 64)));
-        DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->B2, kh * CI, 64, 64, m->B2q));
-        DCS_HIP(hipMalloc(&m->Bfcq, dcs_gemm_bq_bytes(d.h2 * CP, m->hid64)));
-        DCS_CHECK(dcs_gemm_pack_bq(m->ctx, m->Bfc, d.h2 * CP, m->hid64, m->hid64, m->Bfcq));
     }
     if (C == 1) {
         // bf16x3 variant of the final kernel: Bpk[bin][plane 3][K block 2][lane group 4][8 channels], channel
@@ -374,7 +366,6 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g1.B = m->B1; g1.ldb = 64; g1.bias = m->bias1;
     g1.C = w.H1; g1.ldc = CI; g1.c_gdiv = 1 << 30; g1.c_gmul = 0;
     g1.M = n_rows1; g1.n_cols = 64; g1.n_store = CI; g1.K = a_vec ? m->K1 : m->F; g1.relu = 0; g1.a_vec = a_vec;
-    g1.Bq = a_vec ? m->B1q : nullptr;       // (the planes are packed for K1 rows; taken by launches of >= 512 rows only, gemm_ks.hip)
     (void)BIG;
     if (lat & DCS_LAT_CONV1) {
         DcsLatGemm q{};
@@ -393,7 +384,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     else { g2.a_gdiv = d.h2; g2.a_gmul = tc; g2.M = n * d.h2; }
     g2.B = m->B2; g2.ldb = 64; g2.bias = m->bias2;
     g2.C = w.C2; g2.ldc = CP; g2.c_gdiv = 1 << 30; g2.c_gmul = 0;
-    g2.n_cols = 64; g2.n_store = CP; g2.K = d.kh2 * CI; g2.relu = 0; g2.a_vec = 1; g2.Bq = m->B2q;
+    g2.n_cols = 64; g2.n_store = CP; g2.K = d.kh2 * CI; g2.relu = 0; g2.a_vec = 1;
     if (lat & DCS_LAT_CONV2) {
         DcsLatGemm q{};   // the A row of position p is kh consecutive H1 rows = kh * CI contiguous floats: one slice per tap
         q.A = w.H1; q.a_row_stride = CI; q.a_scale = 1.f; q.Bp = m->L2p; q.bias = m->bias2;
@@ -411,7 +402,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     if (ragged) g3.a_rowmap = rowmap;
     g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc;
     g3.C = w.Z; g3.ldc = m->hid64; g3.c_gdiv = 1 << 30; g3.c_gmul = 0;
-    g3.M = n_tiles_all; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1; g3.Bq = m->Bfcq;
+    g3.M = n_tiles_all; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
     if (lat & DCS_LAT_FC) {
         DcsLatGemm q{};   // the A row of tile k is h2 consecutive C2 rows from row k * st: one slice per row
         q.A = w.C2; q.a_row_stride = tile_row_stride * (int64_t)CP; q.a_scale = 1.f; q.Bp = m->Lfcp; q.bias = m->biasfc;
@@ -568,9 +559,6 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     if (m->Bpk) (void)hipFree(m->Bpk);
     if (m->Bw2q) (void)hipFree(m->Bw2q);
     if (m->Bdq) (void)hipFree(m->Bdq);
-    if (m->B1q) (void)hipFree(m->B1q);
-    if (m->B2q) (void)hipFree(m->B2q);
-    if (m->Bfcq) (void)hipFree(m->Bfcq);
     delete m;
     return DCS_OK;
 }
