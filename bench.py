@@ -204,7 +204,7 @@ def headline(line):
         h["hbm_stages"] = {k: _pick(v, ["frac", "GBps", "traffic_ratio"]) for k, v in hs.items()}
     g = line.get("gather")
     if g:
-        gg = _pick(g, ["mode", "impl", "payload_bytes_per_rank_per_group", "round_ms_without_gather",
+        gg = _pick(g, ["mode", "impl", "payload_bytes_per_rank_per_group", "pipelined_half_groups", "round_ms_without_gather",
                        "round_ms_with_gather", "ms_per_group_collective_alone"])
         gg["impl"] = str(gg.get("impl", ""))[:60]
         h["gather"] = gg
@@ -295,10 +295,13 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive extra leg")
     ap.add_argument("--no-cli", action="store_true", help="skip the command-line leg (separate_dsd.py on one wav, separate_batch.py on 50)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the timed launches' output")
-    ap.add_argument("--gather", choices=["allgather", "root", "none"], default="allgather",
+    ap.add_argument("--gather", choices=["allgather", "root", "none"], default="root",
                     help="N > 1: the collective that carries every launch group's int16 PCM inside the timed region: "
-                         "all_gather_into_tensor (every rank gets everything), gather to rank 0 (north_star: 'final gather'), "
-                         "or none (replicas: every rank keeps its own output)")
+                         "gather to rank 0 (the default; north_star: 'final gather' -- only a writer needs the samples), "
+                         "all_gather_into_tensor (every rank gets everything), or none (replicas: every rank keeps its own output)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N > 1 with a round of ONE launch group (the driver's --steps 20): keep it one group (compute, then the "
+                         "collective, on one stream) instead of two half-groups whose collective rides under the other's compute")
     ap.add_argument("--gather-impl", choices=["torch", "dcs"], default="torch",
                     help="who issues the collective: torch.distributed (backend nccl = RCCL), or libdcs's own C-ABI entry "
                          "dcs_gather on an RCCL communicator per HIP stream (deepconvsep_amd.dist.RcclComm)")
@@ -371,6 +374,12 @@ def main():
     frames_per_step = (n_tiles - 1) * (TC - OV) + TC        # unique frames fully separated
     NS = max(1, args.streams)
     groups = split_groups(K, max(1, args.clips_per_launch), NS)
+    # N > 1 and a round of ONE launch group: compute -> int16 -> collective on one stream is serial by construction (the
+    # collective of 20 steps is as long as their compute at N = 8).  Two half-groups on two lanes instead:
+    # B's kernels are ordered behind A's kernels (an event, not a synchronisation), so A's collective rides under B's compute.
+    pipelined = bool(gathering and len(groups) == 1 and K >= 2 and NS >= 2 and args.gather != "none" and not args.no_pipeline)
+    if pipelined:
+        groups = [K - K // 2, K // 2]
     CPL = max(groups)                                        # buffers are sized for the largest group
 
     gather_mode = [args.gather]                              # a list: the gather split below switches it off and on again
@@ -407,9 +416,13 @@ def main():
                                          ctypes.c_void_p(self.pcm.data_ptr()), None, None)
             self._bound = {}
             self.launched_tiles = 0
+            self.compute_done = torch.cuda.Event()
 
-        def step(self, nclips):
-            """One launch group = nclips steps (independent 32-tile batches)."""
+        def step(self, nclips, after=None):
+            """One launch group = nclips steps (independent 32-tile batches).  `after`: an event of another lane this
+            group's kernels are ordered behind (the pipelined N > 1 schedule)."""
+            if after is not None:
+                self.stream.wait_event(after)
             a = self._bound.get(nclips)
             if a is None:
                 a = self._bound[nclips] = self._args(nclips)
@@ -417,6 +430,8 @@ def main():
             if rc:
                 _lib.check(rc)
             self.launched_tiles += nclips * n_tiles
+            if pipelined:
+                self.compute_done.record(self.stream)        # the kernels of this group are enqueued; its collective is not
             if gathering and gather_mode[0] != "none":
                 rc = self._to16(self.ctx._h, ctypes.c_void_p(self.pcm.data_ptr()), nclips * 4 * L,
                                 ctypes.c_void_p(self.pcm16.data_ptr()))
@@ -455,8 +470,11 @@ def main():
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        prev = None
         for i, g in enumerate(group_sizes):
-            use[i % len(use)].step(g)
+            ln = use[i % len(use)]
+            ln.step(g, after=prev.compute_done if (pipelined and prev is not None and prev is not ln) else None)
+            prev = ln
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
@@ -531,6 +549,7 @@ def main():
         gather_split = {"mode": saved, "impl": ("dcs_gather (C ABI, RCCL communicator per HIP stream)" if args.gather_impl == "dcs"
                                                 else "torch.distributed (%s)" % dist.get_backend()),
                         "payload_bytes_per_rank_per_group": int(groups[0] * 4 * L * 2),
+                        "pipelined_half_groups": bool(pipelined),
                         "round_ms_without_gather": round(no_g * 1e3, 4), "round_ms_with_gather": round(med * 1e3, 4),
                         "ms_per_group_collective_alone": round(alone * 1e3, 4) if alone is not None else None,
                         "note": "rounds of the same K steps with the collective switched off, and the collective alone for one "
@@ -903,7 +922,9 @@ def main():
                                    "HIP streams per GPU%s; a round = exactly %d steps between barrier+synchronize, "
                                    "median of %d rounds"
                                    % (N, n_tiles, L / SR, K, "/".join(str(g) for g in sorted(set(groups), reverse=True)),
-                                      NS, ", int16 PCM all-gathered over RCCL" if world > 1 else "", K, len(round_s)),
+                                      NS, (", int16 PCM %s over RCCL%s" % ({"root": "gathered to rank 0", "allgather": "all-gathered", "none": "kept per rank"}[args.gather],
+                                                                             ", two half-groups pipelined (collective of one under the compute of the other)" if pipelined else ""))
+                                      if world > 1 else "", K, len(round_s)),
                        "tiles_per_gpu_per_step": n_tiles, "frames_per_gpu_per_step": frames_per_step,
                        "frame_size": N, "bins": F, "launch_groups_per_round": groups, "streams_per_gpu": NS,
                        "weights": "synthetic Glorot-uniform, seed 2, 15-array DSD .pkl layout",

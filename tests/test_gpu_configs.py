@@ -306,7 +306,7 @@ def test_bench_two_ranks_on_this_gpu_gather_is_exact():
     env = dict(os.environ, DCS_BENCH_SAME_DEVICE="1", DCS_BENCH_CHECK_GATHER="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
-           "--warmup", "2", "--sat-tiles", "0", "--min-time", "0.02", "--legs", ""]
+           "--warmup", "2", "--sat-tiles", "0", "--min-time", "0.02", "--legs", "", "--gather", "allgather"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -314,6 +314,8 @@ def test_bench_two_ranks_on_this_gpu_gather_is_exact():
     assert line["gather_check"] == "ok"
     assert line["scaling"] == "weak" and line["cpu_baseline"] is None
     assert line["gather"]["mode"] == "allgather" and line["gather"]["ms_per_group_collective_alone"] > 0
+    # a round of ONE launch group with N > 1 goes out as two half-groups, B's kernels ordered behind A's (round 6)
+    assert line["gather"]["pipelined_half_groups"] is True and line["config"]["launch_groups_per_round"] == [3, 3]
     assert line["parity_check"]["ok"] is True
 
 
@@ -478,13 +480,18 @@ def _run_bench(n, extra, env_extra, timeout=900):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("impl,mode", [("dcs", "allgather"), ("dcs", "root"), ("torch", "allgather")])
+@pytest.mark.parametrize("impl,mode", [("dcs", "allgather"), ("dcs", "root"), ("torch", "allgather"), ("dcs", "root-serial")])
 def test_bench_gather_code_path_with_a_world_of_one_rank(impl, mode):
     """What a 1-GPU box can run of the N > 1 leg on the REAL backend: DCS_BENCH_FORCE_GATHER makes bench.py --gpus 1 convert
     every launch group's PCM to int16 and push it through the collective of a one-rank world -- with --gather-impl dcs that is
     dcs_gather (the C-ABI entry of SURVEY 8b) on an RCCL communicator per HIP stream, inside the timed region."""
-    line = _run_bench(1, ["--gather", mode, "--gather-impl", impl], {"DCS_BENCH_FORCE_GATHER": "1", "DCS_BENCH_CHECK_GATHER": "1"})
+    serial = mode.endswith("-serial")                   # --no-pipeline: the one-group, one-stream schedule of rounds 2 - 5
+    mode = mode.split("-")[0]
+    line = _run_bench(1, ["--gather", mode, "--gather-impl", impl] + (["--no-pipeline"] if serial else []),
+                      {"DCS_BENCH_FORCE_GATHER": "1", "DCS_BENCH_CHECK_GATHER": "1"})
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["gather_check"] == "ok"
+    assert line["gather"]["pipelined_half_groups"] is (not serial)
+    assert line["config"]["launch_groups_per_round"] == ([6] if serial else [3, 3])
     assert line["gather"]["mode"] == mode and line["gather"]["impl"].startswith("dcs_gather" if impl == "dcs" else "torch.distributed")
     assert line["gather"]["ms_per_group_collective_alone"] > 0
     assert line["parity_check"]["ok"] is True
