@@ -5,7 +5,7 @@ set -euo pipefail
 SELF=$(readlink -f "$0")
 cd "$(dirname "$SELF")"
 OUT=../libdcs.so
-SRCS="api.hip dsd_lat.hip fft.hip fft_wave.hip tiling.hip gemm.hip gemm_bf16x3.hip colconv_wreg.hip colconv_x3.hip colconv_fwd_x3.hip slabconv_ps.hip conv1_mfma.hip deconv1_mfma.hip dsd.hip dsd_bf16x3.hip generic.hip net.hip score.hip gather.hip wavio.hip"
+SRCS="api.hip dsd_lat.hip fft.hip fft_wave.hip tiling.hip gemm.hip gemm_bf16x3.hip gemm_f16.hip colconv_wreg.hip colconv_x3.hip colconv_fwd_x3.hip slabconv_ps.hip conv1_mfma.hip deconv1_mfma.hip dsd.hip dsd_bf16x3.hip generic.hip net.hip score.hip gather.hip wavio.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden"
 mkdir -p build
 newest_header=$(ls -t *.h ../../include/*.h | head -1)

@@ -299,9 +299,13 @@ struct DcsDecoderFused {
 // instruction operand split per row -- 500 instead of 800 MFMAs and ~1 500 fewer vector instructions per column block.
 // BASELINE configs[3] names an "fp16 MFMA conv path"; its stated tolerance (network output 2e-3) is unchanged, the
 // f32-class result of this graph is the path with the switch off.
-template <int KH, int H, bool CL, bool S2H>
+// IN16 (round 6): the input arrives as f16, channels-last with the channel axis padded to 32 (gemm_f16.hip writes it so under the
+// f16 switch): in[image][row][x][32] halves, a lane's eight channels ONE 16-byte load and no conversion -- half the bytes of
+// the f32 input it replaces, which this kernel rounded to f16 on arrival anyway.  g.in / g.in_n_stride are then in halves.
+template <int KH, int H, bool CL, bool S2H, bool IN16 = false>
 __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
                                                                          const DcsDecoderFused d) {
+    static_assert(!IN16 || (CL && S2H), "the f16 input is channels-last and feeds the all-f16 kernel");
     constexpr int HO = H + KH - 1, PH = KH - 1;
     static_assert(HO % 2 == 0, "output rows are processed in pairs");
     // per wave: Pb [2 rows][8 taps mm][32 slots] float4 -- slot 8 + x holds P[x][mm], slots 0..7 and 24..31 stay zero --
@@ -337,7 +341,8 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
     // read side: lanes 0..31 sum row 0 of a pair, lanes 32..63 row 1; lane & 31 = q - 16 b (0..22 are real)
     const int rt = lane >> 5, rq = lane & 31;
     const f32x4* pr = Pb + rt * 256 + (rq < 23 ? rq : 22) + 8;
-    float raw[H][8];
+    float raw[IN16 ? 1 : H][8];
+    u32x4 rawh[IN16 ? H : 1];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // CL: the lane's channels 8 kq .. 8 kq + 7 as four pairs; pairs past Cin (30: the last pair of kq = 3) re-read the pair
     // before them -- finite numbers that meet zero weights -- instead of running into the next position / past the buffer
@@ -352,7 +357,12 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
     {                                                                                                   \
         const int xl_ = (blk_) * 16 + fi;                                                               \
         const float* ib_ = g.in + (img_) * g.in_n_stride;                                               \
-        if constexpr (CL) {                                                                             \
+        if constexpr (IN16) {                                                                           \
+            const _Float16* ih_ = reinterpret_cast<const _Float16*>(g.in) + (img_) * g.in_n_stride +    \
+                                  ((xl_ < W ? xl_ : W - 1) * 32 + 8 * kq);                              \
+            _Pragma("unroll") for (int h = 0; h < H; ++h)                                               \
+                rawh[h] = *reinterpret_cast<const u32x4*>(ih_ + (int64_t)h * W * 32);                   \
+        } else if constexpr (CL) {                                                                      \
             const float* ip_ = ib_ + (xl_ < W ? xl_ : W - 1) * Cin;                                     \
             _Pragma("unroll") for (int h = 0; h < H; ++h) {                                             \
                 const float* ir_ = ip_ + h * W * Cin;                                                   \
@@ -380,7 +390,10 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
         for (int b = b_first; b < b_hi; ++b) {
             h8 a[H];
 #pragma unroll
-            for (int h = 0; h < H; ++h) a[h] = round8(raw[h]);
+            for (int h = 0; h < H; ++h) {
+                if constexpr (IN16) a[h] = as_h8(rawh[h]);
+                else a[h] = round8(raw[h]);
+            }
             {
                 const int nb = b + 1 < b_hi ? b + 1 : b;     // last block of the run: a harmless re-read
                 DCS_FETCH(img, nb)
@@ -557,10 +570,12 @@ bool dcs_decoder_fused_ok(const DcsColConv& a, int F) {
 }
 
 bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out,
-                              int F, bool in_channels_last) {
+                              int F, bool in_channels_last, bool in_f16) {
     if (!Wq || !Wq1 || !dcs_decoder_fused_ok(a, F)) return false;
+    // f16 input (gemm_f16.hip): [image][row][x][32 halves], 16-byte loads
+    if (in_f16 && (!in_channels_last || (a.in_n_stride & 7) || (reinterpret_cast<uintptr_t>(a.in) & 15))) return false;
     // channels-last input: pairs of channels are fetched as 8-byte loads
-    if (in_channels_last && ((a.Cin & 1) || (a.in_n_stride & 1) || (reinterpret_cast<uintptr_t>(a.in) & 7))) return false;
+    if (in_channels_last && !in_f16 && ((a.Cin & 1) || (a.in_n_stride & 1) || (reinterpret_cast<uintptr_t>(a.in) & 7))) return false;
     if (n_images <= 0) return true;
     // runs per image: fewest (rounds of waves) x (blocks per run + the recomputed one)
     const int64_t n_waves = (int64_t)ctx->n_cu * 4;
@@ -583,7 +598,10 @@ bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_image
     const u32x4* wq = reinterpret_cast<const u32x4*>(Wq);
 #define DCS_GO(CL_, S2H_) \
     hipLaunchKernelGGL((colconv_deconv1_fused_kernel<20, 11, CL_, S2H_>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, d)
-    if (in_channels_last) { if (s2h) DCS_GO(true, true); else DCS_GO(true, false); }
+    if (in_f16) {
+        if (!s2h) return false;                          // the three-way split stage 2 takes the f32 rows
+        hipLaunchKernelGGL((colconv_deconv1_fused_kernel<20, 11, true, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, d);
+    } else if (in_channels_last) { if (s2h) DCS_GO(true, true); else DCS_GO(true, false); }
     else { if (s2h) DCS_GO(false, true); else DCS_GO(false, false); }
 #undef DCS_GO
     return true;

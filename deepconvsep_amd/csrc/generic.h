@@ -63,9 +63,15 @@ bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images
 // InverseLayer(conv2) + InverseLayer(conv1) in one kernel (Bach10 graph, f16 switch on): out [image][Ho][F]
 void dcs_decoder_fused_pack(const float* W1p, int nf1, int C, std::vector<uint16_t>* out);
 bool dcs_decoder_fused_ok(const DcsColConv& a, int F);
+// gemm_f16.hip: the per-source dense layers on f16 weights, f16 channels-last output (f16 switch + fused decoder)
+size_t dcs_gemm_bh_bytes(int K, int n_out);
+int dcs_gemm_pack_bh(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_out, int nch, int npos, int chpad, void* Bh_d);
+int dcs_gemm_pack_bias_cl(dcs_ctx* ctx, const float* bias_d, int n_out, int nch, int npos, int chpad, float* out_d);
+bool dcs_launch_gemm_f16_skinny(dcs_ctx* ctx, const float* Z, int64_t ldz, int M, int K, int n_cols, int n_br, const void* const* Bh,
+                                const float* const* bias, void* const* C, int64_t ldc, void* Ah_scratch);
 // in_channels_last: a.in is [image][H][W][Cin] (the dense layer wrote a position's channels together) instead of [image][Cin][H][W]
 bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq, const void* Wq1, float* out,
-                              int F, bool in_channels_last = false);
+                              int F, bool in_channels_last = false, bool in_f16 = false);   // in_f16: [image][H][W][32] halves (gemm_f16.hip)
 
 // the same fusion with f32-class arithmetic (colconv_x3.hip): two waves per column block, ten taps each as bf16 planes in
 // registers; the input MUST be channels-last.  false = shape not covered / not launched

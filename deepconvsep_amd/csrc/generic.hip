@@ -1308,6 +1308,12 @@ struct DcsGenericNet {
     float* biasd[4] = {nullptr, nullptr, nullptr, nullptr};
     float* biasd_cl[4] = {nullptr, nullptr, nullptr, nullptr};   // the same biases in [position][channel] order (channels-last D)
     bool bdq_cl = false;                                         // column order the bf16 planes Bdq are packed in
+    // f16 switch with the fused decoder (gemm_f16.hip): the same weights as ONE f16 plane, columns [position][32 channels]
+    // (30 real), their biases in that order; n_out16 columns per branch (a multiple of 128); made on first need
+    void* Bdh[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* biasd_h[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_out16 = 0;
+    bool bdh_failed = false;
     float* bout = nullptr;
     DcsBuffer ws;
     float* rise_d = nullptr;
@@ -1559,7 +1565,8 @@ void dcs_generic_destroy(DcsGenericNet* g) {
     void* ptrs[] = {g->Wpc_q3, g->Wpc_t_q3, g->Wps_q3, g->Wps_t_q3, g->Wps_h, g->Wps_t_h, g->W1t, g->Wslab, g->Wslab_t, g->Wslab_q3, g->Wslab_t_q3, g->Wslab_h, g->Wslab_t_h, g->W1p, g->Wcol, g->Wcol_t, g->Wcol_h, g->Wcol_t_h, g->Wcol_r, g->Wcol_t_r, g->W1q, g->W1m, g->W1dq, g->W2m_h, g->W2t_h, g->W1c, g->bias1, g->W2m, g->bias2, g->k2off, g->k2uv, g->W2t, g->bias0, g->kt_off, g->kt_uv,
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3], g->biasd_cl[0], g->biasd_cl[1],
-                    g->biasd_cl[2], g->biasd_cl[3], g->Wx3, g->Bfcq, g->Wfx3};
+                    g->biasd_cl[2], g->biasd_cl[3], g->Wx3, g->Bfcq, g->Wfx3, g->Bdh[0], g->Bdh[1], g->Bdh[2], g->Bdh[3], g->biasd_h[0],
+                    g->biasd_h[1], g->biasd_h[2], g->biasd_h[3]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1840,6 +1847,53 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // block); that kernel takes the channels-last layout only, so it is planned when the layout can be had.
     bool fuse_planned = false, fuse_x3 = false;
     const bool want_cl = plans_channels_last(g, &fuse_planned, &fuse_x3);
+    // f16 switch, fused decoder, 128 .. 176 tiles, one input channel: the per-source dense layers on f16 weights with an f16,
+    // channels-last (32 channels per position) output -- gemm_f16.hip: 2 bytes per weight instead of 6, and D written and read
+    // at half the size.  The planes (0.36 GB for Bach10) are made on first need; if they do not fit, the f32-class path stays.
+    static const bool dense16_on = !(getenv("DCS_DENSE_F16") && atoi(getenv("DCS_DENSE_F16")) == 0);
+    bool dense16 = false, d_cl = false;
+    if (dense16_on && g->conv_f16 && fuse_planned && !fuse_x3 && want_cl && C == 1 && n >= 128 && n <= 176 && !g->bdh_failed &&
+        (g->hid64 & 31) == 0) {
+        const int npos = d.h2 * d.w2;
+        const int n_out = (int)dcs_round_up((int64_t)npos * 32, 128);
+        g->n_out16 = n_out;
+        for (int b = 0; b < NB && !g->bdh_failed; ++b) {
+            const int s2 = d.branch_fc[b];
+            if (g->Bdh[s2]) continue;
+            void* planes = nullptr;
+            float* bias_h = nullptr;
+            if (hipMalloc(&planes, dcs_gemm_bh_bytes(g->hid64, n_out)) != hipSuccess || hipMalloc((void**)&bias_h, (size_t)n_out * 4) != hipSuccess) {
+                (void)hipGetLastError();
+                if (planes) (void)hipFree(planes);
+                g->bdh_failed = true;
+                break;
+            }
+            int rc = dcs_gemm_pack_bh(ctx, g->Bd[s2], g->hid64, g->flat64, n_out, d.nf2, npos, 32, planes);
+            if (rc == DCS_OK) rc = dcs_gemm_pack_bias_cl(ctx, g->biasd[s2], n_out, d.nf2, npos, 32, bias_h);
+            if (rc != DCS_OK) {
+                (void)hipFree(planes);
+                (void)hipFree(bias_h);
+                return rc;
+            }
+            g->Bdh[s2] = planes;                         // published only when packed
+            g->biasd_h[s2] = bias_h;
+        }
+        if (!g->bdh_failed) {
+            const void* bh[4] = {nullptr, nullptr, nullptr, nullptr};
+            const float* bs[4] = {nullptr, nullptr, nullptr, nullptr};
+            void* cs[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int b = 0; b < NB; ++b) {
+                const int s2 = d.branch_fc[b];
+                bh[b] = g->Bdh[s2]; bs[b] = g->biasd_h[s2];
+                cs[b] = reinterpret_cast<_Float16*>(D) + (int64_t)b * n_out;      // D16[tile][branch][position][32]
+            }
+            DcsTimer tm(ctx, DCS_TAG_FC1X);
+            dense16 = dcs_launch_gemm_f16_skinny(ctx, Z, g->hid64, (int)n, g->hid64, n_out, NB, bh, bs, cs, (int64_t)NB * n_out, Zq);
+            if (dense16) tm.done(); else tm.cancel();
+            d_cl = dense16;
+        }
+    }
+    if (!dense16) {
     // the bf16 planes of the dense weights, on first need: a launch of >= 128 rows against >= 1024 columns (smaller ones stay
     // on the f32 kernels whatever is packed, dcs_launch_gemm_bf16x3); same stream, so no synchronisation
     static const bool bf16_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
@@ -1899,7 +1953,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         branches_done = dcs_launch_gemm_bf16x3_skinny(ctx, q, &br);
         if (branches_done) tm.done(); else tm.cancel();
     }
-    const bool d_cl = branches_done && planes_cl;        // layout of D as the decoder will find it
+    d_cl = branches_done && planes_cl;                   // layout of D as the decoder will find it
     for (int b = 0; b < NB && !branches_done; ++b) {
         const int s = d.branch_fc[b];
         DcsGemm q{};
@@ -1908,6 +1962,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         q.C = D + (int64_t)b * g->flat_p; q.ldc = (int64_t)NB * g->flat_p; q.c_gdiv = 1 << 30; q.c_gmul = 0;
         q.M = n; q.n_cols = g->flat64; q.n_store = d.flat; q.K = g->hid64; q.relu = 1; q.a_vec = 1;
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC1X));
+    }
     }
     // InverseLayer(., conv2): [n*NB, nf2, h2, w2] -> [n*NB, nf1, tc, wp]
     bool decoder_fused = false;
@@ -1925,6 +1980,10 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.ph = d.kh2 - 1; c.kh = d.kh2; c.n_xb = (c.W + 15) / 16;
             decoder_fused = g->conv_f16 ? (C == 1 && g->W1q && g->Wcol_t_r && dcs_decoder_fused_ok(c, F))
                                         : (fuse_x3 && d_cl);       // f32-class: only on the channels-last layout
+            if (dense16) {
+                if (!decoder_fused) DCS_FAIL(DCS_EHIP, "generic graph: f16 dense output planned without the fused decoder");
+                c.in_n_stride = g->n_out16;                    // halves: D16[image = tile * NB + branch][position][32]
+            }
         }
         if (d_cl && !decoder_fused) {
             // cannot happen while the plan above and the launch conditions agree (the layout is only asked for when the fused
@@ -1942,7 +2001,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         }
         if (decoder_fused) {                                 // both InverseLayers in one kernel: o directly
             DcsTimer tmf(ctx, DCS_TAG_DECODER);
-            const bool ok = g->conv_f16 ? dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F, d_cl)
+            const bool ok = g->conv_f16 ? dcs_launch_decoder_fused(ctx, c, n * NB, g->Wcol_t_r, g->W1q, o, F, d_cl, dense16)
                                         : dcs_launch_decoder_x3(ctx, c, n * NB, g->Wx3, g->W1q, o, F, C);
             tmf.done();
             if (!ok) DCS_FAIL(DCS_EHIP, "generic graph: the fused decoder refused a launch it had accepted (channels-last %d)", (int)d_cl);

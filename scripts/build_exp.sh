@@ -9,7 +9,7 @@ mkdir -p build/exp
 obj=build/exp/${name}_${src%.hip}.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden "$@" -c "$src" -o "$obj"
 objs=()
-for s in api dsd_lat fft fft_wave tiling gemm gemm_bf16x3 colconv_wreg colconv_x3 colconv_fwd_x3 slabconv_ps conv1_mfma deconv1_mfma dsd dsd_bf16x3 generic net score gather wavio; do
+for s in api dsd_lat fft fft_wave tiling gemm gemm_bf16x3 gemm_f16 colconv_wreg colconv_x3 colconv_fwd_x3 slabconv_ps conv1_mfma deconv1_mfma dsd dsd_bf16x3 generic net score gather wavio; do
   if [ "$s.hip" = "$src" ]; then objs+=("$obj"); else objs+=("build/$s.o"); fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=libdcs.map "${objs[@]}" -ldl -lpthread -o ../_exp_${name}.so

@@ -1128,7 +1128,8 @@ np.savez(sys.argv[3], p=p, q=q, same=np.array_equal(p, p2))
 
 
 def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
-    """From 128 tiles on the Bach10 graph with the f16 switch packs the bf16 planes of its per-source dense layers with
+    """(Round 6: the default under the f16 switch is now gemm_f16.hip -- variant "h16" below; the round-4 text describes
+    DCS_DENSE_F16=0.)  From 128 tiles on the Bach10 graph with the f16 switch packs the bf16 planes of its per-source dense layers with
     permuted columns, so that D comes out channels-last and the fused decoder reads a position's channels as 32 consecutive
     bytes (round 4).  140 tiles at F = 257: the default (channels-last) and DCS_DECODER_CL=0 (channel-first) must give the
     SAME bits -- same products, same accumulation order, only the addresses differ -- and meet the f16 path's stated 2e-3
@@ -1140,7 +1141,8 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
     f = tmp_path / "case.npz"
     np.savez(f, x=x, F=F)
     res = {}
-    for name, env in (("cl", {}), ("cf", {"DCS_DECODER_CL": "0"}), ("nox3", {"DCS_DECODER_X3": "0"}), ("f32fc", {"DCS_GEMM_KSPLIT": "40"})):
+    for name, env in (("h16", {}), ("cl", {"DCS_DENSE_F16": "0"}), ("cf", {"DCS_DECODER_CL": "0"}), ("nox3", {"DCS_DECODER_X3": "0", "DCS_DENSE_F16": "0"}),
+                      ("f32fc", {"DCS_GEMM_KSPLIT": "40"})):
         child_env = dict(os.environ)
         child_env.update(env)
         out = str(tmp_path / (name + ".npz"))
@@ -1148,6 +1150,17 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
                            timeout=300)
         assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-1500:])
         res[name] = np.load(out)
+    # round 6: under the f16 switch the dense layers themselves run on f16 weights and write D as f16, channels-last, 32 channels
+    # per position (gemm_f16.hip; DCS_DENSE_F16=0: the f32-class dense layers of rounds 4 / 5 in front of the same decoder)
+    assert np.max(np.abs(res["h16"]["p"] - want)) < 2e-3
+    assert np.max(np.abs(res["h16"]["q"] - want)) < 1e-4          # f32-class after the switch back
+    assert bool(res["h16"]["same"])                                 # and the f16 result again, to the bit
+    assert np.array_equal(res["h16"]["q"], res["cl"]["q"])          # the f32-class path does not know about the f16 planes
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "f16_stats.txt"), "a") as fh:
+        fh.write("bach10 F=257, 140 tiles, f16 switch: raw output max|err| vs oracle: f16 dense + f16 D %.3e, f32-class dense %.3e; "
+                 "between the two %.3e\n" % (np.max(np.abs(res["h16"]["p"] - want)), np.max(np.abs(res["cl"]["p"] - want)),
+                                             np.max(np.abs(res["h16"]["p"] - res["cl"]["p"]))))
     assert np.max(np.abs(res["cl"]["p"] - want)) < 2e-3
     assert np.max(np.abs(res["cl"]["q"] - want)) < 1e-4           # f32-class after the switch back
     assert bool(res["cl"]["same"])                                  # and the f16 result again, to the bit, after re-packing
