@@ -95,13 +95,13 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
     const int fi = lane & 15, kq = lane >> 4;
     // workgroup = (image, band of output rows, tile of output columns)
     // (wide filters keep whole rows: n_xt == 1, and the tile arithmetic below folds to constants)
-    const int xtile = PU ? blockIdx.x % g.n_xt : 0;
-    const int bb = PU ? blockIdx.x / g.n_xt : blockIdx.x;
+    const int xtile = blockIdx.x % g.n_xt;                // (n_xt == 1: whole rows)
+    const int bb = blockIdx.x / g.n_xt;
     const int64_t img = bb / g.n_bands;
     const int y0 = (int)(bb - img * g.n_bands) * g.band;
     const int yb = y0 + g.band < g.Ho ? y0 + g.band : g.Ho;   // output rows [y0, yb)
-    const int xt0 = PU ? xtile * g.xt : 0;
-    const int xt1 = PU ? (xt0 + g.xt < g.Wo ? xt0 + g.xt : g.Wo) : g.Wo;   // output columns [xt0, xt1)
+    const int xt0 = xtile * g.xt;
+    const int xt1 = xt0 + g.xt < g.Wo ? xt0 + g.xt : g.Wo;   // output columns [xt0, xt1)
     const float* in = g.in + img * g.in_n_stride;
     float* out = g.out + img * g.out_n_stride;
     int rbase = y0 - g.ph, rtop = yb - 1 - g.ph + g.kh - 1;
@@ -111,14 +111,11 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
     const int HW = g.H * g.W;
     const int nxb = (xt1 - xt0 + 15) >> 4, nblk = (yb - y0) * nxb;
     const int nvp = PU ? 1 : (g.kw + 1) >> 1;             // tap pairs per filter row
-    // input columns the tile can touch: [cx0, cx1)
-    int cx0 = 0, cx1 = g.W;
-    if (PU) {
-        cx0 = xt0 - g.pw;
-        cx1 = xt0 - g.pw + nxb * 16;
-        if (cx0 < 0) cx0 = 0;
-        if (cx1 > g.W) cx1 = g.W;
-    }
+    // input columns the tile can touch: [cx0, cx1) -- a wide filter's tap pairs reach 2 nvp - 1 columns past the block
+    int cx0 = xt0 - g.pw;
+    int cx1 = xt0 - g.pw + nxb * 16 + (PU ? 0 : 2 * nvp - 1);
+    if (cx0 < 0) cx0 = 0;
+    if (cx1 > g.W) cx1 = g.W;
     const int SW = cx1 > cx0 ? cx1 - cx0 : 0;
     int by[NBW], bx[NBW];
     f32x4 acc0[NBW], acc1[NBW];
@@ -150,7 +147,7 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
             bu0[i] = g.ph - by[i];
             bu1[i] = g.H - 1 + g.ph - by[i];
             bxs[i] = xs0;
-            vb[i] = ((by[i] - g.ph - rbase) * SW + xs0 + lx) * RP + (kq & 1);
+            vb[i] = ((by[i] - g.ph - rbase) * SW + xs0 - cx0 + lx) * RP + (kq & 1);
         }
     }
     int u_lo = g.ph - (yb - 1), u_hi = g.ph - y0 + g.H - 1;
@@ -194,16 +191,31 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
                 wpre[q] = e < np_ * kStageGlb ? Wh[(int64_t)pair_ * kStageGlb + e] : u32x4{0u, 0u, 0u, 0u};    \
             }                                                                                           \
         }
-        if (n_stage > 0) DCS_PS_WFETCH(0)
-        for (int st = 0; st < n_stage; ++st) {
-            u32x4* Wb = Wl + (st & 1) * wstage;
+        // Stages none of the workgroup's blocks can use are skipped by the whole workgroup -- no fetch, no barrier.  With whole
+        // rows per workgroup every stage has a live block somewhere; with a COLUMN tile (round 6: the transposed convolution of
+        // the iKala graph, kw - 1 = 19 columns of padding) the tile's blocks share their column range and so their live tap
+        // pairs: the column tile at the right edge of an 83-wide row uses 2 of the 10 pairs of a filter row.
+        auto stage_live = [&](int st_) -> bool {
+            if (PU || !FAST) return true;
+            const int i0_ = (st_ % nvs) * g.pstage;
+            const int np_ = i0_ + g.pstage <= n_in ? g.pstage : n_in - i0_;
+            const int min_xs = xt0 - g.pw + 2 * i0_, max_xs = xt0 + (nxb - 1) * 16 - g.pw + 2 * (i0_ + np_ - 1);
+            return max_xs + 16 >= 0 && min_xs < g.W;
+        };
+        int st = 0, it = 0;
+        while (st < n_stage && !stage_live(st)) ++st;
+        if (st < n_stage) DCS_PS_WFETCH(st)
+        for (; st < n_stage; ++it) {
+            u32x4* Wb = Wl + (it & 1) * wstage;
 #pragma unroll
             for (int q = 0; q < WPRE; ++q) {
                 const int e = tid + q * NTH;              // the packed order is the LDS order
                 if (e < g.pstage * kStageGlb) Wb[e] = wpre[q];
             }
-            __syncthreads();     // also orders the slab fill before its first use; buffer st & 1 was last read at st - 2
-            if (st + 1 < n_stage) DCS_PS_WFETCH(st + 1)
+            __syncthreads();     // also orders the slab fill before its first use; buffer it & 1 was last read two stages ago
+            int st_next = st + 1;
+            while (st_next < n_stage && !stage_live(st_next)) ++st_next;
+            if (st_next < n_stage) DCS_PS_WFETCH(st_next)
             const int so = st / nvs, i0 = (st - so * nvs) * g.pstage;
             const int np = i0 + g.pstage <= n_in ? g.pstage : n_in - i0;
 #define DCS_PS_MMA(i_, a0, a1, b)                                                                                \
@@ -313,6 +325,7 @@ __global__ __launch_bounds__(64 * NW) void slabconv_ps_kernel(const DcsSlabConv 
                 }
             }
 #undef DCS_PS_MMA
+            st = st_next;
         }
 #undef DCS_PS_WFETCH
     }
@@ -421,6 +434,26 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
             const bool tie = eff > best - 1e-9;
             if (eff > best + 1e-9 || (tie && (ps > ps_best || (ps == ps_best && cand * cxt >= band * (xt / 16))))) {
                 best = eff; band = cand; xt = cxt * 16; lds = need; ps_best = ps;
+            }
+        }
+    }
+    // Wide filters WITH padding (the transposed convolution of the iKala graph: 10 x 20, 9 / 19 of padding): column strips
+    // instead of row bands.  With whole rows per workgroup the sixteen waves of a weight stage have between 2 and 10 live (tap
+    // pair, block) steps -- which tap pairs reach inside the image depends on the block's COLUMN -- and the stage ends with the
+    // slowest: 47 % of the wave-cycles waited at the stage barrier (PMC, profiles/r04_m_ikala_pmc.txt).  A workgroup that owns
+    // ONE column block of every output row has the same live tap pairs in all its blocks: the stages balance, and the stages
+    // no block of the strip can use are skipped by the whole workgroup (slabconv_ps_kernel: stage_live).
+    static const bool strip_on = !(getenv("DCS_SLABCONV_STRIP") && atoi(getenv("DCS_SLABCONV_STRIP")) == 0);
+    if (strip_on && fast && a.pw > 0 && a.Ho <= slots && nxb_all >= 2) {
+        int rows = a.Ho + a.kh - 1;
+        if (rows > a.H) rows = a.H;
+        int sw = 16 + 2 * nvp - 1;
+        if (sw > a.W) sw = a.W;
+        for (int ps = 5; ps >= 1; --ps) {
+            const size_t need = (size_t)2 * ps * np * 128 * 16 + (size_t)(rows * sw + 1) * rec;
+            if (need <= 160 * 1024) {
+                band = a.Ho; xt = 16; lds = need; ps_best = ps;
+                break;
             }
         }
     }

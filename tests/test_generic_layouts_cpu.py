@@ -279,6 +279,63 @@ def test_slabconv_ps_mask_driven_tap_loop_visits_exactly_the_old_loops_steps():
                                         assert idx == old_idx and idx >= 0
 
 
+def test_slabconv_ps_column_strips_read_inside_their_slab_and_skip_only_dead_stages():
+    """Round 6: the transposed convolution of the iKala graph (21 x 64 -> 30 x 83, 10 x 20 filter, pads 9 / 19) runs on COLUMN
+    STRIPS -- a workgroup owns one 16-column block of every output row, its slab holds the input columns [cx0, cx1) that block's
+    taps can reach, and weight stages (groups of `pstage` tap pairs of one filter row) that no block of the strip can use are
+    skipped by the whole workgroup.  Restated from slabconv_ps_kernel: (i) every in-image read of a live step lands inside the
+    slab, at the record the kernel computes (vb with the - cx0 term); (ii) a skipped stage has no live step in any block of
+    the strip, so the strip's set of executed (u, tap pair, block) steps is the whole-row form's restricted to its columns."""
+    KH, KW = 10, 20
+    nvp = (KW + 1) // 2
+    Hh, W, Ho, Wo, ph, pw = 21, 64, 30, 83, 9, 19
+    for xt in (16, 32):                                   # the launcher picks 16; a two-block tile exercises nxb > 1
+        n_xt = ((Wo + 15) // 16 * 16 + xt - 1) // xt
+        seen_blocks = set()
+        for xtile in range(n_xt):
+            xt0 = xtile * xt
+            xt1 = min(xt0 + xt, Wo)
+            if xt0 >= Wo:
+                continue
+            nxb = (xt1 - xt0 + 15) >> 4
+            cx0 = max(xt0 - pw, 0)
+            cx1 = min(xt0 - pw + nxb * 16 + 2 * nvp - 1, W)
+            SW = max(cx1 - cx0, 0)
+            y0, yb = 0, Ho                                # the strip covers every output row
+            rbase = max(y0 - ph, 0)
+            rtop = min(yb - 1 - ph + KH - 1, Hh - 1)
+            rows = rtop - rbase + 1
+            for pstage in (1, 3, 5):
+                nvs = (nvp + pstage - 1) // pstage
+                live_stage = []
+                for sidx in range(nvs):
+                    i0 = sidx * pstage
+                    npp = min(pstage, nvp - i0)
+                    min_xs, max_xs = xt0 - pw + 2 * i0, xt0 + (nxb - 1) * 16 - pw + 2 * (i0 + npp - 1)
+                    live_stage.append(max_xs + 16 >= 0 and min_xs < W)
+                for by in range(y0, yb):
+                    for bxi in range(nxb):
+                        bx = xt0 + bxi * 16
+                        seen_blocks.add((by, bx))
+                        xs0 = bx - pw
+                        for u in range(KH):
+                            r = by + u - ph
+                            for vp in range(nvp):
+                                xs = xs0 + 2 * vp
+                                live = 0 <= r < Hh and xs + 16 >= 0 and xs < W
+                                if live:
+                                    assert live_stage[vp // pstage], (xtile, by, bx, u, vp)     # (ii) never skipped
+                                    for lane in range(64):
+                                        fi, kq = lane & 15, lane >> 4
+                                        lx = fi + (kq >> 1)
+                                        xc = xs + lx
+                                        if 0 <= xc < W:                                          # (i) inside the slab
+                                            assert cx0 <= xc < cx1 and 0 <= r - rbase < rows
+                                            vb = (by - ph - rbase) * SW + xs0 - cx0 + lx
+                                            assert vb + u * SW + 2 * vp == (r - rbase) * SW + (xc - cx0)
+        assert seen_blocks == {(by, bx) for by in range(Ho) for bx in range(0, Wo, 16)}          # every block owned once
+
+
 # ------------------------------------------------------------------ forward STFT edge frames (round 4)
 def test_stft_edge_frames_clamped_loads_and_masks_reproduce_zero_padding():
     """stft_forward_wave_kernel / lat_stft_kernel load the samples of a frame that hangs over either end of the signal from a
