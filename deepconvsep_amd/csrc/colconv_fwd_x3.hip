@@ -234,10 +234,10 @@ __global__ __launch_bounds__(kTh) void colconv_fwd_x3_kernel(const DcsColConv g,
 // the input MUST be channels-last ([image][H][W][Cin], 8-byte aligned), the output is channel-first [image][Cout][HO][W]
 // The default for this shape since round 6 (1.6 x faster than slabconv_ps_kernel; round 5 kept it opt-in because ONE
 // ill-conditioned mask bin of one random draw landed at 1.8e-4 instead of 3.9e-5 with it -- a bin whose value depends on the last
-// bit of the network output whatever kernel computes it; the parity criterion no longer counts such bins).
+// bit of the network output whatever kernel computes it; the parity criterion no longer counts such bins, INTEGRATION.md section 6;
+// same-box A/B against slabconv_ps_kernel, which still serves the other shapes: profiles/r06_a_conv2_default_on_legs_ab.txt).
 bool dcs_colconv_fwd_x3_ok(const DcsColConv& a) {
-    static const bool on = !(getenv("DCS_CONV2_X3") && atoi(getenv("DCS_CONV2_X3")) == 0);   // =0: A/B against slabconv_ps_kernel
-    return on && a.kh == 20 && a.ph == 0 && a.H == 30 && a.Ho == 11 && a.W >= 16 && a.Cout <= 32 && a.Cin <= 32 && a.Cin >= 28 &&
+    return a.kh == 20 && a.ph == 0 && a.H == 30 && a.Ho == 11 && a.W >= 16 && a.Cout <= 32 && a.Cin <= 32 && a.Cin >= 28 &&
            (a.Cin & 1) == 0;
 }
 

@@ -254,34 +254,8 @@ __global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const Dc
 // its left and keeps only the carry.  HBM traffic: the dense-layer output once (445 MB) + the 164 MB result.
 // (scripts/emu_fused_decoder.py: the same index arithmetic lane by lane in NumPy against the direct formula.)
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ f32x4 mma_bf(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ unsigned bf_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
-
-// x = hi + mid + lo exactly (three bf16 by truncation); element j of a piece is k slot j
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h[j] = bf_trunc(x[j]);
-        const float r1 = x[j] - __uint_as_float(h[j]);
-        m[j] = bf_trunc(r1);
-        l[j] = bf_trunc(r1 - __uint_as_float(m[j]));
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        hi[q] = (h[2 * q] >> 16) | h[2 * q + 1];
-        mid[q] = (m[2 * q] >> 16) | m[2 * q + 1];
-        lo[q] = (l[2 * q] >> 16) | l[2 * q + 1];
-    }
-}
-
 struct DcsDecoderFused {
-    const u32x4* Wq1;       // [3 planes][2 tap halves][64 lanes] pieces of the padded conv1 filter
+    const u32x4* Wq1;       // the padded conv1 filter as packed by dcs_decoder_fused_pack; this kernel reads section 3 (the f16 fragments)
     float* out;             // [image][HO][F]
     int F;
     int runs_per_image;
@@ -293,8 +267,8 @@ struct DcsDecoderFused {
 // 8-byte loads, 44 per column block instead of 88 four-byte ones, and a wave's loads of a row cover ONE contiguous run of
 // 16 x Cin floats.  With the channel-first layout (rows of W = 505 floats: every 64-byte segment of 16 x starts on a 4-byte
 // boundary and straddles two lines) the counters showed 2.68 x the algorithmic bytes moving (profiles/r03_traffic.json).
-// S2H (round 4, the default of the f16 switch; DCS_DECODER_S2=bf16x3 selects the three-way split): stage 2 -- the
-// transposed conv1 -- takes f16 inputs like stage 1: G is rounded to f16 once (it is the output of an f16-input
+// Stage 2 -- the transposed conv1 -- takes f16 inputs like stage 1 (round 4; the three-way split form it replaced was a switch
+// until round 6): G is rounded to f16 once (it is the output of an f16-input
 // convolution already) and meets the f16 conv1 filter in ONE MFMA per tap half instead of six bf16 ones behind a 52-
 // instruction operand split per row -- 500 instead of 800 MFMAs and ~1 500 fewer vector instructions per column block.
 // BASELINE configs[3] names an "fp16 MFMA conv path"; its stated tolerance (network output 2e-3) is unchanged, the
@@ -302,10 +276,10 @@ struct DcsDecoderFused {
 // IN16 (round 6): the input arrives as f16, channels-last with the channel axis padded to 32 (gemm_f16.hip writes it so under the
 // f16 switch): in[image][row][x][32] halves, a lane's eight channels ONE 16-byte load and no conversion -- half the bytes of
 // the f32 input it replaces, which this kernel rounded to f16 on arrival anyway.  g.in / g.in_n_stride are then in halves.
-template <int KH, int H, bool CL, bool S2H, bool IN16 = false>
+template <int KH, int H, bool CL, bool IN16 = false>
 __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
                                                                          const DcsDecoderFused d) {
-    static_assert(!IN16 || (CL && S2H), "the f16 input is channels-last and feeds the all-f16 kernel");
+    static_assert(!IN16 || CL, "the f16 input is channels-last");
     constexpr int HO = H + KH - 1, PH = KH - 1;
     static_assert(HO % 2 == 0, "output rows are processed in pairs");
     // per wave: Pb [2 rows][8 taps mm][32 slots] float4 -- slot 8 + x holds P[x][mm], slots 0..7 and 24..31 stay zero --
@@ -325,12 +299,9 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
         w[u][0] = as_h8(Wq[(u * 2) * 64 + lane]);
         w[u][1] = as_h8(Wq[(u * 2 + 1) * 64 + lane]);
     }
-    u32x4 w1[S2H ? 1 : 3][2];
-#pragma unroll
-    for (int p = 0; p < (S2H ? 1 : 3); ++p) {
-        w1[p][0] = d.Wq1[((S2H ? 3 : p) * 2) * 64 + lane];          // section 3 of the packed array: the f16 fragments
-        w1[p][1] = d.Wq1[((S2H ? 3 : p) * 2 + 1) * 64 + lane];
-    }
+    u32x4 w1[2];
+    w1[0] = d.Wq1[(3 * 2) * 64 + lane];                  // section 3 of the packed array: the f16 fragments
+    w1[1] = d.Wq1[(3 * 2 + 1) * 64 + lane];
     // g.bias is not read: an InverseLayer has no bias (the generic path's vector for this layer is all zeros)
     const int W = g.W, n_xb = g.n_xb, F = d.F;
     const int HW = H * W;
@@ -400,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
             }
             const bool x_ok = b * 16 + fi < W;               // columns past W (last block only) must not reach the rows
             const bool edge = b * 16 + 16 > W;
-            if (S2H && edge) {                               // wave-uniform.  No bias in either InverseLayer: a zero input column
+            if (edge) {                                      // wave-uniform.  No bias in either InverseLayer: a zero input column
 #pragma unroll                                               // gives a zero G column and zero products -- masked once, at the source
                 for (int h = 0; h < H; ++h)
                     if (!x_ok) a[h] = h8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -432,29 +403,9 @@ __global__ __launch_bounds__(kThreads) void colconv_deconv1_fused_kernel(const D
                         gv[e] = acc[t][0][e];
                         gv[4 + e] = acc[t][1][e];
                     }
-                    if constexpr (S2H) {
-                        const h8 gh = round8(gv);
+                    const h8 gh = round8(gv);
 #pragma unroll
-                        for (int mh = 0; mh < 2; ++mh) pw[t * 256 + mh * 128] = mma(as_h8(w1[0][mh]), gh, zero4);
-                    } else {
-                        u32x4 g0, g1, g2;
-                        split8(gv, g0, g1, g2);
-#pragma unroll
-                        for (int mh = 0; mh < 2; ++mh) {
-                            f32x4 p = zero4;
-                            p = mma_bf(w1[2][mh], g0, p);          // smallest products first
-                            p = mma_bf(w1[0][mh], g2, p);
-                            p = mma_bf(w1[1][mh], g1, p);
-                            p = mma_bf(w1[1][mh], g0, p);
-                            p = mma_bf(w1[0][mh], g1, p);
-                            p = mma_bf(w1[0][mh], g0, p);
-                            if (edge) {                            // wave-uniform: only the last block of an image
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) p[e] = x_ok ? p[e] : 0.f;
-                            }
-                            pw[t * 256 + mh * 128] = p;
-                        }
-                    }
+                    for (int mh = 0; mh < 2; ++mh) pw[t * 256 + mh * 128] = mma(as_h8(w1[mh]), gh, zero4);
                 }
                 asm volatile("" ::: "memory");               // the pieces of both rows are written (LDS is in order per wave)
                 // all nine reads in flight before the first addition (left alone the compiler waits for each in turn: one
@@ -593,16 +544,12 @@ bool dcs_launch_decoder_fused(dcs_ctx* ctx, const DcsColConv& a, int64_t n_image
     d.runs_per_image = best;
     d.n_runs = n_images * best;
     const unsigned grid = (unsigned)std::min<int64_t>(dcs_cdiv(d.n_runs, 4), ctx->n_cu);
-    // DCS_DECODER_S2=bf16x3: the transposed conv1 inside the kernel on three-way split operands (f32-class, round 2/3)
-    static const bool s2h = !(getenv("DCS_DECODER_S2") && strcmp(getenv("DCS_DECODER_S2"), "bf16x3") == 0);
     const u32x4* wq = reinterpret_cast<const u32x4*>(Wq);
-#define DCS_GO(CL_, S2H_) \
-    hipLaunchKernelGGL((colconv_deconv1_fused_kernel<20, 11, CL_, S2H_>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, d)
-    if (in_f16) {
-        if (!s2h) return false;                          // the three-way split stage 2 takes the f32 rows
-        hipLaunchKernelGGL((colconv_deconv1_fused_kernel<20, 11, true, true, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, d);
-    } else if (in_channels_last) { if (s2h) DCS_GO(true, true); else DCS_GO(true, false); }
-    else { if (s2h) DCS_GO(false, true); else DCS_GO(false, false); }
+#define DCS_GO(CL_, IN16_) \
+    hipLaunchKernelGGL((colconv_deconv1_fused_kernel<20, 11, CL_, IN16_>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, d)
+    if (in_f16) DCS_GO(true, true);
+    else if (in_channels_last) DCS_GO(true, false);
+    else DCS_GO(false, false);
 #undef DCS_GO
     return true;
 }

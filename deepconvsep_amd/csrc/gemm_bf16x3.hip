@@ -522,8 +522,7 @@ bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
 // All rows in one workgroup (gemm_bf16x3_skinny_kernel): 128 <= M <= 176 rows against very wide B planes.  `br` (optional):
 // up to 4 (B planes, bias, C) triples that share g's A and shape -- one launch, blockIdx.y = branch.
 bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemmBranches* br) {
-    static const bool on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0) &&
-                           !(getenv("DCS_GEMM_SKINNY") && atoi(getenv("DCS_GEMM_SKINNY")) == 0);
+    static const bool on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
     DcsGemmBranches b{};
     if (br) b = *br;
     const void* bq0 = b.n > 0 ? b.Bq[0] : g.Bq;

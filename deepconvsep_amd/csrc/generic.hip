@@ -1850,9 +1850,9 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // f16 switch, fused decoder, 128 .. 176 tiles, one input channel: the per-source dense layers on f16 weights with an f16,
     // channels-last (32 channels per position) output -- gemm_f16.hip: 2 bytes per weight instead of 6, and D written and read
     // at half the size.  The planes (0.36 GB for Bach10) are made on first need; if they do not fit, the f32-class path stays.
-    static const bool dense16_on = !(getenv("DCS_DENSE_F16") && atoi(getenv("DCS_DENSE_F16")) == 0);
+    // (same-box A/B against the f32-class dense layers in front of the same decoder: profiles/r06_f_bach10_f16_dense_legs_ab.txt)
     bool dense16 = false, d_cl = false;
-    if (dense16_on && g->conv_f16 && fuse_planned && !fuse_x3 && want_cl && C == 1 && n >= 128 && n <= 176 && !g->bdh_failed &&
+    if (g->conv_f16 && fuse_planned && !fuse_x3 && want_cl && C == 1 && n >= 128 && n <= 176 && !g->bdh_failed &&
         (g->hid64 & 31) == 0) {
         const int npos = d.h2 * d.w2;
         const int n_out = (int)dcs_round_up((int64_t)npos * 32, 128);

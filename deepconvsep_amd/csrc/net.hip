@@ -577,9 +577,9 @@ extern "C" int dcs_model_set_conv_precision(dcs_model* m, int f16) {
     return DCS_OK;
 }
 
-// one clip of at most this many frames takes the one-batch kernels (DCS_LAT_MAX_FRAMES)
+// one clip of at most this many frames takes the one-batch kernels
 static int64_t dcs_lat_max_frames() {
-    static const int64_t v = getenv("DCS_LAT_MAX_FRAMES") ? atoll(getenv("DCS_LAT_MAX_FRAMES")) : 1024;   // ~195 tiles: measured crossover ~220 (profiles/r03_c_lat_vs_throughput_by_tiles.txt)
+    constexpr int64_t v = 1024;   // ~195 tiles: measured crossover ~220 (profiles/r03_c_lat_vs_throughput_by_tiles.txt)
     return v;
 }
 extern "C" int dcs_model_set_latency_stages(dcs_model* m, int stages) {

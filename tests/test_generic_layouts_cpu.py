@@ -480,8 +480,8 @@ def test_conv1_planes_in_lds_give_every_fragment_the_floats_the_old_kernel_split
         assert max(planes_bytes, 32 * kOutS * 4) == 32 * kOutS * 4         # the tile decides the LDS size
 
 
-def test_opt_in_conv2_kernel_visits_every_row_tap_pair_once_and_never_overwrites_a_ring_slot_in_use():
-    """colconv_fwd_x3_kernel (DCS_CONV2_X3=1): KH = 20 taps, H = 30 input rows, HO = 11 output rows.  Step s multiplies input row s
+def test_weights_in_registers_conv2_kernel_visits_every_row_tap_pair_once_and_never_overwrites_a_ring_slot_in_use():
+    """colconv_fwd_x3_kernel (the default conv2 of the Bach10 / score-informed graphs since round 6): KH = 20 taps, H = 30 input rows, HO = 11 output rows.  Step s multiplies input row s
     with every tap u whose output row y = s - u exists; the rows live in a ring of three chunks of two rows (slot = chunk % 3).
     Restated: every (y, u) pair is visited exactly once, in increasing u for a fixed y (the accumulation order of a chain); in
     interval i the chunk being written (i + 2, of the next block from i = 13 on) never shares a slot with the chunks being read
