@@ -297,27 +297,23 @@ __device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, c
 constexpr int kStftStageF2 = 256;
 
 template <int LOG2M>
-__global__ __launch_bounds__(LOG2M <= 10 ? 768 : 256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
+__global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
                                          const float2* __restrict__ tw, float* __restrict__ mag,
                                          float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
                                          int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
-                                         float sqrt_n, int interleave, const int64_t* __restrict__ clip_tab, int win_lds) {
+                                         float sqrt_n, int interleave, const int64_t* __restrict__ clip_tab) {
     constexpr int M = 1 << LOG2M, P = M / 64, MP = M + M / 32;
     constexpr int R1 = Plan<LOG2M>::R1, NB1 = P / R1, stride1 = 64 * NB1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row pointers stay in SGPRs
     FW_STAMP(0);
-    // [waves][kStageF2] output staging (16-byte aligned: first in the segment), then the table, then the waves' exchange buffers,
-    // then (win_lds: twelve-frame workgroups) the window as sample pairs
+    // [waves][kStageF2] output staging (16-byte aligned: first in the segment), then the table, then the waves' exchange buffers
     float2* stage = reinterpret_cast<float2*>(smem) + wave * kStftStageF2;
     float2* lds0 = reinterpret_cast<float2*>(smem) + (blockDim.x >> 6) * kStftStageF2;
     const float2* twl = lds0;
     float2* buf = lds0 + (M + 1) + wave * MP;
-    float2* winl = lds0 + (M + 1) + (blockDim.x >> 6) * MP;
     for (int k = tid; k <= M; k += blockDim.x) lds0[k] = tw[k];
-    if (win_lds)
-        for (int k = tid; k < M; k += blockDim.x) winl[k] = reinterpret_cast<const float2*>(win)[k];
     __syncthreads();
     // output row -> (clip, frame): clips of equal length are stacked with a pitch of rows_pc rows
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -357,10 +353,7 @@ __global__ __launch_bounds__(LOG2M <= 10 ? 768 : 256) void stft_forward_wave_ker
     const int r_hi = rem < 2 * M ? (rem < 0 ? 0 : (int)rem) : 2 * M;
     const float* ap = audio + base;
     const float inv_sqrt_n = 1.f / sqrt_n;
-    // the window: from the workgroup's LDS copy when it has one -- in-kernel timeline at 20 x 32 tiles (profiles/r06_g_*): of a
-    // wave's 23.5 k clocks 8.4 k went into REQUESTING its 8 KB of window and 8 KB of samples: twelve waves per CU pull 192 KB
-    // through an L1 that fills at ~20 bytes per clock
-    const float2* w2 = win_lds ? winl : reinterpret_cast<const float2*>(win);
+    const float2* w2 = reinterpret_cast<const float2*>(win);
     // whole frame in range and its sample pairs 8-byte aligned: one 64-bit load per pair
     const bool inside = r_lo == 0 && r_hi == 2 * M && (reinterpret_cast<uintptr_t>(ap) & 7) == 0;
     // All sample and window loads are issued before the first value is used, on the edge frames too: their loads are
@@ -1133,25 +1126,16 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride,
     constexpr int M = 1 << LOG2M, MP = M + M / 32;
     // frames per workgroup: 4 when there are plenty of frames, 1 to spread a short signal over the CUs (1 / 2 / 3 per
     // workgroup at 640 tiles: 33.1 / 27.5 / 22.4 us against 22.0 with 4)
-    // Round 6: 12 frames per workgroup (one workgroup per CU, the same three waves per SIMD) with the window in LDS beside the
-    // twiddle table: both are filled once per twelve frames instead of once per four / loaded by every wave.  DCS_STFT_FPW=4:
-    // the round-2 .. 5 form.
     const int64_t rows_all = rows_out * n_clips;
-    static const int fpw_env = getenv("DCS_STFT_FPW") ? atoi(getenv("DCS_STFT_FPW")) : 0;
-    int fpw = rows_all >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
-    int win_lds = 0;
-    if (fpw == 4 && fpw_env != 4 && ((size_t)(M + 1) + 12 * (size_t)(MP + kStftStageF2) + (size_t)M) * sizeof(float2) <= 160 * 1024) {
-        fpw = 12;
-        win_lds = 1;
-    }
-    const size_t lds = ((size_t)(M + 1) + (size_t)fpw * (MP + kStftStageF2) + (win_lds ? (size_t)M : 0)) * sizeof(float2);
+    const int fpw = rows_all >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
+    const size_t lds = ((size_t)(M + 1) + (size_t)fpw * (MP + kStftStageF2)) * sizeof(float2);
     auto kern = stft_forward_wave_kernel<LOG2M>;
     if (lds > 48 * 1024)
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)dcs_cdiv(rows_all, fpw)), dim3(64 * fpw), lds, p->ctx->stream, audio, L,
                        p->win_f, p->tw_f, mag, phase, unit, ld, p->hop, T, rows_out, n_clips, audio_stride,
-                       (float)sqrt((double)p->frame), interleave ? 1 : 0, clip_tab, win_lds);
+                       (float)sqrt((double)p->frame), interleave ? 1 : 0, clip_tab);
     return DCS_OK;
 }
 
