@@ -443,8 +443,8 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
     // slowest: 47 % of the wave-cycles waited at the stage barrier (PMC, profiles/r04_m_ikala_pmc.txt).  A workgroup that owns
     // ONE column block of every output row has the same live tap pairs in all its blocks: the stages balance, and the stages
     // no block of the strip can use are skipped by the whole workgroup (slabconv_ps_kernel: stage_live).
-    static const bool strip_on = !(getenv("DCS_SLABCONV_STRIP") && atoi(getenv("DCS_SLABCONV_STRIP")) == 0);
-    if (strip_on && fast && a.pw > 0 && a.Ho <= slots && nxb_all >= 2) {
+    // (same-box A/B: conv2^T 0.673 -> 0.627 ms per 10 s clip, profiles/r06_g_ikala_column_strips_ab.txt)
+    if (fast && a.pw > 0 && a.Ho <= slots && nxb_all >= 2) {
         int rows = a.Ho + a.kh - 1;
         if (rows > a.H) rows = a.H;
         int sw = 16 + 2 * nvp - 1;

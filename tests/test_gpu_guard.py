@@ -239,20 +239,27 @@ json.dump(results, open(OUT, "w"), indent=1)
 '''
 
 
-def _run(poison, out, only=""):
+def _start(poison, out, only=""):
     env = dict(os.environ)
     env.update({"DCS_WS_GUARD": "65536", "DCS_WS_POISON": str(poison)})
-    r = subprocess.run([sys.executable, "-c", _CHILD, ROOT, str(poison), out, only], env=env, capture_output=True, text=True,
-                       timeout=900)
-    assert r.returncode == 0, (poison, r.stdout[-800:], r.stderr[-2500:])
+    return subprocess.Popen([sys.executable, "-c", _CHILD, ROOT, str(poison), out, only], env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True)
+
+
+def _finish(proc, poison, out):
+    so, se = proc.communicate(timeout=900)
+    assert proc.returncode == 0, (poison, so[-800:], se[-2500:])
     with open(out) as fh:
         return json.load(fh)
 
 
 def test_red_zones_untouched_outputs_finite_and_independent_of_the_poison(tmp_path):
     only = os.environ.get("DCS_GUARD_CASES", "")
-    nan_run = _run(0xFF, str(tmp_path / "nan.json"), only)
-    big_run = _run(0x4B, str(tmp_path / "big.json"), only)
+    # the two poison runs are independent processes: side by side on the one GPU (each is ~10 s of start-up and small launches)
+    f_nan, f_big = str(tmp_path / "nan.json"), str(tmp_path / "big.json")
+    p_nan, p_big = _start(0xFF, f_nan, only), _start(0x4B, f_big, only)
+    nan_run = _finish(p_nan, 0xFF, f_nan)
+    big_run = _finish(p_big, 0x4B, f_big)
     for run in (nan_run, big_run):
         st = run.pop("_selftest")
         assert st["before"] == 0 and st["after_one_stray_byte"] == 1, st        # a stray byte in a red zone IS seen

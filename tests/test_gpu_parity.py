@@ -474,6 +474,33 @@ def test_ikala_pool_tie_modes():
     assert np.abs(a - b).max() > 1e-5
 
 
+def _run_children(child_src, args, envs, timeout=300, parallel=4, per_child_args=None):
+    """One fresh process per environment (the switches of libdcs are read once per process), `parallel` of them at a time on the
+    one GPU -- a child is ~3 s of interpreter + torch start-up around a fraction of a second of kernels, so running the variants
+    of a test side by side is what keeps the suite short.  Every child must exit 0; the failing environments are reported."""
+    import subprocess
+    pending, running, failed = list(enumerate(envs)), [], []
+    while pending or running:
+        while pending and len(running) < parallel:
+            i, env = pending.pop(0)
+            child_env = dict(os.environ)
+            child_env.update(env)
+            extra = list(per_child_args[i]) if per_child_args else []        # e.g. the child's own output file
+            running.append((env, subprocess.Popen([sys.executable, "-c", child_src] + [str(a) for a in list(args) + extra], env=child_env,
+                                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        env, proc = running.pop(0)
+        try:
+            out, err = proc.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            out, err = proc.communicate()
+            failed.append((env, "timeout", out[-400:], err[-800:]))
+            continue
+        if proc.returncode != 0:
+            failed.append((env, proc.returncode, out[-400:], err[-800:]))
+    assert not failed, failed
+
+
 _IKALA_POOL_CHILD = """
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
@@ -496,9 +523,7 @@ sys.exit(0 if worst < 1e-4 else 3)
 _IKALA_POOL_CASE = {}
 
 
-@pytest.mark.parametrize("env", [{}, {"DCS_POOL_FUSED": "0"}, {"DCS_POOL_FUSED": "0", "DCS_CONV1_REG": "0"},
-                                 {"DCS_DECONV1_REG": "0"}])
-def test_ikala_pool_fused_and_separate_kernels_agree_with_the_oracle(env, tmp_path):
+def test_ikala_pool_fused_and_separate_kernels_agree_with_the_oracle(tmp_path):
     """The iKala graph's max-pool runs inside conv1 and its VJP inside conv1^T by default (routing bits instead of the
     full-resolution activations); DCS_POOL_FUSED=0 (or either register kernel switched off) takes the four separate
     kernels.  Both against the oracle for both tie routings, on tiles with digital-silence rows and a silent band (every
@@ -521,11 +546,8 @@ def test_ikala_pool_fused_and_separate_kernels_agree_with_the_oracle(env, tmp_pa
                                                                    inverse='explicit').numpy()
     f = tmp_path / "case.npz"
     np.savez(f, **_IKALA_POOL_CASE)
-    child_env = dict(os.environ)
-    child_env.update(env)
-    r = subprocess.run([sys.executable, "-c", _IKALA_POOL_CHILD, ROOT, str(f)], env=child_env, capture_output=True, text=True,
-                       timeout=200)
-    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
+    _run_children(_IKALA_POOL_CHILD, [ROOT, f], [{}, {"DCS_POOL_FUSED": "0"}, {"DCS_POOL_FUSED": "0", "DCS_CONV1_REG": "0"},
+                                                 {"DCS_DECONV1_REG": "0"}], timeout=200)
 
 
 def test_generic_chunked_batch_equals_small_batches():
@@ -922,15 +944,11 @@ def test_whole_path_fallbacks_of_the_generic_graphs_agree(arch, ov, tmp_path):
     46 tiles in 6 chunks), must give the same PCM: the fused kernel is bit-compatible by construction, chunking only
     changes which GEMM variants the sizes select."""
     import subprocess
-    res = {}
-    for name, env in (("default", {}), ("two_kernels", {"DCS_MASK_OLA": "0"}), ("chunks", {"DCS_GENERIC_CHUNK": "8"})):
-        f = str(tmp_path / (name + ".npy"))
-        child_env = dict(os.environ)
-        child_env.update(env)
-        r = subprocess.run([sys.executable, "-c", _WHOLE_PATH_CHILD, ROOT, f, arch, "1024", str(ov)], env=child_env,
-                           capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-800:])
-        res[name] = np.load(f)
+    jobs = (("default", {}), ("two_kernels", {"DCS_MASK_OLA": "0"}), ("chunks", {"DCS_GENERIC_CHUNK": "8"}))
+    files = {name: str(tmp_path / (name + ".npy")) for name, _ in jobs}
+    # (the child takes its output file first: the shared arguments follow)
+    _run_children(_WHOLE_PATH_CHILD, [ROOT], [env for _, env in jobs], per_child_args=[[files[name], arch, "1024", str(ov)] for name, _ in jobs])
+    res = {name: np.load(files[name]) for name, _ in jobs}
     assert np.max(np.abs(res["default"])) > 1e-3
     assert np.array_equal(res["default"], res["two_kernels"])
     assert np.max(np.abs(res["default"] - res["chunks"])) < 5e-6
@@ -1038,9 +1056,8 @@ sys.exit(0 if err < 1e-4 else 3)
 """
 
 
-@pytest.mark.parametrize("env", [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}, {"DCS_SLABCONV_PS": "0"}])
 @pytest.mark.parametrize("F,n", [(513, 9), (1025, 3)])
-def test_ikala_conv2_kernels_agree_with_the_oracle(env, F, n, tmp_path):
+def test_ikala_conv2_kernels_agree_with_the_oracle(F, n, tmp_path):
     """conv2 of the iKala graph (10 x 20) and its transpose: slab kernel on the bf16 matrix pipe with the slab pre-split
     into bf16 planes (default, slabconv_ps.hip: tap loop driven by per-block bit masks), the one that splits per tap
     (DCS_SLABCONV_PS=0) and the implicit-GEMM fallback, on batch sizes that give several row bands per image."""
@@ -1049,11 +1066,7 @@ def test_ikala_conv2_kernels_agree_with_the_oracle(env, F, n, tmp_path):
     want = net_ref.forward("ikala", synth_params("ikala", 30, F, seed=4), x.astype(np.float64), inverse='explicit').numpy()
     f = tmp_path / "case.npz"
     np.savez(f, x=x, want=want, F=F)
-    child_env = dict(os.environ)
-    child_env.update(env)
-    r = subprocess.run([sys.executable, "-c", _IKALA_CHILD, ROOT, str(f)], env=child_env, capture_output=True, text=True,
-                       timeout=200)
-    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
+    _run_children(_IKALA_CHILD, [ROOT, f], [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}, {"DCS_SLABCONV_PS": "0"}], timeout=200)
 
 
 _GENERIC_CASE = []
@@ -1077,15 +1090,17 @@ sys.exit(0 if err < (2e-3 if f16 else 1e-4) else 3)
 """
 
 
-@pytest.mark.parametrize("env", [{"DCS_GENERIC_CHUNK": "8"}, {"DCS_GEMM_KSPLIT": "0"}, {"DCS_GEMM_KSPLIT": "5"},
+_GENERIC_ENVS = [{"DCS_GENERIC_CHUNK": "8"}, {"DCS_GEMM_KSPLIT": "0"}, {"DCS_GEMM_KSPLIT": "5"},
                                  {"DCS_GEMM_KSPLIT": "64"},
                                  {"DCS_COLCONV": "0"}, {"DCS_GEMM_BF16": "0"},
                                  {"DCS_CONV1_MFMA": "0"}, {"DCS_CONV1_MFMA": "0", "DCS_CONV1_REG": "0"}, {"DCS_DECONV1_MFMA": "0"},
                                  {"DCS_DECONV1_MFMA": "0", "DCS_DECONV1_REG": "0"},
                                  {"DCS_TEST_F16": "1"}, {"DCS_TEST_F16": "1", "DCS_DECODER_FUSED": "0"},
                                  {"DCS_TEST_F16": "1", "DCS_COLCONV_WREG": "0"},
-                                 {"DCS_TEST_F16": "1", "DCS_GENERIC_CHUNK": "8"}])
-def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
+                                 {"DCS_TEST_F16": "1", "DCS_GENERIC_CHUNK": "8"}]
+
+
+def test_generic_graph_variants_agree_with_the_oracle(tmp_path):
     """Scratch chunking, the K-split of the long dense layer (register- and LDS-tiled), the column convolution and the
     register-blocked transposed conv1 all have a fallback or a size rule; force each on a 52-tile Bach10 batch (fresh
     process) and compare the network output with the oracle.  DCS_TEST_F16=1 (read by the child, not by libdcs) turns the
@@ -1100,11 +1115,7 @@ def test_generic_graph_variants_agree_with_the_oracle(env, tmp_path):
     x, want = _GENERIC_CASE[0]
     f = tmp_path / "case.npz"
     np.savez(f, x=x, want=want, F=F)
-    child_env = dict(os.environ)
-    child_env.update(env)
-    r = subprocess.run([sys.executable, "-c", _GENERIC_CHILD, ROOT, str(f)], env=child_env, capture_output=True,
-                       text=True, timeout=200)
-    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
+    _run_children(_GENERIC_CHILD, [ROOT, f], _GENERIC_ENVS, timeout=200)
 
 
 _CL_CHILD = r"""
@@ -1142,14 +1153,10 @@ def test_channels_last_dense_output_feeds_the_fused_decoder(tmp_path):
     f = tmp_path / "case.npz"
     np.savez(f, x=x, F=F)
     res = {}
-    for name, env in (("h16", {}), ("cf", {"DCS_DECODER_CL": "0"}), ("nox3", {"DCS_DECODER_X3": "0"}), ("f32fc", {"DCS_GEMM_KSPLIT": "40"})):
-        child_env = dict(os.environ)
-        child_env.update(env)
-        out = str(tmp_path / (name + ".npz"))
-        r = subprocess.run([sys.executable, "-c", _CL_CHILD, ROOT, str(f), out], env=child_env, capture_output=True, text=True,
-                           timeout=300)
-        assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-1500:])
-        res[name] = np.load(out)
+    jobs = (("h16", {}), ("cf", {"DCS_DECODER_CL": "0"}), ("nox3", {"DCS_DECODER_X3": "0"}), ("f32fc", {"DCS_GEMM_KSPLIT": "40"}))
+    outs = {name: str(tmp_path / (name + ".npz")) for name, _ in jobs}
+    _run_children(_CL_CHILD, [ROOT, f], [env for _, env in jobs], per_child_args=[[outs[name]] for name, _ in jobs], parallel=2)
+    res = {name: np.load(outs[name]) for name, _ in jobs}
     # round 6: under the f16 switch the dense layers themselves run on f16 weights and write D as f16, channels-last, 32 channels
     # per position (gemm_f16.hip).  DCS_DECODER_CL=0 keeps the round-4 form: f32-class dense layers, channel-first D, the same
     # decoder -- the same f16 convolutions behind different dense arithmetic: both inside the stated 2e-3, 2.4e-5 apart
@@ -1209,14 +1216,10 @@ def test_scoreinformed_decoder_runs_on_the_fused_three_way_split_kernel(tmp_path
     f = tmp_path / "case.npz"
     np.savez(f, x=x, F=F)
     res = {}
-    for name, env in (("x3", {}), ("two", {"DCS_DECODER_X3": "0"})):
-        child_env = dict(os.environ)
-        child_env.update(env)
-        out = str(tmp_path / (name + ".npz"))
-        r = subprocess.run([sys.executable, "-c", _SI_X3_CHILD, ROOT, str(f), out], env=child_env, capture_output=True, text=True,
-                           timeout=600)
-        assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-1500:])
-        res[name] = np.load(out)
+    jobs = (("x3", {}), ("two", {"DCS_DECODER_X3": "0"}))
+    outs = {name: str(tmp_path / (name + ".npz")) for name, _ in jobs}
+    _run_children(_SI_X3_CHILD, [ROOT, f], [env for _, env in jobs], timeout=600, per_child_args=[[outs[name]] for name, _ in jobs], parallel=2)
+    res = {name: np.load(outs[name]) for name, _ in jobs}
     scale = max(1.0, float(np.max(np.abs(want))))
     for n in (140, 128, 300, 64):
         k = "n%d" % n
@@ -1229,7 +1232,7 @@ def test_scoreinformed_decoder_runs_on_the_fused_three_way_split_kernel(tmp_path
     assert float(res["two"]["decoder_ms"]) == 0 and float(res["two"]["deconv2_ms"]) > 0    # two kernels
 
 
-@pytest.mark.parametrize("env", [
+_VARIANT_ENVS = [
     {"DCS_FINAL_CBW": "2"}, {"DCS_FINAL_CBW": "1"},               # 128-bin workgroups (bf16x3 kernel, G split by a pass) / 64-bin (f32)
     {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2"},                   # bf16x3 kernel fed by the streaming deconv2 (writes the planes)
     {"DCS_DECONV2": "2"}, {"DCS_DECONV2": "1"},                   # streaming / one-shot transposed conv2
@@ -1239,19 +1242,17 @@ def test_scoreinformed_decoder_runs_on_the_fused_three_way_split_kernel(tmp_path
     {"DCS_ISTFT_STAGE_MIN": "1"},                                  # spectra through LDS (long clips' iSTFT) on a short clip
     {"DCS_ISTFT_STAGE": "0"},
     {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "7"},   # chained iSTFT off / forced frames per wave
-])
-def test_kernel_variants_selected_by_size_agree_with_the_oracle(env, tmp_path):
+]
+
+
+def test_kernel_variants_selected_by_size_agree_with_the_oracle(tmp_path):
     """The launchers pick kernel variants by problem size; the debugging switches force each variant on the
     same 3 s clip at both frame sizes (fresh process: the switches are read once) and every one must meet the parity bar."""
     import subprocess
     audio, want = _variant_case()
     f = tmp_path / "case.npz"
     np.savez(f, audio=audio, want1024=want[1024], want2048=want[2048])
-    child_env = dict(os.environ)
-    child_env.update(env)
-    r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, ROOT, str(f)], env=child_env, capture_output=True,
-                       text=True, timeout=200)
-    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
+    _run_children(_VARIANT_CHILD, [ROOT, f], _VARIANT_ENVS, timeout=200)
 
 
 _VARIANT_CASE = []
@@ -1313,10 +1314,12 @@ sys.exit(0 if ok else 3)
 _STAGED_CASE = []
 
 
-@pytest.mark.parametrize("env", [{"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE": "0"},
+_STAGED_ENVS = [{"DCS_ISTFT_STAGE_MIN": "1"}, {"DCS_ISTFT_STAGE": "0"},
                                  {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "5"},   # chained iSTFT: off, forced run lengths (seams at other places)
-                                 ])
-def test_staged_istft_on_ragged_groups_and_batches(env, tmp_path):
+                                 ]
+
+
+def test_staged_istft_on_ragged_groups_and_batches(tmp_path):
     """The LDS-staged inverse STFT (normally long clips only) forced onto short ones: a ragged group (per-clip frame counts
     from the device table: the four waves of a workgroup must still walk the same frames), an equal-length batch and single
     clips agree with each other, and a single clip with the oracle.  DCS_ISTFT_STAGE=0: the same with the plain loads."""
@@ -1328,11 +1331,7 @@ def test_staged_istft_on_ragged_groups_and_batches(env, tmp_path):
     a, want2 = _STAGED_CASE[0]
     f = tmp_path / "case.npz"
     np.savez(f, a0=a[0], a1=a[1], a2=a[2], want2_1024=want2[1024], want2_2048=want2[2048])
-    child_env = dict(os.environ)
-    child_env.update(env)
-    r = subprocess.run([sys.executable, "-c", _STAGED_CHILD, ROOT, str(f)], env=child_env, capture_output=True, text=True,
-                       timeout=300)
-    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])
+    _run_children(_STAGED_CHILD, [ROOT, f], _STAGED_ENVS, timeout=300)
 
 
 @pytest.mark.parametrize("kind", ["glorot", "sparse", "tiny"])
@@ -1355,15 +1354,11 @@ def test_bf16x3_final_kernel_meets_the_parity_bar(kind, tmp_path):
     f = tmp_path / "case.npz"
     np.savez(f, audio=audio, N=N, n_params=len(params), **{"p%d" % i: p for i, p in enumerate(params)})
     res = {}
-    for name, env in (("bf16x3", {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2"}),
-                      ("f32", {"DCS_FINAL_CBW": "1", "DCS_DECONV2": "2"})):          # the f32-MFMA kernel (64-bin workgroups)
-        child_env = dict(os.environ)
-        child_env.update(env)
-        o1, o2 = str(tmp_path / (name + "_sep.npy")), str(tmp_path / (name + "_pcm.npy"))
-        r = subprocess.run([sys.executable, "-c", _BF16X3_CHILD, ROOT, str(f), o1, o2], env=child_env, capture_output=True,
-                           text=True, timeout=300)
-        assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-800:])
-        res[name] = (np.load(o1), np.load(o2))
+    jobs = (("bf16x3", {"DCS_FINAL_CBW": "2", "DCS_DECONV2": "2"}),
+            ("f32", {"DCS_FINAL_CBW": "1", "DCS_DECONV2": "2"}))                     # the f32-MFMA kernel (64-bin workgroups)
+    outs = {name: (str(tmp_path / (name + "_sep.npy")), str(tmp_path / (name + "_pcm.npy"))) for name, _ in jobs}
+    _run_children(_BF16X3_CHILD, [ROOT, f], [env for _, env in jobs], per_child_args=[list(outs[name]) for name, _ in jobs], parallel=2)
+    res = {name: (np.load(outs[name][0]), np.load(outs[name][1])) for name, _ in jobs}
     sep16, pcm16 = res["bf16x3"]
     sep32, pcm32 = res["f32"]
     assert np.max(np.abs(pcm16 - want)) < 1e-4
