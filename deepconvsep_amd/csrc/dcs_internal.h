@@ -249,6 +249,7 @@ struct DcsGemmBranches {         // (B planes, bias, C) of up to 4 GEMMs that sh
 };
 bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemmBranches* br);   // false: not taken
 bool dcs_launch_gemm_bf16x3_longk(dcs_ctx* ctx, const DcsGemm& g);                                   // false: not taken
+void dcs_launch_gemm_longk_reduce(dcs_ctx* ctx, const DcsGemm& q, int ksplit);                       // slices of q.partial added in order, bias, rectifier
 // A [M][K] f32 (lda) -> bf16 x 3 planes for DcsGemm::Aq: [(K + 31) / 32][3][rows_pad][4] 16-byte pieces, rows >= M and k >= K zero
 size_t dcs_gemm_aq_bytes(int K, int rows_pad);
 int dcs_gemm_split_a(dcs_ctx* ctx, const float* A_d, int64_t lda, int64_t M, int K, int rows_pad, void* Aq_d);

@@ -487,6 +487,12 @@ bool dcs_launch_gemm_bf16x3_longk(dcs_ctx* ctx, const DcsGemm& g) {
     return true;
 }
 
+// the second pass alone (the f16 long-K kernel of gemm_f16.hip leaves its slices in the same layout): q.partial, q.M, q.n_cols, q.n_store,
+// q.bias, q.relu, q.C / ldc / c_gdiv / c_gmul
+void dcs_launch_gemm_longk_reduce(dcs_ctx* ctx, const DcsGemm& q, int ksplit) {
+    hipLaunchKernelGGL(gemm_longk_reduce_kernel, dim3((unsigned)dcs_cdiv(q.M * q.n_cols, 64)), dim3(kThreads), 0, ctx->stream, q, ksplit);
+}
+
 size_t dcs_gemm_bq_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * 3 * (size_t)n_cols * 4 * 16; }
 
 int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d, int perm_c, int perm_p) {

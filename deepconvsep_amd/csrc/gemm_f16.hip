@@ -185,6 +185,116 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_skinny_kernel(const DcsG
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The bottleneck layer under the f16 switch (128 .. 176 rows x K = 166 650 x 256): f16 weights (one plane, 85 MB instead of the
+// 256 MB of bf16 planes), the f32 rows of A (conv2's output) split into two f16 terms ON THEIR WAY into LDS, K cut into slices
+// (blockIdx.z; raw f32 sums per slice, then gemm_longk_reduce of gemm_bf16x3.hip adds the slices in order).  Same shape as the
+// all-rows kernel above with four column blocks' worth of rows per workgroup.
+// ------------------------------------------------------------------------------------------------
+struct DcsGemmF16LongK {
+    const float* A; int64_t lda; int M, K;        // K % 4 == 0, rows 16-byte aligned
+    const u32x4* Bh; int n_cols;                  // f16 plane [k tile][n_cols][4 pieces]; n_cols a multiple of 128
+    float* partial;                               // [slices][M][n_cols]
+    int kts;                                      // k tiles per slice
+};
+
+template <int RBT>
+__global__ __launch_bounds__(kThreads, 2) void gemm_f16_longk_kernel(const DcsGemmF16LongK g) {
+    constexpr int CB = 2, ROWS = RBT * 16, CW = CB * 16;
+    constexpr int kPlane = ROWS * kRowU4;
+    __shared__ u32x4 As[2 * kPlane];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int fi = lane & 15, kq = lane >> 4;
+    const int n_cols = g.n_cols, gK = g.K;
+    const int nkt_all = (gK + 31) / 32;
+    const int kt_lo = (int)blockIdx.z * g.kts;
+    const int nkt = kt_lo + g.kts < nkt_all ? kt_lo + g.kts : nkt_all;
+    const int n0 = (blockIdx.x * 4 + wave) * CW;
+    constexpr int A_PER = (ROWS * 4 + kThreads - 1) / kThreads;
+    const float* a_ptr[A_PER];
+    bool a_ok[A_PER];
+    int a_dst[A_PER], a_k0[A_PER];
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        const int idx = tid + u * kThreads;
+        const int row = idx >> 2, q = idx & 3;
+        a_ok[u] = idx < ROWS * 4 && row < g.M;
+        a_ptr[u] = g.A + (int64_t)(a_ok[u] ? row : 0) * g.lda;
+        a_k0[u] = q * 8;
+        a_dst[u] = idx < ROWS * 4 ? row * kRowU4 + q : -1;
+    }
+    const u32x4* Bl = g.Bh + ((int64_t)(n0 + (fi >> 2) * (4 * CB) + (fi & 3))) * 4 + kq;
+    const int64_t b_kt = (int64_t)n_cols * 4;
+    f32x4 ra[A_PER][2];
+    int ra_k[A_PER];
+    u32x4 bn[CB], bc[CB];
+    // unconditional loads (rows past M read row 0, k past K reads the last four of the row), masked at the split
+#define DCS_LOAD(kt_)                                                                                   \
+    {                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                             \
+            const int k = (kt_) * 32 + a_k0[u];                                                         \
+            ra[u][0] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k < gK ? k : gK - 4));               \
+            ra[u][1] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k + 4 < gK ? k + 4 : gK - 4));       \
+            ra_k[u] = k;                                                                                \
+        }                                                                                               \
+        _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) bn[cb] = Bl[(kt_) * b_kt + cb * 16];          \
+    }
+    f32x4 acc[RBT][CB];
+#pragma unroll
+    for (int r = 0; r < RBT; ++r)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[r][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    DCS_LOAD(kt_lo)
+    for (int kt = kt_lo; kt < nkt; ++kt) {
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u)
+            if (a_dst[u] >= 0) {
+                const float s0 = (a_ok[u] && ra_k[u] < gK) ? 1.f : 0.f, s1 = (a_ok[u] && ra_k[u] + 4 < gK) ? 1.f : 0.f;
+                f16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = j < 4 ? ra[u][0][j] * s0 : ra[u][1][j - 4] * s1;
+                    hi[j] = (_Float16)x;
+                    lo[j] = (_Float16)(x - (float)hi[j]);
+                }
+                As[a_dst[u]] = __builtin_bit_cast(u32x4, hi);
+                As[kPlane + a_dst[u]] = __builtin_bit_cast(u32x4, lo);
+            }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) bc[cb] = bn[cb];
+        __syncthreads();
+        {
+            const int ktn = kt + 1 < nkt ? kt + 1 : kt;
+            DCS_LOAD(ktn)
+        }
+        const u32x4* Ab = As + fi * kRowU4 + kq;
+#pragma unroll
+        for (int r = 0; r < RBT; ++r) {
+            const u32x4 a_hi = Ab[r * 16 * kRowU4], a_lo = Ab[kPlane + r * 16 * kRowU4];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                f32x4 c = acc[r][cb];
+                c = mma(bc[cb], a_lo, c);
+                c = mma(bc[cb], a_hi, c);
+                acc[r][cb] = c;
+            }
+        }
+        __syncthreads();
+    }
+#undef DCS_LOAD
+    const int c0 = n0 + kq * (4 * CB);
+#pragma unroll
+    for (int r = 0; r < RBT; ++r) {
+        const int row = r * 16 + fi;
+        if (row < g.M) {
+            float* pp = g.partial + ((int64_t)blockIdx.z * g.M + row) * n_cols + c0;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<f32x4*>(pp + cb * 4) = acc[r][cb];
+        }
+    }
+}
+
 }  // namespace
 
 size_t dcs_gemm_bh_bytes(int K, int n_out) { return (size_t)((K + 31) / 32) * (size_t)n_out * 4 * 16; }
@@ -227,5 +337,35 @@ bool dcs_launch_gemm_f16_skinny(dcs_ctx* ctx, const float* Z, int64_t ldz, int M
     const dim3 grid((unsigned)(n_cols / 128), (unsigned)n_br);
     if (rows_pad == 128) hipLaunchKernelGGL((gemm_f16_skinny_kernel<8>), grid, dim3(kThreads), 0, ctx->stream, g);
     else hipLaunchKernelGGL((gemm_f16_skinny_kernel<11>), grid, dim3(kThreads), 0, ctx->stream, g);
+    return true;
+}
+
+// B f32 [K][ldb] in its own column order -> one f16 plane [k tile][n_cols][4 pieces] (gemm_pack_bh_kernel with one "channel")
+int dcs_gemm_pack_bh_plain(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bh_d) {
+    return dcs_gemm_pack_bh(ctx, B_d, K, ldb, n_cols, 1, n_cols, 1, Bh_d);
+}
+
+// raw sums of the K slices into `partial` ([slices][M][n_cols] floats; the caller sized it with dcs_gemm_f16_longk_slices and runs
+// the reduce pass).  Returns the slice count, 0: not taken.
+int dcs_gemm_f16_longk_slices(const dcs_ctx* ctx, int M, int K, int n_cols) {
+    if (M < 128 || M > 176 || (n_cols % 128) || n_cols > 1024 || K < 16384 || (K & 3)) return 0;
+    const int col_wgs = n_cols / 128, nkt = (K + 31) / 32;
+    int ksplit = (int)((2 * (int64_t)ctx->n_cu + col_wgs - 1) / col_wgs);
+    if (ksplit > nkt) ksplit = nkt;
+    const int kts = (nkt + ksplit - 1) / ksplit;
+    ksplit = (nkt + kts - 1) / kts;
+    return ksplit < 2 ? 0 : ksplit;
+}
+
+bool dcs_launch_gemm_f16_longk(dcs_ctx* ctx, const float* A, int64_t lda, int M, int K, int n_cols, const void* Bh, float* partial) {
+    const int ksplit = dcs_gemm_f16_longk_slices(ctx, M, K, n_cols);
+    if (ksplit < 2 || !Bh || !partial || (lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) return false;
+    const int nkt = (K + 31) / 32;
+    DcsGemmF16LongK g{};
+    g.A = A; g.lda = lda; g.M = M; g.K = K; g.Bh = reinterpret_cast<const u32x4*>(Bh); g.n_cols = n_cols; g.partial = partial;
+    g.kts = (nkt + ksplit - 1) / ksplit;
+    const dim3 grid((unsigned)(n_cols / 128), 1, (unsigned)ksplit);
+    if (M <= 128) hipLaunchKernelGGL((gemm_f16_longk_kernel<8>), grid, dim3(kThreads), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((gemm_f16_longk_kernel<11>), grid, dim3(kThreads), 0, ctx->stream, g);
     return true;
 }

@@ -67,6 +67,9 @@ bool dcs_decoder_fused_ok(const DcsColConv& a, int F);
 size_t dcs_gemm_bh_bytes(int K, int n_out);
 int dcs_gemm_pack_bh(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_out, int nch, int npos, int chpad, void* Bh_d);
 int dcs_gemm_pack_bias_cl(dcs_ctx* ctx, const float* bias_d, int n_out, int nch, int npos, int chpad, float* out_d);
+int dcs_gemm_pack_bh_plain(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bh_d);   // B in its own column order
+int dcs_gemm_f16_longk_slices(const dcs_ctx* ctx, int M, int K, int n_cols);                          // 0: the shape is not the long-K kernel's
+bool dcs_launch_gemm_f16_longk(dcs_ctx* ctx, const float* A, int64_t lda, int M, int K, int n_cols, const void* Bh, float* partial);
 bool dcs_launch_gemm_f16_skinny(dcs_ctx* ctx, const float* Z, int64_t ldz, int M, int K, int n_cols, int n_br, const void* const* Bh,
                                 const float* const* bias, void* const* C, int64_t ldc, void* Ah_scratch);
 // in_channels_last: a.in is [image][H][W][Cin] (the dense layer wrote a position's channels together) instead of [image][Cin][H][W]

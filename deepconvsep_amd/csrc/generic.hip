@@ -1310,6 +1310,8 @@ struct DcsGenericNet {
     bool bdq_cl = false;                                         // column order the bf16 planes Bdq are packed in
     // f16 switch with the fused decoder (gemm_f16.hip): the same weights as ONE f16 plane, columns [position][32 channels]
     // (30 real), their biases in that order; n_out16 columns per branch (a multiple of 128); made on first need
+    void* Bfch = nullptr;                                        // the bottleneck weights as one f16 plane (long-K launches under the switch)
+    bool bfch_failed = false;
     void* Bdh[4] = {nullptr, nullptr, nullptr, nullptr};
     float* biasd_h[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_out16 = 0;
@@ -1566,7 +1568,7 @@ void dcs_generic_destroy(DcsGenericNet* g) {
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3], g->biasd_cl[0], g->biasd_cl[1],
                     g->biasd_cl[2], g->biasd_cl[3], g->Wx3, g->Bfcq, g->Wfx3, g->Bdh[0], g->Bdh[1], g->Bdh[2], g->Bdh[3], g->biasd_h[0],
-                    g->biasd_h[1], g->biasd_h[2], g->biasd_h[3]};
+                    g->biasd_h[1], g->biasd_h[2], g->biasd_h[3], g->Bfch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1818,7 +1820,8 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         // slices (dcs_launch_gemm_bf16x3_longk) -- the planes (1.5 x the f32 weights) are made on first need; without them,
         // or for any other row count, the f32 K-split of gemm.hip
         static const bool fcq_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
-        if (fcq_on && n >= 128 && n <= 176 && g->flat_p >= 16384 && (g->hid64 % 128) == 0 && !g->Bfcq && !g->bfcq_failed) {
+        if (fcq_on && n >= 128 && n <= 176 && g->flat_p >= 16384 && (g->hid64 % 128) == 0 && !g->Bfcq && !g->bfcq_failed &&
+            (!g->conv_f16 || g->bfch_failed)) {           // (under the f16 switch the layer takes the f16 plane below instead)
             void* planes = nullptr;
             if (hipMalloc(&planes, dcs_gemm_bq_bytes(g->flat_p, g->hid64)) != hipSuccess) {
                 (void)hipGetLastError();
@@ -1833,7 +1836,38 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             }
         }
         q.Bq = g->Bfcq;
-        DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC));
+        // f16 switch: the same long-K launch on f16 weights (gemm_f16.hip: one plane, 2 bytes per weight instead of 6; the rows
+        // of A split into two f16 terms on their way into LDS), slices added by the same second pass
+        bool fc16 = false;
+        const int ks16 = (fcq_on && g->conv_f16 && !g->bfch_failed) ? dcs_gemm_f16_longk_slices(ctx, (int)n, g->flat_p, g->hid64) : 0;
+        if (ks16 >= 2) {
+            if (!g->Bfch) {
+                void* plane = nullptr;
+                if (hipMalloc(&plane, dcs_gemm_bh_bytes(g->flat_p, g->hid64)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    g->bfch_failed = true;
+                } else {
+                    const int rc = dcs_gemm_pack_bh_plain(ctx, g->Bfc, g->flat_p, g->hid64, g->hid64, plane);
+                    if (rc != DCS_OK) {
+                        (void)hipFree(plane);
+                        return rc;
+                    }
+                    g->Bfch = plane;
+                }
+            }
+            if (g->Bfch && ctx->gemm_ws.ensure((size_t)ks16 * n * g->hid64 * sizeof(float)) == DCS_OK) {
+                DcsTimer tm(ctx, DCS_TAG_FC);
+                fc16 = dcs_launch_gemm_f16_longk(ctx, a2b, g->flat_p, (int)n, g->flat_p, g->hid64, g->Bfch, (float*)ctx->gemm_ws.ptr);
+                if (fc16) {
+                    DcsGemm r = q;
+                    r.partial = (float*)ctx->gemm_ws.ptr;
+                    dcs_launch_gemm_longk_reduce(ctx, r, ks16);
+                    tm.done();
+                } else
+                    tm.cancel();
+            }
+        }
+        if (!fc16) DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC));
     }
     // per-source dense (rectify): D[n][branch][flat_p]; aliased branches (none in these graphs) would reuse a layer
     if (g->flat_p != d.flat)
