@@ -64,7 +64,7 @@ FINAL_NAMES = {"one_batch": "lat_final_kernel (deconv1+bias+relu+mask+crossfade 
                "bf16x3": "final_bf16x3_kernel (deconv1+bias+relu+mask+crossfade; bf16 MFMA on operands split into "
                          "three bf16 terms, six products kept, f32 accumulation: f32-class results)"}
 PEAK_HBM_GBPS = 8000.0
-TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_traffic.json")
 # which kernel carries a timing tag in each leg (substring of the kernel name in the rocprofv3 counter files); used to look
 # up the HBM traffic record of a leg's kernels in TRAFFIC_FILE["legs"][leg]
 LEG_KERNELS = {
@@ -72,21 +72,24 @@ LEG_KERNELS = {
     # (84 tiles: both dense layers run on gemm_rows_kernel -- the bottleneck K-split over 424 workgroups, the per-source layer 1890)
     "ikala": {"conv1": "conv1_reg_kernel", "conv2": ("slabconv_ps_kernel", "min"), "deconv2": "slabconv_ps_kernel",
               "fc": "gemm_rows_kernel@grid_threads=108544", "fc1x": "gemm_rows_kernel@grid_threads=483840", "final": "deconv1_reg_kernel"},
-    # (the bottleneck layer is the all-rows bf16 x 3 kernel with K cut into 256 slices: 2 x 248 workgroups; the per-source layers
-    # are the same kernel at its widest grid)
+    # (f16 switch, round 6: the dense layers on f16 weight planes, gemm_f16.hip -- the bottleneck layer with K cut into slices, the
+    # per-source layers writing D as f16 channels-last for the fused decoder)
     "bach10_f16": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_wreg_scatter_kernel", "decoder": "colconv_deconv1_fused_kernel",
-                   "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel"},
-    "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel",
+                   "fc": "gemm_f16_longk_kernel", "fc1x": "gemm_f16_skinny_kernel"},
+    # (f32-class graphs: the bottleneck layer is the all-rows bf16 x 3 kernel with K cut into 256 slices: 2 x 248 workgroups; the
+    # per-source layers are the same kernel at its widest grid; conv2 = colconv_fwd_x3_kernel since round 6)
+    "score_informed": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_fwd_x3_kernel", "deconv2": "colconv_kernel",
                        "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel",
                        "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
-    "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "slabconv_ps_kernel", "deconv2": "colconv_kernel",
+    "bach10_f32": {"conv1": "conv1_mfma_kernel", "conv2": "colconv_fwd_x3_kernel", "deconv2": "colconv_kernel",
                    "fc": "gemm_bf16x3_skinny_kernel@grid_threads=126976", "fc1x": "gemm_bf16x3_skinny_kernel",
                    "final": "deconv1_mfma_kernel", "decoder": "colconv_deconv1_fused_x3_kernel"},
 }
 # kernels that execute on the 16-bit matrix pipe: (products issued per f32 product, K padding factor)
 LEG_ISSUED = {
     "ikala": {"conv2": (6, 32.0 / 30.0), "deconv2": (6, 32.0 / 30.0)},   # 84 tiles: the dense layers stay on the f32 MFMA (M < 128)
-    "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc": (6, 1.0), "fc1x": (6, 1.0)},
+    # (f16 dense layers: the rows as two f16 terms x one f16 weight plane = 2 products; 32 output channels per position for 30)
+    "bach10_f16": {"conv1": (6, 32.0 / 30.0), "conv2": (1, 32.0 / 30.0), "fc": (2, 1.0), "fc1x": (2, 32.0 / 30.0)},
     "score_informed": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc": (6, 1.0), "fc1x": (6, 1.0),
                        "decoder": (6, 32.0 / 30.0 * 120.0 / 110.0)},
     "bach10_f32": {"conv1": (6, 32.0 / 30.0), "conv2": (6, 32.0 / 30.0), "final": (6, 32.0 / 30.0), "fc": (6, 1.0), "fc1x": (6, 1.0),
@@ -233,9 +236,11 @@ def emit(line, detail_stdout=False, out=None):
     line, then print the compact headline as the last stdout line."""
     out = out or sys.stdout
     full = json.dumps(_finite(line), allow_nan=False)
-    try:
-        with open(os.path.join(ROOT, DETAIL_FILE), "w") as fh:
+    try:                                                # (temp file + rename: bench processes side by side never interleave)
+        tmp = os.path.join(ROOT, "%s.%d.tmp" % (DETAIL_FILE, os.getpid()))
+        with open(tmp, "w") as fh:
             fh.write(full + "\n")
+        os.replace(tmp, os.path.join(ROOT, DETAIL_FILE))
     except OSError:
         pass
     if detail_stdout:
@@ -1068,15 +1073,19 @@ def arch_work(arch, tc, F, n, f16):
     # kind: which unit executes the flops -- 'mfma' (matrix pipe) or 'valu' (register-blocked vector kernels: conv1_reg /
     # deconv1_reg of the stride-3 iKala graph); both have the 157.3 TFLOP/s f32 peak, the label says which one it is
     vec1 = 'valu' if arch.conv1[2] == 3 else 'mfma'
+    # f16 switch (BASELINE configs[3], SURVEY 8d "fp16: HBM on weights", 426.7 MB): the dense weights and the per-source layers'
+    # output D are 2 bytes per element since round 6 (gemm_f16.hip)
+    wb = 2.0 if f16 else 4.0
+    plane2_d = d['flat'] * wb
     return {
         "conv1": (n * conv1, n * (plane_in + conv1_out), PEAK_F32_TFLOPS, vec1),
         "conv2": (n * conv2, n * (plane1 + plane2), mfma16, 'mfma'),
-        "fc": (n * fc, d['flat'] * arch.hidden * 4.0 + n * (plane2 + arch.hidden * 4.0), PEAK_F32_TFLOPS, 'mfma'),
-        "fc1x": (n * NB * fc, NB * d['flat'] * arch.hidden * 4.0 + n * NB * plane2, PEAK_F32_TFLOPS, 'mfma'),
+        "fc": (n * fc, d['flat'] * arch.hidden * wb + n * (plane2 + arch.hidden * 4.0), mfma16 if f16 else PEAK_F32_TFLOPS, 'mfma'),
+        "fc1x": (n * NB * fc, NB * d['flat'] * arch.hidden * wb + n * NB * plane2_d, mfma16 if f16 else PEAK_F32_TFLOPS, 'mfma'),
         "deconv2": (n * NB * conv2, n * NB * (plane2 + plane1), mfma16, 'mfma'),
         "final": (n * NB * conv1, n * NB * (conv1_out + plane_in), PEAK_F32_TFLOPS, vec1),
         # both InverseLayers in one kernel: the activations between them never reach HBM
-        "decoder": (n * NB * (conv2 + conv1), n * NB * (plane2 + plane_in), mfma16, 'mfma'),
+        "decoder": (n * NB * (conv2 + conv1), n * NB * (plane2_d + plane_in), mfma16, 'mfma'),
     }
 
 

@@ -480,21 +480,31 @@ def _run_bench(n, extra, env_extra, timeout=900):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("impl,mode", [("dcs", "allgather"), ("dcs", "root"), ("torch", "allgather"), ("dcs", "root-serial")])
-def test_bench_gather_code_path_with_a_world_of_one_rank(impl, mode):
+def test_bench_gather_code_path_with_a_world_of_one_rank():
     """What a 1-GPU box can run of the N > 1 leg on the REAL backend: DCS_BENCH_FORCE_GATHER makes bench.py --gpus 1 convert
     every launch group's PCM to int16 and push it through the collective of a one-rank world -- with --gather-impl dcs that is
-    dcs_gather (the C-ABI entry of SURVEY 8b) on an RCCL communicator per HIP stream, inside the timed region."""
-    serial = mode.endswith("-serial")                   # --no-pipeline: the one-group, one-stream schedule of rounds 2 - 5
-    mode = mode.split("-")[0]
-    line = _run_bench(1, ["--gather", mode, "--gather-impl", impl] + (["--no-pipeline"] if serial else []),
-                      {"DCS_BENCH_FORCE_GATHER": "1", "DCS_BENCH_CHECK_GATHER": "1"})
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["gather_check"] == "ok"
-    assert line["gather"]["pipelined_half_groups"] is (not serial)
-    assert line["config"]["launch_groups_per_round"] == ([6] if serial else [3, 3])
-    assert line["gather"]["mode"] == mode and line["gather"]["impl"].startswith("dcs_gather" if impl == "dcs" else "torch.distributed")
-    assert line["gather"]["ms_per_group_collective_alone"] > 0
-    assert line["parity_check"]["ok"] is True
+    dcs_gather (the C-ABI entry of SURVEY 8b) on an RCCL communicator per HIP stream, inside the timed region.  Four variants
+    (all-gather / root through dcs_gather, all-gather through torch.distributed, and the serial one-group schedule of rounds
+    2 - 5 with --no-pipeline), four bench.py processes side by side."""
+    variants = [("dcs", "allgather", False), ("dcs", "root", False), ("torch", "allgather", False), ("dcs", "root", True)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DCS_BENCH_FORCE_GATHER="1", DCS_BENCH_CHECK_GATHER="1")
+    env.pop("DCS_BENCH_SAME_DEVICE", None)
+    procs = []
+    for impl, mode, serial in variants:
+        args = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--sat-tiles", "0", "--min-time", "0.02", "--legs", "", "--no-cpu-baseline",
+                "--no-host-fed", "--no-cli", "--gather", mode, "--gather-impl", impl] + (["--no-pipeline"] if serial else [])
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    for (impl, mode, serial), pr in zip(variants, procs):
+        out, err = pr.communicate(timeout=900)
+        assert pr.returncode == 0, (impl, mode, serial, out[-2000:], err[-4000:])
+        line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 1 and line["value"] > 0 and line["gather_check"] == "ok", (impl, mode, serial)
+        assert line["gather"]["pipelined_half_groups"] is (not serial)
+        assert line["config"]["launch_groups_per_round"] == ([6] if serial else [3, 3])
+        assert line["gather"]["mode"] == mode and line["gather"]["impl"].startswith("dcs_gather" if impl == "dcs" else "torch.distributed")
+        assert line["gather"]["ms_per_group_collective_alone"] > 0
+        assert line["parity_check"]["ok"] is True
 
 
 @needs_two_gpus
