@@ -38,6 +38,7 @@ runc() { name=$1; shift
 runc waves GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 runc insts GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
 cd $GRAFT_REPO_ROOT
+cp $OUT/traffic.json $OUT/r06_traffic.json     # (counters_summary.py writes a traffic.json of its own)
 python scripts/counters_summary.py $OUT > $OUT/r06_counters_summary_k20.txt 2>&1
 grep -v "^lat_" $OUT/r06_counters_summary_k20.txt | head -40
 find $OUT -name "*.db" -delete; find $OUT -path "*pmc_*" -name "*kernel_trace.csv" -delete; find $OUT -path "*prof_*" -name "*kernel_trace.csv" -delete
