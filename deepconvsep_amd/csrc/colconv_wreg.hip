@@ -150,7 +150,9 @@ __global__ __launch_bounds__(kThreads) void colconv_wreg_gather_kernel(const Dcs
 }
 
 // ---- scatter form: 'valid' convolution, input row r feeds output rows y = r - u, HO = H - KH + 1
-template <int KH, int H, int AHEAD /* input rows in flight */>
+// OUT16 (round 6): the output map as f16 (same [channel][row][x] order, g.out_n_stride in halves) -- the bottleneck layer of the
+// f16 switch multiplies f16 rows (gemm_f16_longk_kernel); half the bytes written here and read there.
+template <int KH, int H, int AHEAD /* input rows in flight */, bool OUT16 = false>
 __global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
                                                                         int64_t n_units) {
     constexpr int HO = H - KH + 1;
@@ -214,17 +216,34 @@ __global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const Dc
                 }
             }
         }
-        float* ob = g.out + img * g.out_n_stride + xb;
 #pragma unroll
         for (int y = 0; y < HO; ++y) {
             acc[y][0] += bias0;
             acc[y][1] += bias1;
         }
+        if constexpr (OUT16) {
+            typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));     // rows of W (odd) halves: 2-byte alignment
+            _Float16* ob = reinterpret_cast<_Float16*>(g.out) + img * g.out_n_stride + xb;
+#pragma unroll
+            for (int y = 0; y < HO; ++y) {
+                const h4u v = {(_Float16)acc[y][0][0], (_Float16)acc[y][0][1], (_Float16)acc[y][0][2], (_Float16)acc[y][0][3]};
+                *reinterpret_cast<h4u*>(ob + y * W + out_lane) = v;
+            }
+            if (c1_ok) {
+#pragma unroll
+                for (int y = 0; y < HO; ++y) {
+                    const h4u v = {(_Float16)acc[y][1][0], (_Float16)acc[y][1][1], (_Float16)acc[y][1][2], (_Float16)acc[y][1][3]};
+                    *reinterpret_cast<h4u*>(ob + (16 * HO + y) * W + out_lane) = v;
+                }
+            }
+        } else {
+        float* ob = g.out + img * g.out_n_stride + xb;
 #pragma unroll
         for (int y = 0; y < HO; ++y) *reinterpret_cast<f32x4u*>(ob + y * W + out_lane) = acc[y][0];
         if (c1_ok) {
 #pragma unroll
             for (int y = 0; y < HO; ++y) *reinterpret_cast<f32x4u*>(ob + (16 * HO + y) * W + out_lane) = acc[y][1];
+        }
         }
         img = img_n; xb = xb_n; li = li_n; ib = ib_n;
     }
@@ -463,9 +482,19 @@ void dcs_colconv_wreg_pack(const _Float16* Wh, int kh, std::vector<_Float16>* ou
                         Wh[((size_t)u * 32 + (lane & 15) + 16 * half) * 40 + (lane >> 4) * 8 + j];
 }
 
-bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq) {
+static bool wreg_on() {
     static const bool on = !(getenv("DCS_COLCONV_WREG") && atoi(getenv("DCS_COLCONV_WREG")) == 0);
+    return on;
+}
+
+bool dcs_colconv_wreg_scatter_ok(const DcsColConv& a) {
+    return wreg_on() && a.Cin <= 32 && a.Cout <= 32 && a.kh == 20 && a.W >= 16 && a.ph == 0 && a.H == 30 && a.Ho == 11;
+}
+
+bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq) {
+    const bool on = wreg_on();
     if (!on || !Wq || a.Cin > 32 || a.Cout > 32 || a.kh != 20 || a.W < 16) return false;
+    if (a.out_f16 && !dcs_colconv_wreg_scatter_ok(a)) return false;
     const int64_t n_units = n_images * a.n_xb;
     if (n_units <= 0) return true;
     const unsigned grid = (unsigned)std::min<int64_t>(dcs_cdiv(n_units, 4), ctx->n_cu);
@@ -475,7 +504,8 @@ bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images
         return true;
     }
     if (a.ph == 0 && a.H == 30 && a.Ho == 11) {
-        hipLaunchKernelGGL((colconv_wreg_scatter_kernel<20, 30, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, n_units);
+        if (a.out_f16) hipLaunchKernelGGL((colconv_wreg_scatter_kernel<20, 30, 8, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, n_units);
+        else hipLaunchKernelGGL((colconv_wreg_scatter_kernel<20, 30, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, n_units);
         return true;
     }
     return false;

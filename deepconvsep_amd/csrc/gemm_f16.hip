@@ -192,17 +192,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_skinny_kernel(const DcsG
 // all-rows kernel above with four column blocks' worth of rows per workgroup.
 // ------------------------------------------------------------------------------------------------
 struct DcsGemmF16LongK {
-    const float* A; int64_t lda; int M, K;        // K % 4 == 0, rows 16-byte aligned
+    const float* A; int64_t lda; int M, K;        // K % 4 == 0, rows 16-byte aligned.  A16: A holds f16 rows of lda halves, K == lda % 32 == 0
     const u32x4* Bh; int n_cols;                  // f16 plane [k tile][n_cols][4 pieces]; n_cols a multiple of 128
     float* partial;                               // [slices][M][n_cols]
     int kts;                                      // k tiles per slice
 };
 
-template <int RBT>
+// A16 (round 6): the rows arrive as f16 (the f16 conv2 writes them so, colconv_wreg_scatter_kernel<..., OUT16>): a piece is one
+// 16-byte load, one plane, ONE MFMA per block.
+template <int RBT, bool A16>
 __global__ __launch_bounds__(kThreads, 2) void gemm_f16_longk_kernel(const DcsGemmF16LongK g) {
     constexpr int CB = 2, ROWS = RBT * 16, CW = CB * 16;
     constexpr int kPlane = ROWS * kRowU4;
-    __shared__ u32x4 As[2 * kPlane];
+    __shared__ u32x4 As[(A16 ? 1 : 2) * kPlane];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int fi = lane & 15, kq = lane >> 4;
@@ -227,15 +229,26 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_longk_kernel(const DcsGe
     const u32x4* Bl = g.Bh + ((int64_t)(n0 + (fi >> 2) * (4 * CB) + (fi & 3))) * 4 + kq;
     const int64_t b_kt = (int64_t)n_cols * 4;
     f32x4 ra[A_PER][2];
+    u32x4 rh[A_PER];
     int ra_k[A_PER];
     u32x4 bn[CB], bc[CB];
+    const _Float16* ah_ptr[A_PER];
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        const int idx = tid + u * kThreads;
+        ah_ptr[u] = reinterpret_cast<const _Float16*>(g.A) + (int64_t)(a_ok[u] ? (idx >> 2) : 0) * g.lda + a_k0[u];
+    }
     // unconditional loads (rows past M read row 0, k past K reads the last four of the row), masked at the split
 #define DCS_LOAD(kt_)                                                                                   \
     {                                                                                                   \
         _Pragma("unroll") for (int u = 0; u < A_PER; ++u) {                                             \
             const int k = (kt_) * 32 + a_k0[u];                                                         \
-            ra[u][0] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k < gK ? k : gK - 4));               \
-            ra[u][1] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k + 4 < gK ? k + 4 : gK - 4));       \
+            if constexpr (A16) {                                                                        \
+                rh[u] = *reinterpret_cast<const u32x4*>(ah_ptr[u] + (kt_) * 32);    /* K == lda: inside the row */ \
+            } else {                                                                                    \
+                ra[u][0] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k < gK ? k : gK - 4));           \
+                ra[u][1] = *reinterpret_cast<const f32x4*>(a_ptr[u] + (k + 4 < gK ? k + 4 : gK - 4));   \
+            }                                                                                           \
             ra_k[u] = k;                                                                                \
         }                                                                                               \
         _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) bn[cb] = Bl[(kt_) * b_kt + cb * 16];          \
@@ -250,6 +263,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_longk_kernel(const DcsGe
 #pragma unroll
         for (int u = 0; u < A_PER; ++u)
             if (a_dst[u] >= 0) {
+                if constexpr (A16) {
+                    As[a_dst[u]] = a_ok[u] ? rh[u] : u32x4{0u, 0u, 0u, 0u};
+                    continue;
+                }
                 const float s0 = (a_ok[u] && ra_k[u] < gK) ? 1.f : 0.f, s1 = (a_ok[u] && ra_k[u] + 4 < gK) ? 1.f : 0.f;
                 f16x8 hi, lo;
 #pragma unroll
@@ -271,11 +288,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16_longk_kernel(const DcsGe
         const u32x4* Ab = As + fi * kRowU4 + kq;
 #pragma unroll
         for (int r = 0; r < RBT; ++r) {
-            const u32x4 a_hi = Ab[r * 16 * kRowU4], a_lo = Ab[kPlane + r * 16 * kRowU4];
+            const u32x4 a_hi = Ab[r * 16 * kRowU4];
+            u32x4 a_lo = a_hi;
+            if constexpr (!A16) a_lo = Ab[kPlane + r * 16 * kRowU4];
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 f32x4 c = acc[r][cb];
-                c = mma(bc[cb], a_lo, c);
+                if constexpr (!A16) c = mma(bc[cb], a_lo, c);
                 c = mma(bc[cb], a_hi, c);
                 acc[r][cb] = c;
             }
@@ -357,15 +376,23 @@ int dcs_gemm_f16_longk_slices(const dcs_ctx* ctx, int M, int K, int n_cols) {
     return ksplit < 2 ? 0 : ksplit;
 }
 
-bool dcs_launch_gemm_f16_longk(dcs_ctx* ctx, const float* A, int64_t lda, int M, int K, int n_cols, const void* Bh, float* partial) {
+bool dcs_launch_gemm_f16_longk(dcs_ctx* ctx, const void* A, int64_t lda, int M, int K, int n_cols, const void* Bh, float* partial,
+                               bool a_f16) {
     const int ksplit = dcs_gemm_f16_longk_slices(ctx, M, K, n_cols);
-    if (ksplit < 2 || !Bh || !partial || (lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) return false;
+    if (ksplit < 2 || !Bh || !partial || (reinterpret_cast<uintptr_t>(A) & 15)) return false;
+    if (a_f16 ? ((lda & 31) || K != lda) : ((lda & 3) != 0)) return false;
     const int nkt = (K + 31) / 32;
     DcsGemmF16LongK g{};
-    g.A = A; g.lda = lda; g.M = M; g.K = K; g.Bh = reinterpret_cast<const u32x4*>(Bh); g.n_cols = n_cols; g.partial = partial;
+    g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.M = M; g.K = K; g.Bh = reinterpret_cast<const u32x4*>(Bh); g.n_cols = n_cols;
+    g.partial = partial;
     g.kts = (nkt + ksplit - 1) / ksplit;
     const dim3 grid((unsigned)(n_cols / 128), 1, (unsigned)ksplit);
-    if (M <= 128) hipLaunchKernelGGL((gemm_f16_longk_kernel<8>), grid, dim3(kThreads), 0, ctx->stream, g);
-    else hipLaunchKernelGGL((gemm_f16_longk_kernel<11>), grid, dim3(kThreads), 0, ctx->stream, g);
+    if (a_f16) {
+        if (M <= 128) hipLaunchKernelGGL((gemm_f16_longk_kernel<8, true>), grid, dim3(kThreads), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f16_longk_kernel<11, true>), grid, dim3(kThreads), 0, ctx->stream, g);
+    } else {
+        if (M <= 128) hipLaunchKernelGGL((gemm_f16_longk_kernel<8, false>), grid, dim3(kThreads), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f16_longk_kernel<11, false>), grid, dim3(kThreads), 0, ctx->stream, g);
+    }
     return true;
 }

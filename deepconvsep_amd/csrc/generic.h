@@ -29,6 +29,8 @@ struct DcsColConv {
     int ph, kh;
     int xb_per_wg;              // column blocks (16 x each) a workgroup walks
     int n_xb;                   // column blocks per image
+    int out_f16;                // 1: `out` holds f16 ([image][Cout][Ho][W] halves, out_n_stride in halves) -- the f16 forward conv2 feeding
+                                // the f16 bottleneck layer (colconv_wreg_scatter_kernel only: dcs_colconv_wreg_scatter_ok)
 };
 // slab convolution (general kh x kw): see slabconv_kernel in generic.hip for the operation
 struct DcsSlabConv {
@@ -60,6 +62,7 @@ bool dcs_launch_deconv1_mfma(dcs_ctx* ctx, const float* g, const void* Wq, float
 // weights-in-registers f16 variant (colconv_wreg.hip): false = shape not covered, nothing launched
 void dcs_colconv_wreg_pack(const _Float16* Wh, int kh, std::vector<_Float16>* out);
 bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq);
+bool dcs_colconv_wreg_scatter_ok(const DcsColConv& a);   // the forward ('valid') shape of the weights-in-registers kernel: may write f16
 // InverseLayer(conv2) + InverseLayer(conv1) in one kernel (Bach10 graph, f16 switch on): out [image][Ho][F]
 void dcs_decoder_fused_pack(const float* W1p, int nf1, int C, std::vector<uint16_t>* out);
 bool dcs_decoder_fused_ok(const DcsColConv& a, int F);
@@ -69,7 +72,9 @@ int dcs_gemm_pack_bh(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_out, 
 int dcs_gemm_pack_bias_cl(dcs_ctx* ctx, const float* bias_d, int n_out, int nch, int npos, int chpad, float* out_d);
 int dcs_gemm_pack_bh_plain(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bh_d);   // B in its own column order
 int dcs_gemm_f16_longk_slices(const dcs_ctx* ctx, int M, int K, int n_cols);                          // 0: the shape is not the long-K kernel's
-bool dcs_launch_gemm_f16_longk(dcs_ctx* ctx, const float* A, int64_t lda, int M, int K, int n_cols, const void* Bh, float* partial);
+// A: f32 rows (split into two f16 terms on the way into LDS) or, a_f16, f16 rows of lda halves (lda % 32 == 0, K == lda)
+bool dcs_launch_gemm_f16_longk(dcs_ctx* ctx, const void* A, int64_t lda, int M, int K, int n_cols, const void* Bh, float* partial,
+                               bool a_f16 = false);
 bool dcs_launch_gemm_f16_skinny(dcs_ctx* ctx, const float* Z, int64_t ldz, int M, int K, int n_cols, int n_br, const void* const* Bh,
                                 const float* const* bias, void* const* C, int64_t ldc, void* Ah_scratch);
 // in_channels_last: a.in is [image][H][W][Cin] (the dense layer wrote a position's channels together) instead of [image][Cin][H][W]

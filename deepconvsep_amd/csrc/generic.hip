@@ -1629,6 +1629,7 @@ int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16
                    const uint16_t* Wps = nullptr) {
     a.n_xb = (a.W + 15) / 16;
     if (Wh && Wr && dcs_launch_colconv_wreg(ctx, a, n_images, Wr)) return DCS_OK;
+    if (a.out_f16) DCS_FAIL(DCS_EHIP, "column convolution: f16 output asked of a kernel that cannot write it");
     constexpr bool ps_col = true;
     // f32-class forward conv2: bf16 x 3 with the slab pre-split in LDS (0.41 -> 0.25 ms on the score-informed batch).  The
     // transpose stays with the f32 column kernel: 7 of 20 taps are valid on average there and that kernel walks only
@@ -1768,8 +1769,42 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                            ctx->stream, a1b, p1, n * d.nf1 * tc, d.w1, d.wp, d.pool_w);
         tm.done();
     }
-    // conv2 + both biases -> a2b[n][flat_p] (pad columns zeroed)
-    if (g->flat_p != d.flat)
+    // f16 switch (round 6): when the bottleneck layer will run on its f16 weight plane (gemm_f16_longk_kernel: 128 .. 176 tiles, K >=
+    // 16 384) AND conv2 is the weights-in-registers f16 kernel, conv2 writes its map as f16 -- a2b16[n][pitch16] halves, pitch16 =
+    // flat rounded up to 32 so that every K tile of the layer lies inside a row -- and the layer multiplies those rows as they
+    // are: half the bytes on both sides of the hand-over, one MFMA per block instead of two.  The plane is made on first need.
+    static const bool fc16_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
+    const int pitch16 = (int)dcs_round_up(d.flat, 32);
+    int ks16 = 0;
+    bool a2b16 = false;
+    if (fc16_on && g->conv_f16 && !g->bfch_failed) {
+        ks16 = dcs_gemm_f16_longk_slices(ctx, (int)n, pitch16, g->hid64);
+        if (ks16 >= 2 && !g->Bfch) {
+            void* plane = nullptr;
+            if (hipMalloc(&plane, dcs_gemm_bh_bytes(g->flat_p, g->hid64)) != hipSuccess) {
+                (void)hipGetLastError();
+                g->bfch_failed = true;
+            } else {
+                const int rc = dcs_gemm_pack_bh_plain(ctx, g->Bfc, g->flat_p, g->hid64, g->hid64, plane);
+                if (rc != DCS_OK) {
+                    (void)hipFree(plane);
+                    return rc;
+                }
+                g->Bfch = plane;
+            }
+        }
+        if (ks16 >= 2 && g->Bfch && g->use_colconv && g->Wcol_h && g->Wcol_r && !d.pool_w && (d.flat & 1) == 0) {
+            ColConvArgs c2{};
+            c2.Cin = d.nf1; c2.H = tc; c2.W = d.wp; c2.Cout = d.nf2; c2.Ho = d.h2; c2.ph = 0; c2.kh = d.kh2;
+            a2b16 = dcs_colconv_wreg_scatter_ok(c2);
+        }
+    }
+    // conv2 + both biases -> a2b[n][flat_p] (pad columns zeroed; f16: the pitch16 - flat pad halves, as flat / 2 .. pitch16 / 2 floats)
+    if (a2b16) {
+        if (pitch16 != d.flat)
+            hipLaunchKernelGGL(zero_pad_cols_kernel, dim3((unsigned)dcs_cdiv(n * ((pitch16 - d.flat) / 2), kThreads)), dim3(kThreads), 0,
+                               ctx->stream, a2b, n, d.flat / 2, pitch16 / 2);
+    } else if (g->flat_p != d.flat)
         hipLaunchKernelGGL(zero_pad_cols_kernel, dim3((unsigned)dcs_cdiv(n * (g->flat_p - d.flat), kThreads)), dim3(kThreads), 0,
                            ctx->stream, a2b, n, d.flat, g->flat_p);
     {
@@ -1784,11 +1819,13 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.in = a.in; c.in_n_stride = a.in_n_stride; c.Cin = a.Cin; c.H = a.H; c.W = a.W;
             c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = 0; c.kh = d.kh2;
+            if (a2b16) { c.out_f16 = 1; c.out_n_stride = pitch16; }
             if (a1_cl) {
                 if (!dcs_launch_colconv_fwd_x3(ctx, c, n, g->Wfx3))
                     DCS_FAIL(DCS_EHIP, "generic graph: conv2 refused the channels-last input conv1 was asked to write");
             } else
             DCS_CHECK(launch_colconv(ctx, c, n, g->conv_f16 ? g->Wcol_h : nullptr, g->Wcol_r, g->Wpc_q3));
+            // (launch_colconv fails a launch that asks for f16 output and is not taken by the weights-in-registers kernel)
         } else if (g->conv_f16 && !(g->use_slabconv && !kF16Igemm))
             // general filters (iKala, 10 x 20) go through the slab kernel in either precision unless DCS_F16_IGEMM=1 asks
             // for the f16 implicit GEMM
@@ -1836,37 +1873,24 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             }
         }
         q.Bq = g->Bfcq;
-        // f16 switch: the same long-K launch on f16 weights (gemm_f16.hip: one plane, 2 bytes per weight instead of 6; the rows
-        // of A split into two f16 terms on their way into LDS), slices added by the same second pass
+        // f16 switch: the same long-K launch on f16 weights (gemm_f16.hip: one plane, 2 bytes per weight instead of 6); the rows
+        // of A are conv2's f16 map (a2b16, above) or, when conv2 could not write it, f32 rows split into two f16 terms on their
+        // way into LDS; the slices are added by the same second pass
         bool fc16 = false;
-        const int ks16 = (fcq_on && g->conv_f16 && !g->bfch_failed) ? dcs_gemm_f16_longk_slices(ctx, (int)n, g->flat_p, g->hid64) : 0;
-        if (ks16 >= 2) {
-            if (!g->Bfch) {
-                void* plane = nullptr;
-                if (hipMalloc(&plane, dcs_gemm_bh_bytes(g->flat_p, g->hid64)) != hipSuccess) {
-                    (void)hipGetLastError();
-                    g->bfch_failed = true;
-                } else {
-                    const int rc = dcs_gemm_pack_bh_plain(ctx, g->Bfc, g->flat_p, g->hid64, g->hid64, plane);
-                    if (rc != DCS_OK) {
-                        (void)hipFree(plane);
-                        return rc;
-                    }
-                    g->Bfch = plane;
-                }
-            }
-            if (g->Bfch && ctx->gemm_ws.ensure((size_t)ks16 * n * g->hid64 * sizeof(float)) == DCS_OK) {
-                DcsTimer tm(ctx, DCS_TAG_FC);
-                fc16 = dcs_launch_gemm_f16_longk(ctx, a2b, g->flat_p, (int)n, g->flat_p, g->hid64, g->Bfch, (float*)ctx->gemm_ws.ptr);
-                if (fc16) {
-                    DcsGemm r = q;
-                    r.partial = (float*)ctx->gemm_ws.ptr;
-                    dcs_launch_gemm_longk_reduce(ctx, r, ks16);
-                    tm.done();
-                } else
-                    tm.cancel();
-            }
+        const int ks_fc = a2b16 ? ks16 : ((fc16_on && g->conv_f16 && g->Bfch) ? dcs_gemm_f16_longk_slices(ctx, (int)n, g->flat_p, g->hid64) : 0);
+        if (ks_fc >= 2 && g->Bfch && ctx->gemm_ws.ensure((size_t)ks_fc * n * g->hid64 * sizeof(float)) == DCS_OK) {
+            DcsTimer tm(ctx, DCS_TAG_FC);
+            fc16 = a2b16 ? dcs_launch_gemm_f16_longk(ctx, a2b, pitch16, (int)n, pitch16, g->hid64, g->Bfch, (float*)ctx->gemm_ws.ptr, true)
+                         : dcs_launch_gemm_f16_longk(ctx, a2b, g->flat_p, (int)n, g->flat_p, g->hid64, g->Bfch, (float*)ctx->gemm_ws.ptr, false);
+            if (fc16) {
+                DcsGemm r = q;
+                r.partial = (float*)ctx->gemm_ws.ptr;
+                dcs_launch_gemm_longk_reduce(ctx, r, ks_fc);
+                tm.done();
+            } else
+                tm.cancel();
         }
+        if (a2b16 && !fc16) DCS_FAIL(DCS_EHIP, "generic graph: conv2 wrote an f16 map and the f16 bottleneck layer refused it");
         if (!fc16) DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC));
     }
     // per-source dense (rectify): D[n][branch][flat_p]; aliased branches (none in these graphs) would reuse a layer
