@@ -152,8 +152,11 @@ DCS_API int dcs_model_num_sources(const dcs_model* m);
  * single-channel bach10 graph runs both InverseLayers in one kernel (colconv_wreg.hip): conv2^T in f16 and -- the default since
  * round 4 -- conv1^T in f16 as well: the activations between the two InverseLayers are rounded to f16 and meet an f16 conv1
  * filter in one MFMA per tile (f32 accumulation).  Results stay within the f16 path's stated tolerance (2e-3 of the network
- * output, tests/test_gpu_configs.py), not within 1e-4.  DCS_DECODER_S2=bf16x3 in the environment restores the f32-class second
- * stage (conv1^T on the bf16 pipe with three-way split operands, the intermediate never rounded below f32).  The ikala
+ * output, tests/test_gpu_configs.py), not within 1e-4.  Since round 6 the DENSE layers of that graph follow the switch as well
+ * when a pass has 128 .. 176 tiles (the window of the all-rows kernels): the bottleneck layer and the per-source layers multiply
+ * f16 weights (one plane, 2 bytes per weight -- SURVEY 8d prices this config as HBM-on-weights at fp16), conv2 hands its map to
+ * the bottleneck layer as f16, and the per-source layers write their output once as f16 in the layout the fused decoder reads
+ * (gemm_f16.hip); the measured error of the network output is unchanged (3e-5: the f16 convolutions dominate).  The ikala
  * graph (10 x 20 filters) takes the same slab kernel in either precision (one f16 plane instead of three bf16 planes). */
 DCS_API int dcs_model_set_conv_precision(dcs_model* m, int f16);
 /* Score-informed graphs (DCS_ARCH_BACH10_SI / _SI1): which of the reference's two semantics dcs_separate_scoreinformed and
