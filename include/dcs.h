@@ -167,7 +167,7 @@ DCS_API int dcs_model_set_score_semantics(dcs_model* m, int normalise, int mixtu
 /* Which stages of dcs_separate run on the one-batch ("latency") kernels of csrc/dsd_lat.hip -- the shape of the
  * reference's own call, predict_function2 on ONE batch of 32 tiles (separate_dsd.py:296-298), where a kernel's duration
  * is its chain of dependent memory latencies.  stages = -1 (default): automatic, all of them for one clip of at most
- * DCS_LAT_MAX_FRAMES (1024) frames; 0: the throughput kernels; else a bit set: 1 STFT, 2 conv1, 4 conv2, 8 bottleneck,
+ * 1024 frames; 0: the throughput kernels; else a bit set: 1 STFT, 2 conv1, 4 conv2, 8 bottleneck,
  * 16 per-source dense, 32 transposed conv2, 64 final (transposed conv1 + mask + cross-fade), 128 iSTFT.  Both families
  * read and write the same buffers, so any mix is valid (tests compare each stage against the other family).  DSD graph
  * only (DCS_EUNSUPPORTED otherwise). */
@@ -191,7 +191,7 @@ DCS_API int dcs_model_out_channels(const dcs_model* m);
  * + cross-fade) on n_clips clips of n_frames frames each: 0 = f32 MFMA, 64-bin workgroups (small launches); 1 = f32
  * MFMA, 128-bin workgroups; 2 = bf16 MFMA on operands split exactly into three bf16 terms (f32-class results, the
  * default for launches that fill the chip; DSD / hiphop graph); 3 = the one-batch kernel of csrc/dsd_lat.hip (one clip of
- * at most DCS_LAT_MAX_FRAMES frames, see dcs_model_set_latency_stages; the same bf16x3 arithmetic, 16 x 64 workgroups);
+ * at most 1024 frames, see dcs_model_set_latency_stages; the same bf16x3 arithmetic, 16 x 64 workgroups);
  * negative: not a fused-kernel graph.  bench.py prices its roofline block with this. */
 DCS_API int dcs_model_final_kernel(const dcs_model* m, int64_t n_frames, int64_t n_clips, int eps_mode);
 
