@@ -129,6 +129,18 @@ def split_groups(k, per_group, lanes):
     return [base + 1] * extra + [base] * (g - extra)
 
 
+def plan_round(k, per_group, lanes, gathering, gather_mode="root", no_pipeline=False):
+    """(launch groups of a round, pipelined?).  N = 1: split_groups.  N > 1 (gathering) and a round of ONE launch group: two
+    half-groups on two lanes, the second's kernels ordered behind the first's by an event, so that the first's collective rides
+    under the second's compute -- unless there is no collective (`none`), one lane, one step, or
+    --no-pipeline."""
+    groups = split_groups(k, per_group, lanes)
+    pipelined = bool(gathering and len(groups) == 1 and k >= 2 and lanes >= 2 and gather_mode != "none" and not no_pipeline)
+    if pipelined:
+        groups = [k - k // 2, k // 2]
+    return groups, pipelined
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -378,13 +390,10 @@ def main():
     assert n_tiles == args.tiles, (n_tiles, args.tiles)
     frames_per_step = (n_tiles - 1) * (TC - OV) + TC        # unique frames fully separated
     NS = max(1, args.streams)
-    groups = split_groups(K, max(1, args.clips_per_launch), NS)
     # N > 1 and a round of ONE launch group: compute -> int16 -> collective on one stream is serial by construction (the
     # collective of 20 steps is as long as their compute at N = 8).  Two half-groups on two lanes instead:
     # B's kernels are ordered behind A's kernels (an event, not a synchronisation), so A's collective rides under B's compute.
-    pipelined = bool(gathering and len(groups) == 1 and K >= 2 and NS >= 2 and args.gather != "none" and not args.no_pipeline)
-    if pipelined:
-        groups = [K - K // 2, K // 2]
+    groups, pipelined = plan_round(K, max(1, args.clips_per_launch), NS, gathering, args.gather, args.no_pipeline)
     CPL = max(groups)                                        # buffers are sized for the largest group
 
     gather_mode = [args.gather]                              # a list: the gather split below switches it off and on again

@@ -110,3 +110,18 @@ def test_emit_prints_the_headline_last_and_writes_the_detail(tmp_path, monkeypat
     out = io.StringIO()
     bench.emit(full, out=out)
     assert out.getvalue().splitlines() == [bench.headline(full)]           # default: ONE stdout line
+
+
+def test_round_plan_pipelines_the_gather_only_where_it_can():
+    """bench.py's schedule of a round: the driver's --steps 20 is ONE launch group on one GPU; with N > 1 it becomes two half-groups
+    whose collectives overlap the other half's compute -- not without a collective, not on one lane, not with --no-pipeline, and
+    rounds that already have several groups keep them."""
+    assert bench.plan_round(20, 32, 3, False) == ([20], False)
+    assert bench.plan_round(20, 32, 3, True, "root") == ([10, 10], True)
+    assert bench.plan_round(7, 32, 3, True, "allgather") == ([4, 3], True)
+    assert bench.plan_round(20, 32, 3, True, "none") == ([20], False)
+    assert bench.plan_round(20, 32, 1, True, "root") == ([20], False)
+    assert bench.plan_round(20, 32, 3, True, "root", no_pipeline=True) == ([20], False)
+    assert bench.plan_round(1, 32, 3, True, "root") == ([1], False)
+    groups, piped = bench.plan_round(384, 32, 3, True, "root")
+    assert sum(groups) == 384 and len(groups) == 12 and not piped
