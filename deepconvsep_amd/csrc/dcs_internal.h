@@ -225,6 +225,9 @@ struct DcsGemm {
     // optional (all-rows kernel only): A already split into three bf16 planes by dcs_gemm_split_a, [k tile][plane][aq_rows][4 pieces]
     // -- the workgroups then copy their k tile's pieces into LDS instead of each splitting all the rows again
     const void* Aq; int aq_rows;
+    // Bq holds the weights UNSPLIT, as 32-byte f32 pieces in the planes' piece order (dcs_gemm_pack_b32): the all-rows kernels split
+    // them in registers -- 4 bytes per weight from HBM instead of 6.  Only those kernels take it (M 128 .. 176)
+    int bq_f32;
 };
 
 // row r of a grouped operand: (r / gdiv) * gmul + r % gdiv.  Most launches have ONE group (gdiv = 2^30 > M): a 64-bit division
@@ -240,6 +243,8 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag);
 size_t dcs_gemm_bq_bytes(int K, int n_cols);
 // enqueued on the ctx stream; perm_c > 0: columns re-ordered from [channel perm_c][position perm_p] to [position][channel]
 int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* Bq_d, int perm_c = 0, int perm_p = 0);
+size_t dcs_gemm_b32_bytes(int K, int n_cols);
+int dcs_gemm_pack_b32(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* B32_d, int perm_c = 0, int perm_p = 0);
 bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g);
 struct DcsGemmBranches {         // (B planes, bias, C) of up to 4 GEMMs that share A and shape
     int n;

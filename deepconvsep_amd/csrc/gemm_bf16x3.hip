@@ -77,6 +77,30 @@ __global__ __launch_bounds__(kThreads) void gemm_pack_bq_kernel(const float* __r
     Bq[base + (int64_t)n_cols * 8] = p2;
 }
 
+// The same pieces UNSPLIT (round 6): B32[kt][column][4 pieces of 8 consecutive k] as f32, 32 bytes per piece -- 4 bytes per weight
+// instead of the 6 of three bf16 planes.  For the all-rows kernels, whose time is the HBM stream of the weights (1 GB of planes
+// for the Bach10 per-source layers): they split the piece in registers, beside the matrix pipe; same truncation, same planes,
+// bit-identical products.
+__global__ __launch_bounds__(kThreads) void gemm_pack_b32_kernel(const float* __restrict__ B, int K, int ldb, int n_cols,
+                                                                 f32x4* __restrict__ B32, int64_t n_pieces, int perm_c, int perm_p) {
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;   // (kt, n, kq), kq fastest
+    if (idx >= n_pieces) return;
+    const int kq = (int)(idx & 3);
+    const int64_t t = idx >> 2;
+    const int n = (int)(t % n_cols);
+    const int64_t kt = t / n_cols;
+    const int ns = (perm_c > 0 && n < perm_c * perm_p) ? (n % perm_c) * perm_p + n / perm_c : n;
+    f32x4 x0, x1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t k = kt * 32 + kq * 8 + j;
+        const float v = k < K ? B[k * ldb + ns] : 0.f;
+        if (j < 4) x0[j] = v; else x1[j - 4] = v;
+    }
+    B32[idx * 2] = x0;
+    B32[idx * 2 + 1] = x1;
+}
+
 template <int RB>
 __global__ __launch_bounds__(kThreads) void gemm_bf16x3_kernel(const DcsGemm g, int xcd_map) {
     constexpr int BM = 16 * RB;
@@ -219,7 +243,10 @@ __device__ unsigned long long skinny_trace_buf[8];
 // AQ: the rows come pre-split (DcsGemm::Aq, round 5): the staging of a k tile is three 16-byte loads and three LDS writes per
 // piece, no arithmetic -- with hundreds of workgroups each splitting all 128 .. 176 rows of every k tile the split was 22 % of
 // the kernel (profiles/r04_o_skinny_timeline.txt).  Same planes, same products: bit-identical results.
-template <int RBT /* row blocks of 16 */, int CB /* 16-column blocks per wave */, bool AQ = false>
+// B32 (round 6): g.Bq holds the weights unsplit (gemm_pack_b32_kernel: 32-byte f32 pieces, 4 bytes per weight instead of 6); a wave
+// splits its fragments in registers when it takes them over -- 112 vector instructions per k tile beside 132 MFMAs, for a third
+// fewer bytes on a kernel whose time is the weight stream.
+template <int RBT /* row blocks of 16 */, int CB /* 16-column blocks per wave */, bool AQ = false, bool B32 = false>
 __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_kernel(const DcsGemm g0, const DcsGemmBranches br) {
     // blockIdx.y = branch: the same A against another (B planes, bias, C) triple -- one launch for all sources
     DcsGemm g = g0;
@@ -261,6 +288,9 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
     // B: piece (kt, plane, column, kg); MFMA row fi of block cb is column n0 + 4 CB (fi / 4) + 4 cb + fi % 4
     const int64_t b_plane = (int64_t)n_cols * 4, b_kt = 3 * b_plane;
     const u32x4* Bl = reinterpret_cast<const u32x4*>(g.Bq) + ((int64_t)((live ? n0 : 0) + (fi >> 2) * (4 * CB) + (fi & 3))) * 4 + kq;
+    const f32x4* Bl32 = reinterpret_cast<const f32x4*>(g.Bq) + (((int64_t)((live ? n0 : 0) + (fi >> 2) * (4 * CB) + (fi & 3))) * 4 + kq) * 2;
+    const int64_t b32_kt = (int64_t)n_cols * 8;          // f32x4 units per k tile
+    f32x4 bn32[B32 ? CB : 1][2];
     f32x4 ra[AQ ? 1 : A_PER][2];
     u32x4 rq[AQ ? A_PER : 1][3];                           // AQ: the three planes of the piece in flight
     const u32x4* aq_ptr[A_PER];                            // AQ: plane 0 of this thread's piece of k tile 0
@@ -289,8 +319,14 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
         }                                                                                               \
     }
 #define DCS_LOAD_B(kt_)                                                                                 \
-    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                   \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) bn[cb][p] = Bl[(kt_) * b_kt + p * b_plane + cb * 16];
+    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                                 \
+        if constexpr (B32) {                                                                            \
+            bn32[cb][0] = Bl32[(kt_) * b32_kt + cb * 32];                                               \
+            bn32[cb][1] = Bl32[(kt_) * b32_kt + cb * 32 + 1];                                           \
+        } else {                                                                                        \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) bn[cb][p] = Bl[(kt_) * b_kt + p * b_plane + cb * 16]; \
+        }                                                                                               \
+    }
     f32x4 acc[RBT][CB];
 #pragma unroll
     for (int r = 0; r < RBT; ++r)
@@ -319,9 +355,14 @@ __global__ __launch_bounds__(kThreads, CB <= 2 ? 2 : 1) void gemm_bf16x3_skinny_
             }
         }
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+        for (int cb = 0; cb < CB; ++cb) {
+            if constexpr (B32) {
+                split8(bn32[cb][0], bn32[cb][1], bc[cb][0], bc[cb][1], bc[cb][2]);
+            } else {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bc[cb][p] = bn[cb][p];
+                for (int p = 0; p < 3; ++p) bc[cb][p] = bn[cb][p];
+            }
+        }
         SK_NOW(s1)
         __syncthreads();
         SK_NOW(s2)
@@ -477,7 +518,8 @@ bool dcs_launch_gemm_bf16x3_longk(dcs_ctx* ctx, const DcsGemm& g) {
     q.Aq = nullptr;
     const int rbt = g.M <= 128 ? 8 : 11;
     const size_t lds = (size_t)3 * rbt * 16 * kRowU4 * 16;
-    auto kern = rbt == 8 ? gemm_bf16x3_skinny_kernel<8, 2> : gemm_bf16x3_skinny_kernel<11, 2>;
+    auto kern = g.bq_f32 ? (rbt == 8 ? gemm_bf16x3_skinny_kernel<8, 2, false, true> : gemm_bf16x3_skinny_kernel<11, 2, false, true>)
+                         : (rbt == 8 ? gemm_bf16x3_skinny_kernel<8, 2> : gemm_bf16x3_skinny_kernel<11, 2>);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
@@ -491,6 +533,17 @@ bool dcs_launch_gemm_bf16x3_longk(dcs_ctx* ctx, const DcsGemm& g) {
 // q.bias, q.relu, q.C / ldc / c_gdiv / c_gmul
 void dcs_launch_gemm_longk_reduce(dcs_ctx* ctx, const DcsGemm& q, int ksplit) {
     hipLaunchKernelGGL(gemm_longk_reduce_kernel, dim3((unsigned)dcs_cdiv(q.M * q.n_cols, 64)), dim3(kThreads), 0, ctx->stream, q, ksplit);
+}
+
+size_t dcs_gemm_b32_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * (size_t)n_cols * 4 * 32; }
+
+int dcs_gemm_pack_b32(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols, void* B32_d, int perm_c, int perm_p) {
+    const int64_t n_pieces = (int64_t)((K + 31) / 32) * n_cols * 4;
+    if (perm_c > 0 && (int64_t)perm_c * perm_p > n_cols) DCS_FAIL(DCS_EINVAL, "dcs_gemm_pack_b32: permutation wider than B");
+    hipLaunchKernelGGL(gemm_pack_b32_kernel, dim3((unsigned)dcs_cdiv(n_pieces, kThreads)), dim3(kThreads), 0, ctx->stream, B_d, K,
+                       ldb, n_cols, reinterpret_cast<f32x4*>(B32_d), n_pieces, perm_c, perm_p);
+    DCS_HIP(hipGetLastError());
+    return DCS_OK;
 }
 
 size_t dcs_gemm_bq_bytes(int K, int n_cols) { return (size_t)((K + 31) / 32) * 3 * (size_t)n_cols * 4 * 16; }
@@ -508,6 +561,7 @@ int dcs_gemm_pack_bq(dcs_ctx* ctx, const float* B_d, int K, int ldb, int n_cols,
 bool dcs_launch_gemm_bf16x3(dcs_ctx* ctx, const DcsGemm& g) {
     static const bool on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
     if (!on || !g.Bq || !g.a_vec || g.partial || (g.K & 3) || (g.lda & 3)) return false;
+    if (g.bq_f32) return dcs_launch_gemm_bf16x3_skinny(ctx, g, nullptr);   // unsplit pieces: the all-rows kernel only
     const int64_t groups16 = (g.M + 15) / 16, col_groups = g.n_cols / 64;
     // launches that fill the chip only: with few workgroups a kernel's duration is one wave's dependent chain and the
     // f32 split-K kernels of gemm.hip cut that chain instead.  And wide B only (the per-source dense layers): the
@@ -549,6 +603,9 @@ bool dcs_launch_gemm_bf16x3_skinny(dcs_ctx* ctx, const DcsGemm& g, const DcsGemm
 #endif
     auto kern = rbt == 8 ? (cb == 4 ? gemm_bf16x3_skinny_kernel<8, 4> : (aq ? gemm_bf16x3_skinny_kernel<8, 2, true> : gemm_bf16x3_skinny_kernel<8, 2>))
                          : (cb == 4 ? gemm_bf16x3_skinny_kernel<11, 4> : (aq ? gemm_bf16x3_skinny_kernel<11, 2, true> : gemm_bf16x3_skinny_kernel<11, 2>));
+    if (g.bq_f32)
+        kern = rbt == 8 ? (aq ? gemm_bf16x3_skinny_kernel<8, 2, true, true> : gemm_bf16x3_skinny_kernel<8, 2, false, true>)
+                        : (aq ? gemm_bf16x3_skinny_kernel<11, 2, true, true> : gemm_bf16x3_skinny_kernel<11, 2, false, true>);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;

@@ -1308,6 +1308,10 @@ struct DcsGenericNet {
     float* biasd[4] = {nullptr, nullptr, nullptr, nullptr};
     float* biasd_cl[4] = {nullptr, nullptr, nullptr, nullptr};   // the same biases in [position][channel] order (channels-last D)
     bool bdq_cl = false;                                         // column order the bf16 planes Bdq are packed in
+    // the same weights UNSPLIT in the planes' piece order (dcs_gemm_pack_b32: 4 bytes per weight instead of 6) for passes of
+    // 128 .. 176 tiles, which run the all-rows kernel: it splits the pieces in registers (round 6); Bdq serves the other row counts
+    void* Bd32[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool bd32_cl = false;
     // f16 switch with the fused decoder (gemm_f16.hip): the same weights as ONE f16 plane, columns [position][32 channels]
     // (30 real), their biases in that order; n_out16 columns per branch (a multiple of 128); made on first need
     void* Bfch = nullptr;                                        // the bottleneck weights as one f16 plane (long-K launches under the switch)
@@ -1568,7 +1572,7 @@ void dcs_generic_destroy(DcsGenericNet* g) {
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3], g->biasd_cl[0], g->biasd_cl[1],
                     g->biasd_cl[2], g->biasd_cl[3], g->Wx3, g->Bfcq, g->Wfx3, g->Bdh[0], g->Bdh[1], g->Bdh[2], g->Bdh[3], g->biasd_h[0],
-                    g->biasd_h[1], g->biasd_h[2], g->biasd_h[3], g->Bfch};
+                    g->biasd_h[1], g->biasd_h[2], g->biasd_h[3], g->Bfch, g->Bd32[0], g->Bd32[1], g->Bd32[2], g->Bd32[3]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1859,12 +1863,12 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         static const bool fcq_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
         if (fcq_on && n >= 128 && n <= 176 && g->flat_p >= 16384 && (g->hid64 % 128) == 0 && !g->Bfcq && !g->bfcq_failed &&
             (!g->conv_f16 || g->bfch_failed)) {           // (under the f16 switch the layer takes the f16 plane below instead)
-            void* planes = nullptr;
-            if (hipMalloc(&planes, dcs_gemm_bq_bytes(g->flat_p, g->hid64)) != hipSuccess) {
+            void* planes = nullptr;                       // (unsplit 32-byte pieces since round 6: the long-K launch is the all-rows kernel)
+            if (hipMalloc(&planes, dcs_gemm_b32_bytes(g->flat_p, g->hid64)) != hipSuccess) {
                 (void)hipGetLastError();
                 g->bfcq_failed = true;
             } else {
-                const int rc = dcs_gemm_pack_bq(ctx, g->Bfc, g->flat_p, g->hid64, g->hid64, planes);
+                const int rc = dcs_gemm_pack_b32(ctx, g->Bfc, g->flat_p, g->hid64, g->hid64, planes);
                 if (rc != DCS_OK) {
                     (void)hipFree(planes);
                     return rc;
@@ -1873,6 +1877,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             }
         }
         q.Bq = g->Bfcq;
+        q.bq_f32 = 1;
         // f16 switch: the same long-K launch on f16 weights (gemm_f16.hip: one plane, 2 bytes per weight instead of 6); the rows
         // of A are conv2's f16 map (a2b16, above) or, when conv2 could not write it, f32 rows split into two f16 terms on their
         // way into LDS; the slices are added by the same second pass
@@ -1955,38 +1960,46 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     // the bf16 planes of the dense weights, on first need: a launch of >= 128 rows against >= 1024 columns (smaller ones stay
     // on the f32 kernels whatever is packed, dcs_launch_gemm_bf16x3); same stream, so no synchronisation
     static const bool bf16_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
+    // (same-box A/B against the planes: Bach10 fc1x 0.396 -> 0.352 ms, profiles/r06_m_unsplit_weight_pieces_legs_ab.txt)
+    const bool win = n <= 176;                           // the all-rows kernel's window: unsplit pieces (Bd32), else planes (Bdq)
+    void** store = win ? g->Bd32 : g->Bdq;
+    bool& store_cl = win ? g->bd32_cl : g->bdq_cl;
     if (bf16_on && n >= 128 && g->flat64 >= 1024) {
         const int rows = (int)dcs_round_up(g->hid64, 128);
         const int pc = want_cl ? d.nf2 : 0, pp = want_cl ? d.h2 * d.w2 : 0;
-        if (g->bdq_cl != want_cl) {
-            // the precision switch was flipped since the planes were packed: the existing blocks are re-packed in place, in
+        auto pack = [&](const float* B, void* dst) {
+            return win ? dcs_gemm_pack_b32(ctx, B, rows, g->flat64, g->flat64, dst, pc, pp)
+                       : dcs_gemm_pack_bq(ctx, B, rows, g->flat64, g->flat64, dst, pc, pp);
+        };
+        if (store_cl != want_cl) {
+            // the precision switch was flipped since the weights were packed: the existing blocks are re-packed in place, in
             // the other column order (stream-ordered behind every earlier use)
             for (int s2 = 0; s2 < d.n_fc; ++s2)
-                if (g->Bdq[s2]) DCS_CHECK(dcs_gemm_pack_bq(ctx, g->Bd[s2], rows, g->flat64, g->flat64, g->Bdq[s2], pc, pp));
-            g->bdq_cl = want_cl;
+                if (store[s2]) DCS_CHECK(pack(g->Bd[s2], store[s2]));
+            store_cl = want_cl;
         }
         for (int s2 = 0; s2 < d.n_fc && !g->bdq_failed; ++s2) {
-            if (g->Bdq[s2]) continue;
-            // published only when packed: a failed pack must not leave a non-null, unpacked plane set behind (later calls
-            // would multiply by uninitialised memory).  Out of memory here (~1 GB for Bach10, outside the chunk budget) is
+            if (store[s2]) continue;
+            // published only when packed: a failed pack must not leave a non-null, unpacked block behind (later calls
+            // would multiply by uninitialised memory).  Out of memory here (~0.7 GB for Bach10, outside the chunk budget) is
             // not an error of the forward pass: the layer stays on the f32 GEMM (q.Bq == nullptr) for the model's lifetime.
             void* planes = nullptr;
-            if (hipMalloc(&planes, dcs_gemm_bq_bytes(rows, g->flat64)) != hipSuccess) {
+            if (hipMalloc(&planes, win ? dcs_gemm_b32_bytes(rows, g->flat64) : dcs_gemm_bq_bytes(rows, g->flat64)) != hipSuccess) {
                 (void)hipGetLastError();
                 g->bdq_failed = true;
                 break;
             }
-            const int rc = dcs_gemm_pack_bq(ctx, g->Bd[s2], rows, g->flat64, g->flat64, planes, pc, pp);
+            const int rc = pack(g->Bd[s2], planes);
             if (rc != DCS_OK) {
                 (void)hipFree(planes);
                 return rc;
             }
-            g->Bdq[s2] = planes;
+            store[s2] = planes;
         }
     }
     // planes in channels-last order serve the all-branches launch below and nothing else: a launch that falls back to the
     // per-branch GEMMs runs them on the f32 weights (channel-first), and the decoder is told which layout it got
-    const bool planes_cl = g->bdq_cl;
+    const bool planes_cl = store_cl;
     bool branches_done = false;
     if (NB > 1 || want_cl) {                             // every live branch in one launch when the shape allows it
         DcsGemm q{};
@@ -1997,9 +2010,9 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         br.n = NB;
         for (int b = 0; b < NB; ++b) {
             const int s = d.branch_fc[b];
-            br.Bq[b] = g->Bdq[s]; br.bias[b] = planes_cl ? g->biasd_cl[s] : g->biasd[s]; br.C[b] = D + (int64_t)b * g->flat_p;
+            br.Bq[b] = store[s]; br.bias[b] = planes_cl ? g->biasd_cl[s] : g->biasd[s]; br.C[b] = D + (int64_t)b * g->flat_p;
         }
-        q.B = g->Bd[d.branch_fc[0]]; q.bias = br.bias[0]; q.Bq = br.Bq[0]; q.C = br.C[0];
+        q.B = g->Bd[d.branch_fc[0]]; q.bias = br.bias[0]; q.Bq = br.Bq[0]; q.C = br.C[0]; q.bq_f32 = win ? 1 : 0;
         DcsTimer tm(ctx, DCS_TAG_FC1X);
         // the launch below takes the all-rows kernel: split Z once for all its workgroups (several branches: 0.413 -> 0.392 ms for
         // Bach10; with one branch the extra launch costs what it saves)
@@ -2016,7 +2029,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         const int s = d.branch_fc[b];
         DcsGemm q{};
         q.A = Z; q.lda = g->hid64; q.a_gdiv = 1 << 30; q.a_gmul = 0; q.a_scale = 1.f;
-        q.B = g->Bd[s]; q.ldb = g->flat64; q.bias = g->biasd[s]; q.Bq = planes_cl ? nullptr : g->Bdq[s];
+        q.B = g->Bd[s]; q.ldb = g->flat64; q.bias = g->biasd[s]; q.Bq = planes_cl ? nullptr : store[s]; q.bq_f32 = win ? 1 : 0;
         q.C = D + (int64_t)b * g->flat_p; q.ldc = (int64_t)NB * g->flat_p; q.c_gdiv = 1 << 30; q.c_gmul = 0;
         q.M = n; q.n_cols = g->flat64; q.n_store = d.flat; q.K = g->hid64; q.relu = 1; q.a_vec = 1;
         DCS_CHECK(dcs_launch_gemm_rows(ctx, q, DCS_TAG_FC1X));
