@@ -152,7 +152,9 @@ __global__ __launch_bounds__(kThreads) void colconv_wreg_gather_kernel(const Dcs
 // ---- scatter form: 'valid' convolution, input row r feeds output rows y = r - u, HO = H - KH + 1
 // OUT16 (round 6): the output map as f16 (same [channel][row][x] order, g.out_n_stride in halves) -- the bottleneck layer of the
 // f16 switch multiplies f16 rows (gemm_f16_longk_kernel); half the bytes written here and read there.
-template <int KH, int H, int AHEAD /* input rows in flight */, bool OUT16 = false>
+// IN16 (round 6): the input as f16, channels-last with 32 channels per position (conv1_mfma_kernel<1, 2>): a lane's eight channels of
+// a row are ONE 16-byte load instead of eight 4-byte loads 30 x 505 floats apart, and need no conversion.
+template <int KH, int H, int AHEAD /* input rows in flight */, bool OUT16 = false, bool IN16 = false>
 __global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const DcsColConv g, const u32x4* __restrict__ Wq,
                                                                         int64_t n_units) {
     constexpr int HO = H - KH + 1;
@@ -174,39 +176,57 @@ __global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const Dc
     int64_t unit = (int64_t)blockIdx.x * 4 + wave;
     if (unit >= n_units) return;
     // the first AHEAD rows of a unit are requested while the previous unit's last rows are multiplied
-    float pre[AHEAD][8];
+    float pre[IN16 ? 1 : AHEAD][8];
+    u32x4 preh[IN16 ? AHEAD : 1];
     int64_t img = unit / n_xb;
     int xb = block_x((int)(unit - img * n_xb), W);
     LaneIn li = lane_in(g, kg, xb + fi, HW);
     const float* ib = g.in + img * g.in_n_stride;
+    // IN16: this lane's eight channels of (row r, column xb + fi) are the 16 bytes at ih + r * W * 32
+    const _Float16* ih = reinterpret_cast<const _Float16*>(g.in) + img * g.in_n_stride + ((xb + fi) * 32 + 8 * kg);
 #pragma unroll
-    for (int r = 0; r < AHEAD; ++r)
+    for (int r = 0; r < AHEAD; ++r) {
+        if constexpr (IN16) preh[r] = *reinterpret_cast<const u32x4*>(ih + (int64_t)r * W * 32);
+        else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pre[r][j] = (ib + r * W)[li.idx[j]];
+            for (int j = 0; j < 8; ++j) pre[r][j] = (ib + r * W)[li.idx[j]];
+        }
+    }
     for (; unit < n_units; unit += stride) {
         const int64_t next = unit + stride < n_units ? unit + stride : unit;         // last round: a harmless re-read
         const int64_t img_n = next / n_xb;
         const int xb_n = block_x((int)(next - img_n * n_xb), W);
         const LaneIn li_n = lane_in(g, kg, xb_n + fi, HW);
         const float* ib_n = g.in + img_n * g.in_n_stride;
-        float raw[H][8];                      // fully unrolled: only AHEAD + 1 rows are live at any point
+        const _Float16* ih_n = reinterpret_cast<const _Float16*>(g.in) + img_n * g.in_n_stride + ((xb_n + fi) * 32 + 8 * kg);
+        float raw[IN16 ? 1 : H][8];           // fully unrolled: only AHEAD + 1 rows are live at any point
+        u32x4 rawh[IN16 ? H : 1];
 #pragma unroll
-        for (int r = 0; r < AHEAD; ++r)
+        for (int r = 0; r < AHEAD; ++r) {
+            if constexpr (IN16) rawh[r] = preh[r];
+            else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) raw[r][j] = pre[r][j];
+                for (int j = 0; j < 8; ++j) raw[r][j] = pre[r][j];
+            }
+        }
         f32x4 acc[HO][2];
 #pragma unroll
         for (int y = 0; y < HO; ++y) acc[y][0] = acc[y][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < H; ++r) {
-            if (r + AHEAD < H) {
+            if constexpr (IN16) {
+                if (r + AHEAD < H) rawh[r + AHEAD] = *reinterpret_cast<const u32x4*>(ih + (int64_t)(r + AHEAD) * W * 32);
+                else preh[r + AHEAD - H] = *reinterpret_cast<const u32x4*>(ih_n + (int64_t)(r + AHEAD - H) * W * 32);
+            } else if (r + AHEAD < H) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) raw[r + AHEAD][j] = (ib + (r + AHEAD) * W)[li.idx[j]];
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pre[r + AHEAD - H][j] = (ib_n + (r + AHEAD - H) * W)[li_n.idx[j]];
             }
-            const h8 a = round8(raw[r]);
+            h8 a;
+            if constexpr (IN16) a = as_h8(rawh[r]);
+            else a = round8(raw[r]);
 #pragma unroll
             for (int y = 0; y < HO; ++y) {
                 const int u = r - y;
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void colconv_wreg_scatter_kernel(const Dc
             for (int y = 0; y < HO; ++y) *reinterpret_cast<f32x4u*>(ob + (16 * HO + y) * W + out_lane) = acc[y][1];
         }
         }
-        img = img_n; xb = xb_n; li = li_n; ib = ib_n;
+        img = img_n; xb = xb_n; li = li_n; ib = ib_n; ih = ih_n;
     }
 }
 
@@ -494,7 +514,7 @@ bool dcs_colconv_wreg_scatter_ok(const DcsColConv& a) {
 bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq) {
     const bool on = wreg_on();
     if (!on || !Wq || a.Cin > 32 || a.Cout > 32 || a.kh != 20 || a.W < 16) return false;
-    if (a.out_f16 && !dcs_colconv_wreg_scatter_ok(a)) return false;
+    if ((a.out_f16 || a.in_f16) && !dcs_colconv_wreg_scatter_ok(a)) return false;
     const int64_t n_units = n_images * a.n_xb;
     if (n_units <= 0) return true;
     const unsigned grid = (unsigned)std::min<int64_t>(dcs_cdiv(n_units, 4), ctx->n_cu);
@@ -504,8 +524,11 @@ bool dcs_launch_colconv_wreg(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images
         return true;
     }
     if (a.ph == 0 && a.H == 30 && a.Ho == 11) {
-        if (a.out_f16) hipLaunchKernelGGL((colconv_wreg_scatter_kernel<20, 30, 8, true>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, n_units);
-        else hipLaunchKernelGGL((colconv_wreg_scatter_kernel<20, 30, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, n_units);
+        if (a.in_f16 && ((a.in_n_stride & 7) || (reinterpret_cast<uintptr_t>(a.in) & 15))) return false;
+#define DCS_SC(O16_, I16_) hipLaunchKernelGGL((colconv_wreg_scatter_kernel<20, 30, 8, O16_, I16_>), dim3(grid), dim3(kThreads), 0, ctx->stream, a, wq, n_units)
+        if (a.out_f16) { if (a.in_f16) DCS_SC(true, true); else DCS_SC(true, false); }
+        else { if (a.in_f16) DCS_SC(false, true); else DCS_SC(false, false); }
+#undef DCS_SC
         return true;
     }
     return false;

@@ -76,10 +76,14 @@ __device__ __forceinline__ void split4(const f32x4& x, u32x2& hi, u32x2& mid, u3
 //
 // CL: the output channels-last, out[n][t][j][o] (NF floats per position) -- the layout colconv_fwd_x3_kernel (conv2 of the
 // f32-class Bach10 / score-informed graphs) reads a position's channels from; the tile in LDS is then [position][36].
-template <int C, bool CL>
+// OUT = 2 (round 6): the channels-last output as f16 with 32 channels per position (30 + 2 zeros: the padded filters have zero
+// weights and biases), out16[n][t][j][32] halves -- what the f16 forward conv2 (colconv_wreg_scatter_kernel<..., IN16>) reads as one
+// 16-byte load per lane and row; half the bytes written here, and a quarter of the load instructions there.
+template <int C, int OUT /* 0 channel-first f32 | 1 channels-last f32 | 2 channels-last f16 x 32 */>
 __global__ __launch_bounds__(kThreads, C > 1 ? 3 : 4) void conv1_mfma_kernel(const float* __restrict__ x, const u32x4* __restrict__ Wq,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int NF, int tc, int F, int w1) {
+    constexpr bool CL = OUT != 0;
     constexpr int kQ = kInW / 4;                                  // float4 chunks per channel
     constexpr int kPl = C * kInW / 4;                             // u32x2 units (4 bf16) per plane
     // the planes [plane][channel][chunk] and, once every wave is done with them, the output tile [32 filters][kOutS] in the
@@ -203,6 +207,19 @@ __global__ __launch_bounds__(kThreads, C > 1 ? 3 : 4) void conv1_mfma_kernel(con
     // rows of consecutive positions: a wave instruction writes 256 contiguous bytes of one filter's row.  (Groups of four
     // positions on 16-byte boundaries of `out` -- the alignment depends on the row -- with the head as scalars were slower:
     // 0.22 vs 0.19 ms on the score-informed batch.)
+    if (OUT == 2) {   // 32 halves per position: thread (position jj, octet oq) converts eight filters and stores 16 bytes
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        _Float16* op16 = reinterpret_cast<_Float16*>(out) + ((n * tc + t) * (int64_t)w1 + j_base) * 32;
+        for (int i = tid; i < 4 * cnt; i += kThreads) {
+            const int jj = i >> 2, oq = i & 3;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(obuf + jj * kClS + 8 * oq);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(obuf + jj * kClS + 8 * oq + 4);
+            const f16x8 h = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
+                             (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+            *reinterpret_cast<f16x8*>(op16 + (int64_t)jj * 32 + 8 * oq) = h;
+        }
+        return;
+    }
     if (CL) {   // NF * cnt consecutive floats of the output
         float* op = out + ((n * tc + t) * (int64_t)w1 + j_base) * NF;
         for (int i = tid; i < NF * cnt; i += kThreads) {
@@ -242,19 +259,22 @@ void dcs_conv1_mfma_pack(const float* Wc, int NF, int C, int kw, std::vector<uin
 
 // false: shape not covered, nothing launched.  bias: [NF]
 bool dcs_launch_conv1_mfma(dcs_ctx* ctx, const float* x, const void* Wq, const float* bias, float* out, int64_t n, int C,
-                           int NF, int tc, int F, int kw, int sw, int w1, bool channels_last) {
+                           int NF, int tc, int F, int kw, int sw, int w1, bool channels_last, bool out_f16) {
     static const bool on = !(getenv("DCS_CONV1_MFMA") && atoi(getenv("DCS_CONV1_MFMA")) == 0);
     if (!on || !Wq || sw != 4 || kw > 32 || NF > 32 || (C != 1 && C != 4) || n * tc > 0x7fffffff) return false;
     if (n <= 0) return true;
     const dim3 grid((unsigned)(n * tc), (unsigned)dcs_cdiv(w1, kPos));
     const u32x4* wq = reinterpret_cast<const u32x4*>(Wq);
-    if (C == 1 && channels_last)
-        hipLaunchKernelGGL((conv1_mfma_kernel<1, true>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+    if (out_f16) {                                        // f16, channels-last, 32 channels per position (single-channel graphs)
+        if (C != 1 || !channels_last || (reinterpret_cast<uintptr_t>(out) & 15)) return false;
+        hipLaunchKernelGGL((conv1_mfma_kernel<1, 2>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+    } else if (C == 1 && channels_last)
+        hipLaunchKernelGGL((conv1_mfma_kernel<1, 1>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
     else if (C == 1)
-        hipLaunchKernelGGL((conv1_mfma_kernel<1, false>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+        hipLaunchKernelGGL((conv1_mfma_kernel<1, 0>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
     else if (channels_last)
-        hipLaunchKernelGGL((conv1_mfma_kernel<4, true>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+        hipLaunchKernelGGL((conv1_mfma_kernel<4, 1>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
     else
-        hipLaunchKernelGGL((conv1_mfma_kernel<4, false>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
+        hipLaunchKernelGGL((conv1_mfma_kernel<4, 0>), grid, dim3(kThreads), 0, ctx->stream, x, wq, bias, out, NF, tc, F, w1);
     return true;
 }

@@ -29,6 +29,8 @@ struct DcsColConv {
     int ph, kh;
     int xb_per_wg;              // column blocks (16 x each) a workgroup walks
     int n_xb;                   // column blocks per image
+    int in_f16;                 // 1: `in` holds f16, channels-last with 32 channels per position ([image][H][W][32] halves, in_n_stride in
+                                // halves): conv1_mfma_kernel<1, 2> writes it so for colconv_wreg_scatter_kernel (f16 switch)
     int out_f16;                // 1: `out` holds f16 ([image][Cout][Ho][W] halves, out_n_stride in halves) -- the f16 forward conv2 feeding
                                 // the f16 bottleneck layer (colconv_wreg_scatter_kernel only: dcs_colconv_wreg_scatter_ok)
 };
@@ -51,7 +53,7 @@ bool dcs_launch_slabconv_ps(dcs_ctx* ctx, DcsSlabConv a, int64_t n_images, const
 // conv1 with a frequency stride of 4 on the bf16 matrix pipe (conv1_mfma.hip): false = shape not covered, nothing launched
 void dcs_conv1_mfma_pack(const float* Wc, int NF, int C, int kw, std::vector<uint16_t>* out);
 bool dcs_launch_conv1_mfma(dcs_ctx* ctx, const float* x, const void* Wq, const float* bias, float* out, int64_t n, int C,
-                           int NF, int tc, int F, int kw, int sw, int w1, bool channels_last = false);
+                           int NF, int tc, int F, int kw, int sw, int w1, bool channels_last = false, bool out_f16 = false);
 // conv2 of the Bach10 / score-informed graphs, f32-class, weights in registers (colconv_fwd_x3.hip): channels-last input
 bool dcs_colconv_fwd_x3_ok(const DcsColConv& a);
 bool dcs_launch_colconv_fwd_x3(dcs_ctx* ctx, const DcsColConv& a, int64_t n_images, const void* Wq);

@@ -1633,7 +1633,7 @@ int launch_colconv(dcs_ctx* ctx, ColConvArgs a, int64_t n_images, const _Float16
                    const uint16_t* Wps = nullptr) {
     a.n_xb = (a.W + 15) / 16;
     if (Wh && Wr && dcs_launch_colconv_wreg(ctx, a, n_images, Wr)) return DCS_OK;
-    if (a.out_f16) DCS_FAIL(DCS_EHIP, "column convolution: f16 output asked of a kernel that cannot write it");
+    if (a.out_f16 || a.in_f16) DCS_FAIL(DCS_EHIP, "column convolution: f16 input / output asked of a kernel that cannot take it");
     constexpr bool ps_col = true;
     // f32-class forward conv2: bf16 x 3 with the slab pre-split in LDS (0.41 -> 0.25 ms on the score-informed batch).  The
     // transpose stays with the f32 column kernel: 7 of 20 taps are valid on average there and that kernel walks only
@@ -1709,6 +1709,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     const int NB = mask_mode == 2 ? d.n_branch : (d.S + C - 1) / C < d.n_branch ? (d.S + C - 1) / C : d.n_branch;
     const int64_t plane1 = (int64_t)tc * d.w1, planep = (int64_t)tc * d.wp;
     bool want_a1_cl = false, a1_cl = false;             // conv1's output channels-last: asked for / written that way
+    bool want_a1_16 = false, a1_16 = false;             // ... as f16 with 32 channels per position (f16 switch)
     float* a1b = (float*)w; w += align256((size_t)n * d.nf1 * plane1 * 4);
     float* p1 = a1b;
     if (d.pool_w) { p1 = (float*)w; w += align256((size_t)n * d.nf1 * planep * 4); }
@@ -1748,12 +1749,18 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c2.Cout = d.nf2; c2.Ho = d.h2; c2.ph = 0; c2.kh = d.kh2;
             want_a1_cl = !g->conv_f16 && g->use_colconv && g->Wfx3 && g->W1m && !d.pool_w && d.wp == d.w1 && dcs_colconv_fwd_x3_ok(c2) &&
                          (c2.in_n_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(a1b) & 7) == 0;
+            // f16 switch, one input channel (round 6): the weights-in-registers f16 conv2 takes its input as f16, channels-last, 32
+            // channels per position -- conv1 writes a1b16[n][t][x][32] halves (half the bytes; a lane of conv2 loads 16 bytes per row)
+            want_a1_16 = cl_env && g->conv_f16 && C == 1 && g->use_colconv && g->Wcol_h && g->Wcol_r && g->W1m && !d.pool_w && d.wp == d.w1 &&
+                         d.nf1 <= 32 && dcs_colconv_wreg_scatter_ok(c2) && (reinterpret_cast<uintptr_t>(a1b) & 15) == 0;
         }
         static const int reg1 = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
         const dim3 grid1((unsigned)dcs_cdiv(d.w1, kThreads), (unsigned)(n * tc));
         if (pool_fused) {   // conv1 + max-pool: pooled rows to p1, the un-pooling routing bits where the activations would go
             hipLaunchKernelGGL((conv1_reg_kernel<30, 3, true>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, p1, C,
                                tc, F, d.kw1, d.w1, pool_bits, d.wp, pool_mw, tie_mode == DCS_TIE_FIRST ? 1 : 0);
+        } else if (want_a1_16 && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1, true, true)) {
+            a1_16 = true;
         } else if (g->W1m && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1, want_a1_cl)) {
             a1_cl = want_a1_cl;
         } else if (reg1 && d.nf1 == 30 && d.kw1 <= 32 && d.sw1 == 4)   // the register kernel is built for 30 filters
@@ -1824,6 +1831,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = 0; c.kh = d.kh2;
             if (a2b16) { c.out_f16 = 1; c.out_n_stride = pitch16; }
+            if (a1_16) { c.in_f16 = 1; c.in_n_stride = (int64_t)tc * d.w1 * 32; }
             if (a1_cl) {
                 if (!dcs_launch_colconv_fwd_x3(ctx, c, n, g->Wfx3))
                     DCS_FAIL(DCS_EHIP, "generic graph: conv2 refused the channels-last input conv1 was asked to write");

@@ -154,7 +154,8 @@ DCS_API int dcs_model_num_sources(const dcs_model* m);
  * filter in one MFMA per tile (f32 accumulation).  Results stay within the f16 path's stated tolerance (2e-3 of the network
  * output, tests/test_gpu_configs.py), not within 1e-4.  Since round 6 the DENSE layers of that graph follow the switch as well
  * when a pass has 128 .. 176 tiles (the window of the all-rows kernels): the bottleneck layer and the per-source layers multiply
- * f16 weights (one plane, 2 bytes per weight -- SURVEY 8d prices this config as HBM-on-weights at fp16), conv2 hands its map to
+ * f16 weights (one plane, 2 bytes per weight -- SURVEY 8d prices this config as HBM-on-weights at fp16), conv1 hands its map to
+ * conv2 as f16 (the same values conv2 rounded to before, now rounded once by the producer), conv2 hands its map to
  * the bottleneck layer as f16, and the per-source layers write their output once as f16 in the layout the fused decoder reads
  * (gemm_f16.hip); the measured error of the network output is unchanged (3e-5: the f16 convolutions dominate).  The ikala
  * graph (10 x 20 filters) takes the same slab kernel in either precision (one f16 plane instead of three bf16 planes). */
