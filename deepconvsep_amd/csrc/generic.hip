@@ -1751,7 +1751,8 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                          (c2.in_n_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(a1b) & 7) == 0;
             // f16 switch, one input channel (round 6): the weights-in-registers f16 conv2 takes its input as f16, channels-last, 32
             // channels per position -- conv1 writes a1b16[n][t][x][32] halves (half the bytes; a lane of conv2 loads 16 bytes per row)
-            want_a1_16 = cl_env && g->conv_f16 && C == 1 && g->use_colconv && g->Wcol_h && g->Wcol_r && g->W1m && !d.pool_w && d.wp == d.w1 &&
+            static const bool cl_on = !(getenv("DCS_DECODER_CL") && atoi(getenv("DCS_DECODER_CL")) == 0);
+            want_a1_16 = cl_on && g->conv_f16 && C == 1 && g->use_colconv && g->Wcol_h && g->Wcol_r && g->W1m && !d.pool_w && d.wp == d.w1 &&
                          d.nf1 <= 32 && dcs_colconv_wreg_scatter_ok(c2) && (reinterpret_cast<uintptr_t>(a1b) & 15) == 0;
         }
         static const int reg1 = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
