@@ -93,6 +93,8 @@ struct dcs_model {
     int d2_ng = 4, d2_gs = 0, d2_gcols = 0;  // transposed conv2: channel groups, channels per group, padded columns
     float *B1 = nullptr, *bias1 = nullptr, *B2 = nullptr, *bias2 = nullptr, *Bfc = nullptr, *biasfc = nullptr;
     float *Bd = nullptr, *biasd = nullptr, *Bw2 = nullptr, *Bw2s = nullptr, *Bfin = nullptr, *bout = nullptr;
+    // conv2 -> bias -> bottleneck layer folded into one affine map over a tile's tc rows of conv1 output (pack_dsd)
+    float *B2fc = nullptr, *bias2fc = nullptr;
     // ---- generic path (ikala / bach10 / score-informed)
     DcsGenericNet* gen = nullptr;
     // ---- scratch
@@ -212,6 +214,36 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
             for (int h = 0; h < d.hidden; ++h)
                 Bfc[(size_t)(t * CP + co) * m->hid64 + h] = Wfc[(size_t)(co * d.h2 + t) * d.hidden + h];
     for (int h = 0; h < d.hidden; ++h) biasfc[h] = bfc[h];
+    // conv2 and its BiasLayer are LINEAR (nonlinearity=None, separate_dsd.py:202-203) and feed the bottleneck DenseLayer only
+    // (:206), so  Z = relu(flatten(conv2(H1) + b2) . Wfc + bfc)  is one affine map of the tile's tc rows of H1 followed by the
+    // rectifier:  Z = relu(sum_r H1[row0 + r] . W2fc[r] + c),  W2fc[r][ci][h] = sum_{u + t = r} sum_co W2[co,ci,u] Wfc[(co,t)][h],
+    // c[h] = bfc[h] + sum_{t,co} b2[co] Wfc[(co,t)][h].  Folded here in float64, rounded once to float32: K = tc * CI = 1560
+    // against conv2's 750 on 5.9 x as many rows plus the bottleneck's 832 -- fewer flops, one launch instead of two, and the
+    // conv2 map (positions x 50) is never written.  The fused launches with more than one batch take it (dsd_encode).
+    std::vector<float> B2fc((size_t)dcs_round_up(m->tc * CI, 128) * m->hid64, 0.f), bias2fc(m->hid64, 0.f);
+    {
+        std::vector<double> acc((size_t)m->tc * CI * m->hid64, 0.0), cb(m->hid64, 0.0);
+        for (int u = 0; u < kh; ++u)
+            for (int ci = 0; ci < d.nf1; ++ci)
+                for (int co = 0; co < d.nf2; ++co) {
+                    const double w2 = B2[(size_t)(u * CI + ci) * 64 + co];
+                    if (w2 == 0.0) continue;
+                    for (int t = 0; t < d.h2; ++t) {
+                        const float* fr = &Bfc[(size_t)(t * CP + co) * m->hid64];
+                        double* ar = &acc[(size_t)((u + t) * CI + ci) * m->hid64];
+                        for (int h = 0; h < d.hidden; ++h) ar[h] += w2 * (double)fr[h];
+                    }
+                }
+        for (int h = 0; h < d.hidden; ++h) cb[h] = bfc[h];
+        for (int t = 0; t < d.h2; ++t)
+            for (int co = 0; co < d.nf2; ++co) {
+                const double b = bias2[co];
+                const float* fr = &Bfc[(size_t)(t * CP + co) * m->hid64];
+                for (int h = 0; h < d.hidden; ++h) cb[h] += b * (double)fr[h];
+            }
+        for (size_t i = 0; i < acc.size(); ++i) B2fc[i] = (float)acc[i];
+        for (int h = 0; h < d.hidden; ++h) bias2fc[h] = (float)cb[h];
+    }
     // per-source dense layers, concatenated along N and permuted to [branch][t'][co]
     std::vector<float> Bd((size_t)dcs_round_up(m->hid64, 128) * m->nd64, 0.f), biasd(m->nd64, 0.f);
     for (int s = 0; s < d.n_fc; ++s) {
@@ -253,6 +285,10 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     DCS_CHECK(upload(&m->bias2, bias2));
     DCS_CHECK(upload(&m->Bfc, Bfc));
     DCS_CHECK(upload(&m->biasfc, biasfc));
+    if (d.h2 + kh - 1 == m->tc) {   // (always: h2 = tc - kh + 1)
+        DCS_CHECK(upload(&m->B2fc, B2fc));
+        DCS_CHECK(upload(&m->bias2fc, bias2fc));
+    }
     DCS_CHECK(upload(&m->Bd, Bd));
     DCS_CHECK(upload(&m->biasd, biasd));
     DCS_CHECK(upload(&m->Bw2, Bw2));
@@ -385,7 +421,11 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g2.B = m->B2; g2.ldb = 64; g2.bias = m->bias2;
     g2.C = w.C2; g2.ldc = CP; g2.c_gdiv = 1 << 30; g2.c_gmul = 0;
     g2.n_cols = 64; g2.n_store = CP; g2.K = d.kh2 * CI; g2.relu = 0; g2.a_vec = 1;
-    if (lat & DCS_LAT_CONV2) {
+    // conv2 + bottleneck as ONE affine map of the tile's tc rows of H1 (pack_dsd: B2fc): whenever neither runs on the one-batch kernels
+    static const bool fold_env = !(getenv("DCS_FOLD_CONV2") && atoi(getenv("DCS_FOLD_CONV2")) == 0);
+    const bool fold2 = fold_env && m->B2fc && !(lat & (DCS_LAT_CONV2 | DCS_LAT_FC));
+    if (fold2) {
+    } else if (lat & DCS_LAT_CONV2) {
         DcsLatGemm q{};   // the A row of position p is kh consecutive H1 rows = kh * CI contiguous floats: one slice per tap
         q.A = w.H1; q.a_row_stride = CI; q.a_scale = 1.f; q.Bp = m->L2p; q.bias = m->bias2;
         q.C = w.C2; q.ldc = CP; q.M = (int)g2.M; q.n_store = CP; q.K = d.kh2 * CI; q.slice_len = CI;
@@ -403,6 +443,10 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g3.a_scale = 1.f; g3.B = m->Bfc; g3.ldb = m->hid64; g3.bias = m->biasfc;
     g3.C = w.Z; g3.ldc = m->hid64; g3.c_gdiv = 1 << 30; g3.c_gmul = 0;
     g3.M = n_tiles_all; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
+    if (fold2) {   // A row of tile k = its tc rows of H1 (the same row index as its first conv2 position)
+        g3.A = w.H1; g3.lda = (shared_frames ? tile_row_stride : tc) * (int64_t)CI;
+        g3.B = m->B2fc; g3.bias = m->bias2fc; g3.K = tc * CI;
+    }
     if (lat & DCS_LAT_FC) {
         DcsLatGemm q{};   // the A row of tile k is h2 consecutive C2 rows from row k * st: one slice per row
         q.A = w.C2; q.a_row_stride = tile_row_stride * (int64_t)CP; q.a_scale = 1.f; q.Bp = m->Lfcp; q.bias = m->biasfc;
@@ -543,7 +587,8 @@ extern "C" int dcs_model_create(dcs_ctx* ctx, int arch, int C, int tc, int F, co
 extern "C" int dcs_model_destroy(dcs_model* m) {
     if (!m) return DCS_OK;
     DCS_ON_DEVICE(m->ctx->device);
-    float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bw2s, m->Bfin, m->bout};
+    float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bw2s, m->Bfin, m->bout,
+                     m->B2fc, m->bias2fc};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& t : m->rise_tabs)

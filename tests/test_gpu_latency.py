@@ -119,7 +119,26 @@ def test_one_batch_path_on_adversarial_weights(kind, N):
     s_lat, pcm_lat = out["lat"]
     s_thr, pcm_thr = out["thr"]
     assert np.max(np.abs(pcm_lat - want)) < 1e-4
-    assert np.max(np.abs(pcm_lat - pcm_thr)) < 5e-6
+    # The two kernel families evaluate conv2 + BiasLayer + bottleneck layer in two algebraic forms since round 6 (one batch:
+    # layer by layer; launch groups: the folded affine map of net.hip: pack_dsd), so they agree to float32 rounding of the
+    # network output -- and therefore on every bin of the separated spectrogram except where the mask is discontinuous:
+    # where EVERY source's network output is (nearly) nothing, a difference in the ninth digit decides between a mask of 0 and
+    # a mask of 1 (oracle/maskcheck.py).  Measured: 0 such bins (tiny, dominant), 1 of 191 675 (sparse).  Allowed: at most 2,
+    # and only where the float64 oracle's own network output is below 1e-6 in every source of every tile that covers the bin.
+    diff = np.abs(s_lat - s_thr).max(axis=0)                 # [T, F]
+    flipped = np.argwhere(diff > 5e-6 * max(1.0, float(np.max(mag))))
+    assert len(flipped) <= 2, (kind, len(flipped))
+    if len(flipped):
+        from oracle import net_ref
+        flat = tiles.reshape((-1,) + tiles.shape[2:])[:n]
+        st = TC - 25
+        for t, fbin in flipped:
+            ks = [k for k in range(n) if k * st <= t < k * st + TC]
+            p = net_ref.forward("dsd", params, flat[ks].astype(np.float64)).numpy()
+            worst = max(float(p[i, :, t - k * st, fbin].max()) for i, k in enumerate(ks))
+            assert worst < 1e-6, (kind, int(t), int(fbin), worst)
+    # PCM: identical to rounding away from such a bin; a flipped bin moves one frame's worth of samples by at most its magnitude / sqrt(N)
+    assert np.max(np.abs(pcm_lat - pcm_thr)) < (5e-6 if not len(flipped) else 1e-3)
     err = np.abs(s_lat - mm)
     bad = err.max(axis=0) > 1e-4
     os.makedirs("gpurun_out", exist_ok=True)

@@ -1242,6 +1242,7 @@ _VARIANT_ENVS = [
     {"DCS_ISTFT_STAGE_MIN": "1"},                                  # spectra through LDS (long clips' iSTFT) on a short clip
     {"DCS_ISTFT_STAGE": "0"},
     {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "7"},   # chained iSTFT off / forced frames per wave
+    {"DCS_FOLD_CONV2": "0"},                                       # conv2 and the bottleneck layer as two launches (the unfolded weights)
 ]
 
 
