@@ -154,6 +154,29 @@ __global__ __launch_bounds__(kThreads) void zero_pad_cols_kernel(float* __restri
     buf[r * pitch + width + (int)(idx - r * npad)] = 0.f;
 }
 
+// conv2 -> BiasLayer -> bottleneck DenseLayer folded into one affine map of the tile's conv2 INPUT (model creation, once):
+//   Z[h] = relu(c[h] + sum_{ci,r,x} p1[ci][r][x] W2fc[(ci, r, x)][h]),
+//   W2fc[(ci, r, x)][h] = sum_{u,v : 0 <= r-u < h2, 0 <= x-v < w2} sum_co Wf[u][v][co][ci] Bfc[(co, r-u, x-v)][h]
+// (no nonlinearity between the two layers: separate_ikala.py:181-186).  float64 sums, rounded once to float32.
+// One workgroup per input position k = (ci, r, x), one thread per hidden unit; Wf is read through scalar loads.
+__global__ __launch_bounds__(kThreads) void fold_conv2_fc_kernel(const float* __restrict__ Wf /* [kh*kw][nf2][nf1] */,
+                                                                 const float* __restrict__ Bfc /* [flat_p][hid64] */,
+                                                                 float* __restrict__ out /* [nf1*tc*wp][hid64] */, int nf1, int nf2,
+                                                                 int kh, int kw, int tc, int wp, int h2, int w2, int hid64) {
+    const int k = blockIdx.x, ci = k / (tc * wp), r = (k / wp) % tc, x = k % wp;
+    for (int h = threadIdx.x; h < hid64; h += kThreads) {
+        double acc = 0.0;
+        for (int u = r - h2 + 1 > 0 ? r - h2 + 1 : 0; u < kh && u <= r; ++u)
+            for (int v = x - w2 + 1 > 0 ? x - w2 + 1 : 0; v < kw && v <= x; ++v) {
+                const float* wrow = Wf + ((size_t)(u * kw + v) * nf2) * nf1 + ci;
+                const float* brow = Bfc + ((size_t)(r - u) * w2 + (x - v)) * hid64 + h;
+                for (int co = 0; co < nf2; ++co)
+                    acc += (double)wrow[(size_t)co * nf1] * (double)brow[(size_t)co * h2 * w2 * hid64];
+            }
+        out[(size_t)k * hid64 + h] = (float)acc;
+    }
+}
+
 // max-pool (1,pw), stride pw, ignore_border: rows of w1 -> rows of wp
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void pool_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -1300,6 +1323,8 @@ struct DcsGenericNet {
     int use_colconv = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
+    float *B2fc = nullptr, *bias2fc = nullptr;          // conv2 + bias + bottleneck layer as one affine map of conv2's input (fold_conv2_fc_kernel)
+    int K2fc = 0;                                        // its K = nf1 * tc * wp (0: not folded)
     void* Bfcq = nullptr;                                // the bottleneck weights as bf16 x 3 planes (long-K launches of 128 .. 176 rows), on first need
     bool bfcq_failed = false;
     float* Bd[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1509,6 +1534,49 @@ int dcs_generic_create(dcs_ctx* ctx, const DcsGenericDims& d, int C, int tc, int
             UP(g->W1dq, W1dq)
         }
     }
+    // Fold conv2 + BiasLayer + bottleneck layer where it pays: the folded layer multiplies tc * wp / (h2 * w2) times the
+    // bottleneck's weights, conv2 goes away.  iKala (10 x 20 filters): 159 MFLOP of conv2 per tile against 12 more in the
+    // dense layer -- folded; the column-filter graphs (Bach10: 200 against 147, on a layer that is bound by its weight
+    // stream) stay layer by layer.  DCS_FOLD_CONV2=0: off.
+    {
+        static const bool fold_env = !(getenv("DCS_FOLD_CONV2") && atoi(getenv("DCS_FOLD_CONV2")) == 0);
+        const int64_t Kf = (int64_t)nf1 * tc * d.wp;
+        const double conv2_flop = 2.0 * nf2 * nf1 * kh * kw * d.h2 * d.w2, more_fc_flop = 2.0 * (double)(Kf - d.flat) * d.hidden;
+        if (rc == DCS_OK && fold_env && kw > 1 && (Kf & 3) == 0 && Kf < (1 << 30) && conv2_flop >= 4.0 * more_fc_flop) {
+            std::vector<float> Wf2((size_t)kh * kw * nf2 * nf1);
+            for (int co = 0; co < nf2; ++co)
+                for (int ci = 0; ci < nf1; ++ci)
+                    for (int u = 0; u < kh; ++u)
+                        for (int v = 0; v < kw; ++v)
+                            Wf2[((size_t)(u * kw + v) * nf2 + co) * nf1 + ci] = W2[(((size_t)co * nf1 + ci) * kh + (kh - 1 - u)) * kw + (kw - 1 - v)];
+            std::vector<double> cb(g->hid64, 0.0);
+            for (int h = 0; h < d.hidden; ++h) cb[h] = P[7][h];
+            for (int co = 0; co < nf2; ++co) {
+                const double b = (double)b2[co] + (double)b2b[co];
+                for (int i = 0; i < d.h2 * d.w2; ++i) {
+                    const float* fr = &P[6][((size_t)co * d.h2 * d.w2 + i) * d.hidden];
+                    for (int h = 0; h < d.hidden; ++h) cb[h] += b * (double)fr[h];
+                }
+            }
+            std::vector<float> bias2fc(g->hid64, 0.f);
+            for (int h = 0; h < d.hidden; ++h) bias2fc[h] = (float)cb[h];
+            float* Wf2_d = nullptr;
+            UP(Wf2_d, Wf2) UP(g->bias2fc, bias2fc)
+            const size_t rows = (size_t)dcs_round_up(Kf, 128);
+            if (rc == DCS_OK && hipMalloc((void**)&g->B2fc, rows * g->hid64 * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError();
+                g->B2fc = nullptr;                       // does not fit: layer by layer
+            }
+            if (rc == DCS_OK && g->B2fc) {
+                if (hipMemsetAsync(g->B2fc, 0, rows * g->hid64 * sizeof(float), ctx->stream) != hipSuccess) rc = DCS_EHIP;
+                hipLaunchKernelGGL(fold_conv2_fc_kernel, dim3((unsigned)Kf), dim3(kThreads), 0, ctx->stream, Wf2_d, g->Bfc, g->B2fc, nf1,
+                                   nf2, kh, kw, tc, d.wp, d.h2, d.w2, g->hid64);
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = DCS_EHIP;
+                g->K2fc = (int)Kf;
+            }
+            if (Wf2_d) (void)hipFree(Wf2_d);
+        }
+    }
     if (g->use_slabconv) { UP(g->Wslab, Wslab) UP(g->Wslab_t, Wslab_t) UP(g->Wslab_q3, Wslab_q3) UP(g->Wslab_t_q3, Wslab_t_q3) UP(g->Wslab_h, Wslab_h) UP(g->Wslab_t_h, Wslab_t_h) UP(g->Wps_q3, Wps_q3) UP(g->Wps_t_q3, Wps_t_q3) UP(g->Wps_h, Wps_h) UP(g->Wps_t_h, Wps_t_h) }
     if (g->use_colconv) {
         std::vector<_Float16> Wcol_r, Wcol_t_r;
@@ -1572,7 +1640,7 @@ void dcs_generic_destroy(DcsGenericNet* g) {
                     g->Bfc, g->biasfc, g->Bd[0], g->Bd[1], g->Bd[2], g->Bd[3], g->biasd[0], g->biasd[1], g->biasd[2],
                     g->biasd[3], g->bout, g->rise_d, g->Bdq[0], g->Bdq[1], g->Bdq[2], g->Bdq[3], g->biasd_cl[0], g->biasd_cl[1],
                     g->biasd_cl[2], g->biasd_cl[3], g->Wx3, g->Bfcq, g->Wfx3, g->Bdh[0], g->Bdh[1], g->Bdh[2], g->Bdh[3], g->biasd_h[0],
-                    g->biasd_h[1], g->biasd_h[2], g->biasd_h[3], g->Bfch, g->Bd32[0], g->Bd32[1], g->Bd32[2], g->Bd32[3]};
+                    g->biasd_h[1], g->biasd_h[2], g->biasd_h[3], g->Bfch, g->Bd32[0], g->Bd32[1], g->Bd32[2], g->Bd32[3], g->B2fc, g->bias2fc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     g->ws.release();
@@ -1811,15 +1879,19 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             a2b16 = dcs_colconv_wreg_scatter_ok(c2);
         }
     }
+    // conv2 + BiasLayer + bottleneck layer as one folded affine map of conv2's input (created with the model where it pays:
+    // the iKala graph; f32-class only -- the f16 switch asks for conv2 in f16)
+    const bool fold2 = g->B2fc && g->K2fc > 0 && !g->conv_f16 && !a1_cl && !a1_16;
     // conv2 + both biases -> a2b[n][flat_p] (pad columns zeroed; f16: the pitch16 - flat pad halves, as flat / 2 .. pitch16 / 2 floats)
-    if (a2b16) {
+    if (fold2) {
+    } else if (a2b16) {
         if (pitch16 != d.flat)
             hipLaunchKernelGGL(zero_pad_cols_kernel, dim3((unsigned)dcs_cdiv(n * ((pitch16 - d.flat) / 2), kThreads)), dim3(kThreads), 0,
                                ctx->stream, a2b, n, d.flat / 2, pitch16 / 2);
     } else if (g->flat_p != d.flat)
         hipLaunchKernelGGL(zero_pad_cols_kernel, dim3((unsigned)dcs_cdiv(n * (g->flat_p - d.flat), kThreads)), dim3(kThreads), 0,
                            ctx->stream, a2b, n, d.flat, g->flat_p);
-    {
+    if (!fold2) {
         IgemmArgs a{};
         a.in = p1; a.in_n_stride = (int64_t)d.nf1 * planep; a.Cin = d.nf1; a.H = tc; a.W = d.wp;
         a.Wm = g->W2m; a.koff = g->k2off; a.kuv = g->k2uv; a.bias = g->bias2;
@@ -1866,11 +1938,14 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
         q.B = g->Bfc; q.ldb = g->hid64; q.bias = g->biasfc;
         q.C = Z; q.ldc = g->hid64; q.c_gdiv = 1 << 30; q.c_gmul = 0;
         q.M = n; q.n_cols = g->hid64; q.n_store = g->hid64; q.K = g->flat_p; q.relu = 1; q.a_vec = 1;
+        if (fold2) {   // the tile's conv2 input p1[ci][row][x], contiguous per tile
+            q.A = p1; q.lda = (int64_t)d.nf1 * planep; q.K = g->K2fc; q.B = g->B2fc; q.bias = g->bias2fc;
+        }
         // 128 .. 176 tiles against a very long K (166 650 for the Bach10 graphs): the all-rows bf16 x 3 kernel with K cut into
         // slices (dcs_launch_gemm_bf16x3_longk) -- the planes (1.5 x the f32 weights) are made on first need; without them,
         // or for any other row count, the f32 K-split of gemm.hip
         static const bool fcq_on = !(getenv("DCS_GEMM_BF16") && atoi(getenv("DCS_GEMM_BF16")) == 0);
-        if (fcq_on && n >= 128 && n <= 176 && g->flat_p >= 16384 && (g->hid64 % 128) == 0 && !g->Bfcq && !g->bfcq_failed &&
+        if (!fold2 && fcq_on && n >= 128 && n <= 176 && g->flat_p >= 16384 && (g->hid64 % 128) == 0 && !g->Bfcq && !g->bfcq_failed &&
             (!g->conv_f16 || g->bfch_failed)) {           // (under the f16 switch the layer takes the f16 plane below instead)
             void* planes = nullptr;                       // (unsplit 32-byte pieces since round 6: the long-K launch is the all-rows kernel)
             if (hipMalloc(&planes, dcs_gemm_b32_bytes(g->flat_p, g->hid64)) != hipSuccess) {
@@ -1885,7 +1960,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
                 g->Bfcq = planes;
             }
         }
-        q.Bq = g->Bfcq;
+        q.Bq = fold2 ? nullptr : g->Bfcq;
         q.bq_f32 = 1;
         // f16 switch: the same long-K launch on f16 weights (gemm_f16.hip: one plane, 2 bytes per weight instead of 6); the rows
         // of A are conv2's f16 map (a2b16, above) or, when conv2 could not write it, f32 rows split into two f16 terms on their

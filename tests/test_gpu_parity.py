@@ -1059,14 +1059,19 @@ sys.exit(0 if err < 1e-4 else 3)
 @pytest.mark.parametrize("F,n", [(513, 9), (1025, 3)])
 def test_ikala_conv2_kernels_agree_with_the_oracle(F, n, tmp_path):
     """conv2 of the iKala graph (10 x 20) and its transpose: slab kernel on the bf16 matrix pipe with the slab pre-split
-    into bf16 planes (default, slabconv_ps.hip: tap loop driven by per-block bit masks), the one that splits per tap
-    (DCS_SLABCONV_PS=0) and the implicit-GEMM fallback, on batch sizes that give several row bands per image."""
+    into bf16 planes (slabconv_ps.hip: tap loop driven by per-block bit masks), the one that splits per tap
+    (DCS_SLABCONV_PS=0) and the implicit-GEMM fallback, on batch sizes that give several row bands per image; and the
+    folded conv2 + bottleneck map that replaces the forward conv2 by default (generic.hip: fold_conv2_fc_kernel)."""
     import subprocess
     x = _tiles("ikala", n, 30, F, seed=16)
     want = net_ref.forward("ikala", synth_params("ikala", 30, F, seed=4), x.astype(np.float64), inverse='explicit').numpy()
     f = tmp_path / "case.npz"
     np.savez(f, x=x, want=want, F=F)
-    _run_children(_IKALA_CHILD, [ROOT, f], [{"DCS_SLABCONV": "0"}, {"DCS_SLABCONV": "1"}, {"DCS_SLABCONV_PS": "0"}], timeout=200)
+    # (since round 6 the default folds conv2 + bottleneck layer into one affine map for this graph: the forward conv2 kernels
+    # run with DCS_FOLD_CONV2=0; the first child is the folded default, the second the default conv2 kernel)
+    unfolded = {"DCS_FOLD_CONV2": "0"}
+    _run_children(_IKALA_CHILD, [ROOT, f], [{}, unfolded, dict(unfolded, DCS_SLABCONV="0"), dict(unfolded, DCS_SLABCONV="1"),
+                                            dict(unfolded, DCS_SLABCONV_PS="0")], timeout=200)
 
 
 _GENERIC_CASE = []
