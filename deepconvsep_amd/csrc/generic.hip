@@ -1323,6 +1323,10 @@ struct DcsGenericNet {
     int use_colconv = 0;
     // dense
     float *Bfc = nullptr, *biasfc = nullptr;
+    // whole-path calls on ONE clip: the clip's scaled frames [C][frames_rows][F], tile k = rows k * frames_st .. + tc (set around
+    // dcs_generic_forward by the separate path, null otherwise): conv1 is a per-row operation, so it runs once per FRAME
+    const float* frames_src = nullptr;
+    int frames_rows = 0, frames_st = 0;
     float *B2fc = nullptr, *bias2fc = nullptr;          // conv2 + bias + bottleneck layer as one affine map of conv2's input (fold_conv2_fc_kernel)
     int K2fc = 0;                                        // its K = nf1 * tc * wp (0: not folded)
     void* Bfcq = nullptr;                                // the bottleneck weights as bf16 x 3 planes (long-K launches of 128 .. 176 rows), on first need
@@ -1778,6 +1782,7 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
     const int64_t plane1 = (int64_t)tc * d.w1, planep = (int64_t)tc * d.wp;
     bool want_a1_cl = false, a1_cl = false;             // conv1's output channels-last: asked for / written that way
     bool want_a1_16 = false, a1_16 = false;             // ... as f16 with 32 channels per position (f16 switch)
+    int a1_rows = tc;                                   // rows from one tile's first row to the next's in the channels-last map (per-frame conv1: the stride)
     float* a1b = (float*)w; w += align256((size_t)n * d.nf1 * plane1 * 4);
     float* p1 = a1b;
     if (d.pool_w) { p1 = (float*)w; w += align256((size_t)n * d.nf1 * planep * 4); }
@@ -1823,11 +1828,23 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             want_a1_16 = cl_on && g->conv_f16 && C == 1 && g->use_colconv && g->Wcol_h && g->Wcol_r && g->W1m && !d.pool_w && d.wp == d.w1 &&
                          d.nf1 <= 32 && dcs_colconv_wreg_scatter_ok(c2) && (reinterpret_cast<uintptr_t>(a1b) & 15) == 0;
         }
+        // One clip, all its tiles in this chunk, a channels-last hand-over to conv2: conv1 (a per-row operation) runs once per
+        // FRAME of the clip instead of once per tile row -- tc / (tc - overlap) = 6 x fewer rows at the reference's settings --
+        // and conv2 takes tile k as the window of tc rows from row k * st of that map (its tile stride is a parameter).
+        // Same arithmetic per row: bit-identical to the per-tile form.
+        const bool per_frame = g->frames_src && n == n_total && k_first == 0 && g->frames_st > 0 &&
+                               g->frames_rows == (n - 1) * g->frames_st + tc && g->frames_st < tc;
         static const int reg1 = getenv("DCS_CONV1_REG") ? atoi(getenv("DCS_CONV1_REG")) : 1;
         const dim3 grid1((unsigned)dcs_cdiv(d.w1, kThreads), (unsigned)(n * tc));
         if (pool_fused) {   // conv1 + max-pool: pooled rows to p1, the un-pooling routing bits where the activations would go
             hipLaunchKernelGGL((conv1_reg_kernel<30, 3, true>), grid1, dim3(kThreads), 0, ctx->stream, tiles, g->W1t, g->bias1, p1, C,
                                tc, F, d.kw1, d.w1, pool_bits, d.wp, pool_mw, tie_mode == DCS_TIE_FIRST ? 1 : 0);
+        } else if (per_frame && want_a1_16 &&
+                   dcs_launch_conv1_mfma(ctx, g->frames_src, g->W1m, g->bias1, a1b, 1, C, d.nf1, g->frames_rows, F, d.kw1, d.sw1, d.w1, true, true)) {
+            a1_16 = true; a1_rows = g->frames_st;
+        } else if (per_frame && want_a1_cl &&
+                   dcs_launch_conv1_mfma(ctx, g->frames_src, g->W1m, g->bias1, a1b, 1, C, d.nf1, g->frames_rows, F, d.kw1, d.sw1, d.w1, true)) {
+            a1_cl = true; a1_rows = g->frames_st;
         } else if (want_a1_16 && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1, true, true)) {
             a1_16 = true;
         } else if (g->W1m && dcs_launch_conv1_mfma(ctx, tiles, g->W1m, g->bias1, a1b, n, C, d.nf1, tc, F, d.kw1, d.sw1, d.w1, want_a1_cl)) {
@@ -1904,7 +1921,8 @@ int forward_chunk(DcsGenericNet* g, const float* tiles, int64_t n, int64_t n_tot
             c.Wk = g->Wcol; c.bias = a.bias; c.out = a.out; c.out_n_stride = a.out_n_stride; c.Cout = a.Cout; c.Ho = a.Ho;
             c.ph = 0; c.kh = d.kh2;
             if (a2b16) { c.out_f16 = 1; c.out_n_stride = pitch16; }
-            if (a1_16) { c.in_f16 = 1; c.in_n_stride = (int64_t)tc * d.w1 * 32; }
+            if (a1_16) { c.in_f16 = 1; c.in_n_stride = (int64_t)a1_rows * d.w1 * 32; }
+            else if (a1_cl) c.in_n_stride = (int64_t)a1_rows * d.w1 * d.nf1;
             if (a1_cl) {
                 if (!dcs_launch_colconv_fwd_x3(ctx, c, n, g->Wfx3))
                     DCS_FAIL(DCS_EHIP, "generic graph: conv2 refused the channels-last input conv1 was asked to write");
@@ -2340,11 +2358,20 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
     const size_t b_tiles = align256((size_t)n_all * g->C * tc * F * 4), b_out = align256((size_t)S * n_all * tc * F * 4);
     const size_t b_sep = align256((size_t)n_clips * S * rows * ld * 4);
     const size_t b_inp = notes ? align256((size_t)g->C * T * F * 4) : 0;   // score-informed network input [C][T][F]
+    // one clip through a graph whose conv1 can hand its map to conv2 channels-last: the clip's scaled frames once more as
+    // [C][Tn][F] rows (a sixth of the tiles), so that conv1 runs per frame instead of per tile row (forward_chunk: per_frame)
+    const int64_t Tn = (n - 1) * st + tc;
+#ifdef DCS_EXP_NO_PER_FRAME      // experiment build (scripts/build_exp.sh): the per-tile conv1 of round 5 for a same-box A/B
+    const bool want_frames = false;
+#else
+    const bool want_frames = n_clips == 1 && !lens_h && n >= 2 && st > 0 && st < tc && g->W1m && g->use_colconv && g->C * Tn <= 65535;
+#endif
+    const size_t b_frames = want_frames ? align256((size_t)g->C * Tn * F * 4) : 0;
     if (notes && (n_clips != 1 || notes->ninst != g->C))
         DCS_FAIL(DCS_EINVAL, "score-informed path: one clip, %d score channels (got %d)", g->C, notes->ninst);
     if (lens_h && (notes || g->C != 1 || !clip_tab_d || phase_out || sep_out || mag_out))
         DCS_FAIL(DCS_EUNSUPPORTED, "clips of different lengths: single-channel graphs, PCM output");
-    DCS_CHECK(ws->ensure(b_mag + b_unit + b_ph + b_tiles + b_out + b_sep + b_inp));
+    DCS_CHECK(ws->ensure(b_mag + b_unit + b_ph + b_tiles + b_out + b_sep + b_inp + b_frames));
     char* p = (char*)ws->ptr;
     float* mag = (float*)p; p += b_mag;
     float2* unit = (float2*)p; p += b_unit;
@@ -2353,6 +2380,7 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
     float* outm = (float*)p; p += b_out;
     float* sep = (float*)p; p += b_sep;
     float* inp = (float*)p; p += b_inp;
+    float* frames = (float*)p; p += b_frames;
     DCS_CHECK(dcs_launch_stft_forward_f32_clips(plan, audio, L, audio_stride, n_clips, mag, phase, unit, ld, T, T, false, clip_tab_d));
     if (notes) {
         // separate_bach10.py (score-informed) :503-527: scaled magnitudes x filterSpec masks, one channel per instrument,
@@ -2363,6 +2391,15 @@ int dcs_generic_separate(DcsGenericNet* g, dcs_stft* plan, const float* audio, i
     } else {
         for (int64_t c = 0; c < n_clips; ++c)
             DCS_CHECK(dcs_launch_tile(ctx, mag + c * T * ld, 0, ld, 1, Tc[c], F, tc, ov, tiler, scale, tiles + off[c] * tc * F, nc[c]));
+    }
+    struct FramesScope {                                 // the frames belong to this call only
+        DcsGenericNet* g;
+        ~FramesScope() { g->frames_src = nullptr; g->frames_rows = 0; g->frames_st = 0; }
+    } frames_scope{g};
+    if (want_frames) {
+        if (notes) DCS_CHECK(dcs_launch_tile(ctx, inp, T * (int64_t)F, F, g->C, T, F, (int)Tn, 0, tiler, 1.0f, frames, 1));
+        else DCS_CHECK(dcs_launch_tile(ctx, mag, 0, ld, 1, T, F, (int)Tn, 0, tiler, scale, frames, 1));
+        g->frames_src = frames; g->frames_rows = (int)Tn; g->frames_st = st;
     }
     // mask + cross-fade in one kernel when all tiles go through the graph in one chunk (the masked tiles then never exist)
     static const bool fuse_env = !(getenv("DCS_MASK_OLA") && atoi(getenv("DCS_MASK_OLA")) == 0);
