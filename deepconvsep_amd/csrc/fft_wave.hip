@@ -102,6 +102,18 @@ __device__ __forceinline__ cx tw_fwd(const float2* tw, int j, int M) {
     return j <= M ? w : -w;
 }
 
+// The same from the QUARTER-circle table th[0..M/2] (forward kernel, N <= 2048: half the LDS of the table, see
+// stft_forward_wave_kernel): exp(-i pi k / M) for M/2 < k <= M is -conj(th[M - k]).
+__device__ __forceinline__ cx tw_half(const float2* th, int k, int M) {   // 0 <= k <= M
+    const bool hi = k > M / 2;
+    const cx w = ldc(th + (hi ? M - k : k));
+    return hi ? mk(-w[0], w[1]) : w;
+}
+__device__ __forceinline__ cx tw_fwd_half(const float2* th, int j, int M) {   // 0 <= j < 2M
+    const cx w = tw_half(th, j <= M ? j : j - M, M);
+    return j <= M ? w : -w;
+}
+
 template <int DIR>
 __device__ __forceinline__ void dft4(cx& a, cx& b, cx& c, cx& d) {
     const cx a02 = a + c, s02 = a - c, a13 = b + d, s13 = b - d;
@@ -215,6 +227,15 @@ struct WaveTw {
             for (int t = 1; t < PL::R3; ++t) t3[t - 1] = tw_fwd(tw, t * 2 * lane, M);
         }
     }
+    __device__ __forceinline__ void init_half(const float2* th, int lane) {   // from the quarter-circle table (tw_half)
+        const int step2 = ((2 * M) / PL::R2 / PL::R1) * (lane & (PL::R1 - 1));
+#pragma unroll
+        for (int t = 1; t < PL::R2; ++t) t2[t - 1] = tw_fwd_half(th, t * step2, M);
+        if (REG3) {
+#pragma unroll
+            for (int t = 1; t < PL::R3; ++t) t3[t - 1] = tw_fwd_half(th, t * 2 * lane, M);
+        }
+    }
 };
 
 // Three Stockham passes.  On entry v holds the first-pass input v[b*R1 + t] = x[lane + 64 b + t*M/R1]; on exit
@@ -296,8 +317,16 @@ __device__ __forceinline__ void fft_wave(cx (&v)[(1 << LOG2M) / 64], int lane, c
 // per-wave staging of the forward kernel's outputs: 256 magnitudes (1 KB) + 128 phasors (1 KB), see the wide store path
 constexpr int kStftStageF2 = 256;
 
+// N <= 2048 (HALF): four workgroups of four waves per CU instead of three, so that the 3 720 - 3 800 frames of a 20 x 32-tile launch
+// group are resident in ONE round (4 096 wave slots; with three per CU the launch was 1.24 rounds = two wave lives).  That
+// needs <= 40 KB of LDS per workgroup and <= 128 registers:
+//   * the twiddle table holds the quarter circle only (tw_half: exp(-i pi k / M), k <= M / 2; the rest by symmetry);
+//   * no staging area of its own: bins k and M - k are computed TOGETHER from the one pair (Z[k], Z[M - k]) they share --
+//     X[k] = E + w^k O, X[M - k] = conj(E - w^k O): half the LDS reads and twiddle products of the split -- 256 direct and 256
+//     mirrored bins per phase into registers, and the wide stores are staged through the exchange-buffer slots that phase has
+//     just read for the last time.
 template <int LOG2M>
-__global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
+__global__ __launch_bounds__(256, LOG2M <= 10 ? 4 : 1) void stft_forward_wave_kernel(const float* __restrict__ audio, int64_t L, const float* __restrict__ win,
                                          const float2* __restrict__ tw, float* __restrict__ mag,
                                          float* __restrict__ phase, float2* __restrict__ unit, int64_t ld, int hop,
                                          int64_t T, int64_t rows_pc, int64_t n_clips, int64_t audio_stride,
@@ -308,12 +337,14 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row pointers stay in SGPRs
     FW_STAMP(0);
-    // [waves][kStageF2] output staging (16-byte aligned: first in the segment), then the table, then the waves' exchange buffers
+    constexpr bool HALF = LOG2M <= 10;
+    constexpr int kTab = HALF ? M / 2 + 2 : M + 1;       // table entries (HALF: an even count keeps the buffers 16-byte aligned)
+    // !HALF: [waves][kStageF2] output staging (16-byte aligned: first in the segment), then the table, then the waves' exchange buffers
     float2* stage = reinterpret_cast<float2*>(smem) + wave * kStftStageF2;
-    float2* lds0 = reinterpret_cast<float2*>(smem) + (blockDim.x >> 6) * kStftStageF2;
+    float2* lds0 = reinterpret_cast<float2*>(smem) + (HALF ? 0 : (blockDim.x >> 6) * kStftStageF2);
     const float2* twl = lds0;
-    float2* buf = lds0 + (M + 1) + wave * MP;
-    for (int k = tid; k <= M; k += blockDim.x) lds0[k] = tw[k];
+    float2* buf = lds0 + kTab + wave * MP;
+    for (int k = tid; k <= (HALF ? M / 2 : M); k += blockDim.x) lds0[k] = tw[k];
     __syncthreads();
     // output row -> (clip, frame): clips of equal length are stacked with a pitch of rows_pc rows
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -344,7 +375,7 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     }
     FW_STAMP(1);   // table filled, barrier passed
     WaveTw<LOG2M> wt;
-    wt.init(twl, lane);
+    if (HALF) wt.init_half(twl, lane); else wt.init(twl, lane);
     cx v[P];
     const int64_t base = t * (int64_t)hop - M;
     // 32-bit window-relative bounds instead of two 64-bit compares per sample
@@ -361,12 +392,21 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     // x[0] = ap[r]` the compiler waited for each of an edge frame's 32 loads in turn -- sixteen memory round trips in the
     // wave of the first / last frames of every clip, and a launch ends with its slowest wave.
     cx xs[P], ws[P];
+    // (a load's immediate offset reaches 4 KB: the upper half of the window / frame goes through a second SCALAR base instead of
+    // one address register per load -- eight registers that decide between 128 and 136 in the four-waves-per-SIMD build)
+    auto uniform = [](uint64_t v) {                         // a wave-uniform address the compiler cannot prove uniform
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    const float2* w2_hi = reinterpret_cast<const float2*>(uniform(reinterpret_cast<uint64_t>(w2 + 512)));
+    const float* ap_hi = reinterpret_cast<const float*>(uniform(reinterpret_cast<uint64_t>(ap + 1024)));
 #pragma unroll
     for (int b = 0; b < NB1; ++b)
 #pragma unroll
         for (int tt = 0; tt < R1; ++tt) {
             const int i = lane + 64 * b + tt * stride1;
-            ws[b * R1 + tt] = ldc(w2 + i);
+            const int ic = 64 * b + tt * stride1;          // compile-time part
+            ws[b * R1 + tt] = (HALF && ic >= 512) ? ldc(w2_hi + lane + (ic - 512)) : ldc(w2 + i);
         }
     if (inside) {
 #pragma unroll
@@ -374,7 +414,9 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
 #pragma unroll
             for (int tt = 0; tt < R1; ++tt) {
                 const int r = 2 * (lane + 64 * b + tt * stride1);
-                xs[b * R1 + tt] = *reinterpret_cast<const cx*>(ap + r);
+                const int rc = 2 * (64 * b + tt * stride1);
+                xs[b * R1 + tt] = (HALF && rc >= 1024) ? *reinterpret_cast<const cx*>(ap_hi + 2 * lane + (rc - 1024))
+                                                       : *reinterpret_cast<const cx*>(ap + r);
             }
     } else if (r_hi > r_lo) {
 #pragma unroll
@@ -419,7 +461,7 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
         const cx e2 = c_add_conj(zk, zm);  // 2 E
         const cx d2 = c_sub_conj(zk, zm);  // 2 i O  ->  O = -i d2 / 2
         const cx o2 = c_sub_i(mk(0.f, 0.f), d2);
-        const cx x2 = e2 + c_mul(o2, ldc(twl + k));
+        const cx x2 = e2 + c_mul(o2, HALF ? tw_half(twl, k, M) : ldc(twl + k));
         xr = 0.5f * x2[0];
         xi = 0.5f * x2[1];
         // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded sequences (~8 and ~10 instructions per bin):
@@ -436,7 +478,98 @@ __global__ __launch_bounds__(256) void stft_forward_wave_kernel(const float* __r
     // 4 + 8 + 3 store instructions per frame.  Needs rows of exactly M + 4 bins on 16-byte boundaries and no phase output.
     const bool wide = (P % 4 == 0) && ld == M + 4 && !prow && urow &&
                       ((reinterpret_cast<uintptr_t>(mag) | reinterpret_cast<uintptr_t>(unit)) & 15) == 0;
-    if (wide) {
+    if (wide && HALF) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        constexpr int NPH = P / 8;                            // phases of 4 x 64 pairs: 256 direct + 256 mirrored bins each
+        static_assert(P % 8 == 0, "whole phases");
+        // one pair: both bins' magnitude (before the 1 / sqrt(N) scale) and unit phasor
+        auto pair = [&](cx zk, cx zm, cx w, float& axd, cx& phd, float& axm, cx& phm) {
+            const cx e2 = c_add_conj(zk, zm);                 // 2 E
+            const cx d2 = c_sub_conj(zk, zm);                 // 2 i O
+            const cx t2 = c_mul(c_sub_i(mk(0.f, 0.f), d2), w);   // 2 w^k O
+            const cx xd = (e2 + t2) * 0.5f;                   // X[k]
+            const cx xc = (e2 - t2) * 0.5f;                   // conj X[M - k]
+            axd = __builtin_amdgcn_sqrtf(xd[0] * xd[0] + xd[1] * xd[1]);
+            axm = __builtin_amdgcn_sqrtf(xc[0] * xc[0] + xc[1] * xc[1]);
+            phd = phasor(axd, xd[0], xd[1]);
+            phm = phasor(axm, xc[0], -xc[1]);
+        };
+        // k = M / 2 is its own partner (lane 0): the first bin of the last phase's mirrored group -- the "carry" of a phase is
+        // the bin one past its mirrored run: the mirror of its first pair
+        float c_ax = 0.f;
+        cx c_ph = mk(1.f, 0.f);
+        {
+            float axm;
+            cx phm;
+            const cx z = ldc(buf + pad(M / 2));
+            pair(z, z, mk(0.f, -1.f), c_ax, c_ph, axm, phm);  // w^(M/2) = -i
+        }
+#pragma unroll
+        for (int ph = NPH - 1; ph >= 0; --ph) {
+            float axd[4], axm[4];
+            cx phd[4], phm[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int u = 4 * ph + uu;                    // k = lane + 64 u < M / 2
+                const cx zk = ldc(bk + cpad(64 * u));
+                const cx zm = (u == 0 && lane == 0) ? ldc(buf) : ldc(bm + cpad(M - 64 * (u + 1)));   // Z[(M - k) mod M]
+                pair(zk, zm, ldc(twl + lane + 64 * u), axd[uu], phd[uu], axm[uu], phm[uu]);
+            }
+            // every slot of Z this phase reads has now been read for the last time: k in [256 ph, 256 ph + 255] and its mirror run
+            // [M - 256 ph - 255, M - 256 ph] -- the two staging areas (even slot index: 16-byte aligned, >= 256 slots each)
+            float* sm = reinterpret_cast<float*>(buf + cpad(256 * ph));                          // 512 floats: direct, mirrored
+            float2* su = buf + ((cpad(M - 256 * ph - 255) + 1) & ~1);                            // 256 phasors
+            const int q = M / 256 - 1 - ph;                   // the mirrored group: bins [256 q, 256 q + 255]
+            asm volatile("" ::: "memory");
+            // mirrored bin of (uu, lane) = M - 256 ph - 64 uu - lane; its index in group q = 256 - 64 uu - lane (lane 0 of uu 0: the
+            // NEXT group's first bin = this phase's carry out; index 0 of group q = the carry in)
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                sm[64 * uu + lane] = axd[uu] * inv_sqrt_n;
+                if (uu > 0 || lane > 0) sm[256 + 256 - 64 * uu - lane] = axm[uu] * inv_sqrt_n;
+            }
+            if (lane == 0) sm[256] = c_ax * inv_sqrt_n;
+            asm volatile("" ::: "memory");
+            {
+                const f4 a = *reinterpret_cast<const f4*>(sm + 4 * lane);
+                const f4 b = *reinterpret_cast<const f4*>(sm + 256 + 4 * lane);
+                asm volatile("" ::: "memory");
+                *reinterpret_cast<f4*>(mrow + 256 * ph + 4 * lane) = a;
+                *reinterpret_cast<f4*>(mrow + 256 * q + 4 * lane) = b;
+            }
+            // phasors: the direct group, then the mirrored one, 128 bins per 16-byte store instruction
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) stc(su + 64 * uu + lane, phd[uu]);
+            asm volatile("" ::: "memory");
+            {
+                const f4 a = *reinterpret_cast<const f4*>(su + 2 * lane);
+                const f4 b = *reinterpret_cast<const f4*>(su + 128 + 2 * lane);
+                asm volatile("" ::: "memory");
+                *reinterpret_cast<f4*>(urow + 256 * ph + 2 * lane) = a;
+                *reinterpret_cast<f4*>(urow + 256 * ph + 128 + 2 * lane) = b;
+            }
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu)
+                if (uu > 0 || lane > 0) stc(su + 256 - 64 * uu - lane, phm[uu]);
+            if (lane == 0) stc(su, c_ph);
+            asm volatile("" ::: "memory");
+            {
+                const f4 a = *reinterpret_cast<const f4*>(su + 2 * lane);
+                const f4 b = *reinterpret_cast<const f4*>(su + 128 + 2 * lane);
+                asm volatile("" ::: "memory");
+                *reinterpret_cast<f4*>(urow + 256 * q + 2 * lane) = a;
+                *reinterpret_cast<f4*>(urow + 256 * q + 128 + 2 * lane) = b;
+            }
+            // carry out: the mirror of this phase's first pair (lane 0 of uu 0) = bin M - 256 ph
+            c_ax = axm[0];
+            c_ph = phm[0];
+        }
+        if (lane == 0) {   // bin M (the carry of phase 0) and the three padding bins of the row
+            *reinterpret_cast<f4*>(mrow + M) = f4{c_ax * inv_sqrt_n, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f4*>(urow + M) = f4{c_ph[0], c_ph[1], 1.f, 0.f};
+            *reinterpret_cast<f4*>(urow + M + 2) = f4{1.f, 0.f, 1.f, 0.f};
+        }
+    } else if (wide) {
         float* sm = reinterpret_cast<float*>(stage);          // [256] magnitudes of bins 256 g .. 256 g + 255
         float2* su = stage + 128;                             // [128] phasors of bins 128 h .. 128 h + 127
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1128,7 +1261,8 @@ int launch_fwd(dcs_stft* p, const float* audio, int64_t L, int64_t audio_stride,
     // workgroup at 640 tiles: 33.1 / 27.5 / 22.4 us against 22.0 with 4)
     const int64_t rows_all = rows_out * n_clips;
     const int fpw = rows_all >= 8 * (int64_t)p->ctx->n_cu ? 4 : 1;
-    const size_t lds = ((size_t)(M + 1) + (size_t)fpw * (MP + kStftStageF2)) * sizeof(float2);
+    const size_t lds = LOG2M <= 10 ? ((size_t)(M / 2 + 2) + (size_t)fpw * MP) * sizeof(float2)       // quarter-circle table, no staging area
+                                   : ((size_t)(M + 1) + (size_t)fpw * (MP + kStftStageF2)) * sizeof(float2);
     auto kern = stft_forward_wave_kernel<LOG2M>;
     if (lds > 48 * 1024)
         DCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
