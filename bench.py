@@ -29,7 +29,7 @@ Timing: a *round* is EXACTLY K steps bracketed by a barrier + torch.cuda.synchro
 sides (max over ranks).  Rounds are repeated until `--min-time` (0.25 s) has been timed; `value`
 comes from the MEDIAN round, so it does not depend on K being large (`rounds`, `round_ms` in the
 line).  Every 4th round brackets the launches of the dominant kernel with HIP events; such a round
-issues its K steps on stream 0 alone (kernel by kernel instead of replaying the hipGraph), because
+issues its K steps on stream 0 alone, because
 with kernels of other streams sharing the CUs an event pair measures a time-sliced duration.
 
 Rank 0 prints ONE compact JSON line (< 4 KB, strict JSON) as the LAST line of stdout: the contract keys, `roofline`
@@ -420,8 +420,8 @@ def main():
                 self.comm = RcclComm.from_process_group(device=self.ctx)
             self.stream.synchronize()
             # the C entry point with its arguments bound once: dcs_separate_batch() enqueues on the context's
-            # own stream, so the host cost of a launch group is one ctypes call (and, from the second identical
-            # call on, one hipGraphLaunch inside it)
+            # own stream, so the host cost of a launch group is one ctypes call (seven eager kernel launches inside it;
+            # DCS_GRAPH=1: one hipGraphLaunch from the second identical call on)
             net, plan = self.sep.net, self.sep.plan
             self._fn = self.ctx._lib.dcs_separate_batch
             self._to16 = self.ctx._lib.dcs_pcm_to_int16
@@ -498,8 +498,8 @@ def main():
             el = float(tt.item())
         return el
 
-    # ---- warm-up: at least W steps, and every (lane, group size) pair of the schedule at least twice -- the second
-    # identical call captures its hipGraph -- plus once more so that the first timed round replays
+    # ---- warm-up: at least W steps, and every (lane, group size) pair of the schedule at least twice (with DCS_GRAPH=1 the
+    # second identical call captures its hipGraph) plus once more
     warm = 0
     while warm < max(args.warmup, 3 * K):
         for i, g in enumerate(groups):

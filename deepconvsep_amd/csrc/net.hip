@@ -863,12 +863,14 @@ static int separate_graphed(dcs_model* m, dcs_stft* plan, const float* audio_d, 
     if (!pcm_d) DCS_FAIL(DCS_EINVAL, "dcs_separate: pcm_d is null");
     if (!m) DCS_FAIL(DCS_EINVAL, "dcs_separate: null model");
     DCS_ON_DEVICE(m->ctx->device);
-    static const bool graphs_on = !(getenv("DCS_GRAPH") && atoi(getenv("DCS_GRAPH")) == 0);
-    // graph replay needs a capturable (non-null) stream, no event timing, and an identical repeat call
-    // A replayed hipGraph costs ~4 us more per call than the same launches issued eagerly from a host that keeps ahead of
-    // the GPU (measured on MI355X / ROCm 7.2, one 32-tile batch per call: 55.2 vs 51.3 us; profiles/r03_*): graphs pay off
-    // when several streams compete for the host (launch groups), not for one short call after another: the one-batch path
-    // is always issued eagerly.
+    // hipGraph replay of the step is OPT-IN since round 6 (DCS_GRAPH=1, read per call): on MI355X / ROCm 7.2 a replayed graph
+    // starts its first kernel later than the same launches issued eagerly by a host that keeps ahead of the GPU, at every shape
+    // measured -- one 32-tile batch per call 55.2 vs 51.3 us (profiles/r03_*); launch groups of 2 / 4 / 8 / 20 batches 5 / 7 / 2 /
+    // 1.5 % slower, 32-batch groups over three streams equal (profiles/r06_ab_graph_replay_vs_eager.txt).  It stays for hosts that
+    // cannot keep ahead (many streams per thread).  Replay needs a capturable (non-null) stream, no event timing, and an
+    // identical repeat call; the one-batch path is always issued eagerly.
+    const char* graph_env = getenv("DCS_GRAPH");
+    const bool graphs_on = graph_env && atoi(graph_env) == 1;
     const bool lat_call = plan && m->arch == DCS_ARCH_DSD &&
                           dsd_lat_mask(m, plan, dcs_frame_count(n_samples, plan->hop), n_clips, false, overlap, eps_mode) != 0;
     const bool can_graph = graphs_on && m->ctx->stream != nullptr && m->ctx->timing_mask == 0 && m->arch == DCS_ARCH_DSD &&

@@ -151,10 +151,11 @@ def test_one_batch_path_on_adversarial_weights(kind, N):
         assert float(np.max(np.abs(mm[:, bad]))) < 1e-3 and float(np.max(s_lat[:, bad])) < 1e-3
 
 
-def test_one_batch_graph_replay_tracks_new_input():
-    """On a non-default stream the second identical call captures the launches into a hipGraph; replays must recompute
-    from the buffers' current contents, and switching the stage selection must not replay the other family's graph."""
+def test_one_batch_graph_replay_tracks_new_input(monkeypatch):
+    """With DCS_GRAPH=1, on a non-default stream the second identical call captures the launches into a hipGraph; replays must
+    recompute from the buffers' current contents, and switching the stage selection must not replay the other family's graph."""
     import torch
+    monkeypatch.setenv("DCS_GRAPH", "1")                    # read per call by libdcs
     from deepconvsep_amd.runtime import Context
     N, F = 2048, 1025
     params = synth_params("dsd", TC, F, seed=2)

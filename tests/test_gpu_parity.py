@@ -841,10 +841,12 @@ def test_separate_ragged_rejects_what_it_cannot_do():
         sep2.net.separate_ragged(sep2.plan, dev2, [30000, 5], 25, sep2.tiler, 0.3)     # 5 samples: no tile
 
 
-def test_graph_replay_recomputes_on_a_side_stream():
-    """The fused step is captured into a hipGraph on the second identical call (non-default stream) and
-    replayed afterwards: replays must track new input written into the same buffers."""
+def test_graph_replay_recomputes_on_a_side_stream(monkeypatch):
+    """With DCS_GRAPH=1 (opt-in since round 6: eager launches are at least as fast at every measured shape) the fused step is
+    captured into a hipGraph on the second identical call (non-default stream) and replayed afterwards: replays must track new
+    input written into the same buffers."""
     import torch
+    monkeypatch.setenv("DCS_GRAPH", "1")                    # read per call by libdcs
     from deepconvsep_amd.runtime import Context
     F, N = 513, 1024
     params = synth_params("dsd", 30, F, seed=2)
@@ -1243,7 +1245,7 @@ _VARIANT_ENVS = [
     {"DCS_DECONV2": "2"}, {"DCS_DECONV2": "1"},                   # streaming / one-shot transposed conv2
     {"DCS_STFT_WAVE_MIN": "1"}, {"DCS_FFT_BLOCK": "1"},           # wave-per-frame / block-level FFT everywhere
     {"DCS_ISTFT_CHAIN": "0", "DCS_ISTFT_SEQ_HOPS": "1"}, {"DCS_ISTFT_CHAIN": "0", "DCS_ISTFT_SEQ_HOPS": "37"},   # blocks per wave of the barrier-free iSTFT
-    {"DCS_GRAPH": "0"},
+    {"DCS_GRAPH": "1"},                                            # hipGraph replay of the step (opt-in)
     {"DCS_ISTFT_STAGE_MIN": "1"},                                  # spectra through LDS (long clips' iSTFT) on a short clip
     {"DCS_ISTFT_STAGE": "0"},
     {"DCS_ISTFT_CHAIN": "0"}, {"DCS_ISTFT_CHAIN": "3"}, {"DCS_ISTFT_CHAIN": "7"},   # chained iSTFT off / forced frames per wave
