@@ -114,7 +114,7 @@ struct dcs_model {
     // re-allocated while the model lives (captured graphs of other call shapes keep pointing at theirs)
     std::vector<std::pair<int, float*>> rise_tabs;
     float* rise_d = nullptr;   // the table of the current call (set by ensure_rise)
-    // ---- hipGraph of the fused step (dcs_separate): the 8 launches of one call replayed as one launch.
+    // ---- hipGraph of the fused step (dcs_separate; opt-in, DCS_GRAPH=1): the launches of one call replayed as one launch.
     // A graph is captured the second time the same call (same buffers, sizes, options) arrives.
     struct StepKey {
         const void* plan = nullptr; const void* audio = nullptr; const void* pcm = nullptr; const void* ws = nullptr;
