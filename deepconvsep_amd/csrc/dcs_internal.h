@@ -228,6 +228,10 @@ struct DcsGemm {
     // Bq holds the weights UNSPLIT, as 32-byte f32 pieces in the planes' piece order (dcs_gemm_pack_b32): the all-rows kernels split
     // them in registers -- 4 bytes per weight from HBM instead of 6.  Only those kernels take it (M 128 .. 176)
     int bq_f32;
+    // optional (gemm_rows_splitk_kernel only): B once more in that kernel's FRAGMENT order, [n_cols / 16][(K + 15) / 16][64 lanes][4]:
+    // lane (kq, fi) of column block nt and K chunk c holds B[16 c + 4 kq + e][16 nt + fi], e = 0 .. 3 (rows >= K zero) -- one
+    // 16-byte load per lane and 16 K (1 KB per wave, contiguous) instead of four 4-byte loads on four 64-byte segments
+    const float* Bfrag;
 };
 
 // row r of a grouped operand: (r / gdiv) * gmul + r % gdiv.  Most launches have ONE group (gdiv = 2^30 > M): a 64-bit division

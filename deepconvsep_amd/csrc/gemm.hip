@@ -219,6 +219,8 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const DcsGemm g) {
 // of four consecutive steps are one 16-byte load.  Two accumulators alternate to stay issue-bound
 // (the 16x16x4 f32 MFMA has a 40-cycle dependent latency but a 32-cycle issue interval).
 // ------------------------------------------------------------------------------------------------
+// BF: B from DcsGemm::Bfrag (fragment order: one 16-byte load per lane and 16 K).
+template <bool BF>
 __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGemm g) {
     __shared__ float red[3 * 64 * 4];
     const int tid = threadIdx.x;
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
     const int64_t rr = row_ok ? r : 0;
     const float* a_ptr = g.A + (g.a_rowmap ? (int64_t)g.a_rowmap[rr] : dcs_group_row(rr, g.a_gdiv, g.a_gmul, g.a_gdiv >= g.M)) * g.lda + 4 * kq;
     const float* b_ptr = g.B + (int64_t)(4 * kq) * gldb + n0 + fi;
+    const f32x4* bf_ptr = BF ? reinterpret_cast<const f32x4*>(g.Bfrag) + (int64_t)blockIdx.y * ((gK + 15) >> 4) * 64 + lane : nullptr;
 
     f32x4 a_cur[4], a_nxt[4];
     float b_cur[16], b_nxt[16];
@@ -241,7 +244,12 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_splitk_kernel(const DcsGem
         const int k = (kc_) + 16 * j;                                                             \
         A_[j] = (row_ok && k + 4 * kq < gK) ? *reinterpret_cast<const f32x4*>(a_ptr + k)          \
                                             : f32x4{0.f, 0.f, 0.f, 0.f};                          \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) B_[4 * j + e] = b_ptr[(int64_t)(k + e) * gldb]; \
+        if (BF) {                                                                                 \
+            const f32x4 bv_ = bf_ptr[(int64_t)(k >> 4) * 64];                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) B_[4 * j + e] = bv_[e];                 \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) B_[4 * j + e] = b_ptr[(int64_t)(k + e) * gldb]; \
+        }                                                                                         \
     }
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -376,7 +384,7 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
                                                                           (unsigned)ksplit),
                                    dim3(kThreads), 0, ctx->stream, q);
             else
-                hipLaunchKernelGGL(gemm_rows_splitk_kernel, dim3((unsigned)groups16, (unsigned)(g.n_cols / 16), (unsigned)ksplit),
+                hipLaunchKernelGGL(gemm_rows_splitk_kernel<false>, dim3((unsigned)groups16, (unsigned)(g.n_cols / 16), (unsigned)ksplit),
                                    dim3(kThreads), 0, ctx->stream, q);
             hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3((unsigned)dcs_cdiv(g.M * g.n_cols, kThreads)), dim3(kThreads),
                                0, ctx->stream, q, ksplit);
@@ -405,7 +413,8 @@ int dcs_launch_gemm_rows(dcs_ctx* ctx, const DcsGemm& g, int tag) {
     const int64_t sk_max = sk_env >= 0 ? sk_env : (int64_t)ctx->n_cu / 2;
     if (g.a_vec && groups16 * col_groups <= sk_max) {
         dim3 grid((unsigned)groups16, (unsigned)(g.n_cols / 16));
-        hipLaunchKernelGGL(gemm_rows_splitk_kernel, grid, dim3(kThreads), 0, ctx->stream, g);
+        if (g.Bfrag) hipLaunchKernelGGL(gemm_rows_splitk_kernel<true>, grid, dim3(kThreads), 0, ctx->stream, g);
+        else hipLaunchKernelGGL(gemm_rows_splitk_kernel<false>, grid, dim3(kThreads), 0, ctx->stream, g);
     } else if (groups16 * col_groups <= 2 * (int64_t)ctx->n_cu)
         launch_rb<1, 128>(ctx, g);
     else if (groups16 * col_groups <= 4 * (int64_t)ctx->n_cu)

@@ -95,6 +95,7 @@ struct dcs_model {
     float *Bd = nullptr, *biasd = nullptr, *Bw2 = nullptr, *Bw2s = nullptr, *Bfin = nullptr, *bout = nullptr;
     // conv2 -> bias -> bottleneck layer folded into one affine map over a tile's tc rows of conv1 output (pack_dsd)
     float *B2fc = nullptr, *bias2fc = nullptr;
+    float* B2fc_frag = nullptr;   // the same weights in gemm_rows_splitk_kernel's fragment order (DcsGemm::Bfrag)
     // ---- generic path (ikala / bach10 / score-informed)
     DcsGenericNet* gen = nullptr;
     // ---- scratch
@@ -288,6 +289,18 @@ int pack_dsd(dcs_model* m, const std::vector<std::vector<float>>& P) {
     if (d.h2 + kh - 1 == m->tc) {   // (always: h2 = tc - kh + 1)
         DCS_CHECK(upload(&m->B2fc, B2fc));
         DCS_CHECK(upload(&m->bias2fc, bias2fc));
+        {   // fragment order of the few-rows GEMM (launch groups of up to ~1000 tiles take that kernel for this layer)
+            const int K = m->tc * CI, kc = (K + 15) / 16, nt = m->hid64 / 16;
+            std::vector<float> fr((size_t)nt * kc * 64 * 4, 0.f);
+            for (int t = 0; t < nt; ++t)
+                for (int c = 0; c < kc; ++c)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 16 * c + 4 * (lane >> 4) + e;
+                            if (k < K) fr[(((size_t)t * kc + c) * 64 + lane) * 4 + e] = B2fc[(size_t)k * m->hid64 + 16 * t + (lane & 15)];
+                        }
+            DCS_CHECK(upload(&m->B2fc_frag, fr));
+        }
     }
     DCS_CHECK(upload(&m->Bd, Bd));
     DCS_CHECK(upload(&m->biasd, biasd));
@@ -445,7 +458,7 @@ int dsd_encode(dcs_model* m, const float* rows_src, int64_t lda, bool a_vec, flo
     g3.M = n_tiles_all; g3.n_cols = m->hid64; g3.n_store = m->hid64; g3.K = d.h2 * CP; g3.relu = 1; g3.a_vec = 1;
     if (fold2) {   // A row of tile k = its tc rows of H1 (the same row index as its first conv2 position)
         g3.A = w.H1; g3.lda = (shared_frames ? tile_row_stride : tc) * (int64_t)CI;
-        g3.B = m->B2fc; g3.bias = m->bias2fc; g3.K = tc * CI;
+        g3.B = m->B2fc; g3.bias = m->bias2fc; g3.K = tc * CI; g3.Bfrag = m->B2fc_frag;
     }
     if (lat & DCS_LAT_FC) {
         DcsLatGemm q{};   // the A row of tile k is h2 consecutive C2 rows from row k * st: one slice per row
@@ -588,7 +601,7 @@ extern "C" int dcs_model_destroy(dcs_model* m) {
     if (!m) return DCS_OK;
     DCS_ON_DEVICE(m->ctx->device);
     float* ptrs[] = {m->B1, m->bias1, m->B2, m->bias2, m->Bfc, m->biasfc, m->Bd, m->biasd, m->Bw2, m->Bw2s, m->Bfin, m->bout,
-                     m->B2fc, m->bias2fc};
+                     m->B2fc, m->bias2fc, m->B2fc_frag};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& t : m->rise_tabs)
